@@ -1,0 +1,177 @@
+/*
+ * hypo_gpu.h — C-ABI of the MI355X (gfx950) polishing hot path.
+ *
+ * The reference (kensung-lab/hypo) has no FFI: its hot path is reached through three C++ call
+ * sites in Hypo::polish() (src/Hypo.cpp:100-103 solid scan, :237 prepare_for_poa, :238-247
+ * per-window POA; results read at src/Contig.cpp:357).  This header is the boundary a maintainer
+ * would bind there instead (see INTEGRATION.md for the C++ stub): plain pointers and sizes,
+ * no C++ or torch types.  Every entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *  - every function returns 0 on success, <0 = HYPO_E_* (never throws, never exits);
+ *    hypo_gpu_last_error() gives a thread-local message.
+ *  - "_device" variants take DEVICE pointers inside the batch structs and run asynchronously on the
+ *    given hipStream_t (passed as void*); plain variants take HOST pointers and do H2D/D2H themselves.
+ *  - sequences are packed exactly like the reference's PackedSeq<NB> (src/PackedSeq.cpp:58-89):
+ *    MSB-first inside a byte, 2 bases/byte for NB=4 (codes A0 C1 G2 T3 N4), 4 bases/byte for NB=2.
+ *    Every sequence starts on a byte boundary of its buffer.
+ */
+#ifndef HYPO_GPU_H
+#define HYPO_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HYPO_GPU_ABI_VERSION 1
+
+/* error codes */
+#define HYPO_OK              0
+#define HYPO_E_INVALID      -1   /* bad argument (NULL pointer, k out of range, positive gap score ...) */
+#define HYPO_E_NODEVICE     -2   /* no gfx950 device / hip runtime failure at init */
+#define HYPO_E_HIP          -3   /* a HIP call failed (message in hypo_gpu_last_error) */
+#define HYPO_E_WORKSPACE    -4   /* caller-provided workspace too small */
+#define HYPO_E_NOTINIT      -5
+
+/* per-window status byte written by the POA entry points */
+#define HYPO_ST_OK            0
+#define HYPO_ST_CONS_OVERFLOW 1  /* consensus longer than the caller's slot (len holds the needed size) */
+#define HYPO_ST_CAPACITY      2  /* window exceeds the largest device size class */
+#define HYPO_ST_UNDEFINED     3  /* input hits behaviour that is undefined in the reference
+                                    (graph.cpp:184-200: alignment without any sequence position) */
+
+/* Reference: ScoreParams, include/globalDefs.hpp:58-66 (same field order, INT8 each). */
+typedef struct HypoScoreParams {
+    int8_t sr_match, sr_mismatch, sr_gap;
+    int8_t lr_match, lr_mismatch, lr_gap;
+} HypoScoreParams;
+
+/* Reference: enum class WindowType, include/Window.hpp:35-38. */
+#define HYPO_WIN_SHORT 0
+#define HYPO_WIN_LONG  1
+
+/*
+ * One Window object, flattened.  Reference: data members of hypo::Window (include/Window.hpp:123-135).
+ * The arms of window w are arm indices [first_arm, first_arm + n_internal + n_prefix + n_suffix),
+ * stored as internal arms, then prefix arms, then suffix arms, each group in INSERTION order
+ * (Window::add_internal/add_prefix/add_suffix, Window.hpp:66-101).  The consumption order
+ * (prefix arms reversed, Window.cpp:111) is applied by the callee, as are the dispatch rules of
+ * Window::generate_consensus (Window.cpp:44-61).  n_empty = Window::_num_empty (add_empty, :103).
+ */
+typedef struct HypoWindow {
+    uint8_t  type;          /* HYPO_WIN_SHORT / HYPO_WIN_LONG */
+    uint8_t  reserved[3];
+    uint32_t draft_len;     /* bases */
+    uint64_t draft_off;     /* BYTE offset of the 4-bit packed draft in HypoWindowBatch.draft4 */
+    uint32_t first_arm;
+    uint32_t n_internal;
+    uint32_t n_prefix;
+    uint32_t n_suffix;
+    uint32_t n_empty;
+    uint32_t reserved2;
+} HypoWindow;               /* 40 bytes */
+
+typedef struct HypoWindowBatch {
+    uint32_t          n_windows;
+    uint32_t          n_arms;
+    const HypoWindow* windows;     /* [n_windows] */
+    const uint8_t*    draft4;      /* 4-bit packed drafts (PackedSeq<4>) */
+    uint64_t          draft4_bytes;
+    const uint64_t*   arm_off;     /* [n_arms] BYTE offset of each 2-bit packed arm in arms2 */
+    const uint32_t*   arm_len;     /* [n_arms] bases (0 allowed: skipped like Window.cpp:100,113,124) */
+    const uint8_t*    arms2;       /* 2-bit packed arms (PackedSeq<2>) */
+    uint64_t          arms2_bytes;
+} HypoWindowBatch;
+
+/*
+ * Result of Window::get_consensus() (Window.hpp:63) for every window of the batch.
+ * The caller owns all buffers.  Slot of window w = bases[off[w] .. off[w+1]); the callee writes
+ * len[w] characters (ASCII ACGTN) there, no terminator, and status[w].
+ */
+typedef struct HypoConsensusBatch {
+    char*           bases;
+    const uint64_t* off;       /* [n_windows + 1] */
+    uint32_t*       len;       /* [n_windows] */
+    uint8_t*        status;    /* [n_windows] HYPO_ST_* */
+} HypoConsensusBatch;
+
+/* Runtime ------------------------------------------------------------------------------------- */
+
+/* Selects the HIP device, creates the library's stream and device arenas.  Replaces nothing in the
+ * reference (there is no device there); closest analogue Hypo::Hypo, src/Hypo.cpp:34-36. */
+int hypo_gpu_init(int device_id);
+int hypo_gpu_shutdown(void);
+int hypo_gpu_abi_version(void);
+const char* hypo_gpu_last_error(void);
+/* Number of compute units of the selected device (0 before init). */
+int hypo_gpu_num_cus(void);
+
+/* Solid-kmer scan --------------------------------------------------------------------------------
+ * Replaces Contig::find_solid_pos (src/Contig.cpp:40-74) + suk::SolidKmers::is_solid
+ * (external/suk/include/suk/SolidKmers.hpp:119).
+ *   packed4      contig as PackedSeq<4> bytes, n_bases bases
+ *   k            2..31 (reference derives 11/13/15/17, src/main.cpp:490-528)
+ *   bitset_words 4^k bits as little-endian 64-bit words, bit i at word i>>6, bit i&63
+ *                (sdsl::bit_vector payload, external/suk/src/SolidKmers.cpp:47-48,182-186)
+ * Outputs:
+ *   solid_pos_words  ceil(n_bases/64) words; bit p set <=> Contig::_solid_pos[p] (Contig.cpp:67)
+ *   kids             k-mer ids of the marked positions in increasing position order
+ *                    (Contig::_kmerinfo[i]->kid, Contig.cpp:68); at most kids_cap are written
+ *   word_rank        optional (may be NULL): ceil(n_bases/64)+1 exclusive prefix counts of set bits
+ *                    per word = the directory behind sdsl rank_1/select_1 (Contig.cpp:72-73)
+ *   n_solid          total number of marked positions (even if > kids_cap)
+ */
+int hypo_gpu_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k,
+                        const uint64_t* bitset_words,
+                        uint64_t* solid_pos_words, uint64_t* kids, uint64_t kids_cap,
+                        uint64_t* word_rank, uint64_t* n_solid);
+
+/* Same with device pointers; workspace from hypo_gpu_solid_scan_workspace_bytes(n_bases).
+ * n_solid is a DEVICE pointer to one uint64. */
+size_t hypo_gpu_solid_scan_workspace_bytes(uint64_t n_bases);
+int hypo_gpu_solid_scan_device(const uint8_t* packed4, uint64_t n_bases, uint32_t k,
+                               const uint64_t* bitset_words,
+                               uint64_t* solid_pos_words, uint64_t* kids, uint64_t kids_cap,
+                               uint64_t* word_rank, uint64_t* n_solid,
+                               void* workspace, size_t workspace_bytes, void* hip_stream);
+
+/* Window POA -------------------------------------------------------------------------------------
+ * Replaces Window::prepare_for_poa (src/Window.cpp:31-42) + the per-window loop
+ * `generate_consensus(w, omp_get_thread_num())` of src/Hypo.cpp:238-247, i.e.
+ * Window::generate_consensus (Window.cpp:44-61), generate_consensus_short (:87-154),
+ * generate_consensus_long + curate (:156-254) and the HyPo-adapted spoa underneath
+ * (external/spoa/src/sisd_alignment_engine.cpp:246-439, graph.cpp:117-353,467-476,533-568,610-705).
+ * Scores must have gap <= 0 (spoa throws otherwise, alignment_engine.cpp:43-50) -> HYPO_E_INVALID.
+ * Results are bit-identical to the reference's scalar (SISD) engine.
+ */
+int hypo_gpu_poa_batch(const HypoScoreParams* scores, const HypoWindowBatch* in,
+                       HypoConsensusBatch* out);
+
+size_t hypo_gpu_poa_workspace_bytes(uint32_t n_windows, uint32_t n_arms);
+int hypo_gpu_poa_batch_device(const HypoScoreParams* scores, const HypoWindowBatch* in,
+                              HypoConsensusBatch* out, void* workspace, size_t workspace_bytes,
+                              void* hip_stream);
+
+/* Fills off[0..n_windows] (HOST pointers) with the consensus slot layout the callee recommends:
+ * slot(w) = round_up(2 * max(draft_len, longest arm) + 64, 8).  Pure host helper. */
+int hypo_gpu_poa_slot_layout(const HypoWindowBatch* host_in, uint64_t* off);
+
+/* Telemetry of the last POA call on this thread (windows per size class, escalations, DP cells). */
+typedef struct HypoPoaStats {
+    uint64_t n_windows;
+    uint64_t n_trivial;        /* answered by the dispatch rules without POA */
+    uint64_t n_class[4];       /* windows finished in size class 0..3 */
+    uint64_t n_escalated;      /* windows that overflowed a class and were re-run in the next */
+    uint64_t n_failed;         /* status != OK */
+    uint64_t dp_cells;         /* sum over alignments of (nodes+1)*(len+1), sisd..cpp:266-267 */
+    uint64_t n_alignments;
+} HypoPoaStats;
+int hypo_gpu_poa_last_stats(HypoPoaStats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYPO_GPU_H */

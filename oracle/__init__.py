@@ -1,0 +1,183 @@
+"""ctypes bindings of the TEST-ONLY CPU checkers (see oracle/hypo_oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+  Oracle  -> oracle/_build/libhypo_oracle.so  (this repo's C restatement; built by oracle/Makefile)
+  Ref     -> oracle/_ref/libhyporef.so        (the real reference classes; build container only)
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from hypo_amd import abi
+from hypo_amd.batch import HostBatch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "_build", "libhypo_oracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libhyporef.so")
+
+NW, LOV, ROV = 1, 3, 4
+
+
+def build(ref: bool = True) -> None:
+    subprocess.check_call(["make", "-s", "-C", HERE, "all" if ref else os.path.join(HERE, "_build", "libhypo_oracle.so")])
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def batch_struct(b: HostBatch) -> abi.WindowBatch:
+    s = abi.WindowBatch()
+    s.n_windows = b.n_windows
+    s.n_arms = b.n_arms
+    s.windows = _ptr(b.windows)
+    s.draft4 = _ptr(b.draft4)
+    s.draft4_bytes = b.draft4.size
+    s.arm_off = _ptr(b.arm_off)
+    s.arm_len = _ptr(b.arm_len)
+    s.arms2 = _ptr(b.arms2)
+    s.arms2_bytes = b.arms2.size
+    return s
+
+
+class Oracle:
+    def __init__(self, path: str = ORACLE_SO):
+        if not os.path.exists(path):
+            build(ref=False)
+        self.lib = C.CDLL(path)
+        self.lib.oracle_poa_batch.restype = C.c_int
+        self.lib.oracle_solid_scan.restype = C.c_int
+        self.lib.oracle_replay.restype = C.c_int
+        self.lib.oracle_num_threads.restype = C.c_int
+
+    def num_threads(self) -> int:
+        return int(self.lib.oracle_num_threads())
+
+    def poa_batch(self, b: HostBatch, scores=abi.DEFAULT_SCORES, off=None, n_threads=0):
+        """Returns (list of consensus strings, status array, dp_cells, n_alignments)."""
+        sp = abi.ScoreParams(*scores)
+        if off is None:
+            off = b.slot_layout()
+        n = b.n_windows
+        bases = np.zeros(int(off[-1]) + 1, dtype=np.uint8)
+        ln = np.zeros(n, dtype=np.uint32)
+        st = np.zeros(n, dtype=np.uint8)
+        ins = batch_struct(b)
+        out = abi.ConsensusBatch(_ptr(bases), _ptr(off), _ptr(ln), _ptr(st))
+        cells = C.c_uint64(0)
+        aligns = C.c_uint64(0)
+        rc = self.lib.oracle_poa_batch(C.byref(sp), C.byref(ins), C.byref(out), C.c_int(n_threads),
+                                       C.byref(cells), C.byref(aligns))
+        if rc != 0:
+            raise RuntimeError(f"oracle_poa_batch rc={rc}")
+        cons = [bases[int(off[i]):int(off[i]) + int(ln[i])].tobytes().decode() if st[i] == 0 else None
+                for i in range(n)]
+        return cons, st, int(cells.value), int(aligns.value)
+
+    def poa_batch_raw(self, b: HostBatch, scores=abi.DEFAULT_SCORES, off=None, n_threads=0):
+        """Like poa_batch but returns the raw (bases, off, len, status) arrays."""
+        sp = abi.ScoreParams(*scores)
+        if off is None:
+            off = b.slot_layout()
+        n = b.n_windows
+        bases = np.zeros(int(off[-1]) + 1, dtype=np.uint8)
+        ln = np.zeros(n, dtype=np.uint32)
+        st = np.zeros(n, dtype=np.uint8)
+        ins = batch_struct(b)
+        out = abi.ConsensusBatch(_ptr(bases), _ptr(off), _ptr(ln), _ptr(st))
+        cells = C.c_uint64(0)
+        aligns = C.c_uint64(0)
+        rc = self.lib.oracle_poa_batch(C.byref(sp), C.byref(ins), C.byref(out), C.c_int(n_threads),
+                                       C.byref(cells), C.byref(aligns))
+        if rc != 0:
+            raise RuntimeError(f"oracle_poa_batch rc={rc}")
+        return bases, off, ln, st, int(cells.value), int(aligns.value)
+
+    def solid_scan(self, packed4: np.ndarray, n_bases: int, k: int, bits: np.ndarray, kids_cap=None):
+        nw = (n_bases + 63) // 64
+        words = np.zeros(max(nw, 1), dtype=np.uint64)
+        if kids_cap is None:
+            kids_cap = n_bases
+        kids = np.zeros(max(kids_cap, 1), dtype=np.uint64)
+        rank = np.zeros(nw + 1, dtype=np.uint64)
+        ns = C.c_uint64(0)
+        rc = self.lib.oracle_solid_scan(_ptr(packed4), C.c_uint64(n_bases), C.c_uint32(k), _ptr(bits),
+                                        _ptr(words), _ptr(kids), C.c_uint64(kids_cap), _ptr(rank),
+                                        C.byref(ns))
+        if rc != 0:
+            raise RuntimeError(f"oracle_solid_scan rc={rc}")
+        n = int(ns.value)
+        return words[:nw], kids[:min(n, kids_cap)], rank, n
+
+    def replay(self, seqs, modes, scores=(5, -4, -8)):
+        return _replay(self.lib.oracle_replay, seqs, modes, scores)
+
+
+def _replay(fn, seqs, modes, scores):
+    n = len(seqs)
+    arr = (C.c_char_p * n)(*[s.encode() for s in seqs])
+    md = (C.c_int * n)(*modes)
+    tot = sum(len(s) for s in seqs) + 8
+    pairs = np.zeros(4 * tot, dtype=np.int32)
+    rank = np.zeros(tot, dtype=np.int32)
+    cons = np.zeros(tot, dtype=np.uint8)
+    npairs, nn, cl = C.c_int(0), C.c_int(0), C.c_int(0)
+    rc = fn(C.c_int(scores[0]), C.c_int(scores[1]), C.c_int(scores[2]), C.c_int(n), arr, md,
+            _ptr(pairs), C.c_int(2 * tot), C.byref(npairs), _ptr(rank), C.c_int(tot), C.byref(nn),
+            _ptr(cons), C.c_int(tot), C.byref(cl))
+    if rc != 0:
+        return rc, None, None, None
+    return 0, pairs[:2 * npairs.value].reshape(-1, 2).copy(), rank[:nn.value].copy(), \
+        cons[:cl.value].tobytes().decode()
+
+
+class Ref:
+    """The real reference (hypo::Window + adapted spoa), SISD flavour."""
+
+    def __init__(self, path: str = REF_SO):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path + " (build it with `make -C oracle ref` where /root/reference exists)")
+        self.lib = C.CDLL(path)
+        self.lib.hyporef_new_engine.restype = C.c_int
+        self.lib.hyporef_window.restype = C.c_int
+        self.lib.hyporef_replay.restype = C.c_int
+        self.lib.hyporef_pack_roundtrip.restype = C.c_int
+        self._engines = {}
+
+    @staticmethod
+    def available() -> bool:
+        return os.path.exists(REF_SO)
+
+    def engine(self, scores) -> int:
+        key = tuple(int(x) for x in scores)
+        if key not in self._engines:
+            sc = (C.c_int8 * 6)(*key)
+            self._engines[key] = int(self.lib.hyporef_new_engine(sc))
+        return self._engines[key]
+
+    def window(self, w, scores=abi.DEFAULT_SCORES):
+        """w: hypo_amd.TextWindow.  Returns (consensus, kept flags)."""
+        e = self.engine(scores)
+        mk = lambda xs: (C.c_char_p * max(len(xs), 1))(*[s.encode() for s in xs])
+        narm = len(w.internal) + len(w.prefix) + len(w.suffix)
+        cap = 4 * (len(w.draft) + sum(len(s) for s in w.internal + w.prefix + w.suffix)) + 64
+        out = C.create_string_buffer(cap)
+        kept = (C.c_ubyte * max(narm, 1))()
+        r = self.lib.hyporef_window(C.c_int(e), C.c_int(1 if w.is_long else 0), w.draft.encode(),
+                                    C.c_int(len(w.internal)), mk(w.internal),
+                                    C.c_int(len(w.prefix)), mk(w.prefix),
+                                    C.c_int(len(w.suffix)), mk(w.suffix),
+                                    C.c_int(w.n_empty), out, C.c_int(cap), kept)
+        if r < 0:
+            raise RuntimeError("hyporef_window: output buffer too small")
+        return out.raw[:r].decode(), list(kept)[:narm]
+
+    def replay(self, seqs, modes, scores=(5, -4, -8)):
+        return _replay(self.lib.hyporef_replay, seqs, modes, scores)
+
+    def pack_roundtrip(self, nb: int, text: str) -> str:
+        out = C.create_string_buffer(len(text) + 8)
+        r = self.lib.hyporef_pack_roundtrip(C.c_int(nb), text.encode(), out, C.c_int(len(text) + 8))
+        return out.raw[:r].decode()

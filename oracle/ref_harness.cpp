@@ -1,0 +1,105 @@
+// ref_harness.cpp — thin C entry points around the REAL reference classes (hypo::Window,
+// hypo::PackedSeq, spoa::Graph / AlignmentEngine), compiled from the sources where they lie under
+// /root/reference by oracle/Makefile into oracle/_ref/libhyporef.so.  TEST INFRASTRUCTURE ONLY:
+// used to validate oracle/hypo_oracle.c and to generate tests/golden/ (tests/golden/make_golden.py).
+// Nothing here restates the algorithm; it only drives the reference's own public interface
+// (include/Window.hpp:41-121, external/spoa/include/spoa/*.hpp).
+#include <cstring>
+#include <string>
+#include <vector>
+#include "Window.hpp"
+
+using namespace hypo;
+
+static int g_engines = 0;
+
+extern "C" {
+
+// Appends one short + one long engine with these scores (Window::prepare_for_poa, Window.cpp:31-42)
+// and returns its engine index.
+int hyporef_new_engine(const int8_t sc[6]) {
+    ScoreParams sp{sc[0], sc[1], sc[2], sc[3], sc[4], sc[5]};
+    Window::prepare_for_poa(sp, 1);
+    return g_engines++;
+}
+
+// Builds a real Window, adds the arms in the given order (internal, prefix, suffix, empties) and
+// returns Window::get_consensus().  kept[i] = 1 if arm i was stored (LONG windows filter arms,
+// Window.hpp:66-101).  Returns the consensus length or -1 if out_cap is too small.
+int hyporef_window(int engine_idx, int is_long, const char* draft,
+                   int ni, const char* const* in, int np, const char* const* pre,
+                   int ns, const char* const* suf, int n_empty,
+                   char* out, int out_cap, unsigned char* kept) {
+    std::string d(draft);
+    PackedSeq<4> pd(d);
+    Window w(pd, 0, d.size(), is_long ? WindowType::LONG : WindowType::SHORT);
+    int k = 0;
+    for (int i = 0; i < ni; ++i) {
+        auto before = w.get_num_internal();
+        w.add_internal(PackedSeq<2>(std::string(in[i])));
+        if (kept) kept[k] = (unsigned char)(w.get_num_internal() != before);
+        ++k;
+    }
+    for (int i = 0; i < np; ++i) {
+        auto before = w.get_num_pre();
+        w.add_prefix(PackedSeq<2>(std::string(pre[i])));
+        if (kept) kept[k] = (unsigned char)(w.get_num_pre() != before);
+        ++k;
+    }
+    for (int i = 0; i < ns; ++i) {
+        auto before = w.get_num_suf();
+        w.add_suffix(PackedSeq<2>(std::string(suf[i])));
+        if (kept) kept[k] = (unsigned char)(w.get_num_suf() != before);
+        ++k;
+    }
+    for (int i = 0; i < n_empty; ++i) w.add_empty();
+    w.generate_consensus((UINT32)engine_idx);
+    std::string c = w.get_consensus();
+    if ((int)c.size() > out_cap) return -1;
+    std::memcpy(out, c.data(), c.size());
+    return (int)c.size();
+}
+
+// Sequence-level replay on the reference's spoa: align + add_alignment for every sequence with the
+// given mode (1 = kNW, 3 = kLOV, 4 = kROV); reports the last alignment, the final rank order and
+// the heaviest-bundle consensus.
+int hyporef_replay(int m, int n, int g, int n_seq, const char* const* seqs, const int* modes,
+                   int32_t* pairs_out, int pairs_cap, int* n_pairs,
+                   int32_t* rank_out, int rank_cap, int* n_nodes,
+                   char* cons_out, int cons_cap, int* cons_len) {
+    auto engine = spoa::createAlignmentEngine(spoa::AlignmentType::kNW, (int8_t)m, (int8_t)n, (int8_t)g);
+    auto graph = spoa::createGraph();
+    for (int i = 0; i < n_seq; ++i) {
+        engine->changeAlignType(static_cast<spoa::AlignmentType>(modes[i]));
+        std::string s(seqs[i]);
+        auto aln = engine->align(s, graph);
+        if (i == n_seq - 1 && n_pairs) {
+            *n_pairs = (int)aln.size();
+            for (int k = 0; k < (int)aln.size() && k < pairs_cap; ++k) {
+                pairs_out[2 * k] = aln[k].first; pairs_out[2 * k + 1] = aln[k].second;
+            }
+        }
+        graph->add_alignment(aln, s);
+    }
+    const auto& r = graph->rank_to_node_id();
+    if (n_nodes) *n_nodes = (int)r.size();
+    for (int k = 0; k < (int)r.size() && k < rank_cap; ++k) rank_out[k] = (int32_t)r[k];
+    if (!r.empty()) {
+        std::string c = graph->generate_consensus();
+        if (cons_len) *cons_len = (int)c.size();
+        for (int k = 0; k < (int)c.size() && k < cons_cap; ++k) cons_out[k] = c[k];
+    } else if (cons_len) *cons_len = 0;
+    return 0;
+}
+
+// PackedSeq round trip through the reference (src/PackedSeq.cpp): returns unpack() of a
+// PackedSeq<NB> built from text; used to pin oracle_pack/unpack.
+int hyporef_pack_roundtrip(int nb, const char* text, char* out, int out_cap) {
+    std::string s(text), u;
+    if (nb == 2) { PackedSeq<2> p(s); u = p.unpack(); } else { PackedSeq<4> p(s); u = p.unpack(); }
+    if ((int)u.size() > out_cap) return -1;
+    std::memcpy(out, u.data(), u.size());
+    return (int)u.size();
+}
+
+}  // extern "C"
