@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    import oracle
+    return oracle.Oracle()
+
+
+@pytest.fixture(scope="session")
+def ref_lib():
+    import oracle
+    if not oracle.Ref.available():
+        pytest.skip("oracle/_ref not built (the real reference only exists in the build container)")
+    return oracle.Ref()

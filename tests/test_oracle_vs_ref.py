@@ -1,0 +1,59 @@
+"""CPU, build container only: randomized comparison of oracle/ with the real reference (oracle/_ref).
+Skipped where /root/reference (hence oracle/_ref) does not exist."""
+import random
+
+from hypo_amd.batch import TextWindow, build_batch
+
+
+def _mut(rng, s, e):
+    out = []
+    for c in s:
+        x = rng.random()
+        if x < e / 3:
+            continue
+        out.append(rng.choice("ACGT") if x < 2 * e / 3 else c)
+        if rng.random() < e / 3:
+            out.append(rng.choice("ACGT"))
+    return "".join(out) or "A"
+
+
+def test_random_short_windows(oracle_lib, ref_lib):
+    rng = random.Random(99)
+    wins = []
+    for _ in range(600):
+        L = rng.choice([4, 8, 16, 32, 64, 100, 150])
+        truth = "".join(rng.choice("ACGT") for _ in range(L))
+        w = TextWindow(_mut(rng, truth, 0.05))
+        for _ in range(rng.choice([2, 3, 6, 12, 30])):
+            s = _mut(rng, truth, rng.choice([0.005, 0.08, 0.2]))
+            k = rng.random()
+            if k < 0.5:
+                w.internal.append(s)
+            elif k < 0.75:
+                w.prefix.append(s[:rng.randint(1, len(s))])
+            else:
+                w.suffix.append(s[rng.randint(0, len(s) - 1):])
+        wins.append(w)
+    for scores in [(5, -4, -8, 3, -5, -4), (2, -3, -1, 3, -5, -4)]:
+        cons, st, _, _ = oracle_lib.poa_batch(build_batch(wins), scores=scores)
+        for w, c, s in zip(wins, cons, st):
+            assert s == 0
+            assert ref_lib.window(w, scores)[0] == c
+
+
+def test_random_long_windows(oracle_lib, ref_lib):
+    rng = random.Random(5)
+    wins = []
+    for _ in range(12):
+        L = rng.choice([200, 300, 500])
+        truth = "".join(rng.choice("ACGT") for _ in range(L))
+        w = TextWindow(_mut(rng, truth, 0.03), is_long=True)
+        for _ in range(rng.choice([3, 10, 25])):
+            w.internal.append(_mut(rng, truth, 0.1))
+        _, kept = ref_lib.window(w)
+        w.internal = [s for s, k in zip(w.internal, kept) if k]
+        wins.append(w)
+    cons, st, _, _ = oracle_lib.poa_batch(build_batch(wins))
+    for w, c, s in zip(wins, cons, st):
+        assert s == 0
+        assert ref_lib.window(w)[0] == c
