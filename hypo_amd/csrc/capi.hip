@@ -1,0 +1,222 @@
+// capi.hip — the C-ABI of include/hypo_gpu.h on top of the gfx950 kernels.
+// No CPU implementation of the hot path exists in this library: without a HIP device every entry
+// point fails with HYPO_E_NODEVICE / HYPO_E_NOTINIT.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "../../include/hypo_gpu.h"
+#include "poa_kernel.hpp"
+#include "scan_kernel.hpp"
+
+namespace {
+
+thread_local char tl_err[512] = "";
+thread_local HypoPoaStats tl_stats;
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(tl_err, sizeof(tl_err), fmt, ap); va_end(ap);
+    return code;
+}
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(HYPO_E_HIP, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
+
+struct Ctx { bool ready = false; int device = -1; int num_cus = 0; hipStream_t stream = nullptr; };
+Ctx g_ctx;
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+};
+
+int check_scores(const HypoScoreParams* s) {
+    if (!s) return fail(HYPO_E_INVALID, "scores == NULL");
+    if (s->sr_gap > 0 || s->lr_gap > 0)
+        return fail(HYPO_E_INVALID, "gap penalties must be non-positive (spoa alignment_engine.cpp:43-50)");
+    return HYPO_OK;
+}
+
+hypo::PoaParams make_params(const HypoScoreParams* s, const HypoWindowBatch* in, HypoConsensusBatch* out) {
+    hypo::PoaParams P;
+    P.windows = in->windows; P.draft4 = in->draft4; P.arm_off = in->arm_off; P.arm_len = in->arm_len; P.arms2 = in->arms2;
+    P.out_bases = out->bases; P.out_off = out->off; P.out_len = out->len; P.out_status = out->status;
+    P.sr_m = s->sr_match; P.sr_n = s->sr_mismatch; P.sr_g = s->sr_gap;
+    P.lr_m = s->lr_match; P.lr_n = s->lr_mismatch; P.lr_g = s->lr_gap;
+    return P;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hypo_gpu_abi_version(void) { return HYPO_GPU_ABI_VERSION; }
+const char* hypo_gpu_last_error(void) { return tl_err; }
+int hypo_gpu_num_cus(void) { return g_ctx.ready ? g_ctx.num_cus : 0; }
+
+int hypo_gpu_init(int device_id) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(HYPO_E_NODEVICE, "no HIP device visible");
+    if (device_id < 0 || device_id >= n) return fail(HYPO_E_INVALID, "device %d out of range (0..%d)", device_id, n - 1);
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(HYPO_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+    if (g_ctx.ready && g_ctx.stream) { (void)hipStreamDestroy(g_ctx.stream); g_ctx.stream = nullptr; }
+    HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+    g_ctx.device = device_id; g_ctx.num_cus = prop.multiProcessorCount; g_ctx.ready = true;
+    return HYPO_OK;
+}
+
+int hypo_gpu_shutdown(void) {
+    if (g_ctx.ready && g_ctx.stream) (void)hipStreamDestroy(g_ctx.stream);
+    g_ctx = Ctx();
+    return HYPO_OK;
+}
+
+// ---- POA -------------------------------------------------------------------------------------------
+size_t hypo_gpu_poa_workspace_bytes(uint32_t n_windows, uint32_t /*n_arms*/) {
+    return hypo::poa_workspace_bytes(n_windows);
+}
+
+int hypo_gpu_poa_batch_device(const HypoScoreParams* scores, const HypoWindowBatch* in, HypoConsensusBatch* out,
+                              void* workspace, size_t workspace_bytes, void* hip_stream) {
+    if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
+    int rc = check_scores(scores);
+    if (rc) return rc;
+    if (!in || !out) return fail(HYPO_E_INVALID, "NULL batch");
+    if (in->n_windows == 0) return HYPO_OK;
+    if (!in->windows || !in->draft4 || !out->bases || !out->off || !out->len || !out->status ||
+        (in->n_arms && (!in->arm_off || !in->arm_len || !in->arms2)))
+        return fail(HYPO_E_INVALID, "NULL buffer in batch");
+    if (!workspace || workspace_bytes < hypo::poa_workspace_bytes(in->n_windows))
+        return fail(HYPO_E_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, hypo::poa_workspace_bytes(in->n_windows));
+    hypo::PoaParams P = make_params(scores, in, out);
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_ctx.stream;
+    HIP_TRY(hypo::poa_run(P, in->n_windows, workspace, workspace_bytes, g_ctx.num_cus, st));
+    return HYPO_OK;
+}
+
+// device-side stats of the last device call live at workspace + 128
+int hypo_gpu_poa_read_stats(const void* workspace, void* hip_stream, HypoPoaStats* out) {
+    if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_ctx.stream;
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(out, (const char*)workspace + 128, sizeof(HypoPoaStats), hipMemcpyDeviceToHost));
+    return HYPO_OK;
+}
+
+int hypo_gpu_poa_last_stats(HypoPoaStats* out) {
+    if (!out) return fail(HYPO_E_INVALID, "NULL");
+    *out = tl_stats;
+    return HYPO_OK;
+}
+
+int hypo_gpu_poa_slot_layout(const HypoWindowBatch* in, uint64_t* off) {
+    if (!in || !off) return fail(HYPO_E_INVALID, "NULL");
+    uint64_t acc = 0;
+    for (uint32_t w = 0; w < in->n_windows; ++w) {
+        const HypoWindow& W = in->windows[w];
+        uint64_t longest = W.draft_len;
+        const uint32_t narm = W.n_internal + W.n_prefix + W.n_suffix;
+        for (uint32_t a = 0; a < narm; ++a) if (in->arm_len[W.first_arm + a] > longest) longest = in->arm_len[W.first_arm + a];
+        off[w] = acc;
+        acc += (2 * longest + 64 + 7) / 8 * 8;
+    }
+    off[in->n_windows] = acc;
+    return HYPO_OK;
+}
+
+int hypo_gpu_poa_batch(const HypoScoreParams* scores, const HypoWindowBatch* in, HypoConsensusBatch* out) {
+    if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
+    int rc = check_scores(scores);
+    if (rc) return rc;
+    if (!in || !out) return fail(HYPO_E_INVALID, "NULL batch");
+    memset(&tl_stats, 0, sizeof(tl_stats));
+    const uint32_t n = in->n_windows, na = in->n_arms;
+    if (n == 0) return HYPO_OK;
+    if (!in->windows || !in->draft4 || !out->bases || !out->off || !out->len || !out->status)
+        return fail(HYPO_E_INVALID, "NULL buffer in batch");
+    const uint64_t out_bytes = out->off[n];
+    DevBuf dW, dD, dAO, dAL, dA, dB, dO, dL, dS, dWS;
+    const size_t wsb = hypo::poa_workspace_bytes(n);
+    HIP_TRY(dW.alloc((size_t)n * sizeof(HypoWindow))); HIP_TRY(dD.alloc(in->draft4_bytes));
+    HIP_TRY(dAO.alloc((size_t)na * 8)); HIP_TRY(dAL.alloc((size_t)na * 4)); HIP_TRY(dA.alloc(in->arms2_bytes));
+    HIP_TRY(dB.alloc(out_bytes)); HIP_TRY(dO.alloc((size_t)(n + 1) * 8)); HIP_TRY(dL.alloc((size_t)n * 4));
+    HIP_TRY(dS.alloc(n)); HIP_TRY(dWS.alloc(wsb));
+    hipStream_t st = g_ctx.stream;
+    HIP_TRY(hipMemcpyAsync(dW.p, in->windows, (size_t)n * sizeof(HypoWindow), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dD.p, in->draft4, in->draft4_bytes, hipMemcpyHostToDevice, st));
+    if (na) {
+        HIP_TRY(hipMemcpyAsync(dAO.p, in->arm_off, (size_t)na * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(dAL.p, in->arm_len, (size_t)na * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(dA.p, in->arms2, in->arms2_bytes, hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipMemcpyAsync(dO.p, out->off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+    HypoWindowBatch din = *in;
+    din.windows = (const HypoWindow*)dW.p; din.draft4 = (const uint8_t*)dD.p; din.arm_off = (const uint64_t*)dAO.p;
+    din.arm_len = (const uint32_t*)dAL.p; din.arms2 = (const uint8_t*)dA.p;
+    HypoConsensusBatch dout;
+    dout.bases = (char*)dB.p; dout.off = (const uint64_t*)dO.p; dout.len = (uint32_t*)dL.p; dout.status = (uint8_t*)dS.p;
+    rc = hypo_gpu_poa_batch_device(scores, &din, &dout, dWS.p, wsb, st);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out->bases, dB.p, out_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out->len, dL.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out->status, dS.p, n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&tl_stats, (char*)dWS.p + 128, sizeof(HypoPoaStats), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    tl_stats.n_windows = n;
+    return HYPO_OK;
+}
+
+// ---- solid scan ------------------------------------------------------------------------------------
+size_t hypo_gpu_solid_scan_workspace_bytes(uint64_t n_bases) { return hypo::scan_workspace_bytes(n_bases); }
+
+int hypo_gpu_solid_scan_device(const uint8_t* packed4, uint64_t n_bases, uint32_t k, const uint64_t* bits,
+                               uint64_t* solid_pos_words, uint64_t* kids, uint64_t kids_cap,
+                               uint64_t* word_rank, uint64_t* n_solid,
+                               void* workspace, size_t workspace_bytes, void* hip_stream) {
+    if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
+    if (k < 2 || k > 31) return fail(HYPO_E_INVALID, "k=%u out of range 2..31", k);
+    if ((n_bases && !packed4) || !bits || (n_bases && !solid_pos_words)) return fail(HYPO_E_INVALID, "NULL buffer");
+    if (!workspace || workspace_bytes < hypo::scan_workspace_bytes(n_bases))
+        return fail(HYPO_E_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, hypo::scan_workspace_bytes(n_bases));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_ctx.stream;
+    HIP_TRY(hypo::scan_run(packed4, n_bases, k, bits, solid_pos_words, kids, kids_cap, word_rank, n_solid,
+                           workspace, workspace_bytes, st));
+    return HYPO_OK;
+}
+
+int hypo_gpu_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k, const uint64_t* bits,
+                        uint64_t* solid_pos_words, uint64_t* kids, uint64_t kids_cap,
+                        uint64_t* word_rank, uint64_t* n_solid) {
+    if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
+    if (k < 2 || k > 31) return fail(HYPO_E_INVALID, "k=%u out of range 2..31", k);
+    if ((n_bases && !packed4) || !bits || (n_bases && !solid_pos_words)) return fail(HYPO_E_INVALID, "NULL buffer");
+    const uint64_t nw = (n_bases + 63) / 64, nbytes = (n_bases + 1) / 2, bit_words = (1ull << (2 * k)) / 64 ? (1ull << (2 * k)) / 64 : 1;
+    DevBuf dP, dBits, dWords, dKids, dRank, dN, dWS;
+    const size_t wsb = hypo::scan_workspace_bytes(n_bases);
+    HIP_TRY(dP.alloc(nbytes)); HIP_TRY(dBits.alloc(bit_words * 8)); HIP_TRY(dWords.alloc(nw * 8));
+    HIP_TRY(dKids.alloc(kids_cap * 8)); HIP_TRY(dRank.alloc((nw + 1) * 8)); HIP_TRY(dN.alloc(8)); HIP_TRY(dWS.alloc(wsb));
+    hipStream_t st = g_ctx.stream;
+    if (nbytes) HIP_TRY(hipMemcpyAsync(dP.p, packed4, nbytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dBits.p, bits, bit_words * 8, hipMemcpyHostToDevice, st));
+    int rc = hypo_gpu_solid_scan_device((const uint8_t*)dP.p, n_bases, k, (const uint64_t*)dBits.p, (uint64_t*)dWords.p,
+                                        kids ? (uint64_t*)dKids.p : nullptr, kids ? kids_cap : 0, (uint64_t*)dRank.p,
+                                        (uint64_t*)dN.p, dWS.p, wsb, st);
+    if (rc) return rc;
+    uint64_t ns = 0;
+    HIP_TRY(hipMemcpyAsync(&ns, dN.p, 8, hipMemcpyDeviceToHost, st));
+    if (nw) HIP_TRY(hipMemcpyAsync(solid_pos_words, dWords.p, nw * 8, hipMemcpyDeviceToHost, st));
+    if (word_rank) HIP_TRY(hipMemcpyAsync(word_rank, dRank.p, (nw + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (kids && kids_cap) {
+        const uint64_t cnt = ns < kids_cap ? ns : kids_cap;
+        if (cnt) HIP_TRY(hipMemcpy(kids, dKids.p, cnt * 8, hipMemcpyDeviceToHost));
+    }
+    if (n_solid) *n_solid = ns;
+    return HYPO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,141 @@
+// grp.hpp — "group" primitives of the POA kernel.
+//
+// A group is GW lanes (16/32/64) of one wavefront that together own one window.  Control flow is
+// group-uniform: every lane of a group executes every collective in the same order.  Lanes exchange
+// data through registers (shuffle / ballot) or through the group's private LDS slice, always
+// separated by Grp::sync().
+//
+// Two back ends:
+//   * device (hipcc, gfx950): wave64 cross-lane instructions.  GW == 64 maps to full-wave ops.
+//   * HYPO_EMU (g++, tests only): every lane is a fiber scheduled round-robin; a collective is a
+//     rendezvous through a per-group mailbox.  This lets tests/ run the *same* poa_core.hpp on the
+//     CPU (under -fsanitize=address,undefined) against the oracle before a GPU is involved.
+#pragma once
+#include <stdint.h>
+
+#ifdef HYPO_EMU
+#define HD inline
+#define HYPO_UNROLL
+#else
+#include <hip/hip_runtime.h>
+#define HD __device__ __forceinline__
+#define HYPO_UNROLL _Pragma("unroll")
+#endif
+
+namespace hypo {
+
+#ifdef HYPO_EMU
+// ---- emulator back end -------------------------------------------------------------------------
+struct EmuGroup {              // shared by the GW fibers of one group
+    int gw;
+    int64_t box[64];           // mailbox
+    void (*yield)(void*);      // switch to the next lane's fiber
+    void* sched;
+};
+
+template <int GW>
+struct Grp {
+    int lane;
+    EmuGroup* eg;
+    HD void sync() const { eg->yield(eg->sched); }
+    template <class T> HD T shfl(T v, int src) const {
+        eg->box[lane] = (int64_t)v; sync();
+        T r = (T)eg->box[src & (GW - 1)]; sync();
+        return r;
+    }
+    // value of lane-1 (lane 0 gets `fill`)
+    template <class T> HD T shfl_up1(T v, T fill) const {
+        eg->box[lane] = (int64_t)v; sync();
+        T r = lane ? (T)eg->box[lane - 1] : fill; sync();
+        return r;
+    }
+    HD uint64_t ballot(bool p) const {
+        eg->box[lane] = p ? 1 : 0; sync();
+        uint64_t m = 0;
+        for (int i = 0; i < GW; ++i) m |= (uint64_t)(eg->box[i] & 1) << i;
+        sync();
+        return m;
+    }
+    HD bool any(bool p) const { return ballot(p) != 0; }
+    HD int reduce_max(int v) const {
+        eg->box[lane] = v; sync();
+        int r = (int)eg->box[0];
+        for (int i = 1; i < GW; ++i) if ((int)eg->box[i] > r) r = (int)eg->box[i];
+        sync();
+        return r;
+    }
+    HD int reduce_add(int v) const {
+        eg->box[lane] = v; sync();
+        int r = 0;
+        for (int i = 0; i < GW; ++i) r += (int)eg->box[i];
+        sync();
+        return r;
+    }
+    // exclusive prefix max over lanes (lane 0 gets `ident`)
+    HD int scan_max_excl(int v, int ident) const {
+        eg->box[lane] = v; sync();
+        int r = ident;
+        for (int i = 0; i < lane; ++i) if ((int)eg->box[i] > r) r = (int)eg->box[i];
+        sync();
+        return r;
+    }
+    HD int uniform(int v) const { return v; }
+};
+HD int popc64(uint64_t x) { return __builtin_popcountll(x); }
+HD int ctz64(uint64_t x) { return __builtin_ctzll(x); }
+
+#else
+// ---- device back end (gfx950, wave64) ------------------------------------------------------------
+template <int GW>
+struct Grp {
+    int lane;                                   // lane inside the group
+    HD int wlane() const { return (int)(threadIdx.x & 63); }
+    HD int gbase() const { return wlane() & ~(GW - 1); }
+    // LDS traffic of one wave is processed in order; this only stops the compiler from moving
+    // memory operations across the rendezvous.
+    HD void sync() const {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    template <class T> HD T shfl(T v, int src) const {
+        return (T)__shfl((int)v, src, GW);
+    }
+    template <class T> HD T shfl_up1(T v, T fill) const {
+        int r = __shfl_up((int)v, 1, GW);
+        return lane ? (T)r : fill;
+    }
+    HD uint64_t ballot(bool p) const {
+        uint64_t m = __ballot(p);
+        if (GW == 64) return m;
+        return (m >> gbase()) & ((1ull << (GW & 63)) - 1ull);
+    }
+    HD bool any(bool p) const { return ballot(p) != 0; }
+    HD int reduce_max(int v) const {
+        HYPO_UNROLL
+        for (int d = GW / 2; d >= 1; d >>= 1) { int o = __shfl_xor(v, d, GW); v = o > v ? o : v; }
+        return v;
+    }
+    HD int reduce_add(int v) const {
+        HYPO_UNROLL
+        for (int d = GW / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, GW);
+        return v;
+    }
+    HD int scan_max_excl(int v, int ident) const {
+        // inclusive Hillis-Steele over GW lanes, then shift by one lane
+        HYPO_UNROLL
+        for (int d = 1; d < GW; d <<= 1) {
+            int o = __shfl_up(v, d, GW);
+            if (lane >= d) v = o > v ? o : v;
+        }
+        int e = __shfl_up(v, 1, GW);
+        return lane ? e : ident;
+    }
+    // hint: value is identical in every lane of the WAVE (only true for GW == 64)
+    HD int uniform(int v) const { return GW == 64 ? __builtin_amdgcn_readfirstlane(v) : v; }
+};
+HD int popc64(uint64_t x) { return __popcll(x); }
+HD int ctz64(uint64_t x) { return __ffsll((unsigned long long)x) - 1; }
+#endif
+
+}  // namespace hypo

@@ -1,0 +1,176 @@
+// poa_kernel.hip — gfx950 kernels and launch logic of the batched window POA.
+//
+// Execution model (MI355X: 256 CUs, 64-lane waves, 160 KiB LDS per CU):
+//   * one lane group (= one wavefront for the current classes) owns one window from its first
+//     sequence to its consensus; all of the window's state stays in that group's LDS slice, the only
+//     HBM traffic is the packed input (read once) and the consensus (written once);
+//   * workgroups are single waves and persistent: each pulls window indices from a per-class queue
+//     with one atomic per window (row "dequeue" of the guide's price list: ~0.3-1 us, against
+//     ~100 us of work per window), so occupancy is bounded only by LDS bytes per window;
+//   * a plan kernel bins windows into size classes (poa_classes.hpp) from their sequence lengths;
+//     a window that still overflows its class is re-queued by the kernel to the next class, which is
+//     launched afterwards on the same stream (no host round trip, no CPU fallback).
+// MFMA is not used: the work is integer max/+ over irregular <=128-wide rows with a serial graph
+// update between sequences (see DESIGN.md for the roofline evidence).
+#include <hip/hip_runtime.h>
+#include "poa_classes.hpp"
+#include "poa_kernel.hpp"
+
+namespace hypo {
+
+// ------------------------------------------------------------------------------------------------
+// plan: dispatch + size-class estimate per window
+// ------------------------------------------------------------------------------------------------
+struct ClassLimits { int lmax, nmax, hcells, cpl; };
+
+template <class Cfg> __host__ __device__ constexpr ClassLimits limits_of() {
+    return ClassLimits{Cfg::LMAX, Cfg::NMAX, Cfg::HCELLS, Cfg::CPL};
+}
+
+__global__ void poa_plan_kernel(PoaParams P, PoaQueues Q, uint32_t n_windows) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_windows) return;
+    const HypoWindow W = P.windows[w];
+    const uint32_t narm = W.n_internal + W.n_prefix + W.n_suffix;
+    // longest sequence the window will align (markers included) and a node estimate
+    uint32_t maxlen = (W.n_internal == 0 || W.type != HYPO_WIN_SHORT) ? W.draft_len + 2 : 0;
+    for (uint32_t a = 0; a < narm; ++a) {
+        const uint32_t l = P.arm_len[W.first_arm + a] + 2;
+        maxlen = l > maxlen ? l : maxlen;
+    }
+    const uint32_t est_nodes = maxlen + maxlen / 4 + 8;
+    const ClassLimits lim[kNumPoaClasses] = {
+#define HYPO_LIM(ID, CFG) limits_of<CFG>(),
+        HYPO_FOR_EACH_CLASS(HYPO_LIM)
+#undef HYPO_LIM
+    };
+    int cls = kNumPoaClasses - 1;
+    for (int c = 0; c < kNumPoaClasses; ++c) {
+        const uint32_t S = (maxlen + 1 + lim[c].cpl - 1) / lim[c].cpl * lim[c].cpl;
+        if ((int)maxlen <= lim[c].lmax && (int)est_nodes <= lim[c].nmax &&
+            (uint64_t)(est_nodes + 1) * S <= (uint64_t)lim[c].hcells) { cls = c; break; }
+    }
+    if (W.type != HYPO_WIN_SHORT && cls < kFirstLongClass) cls = kFirstLongClass;
+    const uint32_t slot = atomicAdd(&Q.count[cls], 1u);
+    Q.items[(size_t)cls * Q.stride + slot] = w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// persistent per-class kernel
+// ------------------------------------------------------------------------------------------------
+template <class Cfg, bool USE_LDS>
+__global__ void __launch_bounds__(64) poa_class_kernel(PoaParams P, PoaQueues Q, int cls, char* scratch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int GW = Cfg::GW;
+    constexpr int GPW = 64 / GW;                       // groups per wave
+    const int wl = (int)(threadIdx.x & 63);
+    const int grp = wl / GW;
+    Grp<GW> g{wl & (GW - 1)};
+    char* mem = USE_LDS ? smem + (size_t)grp * PoaLayout<Cfg>::BYTES
+                        : scratch + ((size_t)blockIdx.x * GPW + grp) * PoaLayout<Cfg>::BYTES;
+    const uint32_t count = Q.count[cls];
+    uint64_t cells = 0, aligns = 0;
+    uint32_t n_ok = 0, n_esc = 0, n_fail = 0;
+    for (;;) {
+        uint32_t idx = 0;
+        if (g.lane == 0) idx = atomicAdd(&Q.head[cls], 1u);
+        idx = (uint32_t)g.shfl((int)idx, 0);
+        if (idx >= count) break;
+        const uint32_t w = Q.items[(size_t)cls * Q.stride + idx];
+        Poa<Cfg> poa(g, P, mem);
+        const int rc = poa.run(w);
+        cells += poa.cells; aligns += poa.aligns;
+        if (rc == RES_OK) {
+            ++n_ok;
+        } else if ((rc == RES_OVERFLOW || rc == RES_UNSUPPORTED) && cls + 1 < kNumPoaClasses) {
+            if (g.lane == 0) {
+                const uint32_t slot = atomicAdd(&Q.count[cls + 1], 1u);
+                Q.items[(size_t)(cls + 1) * Q.stride + slot] = w;
+            }
+            ++n_esc;
+        } else {
+            if (g.lane == 0) {
+                P.out_len[w] = 0;
+                P.out_status[w] = (uint8_t)(rc == RES_UNDEFINED ? HYPO_ST_UNDEFINED : HYPO_ST_CAPACITY);
+            }
+            ++n_fail;
+        }
+    }
+    if (g.lane == 0) {
+        atomicAdd((unsigned long long*)&Q.stats->n_class[cls], (unsigned long long)n_ok);
+        atomicAdd((unsigned long long*)&Q.stats->n_escalated, (unsigned long long)n_esc);
+        atomicAdd((unsigned long long*)&Q.stats->n_failed, (unsigned long long)n_fail);
+        atomicAdd((unsigned long long*)&Q.stats->dp_cells, (unsigned long long)cells);
+        atomicAdd((unsigned long long*)&Q.stats->n_alignments, (unsigned long long)aligns);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch
+// ------------------------------------------------------------------------------------------------
+template <class Cfg, bool USE_LDS>
+static hipError_t launch_class(const PoaParams& P, const PoaQueues& Q, int cls, uint32_t n_windows,
+                               char* scratch, int num_cus, int max_global_groups, hipStream_t stream) {
+    auto kern = poa_class_kernel<Cfg, USE_LDS>;
+    constexpr int GPW = 64 / Cfg::GW;
+    const size_t lds = USE_LDS ? (size_t)GPW * PoaLayout<Cfg>::BYTES : 0;
+    hipError_t e;
+    if (lds > 48 * 1024) {
+        e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    int per_cu = 0;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, lds);
+    if (e != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    long grid = (long)per_cu * num_cus;
+    if (!USE_LDS && grid * GPW > max_global_groups) grid = max_global_groups / GPW;
+    const long need = ((long)n_windows + GPW - 1) / GPW;      // never more waves than windows
+    if (grid > need) grid = need;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, stream, P, Q, cls, scratch);
+    return hipGetLastError();
+}
+
+size_t poa_workspace_bytes(uint32_t n_windows) {
+    size_t b = kPoaHeaderBytes;
+    b += (size_t)kNumPoaClasses * n_windows * sizeof(uint32_t);
+    b = (b + 255) / 256 * 256;
+    size_t big = 0;
+#define HYPO_BIG(ID, CFG) if (ID >= kFirstGlobalClass && (size_t)PoaLayout<CFG>::BYTES > big) big = PoaLayout<CFG>::BYTES;
+    HYPO_FOR_EACH_CLASS(HYPO_BIG)
+#undef HYPO_BIG
+    b += (size_t)kMaxGlobalGroups * big;
+    return b;
+}
+
+hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size_t workspace_bytes,
+                   int num_cus, hipStream_t stream) {
+    if (n_windows == 0) return hipSuccess;
+    if (workspace_bytes < poa_workspace_bytes(n_windows)) return hipErrorInvalidValue;
+    char* ws = (char*)workspace;
+    PoaQueues Q;
+    Q.count = (uint32_t*)ws;
+    Q.head = (uint32_t*)(ws + 64);
+    Q.stats = (HypoPoaStats*)(ws + 128);
+    Q.items = (uint32_t*)(ws + kPoaHeaderBytes);
+    Q.stride = n_windows;
+    size_t off = kPoaHeaderBytes + (size_t)kNumPoaClasses * n_windows * sizeof(uint32_t);
+    off = (off + 255) / 256 * 256;
+    char* scratch = ws + off;
+    hipError_t e = hipMemsetAsync(ws, 0, kPoaHeaderBytes, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(poa_plan_kernel, dim3((n_windows + 255) / 256), dim3(256), 0, stream, P, Q, n_windows);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    // Every class is launched with a grid sized for the whole batch: how many windows a class
+    // receives is only known on the device (plan + escalations), and an idle persistent wave exits
+    // after one failed dequeue.
+#define HYPO_LAUNCH(ID, CFG)                                                                              \
+    if ((e = launch_class<CFG, (ID < kFirstGlobalClass)>(P, Q, ID, n_windows, scratch, num_cus,          \
+                                                         kMaxGlobalGroups, stream)) != hipSuccess) return e;
+    HYPO_FOR_EACH_CLASS(HYPO_LAUNCH)
+#undef HYPO_LAUNCH
+    return hipSuccess;
+}
+
+}  // namespace hypo

@@ -1,0 +1,25 @@
+// poa_kernel.hpp — host-visible interface of poa_kernel.hip (internal to libhypo_gpu.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "poa_core.hpp"
+
+namespace hypo {
+
+constexpr int kFirstGlobalClass = 2;     // classes >= this keep their state in HBM scratch, not LDS
+constexpr int kFirstLongClass = 2;       // LONG windows (<= 500 bp, ~1.3 k nodes) start here
+constexpr int kMaxGlobalGroups = 512;    // resident groups of the HBM-scratch classes
+constexpr size_t kPoaHeaderBytes = 512;  // count[8] | head[8] | HypoPoaStats
+
+struct PoaQueues {
+    uint32_t* count;        // [classes] windows queued per class
+    uint32_t* head;         // [classes] next queue slot to hand out
+    HypoPoaStats* stats;
+    uint32_t* items;        // [classes][stride] window indices
+    uint32_t stride;
+};
+
+size_t poa_workspace_bytes(uint32_t n_windows);
+hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size_t workspace_bytes,
+                   int num_cus, hipStream_t stream);
+
+}  // namespace hypo

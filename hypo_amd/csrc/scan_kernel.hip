@@ -1,0 +1,220 @@
+// scan_kernel.hip — solid-kmer scan of a 4-bit packed contig (replaces Contig::find_solid_pos,
+// src/Contig.cpp:40-74, and suk::SolidKmers::is_solid, external/suk/include/suk/SolidKmers.hpp:119).
+//
+// MI355X mapping: HBM/L2-bound integer work, no MFMA.
+//   pass 1  scan_mark_kernel   one lane owns 64 consecutive k-mer start positions (= one output word).
+//           A 256-lane workgroup stages its 8 KiB of packed bases (+ k+1 bases of halo) into LDS with
+//           coalesced 16-byte loads, every lane then rolls the 2-bit k-mer over its 64+k-1 bases out of
+//           LDS and probes the 4^k-bit solid set (random 1-bit gathers: L2-resident for k<=13 = 8 MiB,
+//           Infinity-Cache-resident for k=15 = 128 MiB, HBM sectors for k=17 = 2 GiB).  The reference's
+//           two homopolymer-edge tests are applied, the lane writes its 64 mark bits as one coalesced
+//           8-byte store and its popcount.
+//   pass 2  scan_rank_*        exclusive prefix sum of the per-word popcounts = the rank directory
+//           behind the reference's sdsl rank/select support (Contig.cpp:72-73).
+//   pass 3  scan_kids_kernel   every marked position re-reads its k bases and writes the k-mer id at
+//           rank order (Contig::_kmerinfo order, Contig.cpp:67-68).
+// The 4^k-bit set is NOT staged through LDS for the survey's configurations: k=11 needs 512 KiB,
+// more than the 160 KiB of a CU, while it fits every XCD's 4 MiB L2.
+#include <hip/hip_runtime.h>
+#include "scan_kernel.hpp"
+
+namespace hypo {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_POS_PER_BLOCK = SCAN_THREADS * 64;             // 16384 positions
+constexpr int SCAN_BYTES_PER_BLOCK = SCAN_POS_PER_BLOCK / 2;      // 8192 bytes
+constexpr int SCAN_LDS_BYTES = SCAN_BYTES_PER_BLOCK + 32;         // + 1 byte before, k+1 bases after
+
+__device__ __forceinline__ unsigned nib(const uint8_t* p, long i) { return (p[i >> 1] >> (4 - 4 * (i & 1))) & 15; }
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_mark_kernel(const uint8_t* __restrict__ packed4, uint64_t n_bases, uint32_t k,
+                 const uint64_t* __restrict__ bits, uint64_t* __restrict__ words,
+                 uint32_t* __restrict__ wcount, uint64_t n_words) {
+    __shared__ __attribute__((aligned(16))) uint8_t sb[SCAN_LDS_BYTES + 16];
+    const uint64_t n_bytes = (n_bases + 1) / 2;
+    const uint64_t blk_byte0 = (uint64_t)blockIdx.x * SCAN_BYTES_PER_BLOCK;
+    // sb[16 + x] = packed4[blk_byte0 + x] for x in [-1, 8192 + 16); out of range -> 0x44 ("NN")
+    {
+        const int t = threadIdx.x;
+        // main body: 8192 bytes = 512 x 16 B, two per lane
+        for (int c = t; c < SCAN_BYTES_PER_BLOCK / 16 + 1; c += SCAN_THREADS) {
+            const uint64_t gb = blk_byte0 + (uint64_t)c * 16;
+            uint4 v;
+            if (gb + 16 <= n_bytes && ((uintptr_t)(packed4 + gb) & 15) == 0) {
+                v = *(const uint4*)(packed4 + gb);
+            } else {
+                uint8_t tmp[16];
+                for (int b = 0; b < 16; ++b) tmp[b] = (gb + b < n_bytes) ? packed4[gb + b] : (uint8_t)0x44;
+                v = *(uint4*)tmp;
+            }
+            *(uint4*)(sb + 16 + c * 16) = v;
+        }
+        if (t == 0) sb[15] = blk_byte0 > 0 ? packed4[blk_byte0 - 1] : (uint8_t)0x44;
+    }
+    __syncthreads();
+    const uint64_t word = (uint64_t)blockIdx.x * SCAN_THREADS + threadIdx.x;
+    if (word >= n_words) return;
+    const uint8_t* base = sb + 16;                       // base[-1] valid
+    const long l0 = (long)threadIdx.x * 64;              // local index of my first position
+    const uint64_t g0 = word * 64;                       // global index of my first position
+    const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    uint64_t kmer = 0, out = 0;
+    uint32_t klen = 0;
+    const int steps = 64 + (int)k - 1;
+    for (int s = 0; s < steps; ++s) {
+        const uint64_t gi = g0 + (uint64_t)s;            // k-mer END position i (Contig.cpp:46)
+        if (gi >= n_bases) break;
+        const unsigned b = nib(base, l0 + s);
+        if (b < 4) { kmer = ((kmer << 2) | b) & kmask; if (klen < k) ++klen; }
+        else { klen = 0; kmer = 0; }
+        if (klen == k) {
+            const long lbeg = l0 + s + 1 - (long)k;      // local k-mer start
+            const uint64_t gbeg = gi + 1 - k;
+            if ((bits[kmer >> 6] >> (kmer & 63)) & 1ull) {
+                bool add = true;
+                if (gi + 1 < n_bases && nib(base, l0 + s + 1) == b) add = false;          // Contig.cpp:59
+                if (gbeg > 0 && nib(base, lbeg - 1) == nib(base, lbeg)) add = false;      // Contig.cpp:63
+                if (add) out |= 1ull << (gbeg - g0);
+            }
+        }
+    }
+    words[word] = out;
+    wcount[word] = (uint32_t)__popcll(out);
+}
+
+// ---- exclusive scan of per-word popcounts (three small kernels) ---------------------------------
+constexpr int RANK_THREADS = 256;
+constexpr int RANK_ITEMS = 1024;     // words per block
+
+__global__ void __launch_bounds__(RANK_THREADS)
+scan_rank_partial(const uint32_t* __restrict__ wcount, uint64_t n_words, uint64_t* __restrict__ bsum) {
+    __shared__ uint32_t red[RANK_THREADS / 64];
+    const uint64_t b0 = (uint64_t)blockIdx.x * RANK_ITEMS;
+    uint32_t s = 0;
+    for (int i = threadIdx.x; i < RANK_ITEMS; i += RANK_THREADS) {
+        const uint64_t w = b0 + i;
+        if (w < n_words) s += wcount[w];
+    }
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint64_t t = 0; for (int i = 0; i < RANK_THREADS / 64; ++i) t += red[i]; bsum[blockIdx.x] = t; }
+}
+
+__global__ void __launch_bounds__(1024)
+scan_rank_blocksums(uint64_t* __restrict__ bsum, uint64_t n_blocks, uint64_t* __restrict__ total) {
+    // single workgroup: sequential chunks of 1024 block sums
+    __shared__ uint64_t sh[1024];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint64_t c0 = 0; c0 < n_blocks; c0 += 1024) {
+        const uint64_t i = c0 + threadIdx.x;
+        const uint64_t v = i < n_blocks ? bsum[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            uint64_t add = threadIdx.x >= (unsigned)d ? sh[threadIdx.x - d] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const uint64_t incl = sh[threadIdx.x];
+        if (i < n_blocks) bsum[i] = carry + incl - v;      // exclusive
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total) *total = carry;
+}
+
+__global__ void __launch_bounds__(RANK_THREADS)
+scan_rank_final(const uint32_t* __restrict__ wcount, uint64_t n_words, const uint64_t* __restrict__ bsum,
+                uint64_t* __restrict__ word_rank, const uint64_t* __restrict__ total) {
+    // each lane owns 4 consecutive words of the block's 1024
+    __shared__ uint32_t wsum[RANK_THREADS / 64];
+    const uint64_t b0 = (uint64_t)blockIdx.x * RANK_ITEMS;
+    const uint64_t w0 = b0 + (uint64_t)threadIdx.x * 4;
+    uint32_t c[4];
+    uint32_t mine = 0;
+    for (int i = 0; i < 4; ++i) { c[i] = (w0 + i < n_words) ? wcount[w0 + i] : 0; mine += c[i]; }
+    // wave-inclusive scan
+    uint32_t inc = mine;
+    const int lane = threadIdx.x & 63;
+    for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int i = 0; i < (int)(threadIdx.x >> 6); ++i) woff += wsum[i];
+    uint64_t run = bsum[blockIdx.x] + woff + (inc - mine);
+    for (int i = 0; i < 4; ++i) { if (w0 + i < n_words) word_rank[w0 + i] = run; run += c[i]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) word_rank[n_words] = *total;
+}
+
+// ---- k-mer ids of the marked positions, in position order --------------------------------------
+__global__ void __launch_bounds__(256)
+scan_kids_kernel(const uint8_t* __restrict__ packed4, uint32_t k, const uint64_t* __restrict__ words,
+                 const uint64_t* __restrict__ word_rank, uint64_t n_words,
+                 uint64_t* __restrict__ kids, uint64_t kids_cap) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    uint64_t m = words[w];
+    uint64_t r = word_rank[w];
+    while (m) {
+        const int b = __ffsll((unsigned long long)m) - 1;
+        m &= m - 1;
+        if (r < kids_cap) {
+            const uint64_t beg = w * 64 + (uint64_t)b;
+            uint64_t kmer = 0;
+            for (uint32_t t = 0; t < k; ++t) kmer = (kmer << 2) | (nib(packed4, (long)(beg + t)) & 3);
+            kids[r] = kmer;
+        }
+        ++r;
+    }
+}
+
+size_t scan_workspace_bytes(uint64_t n_bases) {
+    const uint64_t n_words = (n_bases + 63) / 64;
+    const uint64_t n_blocks = (n_words + RANK_ITEMS - 1) / RANK_ITEMS;
+    size_t b = 256;                                        // total
+    b += (n_words * 4 + 255) / 256 * 256;                  // wcount
+    b += (n_blocks * 8 + 255) / 256 * 256;                 // block sums
+    b += (n_words + 1) * 8 + 256;                          // internal rank directory if the caller passes none
+    return b;
+}
+
+hipError_t scan_run(const uint8_t* packed4, uint64_t n_bases, uint32_t k, const uint64_t* bits,
+                    uint64_t* words, uint64_t* kids, uint64_t kids_cap, uint64_t* word_rank,
+                    uint64_t* n_solid, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (workspace_bytes < scan_workspace_bytes(n_bases)) return hipErrorInvalidValue;
+    const uint64_t n_words = (n_bases + 63) / 64;
+    char* ws = (char*)workspace;
+    uint64_t* total = (uint64_t*)ws;
+    uint32_t* wcount = (uint32_t*)(ws + 256);
+    const uint64_t n_rblocks = (n_words + RANK_ITEMS - 1) / RANK_ITEMS;
+    uint64_t* bsum = (uint64_t*)(ws + 256 + (n_words * 4 + 255) / 256 * 256);
+    uint64_t* own_rank = (uint64_t*)((char*)bsum + (n_rblocks * 8 + 255) / 256 * 256);
+    if (!word_rank) word_rank = own_rank;
+    hipError_t e;
+    if (n_words == 0) {
+        if ((e = hipMemsetAsync(total, 0, 8, stream)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(word_rank, 0, 8, stream)) != hipSuccess) return e;
+        if (n_solid) return hipMemsetAsync(n_solid, 0, 8, stream);
+        return hipSuccess;
+    }
+    const unsigned mark_blocks = (unsigned)((n_words + SCAN_THREADS - 1) / SCAN_THREADS);
+    hipLaunchKernelGGL(scan_mark_kernel, dim3(mark_blocks), dim3(SCAN_THREADS), 0, stream,
+                       packed4, n_bases, k, bits, words, wcount, n_words);
+    hipLaunchKernelGGL(scan_rank_partial, dim3((unsigned)n_rblocks), dim3(RANK_THREADS), 0, stream, wcount, n_words, bsum);
+    hipLaunchKernelGGL(scan_rank_blocksums, dim3(1), dim3(1024), 0, stream, bsum, n_rblocks, total);
+    hipLaunchKernelGGL(scan_rank_final, dim3((unsigned)n_rblocks), dim3(RANK_THREADS), 0, stream, wcount, n_words, bsum, word_rank, total);
+    if (kids && kids_cap)
+        hipLaunchKernelGGL(scan_kids_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, stream,
+                           packed4, k, words, word_rank, n_words, kids, kids_cap);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (n_solid) return hipMemcpyAsync(n_solid, total, 8, hipMemcpyDeviceToDevice, stream);
+    return hipSuccess;
+}
+
+}  // namespace hypo

@@ -170,6 +170,8 @@ typedef struct HypoPoaStats {
     uint64_t n_alignments;
 } HypoPoaStats;
 int hypo_gpu_poa_last_stats(HypoPoaStats* out);
+/* Same for a _device call: synchronises the stream and copies the counters out of `workspace`. */
+int hypo_gpu_poa_read_stats(const void* workspace, void* hip_stream, HypoPoaStats* out);
 
 #ifdef __cplusplus
 }

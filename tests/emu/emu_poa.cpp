@@ -1,0 +1,180 @@
+// emu_poa.cpp — TEST-ONLY lockstep emulator for hypo_amd/csrc/poa_core.hpp.
+//
+// Compiles the kernel's per-window code with HYPO_EMU: every lane of a group is a fiber with its own
+// stack, scheduled round-robin; Grp::sync() yields to the next lane, so each collective is a
+// rendezvous of all GW lanes (the kernel's control flow is group-uniform by construction — the
+// emulator aborts if a lane tries to rendezvous with a lane that already returned).
+// The group's memory slice is one heap block of exactly PoaLayout::BYTES, so AddressSanitizer sees
+// out-of-slice accesses.  Built by tests/emu/Makefile into tests/_build/libhypo_emu[_asan].so and driven
+// by tests/test_poa_emulator.py against the oracle.  Not part of the product.
+#define HYPO_EMU 1
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../../hypo_amd/csrc/poa_core.hpp"
+
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define EMU_ASAN 1
+#endif
+#endif
+#if defined(__SANITIZE_ADDRESS__)
+#define EMU_ASAN 1
+#endif
+#ifdef EMU_ASAN
+extern "C" void __asan_unpoison_memory_region(void const volatile*, size_t);
+#endif
+
+extern "C" void emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size emu_switch,.-emu_switch
+)");
+
+namespace {
+
+constexpr size_t STACK_BYTES = 256 * 1024;
+
+struct Sched {
+    int gw = 0, cur = 0;
+    void* sp[64] = {};
+    void* main_sp = nullptr;
+    bool done[64] = {};
+    char* stacks = nullptr;
+    void (*body)(int lane, void* arg) = nullptr;
+    void* arg = nullptr;
+};
+thread_local Sched* tl_sched = nullptr;
+
+void yield_cb(void* s_) {
+    Sched* s = (Sched*)s_;
+    int cur = s->cur, nxt = (cur + 1) % s->gw;
+    if (s->done[nxt]) { fprintf(stderr, "[emu] non-uniform control flow: lane %d waits for finished lane %d\n", cur, nxt); abort(); }
+    s->cur = nxt;
+    emu_switch(&s->sp[cur], s->sp[nxt]);
+}
+
+void fiber_entry() {
+    Sched* s = tl_sched;
+    int lane = s->cur;
+    s->body(lane, s->arg);
+    s->done[lane] = true;
+    int nxt = lane + 1;
+    void* dummy;
+    if (nxt == s->gw) { emu_switch(&dummy, s->main_sp); }
+    else {
+        if (s->done[nxt]) { fprintf(stderr, "[emu] lane order violated\n"); abort(); }
+        s->cur = nxt; emu_switch(&dummy, s->sp[nxt]);
+    }
+    abort();   // a finished fiber is never resumed
+}
+
+void run_group(Sched& s, int gw, void (*body)(int, void*), void* arg) {
+    s.gw = gw; s.body = body; s.arg = arg;
+    if (!s.stacks) s.stacks = (char*)aligned_alloc(64, STACK_BYTES * 64);
+#ifdef EMU_ASAN
+    __asan_unpoison_memory_region(s.stacks, STACK_BYTES * 64);
+#endif
+    for (int l = 0; l < gw; ++l) {
+        s.done[l] = false;
+        uintptr_t top = ((uintptr_t)(s.stacks + STACK_BYTES * (l + 1))) & ~(uintptr_t)15;
+        void** p = (void**)top;
+        *--p = nullptr;                 // fake return address of fiber_entry's caller
+        *--p = (void*)&fiber_entry;     // `ret` target
+        for (int k = 0; k < 6; ++k) *--p = nullptr;   // rbp rbx r12 r13 r14 r15
+        s.sp[l] = (void*)p;
+    }
+    tl_sched = &s;
+    s.cur = 0;
+    emu_switch(&s.main_sp, s.sp[0]);
+    for (int l = 0; l < gw; ++l) if (!s.done[l]) { fprintf(stderr, "[emu] lane %d did not finish\n", l); abort(); }
+}
+
+template <class Cfg>
+struct Job {
+    hypo::EmuGroup eg;
+    const hypo::PoaParams* P;
+    char* mem;
+    uint32_t w;
+    int rc[64];
+    uint64_t cells, aligns;
+};
+
+template <class Cfg>
+void lane_body(int lane, void* arg) {
+    Job<Cfg>* j = (Job<Cfg>*)arg;
+    hypo::Grp<Cfg::GW> g{lane, &j->eg};
+    hypo::Poa<Cfg> poa(g, *j->P, j->mem);
+    j->rc[lane] = poa.run(j->w);
+    if (lane == 0) { j->cells = poa.cells; j->aligns = poa.aligns; }
+}
+
+template <class Cfg>
+int run_cfg(const hypo::PoaParams& P, uint32_t n_windows, uint8_t* res, uint64_t* cells, uint64_t* aligns) {
+    Sched s;
+    Job<Cfg> job;
+    job.P = &P;
+    job.eg.gw = Cfg::GW; job.eg.yield = yield_cb; job.eg.sched = &s;
+    for (uint32_t w = 0; w < n_windows; ++w) {
+        job.mem = (char*)malloc(hypo::PoaLayout<Cfg>::BYTES);       // exact size: ASan sees overruns
+        memset(job.mem, 0xA5, hypo::PoaLayout<Cfg>::BYTES);         // LDS is not zero-initialised
+        job.w = w; job.cells = job.aligns = 0;
+        run_group(s, Cfg::GW, lane_body<Cfg>, &job);
+        for (int l = 1; l < Cfg::GW; ++l) if (job.rc[l] != job.rc[0]) { fprintf(stderr, "[emu] lanes disagree on the result of window %u\n", w); abort(); }
+        res[w] = (uint8_t)job.rc[0];
+        if (job.rc[0] != hypo::RES_OK) { P.out_len[w] = 0; P.out_status[w] = 0xFF; }
+        *cells += job.cells; *aligns += job.aligns;
+        free(job.mem);
+    }
+    free(s.stacks);
+    return 0;
+}
+
+}  // namespace
+
+// configurations mirrored from hypo_amd/csrc/poa_kernel.hip (keep in sync: see poa_classes.hpp)
+#include "../../hypo_amd/csrc/poa_classes.hpp"
+
+extern "C" int emu_poa_batch(const HypoScoreParams* sp, const HypoWindowBatch* in, HypoConsensusBatch* out,
+                             int cfg_id, uint8_t* res, uint64_t* cells, uint64_t* aligns) {
+    hypo::PoaParams P;
+    P.windows = in->windows; P.draft4 = in->draft4; P.arm_off = in->arm_off; P.arm_len = in->arm_len; P.arms2 = in->arms2;
+    P.out_bases = out->bases; P.out_off = out->off; P.out_len = out->len; P.out_status = out->status;
+    P.sr_m = sp->sr_match; P.sr_n = sp->sr_mismatch; P.sr_g = sp->sr_gap;
+    P.lr_m = sp->lr_match; P.lr_n = sp->lr_mismatch; P.lr_g = sp->lr_gap;
+    *cells = 0; *aligns = 0;
+    switch (cfg_id) {
+#define HYPO_CLASS_CASE(ID, CFG) case ID: return run_cfg<hypo::CFG>(P, in->n_windows, res, cells, aligns);
+        HYPO_FOR_EACH_CLASS(HYPO_CLASS_CASE)
+#undef HYPO_CLASS_CASE
+        default: return -1;
+    }
+}
+
+extern "C" int emu_class_bytes(int cfg_id) {
+    switch (cfg_id) {
+#define HYPO_CLASS_CASE(ID, CFG) case ID: return hypo::PoaLayout<hypo::CFG>::BYTES;
+        HYPO_FOR_EACH_CLASS(HYPO_CLASS_CASE)
+#undef HYPO_CLASS_CASE
+        default: return -1;
+    }
+}

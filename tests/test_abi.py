@@ -1,0 +1,58 @@
+"""CPU: the product library builds for gfx950, loads, and exports every symbol include/hypo_gpu.h
+declares.  No compute call is made here (there is no GPU in the build container)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from hypo_amd import abi, capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(capi.LIB_PATH):
+        capi.build_library()
+    return capi.load_library()
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "hypo_gpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hypo_gpu_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_exports_match_header(lib):
+    names = declared_functions()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), f"libhypo_gpu.so does not export {n}"
+    assert sorted(capi.EXPORTS) == names
+
+
+def test_abi_version_and_struct_sizes(lib):
+    assert lib.hypo_gpu_abi_version() == abi.ABI_VERSION
+    assert C.sizeof(abi.Window) == 40 and abi.WINDOW_DTYPE.itemsize == 40
+    assert C.sizeof(abi.ScoreParams) == 6
+    assert C.sizeof(abi.WindowBatch) == 64
+    assert C.sizeof(abi.ConsensusBatch) == 32
+
+
+def test_fails_loudly_without_device(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    assert lib.hypo_gpu_init(0) == abi.HYPO_E_NODEVICE
+    assert b"no HIP device" in lib.hypo_gpu_last_error()
+    sp = abi.ScoreParams(*abi.DEFAULT_SCORES)
+    ins, out = abi.WindowBatch(), abi.ConsensusBatch()
+    assert lib.hypo_gpu_poa_batch(C.byref(sp), C.byref(ins), C.byref(out)) == abi.HYPO_E_NOTINIT
+    with pytest.raises(capi.HypoGpuError):
+        capi.HypoGpu(0)
+
+
+def test_missing_library_is_an_error(tmp_path):
+    with pytest.raises(capi.HypoGpuError):
+        capi.load_library(str(tmp_path / "nope.so"))

@@ -1,0 +1,125 @@
+"""GPU: parity of the HIP POA path (through the C-ABI of libhypo_gpu.so) with the committed goldens
+of the real reference and with the oracle on seeded inputs.  Bit-exact: consensus strings must be equal."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from hypo_amd import abi, capi, sim
+from hypo_amd.batch import TextWindow, build_batch
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    return capi.HypoGpu(0)
+
+
+def _short_only(items):
+    return [it for it in items if not it[0].is_long]
+
+
+@pytest.mark.parametrize("name", gu.WINDOW_FILES)
+def test_goldens_host_api(gpu, name):
+    total = 0
+    for scores, items in gu.windows_by_scores(name).items():
+        items = _short_only(items)
+        if not items:
+            continue
+        cons, st = gpu.poa_consensus(build_batch([w for w, _, _ in items]), scores)
+        for (w, want, tag), got, s in zip(items, cons, st):
+            assert s == 0, (tag, s)
+            assert got == want, (tag, scores)
+            total += 1
+    assert total > 100
+
+
+def test_goldens_device_api(gpu):
+    items = _short_only(gu.windows_by_scores("windows_real_c1.jsonl.gz")[abi.DEFAULT_SCORES])
+    db = gpu.device_batch(build_batch([w for w, _, _ in items]))
+    db.run()
+    cons, st = db.consensus()
+    assert [c for c in cons] == [want for _, want, _ in items]
+    stats = db.stats()
+    assert stats["n_failed"] == 0 and sum(stats["n_class"]) == len(items)
+
+
+def test_vs_oracle_c1_shape(gpu, oracle_lib):
+    b = sim.window_batch(20000, seed=11)
+    off = b.slot_layout()
+    bases, _, ln, st = gpu.poa_batch(b, off=off)
+    ob, _, oln, ost, cells, aligns = oracle_lib.poa_batch_raw(b, off=off)
+    assert (st == 0).all() and (ost == 0).all()
+    assert (ln == oln).all()
+    assert (bases[:int(off[-1])] == ob[:int(off[-1])]).all()
+    s = gpu.last_stats()
+    assert s["dp_cells"] == cells and s["n_alignments"] == aligns
+
+
+@pytest.mark.parametrize("length,arms,err", [(8, 6, 0.08), (32, 30, 0.005), (64, 50, 0.08), (100, 30, 0.08),
+                                             (100, 50, 0.005), (200, 30, 0.08)])
+def test_vs_oracle_grid(gpu, oracle_lib, length, arms, err):
+    b = sim.grid_batch(length, arms, 300, err, seed=length * 1000 + arms)
+    off = b.slot_layout()
+    bases, _, ln, st = gpu.poa_batch(b, off=off)
+    ob, _, oln, ost, _, _ = oracle_lib.poa_batch_raw(b, off=off)
+    assert (st == ost).all() and (ln == oln).all()
+    assert (bases[:int(off[-1])] == ob[:int(off[-1])]).all()
+
+
+@pytest.mark.parametrize("scores", [(2, -3, -1, 3, -5, -4), (1, -1, -1, 1, -1, -1), (10, -10, 0, 3, -5, -4),
+                                    (127, -128, -128, 3, -5, -4)])
+def test_vs_oracle_scores(gpu, oracle_lib, scores):
+    b = sim.grid_batch(60, 12, 300, 0.1, seed=77)
+    off = b.slot_layout()
+    bases, _, ln, st = gpu.poa_batch(b, scores=scores, off=off)
+    ob, _, oln, ost, _, _ = oracle_lib.poa_batch_raw(b, scores=scores, off=off)
+    assert (st == ost).all() and (ln == oln).all()
+    assert (bases[:int(off[-1])] == ob[:int(off[-1])]).all()
+
+
+def test_dispatch_and_edge_cases(gpu, oracle_lib):
+    ws = [
+        TextWindow("ACGTNACGT", ["ACGTACGT"], [], [], 0),
+        TextWindow("ACGTACGT", ["ACGTACGT", "ACGTACGT"], [], [], 3),
+        TextWindow("ACGTACGT", [], [], [], 0),
+        TextWindow("ACGTACGT", ["", ""], [], [], 0),
+        TextWindow("ACGAACGT", ["ACGTACGT", "ACGTACGT", "ACGTACGT"], [], [], 3),
+        TextWindow("A", ["A", "C", "A"], [], [], 0),
+        TextWindow("ACGTNNACGT", [], ["ACG", "ACGTA", "ACGTAC"], ["CGT", "ACGT", "TACGT"], 0),
+    ]
+    b = build_batch(ws)
+    cons, st = gpu.poa_consensus(b)
+    ocons, ost, _, _ = oracle_lib.poa_batch(b)
+    assert list(st) == list(ost)
+    assert cons == ocons
+    assert cons[:5] == ["ACGTNACGT", "", "ACGTACGT", "ACGTACGT", "ACGTACGT"]
+
+
+def test_slot_overflow_and_empty_batch(gpu):
+    b = build_batch([TextWindow("ACGTACGTAC", ["ACGTACGTAC"] * 3)])
+    bases, off, ln, st = gpu.poa_batch(b, off=np.array([0, 4], dtype=np.uint64))
+    assert st[0] == abi.ST_CONS_OVERFLOW and ln[0] == 10
+    e = build_batch([])
+    bases, off, ln, st = gpu.poa_batch(e)
+    assert ln.size == 0
+
+
+def test_invalid_scores_rejected(gpu):
+    b = build_batch([TextWindow("ACGT", ["ACGT", "ACGT"])])
+    with pytest.raises(capi.HypoGpuError):
+        gpu.poa_batch(b, scores=(5, -4, 1, 3, -5, -4))
+
+
+def test_escalation_between_classes(gpu, oracle_lib):
+    """Windows that overflow a size class are re-queued on the device and still come out bit-exact."""
+    b = sim.grid_batch(100, 50, 200, 0.2, seed=5)       # very noisy: graphs outgrow the plan's estimate
+    off = b.slot_layout()
+    bases, _, ln, st = gpu.poa_batch(b, off=off)
+    ob, _, oln, ost, _, _ = oracle_lib.poa_batch_raw(b, off=off)
+    assert (st == ost).all() and (ln == oln).all() and (bases[:int(off[-1])] == ob[:int(off[-1])]).all()
+    s = gpu.last_stats()
+    assert s["n_failed"] == 0
+    assert sum(s["n_class"]) == 200

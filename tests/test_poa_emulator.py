@@ -1,0 +1,52 @@
+"""CPU: the kernel's per-window code (hypo_amd/csrc/poa_core.hpp) compiled for the lockstep emulator
+(tests/emu/) against the committed goldens of the real reference.  This is the same source hipcc
+compiles for gfx950; it catches logic and out-of-slice bugs before a GPU run."""
+import pytest
+
+from hypo_amd.batch import build_batch
+import emu_util
+import golden_util as gu
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return emu_util.Emu()
+
+
+def _check(emu, cfg, name, max_items, allow_overflow):
+    n_ok = 0
+    for scores, items in gu.windows_by_scores(name).items():
+        items = [it for it in items if not it[0].is_long][:max_items]
+        if not items:
+            continue
+        b = build_batch([w for w, _, _ in items])
+        cons, st, res, _, _ = emu.poa_batch(b, cfg, scores)
+        for (w, want, tag), got, r, s in zip(items, cons, res, st):
+            if r == emu_util.RES_OVERFLOW and allow_overflow:
+                continue
+            assert r == emu_util.RES_OK and s == 0, (tag, r, s)
+            assert got == want, (tag, scores)
+            n_ok += 1
+    return n_ok
+
+
+def test_class0_synth(emu):
+    assert _check(emu, 0, "windows_synth.jsonl.gz", 120, True) > 50
+
+
+def test_class1_synth(emu):
+    assert _check(emu, 1, "windows_synth.jsonl.gz", 120, True) > 100
+
+
+def test_class1_real(emu):
+    assert _check(emu, 1, "windows_real_c1.jsonl.gz", 150, False) == 150
+
+
+def test_class2_wide(emu):
+    # the 8-columns-per-lane / 16-bit-id instantiation, including the 200-bp windows
+    items = [it for it in gu.windows_by_scores("windows_synth.jsonl.gz")[(5, -4, -8, 3, -5, -4)]
+             if not it[0].is_long and len(it[0].draft) >= 150][:12]
+    b = build_batch([w for w, _, _ in items])
+    cons, st, res, _, _ = emu.poa_batch(b, 2)
+    for (w, want, tag), got, r in zip(items, cons, res):
+        assert r == emu_util.RES_OK and got == want, tag
