@@ -38,6 +38,10 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     if not os.path.exists(path):
         raise HypoGpuError(f"{path} is missing: build it with `make -C hypo_amd/csrc` "
                            "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+    # One HIP runtime per process: torch bundles its own libamdhip64.so.7; importing it first makes the
+    # loader resolve this library's NEEDED libamdhip64.so.7 to the same copy (two runtimes in one
+    # process cannot both own the GPU).
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     lib.hypo_gpu_last_error.restype = C.c_char_p
     lib.hypo_gpu_poa_workspace_bytes.restype = C.c_size_t

@@ -154,6 +154,7 @@ int hypo_gpu_poa_batch(const HypoScoreParams* scores, const HypoWindowBatch* in,
         HIP_TRY(hipMemcpyAsync(dA.p, in->arms2, in->arms2_bytes, hipMemcpyHostToDevice, st));
     }
     HIP_TRY(hipMemcpyAsync(dO.p, out->off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(dB.p, 0, out_bytes ? out_bytes : 16, st));   // slack bytes of a slot come back as 0
     HypoWindowBatch din = *in;
     din.windows = (const HypoWindow*)dW.p; din.draft4 = (const uint8_t*)dD.p; din.arm_off = (const uint64_t*)dAO.p;
     din.arm_len = (const uint32_t*)dAL.p; din.arms2 = (const uint8_t*)dA.p;
