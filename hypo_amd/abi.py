@@ -56,7 +56,7 @@ class ConsensusBatch(C.Structure):
 class PoaStats(C.Structure):
     _fields_ = [("n_windows", C.c_uint64), ("n_trivial", C.c_uint64), ("n_class", C.c_uint64 * 4),
                 ("n_escalated", C.c_uint64), ("n_failed", C.c_uint64), ("dp_cells", C.c_uint64),
-                ("n_alignments", C.c_uint64)]
+                ("n_alignments", C.c_uint64), ("alg_bytes", C.c_uint64 * 4)]
 
 
 # numpy dtype equivalent of HypoWindow (40 bytes, same offsets)

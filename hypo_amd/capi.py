@@ -20,7 +20,7 @@ EXPORTS = [
     "hypo_gpu_num_cus", "hypo_gpu_solid_scan", "hypo_gpu_solid_scan_workspace_bytes",
     "hypo_gpu_solid_scan_device", "hypo_gpu_poa_batch", "hypo_gpu_poa_workspace_bytes",
     "hypo_gpu_poa_batch_device", "hypo_gpu_poa_slot_layout", "hypo_gpu_poa_last_stats",
-    "hypo_gpu_poa_read_stats",
+    "hypo_gpu_poa_read_stats", "hypo_gpu_profile_begin", "hypo_gpu_profile_calls", "hypo_gpu_profile_read",
 ]
 
 
@@ -122,6 +122,21 @@ class HypoGpu:
         n = int(ns.value)
         return words[:nw], kids[:min(n, kids_cap)], rank, n
 
+    # ---- HIP-event kernel timing --------------------------------------------------------------------------
+    def profile_begin(self, max_calls: int):
+        self._check(self.lib.hypo_gpu_profile_begin(C.c_int(max_calls)))
+
+    def profile_read(self):
+        """List of per-call lists of elapsed milliseconds (see include/hypo_gpu.h)."""
+        out = []
+        buf = (C.c_float * 8)()
+        for c in range(int(self.lib.hypo_gpu_profile_calls())):
+            n = int(self.lib.hypo_gpu_profile_read(C.c_int(c), buf, C.c_int(8)))
+            if n < 0:
+                self._check(n)
+            out.append([float(buf[i]) for i in range(n)])
+        return out
+
     # ---- device-resident entry points (torch tensors own the HBM) --------------------------------------
     def device_batch(self, b: HostBatch, off=None):
         return DeviceBatch(self, b, off)
@@ -133,7 +148,8 @@ class HypoGpu:
 def _stats_dict(s: abi.PoaStats) -> dict:
     return {"n_windows": int(s.n_windows), "n_trivial": int(s.n_trivial),
             "n_class": [int(x) for x in s.n_class], "n_escalated": int(s.n_escalated),
-            "n_failed": int(s.n_failed), "dp_cells": int(s.dp_cells), "n_alignments": int(s.n_alignments)}
+            "n_failed": int(s.n_failed), "dp_cells": int(s.dp_cells), "n_alignments": int(s.n_alignments),
+            "alg_bytes": [int(x) for x in s.alg_bytes]}
 
 
 def _t(arr, dev):

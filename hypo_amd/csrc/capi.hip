@@ -24,6 +24,18 @@ int fail(int code, const char* fmt, ...) {
 struct Ctx { bool ready = false; int device = -1; int num_cus = 0; hipStream_t stream = nullptr; };
 Ctx g_ctx;
 
+// HIP-event recorder for the next calls (hypo_gpu_profile_*)
+struct ProfCall { int kind = 0; hypo::KernelEvents ke; };      // kind 1 = POA, 2 = scan
+struct Prof { std::vector<ProfCall> calls; int used = 0; };
+Prof g_prof;
+
+ProfCall* prof_next(int kind) {
+    if (g_prof.used >= (int)g_prof.calls.size()) return nullptr;
+    ProfCall* c = &g_prof.calls[g_prof.used++];
+    c->kind = kind; c->ke.n = 0;
+    return c;
+}
+
 struct DevBuf {
     void* p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -75,6 +87,31 @@ int hypo_gpu_shutdown(void) {
     return HYPO_OK;
 }
 
+// ---- profiling ---------------------------------------------------------------------------------------
+int hypo_gpu_profile_begin(int max_calls) {
+    if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
+    if (max_calls < 0 || max_calls > 256) return fail(HYPO_E_INVALID, "max_calls out of range 0..256");
+    for (auto& c : g_prof.calls) for (auto& e : c.ke.ev) (void)hipEventDestroy(e);
+    g_prof.calls.assign((size_t)max_calls, ProfCall());
+    g_prof.used = 0;
+    for (auto& c : g_prof.calls) for (auto& e : c.ke.ev) HIP_TRY(hipEventCreate(&e));
+    return HYPO_OK;
+}
+int hypo_gpu_profile_calls(void) { return g_prof.used; }
+int hypo_gpu_profile_read(int call, float* ms, int n) {
+    if (call < 0 || call >= g_prof.used || !ms) return fail(HYPO_E_INVALID, "no such profiled call");
+    ProfCall& c = g_prof.calls[(size_t)call];
+    if (c.ke.n < 2) return 0;
+    HIP_TRY(hipEventSynchronize(c.ke.ev[c.ke.n - 1]));
+    int out = 0;
+    for (int i = 0; i + 1 < c.ke.n && out < n; ++i) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, c.ke.ev[i], c.ke.ev[i + 1]));
+        ms[out++] = t;
+    }
+    return out;
+}
+
 // ---- POA -------------------------------------------------------------------------------------------
 size_t hypo_gpu_poa_workspace_bytes(uint32_t n_windows, uint32_t /*n_arms*/) {
     return hypo::poa_workspace_bytes(n_windows);
@@ -94,7 +131,8 @@ int hypo_gpu_poa_batch_device(const HypoScoreParams* scores, const HypoWindowBat
         return fail(HYPO_E_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, hypo::poa_workspace_bytes(in->n_windows));
     hypo::PoaParams P = make_params(scores, in, out);
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_ctx.stream;
-    HIP_TRY(hypo::poa_run(P, in->n_windows, workspace, workspace_bytes, g_ctx.num_cus, st));
+    ProfCall* pc = prof_next(1);
+    HIP_TRY(hypo::poa_run(P, in->n_windows, workspace, workspace_bytes, g_ctx.num_cus, st, pc ? &pc->ke : nullptr));
     return HYPO_OK;
 }
 
@@ -184,8 +222,10 @@ int hypo_gpu_solid_scan_device(const uint8_t* packed4, uint64_t n_bases, uint32_
     if (!workspace || workspace_bytes < hypo::scan_workspace_bytes(n_bases))
         return fail(HYPO_E_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, hypo::scan_workspace_bytes(n_bases));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_ctx.stream;
+    ProfCall* pc = prof_next(2);
+    if (pc) pc->ke.n = 4;
     HIP_TRY(hypo::scan_run(packed4, n_bases, k, bits, solid_pos_words, kids, kids_cap, word_rank, n_solid,
-                           workspace, workspace_bytes, st));
+                           workspace, workspace_bytes, st, pc ? pc->ke.ev : nullptr));
     return HYPO_OK;
 }
 

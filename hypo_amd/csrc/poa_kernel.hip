@@ -51,6 +51,7 @@ __global__ void poa_plan_kernel(PoaParams P, PoaQueues Q, uint32_t n_windows) {
             (uint64_t)(est_nodes + 1) * S <= (uint64_t)lim[c].hcells) { cls = c; break; }
     }
     if (W.type != HYPO_WIN_SHORT && cls < kFirstLongClass) cls = kFirstLongClass;
+    if (W.n_empty > narm || narm < 2) atomicAdd((unsigned long long*)&Q.stats->n_trivial, 1ull);
     const uint32_t slot = atomicAdd(&Q.count[cls], 1u);
     Q.items[(size_t)cls * Q.stride + slot] = w;
 }
@@ -69,7 +70,7 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaParams P, PoaQueues Q,
     char* mem = USE_LDS ? smem + (size_t)grp * PoaLayout<Cfg>::BYTES
                         : scratch + ((size_t)blockIdx.x * GPW + grp) * PoaLayout<Cfg>::BYTES;
     const uint32_t count = Q.count[cls];
-    uint64_t cells = 0, aligns = 0;
+    uint64_t cells = 0, aligns = 0, abytes = 0;
     uint32_t n_ok = 0, n_esc = 0, n_fail = 0;
     for (;;) {
         uint32_t idx = 0;
@@ -82,6 +83,13 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaParams P, PoaQueues Q,
         cells += poa.cells; aligns += poa.aligns;
         if (rc == RES_OK) {
             ++n_ok;
+            if (g.lane == 0) {                                  // algorithmic bytes, SURVEY.md 8(d)
+                const HypoWindow W = P.windows[w];
+                const uint32_t narm = W.n_internal + W.n_prefix + W.n_suffix;
+                uint64_t a = (W.draft_len + 1) / 2 + 16 + 8 * (1 + (uint64_t)narm) + P.out_len[w];
+                for (uint32_t t = 0; t < narm; ++t) a += (P.arm_len[W.first_arm + t] + 3) / 4;
+                abytes += a;
+            }
         } else if ((rc == RES_OVERFLOW || rc == RES_UNSUPPORTED) && cls + 1 < kNumPoaClasses) {
             if (g.lane == 0) {
                 const uint32_t slot = atomicAdd(&Q.count[cls + 1], 1u);
@@ -102,6 +110,7 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaParams P, PoaQueues Q,
         atomicAdd((unsigned long long*)&Q.stats->n_failed, (unsigned long long)n_fail);
         atomicAdd((unsigned long long*)&Q.stats->dp_cells, (unsigned long long)cells);
         atomicAdd((unsigned long long*)&Q.stats->n_alignments, (unsigned long long)aligns);
+        atomicAdd((unsigned long long*)&Q.stats->alg_bytes[cls], (unsigned long long)abytes);
     }
 }
 
@@ -145,7 +154,7 @@ size_t poa_workspace_bytes(uint32_t n_windows) {
 }
 
 hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size_t workspace_bytes,
-                   int num_cus, hipStream_t stream) {
+                   int num_cus, hipStream_t stream, KernelEvents* prof) {
     if (n_windows == 0) return hipSuccess;
     if (workspace_bytes < poa_workspace_bytes(n_windows)) return hipErrorInvalidValue;
     char* ws = (char*)workspace;
@@ -160,16 +169,21 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
     char* scratch = ws + off;
     hipError_t e = hipMemsetAsync(ws, 0, kPoaHeaderBytes, stream);
     if (e != hipSuccess) return e;
+    int pe = 0;
+    if (prof) (void)hipEventRecord(prof->ev[pe++], stream);
     hipLaunchKernelGGL(poa_plan_kernel, dim3((n_windows + 255) / 256), dim3(256), 0, stream, P, Q, n_windows);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (prof) (void)hipEventRecord(prof->ev[pe++], stream);
     // Every class is launched with a grid sized for the whole batch: how many windows a class
     // receives is only known on the device (plan + escalations), and an idle persistent wave exits
     // after one failed dequeue.
 #define HYPO_LAUNCH(ID, CFG)                                                                              \
     if ((e = launch_class<CFG, (ID < kFirstGlobalClass)>(P, Q, ID, n_windows, scratch, num_cus,          \
-                                                         kMaxGlobalGroups, stream)) != hipSuccess) return e;
+                                                         kMaxGlobalGroups, stream)) != hipSuccess) return e; \
+    if (prof) (void)hipEventRecord(prof->ev[pe++], stream);
     HYPO_FOR_EACH_CLASS(HYPO_LAUNCH)
 #undef HYPO_LAUNCH
+    if (prof) prof->n = pe;
     return hipSuccess;
 }
 

@@ -18,8 +18,11 @@ struct PoaQueues {
     uint32_t stride;
 };
 
+// optional event recorder: ev[0] before plan, ev[1] after plan, ev[2 + c] after class c
+struct KernelEvents { hipEvent_t ev[8]; int n; };
+
 size_t poa_workspace_bytes(uint32_t n_windows);
 hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size_t workspace_bytes,
-                   int num_cus, hipStream_t stream);
+                   int num_cus, hipStream_t stream, KernelEvents* prof);
 
 }  // namespace hypo

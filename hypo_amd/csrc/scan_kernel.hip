@@ -186,7 +186,8 @@ size_t scan_workspace_bytes(uint64_t n_bases) {
 
 hipError_t scan_run(const uint8_t* packed4, uint64_t n_bases, uint32_t k, const uint64_t* bits,
                     uint64_t* words, uint64_t* kids, uint64_t kids_cap, uint64_t* word_rank,
-                    uint64_t* n_solid, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                    uint64_t* n_solid, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                    hipEvent_t* prof_ev) {
     if (workspace_bytes < scan_workspace_bytes(n_bases)) return hipErrorInvalidValue;
     const uint64_t n_words = (n_bases + 63) / 64;
     char* ws = (char*)workspace;
@@ -204,14 +205,18 @@ hipError_t scan_run(const uint8_t* packed4, uint64_t n_bases, uint32_t k, const 
         return hipSuccess;
     }
     const unsigned mark_blocks = (unsigned)((n_words + SCAN_THREADS - 1) / SCAN_THREADS);
+    if (prof_ev) (void)hipEventRecord(prof_ev[0], stream);
     hipLaunchKernelGGL(scan_mark_kernel, dim3(mark_blocks), dim3(SCAN_THREADS), 0, stream,
                        packed4, n_bases, k, bits, words, wcount, n_words);
+    if (prof_ev) (void)hipEventRecord(prof_ev[1], stream);
     hipLaunchKernelGGL(scan_rank_partial, dim3((unsigned)n_rblocks), dim3(RANK_THREADS), 0, stream, wcount, n_words, bsum);
     hipLaunchKernelGGL(scan_rank_blocksums, dim3(1), dim3(1024), 0, stream, bsum, n_rblocks, total);
     hipLaunchKernelGGL(scan_rank_final, dim3((unsigned)n_rblocks), dim3(RANK_THREADS), 0, stream, wcount, n_words, bsum, word_rank, total);
+    if (prof_ev) (void)hipEventRecord(prof_ev[2], stream);
     if (kids && kids_cap)
         hipLaunchKernelGGL(scan_kids_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, stream,
                            packed4, k, words, word_rank, n_words, kids, kids_cap);
+    if (prof_ev) (void)hipEventRecord(prof_ev[3], stream);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (n_solid) return hipMemcpyAsync(n_solid, total, 8, hipMemcpyDeviceToDevice, stream);
     return hipSuccess;

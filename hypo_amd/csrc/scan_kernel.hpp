@@ -8,5 +8,6 @@ size_t scan_workspace_bytes(uint64_t n_bases);
 // All pointers are device pointers; n_solid (optional) receives the number of marked positions.
 hipError_t scan_run(const uint8_t* packed4, uint64_t n_bases, uint32_t k, const uint64_t* bits,
                     uint64_t* words, uint64_t* kids, uint64_t kids_cap, uint64_t* word_rank,
-                    uint64_t* n_solid, void* workspace, size_t workspace_bytes, hipStream_t stream);
+                    uint64_t* n_solid, void* workspace, size_t workspace_bytes, hipStream_t stream,
+                    hipEvent_t* prof_ev /* 4 events or NULL */);
 }  // namespace hypo

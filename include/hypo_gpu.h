@@ -168,10 +168,25 @@ typedef struct HypoPoaStats {
     uint64_t n_failed;         /* status != OK */
     uint64_t dp_cells;         /* sum over alignments of (nodes+1)*(len+1), sisd..cpp:266-267 */
     uint64_t n_alignments;
+    uint64_t alg_bytes[4];     /* algorithmic HBM bytes of the windows finished in class 0..3:
+                                  ceil(Ld/2) + sum ceil(La/4) + Lcons + 16 + 8*(1+n_arms)   */
 } HypoPoaStats;
 int hypo_gpu_poa_last_stats(HypoPoaStats* out);
 /* Same for a _device call: synchronises the stream and copies the counters out of `workspace`. */
 int hypo_gpu_poa_read_stats(const void* workspace, void* hip_stream, HypoPoaStats* out);
+
+/* Kernel timing with HIP events on the stream the kernels run on ----------------------------------
+ * hypo_gpu_profile_begin(max_calls) arms the next max_calls (<= 256) *_device calls: each records
+ * events around its kernels.  hypo_gpu_profile_read(call, ms, n) synchronises that call's last event
+ * and returns up to n elapsed times in milliseconds:
+ *   POA call : ms[0] = plan kernel, ms[1 + c] = size-class kernel c (HYPO_PROFILE_POA_SLOTS values)
+ *   scan call: ms[0] = mark, ms[1] = rank (3 kernels), ms[2] = kids (HYPO_PROFILE_SCAN_SLOTS values)
+ * Returns the number of values written, or <0. */
+#define HYPO_PROFILE_POA_SLOTS 5
+#define HYPO_PROFILE_SCAN_SLOTS 3
+int hypo_gpu_profile_begin(int max_calls);
+int hypo_gpu_profile_calls(void);
+int hypo_gpu_profile_read(int call, float* ms, int n);
 
 #ifdef __cplusplus
 }
