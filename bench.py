@@ -136,7 +136,7 @@ def main():
             raise SystemExit("bench: HIP results differ from the oracle — refusing to report a number")
 
     # ---- roofline of the dominant kernel (HIP events on the kernels' stream) -----------------------------
-    poa_calls = [p for p in prof if len(p) == 4]             # plan + 3 size-class kernels
+    poa_calls = [p for p in prof if len(p) >= 4]             # plan + one entry per size-class kernel
     scan_calls = [p for p in prof if len(p) == 3]
     roofline = None
     extra = {}

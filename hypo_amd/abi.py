@@ -5,7 +5,7 @@ Reference types mirrored: ScoreParams (include/globalDefs.hpp:58-66), hypo::Wind
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 HYPO_OK = 0
 HYPO_E_INVALID = -1
@@ -54,9 +54,9 @@ class ConsensusBatch(C.Structure):
 
 
 class PoaStats(C.Structure):
-    _fields_ = [("n_windows", C.c_uint64), ("n_trivial", C.c_uint64), ("n_class", C.c_uint64 * 4),
+    _fields_ = [("n_windows", C.c_uint64), ("n_trivial", C.c_uint64), ("n_class", C.c_uint64 * 8),
                 ("n_escalated", C.c_uint64), ("n_failed", C.c_uint64), ("dp_cells", C.c_uint64),
-                ("n_alignments", C.c_uint64), ("alg_bytes", C.c_uint64 * 4)]
+                ("n_alignments", C.c_uint64), ("alg_bytes", C.c_uint64 * 8)]
 
 
 # numpy dtype equivalent of HypoWindow (40 bytes, same offsets)

@@ -129,9 +129,9 @@ class HypoGpu:
     def profile_read(self):
         """List of per-call lists of elapsed milliseconds (see include/hypo_gpu.h)."""
         out = []
-        buf = (C.c_float * 8)()
+        buf = (C.c_float * 16)()
         for c in range(int(self.lib.hypo_gpu_profile_calls())):
-            n = int(self.lib.hypo_gpu_profile_read(C.c_int(c), buf, C.c_int(8)))
+            n = int(self.lib.hypo_gpu_profile_read(C.c_int(c), buf, C.c_int(16)))
             if n < 0:
                 self._check(n)
             out.append([float(buf[i]) for i in range(n)])

@@ -86,24 +86,34 @@ HD int ctz64(uint64_t x) { return __builtin_ctzll(x); }
 
 #else
 // ---- device back end (gfx950, wave64) ------------------------------------------------------------
+// Cross-lane traffic uses DPP (row_shr / row_bcast / wave_shr: register-to-register, a few cycles) and
+// v_readlane for group-uniform indices; ds_bpermute (LDS pipe, ~100 cycles) only for per-lane indices.
+template <int CTRL, int ROW_MASK = 0xf>
+HD int dpp_mov(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false); }
+
 template <int GW>
 struct Grp {
     int lane;                                   // lane inside the group
     HD int wlane() const { return (int)(threadIdx.x & 63); }
     HD int gbase() const { return wlane() & ~(GW - 1); }
     // LDS traffic of one wave is processed in order; this only stops the compiler from moving
-    // memory operations across the rendezvous.
+    // memory operations across the rendezvous (wavefront-scope fences emit no instructions).
     HD void sync() const {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    // src must be group-uniform
     template <class T> HD T shfl(T v, int src) const {
+        if (GW == 64) return (T)__builtin_amdgcn_readlane((int)v, src);
         return (T)__shfl((int)v, src, GW);
     }
     template <class T> HD T shfl_up1(T v, T fill) const {
-        int r = __shfl_up((int)v, 1, GW);
-        return lane ? (T)r : fill;
+        int r;
+        if (GW == 16) r = dpp_mov<0x111>((int)fill, (int)v);             // row_shr:1
+        else r = dpp_mov<0x138>((int)fill, (int)v);                      // wave_shr:1
+        if (GW == 32) r = lane ? r : (int)fill;
+        return (T)r;
     }
     HD uint64_t ballot(bool p) const {
         uint64_t m = __ballot(p);
@@ -121,15 +131,16 @@ struct Grp {
         for (int d = GW / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, GW);
         return v;
     }
+    // exclusive prefix max over the group's lanes (lane 0 gets `ident`); ident must be <= every v
     HD int scan_max_excl(int v, int ident) const {
-        // inclusive Hillis-Steele over GW lanes, then shift by one lane
-        HYPO_UNROLL
-        for (int d = 1; d < GW; d <<= 1) {
-            int o = __shfl_up(v, d, GW);
-            if (lane >= d) v = o > v ? o : v;
-        }
-        int e = __shfl_up(v, 1, GW);
-        return lane ? e : ident;
+        int x = v, t;
+        t = dpp_mov<0x111>(ident, x); x = t > x ? t : x;                 // row_shr:1
+        t = dpp_mov<0x112>(ident, x); x = t > x ? t : x;                 // row_shr:2
+        t = dpp_mov<0x114>(ident, x); x = t > x ? t : x;                 // row_shr:4
+        t = dpp_mov<0x118>(ident, x); x = t > x ? t : x;                 // row_shr:8
+        if (GW >= 32) { t = dpp_mov<0x142, 0xa>(ident, x); x = t > x ? t : x; }   // row_bcast:15 -> rows 1,3
+        if (GW == 64) { t = dpp_mov<0x143, 0xc>(ident, x); x = t > x ? t : x; }   // row_bcast:31 -> rows 2,3
+        return shfl_up1(x, ident);
     }
     // hint: value is identical in every lane of the WAVE (only true for GW == 64)
     HD int uniform(int v) const { return GW == 64 ? __builtin_amdgcn_readfirstlane(v) : v; }

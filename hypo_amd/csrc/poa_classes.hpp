@@ -1,21 +1,26 @@
 // poa_classes.hpp — size classes of the POA kernel (one template instantiation + launch each).
 //
-//   class  lanes  cols/lane  max seq  max nodes  in-edges  matrix cells  scores  ids   memory
-//   0      64     2          127      126        4         4096          int16   u8    LDS ~ 13.6 KB / window
-//   1      64     2          127      254        8         16384         int16   u8    LDS ~ 45 KB / window
-//   2      64     8          511      4000       16        1048576       int16   u16   global scratch ~ 2.6 MB / resident group
-// A window that does not fit class c (too many nodes / in-edges / cells, sequence too long, or scores
-// whose magnitude could overflow int16) is re-queued to class c+1 by the kernel itself.
-// int16 is exact iff max(|m|,|n|,|g|) * (nodes + len + 1) < 32767 (same guard as spoa's SIMD path,
-// external/spoa/src/simd_alignment_engine.cpp:660-665); poa_kernel.hip checks it per class.
+//   class lanes cols/lane max seq  nodes in-edges dir cells (bits) ring cells staged arm B  seqs  scores ids  memory / window
+//   0     64    2         47       48    4        2208 (4)        512        384           48    int16  u8   LDS  ~4.6 KB
+//   1     64    2         79       84    4        6720 (4)        1280       768           64    int16  u8   LDS  ~9.6 KB
+//   2     64    2         127      126   6        13440 (4)       2240       1536          96    int16  u8   LDS  ~18 KB
+//   3     64    2         127      254   8        32768 (8)       4096       4096          254   int16  u8   LDS  ~59 KB
+//   4     64    8         511      4000  16       2097152 (8)     65536      16384         1024  int32  u16  HBM scratch ~2.7 MB / resident group
+// A window that does not fit class c (too many nodes / in-edges / cells, a predecessor row that already left
+// the ring, sequence too long, or scores whose magnitude could overflow int16) is re-queued to class c+1 by
+// the kernel itself.  int16 is exact iff max(|m|,|n|,|g|) * (nodes + len + 1) < 32767 (the guard spoa's SIMD
+// path uses, external/spoa/src/simd_alignment_engine.cpp:660-665); Poa::align checks it before every alignment.
 #pragma once
 #include "poa_core.hpp"
 
 namespace hypo {
-typedef PoaCfg<64, 2, 126, 4, 4096, int16_t, uint8_t> PoaClass0;
-typedef PoaCfg<64, 2, 254, 8, 16384, int16_t, uint8_t> PoaClass1;
-typedef PoaCfg<64, 8, 4000, 16, 1 << 20, int16_t, uint16_t> PoaClass2;
-constexpr int kNumPoaClasses = 3;
+//              GW CPL LCAP NMAX KIN DIRCELLS RINGCELLS ARMBYTES SEQMAX
+typedef PoaCfg<64, 2, 47, 48, 4, 2208, 512, 384, 48, int16_t, uint8_t> PoaClass0;
+typedef PoaCfg<64, 2, 79, 84, 4, 6720, 1280, 768, 64, int16_t, uint8_t> PoaClass1;
+typedef PoaCfg<64, 2, 127, 126, 6, 13440, 2240, 1536, 96, int16_t, uint8_t> PoaClass2;
+typedef PoaCfg<64, 2, 127, 254, 8, 32768, 4096, 4096, 254, int16_t, uint8_t> PoaClass3;
+typedef PoaCfg<64, 8, 511, 4000, 16, 1 << 21, 1 << 16, 16384, 1024, int32_t, uint16_t> PoaClass4;
+constexpr int kNumPoaClasses = 5;
 }  // namespace hypo
 
-#define HYPO_FOR_EACH_CLASS(X) X(0, PoaClass0) X(1, PoaClass1) X(2, PoaClass2)
+#define HYPO_FOR_EACH_CLASS(X) X(0, PoaClass0) X(1, PoaClass1) X(2, PoaClass2) X(3, PoaClass3) X(4, PoaClass4)

@@ -5,13 +5,20 @@
 //   ---------------------------------------------------   ------------------------------------------
 //   Window::generate_consensus      src/Window.cpp:44-61   Poa::run (dispatch rules)
 //   generate_consensus_short        src/Window.cpp:87-154  Poa::run_short (sequence order, markers)
-//   SisdAlignmentEngine::linear     sisd..cpp:263-439      Poa::align: rows in rank order, the CPL
-//                                                          columns of a lane in registers, vertical and
-//                                                          diagonal terms from predecessor rows in LDS,
-//                                                          horizontal term = max-plus prefix scan over
-//                                                          lanes (exact: integer max/+ is associative)
-//   traceback                       sisd..cpp:344-438      lanes test the predecessors of a cell in
-//                                                          parallel, ballot picks the reference's first hit
+//   SisdAlignmentEngine::linear     sisd..cpp:263-342      Poa::align, DP part: rows in rank order, the CPL
+//                                                          columns of a lane in registers; vertical/diagonal
+//                                                          terms from predecessor rows kept in a small LDS
+//                                                          ring (only rows a later row can still reference);
+//                                                          horizontal term = max-plus prefix scan over lanes
+//                                                          with DPP (exact: integer max/+ is associative)
+//   traceback                       sisd..cpp:344-438      the reference re-derives each move from H with a
+//                                                          fixed preference order (diagonal pred 0,1.. ->
+//                                                          vertical pred 0,1.. -> horizontal).  Here each lane
+//                                                          resolves that preference for its cells while the
+//                                                          row is still in registers and stores ONE direction
+//                                                          code per cell (4 or 8 bits); the traceback walks the
+//                                                          codes, and runs of "diagonal to the previous row"
+//                                                          are consumed GW cells at a time with one ballot.
 //   Graph::add_alignment            graph.cpp:154-271      lanes own sequence positions (every graph node
 //                                                          and aligned clique occurs at most once on a
 //                                                          path, so the updates are independent)
@@ -20,9 +27,10 @@
 //                                                          an alignment added no node and no edge
 //   traverse_heaviest_bundle        graph.cpp:610-705      lane 0 (once per window)
 //
-// All per-window state (score matrix, graph, order, stack) lives in the group's memory slice `mem`
-// (LDS for the in-LDS size classes).  Compiled by hipcc for gfx950 and, with HYPO_EMU, by g++ for the
-// lockstep emulator used in tests/.
+// All per-window state lives in the group's memory slice `mem` (LDS for the in-LDS size classes): the
+// full score matrix is never materialised — per window the slice holds (nodes x len) direction codes,
+// a ring of score rows, the graph, and the window's packed arms staged once from HBM.
+// Compiled by hipcc for gfx950 and, with HYPO_EMU, by g++ for the lockstep emulator used in tests/.
 #pragma once
 #include "grp.hpp"
 #include "../../include/hypo_gpu.h"
@@ -31,6 +39,16 @@ namespace hypo {
 
 enum { MODE_NW = 1, MODE_LOV = 3, MODE_ROV = 4 };
 enum { C_A = 0, C_C = 1, C_G = 2, C_T = 3, C_N = 4, C_J = 5, C_O = 6, C_NONE = 7 };
+// Optional per-phase cycle accounting (diagnostic build only: make -C hypo_amd/csrc prof).
+enum { PH_LOAD = 0, PH_DP = 1, PH_TRACE = 2, PH_ADD = 3, PH_TOPO = 4, PH_CONS = 5, PH_OUT = 6, PH_META = 7, PH_N = 8 };
+#if defined(HYPO_PHASE_TIMERS) && !defined(HYPO_EMU)
+#define HYPO_TICK(k) do { const uint64_t t1_ = (uint64_t)clock64(); tphase[k] += t1_ - tlast; tlast = t1_; } while (0)
+#define HYPO_TICK_RESET() do { tlast = (uint64_t)clock64(); } while (0)
+#else
+#define HYPO_TICK(k) do { } while (0)
+#define HYPO_TICK_RESET() do { } while (0)
+#endif
+
 enum { RES_OK = 0, RES_OVERFLOW = 1, RES_UNDEFINED = 2, RES_CONS_OVERFLOW = 3, RES_UNSUPPORTED = 4 };
 
 struct PoaParams {
@@ -46,50 +64,61 @@ struct PoaParams {
     int sr_m, sr_n, sr_g, lr_m, lr_n, lr_g;
 };
 
-struct PoaCounters { uint64_t cells, aligns; };
-
-template <int GW_, int CPL_, int NMAX_, int KIN_, int HCELLS_, class ScoreT, class IdT>
+template <int GW_, int CPL_, int LCAP_, int NMAX_, int KIN_, int DIRCELLS_, int RINGCELLS_, int ARMBYTES_,
+          int SEQMAX_, class ScoreT, class IdT>
 struct PoaCfg {
-    static constexpr int GW = GW_;          // lanes per window
-    static constexpr int CPL = CPL_;        // matrix columns per lane
-    static constexpr int NMAX = NMAX_;      // graph nodes
-    static constexpr int KIN = KIN_;        // in-edges per node
-    static constexpr int HCELLS = HCELLS_;  // score-matrix capacity (cells)
-    static constexpr int LMAX = GW_ * CPL_ - 1;   // longest sequence incl. markers
-    static constexpr int AL = 6;            // aligned clique partners (alphabet ACGTNJO -> at most 6)
-    static constexpr int STK = 2 * NMAX_;   // DFS stack
+    static constexpr int GW = GW_;              // lanes per window
+    static constexpr int CPL = CPL_;            // matrix columns per lane
+    static constexpr int LMAX = LCAP_;          // longest sequence incl. markers
+    static constexpr int NMAX = NMAX_;          // graph nodes
+    static constexpr int KIN = KIN_;            // in-edges per node
+    static constexpr int DIRCELLS = DIRCELLS_;  // direction codes (nodes x row stride)
+    static constexpr int RINGCELLS = RINGCELLS_;// score cells of the row ring
+    static constexpr int ARMBYTES = ARMBYTES_;  // packed arm bytes staged per window
+    static constexpr int SEQMAX = SEQMAX_;      // sequences (arms + backbone) per window
+    static constexpr int AL = 6;                // aligned clique partners (alphabet ACGTNJO -> at most 6)
+    static constexpr int STK = 2 * NMAX_;       // DFS stack
+    // direction codes: 4 bits when the pred index fits (diag p = p, vert p = 7+p, horiz = 14, fast = 15)
+    static constexpr bool NIB = (KIN_ <= 7) && (CPL_ % 2 == 0);
+    static constexpr int DIRBYTES = NIB ? DIRCELLS_ / 2 : DIRCELLS_;
     typedef ScoreT score_t;
     typedef IdT id_t;
     static constexpr int ID_NONE = (IdT)~(IdT)0;
+    static_assert(LCAP_ <= GW_ * CPL_ - 1, "columns 0..L must fit the group");
+    static_assert(LCAP_ <= 511 && ARMBYTES_ <= 65535 && SEQMAX_ <= 65535, "sequence table entry is 32 bits");
     static_assert(KIN_ + 6 <= GW_, "dependency lanes");
-    static_assert((int)sizeof(ScoreT) * HCELLS_ >= 8 * NMAX_, "consensus scratch aliases the matrix");
+    static_assert(KIN_ <= 62, "direction byte holds the pred index in 6 bits");
+    static_assert((int)sizeof(ScoreT) * RINGCELLS_ + DIRBYTES >= 8 * NMAX_, "consensus scratch aliases ring+dir");
     static_assert(NMAX_ < ID_NONE, "id range");
+    static_assert(SEQMAX_ <= 2 * NMAX_ && SEQMAX_ <= ID_NONE, "arm indices are parked in the DFS stack while staging");
 };
 
-template <int N> HD constexpr int align16(int x) { return (x + N - 1) / N * N; }
+template <int N> HD constexpr int align_up(int x) { return (x + N - 1) / N * N; }
 
 template <class Cfg>
 struct PoaLayout {   // byte offsets inside a group's memory slice
     typedef typename Cfg::score_t score_t;
     typedef typename Cfg::id_t id_t;
-    static constexpr int oH = 0;
-    static constexpr int oRowmeta = oH + align16<16>(Cfg::HCELLS * (int)sizeof(score_t));
-    static constexpr int oInw = oRowmeta + align16<16>(Cfg::NMAX * 4);
-    static constexpr int oPosnode = oInw + align16<16>(Cfg::NMAX * Cfg::KIN * 2);
-    static constexpr int oCur = oPosnode + align16<16>((Cfg::LMAX + 1) * 2);
-    static constexpr int oProw = oCur + align16<16>((Cfg::LMAX + 1) * 2);
-    static constexpr int oInp = oProw + align16<16>(Cfg::NMAX * Cfg::KIN * (int)sizeof(id_t));
-    static constexpr int oAl = oInp + align16<16>(Cfg::NMAX * Cfg::KIN * (int)sizeof(id_t));
-    static constexpr int oR2n = oAl + align16<16>(Cfg::NMAX * Cfg::AL * (int)sizeof(id_t));
-    static constexpr int oN2r = oR2n + align16<16>(Cfg::NMAX * (int)sizeof(id_t));
-    static constexpr int oStack = oN2r + align16<16>(Cfg::NMAX * (int)sizeof(id_t));
-    static constexpr int oCode = oStack + align16<16>(Cfg::STK * (int)sizeof(id_t));
-    static constexpr int oNin = oCode + align16<16>(Cfg::NMAX);
-    static constexpr int oNout = oNin + align16<16>(Cfg::NMAX);
-    static constexpr int oNal = oNout + align16<16>(Cfg::NMAX);
-    static constexpr int oMark = oNal + align16<16>(Cfg::NMAX);
-    static constexpr int oSeq = oMark + align16<16>(Cfg::NMAX);
-    static constexpr int BYTES = oSeq + align16<16>(Cfg::LMAX + 1);
+    static constexpr int oRing = 0;                                                     // ring, then dir: contiguous
+    static constexpr int oDir = oRing + align_up<16>(Cfg::RINGCELLS * (int)sizeof(score_t));   // (consensus scratch aliases both)
+    static constexpr int oRowmeta = oDir + align_up<16>(Cfg::DIRBYTES);
+    static constexpr int oSeqtab = oRowmeta + align_up<16>(Cfg::NMAX * 4);
+    static constexpr int oInw = oSeqtab + align_up<16>(Cfg::SEQMAX * 4);
+    static constexpr int oPosnode = oInw + align_up<16>(Cfg::NMAX * Cfg::KIN * 2);
+    static constexpr int oProw = oPosnode + align_up<16>((Cfg::LMAX + 1) * 2);
+    static constexpr int oInp = oProw + align_up<16>(Cfg::NMAX * Cfg::KIN * (int)sizeof(id_t));
+    static constexpr int oAl = oInp + align_up<16>(Cfg::NMAX * Cfg::KIN * (int)sizeof(id_t));
+    static constexpr int oR2n = oAl + align_up<16>(Cfg::NMAX * Cfg::AL * (int)sizeof(id_t));
+    static constexpr int oN2r = oR2n + align_up<16>(Cfg::NMAX * (int)sizeof(id_t));
+    static constexpr int oStack = oN2r + align_up<16>(Cfg::NMAX * (int)sizeof(id_t));
+    static constexpr int oCode = oStack + align_up<16>(Cfg::STK * (int)sizeof(id_t));
+    static constexpr int oNin = oCode + align_up<16>(Cfg::NMAX);
+    static constexpr int oNout = oNin + align_up<16>(Cfg::NMAX);
+    static constexpr int oNal = oNout + align_up<16>(Cfg::NMAX);
+    static constexpr int oMark = oNal + align_up<16>(Cfg::NMAX);
+    static constexpr int oSeq = oMark + align_up<16>(Cfg::NMAX);
+    static constexpr int oArms = oSeq + align_up<16>(Cfg::LMAX + 1);
+    static constexpr int BYTES = oArms + align_up<16>(Cfg::ARMBYTES);
 };
 
 template <class Cfg>
@@ -98,77 +127,178 @@ struct Poa {
     typedef typename Cfg::id_t id_t;
     typedef PoaLayout<Cfg> Lay;
     static constexpr int GW = Cfg::GW, CPL = Cfg::CPL, KIN = Cfg::KIN, NMAX = Cfg::NMAX, AL = Cfg::AL;
+    static constexpr bool NIB = Cfg::NIB;
     static constexpr int NEG = -(1 << 29);
+    // direction codes
+    static constexpr int DIR_FAST = NIB ? 15 : 0xFF;     // diagonal via pred 0 and pred 0 is the previous row
+    static constexpr int DIR_HORIZ = NIB ? 14 : 0xFE;
+    HD static int dir_diag(int p) { return NIB ? p : (p << 1); }
+    HD static int dir_vert(int p) { return NIB ? 7 + p : ((p << 1) | 1); }
+    HD static bool is_vert(int d) { return NIB ? d >= 7 : (d & 1); }
+    HD static int dir_pred(int d) { return NIB ? (d >= 7 ? d - 7 : d) : (d >> 1); }
 
     struct alignas(sizeof(score_t) * CPL) Pack { score_t v[CPL]; };
+    struct alignas(NIB ? CPL / 2 : CPL) DPack { uint8_t v[NIB ? CPL / 2 : CPL]; };
+    // sequence table entry: bits 0-15 src (LDS offset of the staged bytes, or arm index), 16-24 length,
+    // 25 head marker J, 26 tail marker O, 27-28 mode (0 NW, 1 LOV, 2 ROV), 29 four-bit packing,
+    // 30-31 where (0 staged in LDS, 1 arms2 in HBM, 2 draft4 in HBM)
+    HD static uint32_t seq_ent(uint32_t src, uint32_t len, bool head, bool tail, int mode, bool four, int where) {
+        const uint32_t mc = mode == MODE_NW ? 0u : (mode == MODE_LOV ? 1u : 2u);
+        return (src & 0xffffu) | (len << 16) | ((head ? 1u : 0u) << 25) | ((tail ? 1u : 0u) << 26) | (mc << 27) |
+               ((four ? 1u : 0u) << 29) | ((uint32_t)where << 30);
+    }
 
     const Grp<GW>& g;
     const PoaParams& P;
     // memory slice
-    score_t* H; uint32_t* rowmeta; uint16_t* inw; int16_t* posnode; int16_t* cur;
+    score_t* ring; uint8_t* dir; uint32_t* rowmeta; uint32_t* seqtab; uint16_t* inw; int16_t* posnode;
     id_t *prow, *inp, *al, *r2n, *n2r, *stack;
-    uint8_t *code, *nin, *nout, *nal, *mark, *seq;
+    uint8_t *code, *nin, *nout, *nal, *mark, *seq, *armbuf;
     // group-uniform state
-    int n_nodes; int L; bool topo_dirty; bool meta_dirty;
+    int n_nodes; int L; bool topo_dirty; bool meta_dirty; int maxdelta;
     int tb_steps; int tb_fv;
     uint64_t cells, aligns;
+    uint64_t tphase[PH_N]; uint64_t tlast;
 
     HD Poa(const Grp<GW>& g_, const PoaParams& P_, char* mem) : g(g_), P(P_) {
-        H = (score_t*)(mem + Lay::oH); rowmeta = (uint32_t*)(mem + Lay::oRowmeta);
+        ring = (score_t*)(mem + Lay::oRing); dir = (uint8_t*)(mem + Lay::oDir);
+        rowmeta = (uint32_t*)(mem + Lay::oRowmeta); seqtab = (uint32_t*)(mem + Lay::oSeqtab);
         inw = (uint16_t*)(mem + Lay::oInw); posnode = (int16_t*)(mem + Lay::oPosnode);
-        cur = (int16_t*)(mem + Lay::oCur); prow = (id_t*)(mem + Lay::oProw);
+        prow = (id_t*)(mem + Lay::oProw);
         inp = (id_t*)(mem + Lay::oInp); al = (id_t*)(mem + Lay::oAl);
         r2n = (id_t*)(mem + Lay::oR2n); n2r = (id_t*)(mem + Lay::oN2r);
         stack = (id_t*)(mem + Lay::oStack); code = (uint8_t*)(mem + Lay::oCode);
         nin = (uint8_t*)(mem + Lay::oNin); nout = (uint8_t*)(mem + Lay::oNout);
         nal = (uint8_t*)(mem + Lay::oNal); mark = (uint8_t*)(mem + Lay::oMark);
-        seq = (uint8_t*)(mem + Lay::oSeq);
-        n_nodes = 0; L = 0; topo_dirty = false; meta_dirty = true; tb_steps = 0; tb_fv = 0;
+        seq = (uint8_t*)(mem + Lay::oSeq); armbuf = (uint8_t*)(mem + Lay::oArms);
+        n_nodes = 0; L = 0; topo_dirty = false; meta_dirty = true; maxdelta = 0; tb_steps = 0; tb_fv = 0;
         cells = 0; aligns = 0;
+        for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
+        tlast = 0;
+        HYPO_TICK_RESET();
     }
 
-    // ---- sequence staging (PackedSeq<2>/<4> bytes -> codes in `seq`, markers J/O added) -----------
-    HD int load_seq(const uint8_t* p, int len, bool four_bit, bool head, bool tail) {
+    // ---- sequence table: the window's sequences in the reference's consumption order -----------------
+    // (Window.cpp:87-130: [draft if no internal arm] internal.. | prefix arms reversed | suffix arms;
+    // zero-length arms are skipped).  Packed arm bytes are staged once into `armbuf` (one exposed HBM
+    // latency per window instead of one per arm); what does not fit is read in place.
+    HD int build_seqtab(const HypoWindow& W, int* n_seq_out, bool* added_out) {
+        const uint32_t a0 = W.first_arm;
+        const int ni = (int)W.n_internal, np = (int)W.n_prefix, ns = (int)W.n_suffix;
+        const int narm = ni + np + ns;
+        const int base = ni == 0 ? 1 : 0;                  // slot 0 = draft backbone
+        if (narm + base > Cfg::SEQMAX) return RES_OVERFLOW;
+        if ((int)W.draft_len + 2 > Cfg::LMAX && base) return RES_OVERFLOW;
+        g.sync();
+        if (base && g.lane == 0) seqtab[0] = seq_ent(0, W.draft_len, true, true, MODE_NW, true, 2);
+        bool over = false, any_len = false;
+        for (int t = g.lane; t < narm; t += GW) {
+            int a, mode; bool head, tail;                  // consumption slot t -> arm index
+            if (t < ni) { a = t; mode = MODE_NW; head = true; tail = true; }
+            else if (t < ni + np) { a = ni + (np - 1 - (t - ni)); mode = MODE_LOV; head = true; tail = false; }
+            else { a = t; mode = MODE_ROV; head = false; tail = true; }
+            const uint32_t len = P.arm_len[a0 + a];
+            if (len + 2 > (uint32_t)Cfg::LMAX) { over = true; continue; }
+            if (len) any_len = true;
+            seqtab[base + t] = seq_ent((uint32_t)a, len, head, tail, mode, false, 1);
+        }
+        if (g.any(over)) return RES_OVERFLOW;
+        any_len = g.any(any_len);
+        g.sync();
+        if (g.lane == 0) {                                  // LDS offsets of the staged arms (serial prefix, <= SEQMAX small adds)
+            int used = 0;
+            for (int t = 0; t < narm; ++t) {
+                const uint32_t e = seqtab[base + t];
+                const int nb = (int)(((e >> 16) & 0x1ff) + 3) >> 2;
+                if (used + nb <= Cfg::ARMBYTES) {
+                    // keep the arm index in posnode-free scratch: staged entries remember it via `stack`
+                    stack[t] = (id_t)(e & 0xffff);
+                    seqtab[base + t] = (e & 0x3fff0000u) | (uint32_t)used;        // where = 0
+                    used += nb;
+                }
+            }
+        }
+        g.sync();
+        for (int t = g.lane; t < narm; t += GW) {           // one lane copies one arm: the loads of a lane pipeline
+            const uint32_t e = seqtab[base + t];
+            if ((e >> 30) == 0) {
+                const int nb = (int)(((e >> 16) & 0x1ff) + 3) >> 2;
+                const uint8_t* src = P.arms2 + P.arm_off[a0 + (uint32_t)stack[t]];
+                uint8_t* dst = armbuf + (e & 0xffff);
+                for (int b = 0; b < nb; ++b) dst[b] = src[b];
+            }
+        }
+        g.sync();
+        *n_seq_out = narm + base;
+        *added_out = any_len;
+        return RES_OK;
+    }
+
+    HD int load_seq(const HypoWindow& W, int s, int* mode_out) {
+        const uint32_t e = seqtab[s];
+        const bool head = (e >> 25) & 1, tail = (e >> 26) & 1, four = (e >> 29) & 1;
+        const int mc = (int)((e >> 27) & 3), where = (int)(e >> 30);
+        *mode_out = mc == 0 ? MODE_NW : (mc == 1 ? MODE_LOV : MODE_ROV);
+        const int len = (int)((e >> 16) & 0x1ff);
+        if (len == 0) { L = 0; return RES_OK; }
         L = len + (head ? 1 : 0) + (tail ? 1 : 0);
         if (L > Cfg::LMAX) return RES_OVERFLOW;
-        g.sync();
+        const uint8_t* p;
+        if (where == 0) p = armbuf + (e & 0xffff);
+        else if (where == 1) p = P.arms2 + P.arm_off[W.first_arm + (e & 0xffff)];
+        else p = P.draft4 + W.draft_off;
         for (int t = g.lane; t < L; t += GW) {
             int c;
             if (head && t == 0) c = C_J;
             else if (tail && t == L - 1) c = C_O;
             else {
-                int b = t - (head ? 1 : 0);
-                if (four_bit) { c = (p[b >> 1] >> (4 - 4 * (b & 1))) & 15; c = c < 4 ? c : C_N; }
+                const int b = t - (head ? 1 : 0);
+                if (four) { c = (p[b >> 1] >> (4 - 4 * (b & 1))) & 15; c = c < 4 ? c : C_N; }
                 else c = (p[b >> 2] >> (6 - 2 * (b & 3))) & 3;
             }
             seq[t] = (uint8_t)c;
         }
         g.sync();
+        HYPO_TICK(PH_LOAD);
         return RES_OK;
     }
 
     // ---- per-row metadata in rank order (rebuilt only when the graph topology changed) -----------
-    // rowmeta[r]: bits 0-7 code, 8-15 in-degree, 16 sink flag; prow[r*KIN+p] = matrix row of pred p.
+    // rowmeta[r]: bits 0-7 code, 8-15 in-degree, 16 sink flag, 17-31 matrix row of pred 0;
+    // prow[r*KIN+p] = matrix row of pred p; maxdelta = largest (row - pred row) over real preds.
     HD void build_rowmeta() {
+        int md = 0;
         for (int r = g.lane; r < n_nodes; r += GW) {
-            int u = r2n[r];
-            int k = nin[u];
-            for (int p = 0; p < k; ++p) prow[r * KIN + p] = (id_t)(n2r[inp[u * KIN + p]] + 1);
-            rowmeta[r] = (uint32_t)code[u] | ((uint32_t)k << 8) | ((nout[u] == 0 ? 1u : 0u) << 16);
+            const int u = r2n[r];
+            const int k = nin[u];
+            int p0 = 0;
+            for (int p = 0; p < k; ++p) {
+                const int pr = (int)n2r[inp[u * KIN + p]] + 1;
+                prow[r * KIN + p] = (id_t)pr;
+                if (p == 0) p0 = pr;
+                const int d = r + 1 - pr;
+                md = d > md ? d : md;
+            }
+            rowmeta[r] = (uint32_t)code[u] | ((uint32_t)k << 8) | ((nout[u] == 0 ? 1u : 0u) << 16) | ((uint32_t)p0 << 17);
         }
+        maxdelta = g.reduce_max(md);
         meta_dirty = false;
         g.sync();
     }
 
-    HD void load_row(int row, int S, int (&out)[CPL]) const {
+    HD void load_ring(int row, int S, int R, int (&out)[CPL]) const {   // row >= 1
         if (CPL * g.lane < S) {
-            Pack pk = *(const Pack*)(H + row * S + CPL * g.lane);
+            const Pack pk = *(const Pack*)(ring + ((row - 1) % R) * S + CPL * g.lane);
             HYPO_UNROLL
             for (int c = 0; c < CPL; ++c) out[c] = (int)pk.v[c];
         } else {
             HYPO_UNROLL
             for (int c = 0; c < CPL; ++c) out[c] = NEG;
         }
+    }
+    HD int read_dir(int cell) const {                      // cell = row_index * S + column
+        if (NIB) { const int b = dir[cell >> 1]; return (cell & 1) ? (b >> 4) : (b & 15); }
+        return dir[cell];
     }
 
     // ---- engine->align (sisd_alignment_engine.cpp:246-439), linear gaps -----------------------------
@@ -178,87 +308,112 @@ struct Poa {
         tb_steps = 0; tb_fv = L;
         if (n_nodes == 0 || L == 0) return RES_OK;
         const int W = L + 1;
-        const int S = (W + CPL - 1) / CPL * CPL;          // row stride
-        if ((n_nodes + 1) * S > Cfg::HCELLS) return RES_OVERFLOW;
-        if (meta_dirty) build_rowmeta();
+        const int S = (W + CPL - 1) / CPL * CPL;           // row stride (even when NIB)
+        if (n_nodes * S > Cfg::DIRCELLS) return RES_OVERFLOW;
+        if (sizeof(score_t) < 4) {                          // int16 rows are exact only below this bound
+            int a = m < 0 ? -m : m, b = n < 0 ? -n : n, c2 = gp < 0 ? -gp : gp;
+            a = a > b ? a : b; a = a > c2 ? a : c2;
+            if (a * (n_nodes + L + 1) >= 32767) return RES_OVERFLOW;
+        }
+        if (meta_dirty) { build_rowmeta(); HYPO_TICK(PH_META); }
+        const int R = Cfg::RINGCELLS / S;                   // ring rows; row i can still see rows i-R .. i-1
+        if (R < maxdelta + 1 || R < 1) return RES_OVERFLOW;
         cells += (uint64_t)(n_nodes + 1) * W; aligns += 1;
 
         const int j0 = CPL * g.lane;
-        int sq[CPL];                                       // sq[c] = code of seq[j-1] for column j = j0+c
+        int sq[CPL];                                        // sq[c] = code of seq[j-1] for column j = j0+c
         HYPO_UNROLL
-        for (int c = 0; c < CPL; ++c) { int j = j0 + c; sq[c] = (j >= 1 && j <= L) ? (int)seq[j - 1] : (int)C_NONE; }
+        for (int c = 0; c < CPL; ++c) { const int j = j0 + c; sq[c] = (j >= 1 && j <= L) ? (int)seq[j - 1] : (int)C_NONE; }
 
-        int last[CPL];                                     // most recently computed row (registers)
+        int last[CPL];                                      // most recently computed row (registers)
         HYPO_UNROLL
-        for (int c = 0; c < CPL; ++c) last[c] = (j0 + c) * gp;
-        if (j0 < S) {
-            Pack pk;
-            HYPO_UNROLL
-            for (int c = 0; c < CPL; ++c) pk.v[c] = (score_t)last[c];
-            *(Pack*)(H + j0) = pk;                          // row 0: H[0][j] = j*g (sisd..cpp:197-199,230-232)
-        }
-        g.sync();
+        for (int c = 0; c < CPL; ++c) last[c] = (j0 + c) * gp;   // row 0: H[0][j] = j*g (sisd..cpp:197-199,230-232)
 
-        const int le = L / CPL, ce = L % CPL;              // owner of the last column
+        const int le = L / CPL, ce = L % CPL;               // owner of the last column
         int best = NEG, best_i = -1;
 
+        uint32_t meta_a = rowmeta[0];                        // two-deep prefetch of the row metadata
+        uint32_t meta_b = n_nodes > 1 ? rowmeta[1] : 0u;
         for (int r = 0; r < n_nodes; ++r) {
             const int i = r + 1;
-            const uint32_t meta = rowmeta[r];
+            const uint32_t meta = meta_a;
+            meta_a = meta_b;
+            if (r + 2 < n_nodes) meta_b = rowmeta[r + 2];
             const int cd = (int)(meta & 0xff), k = (int)((meta >> 8) & 0xff);
             const bool sink = (meta >> 16) & 1;
-            int v[CPL];
-            // first predecessor (row 0 when the node has no in-edge)
+            const int p0 = (int)(meta >> 17);                // 0 when k == 0 (virtual source row)
+            int D[CPL], U[CPL], pD[CPL], pU[CPL];
             {
                 int hp[CPL];
-                const int p0 = k ? (int)prow[r * KIN] : 0;
                 if (p0 == i - 1) { HYPO_UNROLL for (int c = 0; c < CPL; ++c) hp[c] = last[c]; }
-                else load_row(p0, S, hp);
+                else if (p0 == 0) { HYPO_UNROLL for (int c = 0; c < CPL; ++c) hp[c] = (j0 + c) * gp; }
+                else load_ring(p0, S, R, hp);
                 const int left = g.shfl_up1(hp[CPL - 1], NEG);
                 HYPO_UNROLL
                 for (int c = 0; c < CPL; ++c) {
                     const int dsrc = c ? hp[c - 1] : left;
-                    const int d = dsrc + (sq[c] == cd ? m : n);
-                    const int up = hp[c] + gp;
-                    v[c] = d > up ? d : up;
+                    D[c] = dsrc + (sq[c] == cd ? m : n);
+                    U[c] = hp[c] + gp;
+                    pD[c] = 0; pU[c] = 0;
                 }
-                if (g.lane == 0) v[0] = (mode == MODE_ROV) ? 0 : hp[0] + gp;   // first column (sisd..cpp:200-211,237-239)
             }
             for (int p = 1; p < k; ++p) {
                 int hp[CPL];
-                load_row((int)prow[r * KIN + p], S, hp);
+                load_ring((int)prow[r * KIN + p], S, R, hp);
                 const int left = g.shfl_up1(hp[CPL - 1], NEG);
                 HYPO_UNROLL
                 for (int c = 0; c < CPL; ++c) {
                     const int dsrc = c ? hp[c - 1] : left;
                     const int d = dsrc + (sq[c] == cd ? m : n);
-                    const int up = hp[c] + gp;
-                    int x = d > up ? d : up;
-                    if (g.lane == 0 && c == 0) x = (mode == MODE_ROV) ? 0 : up;
-                    v[c] = x > v[c] ? x : v[c];
+                    const int u = hp[c] + gp;
+                    if (d > D[c]) { D[c] = d; pD[c] = p; }   // strict: the first pred reaching the maximum wins
+                    if (u > U[c]) { U[c] = u; pU[c] = p; }
                 }
             }
+            if (g.lane == 0) D[0] = NEG;                     // column 0 has no diagonal
+            int v[CPL];
+            HYPO_UNROLL
+            for (int c = 0; c < CPL; ++c) v[c] = D[c] > U[c] ? D[c] : U[c];
+            if (g.lane == 0 && mode == MODE_ROV) v[0] = 0;   // first column (sisd..cpp:200-211,237-239)
             // horizontal term H[i][j] = max(H[i][j], H[i][j-1] + g): prefix max of H[i][j] - j*g
             {
                 int run = NEG;
                 HYPO_UNROLL
                 for (int c = 0; c < CPL; ++c) {
-                    int x = v[c] - (j0 + c) * gp;
+                    const int x = v[c] - (j0 + c) * gp;
                     run = x > run ? x : run;
                     v[c] = run;
                 }
                 const int ex = g.scan_max_excl(run, NEG);
                 HYPO_UNROLL
                 for (int c = 0; c < CPL; ++c) {
-                    int x = v[c] > ex ? v[c] : ex;
+                    const int x = v[c] > ex ? v[c] : ex;
                     v[c] = x + (j0 + c) * gp;
                 }
             }
             if (j0 < S) {
+                // the reference's traceback preference (sisd..cpp:370-428), resolved per cell
+                const bool fastrow = p0 == i - 1;
+                int dc[CPL];
                 Pack pk;
                 HYPO_UNROLL
-                for (int c = 0; c < CPL; ++c) pk.v[c] = (score_t)v[c];
-                *(Pack*)(H + i * S + j0) = pk;
+                for (int c = 0; c < CPL; ++c) {
+                    if (v[c] == D[c]) dc[c] = (pD[c] == 0 && fastrow) ? (int)DIR_FAST : dir_diag(pD[c]);
+                    else if (v[c] == U[c]) dc[c] = dir_vert(pU[c]);
+                    else dc[c] = DIR_HORIZ;
+                    pk.v[c] = (score_t)v[c];
+                }
+                DPack dk;
+                if (NIB) {
+                    HYPO_UNROLL
+                    for (int c = 0; c < CPL; c += 2) dk.v[c / 2] = (uint8_t)(dc[c] | (dc[c + 1] << 4));
+                    *(DPack*)(dir + ((r * S + j0) >> 1)) = dk;
+                } else {
+                    HYPO_UNROLL
+                    for (int c = 0; c < CPL; ++c) dk.v[c] = (uint8_t)dc[c];
+                    *(DPack*)(dir + r * S + j0) = dk;
+                }
+                *(Pack*)(ring + (r % R) * S + j0) = pk;
             }
             HYPO_UNROLL
             for (int c = 0; c < CPL; ++c) last[c] = v[c];
@@ -272,40 +427,49 @@ struct Poa {
             g.sync();
         }
         best_i = g.shfl(best_i, le);
+        HYPO_TICK(PH_DP);
 
-        // ---- traceback (sisd..cpp:344-438) ----
+        // ---- traceback over direction codes ----
         int i = best_i > 0 ? best_i : 0, j = best_i > 0 ? L : 0;
-        int steps = 0;
+        int steps = 0, guard = 0;
         while (mode == MODE_ROV ? (i != 0 && j != 0) : (i != 0 || j != 0)) {
-            const int hij = (int)H[i * S + j];
-            int pi = 0, node = -1, k = 0, mc = 0;
-            bool dg = false, vt = false;
-            if (i != 0) {
-                const uint32_t meta = rowmeta[i - 1];
-                k = (int)((meta >> 8) & 0xff);
-                node = (int)r2n[i - 1];
-                const int np = k ? k : 1;
-                if (g.lane < np) {
-                    pi = k ? (int)prow[(i - 1) * KIN + g.lane] : 0;
-                    if (j != 0) {
-                        mc = (seq[j - 1] == (uint8_t)(meta & 0xff)) ? m : n;
-                        dg = hij == (int)H[pi * S + j - 1] + mc;
-                    }
-                    vt = hij == (int)H[pi * S + j] + gp;
-                }
+            if (++guard > n_nodes + L + 4) return RES_UNDEFINED;      // cannot loop; protects the GPU from a hang
+            if (i == 0) {                                   // only row 0 left: horizontal moves (insertions)
+                for (int t = g.lane; t < j; t += GW) posnode[t] = -1;
+                steps += j; j = 0;
+                break;
             }
-            const uint64_t bd = g.ballot(dg), bv = g.ballot(vt);
-            int ni_ = i, nj_ = j;
-            if (bd) { ni_ = g.shfl(pi, ctz64(bd)); nj_ = j - 1; }
-            else if (bv) { ni_ = g.shfl(pi, ctz64(bv)); }
-            else if (j != 0 && hij == (int)H[i * S + j - 1] + gp) { nj_ = j - 1; }
-            else return RES_UNDEFINED;                     // inconsistent matrix: cannot happen
-            if (nj_ != j && g.lane == 0) posnode[j - 1] = (int16_t)(ni_ != i ? node : -1);
-            i = ni_; j = nj_; ++steps;
-            if (steps > n_nodes + L + 2) return RES_UNDEFINED;   // bounded by construction; guards the GPU against a hang
+            // run of FAST cells along the diagonal: lane t looks at (i-t, j-t)
+            const int ii = i - g.lane, jj = j - g.lane;
+            const bool fast = (ii >= 1 && jj >= 1) && read_dir((ii - 1) * S + jj) == DIR_FAST;
+            const uint64_t stop = g.ballot(!fast);
+            const int run = stop ? ctz64(stop) : GW;
+            if (run > 0) {
+                if (g.lane < run) posnode[jj - 1] = (int16_t)r2n[ii - 1];
+                i -= run; j -= run; steps += run;
+                continue;
+            }
+            const int d = read_dir((i - 1) * S + j);
+            if (d == DIR_HORIZ) {
+                if (j == 0) return RES_UNDEFINED;
+                if (g.lane == 0) posnode[j - 1] = -1;
+                --j;
+            } else {
+                const int p = dir_pred(d);
+                const int k = (int)((rowmeta[i - 1] >> 8) & 0xff);
+                const int pi = k ? (int)prow[(i - 1) * KIN + p] : 0;
+                if (!is_vert(d)) {
+                    if (j == 0) return RES_UNDEFINED;
+                    if (g.lane == 0) posnode[j - 1] = (int16_t)r2n[i - 1];
+                    --j;
+                }
+                i = pi;
+            }
+            ++steps;
         }
         tb_steps = steps; tb_fv = j;
         g.sync();
+        HYPO_TICK(PH_TRACE);
         return RES_OK;
     }
 
@@ -343,7 +507,8 @@ struct Poa {
             changed = true;
         }
         g.sync();
-        // aligned part [fv, L): every position owns a distinct node / clique
+        // aligned part [fv, L): every position owns a distinct node / clique.  posnode[q] is rewritten
+        // in place from "node the position is aligned to" to "node the position becomes".
         bool over = false;
         for (int base = fv; base < L; base += GW) {
             const int q = base + g.lane;
@@ -383,7 +548,7 @@ struct Poa {
                 }
                 tgt = id;
             }
-            if (act) cur[q] = (int16_t)tgt;
+            if (act) posnode[q] = (int16_t)tgt;
             n_nodes += tot;
             if (tot) changed = true;
         }
@@ -394,8 +559,8 @@ struct Poa {
         for (int base = fv; base < L; base += GW) {
             const int q = base + g.lane;
             if (q < L) {
-                const int prev = q == fv ? head : (int)cur[q - 1];
-                if (prev >= 0) { const int e = add_edge(prev, (int)cur[q]); st = e > st ? e : st; }
+                const int prev = q == fv ? head : (int)posnode[q - 1];
+                if (prev >= 0) { const int e = add_edge(prev, (int)posnode[q]); st = e > st ? e : st; }
             }
         }
         const int sm = g.reduce_max(st);
@@ -462,15 +627,16 @@ struct Poa {
         int rc = align(mode, m, n, gp);
         if (rc != RES_OK) return rc;
         rc = add_alignment();
+        HYPO_TICK(PH_ADD);
         if (rc != RES_OK) return rc;
-        if (topo_dirty) rc = toposort();
+        if (topo_dirty) { rc = toposort(); HYPO_TICK(PH_TOPO); }
         return rc;
     }
 
     // ---- Graph::generate_consensus (graph.cpp:467-476,610-705) --------------------------------------
-    // Scratch aliases the score matrix: score[NMAX] int32, pred[NMAX] int16, path[NMAX] int16.
+    // Scratch aliases ring + dir: score[NMAX] int32, pred[NMAX] int16, path[NMAX] int16.
     HD int consensus(int16_t** path_out) {
-        int32_t* score = (int32_t*)H;
+        int32_t* score = (int32_t*)ring;
         int16_t* pred = (int16_t*)(score + NMAX);
         int16_t* path = pred + NMAX;
         g.sync();
@@ -557,45 +723,26 @@ struct Poa {
         const int m = P.sr_m, n = P.sr_n, gp = P.sr_g;
         const uint8_t* d4 = P.draft4 + W.draft_off;
         n_nodes = 0; topo_dirty = false; meta_dirty = true;
-        bool added = false;
-        int rc;
-        if (W.n_internal == 0) {                            // draft as backbone only without internal arms
-            if ((rc = load_seq(d4, (int)W.draft_len, true, true, true)) != RES_OK) return rc;
-            if ((rc = add_sequence_step(MODE_NW, m, n, gp)) != RES_OK) return rc;
-        }
-        const uint32_t a0 = W.first_arm;
-        for (uint32_t a = 0; a < W.n_internal; ++a) {
-            const int len = (int)P.arm_len[a0 + a];
-            if (len == 0) continue;
-            added = true;
-            if ((rc = load_seq(P.arms2 + P.arm_off[a0 + a], len, false, true, true)) != RES_OK) return rc;
-            if ((rc = add_sequence_step(MODE_NW, m, n, gp)) != RES_OK) return rc;
-        }
-        for (uint32_t t = 0; t < W.n_prefix; ++t) {        // reverse insertion order (Window.cpp:111)
-            const uint32_t a = a0 + W.n_internal + (W.n_prefix - 1 - t);
-            const int len = (int)P.arm_len[a];
-            if (len == 0) continue;
-            added = true;
-            if ((rc = load_seq(P.arms2 + P.arm_off[a], len, false, true, false)) != RES_OK) return rc;
-            if ((rc = add_sequence_step(MODE_LOV, m, n, gp)) != RES_OK) return rc;
-        }
-        for (uint32_t t = 0; t < W.n_suffix; ++t) {
-            const uint32_t a = a0 + W.n_internal + W.n_prefix + t;
-            const int len = (int)P.arm_len[a];
-            if (len == 0) continue;
-            added = true;
-            if ((rc = load_seq(P.arms2 + P.arm_off[a], len, false, false, true)) != RES_OK) return rc;
-            if ((rc = add_sequence_step(MODE_ROV, m, n, gp)) != RES_OK) return rc;
+        int n_seq = 0; bool added = false;
+        int rc = build_seqtab(W, &n_seq, &added);
+        if (rc != RES_OK) return rc;
+        for (int s = 0; s < n_seq; ++s) {
+            int mode;
+            if ((rc = load_seq(W, s, &mode)) != RES_OK) return rc;
+            if (L == 0) continue;                           // zero-length arms are skipped (Window.cpp:100,113,124)
+            if ((rc = add_sequence_step(mode, m, n, gp)) != RES_OK) return rc;
         }
         if (!added) return emit_draft(w, d4, (int)W.draft_len);
         int16_t* path;
         const int len = consensus(&path);
+        HYPO_TICK(PH_CONS);
         if (len < 2) return RES_UNDEFINED;                  // Window.hpp:144 strips two markers
         const int olen = len - 2;
         const uint64_t o = P.out_off[w], cap = P.out_off[w + 1] - o;
         if ((uint64_t)olen > cap) { finish(w, HYPO_ST_CONS_OVERFLOW, (uint32_t)olen); return RES_OK; }
         for (int t = g.lane; t < olen; t += GW) P.out_bases[o + t] = "ACGTNJO"[code[path[len - 2 - t]]];
         finish(w, HYPO_ST_OK, (uint32_t)olen);
+        HYPO_TICK(PH_OUT);
         return RES_OK;
     }
 

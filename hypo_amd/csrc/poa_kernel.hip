@@ -13,6 +13,7 @@
 // MFMA is not used: the work is integer max/+ over irregular <=128-wide rows with a serial graph
 // update between sequences (see DESIGN.md for the roofline evidence).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "poa_classes.hpp"
 #include "poa_kernel.hpp"
 
@@ -21,10 +22,10 @@ namespace hypo {
 // ------------------------------------------------------------------------------------------------
 // plan: dispatch + size-class estimate per window
 // ------------------------------------------------------------------------------------------------
-struct ClassLimits { int lmax, nmax, hcells, cpl; };
+struct ClassLimits { int lmax, nmax, dircells, ringcells, seqmax, cpl; };
 
 template <class Cfg> __host__ __device__ constexpr ClassLimits limits_of() {
-    return ClassLimits{Cfg::LMAX, Cfg::NMAX, Cfg::HCELLS, Cfg::CPL};
+    return ClassLimits{Cfg::LMAX, Cfg::NMAX, Cfg::DIRCELLS, Cfg::RINGCELLS, Cfg::SEQMAX, Cfg::CPL};
 }
 
 __global__ void poa_plan_kernel(PoaParams P, PoaQueues Q, uint32_t n_windows) {
@@ -38,7 +39,7 @@ __global__ void poa_plan_kernel(PoaParams P, PoaQueues Q, uint32_t n_windows) {
         const uint32_t l = P.arm_len[W.first_arm + a] + 2;
         maxlen = l > maxlen ? l : maxlen;
     }
-    const uint32_t est_nodes = maxlen + maxlen / 4 + 8;
+    const uint32_t est_nodes = maxlen + maxlen / 16 + 3;   // near-linear graphs; the kernel re-queues on overflow
     const ClassLimits lim[kNumPoaClasses] = {
 #define HYPO_LIM(ID, CFG) limits_of<CFG>(),
         HYPO_FOR_EACH_CLASS(HYPO_LIM)
@@ -47,8 +48,8 @@ __global__ void poa_plan_kernel(PoaParams P, PoaQueues Q, uint32_t n_windows) {
     int cls = kNumPoaClasses - 1;
     for (int c = 0; c < kNumPoaClasses; ++c) {
         const uint32_t S = (maxlen + 1 + lim[c].cpl - 1) / lim[c].cpl * lim[c].cpl;
-        if ((int)maxlen <= lim[c].lmax && (int)est_nodes <= lim[c].nmax &&
-            (uint64_t)(est_nodes + 1) * S <= (uint64_t)lim[c].hcells) { cls = c; break; }
+        if ((int)maxlen <= lim[c].lmax && (int)est_nodes <= lim[c].nmax && (int)narm + 1 <= lim[c].seqmax &&
+            (uint64_t)est_nodes * S <= (uint64_t)lim[c].dircells && lim[c].ringcells / (int)S >= 6) { cls = c; break; }
     }
     if (W.type != HYPO_WIN_SHORT && cls < kFirstLongClass) cls = kFirstLongClass;
     if (W.n_empty > narm || narm < 2) atomicAdd((unsigned long long*)&Q.stats->n_trivial, 1ull);
@@ -72,6 +73,10 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaParams P, PoaQueues Q,
     const uint32_t count = Q.count[cls];
     uint64_t cells = 0, aligns = 0, abytes = 0;
     uint32_t n_ok = 0, n_esc = 0, n_fail = 0;
+#ifdef HYPO_PHASE_TIMERS
+    uint64_t tph[PH_N] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint64_t tstart = (uint64_t)clock64();
+#endif
     for (;;) {
         uint32_t idx = 0;
         if (g.lane == 0) idx = atomicAdd(&Q.head[cls], 1u);
@@ -81,6 +86,9 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaParams P, PoaQueues Q,
         Poa<Cfg> poa(g, P, mem);
         const int rc = poa.run(w);
         cells += poa.cells; aligns += poa.aligns;
+#ifdef HYPO_PHASE_TIMERS
+        for (int i = 0; i < PH_N; ++i) tph[i] += poa.tphase[i];
+#endif
         if (rc == RES_OK) {
             ++n_ok;
             if (g.lane == 0) {                                  // algorithmic bytes, SURVEY.md 8(d)
@@ -111,6 +119,12 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaParams P, PoaQueues Q,
         atomicAdd((unsigned long long*)&Q.stats->dp_cells, (unsigned long long)cells);
         atomicAdd((unsigned long long*)&Q.stats->n_alignments, (unsigned long long)aligns);
         atomicAdd((unsigned long long*)&Q.stats->alg_bytes[cls], (unsigned long long)abytes);
+#ifdef HYPO_PHASE_TIMERS
+        unsigned long long* ph = (unsigned long long*)((char*)Q.count + 512) + (size_t)cls * 16;   // header + 512: [class][16]
+        for (int i = 0; i < PH_N; ++i) atomicAdd(&ph[i], (unsigned long long)tph[i]);
+        atomicAdd(&ph[PH_N], (unsigned long long)((uint64_t)clock64() - tstart));                // wave lifetime
+        atomicAdd(&ph[PH_N + 1], 1ull);                                                           // waves
+#endif
     }
 }
 
@@ -132,6 +146,10 @@ static hipError_t launch_class(const PoaParams& P, const PoaQueues& Q, int cls, 
     e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, lds);
     if (e != hipSuccess) return e;
     if (per_cu < 1) per_cu = 1;
+    if (const char* cap = getenv("HYPO_POA_WAVES_PER_CU")) {      // tuning/diagnostic knob
+        const int c = atoi(cap);
+        if (c >= 1 && c < per_cu) per_cu = c;
+    }
     long grid = (long)per_cu * num_cus;
     if (!USE_LDS && grid * GPW > max_global_groups) grid = max_global_groups / GPW;
     const long need = ((long)n_windows + GPW - 1) / GPW;      // never more waves than windows

@@ -5,10 +5,10 @@
 
 namespace hypo {
 
-constexpr int kFirstGlobalClass = 2;     // classes >= this keep their state in HBM scratch, not LDS
-constexpr int kFirstLongClass = 2;       // LONG windows (<= 500 bp, ~1.3 k nodes) start here
+constexpr int kFirstGlobalClass = 4;     // classes >= this keep their state in HBM scratch, not LDS
+constexpr int kFirstLongClass = 4;       // LONG windows (<= 500 bp, ~1.3 k nodes) start here
 constexpr int kMaxGlobalGroups = 512;    // resident groups of the HBM-scratch classes
-constexpr size_t kPoaHeaderBytes = 512;  // count[8] | head[8] | HypoPoaStats
+constexpr size_t kPoaHeaderBytes = 2048; // count[8] | head[8] @64 | HypoPoaStats @128 | phase cycles @512 ([class][16] u64, diagnostic build)
 
 struct PoaQueues {
     uint32_t* count;        // [classes] windows queued per class
@@ -19,7 +19,7 @@ struct PoaQueues {
 };
 
 // optional event recorder: ev[0] before plan, ev[1] after plan, ev[2 + c] after class c
-struct KernelEvents { hipEvent_t ev[8]; int n; };
+struct KernelEvents { hipEvent_t ev[12]; int n; };
 
 size_t poa_workspace_bytes(uint32_t n_windows);
 hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size_t workspace_bytes,

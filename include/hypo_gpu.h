@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HYPO_GPU_ABI_VERSION 1
+#define HYPO_GPU_ABI_VERSION 2
 
 /* error codes */
 #define HYPO_OK              0
@@ -163,12 +163,12 @@ int hypo_gpu_poa_slot_layout(const HypoWindowBatch* host_in, uint64_t* off);
 typedef struct HypoPoaStats {
     uint64_t n_windows;
     uint64_t n_trivial;        /* answered by the dispatch rules without POA */
-    uint64_t n_class[4];       /* windows finished in size class 0..3 */
+    uint64_t n_class[8];       /* windows finished in size class 0..7 (5 in use) */
     uint64_t n_escalated;      /* windows that overflowed a class and were re-run in the next */
     uint64_t n_failed;         /* status != OK */
     uint64_t dp_cells;         /* sum over alignments of (nodes+1)*(len+1), sisd..cpp:266-267 */
     uint64_t n_alignments;
-    uint64_t alg_bytes[4];     /* algorithmic HBM bytes of the windows finished in class 0..3:
+    uint64_t alg_bytes[8];     /* algorithmic HBM bytes of the windows finished in class 0..7:
                                   ceil(Ld/2) + sum ceil(La/4) + Lcons + 16 + 8*(1+n_arms)   */
 } HypoPoaStats;
 int hypo_gpu_poa_last_stats(HypoPoaStats* out);
@@ -182,7 +182,7 @@ int hypo_gpu_poa_read_stats(const void* workspace, void* hip_stream, HypoPoaStat
  *   POA call : ms[0] = plan kernel, ms[1 + c] = size-class kernel c (HYPO_PROFILE_POA_SLOTS values)
  *   scan call: ms[0] = mark, ms[1] = rank (3 kernels), ms[2] = kids (HYPO_PROFILE_SCAN_SLOTS values)
  * Returns the number of values written, or <0. */
-#define HYPO_PROFILE_POA_SLOTS 5
+#define HYPO_PROFILE_POA_SLOTS 6
 #define HYPO_PROFILE_SCAN_SLOTS 3
 int hypo_gpu_profile_begin(int max_calls);
 int hypo_gpu_profile_calls(void);

@@ -38,15 +38,20 @@ def test_class1_synth(emu):
     assert _check(emu, 1, "windows_synth.jsonl.gz", 120, True) > 100
 
 
-def test_class1_real(emu):
-    assert _check(emu, 1, "windows_real_c1.jsonl.gz", 150, False) == 150
+def test_class2_real(emu):
+    assert _check(emu, 2, "windows_real_c1.jsonl.gz", 150, False) == 150
 
 
-def test_class2_wide(emu):
-    # the 8-columns-per-lane / 16-bit-id instantiation, including the 200-bp windows
+def test_class3_bytes_dir(emu):
+    # 8-bit direction codes (in-degree capacity 8)
+    assert _check(emu, 3, "windows_synth.jsonl.gz", 60, True) > 50
+
+
+def test_class4_wide(emu):
+    # the 8-columns-per-lane / 16-bit-id / int32 instantiation, including the 200-bp windows
     items = [it for it in gu.windows_by_scores("windows_synth.jsonl.gz")[(5, -4, -8, 3, -5, -4)]
              if not it[0].is_long and len(it[0].draft) >= 150][:12]
     b = build_batch([w for w, _, _ in items])
-    cons, st, res, _, _ = emu.poa_batch(b, 2)
+    cons, st, res, _, _ = emu.poa_batch(b, 4)
     for (w, want, tag), got, r in zip(items, cons, res):
         assert r == emu_util.RES_OK and got == want, tag
