@@ -124,23 +124,25 @@ struct Grp {
     HD int reduce_max(int v) const {
         HYPO_UNROLL
         for (int d = GW / 2; d >= 1; d >>= 1) { int o = __shfl_xor(v, d, GW); v = o > v ? o : v; }
-        return v;
+        return uniform(v);          // tells the compiler the result is wave-uniform -> scalar control flow
     }
     HD int reduce_add(int v) const {
         HYPO_UNROLL
         for (int d = GW / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, GW);
-        return v;
+        return uniform(v);
     }
-    // exclusive prefix max over the group's lanes (lane 0 gets `ident`); ident must be <= every v
-    HD int scan_max_excl(int v, int ident) const {
+    // exclusive prefix max over the group's lanes; lane 0 gets INT_MIN.  INT_MIN is max's identity, which lets
+    // the compiler fold every row_shr / row_bcast move into the v_max_i32 that consumes it (one VALU op per step).
+    HD int scan_max_excl(int v, int /*ident*/) const {
+        constexpr int ID = (int)0x80000000;
         int x = v, t;
-        t = dpp_mov<0x111>(ident, x); x = t > x ? t : x;                 // row_shr:1
-        t = dpp_mov<0x112>(ident, x); x = t > x ? t : x;                 // row_shr:2
-        t = dpp_mov<0x114>(ident, x); x = t > x ? t : x;                 // row_shr:4
-        t = dpp_mov<0x118>(ident, x); x = t > x ? t : x;                 // row_shr:8
-        if (GW >= 32) { t = dpp_mov<0x142, 0xa>(ident, x); x = t > x ? t : x; }   // row_bcast:15 -> rows 1,3
-        if (GW == 64) { t = dpp_mov<0x143, 0xc>(ident, x); x = t > x ? t : x; }   // row_bcast:31 -> rows 2,3
-        return shfl_up1(x, ident);
+        t = dpp_mov<0x111>(ID, x); x = t > x ? t : x;                 // row_shr:1
+        t = dpp_mov<0x112>(ID, x); x = t > x ? t : x;                 // row_shr:2
+        t = dpp_mov<0x114>(ID, x); x = t > x ? t : x;                 // row_shr:4
+        t = dpp_mov<0x118>(ID, x); x = t > x ? t : x;                 // row_shr:8
+        if (GW >= 32) { t = dpp_mov<0x142, 0xa>(ID, x); x = t > x ? t : x; }   // row_bcast:15 -> rows 1,3
+        if (GW == 64) { t = dpp_mov<0x143, 0xc>(ID, x); x = t > x ? t : x; }   // row_bcast:31 -> rows 2,3
+        return shfl_up1(x, ID);
     }
     // hint: value is identical in every lane of the WAVE (only true for GW == 64)
     HD int uniform(int v) const { return GW == 64 ? __builtin_amdgcn_readfirstlane(v) : v; }

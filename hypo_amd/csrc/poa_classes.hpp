@@ -1,11 +1,13 @@
 // poa_classes.hpp — size classes of the POA kernel (one template instantiation + launch each).
 //
-//   class lanes cols/lane max seq  nodes in-edges dir cells (bits) ring cells staged arm B  seqs  scores ids  memory / window
-//   0     64    2         47       48    4        2208 (4)        512        384           48    int16  u8   LDS  ~4.6 KB
-//   1     64    2         79       84    4        6720 (4)        1280       768           64    int16  u8   LDS  ~9.6 KB
-//   2     64    2         127      126   6        13440 (4)       2240       1536          96    int16  u8   LDS  ~18 KB
-//   3     64    2         127      254   8        32768 (8)       4096       4096          254   int16  u8   LDS  ~59 KB
-//   4     64    8         511      4000  16       2097152 (8)     65536      16384         1024  int32  u16  HBM scratch ~2.7 MB / resident group
+//   class lanes/window (windows/wave) cols/lane max seq nodes in-edges dir cells(bits) ring cells arm B seqs scores ids  memory / window
+//   0     16 (4)                      4         47      48    4        2208 (4)       384        384   48   int16  u8   LDS  ~4.3 KB
+//   1     32 (2)                      4         79      84    4        6720 (4)       640        768   64   int16  u8   LDS  ~9 KB
+//   2     64 (1)                      2         127     126   6        13440 (4)      1024       1536  96   int16  u8   LDS  ~16.5 KB
+//   3     64 (1)                      2         127     254   8        32768 (8)      4096       4096  254  int16  u8   LDS  ~59 KB
+//   4     64 (1)                      8         511     4000  16       2097152 (8)    65536      16384 1024 int32  u16  HBM scratch ~2.7 MB / resident group
+// The kernel is VALU-issue bound (profiles/): a wavefront therefore carries 4 / 2 small windows side by side
+// (16- / 32-lane groups with group-uniform control flow), so one instruction stream advances several windows.
 // A window that does not fit class c (too many nodes / in-edges / cells, a predecessor row that already left
 // the ring, sequence too long, or scores whose magnitude could overflow int16) is re-queued to class c+1 by
 // the kernel itself.  int16 is exact iff max(|m|,|n|,|g|) * (nodes + len + 1) < 32767 (the guard spoa's SIMD
@@ -15,9 +17,9 @@
 
 namespace hypo {
 //              GW CPL LCAP NMAX KIN DIRCELLS RINGCELLS ARMBYTES SEQMAX
-typedef PoaCfg<64, 2, 47, 48, 4, 2208, 512, 384, 48, int16_t, uint8_t> PoaClass0;
-typedef PoaCfg<64, 2, 79, 84, 4, 6720, 1280, 768, 64, int16_t, uint8_t> PoaClass1;
-typedef PoaCfg<64, 2, 127, 126, 6, 13440, 2240, 1536, 96, int16_t, uint8_t> PoaClass2;
+typedef PoaCfg<16, 4, 47, 48, 4, 2208, 384, 384, 48, int16_t, uint8_t> PoaClass0;
+typedef PoaCfg<32, 4, 79, 84, 4, 6720, 640, 768, 64, int16_t, uint8_t> PoaClass1;
+typedef PoaCfg<64, 2, 127, 126, 6, 13440, 1024, 1536, 96, int16_t, uint8_t> PoaClass2;
 typedef PoaCfg<64, 2, 127, 254, 8, 32768, 4096, 4096, 254, int16_t, uint8_t> PoaClass3;
 typedef PoaCfg<64, 8, 511, 4000, 16, 1 << 21, 1 << 16, 16384, 1024, int32_t, uint16_t> PoaClass4;
 constexpr int kNumPoaClasses = 5;

@@ -85,7 +85,7 @@ struct PoaCfg {
     typedef IdT id_t;
     static constexpr int ID_NONE = (IdT)~(IdT)0;
     static_assert(LCAP_ <= GW_ * CPL_ - 1, "columns 0..L must fit the group");
-    static_assert(LCAP_ <= 511 && ARMBYTES_ <= 65535 && SEQMAX_ <= 65535, "sequence table entry is 32 bits");
+    static_assert(LCAP_ <= 511 && ARMBYTES_ <= 32767 && SEQMAX_ <= 32767, "sequence table entry is 32 bits");
     static_assert(KIN_ + 6 <= GW_, "dependency lanes");
     static_assert(KIN_ <= 62, "direction byte holds the pred index in 6 bits");
     static_assert((int)sizeof(ScoreT) * RINGCELLS_ + DIRBYTES >= 8 * NMAX_, "consensus scratch aliases ring+dir");
@@ -139,12 +139,13 @@ struct Poa {
 
     struct alignas(sizeof(score_t) * CPL) Pack { score_t v[CPL]; };
     struct alignas(NIB ? CPL / 2 : CPL) DPack { uint8_t v[NIB ? CPL / 2 : CPL]; };
-    // sequence table entry: bits 0-15 src (LDS offset of the staged bytes, or arm index), 16-24 length,
+    // sequence table entry: bits 0-14 src (LDS offset of the staged bytes, or arm index), 15 "byte-identical to
+    // the previous entry" (set for staged arms only), 16-24 length,
     // 25 head marker J, 26 tail marker O, 27-28 mode (0 NW, 1 LOV, 2 ROV), 29 four-bit packing,
     // 30-31 where (0 staged in LDS, 1 arms2 in HBM, 2 draft4 in HBM)
     HD static uint32_t seq_ent(uint32_t src, uint32_t len, bool head, bool tail, int mode, bool four, int where) {
         const uint32_t mc = mode == MODE_NW ? 0u : (mode == MODE_LOV ? 1u : 2u);
-        return (src & 0xffffu) | (len << 16) | ((head ? 1u : 0u) << 25) | ((tail ? 1u : 0u) << 26) | (mc << 27) |
+        return (src & 0x7fffu) | (len << 16) | ((head ? 1u : 0u) << 25) | ((tail ? 1u : 0u) << 26) | (mc << 27) |
                ((four ? 1u : 0u) << 29) | ((uint32_t)where << 30);
     }
 
@@ -157,7 +158,8 @@ struct Poa {
     // group-uniform state
     int n_nodes; int L; bool topo_dirty; bool meta_dirty; int maxdelta;
     int tb_steps; int tb_fv;
-    uint64_t cells, aligns;
+    bool last_changed;         // did the most recent add_alignment change the graph topology?
+    uint64_t cells, aligns, reused;
     uint64_t tphase[PH_N]; uint64_t tlast;
 
     HD Poa(const Grp<GW>& g_, const PoaParams& P_, char* mem) : g(g_), P(P_) {
@@ -172,7 +174,7 @@ struct Poa {
         nal = (uint8_t*)(mem + Lay::oNal); mark = (uint8_t*)(mem + Lay::oMark);
         seq = (uint8_t*)(mem + Lay::oSeq); armbuf = (uint8_t*)(mem + Lay::oArms);
         n_nodes = 0; L = 0; topo_dirty = false; meta_dirty = true; maxdelta = 0; tb_steps = 0; tb_fv = 0;
-        cells = 0; aligns = 0;
+        cells = 0; aligns = 0; reused = 0; last_changed = true;
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
         tlast = 0;
         HYPO_TICK_RESET();
@@ -212,7 +214,7 @@ struct Poa {
                 const int nb = (int)(((e >> 16) & 0x1ff) + 3) >> 2;
                 if (used + nb <= Cfg::ARMBYTES) {
                     // keep the arm index in posnode-free scratch: staged entries remember it via `stack`
-                    stack[t] = (id_t)(e & 0xffff);
+                    stack[t] = (id_t)(e & 0x7fff);
                     seqtab[base + t] = (e & 0x3fff0000u) | (uint32_t)used;        // where = 0
                     used += nb;
                 }
@@ -224,8 +226,21 @@ struct Poa {
             if ((e >> 30) == 0) {
                 const int nb = (int)(((e >> 16) & 0x1ff) + 3) >> 2;
                 const uint8_t* src = P.arms2 + P.arm_off[a0 + (uint32_t)stack[t]];
-                uint8_t* dst = armbuf + (e & 0xffff);
+                uint8_t* dst = armbuf + (e & 0x7fff);
                 for (int b = 0; b < nb; ++b) dst[b] = src[b];
+            }
+        }
+        g.sync();
+        // flag arms that repeat their predecessor byte for byte (same length, markers, mode): one lane per arm
+        for (int t = g.lane + 1; t < narm; t += GW) {
+            const uint32_t a = seqtab[base + t], b = seqtab[base + t - 1];
+            if (((a ^ b) & 0xffff0000u) == 0 && (a >> 30) == 0) {
+                const int nb = (int)(((a >> 16) & 0x1ff) + 3) >> 2;
+                const uint8_t* pa = armbuf + (a & 0x7fff);
+                const uint8_t* pb = armbuf + (b & 0x7fff);
+                bool same = true;
+                for (int k = 0; k < nb; ++k) same &= pa[k] == pb[k];
+                if (same) seqtab[base + t] = a | 0x8000u;
             }
         }
         g.sync();
@@ -244,8 +259,8 @@ struct Poa {
         L = len + (head ? 1 : 0) + (tail ? 1 : 0);
         if (L > Cfg::LMAX) return RES_OVERFLOW;
         const uint8_t* p;
-        if (where == 0) p = armbuf + (e & 0xffff);
-        else if (where == 1) p = P.arms2 + P.arm_off[W.first_arm + (e & 0xffff)];
+        if (where == 0) p = armbuf + (e & 0x7fff);
+        else if (where == 1) p = P.arms2 + P.arm_off[W.first_arm + (e & 0x7fff)];
         else p = P.draft4 + W.draft_off;
         for (int t = g.lane; t < L; t += GW) {
             int c;
@@ -286,9 +301,9 @@ struct Poa {
         g.sync();
     }
 
-    HD void load_ring(int row, int S, int R, int (&out)[CPL]) const {   // row >= 1
+    HD void load_ring(int slot, int S, int (&out)[CPL]) const {
         if (CPL * g.lane < S) {
-            const Pack pk = *(const Pack*)(ring + ((row - 1) % R) * S + CPL * g.lane);
+            const Pack pk = *(const Pack*)(ring + slot * S + CPL * g.lane);
             HYPO_UNROLL
             for (int c = 0; c < CPL; ++c) out[c] = (int)pk.v[c];
         } else {
@@ -332,6 +347,7 @@ struct Poa {
         const int le = L / CPL, ce = L % CPL;               // owner of the last column
         int best = NEG, best_i = -1;
 
+        int slot = 0;                                        // ring slot of row i (no integer division in the loop)
         uint32_t meta_a = rowmeta[0];                        // two-deep prefetch of the row metadata
         uint32_t meta_b = n_nodes > 1 ? rowmeta[1] : 0u;
         for (int r = 0; r < n_nodes; ++r) {
@@ -347,7 +363,7 @@ struct Poa {
                 int hp[CPL];
                 if (p0 == i - 1) { HYPO_UNROLL for (int c = 0; c < CPL; ++c) hp[c] = last[c]; }
                 else if (p0 == 0) { HYPO_UNROLL for (int c = 0; c < CPL; ++c) hp[c] = (j0 + c) * gp; }
-                else load_ring(p0, S, R, hp);
+                else { int ps = slot - (i - p0); ps = ps < 0 ? ps + R : ps; load_ring(ps, S, hp); }
                 const int left = g.shfl_up1(hp[CPL - 1], NEG);
                 HYPO_UNROLL
                 for (int c = 0; c < CPL; ++c) {
@@ -359,7 +375,8 @@ struct Poa {
             }
             for (int p = 1; p < k; ++p) {
                 int hp[CPL];
-                load_ring((int)prow[r * KIN + p], S, R, hp);
+                int ps = slot - (i - (int)prow[r * KIN + p]); ps = ps < 0 ? ps + R : ps;
+                load_ring(ps, S, hp);
                 const int left = g.shfl_up1(hp[CPL - 1], NEG);
                 HYPO_UNROLL
                 for (int c = 0; c < CPL; ++c) {
@@ -396,11 +413,12 @@ struct Poa {
                 const bool fastrow = p0 == i - 1;
                 int dc[CPL];
                 Pack pk;
+                const int fastcode = fastrow ? (int)DIR_FAST : dir_diag(0);
                 HYPO_UNROLL
-                for (int c = 0; c < CPL; ++c) {
-                    if (v[c] == D[c]) dc[c] = (pD[c] == 0 && fastrow) ? (int)DIR_FAST : dir_diag(pD[c]);
-                    else if (v[c] == U[c]) dc[c] = dir_vert(pU[c]);
-                    else dc[c] = DIR_HORIZ;
+                for (int c = 0; c < CPL; ++c) {             // branch-free selects
+                    const int dgc = pD[c] == 0 ? fastcode : dir_diag(pD[c]);
+                    const int vtc = v[c] == U[c] ? dir_vert(pU[c]) : (int)DIR_HORIZ;
+                    dc[c] = v[c] == D[c] ? dgc : vtc;
                     pk.v[c] = (score_t)v[c];
                 }
                 DPack dk;
@@ -413,8 +431,9 @@ struct Poa {
                     for (int c = 0; c < CPL; ++c) dk.v[c] = (uint8_t)dc[c];
                     *(DPack*)(dir + r * S + j0) = dk;
                 }
-                *(Pack*)(ring + (r % R) * S + j0) = pk;
+                *(Pack*)(ring + slot * S + j0) = pk;
             }
+            slot = slot + 1 == R ? 0 : slot + 1;
             HYPO_UNROLL
             for (int c = 0; c < CPL; ++c) last[c] = v[c];
             // end cell: first strictly greater in rank order (sisd..cpp:279-288,332-339)
@@ -568,7 +587,34 @@ struct Poa {
         if (sm == 1) changed = true;
         g.sync();
         if (changed) { topo_dirty = true; meta_dirty = true; }
+        last_changed = changed;
         return RES_OK;
+    }
+
+    // ---- exact reuse of the previous alignment -------------------------------------------------------
+    // The DP and its traceback depend only on the graph's topology (nodes, letters, in-edge order, rank
+    // order) and on the sequence; edge weights never enter.  If sequence s is byte-identical to sequence
+    // s-1 (same mode and markers) and adding s-1 created no node and no edge, the reference would compute
+    // exactly the same alignment again: every position maps to the node it mapped to before.  Then only
+    // the edge weights along that path are incremented (graph.cpp:104-109).  posnode[] still holds the
+    // path of s-1 (rewritten in place to the nodes the positions became).
+    HD bool same_as_previous(int s) const { return s > 0 && (seqtab[s] & 0x8000u) != 0; }
+    // adds `count` more traversals of the path of the previous alignment: weights only
+    HD int readd_alignment(int count) {
+        bool bad = false;
+        for (int base = 0; base < L; base += GW) {
+            const int q = base + g.lane;
+            if (q >= 1 && q < L) {
+                const int prev = (int)posnode[q - 1], to = (int)posnode[q];
+                const int k = nin[to];
+                bool found = false;
+                for (int p = 0; p < k; ++p)
+                    if ((int)inp[to * KIN + p] == prev) { inw[to * KIN + p] = (uint16_t)(inw[to * KIN + p] + 2 * count); found = true; break; }
+                bad |= !found;
+            }
+        }
+        g.sync();
+        return g.any(bad) ? RES_UNDEFINED : RES_OK;
     }
 
     // ---- Graph::topological_sort (graph.cpp:293-353) ---------------------------------------------
@@ -726,11 +772,26 @@ struct Poa {
         int n_seq = 0; bool added = false;
         int rc = build_seqtab(W, &n_seq, &added);
         if (rc != RES_OK) return rc;
-        for (int s = 0; s < n_seq; ++s) {
+        bool prev_aligned = false;                           // the previous non-reused sequence went through align()
+        int s = 0;
+        while (s < n_seq) {
+            if (prev_aligned && !last_changed && tb_steps != 0 && tb_fv == 0) {
+                // run of arms identical to the one just aligned: L and posnode[] are still its path
+                int c = 0;
+                while (s < n_seq && same_as_previous(s)) { ++c; ++s; }
+                if (c) {
+                    cells += (uint64_t)c * (uint64_t)(n_nodes + 1) * (L + 1); aligns += c; reused += c;   // work the reference does
+                    if ((rc = readd_alignment(c)) != RES_OK) return rc;
+                    HYPO_TICK(PH_ADD);
+                    if (s >= n_seq) break;
+                }
+            }
             int mode;
             if ((rc = load_seq(W, s, &mode)) != RES_OK) return rc;
-            if (L == 0) continue;                           // zero-length arms are skipped (Window.cpp:100,113,124)
+            ++s;
+            if (L == 0) { prev_aligned = false; continue; }  // zero-length arms are skipped (Window.cpp:100,113,124)
             if ((rc = add_sequence_step(mode, m, n, gp)) != RES_OK) return rc;
+            prev_aligned = true;
         }
         if (!added) return emit_draft(w, d4, (int)W.draft_len);
         int16_t* path;

@@ -20,7 +20,10 @@
 namespace hypo {
 
 // ------------------------------------------------------------------------------------------------
-// plan: dispatch + size-class estimate per window
+// plan: size class + cost bucket per window, then a counting sort so that every class queue is ordered
+// by decreasing cost.  Groups of one wave dequeue neighbouring indices, i.e. windows of similar size:
+// the wave's loops then run for about the same trip counts in all of its groups, and the expensive
+// windows start first (short tail).
 // ------------------------------------------------------------------------------------------------
 struct ClassLimits { int lmax, nmax, dircells, ringcells, seqmax, cpl; };
 
@@ -28,9 +31,7 @@ template <class Cfg> __host__ __device__ constexpr ClassLimits limits_of() {
     return ClassLimits{Cfg::LMAX, Cfg::NMAX, Cfg::DIRCELLS, Cfg::RINGCELLS, Cfg::SEQMAX, Cfg::CPL};
 }
 
-__global__ void poa_plan_kernel(PoaParams P, PoaQueues Q, uint32_t n_windows) {
-    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_windows) return;
+__device__ __forceinline__ uint32_t plan_key(const PoaParams& P, uint32_t w, bool* trivial) {
     const HypoWindow W = P.windows[w];
     const uint32_t narm = W.n_internal + W.n_prefix + W.n_suffix;
     // longest sequence the window will align (markers included) and a node estimate
@@ -52,8 +53,45 @@ __global__ void poa_plan_kernel(PoaParams P, PoaQueues Q, uint32_t n_windows) {
             (uint64_t)est_nodes * S <= (uint64_t)lim[c].dircells && lim[c].ringcells / (int)S >= 6) { cls = c; break; }
     }
     if (W.type != HYPO_WIN_SHORT && cls < kFirstLongClass) cls = kFirstLongClass;
-    if (W.n_empty > narm || narm < 2) atomicAdd((unsigned long long*)&Q.stats->n_trivial, 1ull);
-    const uint32_t slot = atomicAdd(&Q.count[cls], 1u);
+    *trivial = W.n_empty > narm || narm < 2;
+    // cost ~ rows x sequences; bucket 0 = most expensive of the class
+    const uint32_t cost = *trivial ? 0u : maxlen * (narm + 1);
+    const uint32_t cmax = (uint32_t)lim[cls].lmax * (uint32_t)(lim[cls].seqmax < 64 ? lim[cls].seqmax : 64);
+    uint32_t b = (uint32_t)(((uint64_t)cost * kPlanBuckets) / (cmax ? cmax : 1));
+    b = b >= (uint32_t)kPlanBuckets ? kPlanBuckets - 1 : b;
+    return (uint32_t)cls * kPlanBuckets + (kPlanBuckets - 1 - b);
+}
+
+__global__ void poa_plan_count_kernel(PoaParams P, PoaQueues Q, uint32_t n_windows) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_windows) return;
+    bool trivial;
+    const uint32_t key = plan_key(P, w, &trivial);
+    Q.keys[w] = (uint16_t)key;
+    atomicAdd(&Q.hist[key], 1u);
+    if (trivial) atomicAdd((unsigned long long*)&Q.stats->n_trivial, 1ull);
+}
+
+__global__ void poa_plan_scan_kernel(PoaQueues Q) {       // one small workgroup: kNumPoaClasses x kPlanBuckets entries
+    if (threadIdx.x == 0) {
+        for (int c = 0; c < kNumPoaClasses; ++c) {
+            uint32_t acc = 0;
+            for (int b = 0; b < kPlanBuckets; ++b) {
+                const int k = c * kPlanBuckets + b;
+                Q.start[k] = acc;
+                acc += Q.hist[k];
+            }
+            Q.count[c] = acc;
+        }
+    }
+}
+
+__global__ void poa_plan_scatter_kernel(PoaQueues Q, uint32_t n_windows) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_windows) return;
+    const uint32_t key = Q.keys[w];
+    const uint32_t cls = key / kPlanBuckets;
+    const uint32_t slot = Q.start[key] + atomicAdd(&Q.cursor[key], 1u);
     Q.items[(size_t)cls * Q.stride + slot] = w;
 }
 
@@ -163,6 +201,7 @@ size_t poa_workspace_bytes(uint32_t n_windows) {
     size_t b = kPoaHeaderBytes;
     b += (size_t)kNumPoaClasses * n_windows * sizeof(uint32_t);
     b = (b + 255) / 256 * 256;
+    b += ((size_t)n_windows * 2 + 255) / 256 * 256;        // plan keys
     size_t big = 0;
 #define HYPO_BIG(ID, CFG) if (ID >= kFirstGlobalClass && (size_t)PoaLayout<CFG>::BYTES > big) big = PoaLayout<CFG>::BYTES;
     HYPO_FOR_EACH_CLASS(HYPO_BIG)
@@ -180,16 +219,23 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
     Q.count = (uint32_t*)ws;
     Q.head = (uint32_t*)(ws + 64);
     Q.stats = (HypoPoaStats*)(ws + 128);
+    Q.hist = (uint32_t*)(ws + 2048);
+    Q.start = (uint32_t*)(ws + 4096);
+    Q.cursor = (uint32_t*)(ws + 6144);
     Q.items = (uint32_t*)(ws + kPoaHeaderBytes);
     Q.stride = n_windows;
     size_t off = kPoaHeaderBytes + (size_t)kNumPoaClasses * n_windows * sizeof(uint32_t);
     off = (off + 255) / 256 * 256;
+    Q.keys = (uint16_t*)(ws + off);
+    off += ((size_t)n_windows * 2 + 255) / 256 * 256;
     char* scratch = ws + off;
     hipError_t e = hipMemsetAsync(ws, 0, kPoaHeaderBytes, stream);
     if (e != hipSuccess) return e;
     int pe = 0;
     if (prof) (void)hipEventRecord(prof->ev[pe++], stream);
-    hipLaunchKernelGGL(poa_plan_kernel, dim3((n_windows + 255) / 256), dim3(256), 0, stream, P, Q, n_windows);
+    hipLaunchKernelGGL(poa_plan_count_kernel, dim3((n_windows + 255) / 256), dim3(256), 0, stream, P, Q, n_windows);
+    hipLaunchKernelGGL(poa_plan_scan_kernel, dim3(1), dim3(64), 0, stream, Q);
+    hipLaunchKernelGGL(poa_plan_scatter_kernel, dim3((n_windows + 255) / 256), dim3(256), 0, stream, Q, n_windows);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (prof) (void)hipEventRecord(prof->ev[pe++], stream);
     // Every class is launched with a grid sized for the whole batch: how many windows a class

@@ -8,13 +8,19 @@ namespace hypo {
 constexpr int kFirstGlobalClass = 4;     // classes >= this keep their state in HBM scratch, not LDS
 constexpr int kFirstLongClass = 4;       // LONG windows (<= 500 bp, ~1.3 k nodes) start here
 constexpr int kMaxGlobalGroups = 512;    // resident groups of the HBM-scratch classes
-constexpr size_t kPoaHeaderBytes = 2048; // count[8] | head[8] @64 | HypoPoaStats @128 | phase cycles @512 ([class][16] u64, diagnostic build)
+constexpr size_t kPoaHeaderBytes = 8192; // count[8] | head[8] @64 | HypoPoaStats @128 | phase cycles @512 | hist @2048 | start @4096 | cursor @6144
+
+constexpr int kPlanBuckets = 64;         // cost buckets per class of the plan's counting sort
 
 struct PoaQueues {
     uint32_t* count;        // [classes] windows queued per class
     uint32_t* head;         // [classes] next queue slot to hand out
     HypoPoaStats* stats;
-    uint32_t* items;        // [classes][stride] window indices
+    uint32_t* hist;         // [classes * kPlanBuckets] plan: windows per (class, cost bucket)
+    uint32_t* start;        // exclusive prefix of hist inside each class
+    uint32_t* cursor;       // scatter cursors
+    uint16_t* keys;         // [n_windows] class * kPlanBuckets + bucket
+    uint32_t* items;        // [classes][stride] window indices, each class ordered by decreasing cost
     uint32_t stride;
 };
 
