@@ -88,7 +88,7 @@ struct PoaCfg {
     static_assert(LCAP_ <= 511 && ARMBYTES_ <= 32767 && SEQMAX_ <= 32767, "sequence table entry is 32 bits");
     static_assert(KIN_ + 6 <= GW_, "dependency lanes");
     static_assert(KIN_ <= 62, "direction byte holds the pred index in 6 bits");
-    static_assert((int)sizeof(ScoreT) * RINGCELLS_ + DIRBYTES >= 8 * NMAX_, "consensus scratch aliases ring+dir");
+    static_assert((int)sizeof(ScoreT) * RINGCELLS_ + DIRBYTES >= 14 * NMAX_, "consensus scratch aliases ring+dir");
     static_assert(NMAX_ < ID_NONE, "id range");
     static_assert(SEQMAX_ <= 2 * NMAX_ && SEQMAX_ <= ID_NONE, "arm indices are parked in the DFS stack while staging");
 };
@@ -159,7 +159,7 @@ struct Poa {
     int n_nodes; int L; bool topo_dirty; bool meta_dirty; int maxdelta;
     int tb_steps; int tb_fv;
     bool last_changed;         // did the most recent add_alignment change the graph topology?
-    uint64_t cells, aligns, reused;
+    uint64_t cells, aligns, reused, rows_done, topo_runs;
     uint64_t tphase[PH_N]; uint64_t tlast;
 
     HD Poa(const Grp<GW>& g_, const PoaParams& P_, char* mem) : g(g_), P(P_) {
@@ -174,7 +174,7 @@ struct Poa {
         nal = (uint8_t*)(mem + Lay::oNal); mark = (uint8_t*)(mem + Lay::oMark);
         seq = (uint8_t*)(mem + Lay::oSeq); armbuf = (uint8_t*)(mem + Lay::oArms);
         n_nodes = 0; L = 0; topo_dirty = false; meta_dirty = true; maxdelta = 0; tb_steps = 0; tb_fv = 0;
-        cells = 0; aligns = 0; reused = 0; last_changed = true;
+        cells = 0; aligns = 0; reused = 0; rows_done = 0; topo_runs = 0; last_changed = true;
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
         tlast = 0;
         HYPO_TICK_RESET();
@@ -333,7 +333,7 @@ struct Poa {
         if (meta_dirty) { build_rowmeta(); HYPO_TICK(PH_META); }
         const int R = Cfg::RINGCELLS / S;                   // ring rows; row i can still see rows i-R .. i-1
         if (R < maxdelta + 1 || R < 1) return RES_OVERFLOW;
-        cells += (uint64_t)(n_nodes + 1) * W; aligns += 1;
+        cells += (uint64_t)(n_nodes + 1) * W; aligns += 1; rows_done += (uint64_t)n_nodes;
 
         const int j0 = CPL * g.lane;
         int sq[CPL];                                        // sq[c] = code of seq[j-1] for column j = j0+c
@@ -622,15 +622,45 @@ struct Poa {
     HD int toposort() {
         for (int t = g.lane; t < n_nodes; t += GW) mark[t] = 0;
         g.sync();
-        int cnt = 0, sp = 0;
-        for (int root = 0; root < n_nodes; ++root) {
-            if (mark[root] & 1) continue;
+        int cnt = 0, root = 0, guard = 0;
+        while (root < n_nodes) {
+            if (++guard > 8 * Cfg::STK + 64) return RES_UNDEFINED;       // cannot loop on a DAG; hang guard
+            // Fast path: lane t looks at root+t.  A root that has no aligned nodes and whose in-edge sources are
+            // all marked (or are lower roots of this very batch) is emitted at once by the reference's loop, in id
+            // order; marked roots are skipped.  The leading run of such lanes is retired with one ballot.
+            const int r = root + g.lane;
+            bool pre = false, isdone = false;
+            if (r < n_nodes) {
+                isdone = mark[r] & 1;
+                pre = isdone;
+                if (!isdone && nal[r] == 0) {
+                    const int k = nin[r];
+                    bool ok = true;
+                    for (int p = 0; p < k; ++p) {
+                        const int d = inp[r * KIN + p];
+                        ok &= (d >= root && d < r) || (mark[d] & 1);
+                    }
+                    pre = ok;
+                }
+            }
+            const uint64_t full = GW == 64 ? ~0ull : ((1ull << (GW & 63)) - 1ull);
+            const uint64_t bp = g.ballot(pre);
+            const int run = bp == full ? GW : ctz64(~bp);
+            if (run > 0) {
+                const bool em = g.lane < run && !isdone;       // lanes < run have r < n_nodes (pre is false beyond)
+                const uint64_t eb = g.ballot(em);
+                if (em) { r2n[cnt + popc64(eb & ((1ull << g.lane) - 1ull))] = (id_t)r; mark[r] = 1; }
+                cnt += popc64(eb);
+                root += run;
+                g.sync();
+                continue;
+            }
+            // Slow path: literal DFS from `root` (unmarked, with a pending dependency or an aligned clique)
             if (g.lane == 0) stack[0] = (id_t)root;
-            sp = 1;
+            int sp = 1;
             g.sync();
-            int guard = 0;
             while (sp > 0) {
-                if (++guard > 4 * Cfg::STK + 16) return RES_UNDEFINED;   // cannot loop on a DAG; hang guard
+                if (++guard > 8 * Cfg::STK + 64) return RES_UNDEFINED;
                 const int v = stack[sp - 1];
                 const int mv = mark[v];
                 if (mv & 1) { --sp; continue; }
@@ -662,6 +692,7 @@ struct Poa {
                 }
                 g.sync();
             }
+            root += 1;
         }
         for (int r = g.lane; r < n_nodes; r += GW) n2r[r2n[r]] = (id_t)r;
         topo_dirty = false;
@@ -675,32 +706,50 @@ struct Poa {
         rc = add_alignment();
         HYPO_TICK(PH_ADD);
         if (rc != RES_OK) return rc;
-        if (topo_dirty) { rc = toposort(); HYPO_TICK(PH_TOPO); }
+        if (topo_dirty) { rc = toposort(); topo_runs += 1; HYPO_TICK(PH_TOPO); }
         return rc;
     }
 
     // ---- Graph::generate_consensus (graph.cpp:467-476,610-705) --------------------------------------
-    // Scratch aliases ring + dir: score[NMAX] int32, pred[NMAX] int16, path[NMAX] int16.
+    // Scratch aliases ring + dir: score[NMAX] i32, pred[NMAX] i16, path[NMAX] i16, rs[NMAX] i32, w0r[NMAX] u16.
     HD int consensus(int16_t** path_out) {
-        int32_t* score = (int32_t*)ring;
+        if (meta_dirty) build_rowmeta();
+        int32_t* score = (int32_t*)ring;                   // by node id
         int16_t* pred = (int16_t*)(score + NMAX);
         int16_t* path = pred + NMAX;
+        int32_t* rs = (int32_t*)(path + NMAX);             // by rank
+        uint16_t* w0r = (uint16_t*)(rs + NMAX);            // weight of in-edge 0, by rank
         g.sync();
-        for (int t = g.lane; t < n_nodes; t += GW) { score[t] = -1; pred[t] = -1; }
+        for (int r = g.lane; r < n_nodes; r += GW) {
+            const int u = r2n[r];
+            score[u] = -1; pred[u] = -1;
+            w0r[r] = nin[u] ? inw[u * KIN] : (uint16_t)0;
+        }
         g.sync();
         int max_id = 0;
         if (g.lane == 0) {
+            // One pass in rank order (graph.cpp:615-636).  For a node whose only predecessor is the previous
+            // row the running score stays in a register; everything else it needs was prefetched.
+            int best_val = -1, prev_s = 0;
+            uint32_t meta_n = rowmeta[0]; int w_n = w0r[0]; int u_n = r2n[0];
             for (int r = 0; r < n_nodes; ++r) {
-                const int u = r2n[r];
-                const int k = nin[u];
-                int s = -1, pd = -1;
-                for (int p = 0; p < k; ++p) {
-                    const int w = inw[u * KIN + p], b = inp[u * KIN + p];
-                    if (s < w || (s == w && score[pd] <= score[b])) { s = w; pd = b; }
+                const uint32_t meta = meta_n; const int w0 = w_n; const int u = u_n;
+                if (r + 1 < n_nodes) { meta_n = rowmeta[r + 1]; w_n = w0r[r + 1]; u_n = r2n[r + 1]; }
+                const int k = (int)((meta >> 8) & 0xff), p0 = (int)(meta >> 17);
+                int sc = -1, pd = -1;
+                if (k != 0) {
+                    int bw = w0, bs = p0 == r ? prev_s : rs[p0 - 1], bp = p0;
+                    for (int p = 1; p < k; ++p) {
+                        const int w = inw[u * KIN + p], pr = (int)prow[r * KIN + p];
+                        const int sp = rs[pr - 1];
+                        if (bw < w || (bw == w && bs <= sp)) { bw = w; bs = sp; bp = pr; }
+                    }
+                    sc = bw + bs; pd = (int)r2n[bp - 1];
                 }
-                if (pd != -1) s += score[pd];
-                score[u] = s; pred[u] = (int16_t)pd;
-                if (score[max_id] < s) max_id = u;
+                rs[r] = sc; score[u] = sc; pred[u] = (int16_t)pd;
+                if (u == max_id) best_val = sc;             // scores[max_score_id] < scores[node_id], :633-635
+                else if (best_val < sc) { max_id = u; best_val = sc; }
+                prev_s = sc;
             }
         }
         max_id = g.shfl(max_id, 0);

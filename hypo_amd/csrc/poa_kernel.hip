@@ -113,6 +113,7 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaParams P, PoaQueues Q,
     uint32_t n_ok = 0, n_esc = 0, n_fail = 0;
 #ifdef HYPO_PHASE_TIMERS
     uint64_t tph[PH_N] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t dbg[4] = {0, 0, 0, 0};
     const uint64_t tstart = (uint64_t)clock64();
 #endif
     for (;;) {
@@ -126,6 +127,7 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaParams P, PoaQueues Q,
         cells += poa.cells; aligns += poa.aligns;
 #ifdef HYPO_PHASE_TIMERS
         for (int i = 0; i < PH_N; ++i) tph[i] += poa.tphase[i];
+        dbg[0] += poa.rows_done; dbg[1] += poa.aligns - poa.reused; dbg[2] += poa.reused; dbg[3] += poa.topo_runs;
 #endif
         if (rc == RES_OK) {
             ++n_ok;
@@ -162,6 +164,7 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaParams P, PoaQueues Q,
         for (int i = 0; i < PH_N; ++i) atomicAdd(&ph[i], (unsigned long long)tph[i]);
         atomicAdd(&ph[PH_N], (unsigned long long)((uint64_t)clock64() - tstart));                // wave lifetime
         atomicAdd(&ph[PH_N + 1], 1ull);                                                           // waves
+        for (int i = 0; i < 4; ++i) atomicAdd(&ph[PH_N + 2 + i], (unsigned long long)dbg[i]);      // rows, real alignments, reused, toposorts
 #endif
     }
 }
