@@ -70,22 +70,16 @@ def main():
     ds = gpu.device_scan(packed4, CONTIG_BASES, K, bits)
     n_w = batch.n_windows
 
-    # buffers of the exchange step: equal-size per rank (padded to the largest rank), one collective each
+    # exchange step: sizes agreed once (all_reduce MAX), then two fixed-size all-gathers per batch
     if world > 1:
-        cap = torch.tensor([int(off[-1])], dtype=torch.int64, device=dev)
-        dist.all_reduce(cap, op=dist.ReduceOp.MAX)
-        cap = (int(cap.item()) + 255) // 256 * 256
-        send_bases = torch.zeros(cap, dtype=torch.uint8, device=dev)
-        all_bases = torch.zeros(world * cap, dtype=torch.uint8, device=dev)
-        all_len = torch.zeros(world * n_w, dtype=torch.int32, device=dev)
+        from hypo_amd import dist as hd
+        max_bytes, max_windows = hd.agree_sizes(int(off[-1]), n_w, dev)
 
     def step():
         ds.run()
         db.run()
         if world > 1:
-            send_bases[:db.bases.numel()].copy_(db.bases[:send_bases.numel()])
-            dist.all_gather_into_tensor(all_len, db.len[:n_w])
-            dist.all_gather_into_tensor(all_bases, send_bases)
+            hd.gather_consensus(db.bases, db.len[:n_w], max_bytes, max_windows)
 
     def fence():
         if world > 1:
