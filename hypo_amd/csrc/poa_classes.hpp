@@ -5,7 +5,7 @@
 //   1     32 (2)                      4         79      84    4        6720 (4)       640        768   64   int16  u8   LDS  ~9 KB
 //   2     64 (1)                      2         127     126   6        13440 (4)      1024       1536  96   int16  u8   LDS  ~16.5 KB
 //   3     64 (1)                      2         127     254   8        32768 (8)      4096       4096  254  int16  u8   LDS  ~59 KB
-//   4     64 (1)                      8         511     4000  16       2097152 (8)    65536      16384 1024 int32  u16  HBM scratch ~2.7 MB / resident group
+//   4     64 (1)                      16        1023    4000  16       4194304 (8)    2097152    16384 1024 int32  u16  HBM scratch ~13.6 MB / resident group (ring >= 2048 rows; also LONG windows)
 // The kernel is VALU-issue bound (profiles/): a wavefront therefore carries 4 / 2 small windows side by side
 // (16- / 32-lane groups with group-uniform control flow), so one instruction stream advances several windows.
 // A window that does not fit class c (too many nodes / in-edges / cells, a predecessor row that already left
@@ -21,7 +21,7 @@ typedef PoaCfg<16, 4, 47, 48, 4, 2208, 384, 384, 48, int16_t, uint8_t> PoaClass0
 typedef PoaCfg<32, 4, 79, 84, 4, 6720, 640, 768, 64, int16_t, uint8_t> PoaClass1;
 typedef PoaCfg<64, 2, 127, 126, 6, 13440, 1024, 1536, 96, int16_t, uint8_t> PoaClass2;
 typedef PoaCfg<64, 2, 127, 254, 8, 32768, 4096, 4096, 254, int16_t, uint8_t> PoaClass3;
-typedef PoaCfg<64, 8, 511, 4000, 16, 1 << 21, 1 << 16, 16384, 1024, int32_t, uint16_t> PoaClass4;
+typedef PoaCfg<64, 16, 1023, 4000, 16, 1 << 22, 1 << 21, 16384, 1024, int32_t, uint16_t, 1 << 18> PoaClass4;   // + 256 K path ids: runs LONG windows
 constexpr int kNumPoaClasses = 5;
 }  // namespace hypo
 

@@ -32,6 +32,7 @@
 // a ring of score rows, the graph, and the window's packed arms staged once from HBM.
 // Compiled by hipcc for gfx950 and, with HYPO_EMU, by g++ for the lockstep emulator used in tests/.
 #pragma once
+#include <math.h>
 #include "grp.hpp"
 #include "../../include/hypo_gpu.h"
 
@@ -65,8 +66,9 @@ struct PoaParams {
 };
 
 template <int GW_, int CPL_, int LCAP_, int NMAX_, int KIN_, int DIRCELLS_, int RINGCELLS_, int ARMBYTES_,
-          int SEQMAX_, class ScoreT, class IdT>
+          int SEQMAX_, class ScoreT, class IdT, int PATHCAP_ = 0>
 struct PoaCfg {
+    static constexpr int PATHCAP = PATHCAP_;    // node ids of the sequences' paths (LONG windows only; 0 = class cannot run them)
     static constexpr int GW = GW_;              // lanes per window
     static constexpr int CPL = CPL_;            // matrix columns per lane
     static constexpr int LMAX = LCAP_;          // longest sequence incl. markers
@@ -85,7 +87,7 @@ struct PoaCfg {
     typedef IdT id_t;
     static constexpr int ID_NONE = (IdT)~(IdT)0;
     static_assert(LCAP_ <= GW_ * CPL_ - 1, "columns 0..L must fit the group");
-    static_assert(LCAP_ <= 511 && ARMBYTES_ <= 32767 && SEQMAX_ <= 32767, "sequence table entry is 32 bits");
+    static_assert(LCAP_ <= 1023 && ARMBYTES_ <= 32767 && SEQMAX_ <= 32767, "sequence table entry is 32 bits");
     static_assert(KIN_ + 6 <= GW_, "dependency lanes");
     static_assert(KIN_ <= 62, "direction byte holds the pred index in 6 bits");
     static_assert((int)sizeof(ScoreT) * RINGCELLS_ + DIRBYTES >= 14 * NMAX_, "consensus scratch aliases ring+dir");
@@ -118,7 +120,17 @@ struct PoaLayout {   // byte offsets inside a group's memory slice
     static constexpr int oMark = oNal + align_up<16>(Cfg::NMAX);
     static constexpr int oSeq = oMark + align_up<16>(Cfg::NMAX);
     static constexpr int oArms = oSeq + align_up<16>(Cfg::LMAX + 1);
-    static constexpr int BYTES = oArms + align_up<16>(Cfg::ARMBYTES);
+    // LONG windows (generate_consensus_custom needs every sequence's path through the graph)
+    static constexpr int LONGSEQ = Cfg::PATHCAP ? Cfg::SEQMAX : 0;
+    static constexpr int LONGN = Cfg::PATHCAP ? Cfg::NMAX : 0;
+    static constexpr int oPathNodes = oArms + align_up<16>(Cfg::ARMBYTES);
+    static constexpr int oPathOff = oPathNodes + align_up<16>(Cfg::PATHCAP * (int)sizeof(id_t));
+    static constexpr int oPathLen = oPathOff + align_up<16>(LONGSEQ * 4);
+    static constexpr int oPathMult = oPathLen + align_up<16>(LONGSEQ * 2);
+    static constexpr int oMsa = oPathMult + align_up<16>(LONGSEQ * 2);
+    static constexpr int oDst = oMsa + align_up<16>(LONGN * 2);
+    static constexpr int oCons = oDst + align_up<16>(LONGN * 4);
+    static constexpr int BYTES = oCons + align_up<16>(LONGN);
 };
 
 template <class Cfg>
@@ -140,13 +152,12 @@ struct Poa {
     struct alignas(sizeof(score_t) * CPL) Pack { score_t v[CPL]; };
     struct alignas(NIB ? CPL / 2 : CPL) DPack { uint8_t v[NIB ? CPL / 2 : CPL]; };
     // sequence table entry: bits 0-14 src (LDS offset of the staged bytes, or arm index), 15 "byte-identical to
-    // the previous entry" (set for staged arms only), 16-24 length,
-    // 25 head marker J, 26 tail marker O, 27-28 mode (0 NW, 1 LOV, 2 ROV), 29 four-bit packing,
-    // 30-31 where (0 staged in LDS, 1 arms2 in HBM, 2 draft4 in HBM)
-    HD static uint32_t seq_ent(uint32_t src, uint32_t len, bool head, bool tail, int mode, bool four, int where) {
+    // the previous entry" (set for staged arms only), 16-25 length, 26 head marker J, 27 tail marker O,
+    // 28-29 mode (0 NW, 1 LOV, 2 ROV), 30-31 where (0 staged in LDS, 1 arms2 in HBM, 2 draft4 in HBM: 4-bit packed)
+    HD static uint32_t seq_ent(uint32_t src, uint32_t len, bool head, bool tail, int mode, bool /*four*/, int where) {
         const uint32_t mc = mode == MODE_NW ? 0u : (mode == MODE_LOV ? 1u : 2u);
-        return (src & 0x7fffu) | (len << 16) | ((head ? 1u : 0u) << 25) | ((tail ? 1u : 0u) << 26) | (mc << 27) |
-               ((four ? 1u : 0u) << 29) | ((uint32_t)where << 30);
+        return (src & 0x7fffu) | (len << 16) | ((head ? 1u : 0u) << 26) | ((tail ? 1u : 0u) << 27) | (mc << 28) |
+               ((uint32_t)where << 30);
     }
 
     const Grp<GW>& g;
@@ -155,6 +166,8 @@ struct Poa {
     score_t* ring; uint8_t* dir; uint32_t* rowmeta; uint32_t* seqtab; uint16_t* inw; int16_t* posnode;
     id_t *prow, *inp, *al, *r2n, *n2r, *stack;
     uint8_t *code, *nin, *nout, *nal, *mark, *seq, *armbuf;
+    id_t* pathnodes; uint32_t* pathoff; uint16_t *pathlen, *pathmult, *msa; uint32_t* dstcnt; uint8_t* consbuf;
+    int n_paths, path_used, head_first;
     // group-uniform state
     int n_nodes; int L; bool topo_dirty; bool meta_dirty; int maxdelta;
     int tb_steps; int tb_fv;
@@ -173,6 +186,10 @@ struct Poa {
         nin = (uint8_t*)(mem + Lay::oNin); nout = (uint8_t*)(mem + Lay::oNout);
         nal = (uint8_t*)(mem + Lay::oNal); mark = (uint8_t*)(mem + Lay::oMark);
         seq = (uint8_t*)(mem + Lay::oSeq); armbuf = (uint8_t*)(mem + Lay::oArms);
+        pathnodes = (id_t*)(mem + Lay::oPathNodes); pathoff = (uint32_t*)(mem + Lay::oPathOff);
+        pathlen = (uint16_t*)(mem + Lay::oPathLen); pathmult = (uint16_t*)(mem + Lay::oPathMult);
+        msa = (uint16_t*)(mem + Lay::oMsa); dstcnt = (uint32_t*)(mem + Lay::oDst); consbuf = (uint8_t*)(mem + Lay::oCons);
+        n_paths = 0; path_used = 0; head_first = 0;
         n_nodes = 0; L = 0; topo_dirty = false; meta_dirty = true; maxdelta = 0; tb_steps = 0; tb_fv = 0;
         cells = 0; aligns = 0; reused = 0; rows_done = 0; topo_runs = 0; last_changed = true;
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
@@ -184,23 +201,24 @@ struct Poa {
     // (Window.cpp:87-130: [draft if no internal arm] internal.. | prefix arms reversed | suffix arms;
     // zero-length arms are skipped).  Packed arm bytes are staged once into `armbuf` (one exposed HBM
     // latency per window instead of one per arm); what does not fit is read in place.
-    HD int build_seqtab(const HypoWindow& W, int* n_seq_out, bool* added_out) {
+    HD int build_seqtab(const HypoWindow& W, bool is_long, int* n_seq_out, bool* added_out) {
         const uint32_t a0 = W.first_arm;
         const int ni = (int)W.n_internal, np = (int)W.n_prefix, ns = (int)W.n_suffix;
         const int narm = ni + np + ns;
-        const int base = ni == 0 ? 1 : 0;                  // slot 0 = draft backbone
+        const int base = (ni == 0 || is_long) ? 1 : 0;     // slot 0 = draft backbone (LONG: always, Window.cpp:173-178)
         if (narm + base > Cfg::SEQMAX) return RES_OVERFLOW;
-        if ((int)W.draft_len + 2 > Cfg::LMAX && base) return RES_OVERFLOW;
+        if ((int)W.draft_len + (is_long ? 0 : 2) > Cfg::LMAX && base) return RES_OVERFLOW;
         g.sync();
-        if (base && g.lane == 0) seqtab[0] = seq_ent(0, W.draft_len, true, true, MODE_NW, true, 2);
+        if (base && g.lane == 0) seqtab[0] = seq_ent(0, W.draft_len, !is_long, !is_long, MODE_NW, true, 2);
         bool over = false, any_len = false;
         for (int t = g.lane; t < narm; t += GW) {
             int a, mode; bool head, tail;                  // consumption slot t -> arm index
-            if (t < ni) { a = t; mode = MODE_NW; head = true; tail = true; }
+            if (is_long) { a = t; mode = MODE_NW; head = false; tail = false; }   // all kNW, insertion order, no markers (Window.cpp:179-206)
+            else if (t < ni) { a = t; mode = MODE_NW; head = true; tail = true; }
             else if (t < ni + np) { a = ni + (np - 1 - (t - ni)); mode = MODE_LOV; head = true; tail = false; }
             else { a = t; mode = MODE_ROV; head = false; tail = true; }
             const uint32_t len = P.arm_len[a0 + a];
-            if (len + 2 > (uint32_t)Cfg::LMAX) { over = true; continue; }
+            if (len + (is_long ? 0u : 2u) > (uint32_t)Cfg::LMAX) { over = true; continue; }
             if (len) any_len = true;
             seqtab[base + t] = seq_ent((uint32_t)a, len, head, tail, mode, false, 1);
         }
@@ -211,11 +229,11 @@ struct Poa {
             int used = 0;
             for (int t = 0; t < narm; ++t) {
                 const uint32_t e = seqtab[base + t];
-                const int nb = (int)(((e >> 16) & 0x1ff) + 3) >> 2;
+                const int nb = (int)(((e >> 16) & 0x3ff) + 3) >> 2;
                 if (used + nb <= Cfg::ARMBYTES) {
                     // keep the arm index in posnode-free scratch: staged entries remember it via `stack`
                     stack[t] = (id_t)(e & 0x7fff);
-                    seqtab[base + t] = (e & 0x3fff0000u) | (uint32_t)used;        // where = 0
+                    seqtab[base + t] = (e & 0x3fff0000u) | (uint32_t)used;        // where = 0 (bits 30-31 cleared)
                     used += nb;
                 }
             }
@@ -224,7 +242,7 @@ struct Poa {
         for (int t = g.lane; t < narm; t += GW) {           // one lane copies one arm: the loads of a lane pipeline
             const uint32_t e = seqtab[base + t];
             if ((e >> 30) == 0) {
-                const int nb = (int)(((e >> 16) & 0x1ff) + 3) >> 2;
+                const int nb = (int)(((e >> 16) & 0x3ff) + 3) >> 2;
                 const uint8_t* src = P.arms2 + P.arm_off[a0 + (uint32_t)stack[t]];
                 uint8_t* dst = armbuf + (e & 0x7fff);
                 for (int b = 0; b < nb; ++b) dst[b] = src[b];
@@ -235,7 +253,7 @@ struct Poa {
         for (int t = g.lane + 1; t < narm; t += GW) {
             const uint32_t a = seqtab[base + t], b = seqtab[base + t - 1];
             if (((a ^ b) & 0xffff0000u) == 0 && (a >> 30) == 0) {
-                const int nb = (int)(((a >> 16) & 0x1ff) + 3) >> 2;
+                const int nb = (int)(((a >> 16) & 0x3ff) + 3) >> 2;
                 const uint8_t* pa = armbuf + (a & 0x7fff);
                 const uint8_t* pb = armbuf + (b & 0x7fff);
                 bool same = true;
@@ -251,10 +269,11 @@ struct Poa {
 
     HD int load_seq(const HypoWindow& W, int s, int* mode_out) {
         const uint32_t e = seqtab[s];
-        const bool head = (e >> 25) & 1, tail = (e >> 26) & 1, four = (e >> 29) & 1;
-        const int mc = (int)((e >> 27) & 3), where = (int)(e >> 30);
+        const bool head = (e >> 26) & 1, tail = (e >> 27) & 1;
+        const int mc = (int)((e >> 28) & 3), where = (int)(e >> 30);
+        const bool four = where == 2;
         *mode_out = mc == 0 ? MODE_NW : (mc == 1 ? MODE_LOV : MODE_ROV);
-        const int len = (int)((e >> 16) & 0x1ff);
+        const int len = (int)((e >> 16) & 0x3ff);
         if (len == 0) { L = 0; return RES_OK; }
         L = len + (head ? 1 : 0) + (tail ? 1 : 0);
         if (L > Cfg::LMAX) return RES_OVERFLOW;
@@ -522,6 +541,7 @@ struct Poa {
                 if (t < fv - 1) nout[id] = 1;
             }
             head = n_nodes + fv - 1;
+            head_first = n_nodes;
             n_nodes += fv;
             changed = true;
         }
@@ -798,6 +818,127 @@ struct Poa {
         return len;
     }
 
+    // ---- LONG windows: Window::generate_consensus_long + curate (src/Window.cpp:156-254) ----------------
+    HD static void atomic_inc(uint32_t* p, uint32_t v) {
+#ifdef HYPO_EMU
+        *p += v;
+#else
+        atomicAdd(p, v);
+#endif
+    }
+    // path of the sequence just added (graph.cpp:30-41: successor(label) follows exactly this path)
+    HD int record_path(int fv) {
+        if (n_paths >= Cfg::SEQMAX || path_used + L > Cfg::PATHCAP) return RES_OVERFLOW;
+        for (int q = g.lane; q < L; q += GW) pathnodes[path_used + q] = (id_t)(q < fv ? head_first + q : (int)posnode[q]);
+        if (g.lane == 0) { pathoff[n_paths] = (uint32_t)path_used; pathlen[n_paths] = (uint16_t)L; pathmult[n_paths] = 1; }
+        n_paths += 1; path_used += L;
+        g.sync();
+        return RES_OK;
+    }
+    HD int load_codes(const uint8_t* src, int len) {       // backbone of round 2: the curated consensus
+        L = len;
+        if (L > Cfg::LMAX) return RES_OVERFLOW;
+        for (int t = g.lane; t < L; t += GW) seq[t] = src[t];
+        g.sync();
+        return RES_OK;
+    }
+    HD int long_step(int m, int n, int gp) {
+        int rc = add_sequence_step(MODE_NW, m, n, gp);
+        if (rc != RES_OK) return rc;
+        return record_path(tb_steps == 0 ? L : tb_fv);
+    }
+    HD int run_long(uint32_t w, const HypoWindow& W) {
+        const int m = P.lr_m, n = P.lr_n, gp = P.lr_g;
+        const uint8_t* d4 = P.draft4 + W.draft_off;
+        int n_seq = 0; bool added = false;
+        int rc = build_seqtab(W, true, &n_seq, &added);
+        if (rc != RES_OK) return rc;
+        if (!added) return emit_draft(w, d4, (int)W.draft_len);      // Window.cpp:233-235
+        const unsigned thr = (unsigned)floorf((float)W.n_internal * 0.4f);   // Window.cpp:28,245
+        int conslen = 0;
+        for (int round = 0; round < 2; ++round) {
+            n_nodes = 0; topo_dirty = false; meta_dirty = true; n_paths = 0; path_used = 0; last_changed = true;
+            bool prev_aligned = false;
+            int s = 0;
+            if (round == 1) {                                // backbone = round-1 consensus (skipped when empty)
+                s = 1;
+                if (conslen > 0) {
+                    if ((rc = load_codes(consbuf, conslen)) != RES_OK) return rc;
+                    if ((rc = long_step(m, n, gp)) != RES_OK) return rc;
+                }
+            }
+            while (s < n_seq) {
+                if (prev_aligned && !last_changed && tb_steps != 0 && tb_fv == 0) {
+                    int c = 0;
+                    while (s < n_seq && same_as_previous(s)) { ++c; ++s; }
+                    if (c) {
+                        cells += (uint64_t)c * (uint64_t)(n_nodes + 1) * (L + 1); aligns += c; reused += c;
+                        if ((rc = readd_alignment(c)) != RES_OK) return rc;
+                        if (g.lane == 0) pathmult[n_paths - 1] = (uint16_t)(pathmult[n_paths - 1] + c);
+                        g.sync();
+                        if (s >= n_seq) break;
+                    }
+                }
+                int mode;
+                if ((rc = load_seq(W, s, &mode)) != RES_OK) return rc;
+                ++s;
+                if (L == 0) { prev_aligned = false; continue; }
+                if ((rc = long_step(m, n, gp)) != RES_OK) return rc;
+                prev_aligned = true;
+            }
+            // generate_consensus_custom (graph.cpp:533-568)
+            int16_t* path;
+            const int len = consensus(&path);
+            if (len < 1) return RES_UNDEFINED;
+            // MSA column of every node: cliques share a column (graph.cpp:371-388)
+            if (g.lane == 0) {
+                int col = 0;
+                for (int i = 0; i < n_nodes; ++i) {
+                    const int u = r2n[i];
+                    const int ka = nal[u];
+                    msa[u] = (uint16_t)col;
+                    for (int j = 0; j < ka; ++j) msa[r2n[++i]] = (uint16_t)col;
+                    ++col;
+                }
+            }
+            for (int c = g.lane; c < len; c += GW) dstcnt[c] = 0;
+            g.sync();
+            for (int sidx = g.lane; sidx < n_paths; sidx += GW) {   // one lane walks one sequence's path
+                const id_t* pn = pathnodes + pathoff[sidx];
+                const int pl = pathlen[sidx]; const uint32_t mult = pathmult[sidx];
+                int c = 0;
+                for (int q = 0; q < pl; ++q) {
+                    const int v = pn[q];
+                    const int mv = msa[v];
+                    while (c < len && (int)msa[path[len - 1 - c]] < mv) ++c;
+                    if (c >= len) break;
+                    const int cn = path[len - 1 - c];
+                    if ((int)msa[cn] == mv && code[v] == code[cn]) atomic_inc(&dstcnt[c], mult);
+                }
+            }
+            g.sync();
+            // curate (Window.cpp:239-254): keep position i iff dst[i] >= floor(n_internal * 0.4f)
+            int o = 0;
+            for (int base = 0; base < len; base += GW) {
+                const int c = base + g.lane;
+                const bool keep = c < len && dstcnt[c] >= thr;
+                const uint64_t kb = g.ballot(keep);
+                // consbuf may alias nothing else; positions only move left, chunk by chunk
+                const int cd = c < len ? (int)code[path[len - 1 - c]] : 0;
+                g.sync();
+                if (keep) consbuf[o + popc64(kb & ((1ull << g.lane) - 1ull))] = (uint8_t)cd;
+                o += popc64(kb);
+            }
+            conslen = o;
+            g.sync();
+        }
+        const uint64_t oo = P.out_off[w], cap = P.out_off[w + 1] - oo;
+        if ((uint64_t)conslen > cap) { finish(w, HYPO_ST_CONS_OVERFLOW, (uint32_t)conslen); return RES_OK; }
+        for (int t = g.lane; t < conslen; t += GW) P.out_bases[oo + t] = "ACGTNJO"[consbuf[t]];
+        finish(w, HYPO_ST_OK, (uint32_t)conslen);
+        return RES_OK;
+    }
+
     // ---- outputs -----------------------------------------------------------------------------------
     HD void finish(uint32_t w, int status, uint32_t len) const {
         if (g.lane == 0) { P.out_len[w] = len; P.out_status[w] = (uint8_t)status; }
@@ -819,7 +960,7 @@ struct Poa {
         const uint8_t* d4 = P.draft4 + W.draft_off;
         n_nodes = 0; topo_dirty = false; meta_dirty = true;
         int n_seq = 0; bool added = false;
-        int rc = build_seqtab(W, &n_seq, &added);
+        int rc = build_seqtab(W, false, &n_seq, &added);
         if (rc != RES_OK) return rc;
         bool prev_aligned = false;                           // the previous non-reused sequence went through align()
         int s = 0;
@@ -862,7 +1003,10 @@ struct Poa {
         const uint32_t ne = W.n_internal + W.n_prefix + W.n_suffix;
         if (W.n_empty > ne) { finish(w, HYPO_ST_OK, 0); return RES_OK; }
         if (ne < 2) return emit_draft(w, P.draft4 + W.draft_off, (int)W.draft_len);
-        if (W.type != HYPO_WIN_SHORT) return RES_UNSUPPORTED;
+        if (W.type != HYPO_WIN_SHORT) {
+            if (Cfg::PATHCAP == 0) return RES_UNSUPPORTED;   // re-queued to a class that keeps sequence paths
+            return run_long(w, W);
+        }
         return run_short(w, W);
     }
 };

@@ -7,7 +7,7 @@ namespace hypo {
 
 constexpr int kFirstGlobalClass = 4;     // classes >= this keep their state in HBM scratch, not LDS
 constexpr int kFirstLongClass = 4;       // LONG windows (<= 500 bp, ~1.3 k nodes) start here
-constexpr int kMaxGlobalGroups = 512;    // resident groups of the HBM-scratch classes
+constexpr int kMaxGlobalGroups = 256;    // resident groups of the HBM-scratch classes
 constexpr size_t kPoaHeaderBytes = 8192; // count[8] | head[8] @64 | HypoPoaStats @128 | phase cycles @512 | hist @2048 | start @4096 | cursor @6144
 
 constexpr int kPlanBuckets = 64;         // cost buckets per class of the plan's counting sort

@@ -33,7 +33,6 @@ def _short_only(items):
 def test_goldens_host_api(gpu, name):
     total = 0
     for scores, items in gu.windows_by_scores(name).items():
-        items = _short_only(items)
         if not items:
             continue
         cons, st = gpu.poa_consensus(build_batch([w for w, _, _ in items]), scores)
@@ -45,7 +44,8 @@ def test_goldens_host_api(gpu, name):
 
 
 def test_goldens_device_api(gpu):
-    items = _short_only(gu.windows_by_scores("windows_real_c1.jsonl.gz")[abi.DEFAULT_SCORES])
+    items = gu.windows_by_scores("windows_real_c1.jsonl.gz")[abi.DEFAULT_SCORES] + \
+        gu.windows_by_scores("windows_real_long.jsonl.gz")[abi.DEFAULT_SCORES]
     db = gpu.device_batch(build_batch([w for w, _, _ in items]))
     db.run()
     cons, st = db.consensus()
@@ -131,3 +131,36 @@ def test_escalation_between_classes(gpu, oracle_lib):
     s = gpu.last_stats()
     assert s["n_failed"] == 0
     assert sum(s["n_class"]) == 200
+
+
+def test_long_windows_vs_oracle(gpu, oracle_lib):
+    """LONG windows (two-round curate) of random noisy arms, incl. arms longer than the window."""
+    import random
+    rng = random.Random(3)
+
+    def mut(s, e):
+        out = []
+        for c in s:
+            x = rng.random()
+            if x < e / 3:
+                continue
+            out.append(rng.choice("ACGT") if x < 2 * e / 3 else c)
+            if rng.random() < e / 3:
+                out.append(rng.choice("ACGT"))
+        return "".join(out) or "A"
+    ws = []
+    for _ in range(24):
+        L = rng.choice([200, 350, 500])
+        truth = "".join(rng.choice("ACGT") for _ in range(L))
+        w = TextWindow(mut(truth, 0.03), is_long=True)
+        for _ in range(rng.choice([3, 12, 30])):
+            s = mut(truth, 0.1)
+            k = rng.random()
+            (w.internal if k < 0.7 else w.prefix if k < 0.85 else w.suffix).append(
+                s if k < 0.7 else (s[:rng.randint(len(s) // 2, len(s))] if k < 0.85 else s[rng.randint(0, len(s) // 2):]))
+        ws.append(w)
+    b = build_batch(ws)
+    cons, st = gpu.poa_consensus(b)
+    ocons, ost, _, _ = oracle_lib.poa_batch(b)
+    assert list(st) == list(ost) == [0] * len(ws)
+    assert cons == ocons

@@ -55,3 +55,16 @@ def test_class4_wide(emu):
     cons, st, res, _, _ = emu.poa_batch(b, 4)
     for (w, want, tag), got, r in zip(items, cons, res):
         assert r == emu_util.RES_OK and got == want, tag
+
+
+def test_class4_long_windows(emu):
+    """LONG windows: all-kNW, no markers, generate_consensus_custom + curate, two rounds (Window.cpp:156-254)."""
+    n = 0
+    for name in ("windows_synth.jsonl.gz", "windows_real_long.jsonl.gz"):
+        items = [it for it in gu.windows_by_scores(name)[(5, -4, -8, 3, -5, -4)] if it[0].is_long][:8]
+        b = build_batch([w for w, _, _ in items])
+        cons, st, res, _, _ = emu.poa_batch(b, 4)
+        for (w, want, tag), got, r in zip(items, cons, res):
+            assert r == emu_util.RES_OK and got == want, tag
+            n += 1
+    assert n >= 12
