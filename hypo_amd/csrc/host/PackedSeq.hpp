@@ -1,0 +1,86 @@
+// PackedSeq.hpp — host mirror of hypo::PackedSeq<NB> (reference: include/PackedSeq.hpp:80-160,
+// src/PackedSeq.cpp:58-262).  Same public surface and the same byte layout (MSB-first, NB bits per base,
+// last byte zero padded), written from scratch around one std::vector<uint8_t>; the bytes are what
+// HypoWindowBatch.draft4 / arms2 carry to the device unchanged.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+namespace hypo {
+
+// cNt4Table (include/globalDefs.hpp:160-178): A/a 0, C/c 1, G/g 2, T/t/U/u 3, bytes 0..3 themselves, else 4
+inline uint8_t nt4(unsigned char c) {
+    switch (c) {
+        case 'A': case 'a': case 0: return 0;
+        case 'C': case 'c': case 1: return 1;
+        case 'G': case 'g': case 2: return 2;
+        case 'T': case 't': case 'U': case 'u': case 3: return 3;
+        default: return 4;
+    }
+}
+
+template <int NB>
+class PackedSeq {
+    static_assert(NB == 2 || NB == 4, "2 or 4 bits per base");
+    static constexpr int PER_BYTE = 8 / NB;
+    static constexpr unsigned MASK = (1u << NB) - 1u;
+
+public:
+    PackedSeq() = default;
+    explicit PackedSeq(const std::string& text) { assign(text.data(), text.size()); }
+    // [left, right) of another packed sequence of the same width (PackedSeq.cpp:155-194)
+    PackedSeq(const PackedSeq& ps, size_t left, size_t right) {
+        resize(right - left);
+        for (size_t i = left; i < right; ++i) put(i - left, ps.enc_base_at(i));
+    }
+    // 2-bit copy of [left, right) of a 4-bit sequence; non-ACGT is fatal like the reference (PackedSeq.cpp:197-227)
+    template <int MB>
+    PackedSeq(const PackedSeq<MB>& ps, size_t left, size_t right) {
+        static_assert(NB == 2 && MB == 4, "only 4 -> 2 bit conversion exists");
+        resize(right - left);
+        for (size_t i = left; i < right; ++i) {
+            const uint8_t b = ps.enc_base_at(i);
+            if (b > 3) { std::fprintf(stderr, "[Hypo::PackedSeq] Error: Wrong base (Can not pack in 2 bits): Base code at %zu in a sequence is not A, C, G, or T !\n", i); std::exit(1); }
+            put(i - left, b);
+        }
+    }
+
+    bool is_valid() const { return _valid; }
+    size_t get_seq_size() const { return _len; }
+    uint8_t enc_base_at(size_t i) const { return (uint8_t)((_data[i / PER_BYTE] >> (8 - NB - NB * (int)(i % PER_BYTE))) & MASK); }
+    char base_at(size_t i) const { const uint8_t c = enc_base_at(i); return "ACGTN"[c < 4 ? c : 4]; }
+    std::string unpack() const { return unpack(0, _len); }
+    std::string unpack(size_t left, size_t right) const {
+        std::string s; s.reserve(right - left);
+        for (size_t i = left; i < right; ++i) s.push_back(base_at(i));
+        return s;
+    }
+    // raw PackedSeq bytes for the C-ABI batch
+    const uint8_t* data() const { return _data.data(); }
+    size_t byte_size() const { return _data.size(); }
+
+private:
+    void resize(size_t n) { _len = n; _data.assign((n + PER_BYTE - 1) / PER_BYTE, 0); }
+    void put(size_t i, uint8_t code) { _data[i / PER_BYTE] |= (uint8_t)(code << (8 - NB - NB * (int)(i % PER_BYTE))); }
+    void assign(const char* s, size_t n) {
+        if (n > 0xffffffffu) { std::fprintf(stderr, "[Hypo::PackedSeq] Error: Length exceed limit: The length of a sequence is %zu which exceeds the limit of %u !\n", n, 0xffffffffu); std::exit(1); }
+        resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            const uint8_t b = nt4((unsigned char)s[i]);
+            if (NB == 2 && b > 3) {       // PackedSeq.cpp:75-79: marks the sequence invalid and stops packing
+                std::fprintf(stderr, "[Hypo::PackedSeq] Error: Wrong base (Can not pack in 2 bits): Base %c in a sequence is not A, C, G, or T !\n", s[i]);
+                _valid = false;
+                break;
+            }
+            put(i, b);
+        }
+    }
+    std::vector<uint8_t> _data;
+    size_t _len = 0;
+    bool _valid = true;
+};
+
+}  // namespace hypo

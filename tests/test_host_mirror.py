@@ -1,0 +1,66 @@
+"""The C++ host mirror of the reference's object surface (hypo_amd/csrc/host): PackedSeq and Filter on the
+CPU against goldens of the real reference; Window / Contig through the device on the GPU box."""
+import numpy as np
+import pytest
+
+from hypo_amd import abi, host, sim
+from hypo_amd.batch import TextWindow
+import golden_util as gu
+
+
+@pytest.fixture(scope="module")
+def mirror():
+    return host.HostMirror()
+
+
+def test_packedseq_roundtrip_goldens(mirror):
+    for c in gu.load_json("packedseq_cases.json.gz"):
+        assert mirror.pack_roundtrip(c["nb"], c["text"]) == c["unpacked"]
+
+
+def test_filter_matches_reference_kept_flags(mirror):
+    """Long-arm minimizer filter (include/Filter.hpp) against the kept flags the real Window recorded."""
+    n = 0
+    for r in gu.load_jsonl("windows_synth.jsonl.gz"):
+        if not r["long"]:
+            continue
+        arms = r["internal"] + r["prefix"] + r["suffix"]
+        assert mirror.filter(r["draft"], arms) == r["kept"], r["tag"]
+        n += len(arms)
+    assert n > 100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batched", [True, False])
+def test_window_surface_goldens(mirror, batched):
+    for name in gu.WINDOW_FILES:
+        for scores, _ in gu.windows_by_scores(name).items():
+            recs = [r for r in gu.load_jsonl(name) if tuple(r["scores"]) == scores]
+            recs = recs if batched else recs[:40]
+            wins = [gu.to_window(r, filtered=False) for r in recs]        # LONG: unfiltered arms, the mirror filters
+            mirror.set_scores(scores)
+            cons, kept = mirror.windows(wins, batched=batched)
+            assert cons == [r["consensus"] for r in recs], (name, scores)
+            k = 0
+            for r in recs:
+                narm = len(r["internal"]) + len(r["prefix"]) + len(r["suffix"])
+                if r.get("kept") is not None:
+                    assert kept[k:k + narm] == r["kept"]
+                k += narm
+    mirror.set_scores(abi.DEFAULT_SCORES)
+
+
+@pytest.mark.gpu
+def test_contig_scan_rank_select(mirror, oracle_lib):
+    codes, p4 = sim.random_contig(100001, seed=4, n_frac=0.001)
+    k = 11
+    bits = sim.solid_bitset(codes, k)
+    seq = np.frombuffer(b"ACGTN", dtype=np.uint8)[codes].tobytes().decode()
+    ow, okids, orank, ons = oracle_lib.solid_scan(p4, codes.size, k, bits)
+    pos = np.flatnonzero(np.unpackbits(ow.view(np.uint8), bitorder="little")[:codes.size])
+    rq = [0, 1, 63, 64, 65, 5000, 100000, 100001]
+    sq = [1, 2, ons // 2, ons]
+    n, kids, ra, sa = mirror.contig_scan(seq, k, bits, rq, sq)
+    assert n == ons and (kids == okids).all()
+    assert ra.tolist() == [int((pos < q).sum()) for q in rq]
+    assert sa.tolist() == [int(pos[i - 1]) for i in sq]
