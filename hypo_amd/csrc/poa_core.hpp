@@ -275,7 +275,7 @@ struct Poa {
         *mode_out = mc == 0 ? MODE_NW : (mc == 1 ? MODE_LOV : MODE_ROV);
         const int len = (int)((e >> 16) & 0x3ff);
         if (len == 0) { L = 0; return RES_OK; }
-        L = len + (head ? 1 : 0) + (tail ? 1 : 0);
+        L = g.uniform(len + (head ? 1 : 0) + (tail ? 1 : 0));   // group-uniform by construction; tells the compiler (scalar control flow for 64-lane groups)
         if (L > Cfg::LMAX) return RES_OVERFLOW;
         const uint8_t* p;
         if (where == 0) p = armbuf + (e & 0x7fff);
@@ -341,6 +341,7 @@ struct Poa {
     HD int align(int mode, int m, int n, int gp) {
         tb_steps = 0; tb_fv = L;
         if (n_nodes == 0 || L == 0) return RES_OK;
+        n_nodes = g.uniform(n_nodes);
         const int W = L + 1;
         const int S = (W + CPL - 1) / CPL * CPL;           // row stride (even when NIB)
         if (n_nodes * S > Cfg::DIRCELLS) return RES_OVERFLOW;
@@ -359,9 +360,9 @@ struct Poa {
         HYPO_UNROLL
         for (int c = 0; c < CPL; ++c) { const int j = j0 + c; sq[c] = (j >= 1 && j <= L) ? (int)seq[j - 1] : (int)C_NONE; }
 
-        int last[CPL];                                      // most recently computed row (registers)
+        int jg[CPL], last[CPL];                              // j*g per column; most recently computed row (registers)
         HYPO_UNROLL
-        for (int c = 0; c < CPL; ++c) last[c] = (j0 + c) * gp;   // row 0: H[0][j] = j*g (sisd..cpp:197-199,230-232)
+        for (int c = 0; c < CPL; ++c) { jg[c] = (j0 + c) * gp; last[c] = jg[c]; }   // row 0: H[0][j] = j*g (sisd..cpp:197-199,230-232)
 
         const int le = L / CPL, ce = L % CPL;               // owner of the last column
         int best = NEG, best_i = -1;
@@ -377,11 +378,14 @@ struct Poa {
             const int cd = (int)(meta & 0xff), k = (int)((meta >> 8) & 0xff);
             const bool sink = (meta >> 16) & 1;
             const int p0 = (int)(meta >> 17);                // 0 when k == 0 (virtual source row)
-            int D[CPL], U[CPL], pD[CPL], pU[CPL];
+            int D[CPL], U[CPL];
+            int codeD[CPL], codeU[CPL];                      // direction codes if the cell's value comes from D / U
+            const bool fastrow = p0 == i - 1;
+            const int fastcode = fastrow ? (int)DIR_FAST : dir_diag(0);
             {
                 int hp[CPL];
-                if (p0 == i - 1) { HYPO_UNROLL for (int c = 0; c < CPL; ++c) hp[c] = last[c]; }
-                else if (p0 == 0) { HYPO_UNROLL for (int c = 0; c < CPL; ++c) hp[c] = (j0 + c) * gp; }
+                if (fastrow) { HYPO_UNROLL for (int c = 0; c < CPL; ++c) hp[c] = last[c]; }
+                else if (p0 == 0) { HYPO_UNROLL for (int c = 0; c < CPL; ++c) hp[c] = jg[c]; }
                 else { int ps = slot - (i - p0); ps = ps < 0 ? ps + R : ps; load_ring(ps, S, hp); }
                 const int left = g.shfl_up1(hp[CPL - 1], NEG);
                 HYPO_UNROLL
@@ -389,22 +393,31 @@ struct Poa {
                     const int dsrc = c ? hp[c - 1] : left;
                     D[c] = dsrc + (sq[c] == cd ? m : n);
                     U[c] = hp[c] + gp;
-                    pD[c] = 0; pU[c] = 0;
                 }
             }
-            for (int p = 1; p < k; ++p) {
-                int hp[CPL];
-                int ps = slot - (i - (int)prow[r * KIN + p]); ps = ps < 0 ? ps + R : ps;
-                load_ring(ps, S, hp);
-                const int left = g.shfl_up1(hp[CPL - 1], NEG);
+            if (k > 1) {                                     // several predecessors: remember which one reaches each maximum first
+                int pD[CPL], pU[CPL];
                 HYPO_UNROLL
-                for (int c = 0; c < CPL; ++c) {
-                    const int dsrc = c ? hp[c - 1] : left;
-                    const int d = dsrc + (sq[c] == cd ? m : n);
-                    const int u = hp[c] + gp;
-                    if (d > D[c]) { D[c] = d; pD[c] = p; }   // strict: the first pred reaching the maximum wins
-                    if (u > U[c]) { U[c] = u; pU[c] = p; }
+                for (int c = 0; c < CPL; ++c) { pD[c] = 0; pU[c] = 0; }
+                for (int p = 1; p < k; ++p) {
+                    int hp[CPL];
+                    int ps = slot - (i - (int)prow[r * KIN + p]); ps = ps < 0 ? ps + R : ps;
+                    load_ring(ps, S, hp);
+                    const int left = g.shfl_up1(hp[CPL - 1], NEG);
+                    HYPO_UNROLL
+                    for (int c = 0; c < CPL; ++c) {
+                        const int dsrc = c ? hp[c - 1] : left;
+                        const int d = dsrc + (sq[c] == cd ? m : n);
+                        const int u = hp[c] + gp;
+                        if (d > D[c]) { D[c] = d; pD[c] = p; }   // strict: the first pred reaching the maximum wins
+                        if (u > U[c]) { U[c] = u; pU[c] = p; }
+                    }
                 }
+                HYPO_UNROLL
+                for (int c = 0; c < CPL; ++c) { codeD[c] = pD[c] == 0 ? fastcode : dir_diag(pD[c]); codeU[c] = dir_vert(pU[c]); }
+            } else {
+                HYPO_UNROLL
+                for (int c = 0; c < CPL; ++c) { codeD[c] = fastcode; codeU[c] = dir_vert(0); }
             }
             if (g.lane == 0) D[0] = NEG;                     // column 0 has no diagonal
             int v[CPL];
@@ -416,7 +429,7 @@ struct Poa {
                 int run = NEG;
                 HYPO_UNROLL
                 for (int c = 0; c < CPL; ++c) {
-                    const int x = v[c] - (j0 + c) * gp;
+                    const int x = v[c] - jg[c];
                     run = x > run ? x : run;
                     v[c] = run;
                 }
@@ -424,20 +437,17 @@ struct Poa {
                 HYPO_UNROLL
                 for (int c = 0; c < CPL; ++c) {
                     const int x = v[c] > ex ? v[c] : ex;
-                    v[c] = x + (j0 + c) * gp;
+                    v[c] = x + jg[c];
                 }
             }
             if (j0 < S) {
-                // the reference's traceback preference (sisd..cpp:370-428), resolved per cell
-                const bool fastrow = p0 == i - 1;
+                // the reference's traceback preference (sisd..cpp:370-428), resolved per cell with selects
                 int dc[CPL];
                 Pack pk;
-                const int fastcode = fastrow ? (int)DIR_FAST : dir_diag(0);
                 HYPO_UNROLL
-                for (int c = 0; c < CPL; ++c) {             // branch-free selects
-                    const int dgc = pD[c] == 0 ? fastcode : dir_diag(pD[c]);
-                    const int vtc = v[c] == U[c] ? dir_vert(pU[c]) : (int)DIR_HORIZ;
-                    dc[c] = v[c] == D[c] ? dgc : vtc;
+                for (int c = 0; c < CPL; ++c) {
+                    const int vtc = v[c] == U[c] ? codeU[c] : (int)DIR_HORIZ;
+                    dc[c] = v[c] == D[c] ? codeD[c] : vtc;
                     pk.v[c] = (score_t)v[c];
                 }
                 DPack dk;
@@ -456,7 +466,7 @@ struct Poa {
             HYPO_UNROLL
             for (int c = 0; c < CPL; ++c) last[c] = v[c];
             // end cell: first strictly greater in rank order (sisd..cpp:279-288,332-339)
-            if (g.lane == le && (mode == MODE_LOV || sink)) {
+            if ((mode == MODE_LOV || sink) && g.lane == le) {
                 int val = v[0];
                 HYPO_UNROLL
                 for (int c = 1; c < CPL; ++c) if (c == ce) val = v[c];
@@ -505,7 +515,7 @@ struct Poa {
             }
             ++steps;
         }
-        tb_steps = steps; tb_fv = j;
+        tb_steps = g.uniform(steps); tb_fv = g.uniform(j);
         g.sync();
         HYPO_TICK(PH_TRACE);
         return RES_OK;
@@ -588,7 +598,7 @@ struct Poa {
                 tgt = id;
             }
             if (act) posnode[q] = (int16_t)tgt;
-            n_nodes += tot;
+            n_nodes = g.uniform(n_nodes + tot);
             if (tot) changed = true;
         }
         if (g.any(over)) return RES_OVERFLOW;

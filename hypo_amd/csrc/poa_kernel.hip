@@ -31,15 +31,14 @@ template <class Cfg> __host__ __device__ constexpr ClassLimits limits_of() {
     return ClassLimits{Cfg::LMAX, Cfg::NMAX, Cfg::DIRCELLS, Cfg::RINGCELLS, Cfg::SEQMAX, Cfg::CPL};
 }
 
-__device__ __forceinline__ uint32_t plan_key(const PoaParams& P, uint32_t w, bool* trivial) {
-    const HypoWindow W = P.windows[w];
+constexpr int PLAN_THREADS = 256;
+constexpr int PLAN_STAGE = 8192;          // arm lengths staged per workgroup (32 KiB of LDS)
+
+__device__ __forceinline__ uint32_t plan_key_from(const HypoWindow& W, uint32_t maxarm, bool* trivial) {
     const uint32_t narm = W.n_internal + W.n_prefix + W.n_suffix;
     // longest sequence the window will align (markers included) and a node estimate
     uint32_t maxlen = (W.n_internal == 0 || W.type != HYPO_WIN_SHORT) ? W.draft_len + 2 : 0;
-    for (uint32_t a = 0; a < narm; ++a) {
-        const uint32_t l = P.arm_len[W.first_arm + a] + 2;
-        maxlen = l > maxlen ? l : maxlen;
-    }
+    if (narm) maxlen = maxarm + 2 > maxlen ? maxarm + 2 : maxlen;
     const uint32_t est_nodes = maxlen + maxlen / 16 + 3;   // near-linear graphs; the kernel re-queues on overflow
     const ClassLimits lim[kNumPoaClasses] = {
 #define HYPO_LIM(ID, CFG) limits_of<CFG>(),
@@ -62,14 +61,44 @@ __device__ __forceinline__ uint32_t plan_key(const PoaParams& P, uint32_t w, boo
     return (uint32_t)cls * kPlanBuckets + (kPlanBuckets - 1 - b);
 }
 
-__global__ void poa_plan_count_kernel(PoaParams P, PoaQueues Q, uint32_t n_windows) {
-    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_windows) return;
-    bool trivial;
-    const uint32_t key = plan_key(P, w, &trivial);
-    Q.keys[w] = (uint16_t)key;
-    atomicAdd(&Q.hist[key], 1u);
-    if (trivial) atomicAdd((unsigned long long*)&Q.stats->n_trivial, 1ull);
+// One lane per window.  The arm lengths of a workgroup's windows are normally one contiguous range of
+// arm_len: it is staged through LDS with coalesced loads, then every lane scans its own sub-range there.
+// The (class, bucket) histogram is accumulated in LDS and flushed with one global atomic per non-empty key.
+__global__ void __launch_bounds__(PLAN_THREADS)
+poa_plan_count_kernel(PoaParams P, PoaQueues Q, uint32_t n_windows) {
+    __shared__ uint32_t lens[PLAN_STAGE];
+    __shared__ uint32_t hist[kNumPoaClasses * kPlanBuckets];
+    __shared__ uint32_t amin, amax, ntriv;
+    const uint32_t w = blockIdx.x * PLAN_THREADS + threadIdx.x;
+    for (int i = threadIdx.x; i < kNumPoaClasses * kPlanBuckets; i += PLAN_THREADS) hist[i] = 0;
+    if (threadIdx.x == 0) { amin = 0xffffffffu; amax = 0; ntriv = 0; }
+    __syncthreads();
+    HypoWindow W{};
+    uint32_t narm = 0;
+    if (w < n_windows) {
+        W = P.windows[w];
+        narm = W.n_internal + W.n_prefix + W.n_suffix;
+        if (narm) { atomicMin(&amin, W.first_arm); atomicMax(&amax, W.first_arm + narm); }
+    }
+    __syncthreads();
+    const uint32_t a0 = amin, a1 = amax;
+    const bool staged = a1 > a0 && a1 - a0 <= (uint32_t)PLAN_STAGE;
+    if (staged) for (uint32_t i = threadIdx.x; i < a1 - a0; i += PLAN_THREADS) lens[i] = P.arm_len[a0 + i];
+    __syncthreads();
+    if (w < n_windows) {
+        uint32_t maxarm = 0;
+        if (staged) { for (uint32_t a = 0; a < narm; ++a) { const uint32_t l = lens[W.first_arm - a0 + a]; maxarm = l > maxarm ? l : maxarm; } }
+        else { for (uint32_t a = 0; a < narm; ++a) { const uint32_t l = P.arm_len[W.first_arm + a]; maxarm = l > maxarm ? l : maxarm; } }
+        bool trivial;
+        const uint32_t key = plan_key_from(W, maxarm, &trivial);
+        Q.keys[w] = (uint16_t)key;
+        atomicAdd(&hist[key], 1u);
+        if (trivial) atomicAdd(&ntriv, 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kNumPoaClasses * kPlanBuckets; i += PLAN_THREADS)
+        if (hist[i]) atomicAdd(&Q.hist[i], hist[i]);
+    if (threadIdx.x == 0 && ntriv) atomicAdd((unsigned long long*)&Q.stats->n_trivial, (unsigned long long)ntriv);
 }
 
 __global__ void poa_plan_scan_kernel(PoaQueues Q) {       // one small workgroup: kNumPoaClasses x kPlanBuckets entries
@@ -86,13 +115,21 @@ __global__ void poa_plan_scan_kernel(PoaQueues Q) {       // one small workgroup
     }
 }
 
-__global__ void poa_plan_scatter_kernel(PoaQueues Q, uint32_t n_windows) {
-    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_windows) return;
-    const uint32_t key = Q.keys[w];
-    const uint32_t cls = key / kPlanBuckets;
-    const uint32_t slot = Q.start[key] + atomicAdd(&Q.cursor[key], 1u);
-    Q.items[(size_t)cls * Q.stride + slot] = w;
+// Scatter with one global atomic per (workgroup, key): local ranks come from an LDS histogram.
+__global__ void __launch_bounds__(PLAN_THREADS)
+poa_plan_scatter_kernel(PoaQueues Q, uint32_t n_windows) {
+    __shared__ uint32_t cnt[kNumPoaClasses * kPlanBuckets];
+    __shared__ uint32_t base[kNumPoaClasses * kPlanBuckets];
+    const uint32_t w = blockIdx.x * PLAN_THREADS + threadIdx.x;
+    for (int i = threadIdx.x; i < kNumPoaClasses * kPlanBuckets; i += PLAN_THREADS) cnt[i] = 0;
+    __syncthreads();
+    uint32_t key = 0, local = 0;
+    if (w < n_windows) { key = Q.keys[w]; local = atomicAdd(&cnt[key], 1u); }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kNumPoaClasses * kPlanBuckets; i += PLAN_THREADS)
+        if (cnt[i]) base[i] = Q.start[i] + atomicAdd(&Q.cursor[i], cnt[i]);
+    __syncthreads();
+    if (w < n_windows) Q.items[(size_t)(key / kPlanBuckets) * Q.stride + base[key] + local] = w;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -236,9 +273,9 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
     if (e != hipSuccess) return e;
     int pe = 0;
     if (prof) (void)hipEventRecord(prof->ev[pe++], stream);
-    hipLaunchKernelGGL(poa_plan_count_kernel, dim3((n_windows + 255) / 256), dim3(256), 0, stream, P, Q, n_windows);
+    hipLaunchKernelGGL(poa_plan_count_kernel, dim3((n_windows + PLAN_THREADS - 1) / PLAN_THREADS), dim3(PLAN_THREADS), 0, stream, P, Q, n_windows);
     hipLaunchKernelGGL(poa_plan_scan_kernel, dim3(1), dim3(64), 0, stream, Q);
-    hipLaunchKernelGGL(poa_plan_scatter_kernel, dim3((n_windows + 255) / 256), dim3(256), 0, stream, Q, n_windows);
+    hipLaunchKernelGGL(poa_plan_scatter_kernel, dim3((n_windows + PLAN_THREADS - 1) / PLAN_THREADS), dim3(PLAN_THREADS), 0, stream, Q, n_windows);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (prof) (void)hipEventRecord(prof->ev[pe++], stream);
     // Every class is launched with a grid sized for the whole batch: how many windows a class
