@@ -33,6 +33,7 @@
 // Compiled by hipcc for gfx950 and, with HYPO_EMU, by g++ for the lockstep emulator used in tests/.
 #pragma once
 #include <math.h>
+#include <type_traits>
 #include "grp.hpp"
 #include "../../include/hypo_gpu.h"
 
@@ -85,6 +86,8 @@ struct PoaCfg {
     static constexpr int DIRBYTES = NIB ? DIRCELLS_ / 2 : DIRCELLS_;
     typedef ScoreT score_t;
     typedef IdT id_t;
+    // edge weights grow by 2 per traversal: 8 bits suffice while a window has <= 127 sequences
+    typedef typename std::conditional<(SEQMAX_ <= 127), uint8_t, uint16_t>::type wt_t;
     static constexpr int ID_NONE = (IdT)~(IdT)0;
     static_assert(LCAP_ <= GW_ * CPL_ - 1, "columns 0..L must fit the group");
     static_assert(LCAP_ <= 1023 && ARMBYTES_ <= 32767 && SEQMAX_ <= 32767, "sequence table entry is 32 bits");
@@ -106,14 +109,14 @@ struct PoaLayout {   // byte offsets inside a group's memory slice
     static constexpr int oRowmeta = oDir + align_up<16>(Cfg::DIRBYTES);
     static constexpr int oSeqtab = oRowmeta + align_up<16>(Cfg::NMAX * 4);
     static constexpr int oInw = oSeqtab + align_up<16>(Cfg::SEQMAX * 4);
-    static constexpr int oPosnode = oInw + align_up<16>(Cfg::NMAX * Cfg::KIN * 2);
-    static constexpr int oProw = oPosnode + align_up<16>((Cfg::LMAX + 1) * 2);
-    static constexpr int oInp = oProw + align_up<16>(Cfg::NMAX * Cfg::KIN * (int)sizeof(id_t));
+    static constexpr int oPosnode = oInw + align_up<16>(Cfg::NMAX * Cfg::KIN * (int)sizeof(typename Cfg::wt_t));
+    // posnode (alignment -> graph update) and the DFS stack (toposort, arm staging) are never live together
+    static constexpr int POS_BYTES = (Cfg::LMAX + 1) * 2 > Cfg::STK * (int)sizeof(id_t) ? (Cfg::LMAX + 1) * 2 : Cfg::STK * (int)sizeof(id_t);
+    static constexpr int oInp = oPosnode + align_up<16>(POS_BYTES);
     static constexpr int oAl = oInp + align_up<16>(Cfg::NMAX * Cfg::KIN * (int)sizeof(id_t));
     static constexpr int oR2n = oAl + align_up<16>(Cfg::NMAX * Cfg::AL * (int)sizeof(id_t));
     static constexpr int oN2r = oR2n + align_up<16>(Cfg::NMAX * (int)sizeof(id_t));
-    static constexpr int oStack = oN2r + align_up<16>(Cfg::NMAX * (int)sizeof(id_t));
-    static constexpr int oCode = oStack + align_up<16>(Cfg::STK * (int)sizeof(id_t));
+    static constexpr int oCode = oN2r + align_up<16>(Cfg::NMAX * (int)sizeof(id_t));
     static constexpr int oNin = oCode + align_up<16>(Cfg::NMAX);
     static constexpr int oNout = oNin + align_up<16>(Cfg::NMAX);
     static constexpr int oNal = oNout + align_up<16>(Cfg::NMAX);
@@ -137,6 +140,7 @@ template <class Cfg>
 struct Poa {
     typedef typename Cfg::score_t score_t;
     typedef typename Cfg::id_t id_t;
+    typedef typename Cfg::wt_t wt_t;
     typedef PoaLayout<Cfg> Lay;
     static constexpr int GW = Cfg::GW, CPL = Cfg::CPL, KIN = Cfg::KIN, NMAX = Cfg::NMAX, AL = Cfg::AL;
     static constexpr bool NIB = Cfg::NIB;
@@ -163,8 +167,8 @@ struct Poa {
     const Grp<GW>& g;
     const PoaParams& P;
     // memory slice
-    score_t* ring; uint8_t* dir; uint32_t* rowmeta; uint32_t* seqtab; uint16_t* inw; int16_t* posnode;
-    id_t *prow, *inp, *al, *r2n, *n2r, *stack;
+    score_t* ring; uint8_t* dir; uint32_t* rowmeta; uint32_t* seqtab; wt_t* inw; int16_t* posnode;
+    id_t *inp, *al, *r2n, *n2r, *stack;
     uint8_t *code, *nin, *nout, *nal, *mark, *seq, *armbuf;
     id_t* pathnodes; uint32_t* pathoff; uint16_t *pathlen, *pathmult, *msa; uint32_t* dstcnt; uint8_t* consbuf;
     int n_paths, path_used, head_first;
@@ -178,11 +182,10 @@ struct Poa {
     HD Poa(const Grp<GW>& g_, const PoaParams& P_, char* mem) : g(g_), P(P_) {
         ring = (score_t*)(mem + Lay::oRing); dir = (uint8_t*)(mem + Lay::oDir);
         rowmeta = (uint32_t*)(mem + Lay::oRowmeta); seqtab = (uint32_t*)(mem + Lay::oSeqtab);
-        inw = (uint16_t*)(mem + Lay::oInw); posnode = (int16_t*)(mem + Lay::oPosnode);
-        prow = (id_t*)(mem + Lay::oProw);
+        inw = (wt_t*)(mem + Lay::oInw); posnode = (int16_t*)(mem + Lay::oPosnode);
         inp = (id_t*)(mem + Lay::oInp); al = (id_t*)(mem + Lay::oAl);
         r2n = (id_t*)(mem + Lay::oR2n); n2r = (id_t*)(mem + Lay::oN2r);
-        stack = (id_t*)(mem + Lay::oStack); code = (uint8_t*)(mem + Lay::oCode);
+        stack = (id_t*)(mem + Lay::oPosnode); code = (uint8_t*)(mem + Lay::oCode);
         nin = (uint8_t*)(mem + Lay::oNin); nout = (uint8_t*)(mem + Lay::oNout);
         nal = (uint8_t*)(mem + Lay::oNal); mark = (uint8_t*)(mem + Lay::oMark);
         seq = (uint8_t*)(mem + Lay::oSeq); armbuf = (uint8_t*)(mem + Lay::oArms);
@@ -298,8 +301,8 @@ struct Poa {
     }
 
     // ---- per-row metadata in rank order (rebuilt only when the graph topology changed) -----------
-    // rowmeta[r]: bits 0-7 code, 8-15 in-degree, 16 sink flag, 17-31 matrix row of pred 0;
-    // prow[r*KIN+p] = matrix row of pred p; maxdelta = largest (row - pred row) over real preds.
+    // rowmeta[r]: bits 0-7 code, 8-15 in-degree, 16 sink flag, 17-31 matrix row of pred 0 (further preds are rare
+    // and looked up through pred_row()); maxdelta = largest (row - pred row) over real preds.
     HD void build_rowmeta() {
         int md = 0;
         for (int r = g.lane; r < n_nodes; r += GW) {
@@ -308,7 +311,6 @@ struct Poa {
             int p0 = 0;
             for (int p = 0; p < k; ++p) {
                 const int pr = (int)n2r[inp[u * KIN + p]] + 1;
-                prow[r * KIN + p] = (id_t)pr;
                 if (p == 0) p0 = pr;
                 const int d = r + 1 - pr;
                 md = d > md ? d : md;
@@ -320,6 +322,7 @@ struct Poa {
         g.sync();
     }
 
+    HD int pred_row(int r, int p) const { return (int)n2r[inp[(int)r2n[r] * KIN + p]] + 1; }   // matrix row of pred p of rank r
     HD void load_ring(int slot, int S, int (&out)[CPL]) const {
         if (CPL * g.lane < S) {
             const Pack pk = *(const Pack*)(ring + slot * S + CPL * g.lane);
@@ -368,13 +371,33 @@ struct Poa {
         int best = NEG, best_i = -1;
 
         int slot = 0;                                        // ring slot of row i (no integer division in the loop)
-        uint32_t meta_a = rowmeta[0];                        // two-deep prefetch of the row metadata
-        uint32_t meta_b = n_nodes > 1 ? rowmeta[1] : 0u;
+        // Row metadata: full-wave groups keep it in registers (lane r holds row r, fetched with v_readlane, no
+        // LDS latency in the row loop); narrower groups and the big classes prefetch it from LDS two rows ahead.
+        constexpr int MREG = (NMAX + GW - 1) / GW;
+        constexpr bool META_IN_REGS = (GW == 64) && (MREG <= 4);
+        uint32_t mreg[META_IN_REGS ? MREG : 1];
+        if (META_IN_REGS) {
+            HYPO_UNROLL
+            for (int q = 0; q < (META_IN_REGS ? MREG : 1); ++q) {
+                const int rr = q * GW + g.lane;
+                mreg[q] = rr < n_nodes ? rowmeta[rr] : 0u;
+            }
+        }
+        uint32_t meta_a = META_IN_REGS ? 0u : rowmeta[0];
+        uint32_t meta_b = (!META_IN_REGS && n_nodes > 1) ? rowmeta[1] : 0u;
         for (int r = 0; r < n_nodes; ++r) {
             const int i = r + 1;
-            const uint32_t meta = meta_a;
-            meta_a = meta_b;
-            if (r + 2 < n_nodes) meta_b = rowmeta[r + 2];
+            uint32_t meta;
+            if (META_IN_REGS) {
+                uint32_t mv = mreg[0];
+                HYPO_UNROLL
+                for (int q = 1; q < (META_IN_REGS ? MREG : 1); ++q) if ((r / GW) == q) mv = mreg[q];
+                meta = (uint32_t)g.shfl((int)mv, r % GW);
+            } else {
+                meta = meta_a;
+                meta_a = meta_b;
+                if (r + 2 < n_nodes) meta_b = rowmeta[r + 2];
+            }
             const int cd = (int)(meta & 0xff), k = (int)((meta >> 8) & 0xff);
             const bool sink = (meta >> 16) & 1;
             const int p0 = (int)(meta >> 17);                // 0 when k == 0 (virtual source row)
@@ -401,7 +424,7 @@ struct Poa {
                 for (int c = 0; c < CPL; ++c) { pD[c] = 0; pU[c] = 0; }
                 for (int p = 1; p < k; ++p) {
                     int hp[CPL];
-                    int ps = slot - (i - (int)prow[r * KIN + p]); ps = ps < 0 ? ps + R : ps;
+                    int ps = slot - (i - pred_row(r, p)); ps = ps < 0 ? ps + R : ps;
                     load_ring(ps, S, hp);
                     const int left = g.shfl_up1(hp[CPL - 1], NEG);
                     HYPO_UNROLL
@@ -505,7 +528,7 @@ struct Poa {
             } else {
                 const int p = dir_pred(d);
                 const int k = (int)((rowmeta[i - 1] >> 8) & 0xff);
-                const int pi = k ? (int)prow[(i - 1) * KIN + p] : 0;
+                const int pi = k ? pred_row(i - 1, p) : 0;
                 if (!is_vert(d)) {
                     if (j == 0) return RES_UNDEFINED;
                     if (g.lane == 0) posnode[j - 1] = (int16_t)r2n[i - 1];
@@ -529,7 +552,7 @@ struct Poa {
     HD int add_edge(int prev, int to) {
         const int k = nin[to];
         for (int p = 0; p < k; ++p)
-            if ((int)inp[to * KIN + p] == prev) { inw[to * KIN + p] = (uint16_t)(inw[to * KIN + p] + 2); return 0; }
+            if ((int)inp[to * KIN + p] == prev) { inw[to * KIN + p] = (wt_t)(inw[to * KIN + p] + 2); return 0; }
         if (k == KIN) return 2;
         inp[to * KIN + k] = (id_t)prev; inw[to * KIN + k] = 2; nin[to] = (uint8_t)(k + 1);
         if (nout[prev] != 255) nout[prev] = (uint8_t)(nout[prev] + 1);
@@ -639,7 +662,7 @@ struct Poa {
                 const int k = nin[to];
                 bool found = false;
                 for (int p = 0; p < k; ++p)
-                    if ((int)inp[to * KIN + p] == prev) { inw[to * KIN + p] = (uint16_t)(inw[to * KIN + p] + 2 * count); found = true; break; }
+                    if ((int)inp[to * KIN + p] == prev) { inw[to * KIN + p] = (wt_t)(inw[to * KIN + p] + 2 * count); found = true; break; }
                 bad |= !found;
             }
         }
@@ -770,7 +793,7 @@ struct Poa {
                 if (k != 0) {
                     int bw = w0, bs = p0 == r ? prev_s : rs[p0 - 1], bp = p0;
                     for (int p = 1; p < k; ++p) {
-                        const int w = inw[u * KIN + p], pr = (int)prow[r * KIN + p];
+                        const int w = inw[u * KIN + p], pr = pred_row(r, p);
                         const int sp = rs[pr - 1];
                         if (bw < w || (bw == w && bs <= sp)) { bw = w; bs = sp; bp = pr; }
                     }
@@ -853,9 +876,12 @@ struct Poa {
         return RES_OK;
     }
     HD int long_step(int m, int n, int gp) {
-        int rc = add_sequence_step(MODE_NW, m, n, gp);
+        int rc = align(MODE_NW, m, n, gp);
         if (rc != RES_OK) return rc;
-        return record_path(tb_steps == 0 ? L : tb_fv);
+        if ((rc = add_alignment()) != RES_OK) return rc;
+        if ((rc = record_path(tb_steps == 0 ? L : tb_fv)) != RES_OK) return rc;   // before toposort: its stack aliases posnode
+        if (topo_dirty) { rc = toposort(); topo_runs += 1; }
+        return rc;
     }
     HD int run_long(uint32_t w, const HypoWindow& W) {
         const int m = P.lr_m, n = P.lr_n, gp = P.lr_g;
