@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaParams P, PoaQueues Q,
         const uint32_t w = Q.items[(size_t)cls * Q.stride + idx];
         Poa<Cfg> poa(g, P, mem);
         const int rc = poa.run(w);
-        cells += poa.cells; aligns += poa.aligns;
+        if (rc == RES_OK) { cells += poa.cells; aligns += poa.aligns; }   // reference-equivalent work of FINISHED windows only
 #ifdef HYPO_PHASE_TIMERS
         for (int i = 0; i < PH_N; ++i) tph[i] += poa.tphase[i];
         dbg[0] += poa.rows_done; dbg[1] += poa.aligns - poa.reused; dbg[2] += poa.reused; dbg[3] += poa.topo_runs;

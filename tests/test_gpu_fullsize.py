@@ -1,0 +1,95 @@
+"""GPU, BASELINE.json's full sizes.  The oracle still finishes in seconds on the host cores for the C2 batch and
+for 100-250 Mbp scans, so those are compared directly; the C3-sized POA call (~1.9 M windows in ONE batch) is
+checked through size-independent properties: replicas of the same window must agree wherever they land in the
+queues, waves and size classes, and the base windows must equal the oracle."""
+import numpy as np
+import pytest
+
+from hypo_amd import abi, capi, sim
+from hypo_amd.batch import HostBatch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    return capi.HypoGpu(0)
+
+
+def _cons_list(bases, off, ln):
+    return [bases[int(off[i]):int(off[i]) + int(ln[i])].tobytes() for i in range(ln.size)]
+
+
+def test_c2_full_batch_vs_oracle(gpu, oracle_lib):
+    b = sim.window_batch(97078, seed=2024)
+    off = b.slot_layout()
+    db = gpu.device_batch(b, off=off)
+    db.run()
+    bases, _, ln, st = db.results()
+    ob, _, oln, ost, cells, aligns = oracle_lib.poa_batch_raw(b, off=off)
+    assert (st == 0).all() and (ost == 0).all() and (ln == oln).all()
+    idx = np.repeat(off[:-1].astype(np.int64), ln.astype(np.int64)) + \
+        (np.arange(int(ln.sum()), dtype=np.int64) - np.repeat(np.cumsum(ln.astype(np.int64)) - ln, ln.astype(np.int64)))
+    assert (bases[idx] == ob[idx]).all()
+    s = db.stats()
+    assert s["dp_cells"] == cells and s["n_alignments"] == aligns and s["n_failed"] == 0
+    # determinism: a second run of the same resident batch gives identical bytes
+    db.run()
+    bases2, _, ln2, st2 = db.results()
+    assert (ln2 == ln).all() and (bases2[idx] == bases[idx]).all()
+
+
+def test_c3_sized_batch_replica_property(gpu, oracle_lib):
+    """~1.94 M windows (the C3 configuration's count) in one call: 20 shuffled replicas of a C1-shaped batch that
+    share the packed buffers.  Every replica must produce the consensus of its original, and the originals must
+    equal the oracle."""
+    base = sim.window_batch(97078, seed=7)
+    reps = 20
+    rng = np.random.default_rng(1)
+    order = rng.permutation(base.n_windows * reps)
+    src = order % base.n_windows                         # window i of the big batch is a copy of base window src[i]
+    big = HostBatch(base.windows[src].copy(), base.draft4, base.arm_off, base.arm_len, base.arms2)
+    off = big.slot_layout()
+    bases, _, ln, st = gpu.poa_batch(big, off=off)
+    assert (st == 0).all()
+    s = gpu.last_stats()
+    assert s["n_failed"] == 0 and sum(s["n_class"]) == big.n_windows
+    ob, ooff, oln, ost, _, _ = oracle_lib.poa_batch_raw(base)
+    want = _cons_list(ob, ooff, oln)
+    assert (ln == oln[src]).all()
+    got = _cons_list(bases, off, ln)
+    bad = [i for i in range(big.n_windows) if got[i] != want[src[i]]]
+    assert not bad, f"{len(bad)} of {big.n_windows} windows differ, first {bad[:3]}"
+
+
+def test_dense_sr_shape_vs_oracle(gpu, oracle_lib):
+    """The dense-SR shape of C4/C5: tiny windows (45 % <= 8 bp), ~22 arms of ~12 bases."""
+    rng = np.random.default_rng(3)
+    n = 60000
+    wl = rng.choice([3, 5, 8, 12, 16, 24, 32, 48, 64, 99], size=n, p=[.15, .15, .15, .13, .13, .1, .1, .05, .03, .01])
+    shapes = np.stack([wl, rng.integers(3, 45, size=n), np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.int64)], axis=1)
+    b = sim.window_batch(n, seed=9, shapes=shapes, read_sub=0.01)
+    off = b.slot_layout()
+    bases, _, ln, st = gpu.poa_batch(b, off=off)
+    ob, _, oln, ost, _, _ = oracle_lib.poa_batch_raw(b, off=off)
+    assert (st == ost).all() and (ln == oln).all()
+    assert _cons_list(bases, off, ln) == _cons_list(ob, off, oln)
+
+
+@pytest.mark.parametrize("n_bases,k", [(100_000_000, 13), (250_000_000, 15)])
+def test_scan_c3_c4_sizes_vs_oracle(gpu, oracle_lib, n_bases, k):
+    """100 Mbp / k=13 (8 MiB set, L2-resident) and 250 Mbp / k=15 (128 MiB set, Infinity-Cache-resident)."""
+    rng = np.random.default_rng(k)
+    codes = rng.integers(0, 4, size=n_bases, dtype=np.uint8)
+    codes[rng.integers(0, n_bases, size=n_bases // 5000)] = 4
+    pad = codes.reshape(-1, 2)
+    p4 = ((pad[:, 0] << 4) | pad[:, 1]).astype(np.uint8)
+    bits = rng.integers(0, 1 << 63, size=(1 << (2 * k)) // 64, dtype=np.int64).view(np.uint64)
+    bits &= rng.integers(0, 1 << 63, size=bits.size, dtype=np.int64).view(np.uint64)       # ~25 % of k-mers solid
+    cap = n_bases // 4
+    ds = gpu.device_scan(p4, n_bases, k, bits, kids_cap=cap)
+    ds.run()
+    w, kids, rank, ns = ds.results()
+    ow, okids, orank, ons = oracle_lib.solid_scan(p4, n_bases, k, bits, kids_cap=cap)
+    assert ns == ons and (w == ow).all() and (rank == orank).all() and (kids == okids).all()
+    assert int(rank[-1]) == ns == int(np.unpackbits(w.view(np.uint8)).sum())
