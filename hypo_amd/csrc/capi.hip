@@ -104,8 +104,18 @@ int hypo_gpu_profile_read(int call, float* ms, int n) {
     if (c.ke.n < 2) return 0;
     HIP_TRY(hipEventSynchronize(c.ke.ev[c.ke.n - 1]));
     int out = 0;
+    float t = 0.f;
+    if (c.kind == 1) {          // POA: [plan, class 0..4, whole call]; event pairs may sit on different streams
+        const int pairs = (c.ke.n - 1) / 2;
+        for (int i = 0; i < pairs && out < n; ++i) {
+            HIP_TRY(hipEventSynchronize(c.ke.ev[2 * i + 1]));
+            HIP_TRY(hipEventElapsedTime(&t, c.ke.ev[2 * i], c.ke.ev[2 * i + 1]));
+            ms[out++] = t;
+        }
+        if (out < n) { HIP_TRY(hipEventElapsedTime(&t, c.ke.ev[0], c.ke.ev[c.ke.n - 1])); ms[out++] = t; }
+        return out;
+    }
     for (int i = 0; i + 1 < c.ke.n && out < n; ++i) {
-        float t = 0.f;
         HIP_TRY(hipEventElapsedTime(&t, c.ke.ev[i], c.ke.ev[i + 1]));
         ms[out++] = t;
     }

@@ -13,6 +13,7 @@
 // MFMA is not used: the work is integer max/+ over irregular <=128-wide rows with a serial graph
 // update between sequences (see DESIGN.md for the roofline evidence).
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include "poa_classes.hpp"
 #include "poa_kernel.hpp"
@@ -111,6 +112,8 @@ __global__ void poa_plan_scan_kernel(PoaQueues Q) {       // one small workgroup
                 acc += Q.hist[k];
             }
             Q.count[c] = acc;
+            Q.planned[c] = acc;          // windows the plan put into the class (before any re-queue)
+            Q.head2[c] = acc;
         }
     }
 }
@@ -136,7 +139,8 @@ poa_plan_scatter_kernel(PoaQueues Q, uint32_t n_windows) {
 // persistent per-class kernel
 // ------------------------------------------------------------------------------------------------
 template <class Cfg, bool USE_LDS>
-__global__ void __launch_bounds__(64) poa_class_kernel(PoaParams P, PoaQueues Q, int cls, char* scratch) {
+__global__ void __launch_bounds__(64) poa_class_kernel(PoaParams P, PoaQueues Q, int cls, char* scratch,
+                                                       uint32_t* head, const uint32_t* bound) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int GW = Cfg::GW;
     constexpr int GPW = 64 / GW;                       // groups per wave
@@ -145,7 +149,7 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaParams P, PoaQueues Q,
     Grp<GW> g{wl & (GW - 1)};
     char* mem = USE_LDS ? smem + (size_t)grp * PoaLayout<Cfg>::BYTES
                         : scratch + ((size_t)blockIdx.x * GPW + grp) * PoaLayout<Cfg>::BYTES;
-    const uint32_t count = Q.count[cls];
+    const uint32_t count = *bound;          // queue slots [.., *bound) are final when this launch starts
     uint64_t cells = 0, aligns = 0, abytes = 0;
     uint32_t n_ok = 0, n_esc = 0, n_fail = 0;
 #ifdef HYPO_PHASE_TIMERS
@@ -155,7 +159,7 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaParams P, PoaQueues Q,
 #endif
     for (;;) {
         uint32_t idx = 0;
-        if (g.lane == 0) idx = atomicAdd(&Q.head[cls], 1u);
+        if (g.lane == 0) idx = atomicAdd(head, 1u);
         idx = (uint32_t)g.shfl((int)idx, 0);
         if (idx >= count) break;
         const uint32_t w = Q.items[(size_t)cls * Q.stride + idx];
@@ -211,7 +215,8 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaParams P, PoaQueues Q,
 // ------------------------------------------------------------------------------------------------
 template <class Cfg, bool USE_LDS>
 static hipError_t launch_class(const PoaParams& P, const PoaQueues& Q, int cls, uint32_t n_windows,
-                               char* scratch, int num_cus, int max_global_groups, hipStream_t stream) {
+                               char* scratch, int num_cus, int max_global_groups, hipStream_t stream,
+                               int waves_per_cu_cap = 0, bool mop_up = false) {
     auto kern = poa_class_kernel<Cfg, USE_LDS>;
     constexpr int GPW = 64 / Cfg::GW;
     const size_t lds = USE_LDS ? (size_t)GPW * PoaLayout<Cfg>::BYTES : 0;
@@ -228,12 +233,16 @@ static hipError_t launch_class(const PoaParams& P, const PoaQueues& Q, int cls, 
         const int c = atoi(cap);
         if (c >= 1 && c < per_cu) per_cu = c;
     }
+    if (waves_per_cu_cap >= 1 && waves_per_cu_cap < per_cu) per_cu = waves_per_cu_cap;
     long grid = (long)per_cu * num_cus;
     if (!USE_LDS && grid * GPW > max_global_groups) grid = max_global_groups / GPW;
     const long need = ((long)n_windows + GPW - 1) / GPW;      // never more waves than windows
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, stream, P, Q, cls, scratch);
+    // first pass: slots [0, planned) with cursor head[cls]; mop-up pass: slots [planned, count) with cursor head2[cls]
+    uint32_t* head = mop_up ? Q.head2 + cls : Q.head + cls;
+    const uint32_t* bound = (mop_up || waves_per_cu_cap == 0) ? Q.count + cls : Q.planned + cls;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, stream, P, Q, cls, scratch, head, bound);
     return hipGetLastError();
 }
 
@@ -258,6 +267,8 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
     PoaQueues Q;
     Q.count = (uint32_t*)ws;
     Q.head = (uint32_t*)(ws + 64);
+    Q.planned = (uint32_t*)(ws + 7680);
+    Q.head2 = (uint32_t*)(ws + 7744);
     Q.stats = (HypoPoaStats*)(ws + 128);
     Q.hist = (uint32_t*)(ws + 2048);
     Q.start = (uint32_t*)(ws + 4096);
@@ -272,21 +283,71 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
     hipError_t e = hipMemsetAsync(ws, 0, kPoaHeaderBytes, stream);
     if (e != hipSuccess) return e;
     int pe = 0;
-    if (prof) (void)hipEventRecord(prof->ev[pe++], stream);
+    if (prof) (void)hipEventRecord(prof->ev[0], stream);
     hipLaunchKernelGGL(poa_plan_count_kernel, dim3((n_windows + PLAN_THREADS - 1) / PLAN_THREADS), dim3(PLAN_THREADS), 0, stream, P, Q, n_windows);
     hipLaunchKernelGGL(poa_plan_scan_kernel, dim3(1), dim3(64), 0, stream, Q);
     hipLaunchKernelGGL(poa_plan_scatter_kernel, dim3((n_windows + PLAN_THREADS - 1) / PLAN_THREADS), dim3(PLAN_THREADS), 0, stream, Q, n_windows);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (prof) (void)hipEventRecord(prof->ev[pe++], stream);
-    // Every class is launched with a grid sized for the whole batch: how many windows a class
-    // receives is only known on the device (plan + escalations), and an idle persistent wave exits
-    // after one failed dequeue.
+    if (prof) (void)hipEventRecord(prof->ev[1], stream);
+    // Every class is launched with a grid sized for the whole batch: how many windows a class receives is only
+    // known on the device (plan + escalations), and an idle persistent wave exits after one failed dequeue.
+    //
+    // The three LDS classes run CONCURRENTLY on the caller's stream and two auxiliary streams: the small-window
+    // kernels are latency bound (most sequences reuse an alignment) while the large-window kernel saturates VALU
+    // issue, so sharing the CUs fills issue slots either would leave idle (measured: ~11 % per step).  Each gets a
+    // share of a CU's LDS through a waves-per-CU cap.  A window re-queued by a class that ran next to its successor
+    // is picked up by a small mop-up launch afterwards; the rare classes 3 and 4 follow on the caller's stream.
+    static hipStream_t aux[2] = {nullptr, nullptr};
+    static hipEvent_t fork_ev = nullptr, join_ev[2] = {nullptr, nullptr};
+    int caps[kNumPoaClasses] = {3, 3, 6, 0, 0};
+    if (const char* cs = getenv("HYPO_POA_CAPS")) sscanf(cs, "%d,%d,%d,%d,%d", &caps[0], &caps[1], &caps[2], &caps[3], &caps[4]);
+    const char* seq_env = getenv("HYPO_POA_SEQUENTIAL");
+    const bool sequential = seq_env && atoi(seq_env) > 0;
+    auto rec = [&](int idx, hipStream_t st) { if (prof) (void)hipEventRecord(prof->ev[idx], st); };
+    if (sequential) {
 #define HYPO_LAUNCH(ID, CFG)                                                                              \
-    if ((e = launch_class<CFG, (ID < kFirstGlobalClass)>(P, Q, ID, n_windows, scratch, num_cus,          \
-                                                         kMaxGlobalGroups, stream)) != hipSuccess) return e; \
-    if (prof) (void)hipEventRecord(prof->ev[pe++], stream);
-    HYPO_FOR_EACH_CLASS(HYPO_LAUNCH)
+        rec(2 + 2 * ID, stream);                                                                          \
+        if ((e = launch_class<CFG, (ID < kFirstGlobalClass)>(P, Q, ID, n_windows, scratch, num_cus,      \
+                                                             kMaxGlobalGroups, stream)) != hipSuccess) return e; \
+        rec(3 + 2 * ID, stream);
+        HYPO_FOR_EACH_CLASS(HYPO_LAUNCH)
 #undef HYPO_LAUNCH
+    } else {
+        if (!aux[0]) {
+            for (int i = 0; i < 2; ++i) {
+                if ((e = hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking)) != hipSuccess) return e;
+                if ((e = hipEventCreateWithFlags(&join_ev[i], hipEventDisableTiming)) != hipSuccess) return e;
+            }
+            if ((e = hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming)) != hipSuccess) return e;
+        }
+        (void)hipEventRecord(fork_ev, stream);
+        (void)hipStreamWaitEvent(aux[0], fork_ev, 0);
+        (void)hipStreamWaitEvent(aux[1], fork_ev, 0);
+        rec(2 + 2 * 2, stream);
+        if ((e = launch_class<PoaClass2, true>(P, Q, 2, n_windows, scratch, num_cus, kMaxGlobalGroups, stream, caps[2])) != hipSuccess) return e;
+        rec(3 + 2 * 2, stream);
+        rec(2 + 2 * 0, aux[0]);
+        if ((e = launch_class<PoaClass0, true>(P, Q, 0, n_windows, scratch, num_cus, kMaxGlobalGroups, aux[0], caps[0])) != hipSuccess) return e;
+        rec(3 + 2 * 0, aux[0]);
+        rec(2 + 2 * 1, aux[1]);
+        if ((e = launch_class<PoaClass1, true>(P, Q, 1, n_windows, scratch, num_cus, kMaxGlobalGroups, aux[1], caps[1])) != hipSuccess) return e;
+        rec(3 + 2 * 1, aux[1]);
+        (void)hipEventRecord(join_ev[0], aux[0]);
+        (void)hipEventRecord(join_ev[1], aux[1]);
+        (void)hipStreamWaitEvent(stream, join_ev[0], 0);
+        (void)hipStreamWaitEvent(stream, join_ev[1], 0);
+        // mop-up of re-queued windows (normally none), then the rare classes
+        if ((e = launch_class<PoaClass1, true>(P, Q, 1, 1024, scratch, num_cus, kMaxGlobalGroups, stream, 1, true)) != hipSuccess) return e;
+        if ((e = launch_class<PoaClass2, true>(P, Q, 2, 1024, scratch, num_cus, kMaxGlobalGroups, stream, 1, true)) != hipSuccess) return e;
+        rec(2 + 2 * 3, stream);
+        if ((e = launch_class<PoaClass3, true>(P, Q, 3, n_windows, scratch, num_cus, kMaxGlobalGroups, stream)) != hipSuccess) return e;
+        rec(3 + 2 * 3, stream);
+        rec(2 + 2 * 4, stream);
+        if ((e = launch_class<PoaClass4, false>(P, Q, 4, n_windows, scratch, num_cus, kMaxGlobalGroups, stream)) != hipSuccess) return e;
+        rec(3 + 2 * 4, stream);
+    }
+    rec(2 + 2 * kNumPoaClasses, stream);
+    pe = 3 + 2 * kNumPoaClasses;
     if (prof) prof->n = pe;
     return hipSuccess;
 }

@@ -15,6 +15,8 @@ constexpr int kPlanBuckets = 64;         // cost buckets per class of the plan's
 struct PoaQueues {
     uint32_t* count;        // [classes] windows queued per class
     uint32_t* head;         // [classes] next queue slot to hand out
+    uint32_t* planned;      // [classes] count right after the plan (bound of the concurrent first pass)
+    uint32_t* head2;        // [classes] cursor of the mop-up pass over slots [planned, count)
     HypoPoaStats* stats;
     uint32_t* hist;         // [classes * kPlanBuckets] plan: windows per (class, cost bucket)
     uint32_t* start;        // exclusive prefix of hist inside each class
@@ -24,8 +26,9 @@ struct PoaQueues {
     uint32_t stride;
 };
 
-// optional event recorder: ev[0] before plan, ev[1] after plan, ev[2 + c] after class c
-struct KernelEvents { hipEvent_t ev[12]; int n; };
+// optional event recorder: ev[0]/ev[1] around the plan kernels, ev[2+2c]/ev[3+2c] around size-class kernel c
+// (recorded on the stream that kernel runs on), ev[2+2*classes] after everything has joined the caller's stream
+struct KernelEvents { hipEvent_t ev[16]; int n; };
 
 size_t poa_workspace_bytes(uint32_t n_windows);
 hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size_t workspace_bytes,
