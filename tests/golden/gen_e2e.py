@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Deterministic synthetic end-to-end inputs: truth, draft with sub/ins/del 0.4 %
+each, 30x 150-bp reads with 0.2 % substitutions as coordinate-sorted SAM text whose CIGARs are the composition of
+the truth->draft edit script, the solid-kmer bit vector file the reference loads with `-i`
+(aux/solid_kmers.bvsd + aux/stage.txt), and optionally 40x 8-kbp ONT-like long reads (~8 % error, NM tag) with ten
+3-kbp short-read coverage gaps so that LONG windows appear.
+
+The byte-exact inputs of the committed end-to-end goldens are reproduced by
+    gen_e2e.py <outdir> 1 20000          (tests/golden/e2e_20k_s1.*)
+    gen_e2e.py <outdir> 3 200000 --long  (tests/golden/e2e_200k_long_s3.*)
+    gen_e2e.py <outdir> 5 200000 --k 9   (tests/golden/e2e_200k_k9_s5.*: `-s 100k` => k = 9, many minimizer-cut windows)
+(python's `random` module, seed and call order fixed; md5 of every file is checked against the manifest by the
+tests).  The expected outputs in those goldens were produced from exactly these inputs by the reference binary
+built per SURVEY.md Appendix B (`hypo -d draft.fa -r reads.fa -s 1m -c 30 -b sr.sam [-B lr.sam] -t 1 -i`)."""
+import os
+import random
+import struct
+import sys
+
+COV, RL = 30, 150
+A = "ACGT"
+
+
+def rle(cig):
+    out, last, cnt = [], None, 0
+    for c in cig:
+        if c == last:
+            cnt += 1
+        else:
+            if last:
+                out.append(f"{cnt}{last}")
+            last, cnt = c, 1
+    out.append(f"{cnt}{last}")
+    return "".join(out)
+
+
+def rc(s):
+    return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+
+def generate(outdir, seed, G, with_long, K=11):
+    random.seed(seed)
+    truth = "".join(random.choice(A) for _ in range(G))
+    ops = []                                     # (op, truth base, draft base)
+    for c in truth:
+        r = random.random()
+        if r < 0.004:
+            ops.append(('D', c, None))           # draft lacks this base -> I in read CIGARs
+        elif r < 0.008:
+            ops.append(('X', c, random.choice([b for b in A if b != c])))
+        else:
+            ops.append(('M', c, c))
+        if random.random() < 0.004:
+            ops.append(('I', None, random.choice(A)))   # draft has an extra base -> D in read CIGARs
+    draft = "".join(o[2] for o in ops if o[2] is not None)
+    tpos = [i for i, o in enumerate(ops) if o[1] is not None]
+    dprefix = [0] * (len(ops) + 1)
+    for i, o in enumerate(ops):
+        dprefix[i + 1] = dprefix[i] + (1 if o[2] is not None else 0)
+    gaps = [(g * G // 10 + 3000, g * G // 10 + 6000) for g in range(10)] if with_long else []
+    nreads = G * COV // RL
+    recs = []
+    for n in range(nreads):
+        s = random.randrange(0, G - RL)
+        e = s + RL
+        if with_long and any(s < b and e > a for a, b in gaps):
+            continue
+        i0, i1 = tpos[s], tpos[e - 1] + 1
+        while ops[i0][0] not in "MX":
+            i0 += 1
+        while ops[i1 - 1][0] not in "MX":
+            i1 -= 1
+        seq, cig = [], []
+        for o in ops[i0:i1]:
+            if o[0] in "MX":
+                b = o[1]
+                if random.random() < 0.002:
+                    b = random.choice(A)
+                seq.append(b)
+                cig.append('M')
+            elif o[0] == 'D':
+                seq.append(o[1])
+                cig.append('I')
+            else:
+                cig.append('D')
+        recs.append((dprefix[i0], n, rle(cig), "".join(seq)))
+    recs.sort()
+    os.makedirs(os.path.join(outdir, "aux"), exist_ok=True)
+    w = lambda name, text: open(os.path.join(outdir, name), "w").write(text)
+    w("draft.fa", ">ctg1\n" + draft + "\n")
+    w("truth.fa", ">ctg1\n" + truth + "\n")
+    w("reads.fa", "".join(f">r{n}\n{s}\n" for p, n, c, s in recs))
+    w("sr.sam", f"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:ctg1\tLN:{len(draft)}\n" +
+      "".join(f"r{n}\t0\tctg1\t{p + 1}\t60\t{c}\t*\t0\t0\t{s}\t*\n" for p, n, c, s in recs))
+    # solid k-mers: canonical k-mers occurring exactly once in the truth, no homopolymer at the terminals,
+    # both strands set (external/suk/src/SolidKmers.cpp:166-189)
+    from collections import Counter
+    cnt = Counter()
+
+    def enc(s):
+        v = 0
+        for ch in s:
+            v = (v << 2) | A.index(ch)
+        return v
+    for i in range(G - K + 1):
+        km = truth[i:i + K]
+        cnt[min(km, rc(km))] += 1
+    nb = 1 << (2 * K)
+    words = [0] * (nb // 64)
+    ns = 0
+    for km, c in cnt.items():
+        if c == 1 and km[0] != km[1] and km[-1] != km[-2]:
+            for x in (km, rc(km)):
+                v = enc(x)
+                words[v >> 6] |= (1 << (v & 63))
+            ns += 1
+    with open(os.path.join(outdir, "aux", "solid_kmers.bvsd"), "wb") as f:
+        f.write(struct.pack("<Q", nb))
+        f.write(struct.pack(f"<{len(words)}Q", *words))
+    w("aux/stage.txt", "Stage:SolidKmers [2026-09-28 12:00:00]\t1\n")
+    if with_long:
+        LCOV, LL = 40, 8000
+        nl = G * LCOV // LL
+        lrecs = []
+        for n in range(nl):
+            s = random.randrange(0, max(1, G - LL))
+            e = min(G, s + LL)
+            i0, i1 = tpos[s], tpos[e - 1] + 1
+            while ops[i0][0] not in "MX":
+                i0 += 1
+            while ops[i1 - 1][0] not in "MX":
+                i1 -= 1
+            seq, cig, nm, first = [], [], 0, True
+            for idx, o in enumerate(ops[i0:i1]):
+                last = (idx == i1 - i0 - 1)
+                if o[1] is not None:
+                    r = random.random()
+                    has, b = True, o[1]
+                    if not first and not last:
+                        if r < 0.03:
+                            has = False
+                        elif r < 0.06:
+                            b = random.choice([x for x in A if x != o[1]])
+                    if o[0] in "MX":
+                        if has:
+                            seq.append(b); cig.append('M'); nm += (b != o[2])
+                        else:
+                            cig.append('D'); nm += 1
+                    else:
+                        if has:
+                            seq.append(b); cig.append('I'); nm += 1
+                    if not last and random.random() < 0.02:
+                        seq.append(random.choice(A)); cig.append('I'); nm += 1
+                else:
+                    cig.append('D'); nm += 1
+                first = False
+            lrecs.append((dprefix[i0], n, rle(cig), "".join(seq), nm))
+        lrecs.sort()
+        w("lr.sam", f"@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:ctg1\tLN:{len(draft)}\n" +
+          "".join(f"l{n}\t0\tctg1\t{p + 1}\t60\t{c}\t*\t0\t0\t{s}\t*\tNM:i:{nm}\n" for p, n, c, s, nm in lrecs))
+    return len(draft), len(recs), ns
+
+
+if __name__ == "__main__":
+    out, seed, G = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    k = int(sys.argv[sys.argv.index("--k") + 1]) if "--k" in sys.argv else 11
+    print("draft %d reads %d solid %d" % generate(out, seed, G, "--long" in sys.argv, k))
