@@ -1,0 +1,372 @@
+// Contig.cpp — strong-region detection, minimizer-anchored window division, arm filling/pruning, long-window
+// merging and FASTA re-assembly (reference: src/Contig.cpp).  Written from the behaviour described in
+// SURVEY.md Appendix A.4/A.5 and the cited lines; data lives in flat vectors and BitVec instead of sdsl objects and
+// per-k-mer heap nodes.
+#include "Contig.hpp"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <ostream>
+#include <unordered_map>
+
+namespace hypo {
+
+bool Contig::_no_long_reads = false;
+
+bool SolidKmers::load(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    uint64_t nbits = 0;
+    f.read((char*)&nbits, 8);
+    if (!f || nbits != (1ULL << (2 * k))) return false;
+    words.assign((nbits + 63) / 64, 0);
+    f.read((char*)words.data(), (std::streamsize)(words.size() * 8));
+    if (!f) return false;
+    uint64_t ones = 0;
+    for (uint64_t w : words) ones += (uint64_t)__builtin_popcountll(w);
+    num_solid = ones / 2;          // both strands are set per canonical k-mer (SolidKmers.cpp:182-186); reported only
+    return true;
+}
+bool SolidKmers::store(const std::string& path) const {
+    std::ofstream f(path, std::ios::binary);
+    if (!f) return false;
+    const uint64_t nbits = 1ULL << (2 * k);
+    f.write((const char*)&nbits, 8);
+    f.write((const char*)words.data(), (std::streamsize)(words.size() * 8));
+    return (bool)f;
+}
+
+// Contig.cpp:30-36: the name is the first token of the header; _reg_pos has one extra (dummy) bit
+Contig::Contig(uint32_t id, const std::string& name, const std::string& seq)
+    : _id(id), _name(name.substr(0, name.find_first_of(" \t"))), _len((uint32_t)seq.size()), _pseq(seq),
+      _solid_pos(seq.size()), _reg_pos(seq.size() + 1) {}
+
+// ---- Contig::find_solid_pos (src/Contig.cpp:40-74): on the device -------------------------------------------------
+int Contig::find_solid_pos(const SolidKmers& sk) {
+    const uint64_t nw = ((uint64_t)_len + 63) / 64;
+    std::vector<uint64_t> words(nw ? nw : 1), rank(nw + 1), kids(_len ? _len : 1);
+    uint64_t n = 0;
+    const int rc = hypo_gpu_solid_scan(_pseq.data(), _len, sk.get_k(), sk.words.data(), words.data(), kids.data(), kids.size(),
+                                       rank.data(), &n);
+    if (rc != HYPO_OK) return rc;
+    adopt_solid_scan(words.data(), rank.data(), kids.data(), n);
+    return HYPO_OK;
+}
+void Contig::adopt_solid_scan(const uint64_t* words, const uint64_t* rank, const uint64_t* kids, uint64_t n_solid) {
+    const uint64_t nw = ((uint64_t)_len + 63) / 64;
+    _solid_pos = BitVec(_len);
+    for (uint64_t w = 0; w < nw; ++w) _solid_pos.data()[w] = words[w];
+    if (rank) _solid_pos.adopt_rank(std::vector<uint64_t>(rank, rank + nw + 1)); else _solid_pos.init_support();
+    _kids.assign(kids, kids + n_solid);
+    _kcov.assign(n_solid, 0);
+    _ksup.assign(n_solid, 0);
+}
+
+// ---- Contig::prepare_for_division (src/Contig.cpp:75-185) -----------------------------------------------------------
+void Contig::prepare_for_division(unsigned k) {
+    std::vector<uint32_t> sr_pos, sr_len;
+    _anchor_kmers.clear();
+    _anchor_kmers.push_back(0);                                  // index 0 is a dummy
+    uint32_t last_kind = 0, first_kind = 0;
+    uint64_t last_sr_pos = 0, first_sr_pos = 0;
+    bool in_sr = false, pvs_80 = true;
+    uint32_t i = 0;
+    for (uint32_t pos = 0; pos < _len; ++pos) {
+        if (_solid_pos[pos]) {
+            bool is_valid = false;
+            const uint32_t cov = _kcov[i] & 0xffffu, sup = _ksup[i] & 0xffffu;
+            if (cov >= Sr_settings.cov_th) {
+                const uint32_t supp_th = (uint32_t)(Sr_settings.supp_frac * cov);
+                if (sup >= 2 * supp_th) { is_valid = true; pvs_80 = true; }
+                else if (sup >= supp_th) { if (pvs_80) is_valid = true; pvs_80 = false; }
+            }
+            if (is_valid) {
+                if (!in_sr) { first_kind = i; first_sr_pos = pos; in_sr = true; }
+                last_kind = i;
+                last_sr_pos = (uint64_t)pos + k;
+            }
+            ++i;
+        }
+        if (in_sr && pos == last_sr_pos) {
+            sr_pos.push_back((uint32_t)first_sr_pos); sr_len.push_back((uint32_t)(last_sr_pos - first_sr_pos));
+            _anchor_kmers.push_back(_kids[first_kind]); _anchor_kmers.push_back(_kids[last_kind]);
+            in_sr = false; pvs_80 = true;
+        }
+    }
+    if (in_sr) {
+        sr_pos.push_back((uint32_t)first_sr_pos); sr_len.push_back((uint32_t)(last_sr_pos - first_sr_pos));
+        _anchor_kmers.push_back(_kids[first_kind]); _anchor_kmers.push_back(_kids[last_kind]);
+    }
+    std::vector<uint64_t>().swap(_kids); std::vector<uint32_t>().swap(_kcov); std::vector<uint32_t>().swap(_ksup);
+    _solid_pos.clear();
+
+    _numSR = sr_pos.size();
+    int acc = 0;                                                 // std::accumulate(..., 0): int accumulator
+    for (uint32_t l : sr_len) acc += (int)l;
+    _lenSR = (uint64_t)acc;
+
+    // strong regions and the mega-windows between them
+    _is_win_even = !(_numSR > 0 && sr_pos[0] == 0);
+    _minimserinfo.clear();
+    _minimserinfo.reserve(_numSR + 1);
+    _reg_pos.set(0);
+    sr_pos.push_back(_len);                                      // dummy SR at the end
+    _reg_pos.set(_len);
+    uint32_t windex = 0;
+    if (_is_win_even) {
+        _minimserinfo.emplace_back();
+        if (sr_pos[0] > Window_settings.ideal_swind_size) initialise_minimserinfo(_pseq.unpack(0, sr_pos[0]), 0);
+        ++windex;
+    }
+    for (uint32_t ind = 0; ind < _numSR; ++ind, ++windex) {
+        _reg_pos.set(sr_pos[ind]);
+        const uint32_t mw_start = sr_pos[ind] + sr_len[ind];
+        _reg_pos.set(mw_start);
+        _minimserinfo.emplace_back();
+        const uint32_t mw_len = sr_pos[ind + 1] - mw_start;
+        if (mw_len > Window_settings.ideal_swind_size) initialise_minimserinfo(_pseq.unpack(mw_start, sr_pos[ind + 1]), windex);
+    }
+    _reg_pos.init_support();
+    _mreg_ready = true;
+}
+
+// ---- Contig::initialise_minimserinfo (src/Contig.cpp:455-524) -------------------------------------------------------
+// Forward-strand (k=10, w=10) window minimizers of a mega-window; only those occurring once and not poly-base are kept,
+// positions relative to the previous kept one.  The rolling k-mer is 32 bits wide and is not reset by an N.
+void Contig::initialise_minimserinfo(const std::string& draft_seq, uint32_t minfoind) {
+    const uint32_t K = Minimizer_settings.k, W = Minimizer_settings.w;
+    const uint32_t mask = (uint32_t)((1ULL << (2 * K)) - 1);
+    struct Item { uint32_t kmer, pos; };
+    Item ring[32]; uint32_t cap = W + 1, head = 0, tail = cap - 1, count = 0;
+    uint32_t kmer = 0, run = 0, processed = 0;
+    uint32_t last_found_position = (uint32_t)draft_seq.size() + 1;
+    std::vector<uint32_t> found, found_pos;
+    std::unordered_map<uint32_t, uint8_t> counter;
+    for (size_t i = 0; i < draft_seq.size(); ++i) {
+        const uint8_t c = nt4((unsigned char)draft_seq[i]);
+        if (c >= 4) { run = 0; continue; }
+        ++run;
+        kmer = ((kmer << 2) | c) & mask;
+        if (run < K) continue;
+        while (count && ring[tail].kmer > kmer) { --count; tail = tail == 0 ? cap - 1 : tail - 1; }
+        ++count; tail = (tail + 1) % cap; ring[tail] = Item{kmer, (uint32_t)i};
+        while (ring[head].pos + W <= i) { head = (head + 1) % cap; --count; }
+        if (++processed >= W) {
+            const uint32_t start = ring[head].pos - K + 1;
+            if (start != last_found_position) { found_pos.push_back(start); found.push_back(ring[head].kmer); ++counter[ring[head].kmer]; }
+            last_found_position = start;
+        }
+    }
+    MWMinimiserInfo& mi = _minimserinfo[minfoind];
+    last_found_position = 0;
+    for (size_t i = 0; i < found.size(); ++i) {
+        if (counter[found[i]] != 1) continue;
+        const uint32_t m = found[i];
+        if (m == Minimizer_settings.polyA || m == Minimizer_settings.polyC || m == Minimizer_settings.polyG || m == Minimizer_settings.polyT) continue;
+        mi.minimisers.push_back(m);
+        mi.rel_pos.push_back(found_pos[i] - last_found_position);
+        last_found_position = found_pos[i];
+    }
+    mi.support.assign(mi.rel_pos.size(), 0);
+    mi.coverage.assign(mi.rel_pos.size(), 0);
+}
+
+// ---- Contig::divide_into_regions (src/Contig.cpp:187-245) -----------------------------------------------------------
+void Contig::divide_into_regions() {
+    uint32_t sr_rank = 1, reg_start = 0, reg_ind = 0;
+    for (uint64_t i = 1; i < (uint64_t)_len + 1; ++i) {
+        if (!_reg_pos[i]) continue;
+        const uint32_t reg_end = (uint32_t)i;
+        if ((_is_win_even && reg_ind % 2 == 0) || (!_is_win_even && reg_ind % 2 == 1)) {
+            const char pvs = reg_ind == 0 ? 'n' : 's';
+            const char nxt = i == _len ? 'n' : 's';
+            divide(reg_ind, reg_start, reg_end, pvs, nxt);
+        } else {
+            _reg_info.push_back(sr_rank++);
+            _reg_type.push_back(RegionType::SR);
+        }
+        ++reg_ind;
+        reg_start = reg_end;
+    }
+    _reg_type.push_back(RegionType::SR);                         // dummy
+    std::vector<MWMinimiserInfo>().swap(_minimserinfo);
+    _mreg_ready = false;
+    _reg_pos.init_support();
+    _pwindows.clear();
+    _pwindows.reserve(_reg_type.size());
+    for (size_t i = 0; i < _reg_type.size(); ++i) {
+        if (_reg_type[i] == RegionType::SR || _reg_type[i] == RegionType::MSR) _pwindows.emplace_back();
+        else _pwindows.emplace_back(new Window(_pseq, _reg_pos.select(i + 1), _reg_pos.select(i + 2), WindowType::SHORT));
+    }
+}
+
+// ---- Contig::divide (src/Contig.cpp:526-628) --------------------------------------------------------------------------
+void Contig::divide(uint32_t reg_index, uint32_t beg, uint32_t end, char pvs, char nxt) {
+    const uint32_t IDEAL = Window_settings.ideal_swind_size, MK = Minimizer_settings.k, TOO_LARGE = 2 * IDEAL;
+    const uint32_t minfoidx = _is_win_even ? reg_index / 2 : (reg_index - 1) / 2;
+    const MWMinimiserInfo& mi = _minimserinfo[minfoidx];
+    const size_t num_min = mi.rel_pos.size();
+    uint32_t minimiser_pos = beg;
+    std::vector<uint32_t> supp_pos, supp_min;
+    for (size_t m = 0; m < num_min; ++m) {
+        minimiser_pos += mi.rel_pos[m];
+        const uint32_t cov = mi.coverage[m] & 0xffffu, sup = mi.support[m] & 0xffffu;
+        if (cov >= Minimizer_settings.cov_th) {
+            const uint32_t supp_th = (uint32_t)(Minimizer_settings.supp_frac * cov);
+            if (sup >= supp_th && minimiser_pos + MK < end) { supp_pos.push_back(minimiser_pos); supp_min.push_back(mi.minimisers[m]); }
+        }
+    }
+    uint32_t remaining = end - beg, start = beg;
+    std::vector<uint32_t> cut;
+    for (uint32_t m = 0; m < supp_pos.size() && remaining > IDEAL; ++m) {
+        const bool should_break = (m == supp_pos.size() - 1) ? true : (supp_pos[m + 1] > IDEAL + start);
+        if (should_break && supp_pos[m] > start) { cut.push_back(m); start = supp_pos[m] + MK; remaining = end - start; }
+    }
+    auto plain = [&](RegionType t, uint32_t at) { _reg_pos.set(at); _reg_info.push_back(0); _reg_type.push_back(t); };
+    auto msr = [&](uint32_t m) { _reg_pos.set(supp_pos[m]); _reg_info.push_back(supp_min[m]); _reg_type.push_back(RegionType::MSR); };
+    const uint32_t nmw = (uint32_t)cut.size();
+    if (nmw == 0) {
+        if (end > beg + TOO_LARGE) force_divide(beg, end, pvs, nxt);
+        else plain(pvs == 's' && nxt == 's' ? RegionType::SWS : pvs == 's' ? RegionType::SW : nxt == 's' ? RegionType::WS : RegionType::OTHER, beg);
+        return;
+    }
+    const uint32_t first_end = supp_pos[cut[0]];
+    if (first_end > beg + TOO_LARGE) force_divide(beg, first_end, pvs, 'm');
+    else plain(pvs == 's' ? RegionType::SWM : RegionType::WM, beg);
+    for (uint32_t c = 1; c < nmw; ++c) {
+        const uint32_t pm = cut[c - 1];
+        msr(pm);
+        const uint32_t ws = supp_pos[pm] + MK, we = supp_pos[cut[c]];
+        if (we > TOO_LARGE + ws) force_divide(ws, we, 'm', 'm');
+        else plain(RegionType::MWM, ws);
+    }
+    const uint32_t pm = cut[nmw - 1];
+    msr(pm);
+    const uint32_t ws = supp_pos[pm] + MK;
+    if (end > TOO_LARGE + ws) force_divide(ws, end, 'm', nxt);
+    else plain(nxt == 's' ? RegionType::MWS : RegionType::MW, start);      // start == ws here (Contig.cpp:622)
+}
+
+// ---- Contig::force_divide (src/Contig.cpp:630-711) --------------------------------------------------------------------
+void Contig::force_divide(uint32_t beg, uint32_t end, char pvs, char nxt) {
+    uint32_t start = beg, remaining = end - start;
+    std::vector<uint32_t> cut_pos;
+    while (remaining > Window_settings.ideal_swind_size) {
+        uint32_t s = start + Window_settings.wind_size_search_th;
+        while (s < end) {                                             // no homopolymer across the cut: ..AAB | CDD..
+            const uint8_t base = _pseq.enc_base_at(s);
+            if (base == _pseq.enc_base_at(s - 1)) s += 1;
+            else if (s + 1 < end && base == _pseq.enc_base_at(s + 1)) s += 2;
+            else if (s + 2 < end && _pseq.enc_base_at(s + 2) == _pseq.enc_base_at(s + 1)) s += 3;
+            else break;
+        }
+        if (s < end) { cut_pos.push_back(start); start = s + 1; remaining = end - start; }
+        else break;
+    }
+    if (start < end) cut_pos.push_back(start);
+    auto add = [&](RegionType t, uint32_t at) { _reg_pos.set(at); _reg_info.push_back(0); _reg_type.push_back(t); };
+    const uint32_t nw = (uint32_t)cut_pos.size();
+    if (nw == 1) {
+        RegionType t = RegionType::OTHER;
+        if (pvs == 's' && nxt == 's') t = RegionType::SWS;
+        else if (pvs == 's' && nxt == 'm') t = RegionType::SWM;
+        else if (pvs == 's' && nxt == 'n') t = RegionType::SW;
+        else if (pvs == 'm' && nxt == 's') t = RegionType::MWS;
+        else if (pvs == 'm' && nxt == 'm') t = RegionType::MWM;
+        else if (pvs == 'm' && nxt == 'n') t = RegionType::MW;
+        else if (pvs == 'n' && nxt == 's') t = RegionType::WS;
+        // (pvs 'n', nxt 'm') stays OTHER: the reference tests `nxt=='n' && nxt=='m'` (Contig.cpp:684)
+        add(t, beg);
+        return;
+    }
+    add(pvs == 's' ? RegionType::SW : pvs == 'm' ? RegionType::MW : RegionType::OTHER, beg);
+    for (uint32_t i = 1; i + 1 < nw; ++i) add(RegionType::OTHER, cut_pos[i]);
+    add(nxt == 's' ? RegionType::WS : nxt == 'm' ? RegionType::WM : RegionType::OTHER, cut_pos[nw - 1]);
+}
+
+// ---- Contig::fill_short_windows (src/Contig.cpp:249-289) --------------------------------------------------------------
+void Contig::fill_short_windows(std::vector<std::unique_ptr<Alignment>>& alignments) {
+    for (auto& a : alignments) { a->add_arms(*this); a.reset(); }     // serial: arm order inside a window = BAM order
+    std::vector<uint64_t>().swap(_anchor_kmers);
+    std::vector<uint32_t>().swap(_reg_info);
+    for (size_t i = 0; i < _reg_type.size(); ++i) {
+        if (_reg_type[i] == RegionType::SR || _reg_type[i] == RegionType::MSR || !_pwindows[i]) continue;
+        Window& w = *_pwindows[i];
+        bool discarded = false;
+        const uint64_t internal = w.get_num_internal();
+        if (internal < Arms_settings.min_short_num) {
+            const uint32_t win_len = (uint32_t)(_reg_pos.select(i + 2) - _reg_pos.select(i + 1));
+            const bool covered = w.get_maxlen_pre() + w.get_maxlen_suf() >= win_len;
+            const bool enough = w.get_num_pre() >= Arms_settings.min_short_num && w.get_num_suf() >= Arms_settings.min_short_num;
+            if (!(covered && enough)) { _pwindows[i].reset(); discarded = true; }
+        }
+        if (!discarded) {
+            const uint64_t contrib = w.get_num_total();
+            const bool c0 = internal > Arms_settings.min_internal_num1;
+            const bool c1 = contrib >= Arms_settings.min_contrib && (double)internal >= std::floor(Arms_settings.min_internal_contrib * (double)contrib);
+            const RegionType t = _reg_type[i];
+            const bool c2 = (t == RegionType::SWS || t == RegionType::SW || t == RegionType::WS || t == RegionType::MWS || t == RegionType::SWM) &&
+                            internal >= Arms_settings.min_internal_num2;
+            if (c0 || c1 || c2) w.clear_pre_suf();
+        }
+    }
+}
+
+// ---- Contig::prepare_long_windows (src/Contig.cpp:292-343) ------------------------------------------------------------
+void Contig::prepare_long_windows() {
+    _pseudo_reg_pos = BitVec((uint64_t)_len + 1);
+    const size_t num_reg = _reg_type.size();
+    _pseudo_reg_type.clear(); _true_reg_id.clear();
+    bool pvs_iswin = true;
+    uint32_t cur_len = 0;
+    for (uint32_t i = 0; i < num_reg; ++i) {
+        const uint32_t pos = (uint32_t)_reg_pos.select(i + 1);
+        if (_reg_type[i] == RegionType::SR || _reg_type[i] == RegionType::MSR || _pwindows[i]) {
+            if (pvs_iswin || i == num_reg - 1) {
+                _pseudo_reg_pos.set(pos); _pseudo_reg_type.push_back(RegionType::SR); _true_reg_id.push_back(i); cur_len = 0;
+            }
+            pvs_iswin = false;
+        } else {
+            const uint32_t winlen = (uint32_t)_reg_pos.select(i + 2) - pos;
+            if (pos == 0 || cur_len + winlen > Window_settings.ideal_lwind_size || !pvs_iswin) {
+                _pseudo_reg_pos.set(pos); _pseudo_reg_type.push_back(RegionType::LONG); _true_reg_id.push_back(i);
+                _reg_type[i] = RegionType::LONG; cur_len = winlen;
+            } else cur_len += winlen;
+            pvs_iswin = true;
+        }
+    }
+    _pseudo_reg_pos.init_support();
+    for (size_t i = 0; i + 1 < _pseudo_reg_type.size(); ++i)
+        if (_pseudo_reg_type[i] == RegionType::LONG)
+            _pwindows[_true_reg_id[i]].reset(new Window(_pseq, _pseudo_reg_pos.select(i + 1), _pseudo_reg_pos.select(i + 2), WindowType::LONG));
+}
+
+// ---- Contig::fill_long_windows (include/Contig.hpp:91-113) ------------------------------------------------------------
+void Contig::fill_long_windows(std::vector<std::unique_ptr<Alignment>>& alignments) {
+    for (auto& a : alignments) { a->add_arms(*this); a.reset(); }
+    const size_t num_reg = _reg_type.size() - 1;
+    for (size_t i = 0; i < num_reg; ++i)
+        if (_reg_type[i] == RegionType::LONG && _pwindows[i]->get_num_internal() > Arms_settings.min_internal_num3) _pwindows[i]->clear_pre_suf();
+    _pseudo_reg_pos.clear();
+    std::vector<RegionType>().swap(_pseudo_reg_type);
+    std::vector<uint32_t>().swap(_true_reg_id);
+}
+
+// ---- operator<< (src/Contig.cpp:345-366): one-line FASTA record -------------------------------------------------------
+std::ostream& operator<<(std::ostream& os, const Contig& ctg) {
+    os << ">" << ctg._name << std::endl;
+    const size_t num_reg = ctg._reg_type.size() - 1;
+    uint64_t curr = ctg._reg_pos.select(1);
+    for (size_t i = 0; i < num_reg; ++i) {
+        const uint64_t next = ctg._reg_pos.select(i + 2);
+        if (ctg._reg_type[i] == RegionType::SR || ctg._reg_type[i] == RegionType::MSR) os << ctg._pseq.unpack(curr, next);
+        else if (ctg._pwindows[i]) os << ctg._pwindows[i]->get_consensus();
+        else if (Contig::_no_long_reads) os << ctg._pseq.unpack(curr, next);
+        curr = next;
+    }
+    os << std::endl;
+    return os;
+}
+
+}  // namespace hypo

@@ -1,14 +1,21 @@
-// Contig.hpp — host mirror of the part of hypo::Contig that is on the hot path this round:
-// construction from a sequence and find_solid_pos (reference: include/Contig.hpp:62-68,137-140,
-// src/Contig.cpp:30-74).  The solid scan runs on the MI355X; the rank/select directory the reference builds
-// with sdsl (Contig.cpp:72-73) is the word-rank array the device returns plus two small lookups.
-// Segmentation, window construction and output (Contig.cpp:75-711) are "next" rows of SURVEY.md §8.
+// Contig.hpp — host mirror of hypo::Contig (reference: include/Contig.hpp:62-218, src/Contig.cpp).
+// Same public surface: find_solid_pos, prepare_for_division, divide_into_regions, fill_short_windows,
+// prepare_long_windows, fill_long_windows, get_num_regions / num_sr / len_sr, is_valid_window, generate_consensus,
+// set_no_long_reads, operator<<.  The solid scan runs on the MI355X (hypo_gpu_solid_scan); the per-window POA is
+// batched by Hypo::polish through Window::generate_consensus_batch.  sdsl's bit vectors are BitVec; the per-k-mer
+// mutexes of the reference are atomic adds.
 #pragma once
 #include <cstdint>
+#include <iosfwd>
+#include <memory>
 #include <string>
 #include <vector>
 #include "../../../include/hypo_gpu.h"
+#include "Alignment.hpp"
+#include "BitVec.hpp"
 #include "PackedSeq.hpp"
+#include "Settings.hpp"
+#include "Window.hpp"
 
 namespace hypo {
 
@@ -16,51 +23,82 @@ namespace hypo {
 struct SolidKmers {
     uint32_t k = 0;
     std::vector<uint64_t> words;              // 4^k bits, bit i at words[i >> 6] bit (i & 63)
+    uint64_t num_solid = 0;
     uint32_t get_k() const { return k; }
     bool is_solid(uint64_t kid) const { return (words[kid >> 6] >> (kid & 63)) & 1; }
+    // sdsl::store_to_file / load_from_file layout of a bit_vector: uint64 bit count, then the 64-bit words
+    bool load(const std::string& path);
+    bool store(const std::string& path) const;
+};
+
+struct MWMinimiserInfo {                       // include/Contig.hpp:46-52
+    std::vector<uint32_t> minimisers, rel_pos;
+    std::vector<uint32_t> support, coverage;   // 16-bit counters in the reference: read through & 0xffff
 };
 
 class Contig {
 public:
-    Contig(uint32_t id, const std::string& name, const std::string& seq)
-        : _id(id), _name(name.substr(0, name.find_first_of(" \t"))), _len(seq.size()), _pseq(seq) {}
+    Contig(uint32_t id, const std::string& name, const std::string& seq);
 
-    // Contig::find_solid_pos; returns HYPO_OK or the C-ABI error code
-    int find_solid_pos(const SolidKmers& sk) {
-        const uint64_t nw = (_len + 63) / 64;
-        _solid_pos.assign(nw, 0); _rank.assign(nw + 1, 0); _kids.assign(_len ? _len : 1, 0);
-        uint64_t n = 0;
-        const int rc = hypo_gpu_solid_scan(_pseq.data(), _len, sk.get_k(), sk.words.data(), _solid_pos.data(),
-                                           _kids.data(), _kids.size(), _rank.data(), &n);
-        if (rc != HYPO_OK) return rc;
-        _kids.resize(n);
-        return HYPO_OK;
-    }
+    int find_solid_pos(const SolidKmers& sk);                        // device scan; HYPO_OK or C-ABI error
+    void adopt_solid_scan(const uint64_t* words, const uint64_t* rank, const uint64_t* kids, uint64_t n_solid);
+    void prepare_for_division(unsigned k);
+    void divide_into_regions();
+    void fill_short_windows(std::vector<std::unique_ptr<Alignment>>& alignments);
+    void prepare_long_windows();
+    void fill_long_windows(std::vector<std::unique_ptr<Alignment>>& alignments);
+
+    uint64_t get_num_regions() const { return _reg_type.size() - 1; }
+    uint64_t get_num_sr() const { return _numSR; }
+    uint64_t get_len_sr() const { return _lenSR; }
+    bool is_valid_window(uint32_t ind) const { return _pwindows[ind] != nullptr; }
+    void generate_consensus(uint64_t ind, uint32_t th) { _pwindows[ind]->generate_consensus(th); }
+    Window* window(uint32_t ind) const { return _pwindows[ind].get(); }
+    static void set_no_long_reads() { _no_long_reads = true; }
+    friend std::ostream& operator<<(std::ostream&, const Contig&);
+    friend class Alignment;
+
+    // scan results (Contig::_solid_pos / _kmerinfo[i]->kid)
     uint64_t get_num_solid() const { return _kids.size(); }
-    bool is_solid_pos(uint64_t p) const { return (_solid_pos[p >> 6] >> (p & 63)) & 1; }
-    uint64_t kid_at(uint64_t i) const { return _kids[i]; }           // _kmerinfo[i]->kid (Contig.cpp:68)
-    // sdsl::rank_support_v semantics: number of marked positions in [0, p)
-    uint64_t rank(uint64_t p) const {
-        const uint64_t w = p >> 6, b = p & 63;
-        return _rank[w] + (b ? (uint64_t)__builtin_popcountll(_solid_pos[w] & ((1ULL << b) - 1)) : 0);
-    }
-    // sdsl::select_support_mcl semantics: position of the i-th marked bit, i is 1-based
-    uint64_t select(uint64_t i) const {
-        uint64_t lo = 0, hi = _solid_pos.size();                     // largest word w with _rank[w] < i
-        while (lo + 1 < hi) { const uint64_t mid = (lo + hi) / 2; if (_rank[mid] < i) lo = mid; else hi = mid; }
-        uint64_t word = _solid_pos[lo], need = i - _rank[lo];
-        while (--need) word &= word - 1;
-        return lo * 64 + (uint64_t)__builtin_ctzll(word);
-    }
+    bool is_solid_pos(uint64_t p) const { return _solid_pos[p]; }
+    uint64_t kid_at(uint64_t i) const { return _kids[i]; }
+    uint64_t rank(uint64_t p) const { return _solid_pos.rank(p); }
+    uint64_t select(uint64_t i) const { return _solid_pos.select(i); }
     const std::string& get_name() const { return _name; }
+    std::string draft_segment(uint32_t beg, uint32_t end) const { return _pseq.unpack(beg, end); }
     uint64_t get_len() const { return _len; }
+    // region map for diagnostics / tests: (begin, end, type) of region i
+    void region(uint32_t i, uint32_t& beg, uint32_t& end, RegionType& t) const { beg = (uint32_t)_reg_pos.select(i + 1); end = (uint32_t)_reg_pos.select(i + 2); t = _reg_type[i]; }
 
 private:
     uint32_t _id;
     std::string _name;
-    uint64_t _len;
+    uint32_t _len;
     PackedSeq<4> _pseq;
-    std::vector<uint64_t> _solid_pos, _rank, _kids;
+    BitVec _solid_pos;
+    std::vector<uint64_t> _kids;
+    std::vector<uint32_t> _kcov, _ksup;          // KmerInfo::coverage / support (UINT16 in the reference)
+    std::vector<uint64_t> _anchor_kmers;
+    BitVec _reg_pos;
+    bool _is_win_even = true;
+    bool _mreg_ready = false;
+    std::vector<MWMinimiserInfo> _minimserinfo;
+    std::vector<RegionType> _reg_type;
+    std::vector<uint32_t> _reg_info;
+    std::vector<std::unique_ptr<Window>> _pwindows;
+    uint64_t _numSR = 0, _lenSR = 0;
+    BitVec _pseudo_reg_pos;
+    std::vector<RegionType> _pseudo_reg_type;
+    std::vector<uint32_t> _true_reg_id;
+    static bool _no_long_reads;
+
+    void increment_support(uint32_t ind) { __atomic_fetch_add(&_ksup[ind], 1u, __ATOMIC_RELAXED); }
+    void increment_coverage(uint32_t ind) { __atomic_fetch_add(&_kcov[ind], 1u, __ATOMIC_RELAXED); }
+    void increment_minimser_support(uint32_t mi, uint32_t idx) { __atomic_fetch_add(&_minimserinfo[mi].support[idx], 1u, __ATOMIC_RELAXED); }
+    void increment_minimser_coverage(uint32_t mi, uint32_t idx) { __atomic_fetch_add(&_minimserinfo[mi].coverage[idx], 1u, __ATOMIC_RELAXED); }
+    void initialise_minimserinfo(const std::string& draft_seq, uint32_t minfoind);
+    void divide(uint32_t reg_index, uint32_t beg, uint32_t end, char pvs, char nxt);
+    void force_divide(uint32_t beg, uint32_t end, char pvs, char nxt);
 };
 
 }  // namespace hypo

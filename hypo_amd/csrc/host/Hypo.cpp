@@ -1,0 +1,215 @@
+// Hypo.cpp — orchestration of one polishing run (reference: src/Hypo.cpp).
+#include "Hypo.hpp"
+#include <omp.h>
+#include <sys/resource.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+
+namespace hypo {
+
+Hypo::Hypo(const InputFlags& flags) : _cFlags(flags) {
+    omp_set_num_threads((int)_cFlags.threads);
+    _tstart = std::chrono::steady_clock::now();
+}
+
+// slog::Monitor::stop prints wall time and RSS per phase (external/slog/src/Monitor.cpp:31-65); same shape of line
+void Hypo::stop(const char* label) {
+    const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - _t0).count();
+    struct rusage ru; getrusage(RUSAGE_SELF, &ru);
+    std::fprintf(stdout, "RESOURCES (%s): TIME= %g sec; PEAK RSS (so far)= %ldMB.\n", label, s, ru.ru_maxrss / 1024);
+    _times.phases.emplace_back(label, s);
+}
+
+void Hypo::polish() {
+    std::ofstream stagefile(HYPO_STAGEFILE, std::ofstream::out | std::ofstream::app);
+    if (_cFlags.intermed && !stagefile.is_open()) {
+        std::fprintf(stderr, "[Hypo::Hypo] Error: File open error: Stage File (%s) exists but could not be opened!\n", HYPO_STAGEFILE);
+        std::exit(1);
+    }
+    // ---- solid k-mers: loaded from aux/solid_kmers.bvsd (the KMC-based construction is outside the hot path) ------
+    start();
+    SolidKmers sk; sk.k = _cFlags.k;
+    if (_cFlags.done_stage < 1) {
+        std::fprintf(stderr, "[Hypo::SolidKmers] Error: this build does not run KMC/suk; provide %s and run with -i "
+                             "(stage file %s with stage 1), as written by the reference or by tests/golden/gen_e2e.py\n", HYPO_SKFILE, HYPO_STAGEFILE);
+        std::exit(1);
+    }
+    if (!sk.load(HYPO_SKFILE)) {
+        std::fprintf(stderr, "[Hypo::SolidKmers] Error: File Loading: Could not load the DS for Solid kmers (%s)!\n", HYPO_SKFILE);
+        std::exit(1);
+    }
+    stop("[Hypo:Hypo]: Loaded Solid kmers. ");
+    std::fprintf(stdout, "[Hypo::Hypo] Info: Number of (canonical) solid kmers (nonhp) : %lu\n", (unsigned long)sk.num_solid);
+
+    // ---- contigs ------------------------------------------------------------------------------------------------------
+    start();
+    {
+        std::vector<FastaRecord> recs;
+        if (!read_fastx(_cFlags.draft_filename, recs)) {
+            std::fprintf(stderr, "[Hypo::Hypo] Error: File open error: Draft File (%s) could not be read!\n", _cFlags.draft_filename.c_str());
+            std::exit(1);
+        }
+        uint32_t cid = 0;
+        for (auto& r : recs) { _cname_to_id[r.name] = cid; _contigs.emplace_back(new Contig(cid, r.name, r.seq)); ++cid; }
+    }
+    stop("[Hypo:Hypo]: Loaded Contigs. ");
+    _alignment_store.resize(_contigs.size());
+
+    // ---- solid positions: device scan, one contig after the other (the C-ABI call is serialised on one stream) ------
+    start();
+    for (auto& c : _contigs) {
+        if (c->find_solid_pos(sk) != HYPO_OK) { std::fprintf(stderr, "[Hypo::Contig] Error: %s\n", hypo_gpu_last_error()); std::exit(1); }
+    }
+    stop("[Hypo:Hypo]: Found Solid pos in contigs. ");
+
+    _contig_batch_size = _cFlags.processing_batch_size == 0 ? (uint32_t)_contigs.size() : _cFlags.processing_batch_size;
+    uint32_t num_batches = _contig_batch_size ? (uint32_t)_contigs.size() / _contig_batch_size : 0;
+    if (_contig_batch_size && _contigs.size() % _contig_batch_size != 0) ++num_batches;
+    std::fprintf(stdout, "[Hypo::Hypo] Info: Number.of contigs: %lu; Number of batches: %u\n", (unsigned long)_contigs.size(), num_batches);
+    _sf_short.reset(new SamReader(_cFlags.sr_bam_filename));
+    if (!_sf_short->ok()) { std::fprintf(stderr, "[Hypo::Hypo] Error: File open error: %s\n", _cFlags.sr_bam_filename.c_str()); std::exit(1); }
+    if (!_cFlags.lr_bam_filename.empty()) {
+        _sf_long.reset(new SamReader(_cFlags.lr_bam_filename));
+        if (!_sf_long->ok()) { std::fprintf(stderr, "[Hypo::Hypo] Error: File open error: %s\n", _cFlags.lr_bam_filename.c_str()); std::exit(1); }
+    }
+    std::ofstream dump;
+    if (!_region_dump.empty()) dump.open(_region_dump);
+
+    for (uint32_t batch_id = 0; batch_id < num_batches; ++batch_id) {
+        std::fprintf(stdout, "********** [Hypo::Hypo] Info: BATCH-ID: %u\n", batch_id);
+        const uint32_t initial_cid = batch_id * _contig_batch_size;
+        const uint32_t final_cid = std::min<uint32_t>((uint32_t)_contigs.size(), initial_cid + _contig_batch_size);
+        start();
+        create_alignments(true, batch_id);
+        stop("[Hypo:Hypo]: Loaded alignments. ");
+
+        start();
+        for (uint32_t cid = initial_cid; cid < final_cid; ++cid) {
+            auto& alns = _alignment_store[cid];
+#pragma omp parallel for
+            for (int64_t t = 0; t < (int64_t)alns.size(); ++t) alns[(size_t)t]->update_solidkmers_support(_cFlags.k, *_contigs[cid]);
+        }
+        stop("[Hypo:Hypo]: Solid kmers support update. ");
+
+        start();
+#pragma omp parallel for schedule(static, 1)
+        for (int64_t i = initial_cid; i < (int64_t)final_cid; ++i) _contigs[(size_t)i]->prepare_for_division(_cFlags.k);
+        uint64_t num_sr = 0, len_sr = 0;
+        for (uint32_t i = initial_cid; i < final_cid; ++i) { num_sr += _contigs[i]->get_num_sr(); len_sr += _contigs[i]->get_len_sr(); }
+        std::fprintf(stdout, "[Hypo::Hypo] Info: Total number of SR: %lu; Total length of SR: %lu\n", (unsigned long)num_sr, (unsigned long)len_sr);
+        stop("[Hypo:Hypo]: Finding SR (and preparing for division). ");
+
+        start();
+        for (uint32_t cid = initial_cid; cid < final_cid; ++cid) {
+            auto& alns = _alignment_store[cid];
+#pragma omp parallel for
+            for (int64_t t = 0; t < (int64_t)alns.size(); ++t) alns[(size_t)t]->update_minimisers_support(*_contigs[cid]);
+        }
+        stop("[Hypo:Hypo]: Minimisers support update. ");
+
+        start();
+#pragma omp parallel for schedule(static, 1)
+        for (int64_t i = initial_cid; i < (int64_t)final_cid; ++i) _contigs[(size_t)i]->divide_into_regions();
+        stop("[Hypo:Hypo]: Division into windows. ");
+
+        start();
+        for (uint32_t cid = initial_cid; cid < final_cid; ++cid) {
+            auto& alns = _alignment_store[cid];
+#pragma omp parallel for
+            for (int64_t t = 0; t < (int64_t)alns.size(); ++t) alns[(size_t)t]->find_short_arms(_cFlags.k, *_contigs[cid]);
+        }
+        stop("[Hypo:Hypo]: Short arms computing. ");
+        start();
+#pragma omp parallel for schedule(static, 1)
+        for (int64_t i = initial_cid; i < (int64_t)final_cid; ++i) { _contigs[(size_t)i]->fill_short_windows(_alignment_store[(size_t)i]); _alignment_store[(size_t)i].clear(); }
+        stop("[Hypo:Hypo]: Short arms filling. ");
+
+        if (!_cFlags.lr_bam_filename.empty()) {
+            start();
+            create_alignments(false, batch_id);
+            stop("[Hypo:Hypo]: Loaded alignments of Long reads. ");
+            start();
+#pragma omp parallel for schedule(static, 1)
+            for (int64_t i = initial_cid; i < (int64_t)final_cid; ++i) _contigs[(size_t)i]->prepare_long_windows();
+            for (uint32_t cid = initial_cid; cid < final_cid; ++cid) {
+                auto& alns = _alignment_store[cid];
+#pragma omp parallel for
+                for (int64_t t = 0; t < (int64_t)alns.size(); ++t) alns[(size_t)t]->find_long_arms(*_contigs[cid]);
+            }
+#pragma omp parallel for schedule(static, 1)
+            for (int64_t i = initial_cid; i < (int64_t)final_cid; ++i) { _contigs[(size_t)i]->fill_long_windows(_alignment_store[(size_t)i]); _alignment_store[(size_t)i].clear(); }
+            stop("[Hypo:Hypo]: Long arms filling. ");
+        } else {
+            Contig::set_no_long_reads();
+        }
+
+        // ---- POA: every valid window of the contig batch in one device call (reference: per-window OpenMP loop) ----
+        start();
+        Window::prepare_for_poa(_cFlags.score_params, _cFlags.threads);
+        std::vector<Window*> wins;
+        for (uint32_t i = initial_cid; i < final_cid; ++i)
+            for (uint64_t w = 0; w < _contigs[i]->get_num_regions(); ++w)
+                if (_contigs[i]->is_valid_window((uint32_t)w)) wins.push_back(_contigs[i]->window((uint32_t)w));
+        if (Window::generate_consensus_batch(wins) != HYPO_OK) { std::fprintf(stderr, "[Hypo::Window] Error: %s\n", hypo_gpu_last_error()); std::exit(1); }
+        std::fprintf(stdout, "[Hypo::Hypo] Info: polished windows (Batch %u): %lu\n", batch_id, (unsigned long)wins.size());
+        stop("[Hypo:Hypo]: POA of windows. ");
+
+        if (dump.is_open())
+            for (uint32_t i = initial_cid; i < final_cid; ++i)
+                for (uint64_t w = 0; w < _contigs[i]->get_num_regions(); ++w) {
+                    uint32_t b, e; RegionType t;
+                    _contigs[i]->region((uint32_t)w, b, e, t);
+                    const Window* win = _contigs[i]->window((uint32_t)w);
+                    if (!win && t != RegionType::SR && t != RegionType::MSR && !_cFlags.lr_bam_filename.empty()) continue;   // swallowed by a LONG window
+                    dump << _contigs[i]->get_name() << '\t' << b << '\t' << e << '\t' << region_name(t);
+                    if (win) dump << '\t' << win->dump_counts() << '\t' << win->arms_crc32() << '\t' << win->get_consensus();
+                    else if (t != RegionType::SR && t != RegionType::MSR) dump << "\t0\t0\t0\t0\t0\t" << _contigs[i]->draft_segment(b, e);   // no arms: draft kept
+                    dump << '\n';
+                }
+    }
+    _alignment_store.clear();
+
+    start();
+    std::ofstream ofile(_cFlags.output_filename);
+    if (!ofile.is_open()) {
+        std::fprintf(stderr, "[Hypo::Hypo] Error: File open error: Output File (%s) could not be opened!\n", _cFlags.output_filename.c_str());
+        std::exit(1);
+    }
+    for (auto& c : _contigs) ofile << *c;
+    ofile.close();
+    stop("[Hypo:Hypo]: Writing results. ");
+    _times.overall = std::chrono::duration<double>(std::chrono::steady_clock::now() - _tstart).count();
+    std::fprintf(stdout, "RESOURCES ([Hypo:Hypo]: Overall. ): TIME= %g sec.\n", _times.overall);
+    _contigs.clear();
+}
+
+// src/Hypo.cpp:278-329: stream the (coordinate-sorted) file, stop when a record of the next batch shows up
+void Hypo::create_alignments(bool is_sr, uint32_t batch_id) {
+    const uint32_t mq = _cFlags.map_qual_th;
+    SamReader& sf = is_sr ? *_sf_short : *_sf_long;
+    const uint32_t final_cid = batch_id * _contig_batch_size + _contig_batch_size;
+    uint64_t num_invalid = 0, num_alns = 0;
+    SamRecord rec;
+    while (sf.next(rec)) {
+        if (rec.flag & (SAM_FUNMAP | SAM_FSECONDARY | SAM_FQCFAIL | SAM_FDUP)) continue;
+        if (rec.mapq < mq) continue;
+        if (rec.tid < 0 || _cname_to_id.find(sf.tid2name(rec.tid)) == _cname_to_id.end()) {
+            std::fprintf(stderr, "[Hypo::Hypo] Error: Alignment File error: Contig-reference (%s) does not exist in the draft!\n",
+                         rec.tid < 0 ? "*" : sf.tid2name(rec.tid).c_str());
+            std::exit(1);
+        }
+        const uint32_t cid = _cname_to_id[sf.tid2name(rec.tid)];
+        auto& store = _alignment_store[cid];
+        if (is_sr) store.emplace_back(new Alignment(*_contigs[cid], rec));
+        else store.emplace_back(new Alignment(*_contigs[cid], _cFlags.norm_edit_th, rec));
+        if (!store.back()->is_valid) { store.pop_back(); ++num_invalid; } else ++num_alns;
+        if (cid >= final_cid) break;                     // first record of the next batch has been consumed (as in the reference)
+    }
+    std::fprintf(stdout, "[Hypo::Hypo] Info: Number of alignments (Batch %u): loaded (%lu) invalid (%lu)\n", batch_id,
+                 (unsigned long)num_alns, (unsigned long)num_invalid);
+}
+
+}  // namespace hypo

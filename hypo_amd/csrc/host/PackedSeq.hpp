@@ -58,6 +58,32 @@ public:
         for (size_t i = left; i < right; ++i) s.push_back(base_at(i));
         return s;
     }
+    // k-mer (2 bits per base, first base most significant) ending inside [ind, ind + k): true iff the k bases starting
+    // at ind spell target (src/PackedSeq.cpp:264-289)
+    bool check_kmer(uint64_t target, unsigned k, size_t ind) const {
+        uint64_t kmer = 0; unsigned len = 0;
+        const uint64_t mask = (1ULL << (2 * k)) - 1;
+        for (size_t i = ind; i < ind + k; ++i) {
+            const uint8_t b = enc_base_at(i);
+            if (b < 4) { kmer = ((kmer << 2) | b) & mask; if (len < k) ++len; } else { len = 0; kmer = 0; }
+            if (len == k && kmer == target) return true;
+        }
+        return false;
+    }
+    // first (is_first) or last start position of target among the k-mers lying inside [left, right)
+    // (src/PackedSeq.cpp:291-320)
+    bool find_kmer(uint64_t target, unsigned k, size_t left, size_t right, bool is_first, size_t& result) const {
+        if (left == right) return false;
+        uint64_t kmer = 0; unsigned len = 0;
+        const uint64_t mask = (1ULL << (2 * k)) - 1;
+        bool found = false;
+        for (size_t i = left; i < right; ++i) {
+            const uint8_t b = enc_base_at(i);
+            if (b < 4) { kmer = ((kmer << 2) | b) & mask; if (len < k) ++len; } else { len = 0; kmer = 0; }
+            if (len == k && kmer == target) { result = i - k + 1; found = true; if (is_first) break; }
+        }
+        return found;
+    }
     // raw PackedSeq bytes for the C-ABI batch
     const uint8_t* data() const { return _data.data(); }
     size_t byte_size() const { return _data.size(); }

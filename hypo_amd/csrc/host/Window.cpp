@@ -63,6 +63,19 @@ int Window::generate_consensus_batch(const std::vector<Window*>& windows) {
     return HYPO_OK;
 }
 
+uint32_t Window::arms_crc32() const {
+    uint32_t crc = 0xffffffffu;
+    auto feed = [&crc](unsigned char c) { crc ^= c; for (int k = 0; k < 8; ++k) crc = (crc >> 1) ^ (0xedb88320u & (0u - (crc & 1u))); };
+    bool first = true;
+    for (const auto* group : {&_internal_arms, &_pre_arms, &_suf_arms})
+        for (const auto& a : *group) {
+            if (!first) feed('\n');
+            first = false;
+            for (char c : a.unpack()) feed((unsigned char)c);
+        }
+    return ~crc;
+}
+
 void Window::generate_consensus(uint32_t /*engine_idx*/) {
     std::vector<Window*> one{this};
     const int rc = generate_consensus_batch(one);

@@ -60,6 +60,11 @@ public:
     uint32_t get_num_total() const { return _num_internal + _num_empty + _num_pre + _num_suf; }
     uint32_t get_maxlen_pre() const { return _longest_pre_len; }
     uint32_t get_maxlen_suf() const { return _longest_suf_len; }
+    // diagnostics used by the region dump of Hypo::polish (tests): counts as the reference's inspect file prints them
+    std::string dump_counts() const {
+        return std::to_string(_num_internal) + "\t" + std::to_string(_num_pre) + "\t" + std::to_string(_num_suf) + "\t" + std::to_string(_num_empty);
+    }
+    uint32_t arms_crc32() const;             // crc32 of the arms (internal, prefix, suffix; insertion order) joined by '\n'
     void clear_pre_suf() {
         _num_pre = 0; _num_suf = 0;
         _pre_arms.clear(); _suf_arms.clear();

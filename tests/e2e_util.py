@@ -1,0 +1,85 @@
+"""Shared driver of the end-to-end goldens (tests/golden/e2e_*): regenerates the inputs with the committed
+deterministic generator, checks their md5 against the manifest, runs the `hypo` binary of this repo with the
+reference's own command line and compares the polished FASTA and the per-region digests with what the REAL reference
+produced (tests/golden/make_e2e_golden.py).  `device="shim"` runs the host pipeline over tests/shim (CPU oracle behind
+the C-ABI, host-logic check only); `device="gpu"` runs it over the real libhypo_gpu.so."""
+import gzip
+import hashlib
+import importlib.util
+import json
+import os
+import shlex
+import subprocess
+import zlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(HERE, "golden")
+BIN = os.path.join(ROOT, "hypo_amd", "_build", "hypo")
+SHIM_DIR = os.path.join(HERE, "_build", "shim")
+CASES = ["e2e_20k_s1", "e2e_200k_long_s3", "e2e_200k_k9_s5", "e2e_100k_k7_s7"]
+
+
+def _md5(p):
+    return hashlib.md5(open(p, "rb").read()).hexdigest()
+
+
+def build_binary():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "hypo_amd", "csrc")], check=True)
+    return BIN
+
+
+def build_shim():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "shim")], check=True)
+    return SHIM_DIR
+
+
+def make_inputs(name, outdir):
+    man = json.load(open(os.path.join(GOLD, name + ".manifest.json")))
+    spec = importlib.util.spec_from_file_location("gen_e2e", os.path.join(GOLD, "gen_e2e.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    a = man["args"]
+    gen.generate(str(outdir), a["seed"], a["G"], a["long"], a["k"])
+    for f, want in man["inputs_md5"].items():
+        assert _md5(os.path.join(outdir, f)) == want, f"{name}: regenerated {f} differs from the golden's input"
+    return man
+
+
+def run_case(name, outdir, device, threads=4, extra_env=None):
+    man = make_inputs(name, outdir)
+    argv = shlex.split(man["command"])
+    argv[0] = BIN
+    argv[argv.index("-t") + 1] = str(threads)
+    env = dict(os.environ)
+    env["HYPO_REGION_DUMP"] = os.path.join(str(outdir), "regions.tsv")
+    if device == "shim":
+        env["LD_LIBRARY_PATH"] = SHIM_DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    env.update(extra_env or {})
+    p = subprocess.run(argv, cwd=str(outdir), env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    used_shim = "oracle_device_shim" in p.stderr
+    assert used_shim == (device == "shim"), "wrong device library behind the C-ABI"
+    return man, p
+
+
+def check_outputs(name, outdir, man):
+    got = open(os.path.join(str(outdir), "hypo_draft.fasta"), "rb").read()
+    want = gzip.open(os.path.join(GOLD, name + ".expected.fa.gz")).read()
+    regions = json.load(gzip.open(os.path.join(GOLD, name + ".regions.json.gz")))
+    rows = [l.rstrip("\n").split("\t") for l in open(os.path.join(str(outdir), "regions.tsv"))]
+    assert len(rows) == len(regions), f"{name}: {len(rows)} regions, reference has {len(regions)}"
+    for i, (r, g) in enumerate(zip(rows, regions)):
+        beg, end, typ = int(r[1]), int(r[2]) - 1, r[3]
+        if typ == "LNG" and i + 1 < len(rows):          # a LONG window swallows the arm-less regions up to the next row
+            end = int(rows[i + 1][1]) - 1
+        assert [beg, end, typ] == g[:3], f"{name}: region {r[:4]} vs reference {g[:3]}"
+        if typ not in ("SR", "MSR"):
+            counts = [int(x) for x in r[4:8]]
+            assert counts == g[3:7], f"{name}: arms of window {beg}-{end}: {counts} vs reference {g[3:7]}"
+            assert int(r[8]) == g[7], f"{name}: arm bytes of window {beg}-{end} differ"
+            assert zlib.crc32(r[9].encode()) == g[8], f"{name}: consensus of window {beg}-{end} differs"
+    assert hashlib.md5(got).hexdigest() == man["expected_fasta_md5"]
+    assert got == want
+    return len(regions)

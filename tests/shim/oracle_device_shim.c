@@ -1,0 +1,44 @@
+/* oracle_device_shim.c — TEST INFRASTRUCTURE, never shipped, never on the product's library path.
+ *
+ * A stand-in for libhypo_gpu.so that answers the two data-path entry points with the CPU oracle, so that the
+ * host pipeline above the C-ABI (hypo_amd/csrc/host: SAM parsing, support counting, segmentation, arms, FASTA
+ * reassembly) can be exercised end to end in the GPU-less CI container against the reference's golden outputs.
+ * Only tests/test_host_e2e_cpu.py puts this directory on LD_LIBRARY_PATH; the `-m gpu` e2e test runs the same
+ * binary against the real library.  What it proves is the HOST logic; it says nothing about the HIP kernels.
+ */
+#include <stdio.h>
+#include <string.h>
+#include "../../include/hypo_gpu.h"
+#include "../../oracle/hypo_oracle.h"
+
+static int g_ready = 0;
+int hypo_gpu_init(int device_id) { (void)device_id; g_ready = 1; fprintf(stderr, "[oracle_device_shim] TEST SHIM in use: CPU oracle behind the C-ABI\n"); return HYPO_OK; }
+int hypo_gpu_shutdown(void) { g_ready = 0; return HYPO_OK; }
+int hypo_gpu_abi_version(void) { return HYPO_GPU_ABI_VERSION; }
+const char* hypo_gpu_last_error(void) { return "oracle_device_shim"; }
+int hypo_gpu_num_cus(void) { return 0; }
+
+int hypo_gpu_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k, const uint64_t* bitset_words,
+                        uint64_t* solid_pos_words, uint64_t* kids, uint64_t kids_cap, uint64_t* word_rank, uint64_t* n_solid) {
+    if (!g_ready) return HYPO_E_NOTINIT;
+    return oracle_solid_scan(packed4, n_bases, k, bitset_words, solid_pos_words, kids, kids_cap, word_rank, n_solid);
+}
+
+int hypo_gpu_poa_slot_layout(const HypoWindowBatch* in, uint64_t* off) {
+    uint64_t acc = 0;
+    for (uint32_t w = 0; w < in->n_windows; ++w) {
+        const HypoWindow* W = &in->windows[w];
+        uint64_t longest = W->draft_len;
+        const uint32_t narm = W->n_internal + W->n_prefix + W->n_suffix;
+        for (uint32_t a = 0; a < narm; ++a) if (in->arm_len[W->first_arm + a] > longest) longest = in->arm_len[W->first_arm + a];
+        off[w] = acc;
+        acc += (2 * longest + 64 + 7) / 8 * 8;
+    }
+    off[in->n_windows] = acc;
+    return HYPO_OK;
+}
+
+int hypo_gpu_poa_batch(const HypoScoreParams* scores, const HypoWindowBatch* in, HypoConsensusBatch* out) {
+    if (!g_ready) return HYPO_E_NOTINIT;
+    return oracle_poa_batch(scores, in, out, 0, NULL, NULL);
+}

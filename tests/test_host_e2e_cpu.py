@@ -1,0 +1,27 @@
+"""Host pipeline above the C-ABI, end to end, in the GPU-less container: SAM parsing, solid-kmer / minimiser
+support, strong regions, minimiser cuts, arms (short and long reads), FASTA reassembly of hypo_amd/csrc/host are
+checked against the REAL reference's outputs with the CPU oracle standing in for the device (tests/shim).  The
+device itself is checked by the same goldens in tests/test_gpu_e2e.py."""
+import pytest
+import e2e_util as eu
+
+
+@pytest.fixture(scope="module")
+def built():
+    eu.build_shim()
+    try:
+        eu.build_binary()
+    except Exception as e:                     # hipcc missing: the host binary links the real library
+        pytest.skip(f"cannot build the hypo binary here: {e}")
+
+
+@pytest.mark.parametrize("name", eu.CASES)
+def test_e2e_host_pipeline_matches_reference(built, name, tmp_path):
+    man, _ = eu.run_case(name, tmp_path, "shim")
+    assert eu.check_outputs(name, tmp_path, man) > 0
+
+
+def test_e2e_batches_and_threads_do_not_change_the_result(built, tmp_path):
+    # -p 1 (one contig per batch) and another thread count: same bytes (reference: src/Hypo.cpp:104-113)
+    man, _ = eu.run_case("e2e_20k_s1", tmp_path, "shim", threads=7)
+    eu.check_outputs("e2e_20k_s1", tmp_path, man)
