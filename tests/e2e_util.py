@@ -66,6 +66,9 @@ def run_case(name, outdir, device, threads=4, extra_env=None):
 
 def check_outputs(name, outdir, man):
     got = open(os.path.join(str(outdir), "hypo_draft.fasta"), "rb").read()
+    if not os.path.exists(os.path.join(GOLD, name + ".expected.fa.gz")):      # full-size set: md5 only
+        assert hashlib.md5(got).hexdigest() == man["expected_fasta_md5"], f"{name}: polished FASTA differs from the reference's"
+        return sum(1 for _ in open(os.path.join(str(outdir), "regions.tsv")))
     want = gzip.open(os.path.join(GOLD, name + ".expected.fa.gz")).read()
     regions = json.load(gzip.open(os.path.join(GOLD, name + ".regions.json.gz")))
     rows = [l.rstrip("\n").split("\t") for l in open(os.path.join(str(outdir), "regions.tsv"))]
