@@ -16,10 +16,17 @@
 #ifdef HYPO_EMU
 #define HD inline
 #define HYPO_UNROLL
+#define HYPO_IN_VGPR(x) do { } while (0)
+#define HYPO_NO_IFCVT() do { } while (0)
 #else
 #include <hip/hip_runtime.h>
 #define HD __device__ __forceinline__
 #define HYPO_UNROLL _Pragma("unroll")
+// keeps a group-uniform value in a vector register (the row loop runs out of scalar registers and the compiler would
+// otherwise park it in a VGPR lane and v_readlane it back on every use)
+#define HYPO_IN_VGPR(x) asm volatile("" : "+v"(x))
+// an empty volatile statement keeps a rarely taken, group-uniform branch a branch (no if-conversion into selects)
+#define HYPO_NO_IFCVT() asm volatile("")
 #endif
 
 namespace hypo {

@@ -333,6 +333,16 @@ struct Poa {
             for (int c = 0; c < CPL; ++c) out[c] = NEG;
         }
     }
+    HD void load_ring_at(int off, int S, int (&out)[CPL]) const {   // off = slot * S
+        if (CPL * g.lane < S) {
+            const Pack pk = *(const Pack*)(ring + off + CPL * g.lane);
+            HYPO_UNROLL
+            for (int c = 0; c < CPL; ++c) out[c] = (int)pk.v[c];
+        } else {
+            HYPO_UNROLL
+            for (int c = 0; c < CPL; ++c) out[c] = NEG;
+        }
+    }
     HD int read_dir(int cell) const {                      // cell = row_index * S + column
         if (NIB) { const int b = dir[cell >> 1]; return (cell & 1) ? (b >> 4) : (b & 15); }
         return dir[cell];
@@ -345,7 +355,7 @@ struct Poa {
         tb_steps = 0; tb_fv = L;
         if (n_nodes == 0 || L == 0) return RES_OK;
         n_nodes = g.uniform(n_nodes);
-        const int W = L + 1;
+        const int W = g.uniform(L) + 1;
         const int S = (W + CPL - 1) / CPL * CPL;           // row stride (even when NIB)
         if (n_nodes * S > Cfg::DIRCELLS) return RES_OVERFLOW;
         if (sizeof(score_t) < 4) {                          // int16 rows are exact only below this bound
@@ -354,10 +364,11 @@ struct Poa {
             if (a * (n_nodes + L + 1) >= 32767) return RES_OVERFLOW;
         }
         if (meta_dirty) { build_rowmeta(); HYPO_TICK(PH_META); }
-        const int R = Cfg::RINGCELLS / S;                   // ring rows; row i can still see rows i-R .. i-1
+        const int R = g.uniform(Cfg::RINGCELLS / S);        // ring rows; row i can still see rows i-R .. i-1
         if (R < maxdelta + 1 || R < 1) return RES_OVERFLOW;
         cells += (uint64_t)(n_nodes + 1) * W; aligns += 1; rows_done += (uint64_t)n_nodes;
 
+        HYPO_IN_VGPR(m); HYPO_IN_VGPR(n); HYPO_IN_VGPR(gp);
         const int j0 = CPL * g.lane;
         int sq[CPL];                                        // sq[c] = code of seq[j-1] for column j = j0+c
         HYPO_UNROLL
@@ -371,6 +382,8 @@ struct Poa {
         int best = NEG, best_i = -1;
 
         int slot = 0;                                        // ring slot of row i (no integer division in the loop)
+        int slotS = 0, rowS = 0;                             // slot * S and r * S, advanced by addition (group-uniform)
+        const int RS = R * S;
         // Row metadata: full-wave groups keep it in registers (lane r holds row r, fetched with v_readlane, no
         // LDS latency in the row loop); narrower groups and the big classes prefetch it from LDS two rows ahead.
         constexpr int MREG = (NMAX + GW - 1) / GW;
@@ -409,7 +422,7 @@ struct Poa {
                 int hp[CPL];
                 if (fastrow) { HYPO_UNROLL for (int c = 0; c < CPL; ++c) hp[c] = last[c]; }
                 else if (p0 == 0) { HYPO_UNROLL for (int c = 0; c < CPL; ++c) hp[c] = jg[c]; }
-                else { int ps = slot - (i - p0); ps = ps < 0 ? ps + R : ps; load_ring(ps, S, hp); }
+                else { int ps = slotS - (i - p0) * S; ps = ps < 0 ? ps + RS : ps; load_ring_at(ps, S, hp); }
                 const int left = g.shfl_up1(hp[CPL - 1], NEG);
                 HYPO_UNROLL
                 for (int c = 0; c < CPL; ++c) {
@@ -424,8 +437,8 @@ struct Poa {
                 for (int c = 0; c < CPL; ++c) { pD[c] = 0; pU[c] = 0; }
                 for (int p = 1; p < k; ++p) {
                     int hp[CPL];
-                    int ps = slot - (i - pred_row(r, p)); ps = ps < 0 ? ps + R : ps;
-                    load_ring(ps, S, hp);
+                    int ps = slotS - (i - pred_row(r, p)) * S; ps = ps < 0 ? ps + RS : ps;
+                    load_ring_at(ps, S, hp);
                     const int left = g.shfl_up1(hp[CPL - 1], NEG);
                     HYPO_UNROLL
                     for (int c = 0; c < CPL; ++c) {
@@ -449,9 +462,10 @@ struct Poa {
             if (g.lane == 0 && mode == MODE_ROV) v[0] = 0;   // first column (sisd..cpp:200-211,237-239)
             // horizontal term H[i][j] = max(H[i][j], H[i][j-1] + g): prefix max of H[i][j] - j*g
             {
-                int run = NEG;
+                int run = v[0] - jg[0];
+                v[0] = run;
                 HYPO_UNROLL
-                for (int c = 0; c < CPL; ++c) {
+                for (int c = 1; c < CPL; ++c) {
                     const int x = v[c] - jg[c];
                     run = x > run ? x : run;
                     v[c] = run;
@@ -477,23 +491,28 @@ struct Poa {
                 if (NIB) {
                     HYPO_UNROLL
                     for (int c = 0; c < CPL; c += 2) dk.v[c / 2] = (uint8_t)(dc[c] | (dc[c + 1] << 4));
-                    *(DPack*)(dir + ((r * S + j0) >> 1)) = dk;
+                    *(DPack*)(dir + ((rowS + j0) >> 1)) = dk;
                 } else {
                     HYPO_UNROLL
                     for (int c = 0; c < CPL; ++c) dk.v[c] = (uint8_t)dc[c];
-                    *(DPack*)(dir + r * S + j0) = dk;
+                    *(DPack*)(dir + rowS + j0) = dk;
                 }
-                *(Pack*)(ring + slot * S + j0) = pk;
+                *(Pack*)(ring + slotS + j0) = pk;
             }
             slot = slot + 1 == R ? 0 : slot + 1;
+            slotS = slot == 0 ? 0 : slotS + S;
+            rowS += S;
             HYPO_UNROLL
             for (int c = 0; c < CPL; ++c) last[c] = v[c];
             // end cell: first strictly greater in rank order (sisd..cpp:279-288,332-339)
-            if ((mode == MODE_LOV || sink) && g.lane == le) {
-                int val = v[0];
-                HYPO_UNROLL
-                for (int c = 1; c < CPL; ++c) if (c == ce) val = v[c];
-                if (val > best) { best = val; best_i = i; }
+            if (mode == MODE_LOV || sink) {                  // group-uniform: most rows of kNW / kROV skip it
+                HYPO_NO_IFCVT();
+                if (g.lane == le) {
+                    int val = v[0];
+                    HYPO_UNROLL
+                    for (int c = 1; c < CPL; ++c) if (c == ce) val = v[c];
+                    if (val > best) { best = val; best_i = i; }
+                }
             }
             g.sync();
         }
