@@ -66,6 +66,22 @@ struct PoaParams {
     int sr_m, sr_n, sr_g, lr_m, lr_n, lr_g;
 };
 
+// How the per-window code reaches PoaParams.  On the device it is a pointer into the kernel-argument segment
+// (constant address space) that is made opaque at every use, so each use is a fresh scalar load instead of nine
+// 64-bit pointers pinned in SGPRs for the lifetime of a persistent wave (the row loop needs those registers).
+#ifdef HYPO_EMU
+struct PoaParamRef {
+    const PoaParams* p;
+    HD const PoaParams* operator->() const { return p; }
+};
+#else
+struct PoaParamRef {
+    typedef const PoaParams __attribute__((address_space(4)))* cptr;
+    cptr p;
+    HD cptr operator->() const { cptr q = p; asm volatile("" : "+s"(q)); return q; }
+};
+#endif
+
 template <int GW_, int CPL_, int LCAP_, int NMAX_, int KIN_, int DIRCELLS_, int RINGCELLS_, int ARMBYTES_,
           int SEQMAX_, class ScoreT, class IdT, int PATHCAP_ = 0>
 struct PoaCfg {
@@ -165,7 +181,7 @@ struct Poa {
     }
 
     const Grp<GW>& g;
-    const PoaParams& P;
+    const PoaParamRef P;
     // memory slice
     score_t* ring; uint8_t* dir; uint32_t* rowmeta; uint32_t* seqtab; wt_t* inw; int16_t* posnode;
     id_t *inp, *al, *r2n, *n2r, *stack;
@@ -179,7 +195,7 @@ struct Poa {
     uint64_t cells, aligns, reused, rows_done, topo_runs;
     uint64_t tphase[PH_N]; uint64_t tlast;
 
-    HD Poa(const Grp<GW>& g_, const PoaParams& P_, char* mem) : g(g_), P(P_) {
+    HD Poa(const Grp<GW>& g_, const PoaParamRef& P_, char* mem) : g(g_), P(P_) {
         ring = (score_t*)(mem + Lay::oRing); dir = (uint8_t*)(mem + Lay::oDir);
         rowmeta = (uint32_t*)(mem + Lay::oRowmeta); seqtab = (uint32_t*)(mem + Lay::oSeqtab);
         inw = (wt_t*)(mem + Lay::oInw); posnode = (int16_t*)(mem + Lay::oPosnode);
@@ -220,7 +236,7 @@ struct Poa {
             else if (t < ni) { a = t; mode = MODE_NW; head = true; tail = true; }
             else if (t < ni + np) { a = ni + (np - 1 - (t - ni)); mode = MODE_LOV; head = true; tail = false; }
             else { a = t; mode = MODE_ROV; head = false; tail = true; }
-            const uint32_t len = P.arm_len[a0 + a];
+            const uint32_t len = P->arm_len[a0 + a];
             if (len + (is_long ? 0u : 2u) > (uint32_t)Cfg::LMAX) { over = true; continue; }
             if (len) any_len = true;
             seqtab[base + t] = seq_ent((uint32_t)a, len, head, tail, mode, false, 1);
@@ -246,7 +262,7 @@ struct Poa {
             const uint32_t e = seqtab[base + t];
             if ((e >> 30) == 0) {
                 const int nb = (int)(((e >> 16) & 0x3ff) + 3) >> 2;
-                const uint8_t* src = P.arms2 + P.arm_off[a0 + (uint32_t)stack[t]];
+                const uint8_t* src = P->arms2 + P->arm_off[a0 + (uint32_t)stack[t]];
                 uint8_t* dst = armbuf + (e & 0x7fff);
                 for (int b = 0; b < nb; ++b) dst[b] = src[b];
             }
@@ -282,8 +298,8 @@ struct Poa {
         if (L > Cfg::LMAX) return RES_OVERFLOW;
         const uint8_t* p;
         if (where == 0) p = armbuf + (e & 0x7fff);
-        else if (where == 1) p = P.arms2 + P.arm_off[W.first_arm + (e & 0x7fff)];
-        else p = P.draft4 + W.draft_off;
+        else if (where == 1) p = P->arms2 + P->arm_off[W.first_arm + (e & 0x7fff)];
+        else p = P->draft4 + W.draft_off;
         for (int t = g.lane; t < L; t += GW) {
             int c;
             if (head && t == 0) c = C_J;
@@ -903,8 +919,8 @@ struct Poa {
         return rc;
     }
     HD int run_long(uint32_t w, const HypoWindow& W) {
-        const int m = P.lr_m, n = P.lr_n, gp = P.lr_g;
-        const uint8_t* d4 = P.draft4 + W.draft_off;
+        const int m = P->lr_m, n = P->lr_n, gp = P->lr_g;
+        const uint8_t* d4 = P->draft4 + W.draft_off;
         int n_seq = 0; bool added = false;
         int rc = build_seqtab(W, true, &n_seq, &added);
         if (rc != RES_OK) return rc;
@@ -987,23 +1003,23 @@ struct Poa {
             conslen = o;
             g.sync();
         }
-        const uint64_t oo = P.out_off[w], cap = P.out_off[w + 1] - oo;
+        const uint64_t oo = P->out_off[w], cap = P->out_off[w + 1] - oo;
         if ((uint64_t)conslen > cap) { finish(w, HYPO_ST_CONS_OVERFLOW, (uint32_t)conslen); return RES_OK; }
-        for (int t = g.lane; t < conslen; t += GW) P.out_bases[oo + t] = "ACGTNJO"[consbuf[t]];
+        for (int t = g.lane; t < conslen; t += GW) P->out_bases[oo + t] = "ACGTNJO"[consbuf[t]];
         finish(w, HYPO_ST_OK, (uint32_t)conslen);
         return RES_OK;
     }
 
     // ---- outputs -----------------------------------------------------------------------------------
     HD void finish(uint32_t w, int status, uint32_t len) const {
-        if (g.lane == 0) { P.out_len[w] = len; P.out_status[w] = (uint8_t)status; }
+        if (g.lane == 0) { P->out_len[w] = len; P->out_status[w] = (uint8_t)status; }
     }
     HD int emit_draft(uint32_t w, const uint8_t* d4, int dlen) const {
-        const uint64_t o = P.out_off[w], cap = P.out_off[w + 1] - o;
+        const uint64_t o = P->out_off[w], cap = P->out_off[w + 1] - o;
         if ((uint64_t)dlen > cap) { finish(w, HYPO_ST_CONS_OVERFLOW, (uint32_t)dlen); return RES_OK; }
         for (int t = g.lane; t < dlen; t += GW) {
             int c = (d4[t >> 1] >> (4 - 4 * (t & 1))) & 15;
-            P.out_bases[o + t] = "ACGTN"[c < 4 ? c : 4];
+            P->out_bases[o + t] = "ACGTN"[c < 4 ? c : 4];
         }
         finish(w, HYPO_ST_OK, (uint32_t)dlen);
         return RES_OK;
@@ -1011,8 +1027,8 @@ struct Poa {
 
     // Window::generate_consensus_short (src/Window.cpp:87-154)
     HD int run_short(uint32_t w, const HypoWindow& W) {
-        const int m = P.sr_m, n = P.sr_n, gp = P.sr_g;
-        const uint8_t* d4 = P.draft4 + W.draft_off;
+        const int m = P->sr_m, n = P->sr_n, gp = P->sr_g;
+        const uint8_t* d4 = P->draft4 + W.draft_off;
         n_nodes = 0; topo_dirty = false; meta_dirty = true;
         int n_seq = 0; bool added = false;
         int rc = build_seqtab(W, false, &n_seq, &added);
@@ -1044,9 +1060,9 @@ struct Poa {
         HYPO_TICK(PH_CONS);
         if (len < 2) return RES_UNDEFINED;                  // Window.hpp:144 strips two markers
         const int olen = len - 2;
-        const uint64_t o = P.out_off[w], cap = P.out_off[w + 1] - o;
+        const uint64_t o = P->out_off[w], cap = P->out_off[w + 1] - o;
         if ((uint64_t)olen > cap) { finish(w, HYPO_ST_CONS_OVERFLOW, (uint32_t)olen); return RES_OK; }
-        for (int t = g.lane; t < olen; t += GW) P.out_bases[o + t] = "ACGTNJO"[code[path[len - 2 - t]]];
+        for (int t = g.lane; t < olen; t += GW) P->out_bases[o + t] = "ACGTNJO"[code[path[len - 2 - t]]];
         finish(w, HYPO_ST_OK, (uint32_t)olen);
         HYPO_TICK(PH_OUT);
         return RES_OK;
@@ -1054,10 +1070,10 @@ struct Poa {
 
     // Window::generate_consensus (src/Window.cpp:44-61)
     HD int run(uint32_t w) {
-        const HypoWindow W = P.windows[w];
+        const HypoWindow W = P->windows[w];
         const uint32_t ne = W.n_internal + W.n_prefix + W.n_suffix;
         if (W.n_empty > ne) { finish(w, HYPO_ST_OK, 0); return RES_OK; }
-        if (ne < 2) return emit_draft(w, P.draft4 + W.draft_off, (int)W.draft_len);
+        if (ne < 2) return emit_draft(w, P->draft4 + W.draft_off, (int)W.draft_len);
         if (W.type != HYPO_WIN_SHORT) {
             if (Cfg::PATHCAP == 0) return RES_UNSUPPORTED;   // re-queued to a class that keeps sequence paths
             return run_long(w, W);

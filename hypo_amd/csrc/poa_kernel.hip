@@ -138,18 +138,35 @@ poa_plan_scatter_kernel(PoaQueues Q, uint32_t n_windows) {
 // ------------------------------------------------------------------------------------------------
 // persistent per-class kernel
 // ------------------------------------------------------------------------------------------------
+// All arguments travel as one struct: the kernel never names it, it reads the kernel-argument segment through an
+// opaque constant-address-space pointer at the (rare) points of use.  Passing PoaParams / PoaQueues as ordinary by-value
+// arguments made the compiler keep ~20 64-bit pointers in SGPRs across the whole persistent loop; the row loop of
+// Poa::align then spilled its own scalars into VGPR lanes and read them back with v_readlane on every row.
+struct PoaKArgs {
+    PoaParams P;
+    PoaQueues Q;
+    int cls;
+    char* scratch;
+    uint32_t* head;
+    const uint32_t* bound;
+};
+typedef const PoaKArgs __attribute__((address_space(4)))* PoaKArgPtr;
+__device__ __forceinline__ PoaKArgPtr fresh(PoaKArgPtr p) { asm volatile("" : "+s"(p)); return p; }
+
 template <class Cfg, bool USE_LDS>
-__global__ void __launch_bounds__(64) poa_class_kernel(PoaParams P, PoaQueues Q, int cls, char* scratch,
-                                                       uint32_t* head, const uint32_t* bound) {
+__global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through the kernarg segment*/) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const PoaKArgPtr ka = (PoaKArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int GW = Cfg::GW;
     constexpr int GPW = 64 / GW;                       // groups per wave
     const int wl = (int)(threadIdx.x & 63);
     const int grp = wl / GW;
     Grp<GW> g{wl & (GW - 1)};
     char* mem = USE_LDS ? smem + (size_t)grp * PoaLayout<Cfg>::BYTES
-                        : scratch + ((size_t)blockIdx.x * GPW + grp) * PoaLayout<Cfg>::BYTES;
-    const uint32_t count = *bound;          // queue slots [.., *bound) are final when this launch starts
+                        : fresh(ka)->scratch + ((size_t)blockIdx.x * GPW + grp) * PoaLayout<Cfg>::BYTES;
+    const int cls = fresh(ka)->cls;
+    const uint32_t count = *fresh(ka)->bound;   // queue slots [.., *bound) are final when this launch starts
+    const PoaParamRef P{&ka->P};
     uint64_t cells = 0, aligns = 0, abytes = 0;
     uint32_t n_ok = 0, n_esc = 0, n_fail = 0;
 #ifdef HYPO_PHASE_TIMERS
@@ -159,10 +176,10 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaParams P, PoaQueues Q,
 #endif
     for (;;) {
         uint32_t idx = 0;
-        if (g.lane == 0) idx = atomicAdd(head, 1u);
+        if (g.lane == 0) idx = atomicAdd(fresh(ka)->head, 1u);
         idx = (uint32_t)g.shfl((int)idx, 0);
         if (idx >= count) break;
-        const uint32_t w = Q.items[(size_t)cls * Q.stride + idx];
+        const uint32_t w = fresh(ka)->Q.items[(size_t)cls * fresh(ka)->Q.stride + idx];
         Poa<Cfg> poa(g, P, mem);
         const int rc = poa.run(w);
         if (rc == RES_OK) { cells += poa.cells; aligns += poa.aligns; }   // reference-equivalent work of FINISHED windows only
@@ -173,35 +190,37 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaParams P, PoaQueues Q,
         if (rc == RES_OK) {
             ++n_ok;
             if (g.lane == 0) {                                  // algorithmic bytes, SURVEY.md 8(d)
-                const HypoWindow W = P.windows[w];
+                const HypoWindow W = P->windows[w];
                 const uint32_t narm = W.n_internal + W.n_prefix + W.n_suffix;
-                uint64_t a = (W.draft_len + 1) / 2 + 16 + 8 * (1 + (uint64_t)narm) + P.out_len[w];
-                for (uint32_t t = 0; t < narm; ++t) a += (P.arm_len[W.first_arm + t] + 3) / 4;
+                uint64_t a = (W.draft_len + 1) / 2 + 16 + 8 * (1 + (uint64_t)narm) + P->out_len[w];
+                const uint32_t* alen = P->arm_len;
+                for (uint32_t t = 0; t < narm; ++t) a += (alen[W.first_arm + t] + 3) / 4;
                 abytes += a;
             }
         } else if ((rc == RES_OVERFLOW || rc == RES_UNSUPPORTED) && cls + 1 < kNumPoaClasses) {
             if (g.lane == 0) {
-                const uint32_t slot = atomicAdd(&Q.count[cls + 1], 1u);
-                Q.items[(size_t)(cls + 1) * Q.stride + slot] = w;
+                const uint32_t slot = atomicAdd(&fresh(ka)->Q.count[cls + 1], 1u);
+                fresh(ka)->Q.items[(size_t)(cls + 1) * fresh(ka)->Q.stride + slot] = w;
             }
             ++n_esc;
         } else {
             if (g.lane == 0) {
-                P.out_len[w] = 0;
-                P.out_status[w] = (uint8_t)(rc == RES_UNDEFINED ? HYPO_ST_UNDEFINED : HYPO_ST_CAPACITY);
+                P->out_len[w] = 0;
+                P->out_status[w] = (uint8_t)(rc == RES_UNDEFINED ? HYPO_ST_UNDEFINED : HYPO_ST_CAPACITY);
             }
             ++n_fail;
         }
     }
     if (g.lane == 0) {
-        atomicAdd((unsigned long long*)&Q.stats->n_class[cls], (unsigned long long)n_ok);
-        atomicAdd((unsigned long long*)&Q.stats->n_escalated, (unsigned long long)n_esc);
-        atomicAdd((unsigned long long*)&Q.stats->n_failed, (unsigned long long)n_fail);
-        atomicAdd((unsigned long long*)&Q.stats->dp_cells, (unsigned long long)cells);
-        atomicAdd((unsigned long long*)&Q.stats->n_alignments, (unsigned long long)aligns);
-        atomicAdd((unsigned long long*)&Q.stats->alg_bytes[cls], (unsigned long long)abytes);
+        HypoPoaStats* st = fresh(ka)->Q.stats;
+        atomicAdd((unsigned long long*)&st->n_class[cls], (unsigned long long)n_ok);
+        atomicAdd((unsigned long long*)&st->n_escalated, (unsigned long long)n_esc);
+        atomicAdd((unsigned long long*)&st->n_failed, (unsigned long long)n_fail);
+        atomicAdd((unsigned long long*)&st->dp_cells, (unsigned long long)cells);
+        atomicAdd((unsigned long long*)&st->n_alignments, (unsigned long long)aligns);
+        atomicAdd((unsigned long long*)&st->alg_bytes[cls], (unsigned long long)abytes);
 #ifdef HYPO_PHASE_TIMERS
-        unsigned long long* ph = (unsigned long long*)((char*)Q.count + 512) + (size_t)cls * 16;   // header + 512: [class][16]
+        unsigned long long* ph = (unsigned long long*)((char*)fresh(ka)->Q.count + 512) + (size_t)cls * 16;   // header + 512: [class][16]
         for (int i = 0; i < PH_N; ++i) atomicAdd(&ph[i], (unsigned long long)tph[i]);
         atomicAdd(&ph[PH_N], (unsigned long long)((uint64_t)clock64() - tstart));                // wave lifetime
         atomicAdd(&ph[PH_N + 1], 1ull);                                                           // waves
@@ -242,7 +261,9 @@ static hipError_t launch_class(const PoaParams& P, const PoaQueues& Q, int cls, 
     // first pass: slots [0, planned) with cursor head[cls]; mop-up pass: slots [planned, count) with cursor head2[cls]
     uint32_t* head = mop_up ? Q.head2 + cls : Q.head + cls;
     const uint32_t* bound = (mop_up || waves_per_cu_cap == 0) ? Q.count + cls : Q.planned + cls;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, stream, P, Q, cls, scratch, head, bound);
+    PoaKArgs a;
+    a.P = P; a.Q = Q; a.cls = cls; a.scratch = scratch; a.head = head; a.bound = bound;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, stream, a);
     return hipGetLastError();
 }
 

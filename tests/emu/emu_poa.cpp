@@ -123,7 +123,7 @@ template <class Cfg>
 void lane_body(int lane, void* arg) {
     Job<Cfg>* j = (Job<Cfg>*)arg;
     hypo::Grp<Cfg::GW> g{lane, &j->eg};
-    hypo::Poa<Cfg> poa(g, *j->P, j->mem);
+    hypo::Poa<Cfg> poa(g, hypo::PoaParamRef{j->P}, j->mem);
     j->rc[lane] = poa.run(j->w);
     if (lane == 0) { j->cells = poa.cells; j->aligns = poa.aligns; }
 }
