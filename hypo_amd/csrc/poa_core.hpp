@@ -192,7 +192,7 @@ struct Poa {
     int n_nodes; int L; bool topo_dirty; bool meta_dirty; int maxdelta;
     int tb_steps; int tb_fv;
     bool last_changed;         // did the most recent add_alignment change the graph topology?
-    uint64_t cells, aligns, reused, rows_done, topo_runs;
+    uint64_t cells, aligns, reused, rows_done, topo_runs, cons_serial;
     uint64_t tphase[PH_N]; uint64_t tlast;
 
     HD Poa(const Grp<GW>& g_, const PoaParamRef& P_, char* mem) : g(g_), P(P_) {
@@ -210,7 +210,7 @@ struct Poa {
         msa = (uint16_t*)(mem + Lay::oMsa); dstcnt = (uint32_t*)(mem + Lay::oDst); consbuf = (uint8_t*)(mem + Lay::oCons);
         n_paths = 0; path_used = 0; head_first = 0;
         n_nodes = 0; L = 0; topo_dirty = false; meta_dirty = true; maxdelta = 0; tb_steps = 0; tb_fv = 0;
-        cells = 0; aligns = 0; reused = 0; rows_done = 0; topo_runs = 0; last_changed = true;
+        cells = 0; aligns = 0; reused = 0; rows_done = 0; topo_runs = 0; cons_serial = 0; last_changed = true;
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
         tlast = 0;
         HYPO_TICK_RESET();
@@ -798,10 +798,96 @@ struct Poa {
         return rc;
     }
 
+    // ---- heaviest bundle, all lanes (graph.cpp:610-658 when no tie rule and no branch completion is involved) ------
+    // The reference scores nodes in rank order: score = weight of the heaviest in-edge + score of its source (sources
+    // -1), and among in-edges of equal weight the one whose source scores >= wins.  When no node has two in-edges
+    // sharing its maximum weight, the chosen in-edge does not depend on any score, so the scores are sums along the
+    // chosen-predecessor forest: pointer doubling over ranks (log2(n) rounds, every lane busy) instead of one lane
+    // walking n nodes with a dependent LDS round trip each.  The doubling table is kept: position t of the
+    // consensus path is the t-th ancestor of the best node, found by all lanes at once.  Returns CONS_SERIAL when a
+    // weight tie, or a best node that is not a sink (branch completion), needs the literal pass below.
+    static constexpr int CONS_SERIAL = -2;
+    static constexpr int NN = NMAX + 1;                     // ranks + one "no predecessor" sentinel
+    static constexpr int LV = NN <= 64 ? 6 : (NN <= 128 ? 7 : 8);
+    static constexpr int RPL = (NN + GW - 1) / GW;          // ranks per lane
+    static constexpr bool FAST_CONS = sizeof(id_t) == 1 && NN <= 255 && RPL <= 16;
+    static_assert(!FAST_CONS || 4 * NN + LV * NN + 1 + 2 * NMAX <= (int)sizeof(score_t) * Cfg::RINGCELLS + Cfg::DIRBYTES, "fast consensus scratch aliases ring+dir");
+    HD int consensus_fast(int16_t** path_out) {
+        int32_t* acc = (int32_t*)ring;                       // (sum of chosen weights << 8) + nodes on the chain, by rank
+        uint8_t* up = (uint8_t*)(acc + NN);                  // up[lv][r]: 2^lv-th ancestor of rank r (n = none)
+        int16_t* path = (int16_t*)(up + ((LV * NN + 1) & ~1));
+        const int n = n_nodes;
+        bool tie = false;
+        for (int r = g.lane; r <= n; r += GW) {
+            int a = 0, pr = n;
+            if (r < n) {
+                const uint32_t meta = rowmeta[r];
+                const int k = (int)((meta >> 8) & 0xff);
+                a = -255;                                    // a source scores -1 and is one node
+                if (k != 0) {
+                    const int u = r2n[r];
+                    int bw = inw[u * KIN], bp = (int)(meta >> 17);
+                    bool tied = false;
+                    for (int p = 1; p < k; ++p) {
+                        const int w = inw[u * KIN + p];
+                        if (w > bw) { bw = w; bp = pred_row(r, p); tied = false; }
+                        else if (w == bw) tied = true;
+                    }
+                    tie |= tied;
+                    a = (bw << 8) + 1; pr = bp - 1;
+                }
+            }
+            acc[r] = a; up[r] = (uint8_t)pr;
+        }
+        g.sync();
+        if (g.any(tie)) return CONS_SERIAL;
+        for (int lv = 1; lv <= LV; ++lv) {                  // after round lv a rank has summed 2^lv chain nodes; tables 0..LV-1 are kept
+            int na[RPL], nacc[RPL];
+            const uint8_t* prev = up + (lv - 1) * NN;
+            HYPO_UNROLL
+            for (int q = 0; q < RPL; ++q) {
+                const int r = g.lane + q * GW;
+                if (r <= n) { const int a = prev[r]; na[q] = prev[a]; nacc[q] = acc[r] + acc[a]; }
+            }
+            g.sync();
+            HYPO_UNROLL
+            for (int q = 0; q < RPL; ++q) {
+                const int r = g.lane + q * GW;
+                if (r <= n) { if (lv < LV) up[lv * NN + r] = (uint8_t)na[q]; acc[r] = nacc[q]; }
+            }
+            g.sync();
+        }
+        // best node: first strictly greater score in rank order, node 0 if every score is -1 (graph.cpp:618,633-635)
+        int key = 0;
+        for (int r = g.lane; r < n; r += GW) {
+            const int k2 = (((acc[r] >> 8) + 1) << 8) | (255 - r);
+            key = k2 > key ? k2 : key;
+        }
+        key = g.reduce_max(key);
+        const int best_r = (key >> 8) == 0 ? (int)n2r[0] : 255 - (key & 255);
+        const int max_id = r2n[best_r];
+        if (nout[max_id] != 0) return CONS_SERIAL;
+        const int len = g.uniform(acc[best_r] & 255);
+        for (int t = g.lane; t < len; t += GW) {
+            int x = best_r;
+            HYPO_UNROLL
+            for (int lv = 0; lv < LV; ++lv) if ((t >> lv) & 1) x = up[lv * NN + x];
+            path[t] = (int16_t)r2n[x];
+        }
+        g.sync();
+        *path_out = path;                                   // reversed: path[len-1] is the first node
+        return len;
+    }
+
     // ---- Graph::generate_consensus (graph.cpp:467-476,610-705) --------------------------------------
     // Scratch aliases ring + dir: score[NMAX] i32, pred[NMAX] i16, path[NMAX] i16, rs[NMAX] i32, w0r[NMAX] u16.
     HD int consensus(int16_t** path_out) {
         if (meta_dirty) build_rowmeta();
+        if (FAST_CONS) {
+            const int fl = consensus_fast(path_out);
+            if (fl != CONS_SERIAL) return fl;
+            cons_serial += 1;
+        }
         int32_t* score = (int32_t*)ring;                   // by node id
         int16_t* pred = (int16_t*)(score + NMAX);
         int16_t* path = pred + NMAX;

@@ -171,21 +171,15 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through t
     uint32_t n_ok = 0, n_esc = 0, n_fail = 0;
 #ifdef HYPO_PHASE_TIMERS
     uint64_t tph[PH_N] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t dbg[4] = {0, 0, 0, 0};
+    uint64_t dbg[5] = {0, 0, 0, 0, 0};
     const uint64_t tstart = (uint64_t)clock64();
 #endif
-    for (;;) {
-        uint32_t idx = 0;
-        if (g.lane == 0) idx = atomicAdd(fresh(ka)->head, 1u);
-        idx = (uint32_t)g.shfl((int)idx, 0);
-        if (idx >= count) break;
-        const uint32_t w = fresh(ka)->Q.items[(size_t)cls * fresh(ka)->Q.stride + idx];
-        Poa<Cfg> poa(g, P, mem);
-        const int rc = poa.run(w);
+    // what happens to a window once Poa::run / step has returned something other than RES_CONTINUE
+    auto account = [&](Poa<Cfg>& poa, uint32_t w, int rc) {
         if (rc == RES_OK) { cells += poa.cells; aligns += poa.aligns; }   // reference-equivalent work of FINISHED windows only
 #ifdef HYPO_PHASE_TIMERS
         for (int i = 0; i < PH_N; ++i) tph[i] += poa.tphase[i];
-        dbg[0] += poa.rows_done; dbg[1] += poa.aligns - poa.reused; dbg[2] += poa.reused; dbg[3] += poa.topo_runs;
+        dbg[0] += poa.rows_done; dbg[1] += poa.aligns - poa.reused; dbg[2] += poa.reused; dbg[3] += poa.topo_runs; dbg[4] += poa.cons_serial;
 #endif
         if (rc == RES_OK) {
             ++n_ok;
@@ -210,7 +204,21 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through t
             }
             ++n_fail;
         }
-    }
+    };
+    auto dequeue = [&](uint32_t* w) -> bool {
+        uint32_t idx = 0;
+        if (g.lane == 0) idx = atomicAdd(fresh(ka)->head, 1u);
+        idx = (uint32_t)g.shfl((int)idx, 0);
+        if (idx >= count) return false;
+        *w = fresh(ka)->Q.items[(size_t)cls * fresh(ka)->Q.stride + idx];
+        return true;
+    };
+    Poa<Cfg> poa(g, P, mem);
+    // The groups of a wavefront (GPW > 1) take windows in lock step: all dequeue, all run, all write their consensus.
+    // (Letting a finished group open its next window while its neighbours are still aligning was measured and is
+    // slower: the dequeue + descriptor + arm staging round trips of one group then stall the other three, 4x as often.)
+    uint32_t w;
+    while (dequeue(&w)) account(poa, w, poa.run(w));
     if (g.lane == 0) {
         HypoPoaStats* st = fresh(ka)->Q.stats;
         atomicAdd((unsigned long long*)&st->n_class[cls], (unsigned long long)n_ok);
@@ -224,7 +232,7 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through t
         for (int i = 0; i < PH_N; ++i) atomicAdd(&ph[i], (unsigned long long)tph[i]);
         atomicAdd(&ph[PH_N], (unsigned long long)((uint64_t)clock64() - tstart));                // wave lifetime
         atomicAdd(&ph[PH_N + 1], 1ull);                                                           // waves
-        for (int i = 0; i < 4; ++i) atomicAdd(&ph[PH_N + 2 + i], (unsigned long long)dbg[i]);      // rows, real alignments, reused, toposorts
+        for (int i = 0; i < 5; ++i) atomicAdd(&ph[PH_N + 2 + i], (unsigned long long)dbg[i]);      // rows, real alignments, reused, toposorts, serial consensus passes
 #endif
     }
 }

@@ -34,7 +34,7 @@ def main():
               f"accounted={100 * tot / life:.1f}%  cycles/window={life / max(st['n_class'][c], 1) / 1e3:.1f}k")
         nw = max(st['n_class'][c], 1)
         print(f"    per window: DP rows={ph[c, 10] / nw:.1f} real alignments={ph[c, 11] / nw:.2f} reused={ph[c, 12] / nw:.2f} "
-              f"toposorts={ph[c, 13] / nw:.2f}; dp cycles/row={ph[c, 1] / max(ph[c, 10], 1):.0f}")
+              f"toposorts={ph[c, 13] / nw:.2f} serial consensus={ph[c, 14] / nw:.3f}; dp cycles/row={ph[c, 1] / max(ph[c, 10], 1):.0f}")
         for i in range(8):
             print(f"    {NAMES[i]:14s} {100 * ph[c, i] / tot:6.2f}%   {ph[c, i] / max(st['n_class'][c], 1) / 1e3:9.2f} kcycles/window")
 
