@@ -18,6 +18,7 @@
 #define HYPO_UNROLL
 #define HYPO_IN_VGPR(x) do { } while (0)
 #define HYPO_NO_IFCVT() do { } while (0)
+#define HYPO_ARRIVED(x) do { } while (0)
 #else
 #include <hip/hip_runtime.h>
 #define HD __device__ __forceinline__
@@ -27,6 +28,9 @@
 #define HYPO_IN_VGPR(x) asm volatile("" : "+v"(x))
 // an empty volatile statement keeps a rarely taken, group-uniform branch a branch (no if-conversion into selects)
 #define HYPO_NO_IFCVT() asm volatile("")
+// consumes a loaded value here, so the wait for the load is placed here and not at the first use inside a loop (where it
+// would be an s_waitcnt lgkmcnt(0) per iteration that also waits for the previous iteration's LDS stores)
+#define HYPO_ARRIVED(x) asm volatile("" :: "v"(x))
 #endif
 
 namespace hypo {

@@ -411,6 +411,8 @@ struct Poa {
                 const int rr = q * GW + g.lane;
                 mreg[q] = rr < n_nodes ? rowmeta[rr] : 0u;
             }
+            HYPO_UNROLL
+            for (int q = 0; q < (META_IN_REGS ? MREG : 1); ++q) HYPO_ARRIVED(mreg[q]);
         }
         uint32_t meta_a = META_IN_REGS ? 0u : rowmeta[0];
         uint32_t meta_b = (!META_IN_REGS && n_nodes > 1) ? rowmeta[1] : 0u;
