@@ -509,7 +509,7 @@ struct Poa {
                 if (NIB) {
                     HYPO_UNROLL
                     for (int c = 0; c < CPL; c += 2) dk.v[c / 2] = (uint8_t)(dc[c] | (dc[c + 1] << 4));
-                    *(DPack*)(dir + ((rowS + j0) >> 1)) = dk;
+                    *(DPack*)(dir + (rowS >> 1) + (j0 >> 1)) = dk;      // S and j0 are even here
                 } else {
                     HYPO_UNROLL
                     for (int c = 0; c < CPL; ++c) dk.v[c] = (uint8_t)dc[c];
@@ -1158,6 +1158,11 @@ struct Poa {
 
     // Window::generate_consensus (src/Window.cpp:44-61)
     HD int run(uint32_t w) {
+        // the object outlives the window (one per persistent group): per-window counters and flags start over here
+        cells = 0; aligns = 0; reused = 0; rows_done = 0; topo_runs = 0; cons_serial = 0; last_changed = true;
+        n_paths = 0; path_used = 0; head_first = 0; L = 0; maxdelta = 0; tb_steps = 0; tb_fv = 0;
+        for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
+        HYPO_TICK_RESET();
         const HypoWindow W = P->windows[w];
         const uint32_t ne = W.n_internal + W.n_prefix + W.n_suffix;
         if (W.n_empty > ne) { finish(w, HYPO_ST_OK, 0); return RES_OK; }
