@@ -1,11 +1,11 @@
 // poa_classes.hpp — size classes of the POA kernel (one template instantiation + launch each).
 //
 //   class lanes/window (windows/wave) cols/lane max seq nodes in-edges dir cells(bits) ring cells arm B seqs scores ids  memory / window
-//   0     16 (4)                      4         47      48    4        2208 (4)       384        384   48   int16  u8   LDS  ~4.3 KB
-//   1     32 (2)                      4         79      84    4        6720 (4)       640        768   64   int16  u8   LDS  ~9 KB
-//   2     64 (1)                      2         127     126   6        13440 (4)      1024       1536  96   int16  u8   LDS  ~16.5 KB
-//   3     64 (1)                      2         127     254   8        32768 (8)      4096       4096  254  int16  u8   LDS  ~59 KB
-//   4     64 (1)                      16        1023    4000  16       4194304 (8)    2097152    16384 1024 int32  u16  HBM scratch ~13.6 MB / resident group (ring >= 2048 rows; also LONG windows)
+//   0     16 (4)                      4         47      48    4        2208 (4)       384        384   48   int16  u8   LDS  3.7 KB
+//   1     32 (2)                      4         79      84    4        6720 (4)       640        768   64   int16  u8   LDS  7.9 KB
+//   2     64 (1)                      2         127     126   6        13440 (4)      1024       1024  96   int16  u8   LDS  13.9 KB
+//   3     64 (1)                      2         127     254   8        32768 (8)      4096       4096  254  int16  u8   LDS  55.8 KB
+//   4     64 (1)                      16        1023    4000  16       4194304 (8)    2097152    16384 1024 int32  u16  HBM scratch 13.5 MB / resident group (ring >= 2048 rows; also LONG windows)
 // The kernel is VALU-issue bound (profiles/): a wavefront therefore carries 4 / 2 small windows side by side
 // (16- / 32-lane groups with group-uniform control flow), so one instruction stream advances several windows.
 // A window that does not fit class c (too many nodes / in-edges / cells, a predecessor row that already left

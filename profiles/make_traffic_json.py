@@ -14,8 +14,10 @@ CLASS_CFG = {0: "16;4;47", 1: "32;4;79", 2: "64;2;127;126", 3: "64;2;127;254", 4
 
 
 def main(path, cls, n_windows):
-    for row in csv.DictReader(open(path)):
-        if row["kernel"].startswith("poa_class_kernel<" + CLASS_CFG[cls]):
+    rows = [r for r in csv.DictReader(open(path)) if r["kernel"].startswith("poa_class_kernel<" + CLASS_CFG[cls])]
+    rows.sort(key=lambda r: -int(r["kernel"].rsplit("grid=", 1)[1]))       # main launch = largest grid (mop-up launches are tiny)
+    for row in rows[:1]:
+        if True:
             f, w = float(row["FETCH_SIZE"]) * 1024, float(row["WRITE_SIZE"]) * 1024
             out = {"kernel": f"poa_class_kernel<class {cls}>", "windows": n_windows,
                    "hbm_bytes_per_launch": int(f + w), "fetch_bytes": int(f), "write_bytes": int(w),

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Per-kernel mean of rocprofv3 --pmc counters from *_counter_collection.csv files.
-usage: summarize_pmc.py dir_with_pass_subdirs   (prints one table; FETCH/WRITE_SIZE in KiB per dispatch)"""
+"""Per-launch mean of rocprofv3 --pmc counters from *_counter_collection.csv files.  Launches are grouped by
+(kernel, grid size): the concurrent POA schedule runs every LDS class kernel twice per call, the main launch (full
+grid) and a mop-up launch for windows re-queued meanwhile (a handful of waves), and the two must not be averaged.
+usage: summarize_pmc.py dir_with_pass_subdirs   (prints one table; FETCH/WRITE_SIZE in KiB per launch)"""
 import csv
 import glob
 import os
@@ -9,6 +11,11 @@ from collections import defaultdict
 
 
 def short(name):
+    name, _, grid = name.partition(" grid=")
+    return _short(name) + " grid=" + grid
+
+
+def _short(name):
     if "poa_class_kernel" in name:
         cfg = name.split("PoaCfg<")[1].split(">")[0].replace(" ", "")
         return "poa_class_kernel<" + cfg.replace(",", ";") + ">"
@@ -20,7 +27,7 @@ def main(root):
     for f in glob.glob(os.path.join(root, "*", "*_counter_collection.csv")):
         per_dispatch = defaultdict(lambda: defaultdict(float))
         for row in csv.DictReader(open(f)):
-            per_dispatch[(row["Dispatch_Id"], row["Kernel_Name"])][row["Counter_Name"]] += float(row["Counter_Value"])
+            per_dispatch[(row["Dispatch_Id"], row["Kernel_Name"] + " grid=" + row["Grid_Size"])][row["Counter_Name"]] += float(row["Counter_Value"])
         for (did, kn), cs in per_dispatch.items():
             for c, v in cs.items():
                 acc[short(kn)][c].append(v)
