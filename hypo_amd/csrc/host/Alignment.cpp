@@ -228,6 +228,17 @@ void Alignment::add_arms(const Contig& contig) {                     // Alignmen
     _arms.clear();
 }
 
+void Alignment::add_arms(const Contig& contig, uint32_t w0, uint32_t w1) const {
+    for (const Arm& a : _arms) {
+        if (a.windex < w0 || a.windex >= w1) continue;
+        Window* w = contig.window(a.windex);
+        if (a.armtype == ArmType::PREFIX) w->add_prefix(a.arm);
+        else if (a.armtype == ArmType::SUFFIX) w->add_suffix(a.arm);
+        else if (a.armtype == ArmType::INTERNAL) w->add_internal(a.arm);
+        else w->add_empty();
+    }
+}
+
 // ---- Alignment::find_bp (Alignment.cpp:321-406): query positions where the read crosses region borders -----------------
 // An op that ends exactly on a border defers the decision (`corner`): a following M/D emits the current query position, a
 // following insertion goes to the right-hand window if the region on the left is an SR/MSR and to the left-hand one otherwise.

@@ -3,6 +3,7 @@
 // SURVEY.md Appendix A.4/A.5 and the cited lines; data lives in flat vectors and BitVec instead of sdsl objects and
 // per-k-mer heap nodes.
 #include "Contig.hpp"
+#include <omp.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -285,12 +286,41 @@ void Contig::force_divide(uint32_t beg, uint32_t end, char pvs, char nxt) {
     add(nxt == 's' ? RegionType::WS : nxt == 'm' ? RegionType::WM : RegionType::OTHER, cut_pos[nw - 1]);
 }
 
+// The reference hands every alignment's arms to their windows one alignment after the other (serial inside a contig:
+// the order of the arms inside a window is the order of the records and it decides the POA result).  Here every thread
+// owns a contiguous range of windows and walks ALL alignments in record order, taking only the arms of its own windows:
+// same per-window order, no locks; the (first, last) window index of every alignment is tabulated first so that the
+// walk touches an alignment's arm list only when it overlaps the range.
+void Contig::add_arms_by_window_range(std::vector<std::unique_ptr<Alignment>>& alignments) {
+    const int64_t n = (int64_t)alignments.size();
+    const uint32_t nreg = (uint32_t)_pwindows.size();
+    std::vector<uint32_t> first((size_t)n), last((size_t)n);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t f, l;
+        if (alignments[(size_t)i]->arm_span(f, l)) { first[(size_t)i] = f; last[(size_t)i] = l; }
+        else { first[(size_t)i] = 1; last[(size_t)i] = 0; }           // no arms: overlaps nothing
+    }
+#pragma omp parallel
+    {
+        const uint32_t nt = (uint32_t)omp_get_num_threads(), t = (uint32_t)omp_get_thread_num();
+        const uint32_t w0 = (uint32_t)((uint64_t)nreg * t / nt), w1 = (uint32_t)((uint64_t)nreg * (t + 1) / nt);
+        if (w0 < w1)
+            for (int64_t i = 0; i < n; ++i)
+                if (first[(size_t)i] < w1 && last[(size_t)i] >= w0 && first[(size_t)i] <= last[(size_t)i]) alignments[(size_t)i]->add_arms(*this, w0, w1);
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) alignments[(size_t)i].reset();
+}
+
 // ---- Contig::fill_short_windows (src/Contig.cpp:249-289) --------------------------------------------------------------
 void Contig::fill_short_windows(std::vector<std::unique_ptr<Alignment>>& alignments) {
-    for (auto& a : alignments) { a->add_arms(*this); a.reset(); }     // serial: arm order inside a window = BAM order
+    add_arms_by_window_range(alignments);                              // arm order inside a window = BAM order
     std::vector<uint64_t>().swap(_anchor_kmers);
     std::vector<uint32_t>().swap(_reg_info);
-    for (size_t i = 0; i < _reg_type.size(); ++i) {
+#pragma omp parallel for schedule(static)
+    for (int64_t ii = 0; ii < (int64_t)_reg_type.size(); ++ii) {
+        const size_t i = (size_t)ii;
         if (_reg_type[i] == RegionType::SR || _reg_type[i] == RegionType::MSR || !_pwindows[i]) continue;
         Window& w = *_pwindows[i];
         bool discarded = false;
@@ -344,7 +374,7 @@ void Contig::prepare_long_windows() {
 
 // ---- Contig::fill_long_windows (include/Contig.hpp:91-113) ------------------------------------------------------------
 void Contig::fill_long_windows(std::vector<std::unique_ptr<Alignment>>& alignments) {
-    for (auto& a : alignments) { a->add_arms(*this); a.reset(); }
+    add_arms_by_window_range(alignments);
     const size_t num_reg = _reg_type.size() - 1;
     for (size_t i = 0; i < num_reg; ++i)
         if (_reg_type[i] == RegionType::LONG && _pwindows[i]->get_num_internal() > Arms_settings.min_internal_num3) _pwindows[i]->clear_pre_suf();

@@ -47,6 +47,8 @@ public:
     void fill_short_windows(std::vector<std::unique_ptr<Alignment>>& alignments);
     void prepare_long_windows();
     void fill_long_windows(std::vector<std::unique_ptr<Alignment>>& alignments);
+    // Alignment::add_arms for all alignments, in file order per window, on all threads (each thread owns a window range)
+    void add_arms_by_window_range(std::vector<std::unique_ptr<Alignment>>& alignments);
 
     uint64_t get_num_regions() const { return _reg_type.size() - 1; }
     uint64_t get_num_sr() const { return _numSR; }

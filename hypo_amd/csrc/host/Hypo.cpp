@@ -82,6 +82,7 @@ void Hypo::polish() {
         std::fprintf(stdout, "********** [Hypo::Hypo] Info: BATCH-ID: %u\n", batch_id);
         const uint32_t initial_cid = batch_id * _contig_batch_size;
         const uint32_t final_cid = std::min<uint32_t>((uint32_t)_contigs.size(), initial_cid + _contig_batch_size);
+        const bool over_contigs = (final_cid - initial_cid) >= _cFlags.threads;
         start();
         create_alignments(true, batch_id);
         stop("[Hypo:Hypo]: Loaded alignments. ");
@@ -123,7 +124,8 @@ void Hypo::polish() {
         }
         stop("[Hypo:Hypo]: Short arms computing. ");
         start();
-#pragma omp parallel for schedule(static, 1)
+        // few contigs: the parallelism is inside a contig (window ranges); many contigs: one contig per thread as in the reference
+#pragma omp parallel for schedule(static, 1) if (over_contigs)
         for (int64_t i = initial_cid; i < (int64_t)final_cid; ++i) { _contigs[(size_t)i]->fill_short_windows(_alignment_store[(size_t)i]); _alignment_store[(size_t)i].clear(); }
         stop("[Hypo:Hypo]: Short arms filling. ");
 
@@ -139,7 +141,7 @@ void Hypo::polish() {
 #pragma omp parallel for
                 for (int64_t t = 0; t < (int64_t)alns.size(); ++t) alns[(size_t)t]->find_long_arms(*_contigs[cid]);
             }
-#pragma omp parallel for schedule(static, 1)
+#pragma omp parallel for schedule(static, 1) if (over_contigs)
             for (int64_t i = initial_cid; i < (int64_t)final_cid; ++i) { _contigs[(size_t)i]->fill_long_windows(_alignment_store[(size_t)i]); _alignment_store[(size_t)i].clear(); }
             stop("[Hypo:Hypo]: Long arms filling. ");
         } else {
@@ -186,28 +188,61 @@ void Hypo::polish() {
     _contigs.clear();
 }
 
-// src/Hypo.cpp:278-329: stream the (coordinate-sorted) file, stop when a record of the next batch shows up
+// src/Hypo.cpp:278-329: stream the (coordinate-sorted) file, stop when a record of the next batch shows up.
+// Lines are read serially (zlib) in blocks; record parsing and the Alignment constructors (CIGAR walk, 2-bit packing)
+// of a block run on all threads; a serial pass then files the alignments in record order, so every contig's store
+// is in file order exactly as the reference builds it.
 void Hypo::create_alignments(bool is_sr, uint32_t batch_id) {
     const uint32_t mq = _cFlags.map_qual_th;
     SamReader& sf = is_sr ? *_sf_short : *_sf_long;
+    std::vector<std::string>& carry = is_sr ? _carry_short : _carry_long;
     const uint32_t final_cid = batch_id * _contig_batch_size + _contig_batch_size;
     uint64_t num_invalid = 0, num_alns = 0;
-    SamRecord rec;
-    while (sf.next(rec)) {
-        if (rec.flag & (SAM_FUNMAP | SAM_FSECONDARY | SAM_FQCFAIL | SAM_FDUP)) continue;
-        if (rec.mapq < mq) continue;
-        if (rec.tid < 0 || _cname_to_id.find(sf.tid2name(rec.tid)) == _cname_to_id.end()) {
-            std::fprintf(stderr, "[Hypo::Hypo] Error: Alignment File error: Contig-reference (%s) does not exist in the draft!\n",
-                         rec.tid < 0 ? "*" : sf.tid2name(rec.tid).c_str());
-            std::exit(1);
+    constexpr size_t kBlock = 1 << 16;
+    struct Slot { std::unique_ptr<Alignment> aln; int32_t cid; bool skip, bad_ref; };
+    std::vector<std::string> lines;
+    std::vector<Slot> slots;
+    bool more = true, stop = false;
+    double t_read = 0, t_par = 0; auto now = []{ return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    while (!stop && (more || !carry.empty())) {
+        double t0 = now();
+        lines.clear();
+        if (!carry.empty()) lines.swap(carry);
+        else more = sf.read_lines(lines, kBlock);
+        if (lines.empty()) break;
+        slots.clear(); slots.resize(lines.size());
+        double t1 = now(); t_read += t1 - t0;
+#pragma omp parallel for schedule(dynamic, 256)
+        for (int64_t i = 0; i < (int64_t)lines.size(); ++i) {
+            Slot& sl = slots[(size_t)i];
+            sl.skip = false; sl.bad_ref = false; sl.cid = -1;
+            SamRecord rec;
+            sf.parse(lines[(size_t)i], rec);
+            if ((rec.flag & (SAM_FUNMAP | SAM_FSECONDARY | SAM_FQCFAIL | SAM_FDUP)) || rec.mapq < mq) { sl.skip = true; continue; }
+            auto it = rec.tid < 0 ? _cname_to_id.end() : _cname_to_id.find(sf.tid2name(rec.tid));
+            if (it == _cname_to_id.end()) { sl.bad_ref = true; continue; }
+            sl.cid = (int32_t)it->second;
+            if (is_sr) sl.aln.reset(new Alignment(*_contigs[it->second], rec));
+            else sl.aln.reset(new Alignment(*_contigs[it->second], _cFlags.norm_edit_th, rec));
         }
-        const uint32_t cid = _cname_to_id[sf.tid2name(rec.tid)];
-        auto& store = _alignment_store[cid];
-        if (is_sr) store.emplace_back(new Alignment(*_contigs[cid], rec));
-        else store.emplace_back(new Alignment(*_contigs[cid], _cFlags.norm_edit_th, rec));
-        if (!store.back()->is_valid) { store.pop_back(); ++num_invalid; } else ++num_alns;
-        if (cid >= final_cid) break;                     // first record of the next batch has been consumed (as in the reference)
+        double t2 = now(); t_par += t2 - t1;
+        for (size_t i = 0; i < slots.size(); ++i) {
+            Slot& sl = slots[i];
+            if (sl.skip) continue;
+            if (sl.bad_ref) {
+                std::fprintf(stderr, "[Hypo::Hypo] Error: Alignment File error: Contig-reference of record %s does not exist in the draft!\n",
+                             lines[i].substr(0, lines[i].find('\t')).c_str());
+                std::exit(1);
+            }
+            if (sl.aln->is_valid) { _alignment_store[(size_t)sl.cid].emplace_back(std::move(sl.aln)); ++num_alns; } else ++num_invalid;
+            if ((uint32_t)sl.cid >= final_cid) {            // first record of the next batch has been consumed (as in the reference)
+                carry.assign(std::make_move_iterator(lines.begin() + (long)i + 1), std::make_move_iterator(lines.end()));
+                stop = true;
+                break;
+            }
+        }
     }
+    if (std::getenv("HYPO_HOST_TIMING")) std::fprintf(stderr, "[timing] create_alignments: read %.3f parse+construct %.3f (file pass included)\n", t_read, t_par);
     std::fprintf(stdout, "[Hypo::Hypo] Info: Number of alignments (Batch %u): loaded (%lu) invalid (%lu)\n", batch_id,
                  (unsigned long)num_alns, (unsigned long)num_invalid);
 }

@@ -32,8 +32,7 @@ private:
     std::vector<std::vector<std::unique_ptr<Alignment>>> _alignment_store;
     uint32_t _contig_batch_size = 0;
     std::unique_ptr<SamReader> _sf_short, _sf_long;
-    SamRecord _pending_short, _pending_long;
-    bool _has_pending_short = false, _has_pending_long = false;
+    std::vector<std::string> _carry_short, _carry_long;   // lines read past the end of a contig batch
     PhaseTimes _times;
     std::string _region_dump;
     std::chrono::steady_clock::time_point _t0, _tstart;

@@ -14,26 +14,43 @@
 
 namespace hypo {
 
-class LineReader {
+class LineReader {                           // lines of a plain or gzip file: block reads through zlib, memchr for the line ends
 public:
-    explicit LineReader(const std::string& path) : _fp(gzopen(path.c_str(), "r")) { if (_fp) gzbuffer(_fp, 1 << 20); }
+    explicit LineReader(const std::string& path) : _fp(gzopen(path.c_str(), "r")), _buf(kBuf) { if (_fp) gzbuffer(_fp, 1 << 20); }
     ~LineReader() { if (_fp) gzclose(_fp); }
+    LineReader(const LineReader&) = delete;
+    LineReader& operator=(const LineReader&) = delete;
     bool ok() const { return _fp != nullptr; }
     bool next(std::string& line) {
         line.clear();
         if (!_fp) return false;
-        char buf[1 << 16];
         bool any = false;
-        while (gzgets(_fp, buf, sizeof(buf))) {
+        for (;;) {
+            if (_pos == _end) {
+                if (_eof) return any;
+                const int n = gzread(_fp, _buf.data(), (unsigned)kBuf);
+                if (n <= 0) { _eof = true; return any; }
+                _pos = 0; _end = (size_t)n;
+            }
+            const char* b = _buf.data() + _pos;
+            const char* nl = (const char*)std::memchr(b, '\n', _end - _pos);
             any = true;
-            const size_t n = std::strlen(buf);
-            line.append(buf, n);
-            if (n && buf[n - 1] == '\n') { line.pop_back(); if (!line.empty() && line.back() == '\r') line.pop_back(); return true; }
+            if (nl) {
+                line.append(b, (size_t)(nl - b));
+                _pos += (size_t)(nl - b) + 1;
+                if (!line.empty() && line.back() == '\r') line.pop_back();
+                return true;
+            }
+            line.append(b, _end - _pos);
+            _pos = _end;
         }
-        return any;
     }
 private:
+    static constexpr size_t kBuf = 4u << 20;
     gzFile _fp;
+    std::vector<char> _buf;
+    size_t _pos = 0, _end = 0;
+    bool _eof = false;
 };
 
 struct FastaRecord { std::string name, seq; };
@@ -99,9 +116,29 @@ public:
     const std::string& tid2name(int32_t tid) const { return _names[(size_t)tid]; }
     bool next(SamRecord& r) {
         std::string line;
+        if (!next_line(line)) return false;
+        parse(line, r);
+        return true;
+    }
+    // next non-empty alignment line (I/O and inflate are serial; parsing is not, see parse())
+    bool next_line(std::string& line) {
         if (_have_pending) { line.swap(_pending); _have_pending = false; }
         else if (!_lr.next(line)) return false;
         while (line.empty()) if (!_lr.next(line)) return false;
+        return true;
+    }
+    // up to `max` lines appended to `out`; false at end of file
+    bool read_lines(std::vector<std::string>& out, size_t max) {
+        std::string line;
+        for (size_t i = 0; i < max; ++i) {
+            if (!next_line(line)) return false;
+            out.emplace_back(std::move(line));
+            line.clear();
+        }
+        return true;
+    }
+    // one alignment line -> record; const and re-entrant (Hypo::create_alignments parses blocks of lines in parallel)
+    void parse(const std::string& line, SamRecord& r) const {
         size_t f[12]; int nf = 0; f[0] = 0;
         for (size_t i = 0; i < line.size() && nf < 11; ++i) if (line[i] == '\t') f[++nf] = i + 1;
         if (nf < 10) { std::fprintf(stderr, "[Hypo::SamReader] Error: malformed SAM record: %s\n", line.substr(0, 60).c_str()); std::exit(1); }
@@ -132,7 +169,6 @@ public:
             const size_t p = line.find("\tNM:i:", f[10] - 1);
             if (p != std::string::npos) { r.has_nm = true; r.nm = std::strtoll(line.c_str() + p + 6, nullptr, 10); }
         }
-        return true;
     }
 private:
     LineReader _lr;

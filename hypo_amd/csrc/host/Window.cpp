@@ -1,5 +1,6 @@
 // Window.cpp — batched device consensus behind hypo::Window (see Window.hpp).
 #include "Window.hpp"
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 
@@ -39,9 +40,46 @@ struct WindowFlattener {
 
 int Window::generate_consensus_batch(const std::vector<Window*>& windows) {
     if (windows.empty()) return HYPO_OK;
+    // flatten on all threads: sizes, exclusive prefix sums, then every window copies into its own slices
     WindowFlattener f;
-    for (const Window* w : windows) f.add(*w);
-    f.draft4.resize(f.draft4.size() + 16); f.arms2.resize(f.arms2.size() + 16);
+    const int64_t nw = (int64_t)windows.size();
+    std::vector<uint64_t> d_off((size_t)nw + 1), a_cnt((size_t)nw + 1), a_off((size_t)nw + 1);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < nw; ++i) {
+        const Window& w = *windows[(size_t)i];
+        uint64_t bytes = 0;
+        for (const auto* group : {&w._internal_arms, &w._pre_arms, &w._suf_arms}) for (const auto& a : *group) bytes += a.byte_size();
+        d_off[(size_t)i + 1] = w._draft.byte_size();
+        a_cnt[(size_t)i + 1] = w._internal_arms.size() + w._pre_arms.size() + w._suf_arms.size();
+        a_off[(size_t)i + 1] = bytes;
+    }
+    d_off[0] = a_cnt[0] = a_off[0] = 0;
+    for (int64_t i = 0; i < nw; ++i) { d_off[(size_t)i + 1] += d_off[(size_t)i]; a_cnt[(size_t)i + 1] += a_cnt[(size_t)i]; a_off[(size_t)i + 1] += a_off[(size_t)i]; }
+    f.win.resize((size_t)nw);
+    f.draft4.resize(d_off[(size_t)nw] + 16); f.arms2.resize(a_off[(size_t)nw] + 16);
+    f.arm_off.resize(a_cnt[(size_t)nw]); f.arm_len.resize(a_cnt[(size_t)nw]);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < nw; ++i) {
+        const Window& w = *windows[(size_t)i];
+        HypoWindow d{};
+        d.type = w._wtype == WindowType::SHORT ? HYPO_WIN_SHORT : HYPO_WIN_LONG;
+        d.draft_len = (uint32_t)w._draft.get_seq_size();
+        d.draft_off = d_off[(size_t)i];
+        std::memcpy(f.draft4.data() + d_off[(size_t)i], w._draft.data(), w._draft.byte_size());
+        d.first_arm = (uint32_t)a_cnt[(size_t)i];
+        d.n_internal = (uint32_t)w._internal_arms.size();
+        d.n_prefix = (uint32_t)w._pre_arms.size();
+        d.n_suffix = (uint32_t)w._suf_arms.size();
+        d.n_empty = w._num_empty;
+        uint64_t ai = a_cnt[(size_t)i], ao = a_off[(size_t)i];
+        for (const auto* group : {&w._internal_arms, &w._pre_arms, &w._suf_arms})      // insertion order, as stored
+            for (const auto& a : *group) {
+                f.arm_off[ai] = ao; f.arm_len[ai] = (uint32_t)a.get_seq_size();
+                std::memcpy(f.arms2.data() + ao, a.data(), a.byte_size());
+                ++ai; ao += a.byte_size();
+            }
+        f.win[(size_t)i] = d;
+    }
     HypoWindowBatch in{(uint32_t)f.win.size(), (uint32_t)f.arm_len.size(), f.win.data(), f.draft4.data(), f.draft4.size(),
                        f.arm_off.data(), f.arm_len.data(), f.arms2.data(), f.arms2.size()};
     std::vector<uint64_t> off(f.win.size() + 1);
@@ -53,13 +91,13 @@ int Window::generate_consensus_batch(const std::vector<Window*>& windows) {
     HypoConsensusBatch out{bases.data(), off.data(), len.data(), st.data()};
     rc = hypo_gpu_poa_batch(&_score_params, &in, &out);
     if (rc != HYPO_OK) return rc;
-    for (size_t i = 0; i < windows.size(); ++i) {
+    for (size_t i = 0; i < windows.size(); ++i)
         if (st[i] != HYPO_ST_OK) {
             std::fprintf(stderr, "[Hypo::Window] Error: window %zu could not be polished on the device (status %u)\n", i, (unsigned)st[i]);
             return HYPO_E_INVALID;
         }
-        windows[i]->_consensus.assign(bases.data() + off[i], len[i]);
-    }
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < nw; ++i) windows[(size_t)i]->_consensus.assign(bases.data() + off[(size_t)i], len[(size_t)i]);
     return HYPO_OK;
 }
 

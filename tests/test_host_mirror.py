@@ -13,6 +13,13 @@ def mirror():
     return host.HostMirror()
 
 
+@pytest.fixture(scope="module")
+def device():
+    """hypo_gpu_init for the tests whose C++ mirror calls the device (libhypo_host.so shares the process-wide context)."""
+    from hypo_amd import capi
+    return capi.HypoGpu(0)
+
+
 def test_packedseq_roundtrip_goldens(mirror):
     for c in gu.load_json("packedseq_cases.json.gz"):
         assert mirror.pack_roundtrip(c["nb"], c["text"]) == c["unpacked"]
@@ -32,7 +39,7 @@ def test_filter_matches_reference_kept_flags(mirror):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("batched", [True, False])
-def test_window_surface_goldens(mirror, batched):
+def test_window_surface_goldens(mirror, device, batched):
     for name in gu.WINDOW_FILES:
         for scores, _ in gu.windows_by_scores(name).items():
             recs = [r for r in gu.load_jsonl(name) if tuple(r["scores"]) == scores]
@@ -51,7 +58,7 @@ def test_window_surface_goldens(mirror, batched):
 
 
 @pytest.mark.gpu
-def test_contig_scan_rank_select(mirror, oracle_lib):
+def test_contig_scan_rank_select(mirror, device, oracle_lib):
     codes, p4 = sim.random_contig(100001, seed=4, n_frac=0.001)
     k = 11
     bits = sim.solid_bitset(codes, k)
