@@ -228,13 +228,13 @@ void Alignment::add_arms(const Contig& contig) {                     // Alignmen
     _arms.clear();
 }
 
-void Alignment::add_arms(const Contig& contig, uint32_t w0, uint32_t w1) const {
-    for (const Arm& a : _arms) {
+void Alignment::add_arms(const Contig& contig, uint32_t w0, uint32_t w1) {
+    for (Arm& a : _arms) {
         if (a.windex < w0 || a.windex >= w1) continue;
         Window* w = contig.window(a.windex);
-        if (a.armtype == ArmType::PREFIX) w->add_prefix(a.arm);
-        else if (a.armtype == ArmType::SUFFIX) w->add_suffix(a.arm);
-        else if (a.armtype == ArmType::INTERNAL) w->add_internal(a.arm);
+        if (a.armtype == ArmType::PREFIX) w->add_prefix(std::move(a.arm));
+        else if (a.armtype == ArmType::SUFFIX) w->add_suffix(std::move(a.arm));
+        else if (a.armtype == ArmType::INTERNAL) w->add_internal(std::move(a.arm));
         else w->add_empty();
     }
 }

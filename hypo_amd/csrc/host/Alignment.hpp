@@ -38,8 +38,8 @@ public:
     void find_short_arms(unsigned k, Contig& contig);
     void find_long_arms(Contig& contig);
     void add_arms(const Contig& contig);
-    // the arms that belong to windows [w0, w1) only; nothing is released (Contig::add_arms_by_window_range)
-    void add_arms(const Contig& contig, uint32_t w0, uint32_t w1) const;
+    // the arms that belong to windows [w0, w1) only (their bytes move into the windows) (Contig::add_arms_by_window_range)
+    void add_arms(const Contig& contig, uint32_t w0, uint32_t w1);
     bool arm_span(uint32_t& first, uint32_t& last) const {          // smallest / largest window index among the arms
         if (_arms.empty()) return false;
         first = last = _arms[0].windex;

@@ -2,6 +2,7 @@
 #include "Hypo.hpp"
 #include <omp.h>
 #include <sys/resource.h>
+#include <thread>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -166,6 +167,7 @@ void Hypo::polish() {
                     _contigs[i]->region((uint32_t)w, b, e, t);
                     const Window* win = _contigs[i]->window((uint32_t)w);
                     if (!win && t != RegionType::SR && t != RegionType::MSR && !_cFlags.lr_bam_filename.empty()) continue;   // swallowed by a LONG window
+                    if (win) e = b + (uint32_t)win->get_window_len();           // a LONG window spans the arm-less regions that follow it
                     dump << _contigs[i]->get_name() << '\t' << b << '\t' << e << '\t' << region_name(t);
                     if (win) dump << '\t' << win->dump_counts() << '\t' << win->arms_crc32() << '\t' << win->get_consensus();
                     else if (t != RegionType::SR && t != RegionType::MSR) dump << "\t0\t0\t0\t0\t0\t" << _contigs[i]->draft_segment(b, e);   // no arms: draft kept
@@ -200,16 +202,19 @@ void Hypo::create_alignments(bool is_sr, uint32_t batch_id) {
     uint64_t num_invalid = 0, num_alns = 0;
     constexpr size_t kBlock = 1 << 16;
     struct Slot { std::unique_ptr<Alignment> aln; int32_t cid; bool skip, bad_ref; };
-    std::vector<std::string> lines;
+    std::vector<std::string> lines, ahead;                  // current block; block a reader thread fetches meanwhile
     std::vector<Slot> slots;
-    bool more = true, stop = false;
+    bool more = true, stop = false, have_ahead = false, more_ahead = true;
     double t_read = 0, t_par = 0; auto now = []{ return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    while (!stop && (more || !carry.empty())) {
+    while (!stop) {
         double t0 = now();
         lines.clear();
         if (!carry.empty()) lines.swap(carry);
-        else more = sf.read_lines(lines, kBlock);
+        else if (have_ahead) { lines.swap(ahead); have_ahead = false; }
+        else if (more) more = sf.read_lines(lines, kBlock);
         if (lines.empty()) break;
+        std::thread reader;                                  // inflate + line splitting of the next block overlap the parsing of this one
+        if (more && !have_ahead) { ahead.clear(); reader = std::thread([&] { more_ahead = sf.read_lines(ahead, kBlock); }); }
         slots.clear(); slots.resize(lines.size());
         double t1 = now(); t_read += t1 - t0;
 #pragma omp parallel for schedule(dynamic, 256)
@@ -240,6 +245,11 @@ void Hypo::create_alignments(bool is_sr, uint32_t batch_id) {
                 stop = true;
                 break;
             }
+        }
+        if (reader.joinable()) { reader.join(); more = more_ahead; have_ahead = !ahead.empty(); }
+        if (stop && have_ahead) {                            // the prefetched block belongs to the next contig batch as well
+            carry.insert(carry.end(), std::make_move_iterator(ahead.begin()), std::make_move_iterator(ahead.end()));
+            ahead.clear(); have_ahead = false;
         }
     }
     if (std::getenv("HYPO_HOST_TIMING")) std::fprintf(stderr, "[timing] create_alignments: read %.3f parse+construct %.3f (file pass included)\n", t_read, t_par);

@@ -7,6 +7,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 #include "../../../include/hypo_gpu.h"
 #include "Filter.hpp"
@@ -35,22 +36,26 @@ public:
     std::string get_consensus() const { return _consensus; }
     size_t get_window_len() const { return _draft.get_seq_size(); }
 
-    void add_prefix(const PackedSeq<2>& ps) {
+    // The reference takes const references and copies (Window.hpp:66-101); an rvalue is adopted without a second copy.
+    void add_prefix(const PackedSeq<2>& ps) { add_prefix(PackedSeq<2>(ps)); }
+    void add_suffix(const PackedSeq<2>& ps) { add_suffix(PackedSeq<2>(ps)); }
+    void add_internal(const PackedSeq<2>& ps) { add_internal(PackedSeq<2>(ps)); }
+    void add_prefix(PackedSeq<2>&& ps) {
         if (_wtype == WindowType::LONG && !_filter.is_good(ps.unpack())) return;
         ++_num_pre;
         if (ps.get_seq_size() > _longest_pre_len) _longest_pre_len = (uint32_t)ps.get_seq_size();
-        _pre_arms.push_back(ps);
+        _pre_arms.push_back(std::move(ps));
     }
-    void add_suffix(const PackedSeq<2>& ps) {
+    void add_suffix(PackedSeq<2>&& ps) {
         if (_wtype == WindowType::LONG && !_filter.is_good(ps.unpack())) return;
         ++_num_suf;
         if (ps.get_seq_size() > _longest_suf_len) _longest_suf_len = (uint32_t)ps.get_seq_size();
-        _suf_arms.push_back(ps);
+        _suf_arms.push_back(std::move(ps));
     }
-    void add_internal(const PackedSeq<2>& ps) {
+    void add_internal(PackedSeq<2>&& ps) {
         if (_wtype == WindowType::LONG && !_filter.is_good(ps.unpack())) return;
         ++_num_internal;
-        _internal_arms.push_back(ps);
+        _internal_arms.push_back(std::move(ps));
     }
     void add_empty() { ++_num_empty; }
 

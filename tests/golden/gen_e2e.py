@@ -9,6 +9,7 @@ The byte-exact inputs of the committed end-to-end goldens are reproduced by
     gen_e2e.py <outdir> 1 20000          (tests/golden/e2e_20k_s1.*)
     gen_e2e.py <outdir> 3 200000 --long  (tests/golden/e2e_200k_long_s3.*)
     gen_e2e.py <outdir> 5 200000 --k 9   (tests/golden/e2e_200k_k9_s5.*: `-s 100k` => k = 9, many minimizer-cut windows)
+    gen_e2e.py <outdir> 21 60000 --long --contigs 5   (tests/golden/e2e_5ctg_long_s21.*: five contigs, run with `-p 2`)
 (python's `random` module, seed and call order fixed; md5 of every file is checked against the manifest by the
 tests).  The expected outputs in those goldens were produced from exactly these inputs by the reference binary
 built per SURVEY.md Appendix B (`hypo -d draft.fa -r reads.fa -s 1m -c 30 -b sr.sam [-B lr.sam] -t 1 -i`)."""
@@ -161,7 +162,61 @@ def generate(outdir, seed, G, with_long, K=11):
     return len(draft), len(recs), ns
 
 
+def generate_multi(outdir, seed, G, with_long, K, n_contigs):
+    """n_contigs independent sets (seeds seed, seed+1, ...; lengths G, G/2, G/3, ...) merged into one input: contigs
+    ctg1..ctgN in one draft, records contig after contig (coordinate-sorted per contig, header order), the OR of the
+    solid-kmer sets.  Exercises contig batches (-p) and the reader's look-ahead across batch borders."""
+    import shutil
+    import tempfile
+    drafts, reads, sam_hdr, sam_body, lsam_body, words_all, total = [], [], [], [], [], None, [0, 0, 0]
+    for c in range(n_contigs):
+        tmp = tempfile.mkdtemp(prefix="gen_e2e_")
+        try:
+            res = generate(tmp, seed + c, G // (c + 1), with_long, K)
+            name = f"ctg{c + 1}"
+            d = open(os.path.join(tmp, "draft.fa")).read().split("\n")[1]
+            drafts.append(f">{name} part {c + 1}\n{d}\n")           # header with a comment: only the first token is the name
+            reads.append(open(os.path.join(tmp, "reads.fa")).read().replace(">r", f">c{c + 1}r"))
+            for line in open(os.path.join(tmp, "sr.sam")):
+                if line.startswith("@SQ"):
+                    sam_hdr.append(line.replace("SN:ctg1", "SN:" + name))
+                elif not line.startswith("@"):
+                    f = line.split("\t")
+                    f[0] = f"c{c + 1}{f[0]}"; f[2] = name
+                    sam_body.append("\t".join(f))
+            if with_long:
+                for line in open(os.path.join(tmp, "lr.sam")):
+                    if not line.startswith("@"):
+                        f = line.split("\t")
+                        f[0] = f"c{c + 1}{f[0]}"; f[2] = name
+                        lsam_body.append("\t".join(f))
+            raw = open(os.path.join(tmp, "aux", "solid_kmers.bvsd"), "rb").read()
+            words = list(struct.unpack(f"<{(len(raw) - 8) // 8}Q", raw[8:]))
+            words_all = words if words_all is None else [a | b for a, b in zip(words_all, words)]
+            for i in range(3):
+                total[i] += res[i]
+        finally:
+            shutil.rmtree(tmp)
+    os.makedirs(os.path.join(outdir, "aux"), exist_ok=True)
+    w = lambda name, text: open(os.path.join(outdir, name), "w").write(text)
+    w("draft.fa", "".join(drafts))
+    w("reads.fa", "".join(reads))
+    hdr = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(sam_hdr)
+    w("sr.sam", hdr + "".join(sam_body))
+    if with_long:
+        w("lr.sam", hdr + "".join(lsam_body))
+    with open(os.path.join(outdir, "aux", "solid_kmers.bvsd"), "wb") as f:
+        f.write(struct.pack("<Q", 1 << (2 * K)))
+        f.write(struct.pack(f"<{len(words_all)}Q", *words_all))
+    w("aux/stage.txt", "Stage:SolidKmers [2026-09-28 12:00:00]\t1\n")
+    return tuple(total)
+
+
 if __name__ == "__main__":
     out, seed, G = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     k = int(sys.argv[sys.argv.index("--k") + 1]) if "--k" in sys.argv else 11
-    print("draft %d reads %d solid %d" % generate(out, seed, G, "--long" in sys.argv, k))
+    nc = int(sys.argv[sys.argv.index("--contigs") + 1]) if "--contigs" in sys.argv else 1
+    if nc > 1:
+        print("draft %d reads %d solid %d" % generate_multi(out, seed, G, "--long" in sys.argv, k, nc))
+    else:
+        print("draft %d reads %d solid %d" % generate(out, seed, G, "--long" in sys.argv, k))

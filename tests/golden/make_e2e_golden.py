@@ -44,15 +44,22 @@ def regions(path):
 def main():
     name, d, outfa, seed, G, k, size = sys.argv[1:8]
     is_long = "--long" in sys.argv
+    nc = int(sys.argv[sys.argv.index("--contigs") + 1]) if "--contigs" in sys.argv else 1
+    extra = sys.argv[sys.argv.index("--extra") + 1] if "--extra" in sys.argv else ""        # e.g. "-p 2"
     ins = ["draft.fa", "sr.sam", "aux/solid_kmers.bvsd"] + (["lr.sam"] if is_long else [])
-    man = {"generator": "tests/golden/gen_e2e.py", "args": {"seed": int(seed), "G": int(G), "k": int(k), "long": is_long},
-           "command": f"hypo -d draft.fa -r reads.fa -s {size} -c 30 -b sr.sam" + (" -B lr.sam" if is_long else "") + " -t 1 -i",
+    args = {"seed": int(seed), "G": int(G), "k": int(k), "long": is_long}
+    if nc > 1:
+        args["contigs"] = nc
+    man = {"generator": "tests/golden/gen_e2e.py", "args": args,
+           "command": f"hypo -d draft.fa -r reads.fa -s {size} -c 30 -b sr.sam" + (" -B lr.sam" if is_long else "") + " -t 1 -i" + (" " + extra if extra else ""),
            "size_flag": size, "inputs_md5": {f: md5(os.path.join(d, f)) for f in ins},
            "expected_fasta_md5": md5(os.path.join(d, outfa))}
     json.dump(man, open(os.path.join(HERE, name + ".manifest.json"), "w"), indent=1)
     with gzip.GzipFile(os.path.join(HERE, name + ".expected.fa.gz"), "wb", mtime=0) as f:
         f.write(open(os.path.join(d, outfa), "rb").read())
-    reg = regions(os.path.join(d, "aux", "inspect_ctg1.txt"))
+    reg = []
+    for c in range(nc):                                  # contigs in draft order, like the region dump of this repo's host
+        reg += regions(os.path.join(d, "aux", f"inspect_ctg{c + 1}.txt"))
     with gzip.GzipFile(os.path.join(HERE, name + ".regions.json.gz"), "wb", mtime=0) as f:
         f.write(json.dumps(reg, separators=(",", ":")).encode())
     print(name, len(reg), "regions")
