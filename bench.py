@@ -53,13 +53,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Debug knobs for a box with fewer GPUs than ranks (never set by the driver): all ranks on device 0 and a gloo
+    # group exercise the whole N>1 code path except RCCL itself.
+    share = os.environ.get("HYPO_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("HYPO_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
-    gpu = capi.HypoGpu(local_rank)
+    gpu = capi.HypoGpu(dev_index)
 
     # ---- synthetic workload, resident in HBM ----------------------------------------------------------
     batch = sim.window_batch(args.windows, seed=1000 + rank)
