@@ -138,7 +138,7 @@ def main():
             raise SystemExit("bench: HIP results differ from the oracle — refusing to report a number")
 
     # ---- roofline of the dominant kernel (HIP events on the kernels' stream) -----------------------------
-    poa_calls = [p for p in prof if len(p) == 7]             # plan, 5 size-class kernels, whole call
+    poa_calls = [p for p in prof if len(p) == 8]             # plan, 6 size-class kernels, whole call
     scan_calls = [p for p in prof if len(p) == 3]
     roofline = None
     extra = {}

@@ -5,7 +5,9 @@
 //   1     32 (2)                      4         79      84    4        6720 (4)       640        768   64   int16  u8   LDS  7.9 KB
 //   2     64 (1)                      2         127     126   6        13440 (4)      1024       1024  96   int16  u8   LDS  13.9 KB
 //   3     64 (1)                      2         127     254   8        32768 (8)      4096       4096  254  int16  u8   LDS  55.8 KB
-//   4     64 (1)                      16        1023    4000  16       4194304 (8)    2097152    16384 1024 int32  u16  HBM scratch 13.5 MB / resident group (ring >= 2048 rows; also LONG windows)
+//   4     64 (1)                      10        639     2400  12       1536000 (8)    491520     16384 256  int16  u16  HBM scratch 3.3 MB / resident group: the LONG windows (<= 500 bp, arms ~ window length,
+//                                                                                                                     graphs ~1.3 k nodes; src/Window.cpp:156-236), up to 2048 groups resident
+//   5     64 (1)                      16        1023    4000  16       4194304 (8)    2097152    16384 1024 int32  u16  HBM scratch 13.5 MB / resident group: whatever overflows everything else (64 groups)
 // The kernel is VALU-issue bound (profiles/): a wavefront therefore carries 4 / 2 small windows side by side
 // (16- / 32-lane groups with group-uniform control flow), so one instruction stream advances several windows.
 // A window that does not fit class c (too many nodes / in-edges / cells, a predecessor row that already left
@@ -25,8 +27,9 @@ typedef PoaCfg<32, 4, 79, 84, 4, 6720, 640, 768, 64, int16_t, uint8_t> PoaClass1
 #endif
 typedef PoaCfg<HYPO_C2_GW, HYPO_C2_CPL, 127, 126, 6, 13440, 1024, 1024, 96, int16_t, uint8_t> PoaClass2;
 typedef PoaCfg<64, 2, 127, 254, 8, 32768, 4096, 4096, 254, int16_t, uint8_t> PoaClass3;
-typedef PoaCfg<64, 16, 1023, 4000, 16, 1 << 22, 1 << 21, 16384, 1024, int32_t, uint16_t, 1 << 18> PoaClass4;   // + 256 K path ids: runs LONG windows
-constexpr int kNumPoaClasses = 5;
+typedef PoaCfg<64, 10, 639, 2400, 12, 1536000, 491520, 16384, 256, int16_t, uint16_t, 1 << 18> PoaClass4;          // + 256 K path ids: runs LONG windows
+typedef PoaCfg<64, 16, 1023, 4000, 16, 1 << 22, 1 << 21, 16384, 1024, int32_t, uint16_t, 1 << 18> PoaClass5;    // last resort, also runs LONG windows
+constexpr int kNumPoaClasses = 6;
 }  // namespace hypo
 
-#define HYPO_FOR_EACH_CLASS(X) X(0, PoaClass0) X(1, PoaClass1) X(2, PoaClass2) X(3, PoaClass3) X(4, PoaClass4)
+#define HYPO_FOR_EACH_CLASS(X) X(0, PoaClass0) X(1, PoaClass1) X(2, PoaClass2) X(3, PoaClass3) X(4, PoaClass4) X(5, PoaClass5)

@@ -169,8 +169,10 @@ struct Poa {
     HD static bool is_vert(int d) { return NIB ? d >= 7 : (d & 1); }
     HD static int dir_pred(int d) { return NIB ? (d >= 7 ? d - 7 : d) : (d >> 1); }
 
-    struct alignas(sizeof(score_t) * CPL) Pack { score_t v[CPL]; };
-    struct alignas(NIB ? CPL / 2 : CPL) DPack { uint8_t v[NIB ? CPL / 2 : CPL]; };
+    // a lane's cells of one row move as one block; aligned to the largest power of two dividing its size (CPL = 10 -> 4 / 2 bytes)
+    static constexpr int pow2_of(int x) { return x & -x; }
+    struct alignas(pow2_of((int)sizeof(score_t) * CPL)) Pack { score_t v[CPL]; };
+    struct alignas(pow2_of(NIB ? CPL / 2 : CPL)) DPack { uint8_t v[NIB ? CPL / 2 : CPL]; };
     // sequence table entry: bits 0-14 src (LDS offset of the staged bytes, or arm index), 15 "byte-identical to
     // the previous entry" (set for staged arms only), 16-25 length, 26 head marker J, 27 tail marker O,
     // 28-29 mode (0 NW, 1 LOV, 2 ROV), 30-31 where (0 staged in LDS, 1 arms2 in HBM, 2 draft4 in HBM: 4-bit packed)

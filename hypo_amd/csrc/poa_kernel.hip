@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through t
 // ------------------------------------------------------------------------------------------------
 template <class Cfg, bool USE_LDS>
 static hipError_t launch_class(const PoaParams& P, const PoaQueues& Q, int cls, uint32_t n_windows,
-                               char* scratch, int num_cus, int max_global_groups, hipStream_t stream,
+                               char* scratch, int num_cus, int group_cap, hipStream_t stream,
                                int waves_per_cu_cap = 0, bool mop_up = false) {
     auto kern = poa_class_kernel<Cfg, USE_LDS>;
     constexpr int GPW = 64 / Cfg::GW;
@@ -262,7 +262,7 @@ static hipError_t launch_class(const PoaParams& P, const PoaQueues& Q, int cls, 
     }
     if (waves_per_cu_cap >= 1 && waves_per_cu_cap < per_cu) per_cu = waves_per_cu_cap;
     long grid = (long)per_cu * num_cus;
-    if (!USE_LDS && grid * GPW > max_global_groups) grid = max_global_groups / GPW;
+    if (!USE_LDS && grid * GPW > group_cap) grid = group_cap / GPW;
     const long need = ((long)n_windows + GPW - 1) / GPW;      // never more waves than windows
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
@@ -280,11 +280,11 @@ size_t poa_workspace_bytes(uint32_t n_windows) {
     b += (size_t)kNumPoaClasses * n_windows * sizeof(uint32_t);
     b = (b + 255) / 256 * 256;
     b += ((size_t)n_windows * 2 + 255) / 256 * 256;        // plan keys
-    size_t big = 0;
-#define HYPO_BIG(ID, CFG) if (ID >= kFirstGlobalClass && (size_t)PoaLayout<CFG>::BYTES > big) big = PoaLayout<CFG>::BYTES;
+    size_t big = 0;                                         // the HBM-scratch classes run one after the other and share the region
+#define HYPO_BIG(ID, CFG) if (ID >= kFirstGlobalClass) { const size_t x = (size_t)max_global_groups(ID, n_windows) * PoaLayout<CFG>::BYTES; big = x > big ? x : big; }
     HYPO_FOR_EACH_CLASS(HYPO_BIG)
 #undef HYPO_BIG
-    b += (size_t)kMaxGlobalGroups * big;
+    b += big;
     return b;
 }
 
@@ -337,7 +337,7 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
 #define HYPO_LAUNCH(ID, CFG)                                                                              \
         rec(2 + 2 * ID, stream);                                                                          \
         if ((e = launch_class<CFG, (ID < kFirstGlobalClass)>(P, Q, ID, n_windows, scratch, num_cus,      \
-                                                             kMaxGlobalGroups, stream)) != hipSuccess) return e; \
+                                                             max_global_groups(ID, n_windows), stream)) != hipSuccess) return e; \
         rec(3 + 2 * ID, stream);
         HYPO_FOR_EACH_CLASS(HYPO_LAUNCH)
 #undef HYPO_LAUNCH
@@ -353,27 +353,30 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
         (void)hipStreamWaitEvent(aux[0], fork_ev, 0);
         (void)hipStreamWaitEvent(aux[1], fork_ev, 0);
         rec(2 + 2 * 2, stream);
-        if ((e = launch_class<PoaClass2, true>(P, Q, 2, n_windows, scratch, num_cus, kMaxGlobalGroups, stream, caps[2])) != hipSuccess) return e;
+        if ((e = launch_class<PoaClass2, true>(P, Q, 2, n_windows, scratch, num_cus, 0, stream, caps[2])) != hipSuccess) return e;
         rec(3 + 2 * 2, stream);
         rec(2 + 2 * 0, aux[0]);
-        if ((e = launch_class<PoaClass0, true>(P, Q, 0, n_windows, scratch, num_cus, kMaxGlobalGroups, aux[0], caps[0])) != hipSuccess) return e;
+        if ((e = launch_class<PoaClass0, true>(P, Q, 0, n_windows, scratch, num_cus, 0, aux[0], caps[0])) != hipSuccess) return e;
         rec(3 + 2 * 0, aux[0]);
         rec(2 + 2 * 1, aux[1]);
-        if ((e = launch_class<PoaClass1, true>(P, Q, 1, n_windows, scratch, num_cus, kMaxGlobalGroups, aux[1], caps[1])) != hipSuccess) return e;
+        if ((e = launch_class<PoaClass1, true>(P, Q, 1, n_windows, scratch, num_cus, 0, aux[1], caps[1])) != hipSuccess) return e;
         rec(3 + 2 * 1, aux[1]);
         (void)hipEventRecord(join_ev[0], aux[0]);
         (void)hipEventRecord(join_ev[1], aux[1]);
         (void)hipStreamWaitEvent(stream, join_ev[0], 0);
         (void)hipStreamWaitEvent(stream, join_ev[1], 0);
         // mop-up of re-queued windows (normally none), then the rare classes
-        if ((e = launch_class<PoaClass1, true>(P, Q, 1, 1024, scratch, num_cus, kMaxGlobalGroups, stream, 1, true)) != hipSuccess) return e;
-        if ((e = launch_class<PoaClass2, true>(P, Q, 2, 1024, scratch, num_cus, kMaxGlobalGroups, stream, 1, true)) != hipSuccess) return e;
+        if ((e = launch_class<PoaClass1, true>(P, Q, 1, 1024, scratch, num_cus, 0, stream, 1, true)) != hipSuccess) return e;
+        if ((e = launch_class<PoaClass2, true>(P, Q, 2, 1024, scratch, num_cus, 0, stream, 1, true)) != hipSuccess) return e;
         rec(2 + 2 * 3, stream);
-        if ((e = launch_class<PoaClass3, true>(P, Q, 3, n_windows, scratch, num_cus, kMaxGlobalGroups, stream)) != hipSuccess) return e;
+        if ((e = launch_class<PoaClass3, true>(P, Q, 3, n_windows, scratch, num_cus, 0, stream)) != hipSuccess) return e;
         rec(3 + 2 * 3, stream);
         rec(2 + 2 * 4, stream);
-        if ((e = launch_class<PoaClass4, false>(P, Q, 4, n_windows, scratch, num_cus, kMaxGlobalGroups, stream)) != hipSuccess) return e;
+        if ((e = launch_class<PoaClass4, false>(P, Q, 4, n_windows, scratch, num_cus, max_global_groups(4, n_windows), stream)) != hipSuccess) return e;
         rec(3 + 2 * 4, stream);
+        rec(2 + 2 * 5, stream);
+        if ((e = launch_class<PoaClass5, false>(P, Q, 5, n_windows, scratch, num_cus, max_global_groups(5, n_windows), stream)) != hipSuccess) return e;
+        rec(3 + 2 * 5, stream);
     }
     rec(2 + 2 * kNumPoaClasses, stream);
     pe = 3 + 2 * kNumPoaClasses;

@@ -7,7 +7,15 @@ namespace hypo {
 
 constexpr int kFirstGlobalClass = 4;     // classes >= this keep their state in HBM scratch, not LDS
 constexpr int kFirstLongClass = 4;       // LONG windows (<= 500 bp, ~1.3 k nodes) start here
-constexpr int kMaxGlobalGroups = 256;    // resident groups of the HBM-scratch classes
+// resident groups of the HBM-scratch classes (one wavefront each; the scratch is provisioned for this many).  The LONG class
+// is register-bound at 2 waves per SIMD: 8 per CU x 256 CUs; the last class is a rare safety net.
+constexpr int kMaxGlobalGroups4 = 2048;
+constexpr int kMaxGlobalGroups5 = 64;
+inline int max_global_groups(int cls, uint32_t n_windows) {
+    const int cap = cls == 4 ? kMaxGlobalGroups4 : kMaxGlobalGroups5;
+    const int want = n_windows < 16u ? 16 : (n_windows > (uint32_t)cap ? cap : (int)n_windows);   // no batch needs more groups than windows
+    return want < cap ? want : cap;
+}
 constexpr size_t kPoaHeaderBytes = 8192; // count[8] | head[8] @64 | HypoPoaStats @128 | phase cycles @512 | hist @2048 | start @4096 | cursor @6144
 
 constexpr int kPlanBuckets = 64;         // cost buckets per class of the plan's counting sort

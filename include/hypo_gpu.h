@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HYPO_GPU_ABI_VERSION 2
+#define HYPO_GPU_ABI_VERSION 3
 
 /* error codes */
 #define HYPO_OK              0
@@ -179,11 +179,11 @@ int hypo_gpu_poa_read_stats(const void* workspace, void* hip_stream, HypoPoaStat
  * hypo_gpu_profile_begin(max_calls) arms the next max_calls (<= 256) *_device calls: each records
  * events around its kernels.  hypo_gpu_profile_read(call, ms, n) synchronises that call's last event
  * and returns up to n elapsed times in milliseconds:
- *   POA call : ms[0] = plan kernels, ms[1 + c] = size-class kernel c (5 classes; the LDS classes overlap in time),
- *              ms[6] = the whole call on the caller's stream (HYPO_PROFILE_POA_SLOTS values)
+ *   POA call : ms[0] = plan kernels, ms[1 + c] = size-class kernel c (6 classes; the LDS classes overlap in time),
+ *              ms[7] = the whole call on the caller's stream (HYPO_PROFILE_POA_SLOTS values)
  *   scan call: ms[0] = mark, ms[1] = rank (3 kernels), ms[2] = kids (HYPO_PROFILE_SCAN_SLOTS values)
  * Returns the number of values written, or <0. */
-#define HYPO_PROFILE_POA_SLOTS 7
+#define HYPO_PROFILE_POA_SLOTS 8
 #define HYPO_PROFILE_SCAN_SLOTS 3
 int hypo_gpu_profile_begin(int max_calls);
 int hypo_gpu_profile_calls(void);
