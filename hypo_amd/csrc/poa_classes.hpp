@@ -27,7 +27,7 @@ typedef PoaCfg<32, 4, 79, 84, 4, 6720, 640, 768, 64, int16_t, uint8_t> PoaClass1
 #endif
 typedef PoaCfg<HYPO_C2_GW, HYPO_C2_CPL, 127, 126, 6, 13440, 1024, 1024, 96, int16_t, uint8_t> PoaClass2;
 typedef PoaCfg<64, 2, 127, 254, 8, 32768, 4096, 4096, 254, int16_t, uint8_t> PoaClass3;
-typedef PoaCfg<64, 10, 639, 2400, 12, 1536000, 491520, 16384, 256, int16_t, uint16_t, 1 << 18> PoaClass4;          // + 256 K path ids: runs LONG windows
+typedef PoaCfg<64, 10, 639, 2400, 12, 1536000, 491520, 16384, 256, int16_t, uint16_t, 1 << 18, true> PoaClass4;          // + 256 K path ids: runs LONG windows
 typedef PoaCfg<64, 16, 1023, 4000, 16, 1 << 22, 1 << 21, 16384, 1024, int32_t, uint16_t, 1 << 18> PoaClass5;    // last resort, also runs LONG windows
 constexpr int kNumPoaClasses = 6;
 }  // namespace hypo

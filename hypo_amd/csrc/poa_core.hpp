@@ -83,8 +83,9 @@ struct PoaParamRef {
 #endif
 
 template <int GW_, int CPL_, int LCAP_, int NMAX_, int KIN_, int DIRCELLS_, int RINGCELLS_, int ARMBYTES_,
-          int SEQMAX_, class ScoreT, class IdT, int PATHCAP_ = 0>
+          int SEQMAX_, class ScoreT, class IdT, int PATHCAP_ = 0, bool HYBRID_ = false>
 struct PoaCfg {
+    static constexpr bool HYBRID = HYBRID_;     // state in HBM scratch except the arrays the graph walks hammer (PoaLayout::FAST_BYTES of LDS)
     static constexpr int PATHCAP = PATHCAP_;    // node ids of the sequences' paths (LONG windows only; 0 = class cannot run them)
     static constexpr int GW = GW_;              // lanes per window
     static constexpr int CPL = CPL_;            // matrix columns per lane
@@ -150,6 +151,16 @@ struct PoaLayout {   // byte offsets inside a group's memory slice
     static constexpr int oDst = oMsa + align_up<16>(LONGN * 2);
     static constexpr int oCons = oDst + align_up<16>(LONGN * 4);
     static constexpr int BYTES = oCons + align_up<16>(LONGN);
+    // Hybrid classes (Cfg::HYBRID) keep everything above in HBM scratch except what the topological sort and the graph update
+    // chase with dependent loads: DFS stack / posnode, in-degree, clique size, marks, current sequence.  These live in a
+    // second, small slice in LDS (their slots in the big slice stay unused).
+    static constexpr int fPosnode = 0;
+    static constexpr int fNin = fPosnode + align_up<16>(POS_BYTES);
+    static constexpr int fNal = fNin + align_up<16>(Cfg::NMAX);
+    static constexpr int fMark = fNal + align_up<16>(Cfg::NMAX);
+    static constexpr int fSeq = fMark + align_up<16>(Cfg::NMAX);
+    static constexpr int FAST_BYTES = fSeq + align_up<16>(Cfg::LMAX + 1);   // (row metadata in LDS as well was measured: fewer resident
+                                                                             // waves cost more than the shorter row loop gains)
 };
 
 template <class Cfg>
@@ -197,16 +208,19 @@ struct Poa {
     uint64_t cells, aligns, reused, rows_done, topo_runs, cons_serial;
     uint64_t tphase[PH_N]; uint64_t tlast;
 
-    HD Poa(const Grp<GW>& g_, const PoaParamRef& P_, char* mem) : g(g_), P(P_) {
+    // `fast`: the LDS slice of a hybrid class (ignored otherwise: one slice, LDS or HBM, holds everything)
+    HD Poa(const Grp<GW>& g_, const PoaParamRef& P_, char* mem, char* fast = nullptr) : g(g_), P(P_) {
         ring = (score_t*)(mem + Lay::oRing); dir = (uint8_t*)(mem + Lay::oDir);
         rowmeta = (uint32_t*)(mem + Lay::oRowmeta); seqtab = (uint32_t*)(mem + Lay::oSeqtab);
-        inw = (wt_t*)(mem + Lay::oInw); posnode = (int16_t*)(mem + Lay::oPosnode);
+        inw = (wt_t*)(mem + Lay::oInw);
+        constexpr bool HYB = Cfg::HYBRID;
+        posnode = (int16_t*)(HYB ? fast + Lay::fPosnode : mem + Lay::oPosnode);
         inp = (id_t*)(mem + Lay::oInp); al = (id_t*)(mem + Lay::oAl);
         r2n = (id_t*)(mem + Lay::oR2n); n2r = (id_t*)(mem + Lay::oN2r);
-        stack = (id_t*)(mem + Lay::oPosnode); code = (uint8_t*)(mem + Lay::oCode);
-        nin = (uint8_t*)(mem + Lay::oNin); nout = (uint8_t*)(mem + Lay::oNout);
-        nal = (uint8_t*)(mem + Lay::oNal); mark = (uint8_t*)(mem + Lay::oMark);
-        seq = (uint8_t*)(mem + Lay::oSeq); armbuf = (uint8_t*)(mem + Lay::oArms);
+        stack = (id_t*)(HYB ? fast + Lay::fPosnode : mem + Lay::oPosnode); code = (uint8_t*)(mem + Lay::oCode);
+        nin = (uint8_t*)(HYB ? fast + Lay::fNin : mem + Lay::oNin); nout = (uint8_t*)(mem + Lay::oNout);
+        nal = (uint8_t*)(HYB ? fast + Lay::fNal : mem + Lay::oNal); mark = (uint8_t*)(HYB ? fast + Lay::fMark : mem + Lay::oMark);
+        seq = (uint8_t*)(HYB ? fast + Lay::fSeq : mem + Lay::oSeq); armbuf = (uint8_t*)(mem + Lay::oArms);
         pathnodes = (id_t*)(mem + Lay::oPathNodes); pathoff = (uint32_t*)(mem + Lay::oPathOff);
         pathlen = (uint16_t*)(mem + Lay::oPathLen); pathmult = (uint16_t*)(mem + Lay::oPathMult);
         msa = (uint16_t*)(mem + Lay::oMsa); dstcnt = (uint32_t*)(mem + Lay::oDst); consbuf = (uint8_t*)(mem + Lay::oCons);
@@ -721,29 +735,57 @@ struct Poa {
             // all marked (or are lower roots of this very batch) is emitted at once by the reference's loop, in id
             // order; marked roots are skipped.  The leading run of such lanes is retired with one ballot.
             const int r = root + g.lane;
-            bool pre = false, isdone = false;
+            bool pre = false, isdone = false, clq = false;
+            int ka = 0;
             if (r < n_nodes) {
                 isdone = mark[r] & 1;
                 pre = isdone;
-                if (!isdone && nal[r] == 0) {
+                if (!isdone) {
+                    ka = nal[r];
                     const int k = nin[r];
                     bool ok = true;
                     for (int p = 0; p < k; ++p) {
                         const int d = inp[r * KIN + p];
                         ok &= (d >= root && d < r) || (mark[d] & 1);
                     }
-                    pre = ok;
+                    if (ka == 0) pre = ok;
+                    else if (ok) {
+                        // A root with an aligned clique whose members' in-edge sources are all emitted: the reference's DFS pushes
+                        // the members, finds each of them ready, marks them and emits root + members in aligned-list order
+                        // (graph.cpp:311-349).  Such a root may END a run (it is the lane right after the leading plain roots).
+                        bool cok = true;
+                        for (int j = 0; j < ka; ++j) {
+                            const int a = al[r * AL + j];
+                            const int k2 = nin[a];
+                            for (int p = 0; p < k2; ++p) {
+                                const int d = inp[a * KIN + p];
+                                cok &= (d >= root && d < r) || (mark[d] & 1);
+                            }
+                        }
+                        clq = cok;
+                    }
                 }
             }
             const uint64_t full = GW == 64 ? ~0ull : ((1ull << (GW & 63)) - 1ull);
             const uint64_t bp = g.ballot(pre);
             const int run = bp == full ? GW : ctz64(~bp);
-            if (run > 0) {
+            const uint64_t cb = g.ballot(clq);
+            const bool has_clq = run < GW && ((cb >> run) & 1ull);
+            if (run > 0 || has_clq) {
                 const bool em = g.lane < run && !isdone;       // lanes < run have r < n_nodes (pre is false beyond)
                 const uint64_t eb = g.ballot(em);
                 if (em) { r2n[cnt + popc64(eb & ((1ull << g.lane) - 1ull))] = (id_t)r; mark[r] = 1; }
                 cnt += popc64(eb);
                 root += run;
+                if (has_clq) {
+                    const int kc = g.shfl(ka, run);
+                    if (g.lane == run) {
+                        r2n[cnt] = (id_t)r; mark[r] = 1;
+                        for (int j = 0; j < ka; ++j) { const int a = al[r * AL + j]; r2n[cnt + 1 + j] = (id_t)a; mark[a] = 1; }
+                    }
+                    cnt += 1 + kc;
+                    root += 1;
+                }
                 g.sync();
                 continue;
             }
@@ -1005,7 +1047,8 @@ struct Poa {
         if (rc != RES_OK) return rc;
         if ((rc = add_alignment()) != RES_OK) return rc;
         if ((rc = record_path(tb_steps == 0 ? L : tb_fv)) != RES_OK) return rc;   // before toposort: its stack aliases posnode
-        if (topo_dirty) { rc = toposort(); topo_runs += 1; }
+        HYPO_TICK(PH_ADD);
+        if (topo_dirty) { rc = toposort(); topo_runs += 1; HYPO_TICK(PH_TOPO); }
         return rc;
     }
     HD int run_long(uint32_t w, const HypoWindow& W) {
@@ -1092,6 +1135,7 @@ struct Poa {
             }
             conslen = o;
             g.sync();
+            HYPO_TICK(PH_CONS);
         }
         const uint64_t oo = P->out_off[w], cap = P->out_off[w + 1] - oo;
         if ((uint64_t)conslen > cap) { finish(w, HYPO_ST_CONS_OVERFLOW, (uint32_t)conslen); return RES_OK; }

@@ -164,6 +164,7 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through t
     Grp<GW> g{wl & (GW - 1)};
     char* mem = USE_LDS ? smem + (size_t)grp * PoaLayout<Cfg>::BYTES
                         : fresh(ka)->scratch + ((size_t)blockIdx.x * GPW + grp) * PoaLayout<Cfg>::BYTES;
+    char* fast = smem + (size_t)grp * PoaLayout<Cfg>::FAST_BYTES;     // hybrid classes only
     const int cls = fresh(ka)->cls;
     const uint32_t count = *fresh(ka)->bound;   // queue slots [.., *bound) are final when this launch starts
     const PoaParamRef P{&ka->P};
@@ -213,7 +214,7 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through t
         *w = fresh(ka)->Q.items[(size_t)cls * fresh(ka)->Q.stride + idx];
         return true;
     };
-    Poa<Cfg> poa(g, P, mem);
+    Poa<Cfg> poa(g, P, mem, fast);
     // The groups of a wavefront (GPW > 1) take windows in lock step: all dequeue, all run, all write their consensus.
     // (Letting a finished group open its next window while its neighbours are still aligning was measured and is
     // slower: the dequeue + descriptor + arm staging round trips of one group then stall the other three, 4x as often.)
@@ -246,7 +247,7 @@ static hipError_t launch_class(const PoaParams& P, const PoaQueues& Q, int cls, 
                                int waves_per_cu_cap = 0, bool mop_up = false) {
     auto kern = poa_class_kernel<Cfg, USE_LDS>;
     constexpr int GPW = 64 / Cfg::GW;
-    const size_t lds = USE_LDS ? (size_t)GPW * PoaLayout<Cfg>::BYTES : 0;
+    const size_t lds = USE_LDS ? (size_t)GPW * PoaLayout<Cfg>::BYTES : (Cfg::HYBRID ? (size_t)GPW * PoaLayout<Cfg>::FAST_BYTES : 0);
     hipError_t e;
     if (lds > 48 * 1024) {
         e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -114,6 +114,7 @@ struct Job {
     hypo::EmuGroup eg;
     const hypo::PoaParams* P;
     char* mem;
+    char* fast;           // second slice of a hybrid class (PoaLayout::FAST_BYTES)
     uint32_t w;
     int rc[64];
     uint64_t cells, aligns;
@@ -123,7 +124,7 @@ template <class Cfg>
 void lane_body(int lane, void* arg) {
     Job<Cfg>* j = (Job<Cfg>*)arg;
     hypo::Grp<Cfg::GW> g{lane, &j->eg};
-    hypo::Poa<Cfg> poa(g, hypo::PoaParamRef{j->P}, j->mem);
+    hypo::Poa<Cfg> poa(g, hypo::PoaParamRef{j->P}, j->mem, j->fast);
     j->rc[lane] = poa.run(j->w);
     if (lane == 0) { j->cells = poa.cells; j->aligns = poa.aligns; }
 }
@@ -137,6 +138,8 @@ int run_cfg(const hypo::PoaParams& P, uint32_t n_windows, uint8_t* res, uint64_t
     for (uint32_t w = 0; w < n_windows; ++w) {
         job.mem = (char*)malloc(hypo::PoaLayout<Cfg>::BYTES);       // exact size: ASan sees overruns
         memset(job.mem, 0xA5, hypo::PoaLayout<Cfg>::BYTES);         // LDS is not zero-initialised
+        job.fast = (char*)malloc(hypo::PoaLayout<Cfg>::FAST_BYTES);
+        memset(job.fast, 0x5A, hypo::PoaLayout<Cfg>::FAST_BYTES);
         job.w = w; job.cells = job.aligns = 0;
         run_group(s, Cfg::GW, lane_body<Cfg>, &job);
         for (int l = 1; l < Cfg::GW; ++l) if (job.rc[l] != job.rc[0]) { fprintf(stderr, "[emu] lanes disagree on the result of window %u\n", w); abort(); }
@@ -144,6 +147,7 @@ int run_cfg(const hypo::PoaParams& P, uint32_t n_windows, uint8_t* res, uint64_t
         if (job.rc[0] != hypo::RES_OK) { P.out_len[w] = 0; P.out_status[w] = 0xFF; }
         *cells += job.cells; *aligns += job.aligns;
         free(job.mem);
+        free(job.fast);
     }
     free(s.stacks);
     return 0;
