@@ -97,7 +97,8 @@ struct PoaCfg {
     static constexpr int ARMBYTES = ARMBYTES_;  // packed arm bytes staged per window
     static constexpr int SEQMAX = SEQMAX_;      // sequences (arms + backbone) per window
     static constexpr int AL = 6;                // aligned clique partners (alphabet ACGTNJO -> at most 6)
-    static constexpr int STK = 2 * NMAX_;       // DFS stack
+    static constexpr int STK = HYBRID_ ? 1536 : 2 * NMAX_;   // DFS stack entries (hybrid: the LDS copy is smaller; deeper DFS -> next class)
+    static constexpr int RING1 = HYBRID_ ? 6 : 0;  // hybrid: this many most recent score rows are also kept in LDS
     // direction codes: 4 bits when the pred index fits (diag p = p, vert p = 7+p, horiz = 14, fast = 15)
     static constexpr bool NIB = (KIN_ <= 7) && (CPL_ % 2 == 0);
     static constexpr int DIRBYTES = NIB ? DIRCELLS_ / 2 : DIRCELLS_;
@@ -112,7 +113,7 @@ struct PoaCfg {
     static_assert(KIN_ <= 62, "direction byte holds the pred index in 6 bits");
     static_assert((int)sizeof(ScoreT) * RINGCELLS_ + DIRBYTES >= 14 * NMAX_, "consensus scratch aliases ring+dir");
     static_assert(NMAX_ < ID_NONE, "id range");
-    static_assert(SEQMAX_ <= 2 * NMAX_ && SEQMAX_ <= ID_NONE, "arm indices are parked in the DFS stack while staging");
+    static_assert(SEQMAX_ <= STK && SEQMAX_ <= ID_NONE, "arm indices are parked in the DFS stack while staging");
 };
 
 template <int N> HD constexpr int align_up(int x) { return (x + N - 1) / N * N; }
@@ -150,7 +151,10 @@ struct PoaLayout {   // byte offsets inside a group's memory slice
     static constexpr int oMsa = oPathMult + align_up<16>(LONGSEQ * 2);
     static constexpr int oDst = oMsa + align_up<16>(LONGN * 2);
     static constexpr int oCons = oDst + align_up<16>(LONGN * 4);
-    static constexpr int BYTES = oCons + align_up<16>(LONGN);
+    // HBM-scratch classes: matrix row of every in-edge source by rank, so that the row loop needs one load per extra
+    // predecessor instead of the r2n -> inp -> n2r chain (three dependent HBM round trips per predecessor)
+    static constexpr int oPredRows = oCons + align_up<16>(LONGN);
+    static constexpr int BYTES = oPredRows + align_up<16>(LONGN * Cfg::KIN * (int)sizeof(id_t));
     // Hybrid classes (Cfg::HYBRID) keep everything above in HBM scratch except what the topological sort and the graph update
     // chase with dependent loads: DFS stack / posnode, in-degree, clique size, marks, current sequence.  These live in a
     // second, small slice in LDS (their slots in the big slice stay unused).
@@ -159,7 +163,9 @@ struct PoaLayout {   // byte offsets inside a group's memory slice
     static constexpr int fNal = fNin + align_up<16>(Cfg::NMAX);
     static constexpr int fMark = fNal + align_up<16>(Cfg::NMAX);
     static constexpr int fSeq = fMark + align_up<16>(Cfg::NMAX);
-    static constexpr int FAST_BYTES = fSeq + align_up<16>(Cfg::LMAX + 1);   // (row metadata in LDS as well was measured: fewer resident
+    static constexpr int SMAX = (Cfg::LMAX + 1 + Cfg::CPL - 1) / Cfg::CPL * Cfg::CPL;          // largest row stride
+    static constexpr int fRing1 = fSeq + align_up<16>(Cfg::LMAX + 1);                              // RING1 recent score rows
+    static constexpr int FAST_BYTES = fRing1 + align_up<16>(Cfg::RING1 * SMAX * (int)sizeof(score_t));   // (row metadata in LDS as well was measured: fewer resident
                                                                              // waves cost more than the shorter row loop gains)
 };
 
@@ -199,7 +205,7 @@ struct Poa {
     score_t* ring; uint8_t* dir; uint32_t* rowmeta; uint32_t* seqtab; wt_t* inw; int16_t* posnode;
     id_t *inp, *al, *r2n, *n2r, *stack;
     uint8_t *code, *nin, *nout, *nal, *mark, *seq, *armbuf;
-    id_t* pathnodes; uint32_t* pathoff; uint16_t *pathlen, *pathmult, *msa; uint32_t* dstcnt; uint8_t* consbuf;
+    id_t* pathnodes; uint32_t* pathoff; uint16_t *pathlen, *pathmult, *msa; uint32_t* dstcnt; uint8_t* consbuf; id_t* predrows; score_t* ring1;
     int n_paths, path_used, head_first;
     // group-uniform state
     int n_nodes; int L; bool topo_dirty; bool meta_dirty; int maxdelta;
@@ -224,6 +230,8 @@ struct Poa {
         pathnodes = (id_t*)(mem + Lay::oPathNodes); pathoff = (uint32_t*)(mem + Lay::oPathOff);
         pathlen = (uint16_t*)(mem + Lay::oPathLen); pathmult = (uint16_t*)(mem + Lay::oPathMult);
         msa = (uint16_t*)(mem + Lay::oMsa); dstcnt = (uint32_t*)(mem + Lay::oDst); consbuf = (uint8_t*)(mem + Lay::oCons);
+        predrows = (id_t*)(mem + Lay::oPredRows);
+        ring1 = (score_t*)(HYB ? fast + Lay::fRing1 : mem + Lay::oRing);
         n_paths = 0; path_used = 0; head_first = 0;
         n_nodes = 0; L = 0; topo_dirty = false; meta_dirty = true; maxdelta = 0; tb_steps = 0; tb_fv = 0;
         cells = 0; aligns = 0; reused = 0; rows_done = 0; topo_runs = 0; cons_serial = 0; last_changed = true;
@@ -343,6 +351,7 @@ struct Poa {
             int p0 = 0;
             for (int p = 0; p < k; ++p) {
                 const int pr = (int)n2r[inp[u * KIN + p]] + 1;
+                if (PRED_TABLE) predrows[r * KIN + p] = (id_t)pr;
                 if (p == 0) p0 = pr;
                 const int d = r + 1 - pr;
                 md = d > md ? d : md;
@@ -352,9 +361,33 @@ struct Poa {
         maxdelta = g.reduce_max(md);
         meta_dirty = false;
         g.sync();
+        if (Cfg::RING1 > 0 && maxdelta > Cfg::RING1) {
+            // hybrid classes: only rows that some later row reads from further back than the LDS ring reaches go to the HBM ring
+            for (int r = g.lane; r < n_nodes; r += GW) {
+                const int k = (int)((rowmeta[r] >> 8) & 0xff);
+                for (int p = 0; p < k; ++p) {
+                    const int pr = pred_row(r, p);
+                    if (pr > 0 && r + 1 - pr > Cfg::RING1) atomic_or(&rowmeta[pr - 1], META_DEEP);
+                }
+            }
+            g.sync();
+        }
+    }
+    static constexpr uint32_t META_DEEP = 0x80000000u;     // rowmeta bit 31: a row further than RING1 ahead reads this row
+    HD static int meta_p0(uint32_t meta) { return (int)((meta >> 17) & 0x3fffu); }
+    HD static void atomic_or(uint32_t* p, uint32_t v) {
+#ifdef HYPO_EMU
+        *p |= v;
+#else
+        atomicOr(p, v);
+#endif
     }
 
-    HD int pred_row(int r, int p) const { return (int)n2r[inp[(int)r2n[r] * KIN + p]] + 1; }   // matrix row of pred p of rank r
+    static constexpr bool PRED_TABLE = Cfg::PATHCAP > 0;    // the HBM-scratch classes tabulate pred rows in build_rowmeta
+    HD int pred_row(int r, int p) const {                   // matrix row of pred p of rank r
+        if (PRED_TABLE) return (int)predrows[r * KIN + p];
+        return (int)n2r[inp[(int)r2n[r] * KIN + p]] + 1;
+    }
     HD void load_ring(int slot, int S, int (&out)[CPL]) const {
         if (CPL * g.lane < S) {
             const Pack pk = *(const Pack*)(ring + slot * S + CPL * g.lane);
@@ -365,9 +398,9 @@ struct Poa {
             for (int c = 0; c < CPL; ++c) out[c] = NEG;
         }
     }
-    HD void load_ring_at(int off, int S, int (&out)[CPL]) const {   // off = slot * S
+    HD void load_ring_at(const score_t* base, int off, int S, int (&out)[CPL]) const {   // off = slot * S
         if (CPL * g.lane < S) {
-            const Pack pk = *(const Pack*)(ring + off + CPL * g.lane);
+            const Pack pk = *(const Pack*)(base + off + CPL * g.lane);
             HYPO_UNROLL
             for (int c = 0; c < CPL; ++c) out[c] = (int)pk.v[c];
         } else {
@@ -416,6 +449,9 @@ struct Poa {
         int slot = 0;                                        // ring slot of row i (no integer division in the loop)
         int slotS = 0, rowS = 0;                             // slot * S and r * S, advanced by addition (group-uniform)
         const int RS = R * S;
+        constexpr int R1 = Cfg::RING1;                       // hybrid classes: LDS ring of the R1 most recent rows (0 = none)
+        int slot1S = 0;                                      // (i mod R1) * S
+        const int R1S = R1 * S;
         // Row metadata: full-wave groups keep it in registers (lane r holds row r, fetched with v_readlane, no
         // LDS latency in the row loop); narrower groups and the big classes prefetch it from LDS two rows ahead.
         constexpr int MREG = (NMAX + GW - 1) / GW;
@@ -430,12 +466,20 @@ struct Poa {
             HYPO_UNROLL
             for (int q = 0; q < (META_IN_REGS ? MREG : 1); ++q) HYPO_ARRIVED(mreg[q]);
         }
-        uint32_t meta_a = META_IN_REGS ? 0u : rowmeta[0];
-        uint32_t meta_b = (!META_IN_REGS && n_nodes > 1) ? rowmeta[1] : 0u;
+        // Full-wave groups with more rows than that refill one register every 64 rows (lane t = row base + t) and wait for the
+        // load right there: a per-row prefetch from HBM makes the compiler wait for ALL outstanding memory operations (the
+        // row's own stores included) once per row, which was most of the row time of the HBM-scratch classes.
+        constexpr bool META_CHUNKED = (GW == 64) && !META_IN_REGS;
+        uint32_t mchunk = 0u;
+        uint32_t meta_a = (META_IN_REGS || META_CHUNKED) ? 0u : rowmeta[0];
+        uint32_t meta_b = (!META_IN_REGS && !META_CHUNKED && n_nodes > 1) ? rowmeta[1] : 0u;
         for (int r = 0; r < n_nodes; ++r) {
             const int i = r + 1;
             uint32_t meta;
-            if (META_IN_REGS) {
+            if (META_CHUNKED) {
+                if ((r & 63) == 0) { mchunk = r + g.lane < n_nodes ? rowmeta[r + g.lane] : 0u; HYPO_ARRIVED(mchunk); }
+                meta = (uint32_t)g.shfl((int)mchunk, r & 63);
+            } else if (META_IN_REGS) {
                 uint32_t mv = mreg[0];
                 HYPO_UNROLL
                 for (int q = 1; q < (META_IN_REGS ? MREG : 1); ++q) if ((r / GW) == q) mv = mreg[q];
@@ -447,7 +491,7 @@ struct Poa {
             }
             const int cd = (int)(meta & 0xff), k = (int)((meta >> 8) & 0xff);
             const bool sink = (meta >> 16) & 1;
-            const int p0 = (int)(meta >> 17);                // 0 when k == 0 (virtual source row)
+            const int p0 = meta_p0(meta);                    // 0 when k == 0 (virtual source row)
             int D[CPL], U[CPL];
             int codeD[CPL], codeU[CPL];                      // direction codes if the cell's value comes from D / U
             const bool fastrow = p0 == i - 1;
@@ -456,7 +500,8 @@ struct Poa {
                 int hp[CPL];
                 if (fastrow) { HYPO_UNROLL for (int c = 0; c < CPL; ++c) hp[c] = last[c]; }
                 else if (p0 == 0) { HYPO_UNROLL for (int c = 0; c < CPL; ++c) hp[c] = jg[c]; }
-                else { int ps = slotS - (i - p0) * S; ps = ps < 0 ? ps + RS : ps; load_ring_at(ps, S, hp); }
+                else if (R1 > 0 && i - p0 <= R1) { int ps = slot1S - (i - p0) * S; ps = ps < 0 ? ps + R1S : ps; load_ring_at(ring1, ps, S, hp); }
+                else { int ps = slotS - (i - p0) * S; ps = ps < 0 ? ps + RS : ps; load_ring_at(ring, ps, S, hp); }
                 const int left = g.shfl_up1(hp[CPL - 1], NEG);
                 HYPO_UNROLL
                 for (int c = 0; c < CPL; ++c) {
@@ -471,8 +516,9 @@ struct Poa {
                 for (int c = 0; c < CPL; ++c) { pD[c] = 0; pU[c] = 0; }
                 for (int p = 1; p < k; ++p) {
                     int hp[CPL];
-                    int ps = slotS - (i - pred_row(r, p)) * S; ps = ps < 0 ? ps + RS : ps;
-                    load_ring_at(ps, S, hp);
+                    const int pr = g.uniform(pred_row(r, p));
+                    if (R1 > 0 && i - pr <= R1) { int ps = slot1S - (i - pr) * S; ps = ps < 0 ? ps + R1S : ps; load_ring_at(ring1, ps, S, hp); }
+                    else { int ps = slotS - (i - pr) * S; ps = ps < 0 ? ps + RS : ps; load_ring_at(ring, ps, S, hp); }
                     const int left = g.shfl_up1(hp[CPL - 1], NEG);
                     HYPO_UNROLL
                     for (int c = 0; c < CPL; ++c) {
@@ -531,10 +577,16 @@ struct Poa {
                     for (int c = 0; c < CPL; ++c) dk.v[c] = (uint8_t)dc[c];
                     *(DPack*)(dir + rowS + j0) = dk;
                 }
-                *(Pack*)(ring + slotS + j0) = pk;
+                if (R1 > 0) {
+                    *(Pack*)(ring1 + slot1S + j0) = pk;
+                    if (meta & META_DEEP) *(Pack*)(ring + slotS + j0) = pk;      // read again from further back than the LDS ring reaches
+                } else {
+                    *(Pack*)(ring + slotS + j0) = pk;
+                }
             }
             slot = slot + 1 == R ? 0 : slot + 1;
             slotS = slot == 0 ? 0 : slotS + S;
+            if (R1 > 0) slot1S = slot1S + S == R1S ? 0 : slot1S + S;
             rowS += S;
             HYPO_UNROLL
             for (int c = 0; c < CPL; ++c) last[c] = v[c];
@@ -872,7 +924,7 @@ struct Poa {
                 a = -255;                                    // a source scores -1 and is one node
                 if (k != 0) {
                     const int u = r2n[r];
-                    int bw = inw[u * KIN], bp = (int)(meta >> 17);
+                    int bw = inw[u * KIN], bp = meta_p0(meta);
                     bool tied = false;
                     for (int p = 1; p < k; ++p) {
                         const int w = inw[u * KIN + p];
@@ -955,7 +1007,7 @@ struct Poa {
             for (int r = 0; r < n_nodes; ++r) {
                 const uint32_t meta = meta_n; const int w0 = w_n; const int u = u_n;
                 if (r + 1 < n_nodes) { meta_n = rowmeta[r + 1]; w_n = w0r[r + 1]; u_n = r2n[r + 1]; }
-                const int k = (int)((meta >> 8) & 0xff), p0 = (int)(meta >> 17);
+                const int k = (int)((meta >> 8) & 0xff), p0 = meta_p0(meta);
                 int sc = -1, pd = -1;
                 if (k != 0) {
                     int bw = w0, bs = p0 == r ? prev_s : rs[p0 - 1], bp = p0;
