@@ -236,7 +236,7 @@ void Hypo::create_alignments(bool is_sr, uint32_t batch_id) {
             if (sl.skip) continue;
             if (sl.bad_ref) {
                 std::fprintf(stderr, "[Hypo::Hypo] Error: Alignment File error: Contig-reference of record %s does not exist in the draft!\n",
-                             lines[i].substr(0, lines[i].find('\t')).c_str());
+                             sf.record_name(lines[i]).c_str());
                 std::exit(1);
             }
             if (sl.aln->is_valid) { _alignment_store[(size_t)sl.cid].emplace_back(std::move(sl.aln)); ++num_alns; } else ++num_invalid;

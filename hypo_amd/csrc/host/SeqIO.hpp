@@ -1,7 +1,8 @@
 // SeqIO.hpp — FASTA/FASTQ and SAM-text readers for the host pipeline (plain or gzip, via zlib).
 // The reference reads drafts with klib's kseq (src/Hypo.cpp:82-95) and alignments with htslib
 // (src/Hypo.cpp:278-329); only the fields HyPo consumes are parsed here: FLAG, RNAME, POS, MAPQ, CIGAR, SEQ and
-// the NM:i tag (src/Alignment.cpp:514-571, :51-58).  BAM (BGZF) input is not decoded by this reader.
+// the NM:i tag (src/Alignment.cpp:514-571, :51-58).  Alignment files may be SAM text (plain or gzip) or BAM: BGZF is a
+// series of gzip members, which zlib's gz* layer inflates as one stream, and the BAM records are decoded here.
 #pragma once
 #include <zlib.h>
 #include <cstdint>
@@ -44,6 +45,30 @@ public:
             line.append(b, _end - _pos);
             _pos = _end;
         }
+    }
+    // exactly n raw bytes of the (inflated) stream; false at end of file
+    bool read_bytes(void* dst, size_t n) {
+        char* d = (char*)dst;
+        while (n) {
+            if (_pos == _end) {
+                if (_eof || !_fp) return false;
+                const int got = gzread(_fp, _buf.data(), (unsigned)kBuf);
+                if (got <= 0) { _eof = true; return false; }
+                _pos = 0; _end = (size_t)got;
+            }
+            const size_t take = n < _end - _pos ? n : _end - _pos;
+            std::memcpy(d, _buf.data() + _pos, take);
+            d += take; _pos += take; n -= take;
+        }
+        return true;
+    }
+    // first bytes of the stream without consuming them (used once, right after opening)
+    bool starts_with(const char* magic, size_t n) {
+        if (_pos == _end && !_eof && _fp) {
+            const int got = gzread(_fp, _buf.data(), (unsigned)kBuf);
+            if (got <= 0) _eof = true; else { _pos = 0; _end = (size_t)got; }
+        }
+        return _end - _pos >= n && std::memcmp(_buf.data() + _pos, magic, n) == 0;
     }
 private:
     static constexpr size_t kBuf = 4u << 20;
@@ -99,6 +124,7 @@ struct SamRecord {
 class SamReader {
 public:
     explicit SamReader(const std::string& path) : _lr(path) {
+        if (_lr.ok() && _lr.starts_with("BAM\1", 4)) { _bam = true; read_bam_header(); return; }
         // header: @SQ SN: names define the tids
         while (_lr.next(_pending)) {
             if (_pending.empty() || _pending[0] != '@') { _have_pending = true; break; }
@@ -122,6 +148,13 @@ public:
     }
     // next non-empty alignment line (I/O and inflate are serial; parsing is not, see parse())
     bool next_line(std::string& line) {
+        if (_bam) {                                   // one BAM alignment block (without its 4-byte size) as an opaque "line"
+            int32_t bs = 0;
+            if (!_bam_ok || !_lr.read_bytes(&bs, 4) || bs < 32) return false;
+            line.resize((size_t)bs);
+            if (!_lr.read_bytes(&line[0], (size_t)bs)) { std::fprintf(stderr, "[Hypo::SamReader] Error: truncated BAM record\n"); std::exit(1); }
+            return true;
+        }
         if (_have_pending) { line.swap(_pending); _have_pending = false; }
         else if (!_lr.next(line)) return false;
         while (line.empty()) if (!_lr.next(line)) return false;
@@ -139,6 +172,7 @@ public:
     }
     // one alignment line -> record; const and re-entrant (Hypo::create_alignments parses blocks of lines in parallel)
     void parse(const std::string& line, SamRecord& r) const {
+        if (_bam) { parse_bam(line, r); return; }
         size_t f[12]; int nf = 0; f[0] = 0;
         for (size_t i = 0; i < line.size() && nf < 11; ++i) if (line[i] == '\t') f[++nf] = i + 1;
         if (nf < 10) { std::fprintf(stderr, "[Hypo::SamReader] Error: malformed SAM record: %s\n", line.substr(0, 60).c_str()); std::exit(1); }
@@ -170,7 +204,81 @@ public:
             if (p != std::string::npos) { r.has_nm = true; r.nm = std::strtoll(line.c_str() + p + 6, nullptr, 10); }
         }
     }
+    // read name of a raw record as handed out by next_line() (for messages)
+    std::string record_name(const std::string& line) const {
+        if (_bam) return line.size() > 32 ? std::string(line.c_str() + 32) : std::string("?");
+        return line.substr(0, line.find('\t'));
+    }
 private:
+    static int32_t le32(const char* p) { int32_t v; std::memcpy(&v, p, 4); return v; }
+    static uint16_t le16(const char* p) { uint16_t v; std::memcpy(&v, p, 2); return v; }
+    void read_bam_header() {                          // SAM spec 4.2: magic, l_text, text, n_ref, (l_name, name, l_ref)*
+        char magic[4]; int32_t l_text = 0, n_ref = 0;
+        _bam_ok = _lr.read_bytes(magic, 4) && _lr.read_bytes(&l_text, 4) && l_text >= 0;
+        if (_bam_ok) { std::string text((size_t)l_text, '\0'); _bam_ok = l_text == 0 || _lr.read_bytes(&text[0], (size_t)l_text); }
+        _bam_ok = _bam_ok && _lr.read_bytes(&n_ref, 4) && n_ref >= 0;
+        for (int32_t i = 0; _bam_ok && i < n_ref; ++i) {
+            int32_t l_name = 0, l_ref = 0;
+            _bam_ok = _lr.read_bytes(&l_name, 4) && l_name > 0;
+            if (!_bam_ok) break;
+            std::string name((size_t)l_name, '\0');
+            _bam_ok = _lr.read_bytes(&name[0], (size_t)l_name) && _lr.read_bytes(&l_ref, 4);
+            name.resize(std::strlen(name.c_str()));
+            _names.push_back(name);
+            _tid[name] = (int32_t)_names.size() - 1;
+        }
+        if (!_bam_ok) { std::fprintf(stderr, "[Hypo::SamReader] Error: malformed BAM header\n"); std::exit(1); }
+    }
+    void parse_bam(const std::string& b, SamRecord& r) const {      // SAM spec 4.2.1; fields after block_size
+        const char* p = b.data();
+        const size_t n = b.size();
+        const int32_t ref = le32(p), pos = le32(p + 4), l_seq = le32(p + 16);
+        const unsigned l_name = (unsigned char)p[8], mapq = (unsigned char)p[9];
+        const unsigned n_cig = le16(p + 12), flag = le16(p + 14);
+        size_t o = 32;
+        if (l_seq < 0 || o + l_name + 4ull * n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq > n) {
+            std::fprintf(stderr, "[Hypo::SamReader] Error: malformed BAM record\n"); std::exit(1);
+        }
+        r.qname.assign(p + o, l_name ? l_name - 1 : 0); o += l_name;
+        r.flag = flag; r.mapq = mapq;
+        r.tid = (ref >= 0 && (size_t)ref < _names.size()) ? ref : -1;
+        r.pos = (uint32_t)pos;                                       // 0-based in BAM
+        r.cigar.resize(n_cig);
+        for (unsigned i = 0; i < n_cig; ++i) { const uint32_t c = (uint32_t)le32(p + o + 4 * i); r.cigar[i] = (c & 0xf) | ((c >> 4) << 4); }
+        o += 4ull * n_cig;
+        static const char kBase[] = "=ACMGRSVTWYHKDBN";
+        r.seq.resize((size_t)l_seq);
+        for (int32_t i = 0; i < l_seq; ++i) { const unsigned char v = (unsigned char)p[o + (size_t)i / 2]; r.seq[(size_t)i] = kBase[(i & 1) ? (v & 15) : (v >> 4)]; }
+        o += ((size_t)l_seq + 1) / 2 + (size_t)l_seq;                // seq, qual
+        r.has_nm = false;
+        while (o + 3 <= n) {                                          // optional fields: tag[2] type value
+            const char t0 = p[o], t1 = p[o + 1], ty = p[o + 2];
+            o += 3;
+            int64_t iv = 0; bool is_int = true; size_t adv = 0;
+            switch (ty) {
+                case 'c': iv = (int8_t)p[o]; adv = 1; break;
+                case 'C': iv = (uint8_t)p[o]; adv = 1; break;
+                case 's': iv = (int16_t)le16(p + o); adv = 2; break;
+                case 'S': iv = le16(p + o); adv = 2; break;
+                case 'i': iv = le32(p + o); adv = 4; break;
+                case 'I': iv = (uint32_t)le32(p + o); adv = 4; break;
+                case 'A': is_int = false; adv = 1; break;
+                case 'f': is_int = false; adv = 4; break;
+                case 'Z': case 'H': is_int = false; adv = std::strlen(p + o) + 1; break;
+                case 'B': {
+                    is_int = false;
+                    const char st = p[o]; const uint32_t cnt = (uint32_t)le32(p + o + 1);
+                    const size_t es = (st == 'c' || st == 'C') ? 1 : ((st == 's' || st == 'S') ? 2 : 4);
+                    adv = 5 + es * cnt; break;
+                }
+                default: return;                                      // unknown type: stop scanning
+            }
+            if (o + adv > n) return;
+            if (t0 == 'N' && t1 == 'M' && is_int) { r.has_nm = true; r.nm = iv; return; }
+            o += adv;
+        }
+    }
+    bool _bam = false, _bam_ok = true;
     LineReader _lr;
     std::vector<std::string> _names;
     std::unordered_map<std::string, int32_t> _tid;

@@ -32,11 +32,11 @@ void usage() {
         "  mandatory\n"
         "    -r, --reads-short FILE     short reads file or @file-of-names (only checked for existence here)\n"
         "    -d, --draft FILE           draft contigs, FASTA/FASTQ, plain or gzip\n"
-        "    -b, --bam-sr FILE          short reads mapped to the draft, coordinate sorted (SAM text, plain or gzip)\n"
+        "    -b, --bam-sr FILE          short reads mapped to the draft, coordinate sorted (BAM, or SAM text plain/gzip)\n"
         "    -c, --coverage-short INT   approximate coverage of the short reads\n"
         "    -s, --size-ref STR         approximate genome size: number with unit k/m/g/t; fixes the solid k-mer length\n"
         "  optional\n"
-        "    -B, --bam-lr FILE          long reads mapped to the draft (SAM text)         [none]\n"
+        "    -B, --bam-lr FILE          long reads mapped to the draft (BAM or SAM)       [none]\n"
         "    -o, --output FILE          polished contigs                                  [hypo_<draft>.fasta]\n"
         "    -t, --threads INT          host threads                                      [1]\n"
         "    -p, --processing-size INT  contigs per batch, 0 = all                        [0]\n"

@@ -50,10 +50,19 @@ def make_inputs(name, outdir):
     return man
 
 
-def run_case(name, outdir, device, threads=4, extra_env=None):
+def run_case(name, outdir, device, threads=4, extra_env=None, as_bam=False):
     man = make_inputs(name, outdir)
     argv = shlex.split(man["command"])
     argv[0] = BIN
+    if as_bam:                                      # same records as BAM (BGZF): tests/bam_util.py
+        import bam_util
+        for flag, nm in (("-b", "i"), ("-B", "C")):
+            if flag in argv:
+                i = argv.index(flag) + 1
+                bam = os.path.splitext(argv[i])[0] + ".bam"
+                bam_util.sam_to_bam(os.path.join(str(outdir), argv[i]), os.path.join(str(outdir), bam), nm_type=nm)
+                os.remove(os.path.join(str(outdir), argv[i]))
+                argv[i] = bam
     argv[argv.index("-t") + 1] = str(threads)
     env = dict(os.environ)
     env["HYPO_REGION_DUMP"] = os.path.join(str(outdir), "regions.tsv")

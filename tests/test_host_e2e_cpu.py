@@ -25,3 +25,10 @@ def test_e2e_batches_and_threads_do_not_change_the_result(built, tmp_path):
     # -p 1 (one contig per batch) and another thread count: same bytes (reference: src/Hypo.cpp:104-113)
     man, _ = eu.run_case("e2e_20k_s1", tmp_path, "shim", threads=7)
     eu.check_outputs("e2e_20k_s1", tmp_path, man)
+
+
+@pytest.mark.parametrize("name", ["e2e_20k_s1", "e2e_5ctg_long_s21"])
+def test_e2e_bam_input_gives_the_same_result(built, name, tmp_path):
+    """alignments as BAM (BGZF blocks, binary records, NM as a small-integer tag) instead of SAM text"""
+    man, _ = eu.run_case(name, tmp_path, "shim", as_bam=True)
+    eu.check_outputs(name, tmp_path, man)
