@@ -144,7 +144,7 @@ def main():
     extra = {}
     if poa_calls:
         ms = np.array(poa_calls, dtype=np.float64)             # [calls, 1 + classes]
-        cls_ms = ms[:, 1:6].mean(axis=0)
+        cls_ms = ms[:, 1:-1].mean(axis=0)                      # the size-class kernels
         dom = int(np.argmax(cls_ms))
         alg = float(stats["alg_bytes"][dom])
         achieved = alg / (cls_ms[dom] * 1e-3) / 1e9 if cls_ms[dom] > 0 else 0.0
@@ -156,11 +156,11 @@ def main():
         if os.path.exists(tr):
             try:
                 j = json.load(open(tr))
-                if j.get("kernel") == roofline["kernel"] and j.get("windows") == n_w:
+                if j.get("kernel") == roofline["kernel"] and j.get("windows") == roofline["windows_per_launch"]:
                     roofline["traffic"] = j.get("hbm_bytes_per_launch")
             except Exception:
                 pass
-        poa_ms_total = float(ms[:, 6].mean())                     # whole POA call (the class kernels overlap)
+        poa_ms_total = float(ms[:, -1].mean())                    # whole POA call (the class kernels overlap)
         extra["poa_kernels_ms"] = [round(float(x), 4) for x in ms.mean(axis=0)]
         extra["gcups"] = round(stats["dp_cells"] / (poa_ms_total * 1e-3) / 1e9, 3)
         extra["windows_per_class"] = stats["n_class"]

@@ -207,6 +207,9 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through t
         }
     };
     auto dequeue = [&](uint32_t* w) -> bool {
+        // a plain look first: the waves of an empty class (most launches of the rare classes) leave without queueing up
+        // on one atomic counter
+        if (__atomic_load_n(fresh(ka)->head, __ATOMIC_RELAXED) >= count) return false;
         uint32_t idx = 0;
         if (g.lane == 0) idx = atomicAdd(fresh(ka)->head, 1u);
         idx = (uint32_t)g.shfl((int)idx, 0);
@@ -362,13 +365,17 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
         rec(2 + 2 * 1, aux[1]);
         if ((e = launch_class<PoaClass1, true>(P, Q, 1, n_windows, scratch, num_cus, 0, aux[1], caps[1])) != hipSuccess) return e;
         rec(3 + 2 * 1, aux[1]);
+        // Mop-up of re-queued windows (normally a handful): a class's mop-up pass only needs its PREDECESSOR to be finished
+        // (its own first pass works on the disjoint slot range [0, planned)), so it runs behind the predecessor on that
+        // stream and hides under the longer first passes instead of forming a serial tail.
+        if ((e = launch_class<PoaClass1, true>(P, Q, 1, 1024, scratch, num_cus, 0, aux[0], 1, true)) != hipSuccess) return e;
         (void)hipEventRecord(join_ev[0], aux[0]);
+        (void)hipStreamWaitEvent(aux[1], join_ev[0], 0);
+        if ((e = launch_class<PoaClass2, true>(P, Q, 2, 1024, scratch, num_cus, 0, aux[1], 1, true)) != hipSuccess) return e;
         (void)hipEventRecord(join_ev[1], aux[1]);
         (void)hipStreamWaitEvent(stream, join_ev[0], 0);
         (void)hipStreamWaitEvent(stream, join_ev[1], 0);
-        // mop-up of re-queued windows (normally none), then the rare classes
-        if ((e = launch_class<PoaClass1, true>(P, Q, 1, 1024, scratch, num_cus, 0, stream, 1, true)) != hipSuccess) return e;
-        if ((e = launch_class<PoaClass2, true>(P, Q, 2, 1024, scratch, num_cus, 0, stream, 1, true)) != hipSuccess) return e;
+        // then the rare classes
         rec(2 + 2 * 3, stream);
         if ((e = launch_class<PoaClass3, true>(P, Q, 3, n_windows, scratch, num_cus, 0, stream)) != hipSuccess) return e;
         rec(3 + 2 * 3, stream);
