@@ -322,6 +322,22 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
     hipLaunchKernelGGL(poa_plan_scatter_kernel, dim3((n_windows + PLAN_THREADS - 1) / PLAN_THREADS), dim3(PLAN_THREADS), 0, stream, Q, n_windows);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (prof) (void)hipEventRecord(prof->ev[1], stream);
+    // How many windows the plan put into the rare classes (3: oversized, 4: LONG, 5: catch-all) comes back to the host while
+    // the three big kernels run; their grids are then sized for it.  A grid of 2 048 single-wave workgroups costs ~0.1 ms of
+    // dispatch even if every wave leaves at once, and these classes are empty in most batches (a few escalated windows still
+    // find a small grid waiting).
+    static uint32_t* planned_host = nullptr;
+    static hipEvent_t planned_ev = nullptr;
+    if (!planned_host) {
+        if ((e = hipHostMalloc((void**)&planned_host, 8 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&planned_ev, hipEventDisableTiming)) != hipSuccess) return e;
+    }
+    if ((e = hipMemcpyAsync(planned_host, Q.planned, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    (void)hipEventRecord(planned_ev, stream);
+    auto rare_grid_hint = [&](int cls) -> uint32_t {         // windows to size the grid of a rare class for
+        const uint32_t planned = planned_host[cls];
+        return planned ? (planned + 64 < n_windows ? planned + 64 : n_windows) : 64u;
+    };
     // Every class is launched with a grid sized for the whole batch: how many windows a class receives is only
     // known on the device (plan + escalations), and an idle persistent wave exits after one failed dequeue.
     //
@@ -339,8 +355,9 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
     auto rec = [&](int idx, hipStream_t st) { if (prof) (void)hipEventRecord(prof->ev[idx], st); };
     if (sequential) {
 #define HYPO_LAUNCH(ID, CFG)                                                                              \
+        if (ID == 3 && (e = hipEventSynchronize(planned_ev)) != hipSuccess) return e;                     \
         rec(2 + 2 * ID, stream);                                                                          \
-        if ((e = launch_class<CFG, (ID < kFirstGlobalClass)>(P, Q, ID, n_windows, scratch, num_cus,      \
+        if ((e = launch_class<CFG, (ID < kFirstGlobalClass)>(P, Q, ID, ID >= 3 ? rare_grid_hint(ID) : n_windows, scratch, num_cus, \
                                                              max_global_groups(ID, n_windows), stream)) != hipSuccess) return e; \
         rec(3 + 2 * ID, stream);
         HYPO_FOR_EACH_CLASS(HYPO_LAUNCH)
@@ -375,15 +392,16 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
         (void)hipEventRecord(join_ev[1], aux[1]);
         (void)hipStreamWaitEvent(stream, join_ev[0], 0);
         (void)hipStreamWaitEvent(stream, join_ev[1], 0);
-        // then the rare classes
+        // then the rare classes (the host waits here for the plan's counts only; the big kernels are already queued)
+        if ((e = hipEventSynchronize(planned_ev)) != hipSuccess) return e;
         rec(2 + 2 * 3, stream);
-        if ((e = launch_class<PoaClass3, true>(P, Q, 3, n_windows, scratch, num_cus, 0, stream)) != hipSuccess) return e;
+        if ((e = launch_class<PoaClass3, true>(P, Q, 3, rare_grid_hint(3), scratch, num_cus, 0, stream)) != hipSuccess) return e;
         rec(3 + 2 * 3, stream);
         rec(2 + 2 * 4, stream);
-        if ((e = launch_class<PoaClass4, false>(P, Q, 4, n_windows, scratch, num_cus, max_global_groups(4, n_windows), stream)) != hipSuccess) return e;
+        if ((e = launch_class<PoaClass4, false>(P, Q, 4, rare_grid_hint(4), scratch, num_cus, max_global_groups(4, n_windows), stream)) != hipSuccess) return e;
         rec(3 + 2 * 4, stream);
         rec(2 + 2 * 5, stream);
-        if ((e = launch_class<PoaClass5, false>(P, Q, 5, n_windows, scratch, num_cus, max_global_groups(5, n_windows), stream)) != hipSuccess) return e;
+        if ((e = launch_class<PoaClass5, false>(P, Q, 5, rare_grid_hint(5), scratch, num_cus, max_global_groups(5, n_windows), stream)) != hipSuccess) return e;
         rec(3 + 2 * 5, stream);
     }
     rec(2 + 2 * kNumPoaClasses, stream);
