@@ -33,6 +33,16 @@ def main():
     st = db.stats()
     print(f"dense-SR shape: {n} windows, {b.n_arms} arms in {dt * 1e3:.2f} ms = {n / dt / 1e6:.1f} M windows/s; {st['dp_cells'] / dt / 1e9:.0f} GCUPS; "
           f"classes {st['n_class'][:6]} trivial {st['n_trivial']}")
+    if os.environ.get("HYPO_CPU", "1") == "1":
+        import oracle
+        orc = oracle.Oracle()
+        ns = min(n, 400000)
+        sub = sim.window_batch(ns, seed=9, shapes=shapes[:ns], read_sub=0.002)
+        best = None
+        for _ in range(2):
+            c0 = time.perf_counter(); orc.poa_batch_raw(sub); c1 = time.perf_counter() - c0
+            best = c1 if best is None or c1 < best else best
+        print(f"CPU restatement ({orc.num_threads()} threads): {ns} windows in {best * 1e3:.0f} ms = {ns / best / 1e6:.2f} M windows/s -> GPU/CPU = {(n / dt) / (ns / best):.1f}x")
     if lib and "prof" in lib:
         names = ["load_seq", "dp_rows", "traceback", "add_alignment", "toposort", "consensus", "output", "rowmeta"]
         ph = db.workspace[512:512 + 8 * 16 * 8].cpu().numpy().view(np.uint64).reshape(8, 16)
