@@ -22,14 +22,20 @@
 //   Graph::add_alignment            graph.cpp:154-271      lanes own sequence positions (every graph node
 //                                                          and aligned clique occurs at most once on a
 //                                                          path, so the updates are independent)
-//   Graph::topological_sort         graph.cpp:293-353      literal DFS replay, dependencies of the stack
-//                                                          top checked by lanes in parallel; skipped when
-//                                                          an alignment added no node and no edge
-//   traverse_heaviest_bundle        graph.cpp:610-705      lane 0 (once per window)
+//   Graph::topological_sort         graph.cpp:293-353      runs of ready roots (and a ready aligned clique) are
+//                                                          retired GW at a time; otherwise literal DFS replay,
+//                                                          dependencies of the stack top checked by lanes in
+//                                                          parallel; skipped when an alignment added no node
+//                                                          and no edge
+//   traverse_heaviest_bundle        graph.cpp:610-705      all lanes (pointer doubling over the chosen-pred
+//                                                          forest) when no weight tie / branch completion is
+//                                                          involved, else the literal pass on lane 0
+//   generate_consensus_long, curate src/Window.cpp:156-254 Poa::run_long (HBM-scratch classes)
 //
-// All per-window state lives in the group's memory slice `mem` (LDS for the in-LDS size classes): the
-// full score matrix is never materialised — per window the slice holds (nodes x len) direction codes,
-// a ring of score rows, the graph, and the window's packed arms staged once from HBM.
+// All per-window state lives in the group's memory slice `mem` (LDS for the in-LDS size classes, HBM scratch
+// for the last two, of which the hybrid LONG class keeps a second small slice in LDS): the full score matrix
+// is never materialised — per window the slice holds (nodes x len) direction codes, a ring of score rows,
+// the graph, and the window's packed arms staged once from HBM.
 // Compiled by hipcc for gfx950 and, with HYPO_EMU, by g++ for the lockstep emulator used in tests/.
 #pragma once
 #include <math.h>
@@ -387,16 +393,6 @@ struct Poa {
     HD int pred_row(int r, int p) const {                   // matrix row of pred p of rank r
         if (PRED_TABLE) return (int)predrows[r * KIN + p];
         return (int)n2r[inp[(int)r2n[r] * KIN + p]] + 1;
-    }
-    HD void load_ring(int slot, int S, int (&out)[CPL]) const {
-        if (CPL * g.lane < S) {
-            const Pack pk = *(const Pack*)(ring + slot * S + CPL * g.lane);
-            HYPO_UNROLL
-            for (int c = 0; c < CPL; ++c) out[c] = (int)pk.v[c];
-        } else {
-            HYPO_UNROLL
-            for (int c = 0; c < CPL; ++c) out[c] = NEG;
-        }
     }
     HD void load_ring_at(const score_t* base, int off, int S, int (&out)[CPL]) const {   // off = slot * S
         if (CPL * g.lane < S) {

@@ -1,15 +1,16 @@
 // poa_kernel.hip — gfx950 kernels and launch logic of the batched window POA.
 //
 // Execution model (MI355X: 256 CUs, 64-lane waves, 160 KiB LDS per CU):
-//   * one lane group (= one wavefront for the current classes) owns one window from its first
-//     sequence to its consensus; all of the window's state stays in that group's LDS slice, the only
-//     HBM traffic is the packed input (read once) and the consensus (written once);
+//   * one lane group (16, 32 or 64 lanes of a wavefront, by size class) owns one window from its first sequence
+//     to its consensus; the window's state stays in that group's LDS slice (HBM scratch for the two largest
+//     classes), the only algorithmic HBM traffic is the packed input (read once) and the consensus (written once);
 //   * workgroups are single waves and persistent: each pulls window indices from a per-class queue
-//     with one atomic per window (row "dequeue" of the guide's price list: ~0.3-1 us, against
-//     ~100 us of work per window), so occupancy is bounded only by LDS bytes per window;
-//   * a plan kernel bins windows into size classes (poa_classes.hpp) from their sequence lengths;
-//     a window that still overflows its class is re-queued by the kernel to the next class, which is
-//     launched afterwards on the same stream (no host round trip, no CPU fallback).
+//     with one atomic per window (~0.3-1 us, against >= 50 us of work per window), so occupancy is bounded
+//     only by LDS bytes per window;
+//   * plan kernels bin windows into size classes (poa_classes.hpp) and cost buckets; a window that still
+//     overflows its class is re-queued by the kernel to the next class (no host round trip, no CPU fallback);
+//   * the three common classes run concurrently on three streams, their mop-up passes behind them, then the
+//     rare classes with grids sized from the plan's counts (poa_run).
 // MFMA is not used: the work is integer max/+ over irregular <=128-wide rows with a serial graph
 // update between sequences (see DESIGN.md for the roofline evidence).
 #include <hip/hip_runtime.h>

@@ -12,6 +12,8 @@
  *    hypo_gpu_last_error() gives a thread-local message.
  *  - "_device" variants take DEVICE pointers inside the batch structs and run asynchronously on the
  *    given hipStream_t (passed as void*); plain variants take HOST pointers and do H2D/D2H themselves.
+ *    (hypo_gpu_poa_batch_device returns once all kernels are queued; on the way it waits for its own plan
+ *    step, ~0.1 ms of device time, to size the launches of the rare size classes.)
  *  - sequences are packed exactly like the reference's PackedSeq<NB> (src/PackedSeq.cpp:58-89):
  *    MSB-first inside a byte, 2 bases/byte for NB=4 (codes A0 C1 G2 T3 N4), 4 bases/byte for NB=2.
  *    Every sequence starts on a byte boundary of its buffer.
