@@ -185,6 +185,32 @@ def main():
             best = c1 if best is None or c1 < best else best
         cpu = {"value": round(n_w / best, 1), "unit": "windows/s", "cores": thr, "kind": "port",
                "sample": f"the same {n_w}-window batch, POA only, OpenMP schedule(static,1), best of 3"}
+        # The real reference classes (hypo::Window + its spoa, compiled from /root/reference in the build container into
+        # oracle/_ref/libhyporef.so, which travels prebuilt): the reference's own POA loop on the same batch.  When it is
+        # there it is the baseline of record (kind "reference"), the port's rate stays beside it, and the device results of
+        # the timed batch are compared with the reference's byte for byte.
+        if oracle.Ref.available():
+            try:
+                ref = oracle.Ref()
+                rbest, rout = None, None
+                for _ in range(2):
+                    rb, _, rln, rst, sec = ref.poa_batch_raw(batch, off=off, n_threads=thr)
+                    if rbest is None or sec < rbest:
+                        rbest, rout = sec, (rb, rln, rst)
+                same = bool((rout[1] == ln).all() and (rout[2] == st).all())
+                if same:
+                    o64, l64 = off[:-1].astype(np.int64), ln.astype(np.int64)
+                    idx = np.repeat(o64, l64) + (np.arange(int(l64.sum()), dtype=np.int64) - np.repeat(np.cumsum(l64) - l64, l64))
+                    same = bool((rout[0][idx] == bases[idx]).all())
+                if not same:
+                    raise SystemExit("bench: HIP results differ from the real reference — refusing to report a number")
+                extra["cpu_port"] = cpu
+                cpu = {"value": round(n_w / rbest, 1), "unit": "windows/s", "cores": thr, "kind": "reference",
+                       "sample": f"the same {n_w}-window batch through the reference's own Window::generate_consensus loop "
+                                 "(OpenMP schedule(static,1), consensus loop only, best of 2)"}
+                parity = (parity or "") + f"; timed batch bit-exact vs the real reference classes ({n_w} windows)"
+            except (OSError, RuntimeError) as ex:            # stale or unloadable prebuilt library: keep the port
+                extra["cpu_reference_error"] = str(ex)[:200]
 
     total_windows = n_w * world * args.steps
     value = total_windows / dt

@@ -177,6 +177,26 @@ class Ref:
     def replay(self, seqs, modes, scores=(5, -4, -8)):
         return _replay(self.lib.hyporef_replay, seqs, modes, scores)
 
+    def poa_batch_raw(self, b: HostBatch, scores=abi.DEFAULT_SCORES, off=None, n_threads=0):
+        """The reference's POA phase (Window::generate_consensus in its OpenMP loop, src/Hypo.cpp:236-247) on a flattened
+        batch.  Returns (bases, off, len, status, seconds of the consensus loop)."""
+        if not hasattr(self.lib, "hyporef_batch"):
+            raise RuntimeError("oracle/_ref/libhyporef.so predates hyporef_batch: rebuild it with `make -C oracle ref`")
+        if off is None:
+            off = b.slot_layout()
+        n = b.n_windows
+        bases = np.zeros(int(off[-1]) + 1, dtype=np.uint8)
+        ln = np.zeros(n, dtype=np.uint32)
+        st = np.zeros(n, dtype=np.uint8)
+        ins = batch_struct(b)
+        out = abi.ConsensusBatch(_ptr(bases), _ptr(off), _ptr(ln), _ptr(st))
+        sec = C.c_double(0.0)
+        sc = (C.c_int8 * 6)(*[int(x) for x in scores])
+        rc = self.lib.hyporef_batch(sc, C.byref(ins), C.byref(out), C.c_int(n_threads), C.byref(sec))
+        if rc != 0:
+            raise RuntimeError(f"hyporef_batch rc={rc}")
+        return bases, off, ln, st, float(sec.value)
+
     def pack_roundtrip(self, nb: int, text: str) -> str:
         out = C.create_string_buffer(len(text) + 8)
         r = self.lib.hyporef_pack_roundtrip(C.c_int(nb), text.encode(), out, C.c_int(len(text) + 8))

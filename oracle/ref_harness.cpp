@@ -4,10 +4,14 @@
 // used to validate oracle/hypo_oracle.c and to generate tests/golden/ (tests/golden/make_golden.py).
 // Nothing here restates the algorithm; it only drives the reference's own public interface
 // (include/Window.hpp:41-121, external/spoa/include/spoa/*.hpp).
+#include <omp.h>
+#include <chrono>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 #include "Window.hpp"
+#include "../include/hypo_gpu.h"
 
 using namespace hypo;
 
@@ -100,6 +104,46 @@ int hyporef_pack_roundtrip(int nb, const char* text, char* out, int out_cap) {
     if ((int)u.size() > out_cap) return -1;
     std::memcpy(out, u.data(), u.size());
     return (int)u.size();
+}
+
+// The reference's POA phase (src/Hypo.cpp:236-247) on a flattened batch.  Real hypo::Window objects are built from the packed
+// batch first (not timed); then the reference's own loop shape runs: Window::prepare_for_poa(sp, threads) and
+// `#pragma omp parallel for schedule(static,1)` over windows calling generate_consensus(omp_get_thread_num()).
+// *seconds_out = wall time of that loop.  Used for parity at full batch size and as the CPU baseline of kind "reference".
+int hyporef_batch(const int8_t sc[6], const HypoWindowBatch* in, HypoConsensusBatch* out, int n_threads, double* seconds_out) {
+    static const char kB4[] = "ACGTN", kB2[] = "ACGT";
+    auto text4 = [&](const uint8_t* p, uint32_t n) { std::string t(n, 'N'); for (uint32_t i = 0; i < n; ++i) { unsigned c = (p[i >> 1] >> (4 - 4 * (i & 1))) & 15; t[i] = kB4[c < 4 ? c : 4]; } return t; };
+    auto text2 = [&](const uint8_t* p, uint32_t n) { std::string t(n, 'A'); for (uint32_t i = 0; i < n; ++i) t[i] = kB2[(p[i >> 2] >> (6 - 2 * (i & 3))) & 3]; return t; };
+    if (n_threads < 1) n_threads = omp_get_max_threads();
+    const uint32_t n = in->n_windows;
+    std::vector<std::unique_ptr<Window>> ws(n);
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+    for (int64_t w = 0; w < (int64_t)n; ++w) {
+        const HypoWindow& W = in->windows[w];
+        PackedSeq<4> pd(text4(in->draft4 + W.draft_off, W.draft_len));
+        ws[w].reset(new Window(pd, 0, W.draft_len, W.type == HYPO_WIN_SHORT ? WindowType::SHORT : WindowType::LONG));
+        uint32_t a = W.first_arm;
+        for (uint32_t i = 0; i < W.n_internal; ++i, ++a) ws[w]->add_internal(PackedSeq<2>(text2(in->arms2 + in->arm_off[a], in->arm_len[a])));
+        for (uint32_t i = 0; i < W.n_prefix; ++i, ++a) ws[w]->add_prefix(PackedSeq<2>(text2(in->arms2 + in->arm_off[a], in->arm_len[a])));
+        for (uint32_t i = 0; i < W.n_suffix; ++i, ++a) ws[w]->add_suffix(PackedSeq<2>(text2(in->arms2 + in->arm_off[a], in->arm_len[a])));
+        for (uint32_t i = 0; i < W.n_empty; ++i) ws[w]->add_empty();
+    }
+    ScoreParams sp{sc[0], sc[1], sc[2], sc[3], sc[4], sc[5]};
+    const int base = g_engines;
+    Window::prepare_for_poa(sp, (UINT32)n_threads);
+    g_engines += n_threads;
+    const auto t0 = std::chrono::steady_clock::now();
+#pragma omp parallel for schedule(static, 1) num_threads(n_threads)
+    for (int64_t w = 0; w < (int64_t)n; ++w) ws[w]->generate_consensus((UINT32)(base + omp_get_thread_num()));
+    if (seconds_out) *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (uint32_t w = 0; w < n; ++w) {
+        const std::string c = ws[w]->get_consensus();
+        const uint64_t cap = out->off[w + 1] - out->off[w];
+        out->len[w] = (uint32_t)c.size();
+        out->status[w] = c.size() > cap ? HYPO_ST_CONS_OVERFLOW : HYPO_ST_OK;
+        if (c.size() <= cap) std::memcpy(out->bases + out->off[w], c.data(), c.size());
+    }
+    return 0;
 }
 
 }  // extern "C"
