@@ -62,6 +62,26 @@ def test_c3_sized_batch_replica_property(gpu, oracle_lib):
     assert not bad, f"{len(bad)} of {big.n_windows} windows differ, first {bad[:3]}"
 
 
+def test_c2_full_batch_and_long_windows_vs_real_reference(gpu, ref_lib):
+    """The prebuilt real reference classes (oracle/_ref, built where /root/reference exists) travel to the GPU box: the
+    full C2 batch and a batch of LONG windows are compared with hypo::Window::generate_consensus itself."""
+    if not hasattr(ref_lib.lib, "hyporef_batch"):
+        pytest.skip("oracle/_ref/libhyporef.so predates hyporef_batch")
+    import golden_util as gu
+    from hypo_amd.batch import build_batch
+    longs = [gu.to_window(r) for r in gu.load_jsonl("windows_real_long.jsonl.gz") if r["long"]]
+    for b in (sim.window_batch(97078, seed=77), build_batch(longs * 4)):
+        off = b.slot_layout()
+        db = gpu.device_batch(b, off=off)
+        db.run()
+        bases, _, ln, st = db.results()
+        rb, _, rln, rst, _ = ref_lib.poa_batch_raw(b, off=off)
+        assert (st == rst).all() and (ln == rln).all()
+        l64 = ln.astype(np.int64)
+        idx = np.repeat(off[:-1].astype(np.int64), l64) + (np.arange(int(l64.sum()), dtype=np.int64) - np.repeat(np.cumsum(l64) - l64, l64))
+        assert (bases[idx] == rb[idx]).all()
+
+
 def test_dense_sr_shape_vs_oracle(gpu, oracle_lib):
     """The dense-SR shape of C4/C5: tiny windows (45 % <= 8 bp), ~22 arms of ~12 bases."""
     rng = np.random.default_rng(3)
