@@ -17,7 +17,7 @@ ROOT = os.path.dirname(HERE)
 GOLD = os.path.join(HERE, "golden")
 BIN = os.path.join(ROOT, "hypo_amd", "_build", "hypo")
 SHIM_DIR = os.path.join(HERE, "_build", "shim")
-CASES = ["e2e_20k_s1", "e2e_200k_long_s3", "e2e_200k_k9_s5", "e2e_100k_k7_s7", "e2e_5ctg_long_s21"]
+CASES = ["e2e_20k_s1", "e2e_200k_long_s3", "e2e_200k_k9_s5", "e2e_100k_k7_s7", "e2e_5ctg_long_s21", "e2e_messy_s102", "e2e_messy_s103"]
 
 
 def _md5(p):
@@ -41,7 +41,9 @@ def make_inputs(name, outdir):
     gen = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(gen)
     a = man["args"]
-    if a.get("contigs", 1) > 1:
+    if "messy" in a:
+        gen.generate_messy(str(outdir), a["messy"])
+    elif a.get("contigs", 1) > 1:
         gen.generate_multi(str(outdir), a["seed"], a["G"], a["long"], a["k"], a["contigs"])
     else:
         gen.generate(str(outdir), a["seed"], a["G"], a["long"], a["k"])

@@ -212,6 +212,93 @@ def generate_multi(outdir, seed, G, with_long, K, n_contigs):
     return tuple(total)
 
 
+def generate_messy(outdir, seed):
+    """A small set with everything the clean sets lack: N and lower-case stretches in the draft, soft and hard clips,
+    `=`/`X` CIGAR operators, unmapped / secondary / duplicate / QC-fail / reverse-strand flags, low mapping qualities,
+    N and lower-case bases in reads, long reads without an NM tag, 1-3 contigs, with or without long reads, and
+    non-default -p / -q / -m -x -g / -n options.  Returns the command-line arguments (after the program name) that go
+    with the set.  Used by tests/golden/fuzz_e2e.py (differential fuzz against the real reference binary) and by the
+    committed `e2e_messy_*` goldens."""
+    rnd = random.Random(seed * 7919 + 13)
+    nc = rnd.choice([1, 2, 3])
+    G = rnd.choice([6000, 15000, 30000])
+    with_long = rnd.random() < 0.5
+    K = rnd.choice([7, 9, 11])
+    if nc > 1:
+        generate_multi(outdir, seed, G, with_long, K, nc)
+    else:
+        generate(outdir, seed, G, with_long, K)
+    lines = open(os.path.join(outdir, "draft.fa")).read().split("\n")
+    out = []
+    for l in lines:
+        if l.startswith(">") or not l:
+            out.append(l)
+            continue
+        s = list(l)
+        for _ in range(max(1, len(s) // 3000)):
+            s[rnd.randrange(len(s))] = "N"
+        if rnd.random() < 0.5:
+            a = rnd.randrange(len(s))
+            b = min(len(s), a + rnd.randrange(1, 200))
+            s[a:b] = [c.lower() for c in s[a:b]]
+        out.append("".join(s))
+    open(os.path.join(outdir, "draft.fa"), "w").write("\n".join(out))
+    for name in ["sr.sam"] + (["lr.sam"] if with_long else []):
+        p = os.path.join(outdir, name)
+        res = []
+        for line in open(p):
+            if line.startswith("@"):
+                res.append(line)
+                continue
+            f = line.rstrip("\n").split("\t")
+            r = rnd.random()
+            cig, seq = f[5], f[9]
+            if r < 0.08:
+                a, b = rnd.randrange(0, 12), rnd.randrange(0, 12)
+                seq = "".join(rnd.choice(A) for _ in range(a)) + seq + "".join(rnd.choice(A) for _ in range(b))
+                cig = (f"{a}S" if a else "") + cig + (f"{b}S" if b else "")
+            elif r < 0.12:
+                cig = f"{rnd.randrange(1, 30)}H" + cig + f"{rnd.randrange(1, 30)}H"
+            elif r < 0.16:
+                cig = cig.replace("M", "=") if rnd.random() < 0.5 else cig.replace("M", "X")
+            r = rnd.random()
+            if r < 0.03:
+                f[1] = str(int(f[1]) | 4)
+            elif r < 0.06:
+                f[1] = str(int(f[1]) | 256)
+            elif r < 0.08:
+                f[1] = str(int(f[1]) | 1024)
+            elif r < 0.10:
+                f[1] = str(int(f[1]) | 512)
+            elif r < 0.3:
+                f[1] = str(int(f[1]) | 16)
+            if rnd.random() < 0.1:
+                f[4] = str(rnd.choice([0, 1, 2, 3, 10]))
+            if rnd.random() < 0.02:
+                s = list(seq)
+                s[rnd.randrange(len(s))] = "N"
+                seq = "".join(s)
+            if rnd.random() < 0.02:
+                seq = seq.lower()
+            if name == "lr.sam" and rnd.random() < 0.05:
+                f = f[:11]
+            f[5], f[9] = cig, seq
+            res.append("\t".join(f) + "\n")
+        open(p, "w").write("".join(res))
+    size = {7: "10k", 9: "100k", 11: "1m"}[K]
+    extra = []
+    if rnd.random() < 0.4:
+        extra += ["-p", str(rnd.choice([1, 2]))]
+    if rnd.random() < 0.3:
+        extra += ["-q", str(rnd.choice([0, 5, 20]))]
+    if rnd.random() < 0.3:
+        extra += ["-m", "3", "-x", "-6", "-g", "-5"]
+    if with_long and rnd.random() < 0.3:
+        extra += ["-n", str(rnd.choice([5, 12, 40]))]
+    return (["-d", "draft.fa", "-r", "reads.fa", "-s", size, "-c", "30", "-b", "sr.sam"] + (["-B", "lr.sam"] if with_long else []) +
+            ["-t", "1", "-i"] + extra), nc, with_long
+
+
 if __name__ == "__main__":
     out, seed, G = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     k = int(sys.argv[sys.argv.index("--k") + 1]) if "--k" in sys.argv else 11

@@ -41,7 +41,34 @@ def regions(path):
     return out
 
 
+def main_messy():
+    """make_e2e_golden.py --messy <name> <run dir> <polished fasta> <seed>: golden of one gen_e2e.generate_messy set."""
+    import tempfile
+    sys.path.insert(0, HERE)
+    import gen_e2e
+    name, d, outfa, seed = sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5])
+    with tempfile.TemporaryDirectory() as tmp:
+        cmd, nc, is_long = gen_e2e.generate_messy(tmp, seed)
+        ins = ["draft.fa", "sr.sam", "aux/solid_kmers.bvsd"] + (["lr.sam"] if is_long else [])
+        for f in ins:
+            assert md5(os.path.join(tmp, f)) == md5(os.path.join(d, f)), f"{f}: run dir does not hold generate_messy({seed})"
+    man = {"generator": "tests/golden/gen_e2e.py", "args": {"messy": seed, "contigs": nc, "long": is_long},
+           "command": "hypo " + " ".join(cmd), "inputs_md5": {f: md5(os.path.join(d, f)) for f in ins},
+           "expected_fasta_md5": md5(os.path.join(d, outfa))}
+    json.dump(man, open(os.path.join(HERE, name + ".manifest.json"), "w"), indent=1)
+    with gzip.GzipFile(os.path.join(HERE, name + ".expected.fa.gz"), "wb", mtime=0) as f:
+        f.write(open(os.path.join(d, outfa), "rb").read())
+    reg = []
+    for c in range(nc):
+        reg += regions(os.path.join(d, "aux", f"inspect_ctg{c + 1}.txt"))
+    with gzip.GzipFile(os.path.join(HERE, name + ".regions.json.gz"), "wb", mtime=0) as f:
+        f.write(json.dumps(reg, separators=(",", ":")).encode())
+    print(name, len(reg), "regions")
+
+
 def main():
+    if sys.argv[1] == "--messy":
+        return main_messy()
     name, d, outfa, seed, G, k, size = sys.argv[1:8]
     is_long = "--long" in sys.argv
     nc = int(sys.argv[sys.argv.index("--contigs") + 1]) if "--contigs" in sys.argv else 1
