@@ -24,7 +24,7 @@ def _reg2bin(beg, end):
     return 0
 
 
-def sam_to_bam(sam_path, bam_path, nm_type="i"):
+def sam_to_bam(sam_path, bam_path, nm_type="i", extra_tags=False):
     text, refs, recs = [], [], []
     for line in open(sam_path):
         if line.startswith("@"):
@@ -55,6 +55,10 @@ def sam_to_bam(sam_path, bam_path, nm_type="i"):
         for i, c in enumerate(seq):
             seqb[i >> 1] |= _NT16.get(c, 15) << (4 if i % 2 == 0 else 0)
         tags = b""
+        if extra_tags:                                            # one of every value type in front of NM: the reader must step over them
+            tags += b"XAAx" + b"XZZsome text\x00" + b"XHH1AE301\x00" + b"Xff" + struct.pack("<f", 1.5) + b"Xcc" + struct.pack("<b", -3)
+            tags += b"XBBs" + struct.pack("<i", 3) + struct.pack("<3h", 1, -2, 3) + b"XCBC" + struct.pack("<i", 2) + b"\x01\x02"
+            tags += b"XIBI" + struct.pack("<i", 1) + struct.pack("<I", 7) + b"XSS" + struct.pack("<H", 65535) + b"Xii" + struct.pack("<i", -9)
         for t in f[11:]:
             if t.startswith("NM:i:"):
                 v = int(t[5:])

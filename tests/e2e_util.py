@@ -62,7 +62,7 @@ def run_case(name, outdir, device, threads=4, extra_env=None, as_bam=False):
             if flag in argv:
                 i = argv.index(flag) + 1
                 bam = os.path.splitext(argv[i])[0] + ".bam"
-                bam_util.sam_to_bam(os.path.join(str(outdir), argv[i]), os.path.join(str(outdir), bam), nm_type=nm)
+                bam_util.sam_to_bam(os.path.join(str(outdir), argv[i]), os.path.join(str(outdir), bam), nm_type=nm, extra_tags=True)
                 os.remove(os.path.join(str(outdir), argv[i]))
                 argv[i] = bam
     argv[argv.index("-t") + 1] = str(threads)
