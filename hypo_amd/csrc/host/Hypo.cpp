@@ -191,68 +191,70 @@ void Hypo::polish() {
 }
 
 // src/Hypo.cpp:278-329: stream the (coordinate-sorted) file, stop when a record of the next batch shows up.
-// Lines are read serially (zlib) in blocks; record parsing and the Alignment constructors (CIGAR walk, 2-bit packing)
-// of a block run on all threads; a serial pass then files the alignments in record order, so every contig's store
-// is in file order exactly as the reference builds it.
+// A reader thread inflates the file and cuts it into blocks of raw records (SeqIO.hpp); while it fetches the next block,
+// record parsing and the Alignment constructors (CIGAR walk, 2-bit packing) of the current block run on all threads; a serial
+// pass then files the alignments in record order, so every contig's store is in file order exactly as the reference builds it.
 void Hypo::create_alignments(bool is_sr, uint32_t batch_id) {
     const uint32_t mq = _cFlags.map_qual_th;
     SamReader& sf = is_sr ? *_sf_short : *_sf_long;
-    std::vector<std::string>& carry = is_sr ? _carry_short : _carry_long;
+    RecordStream& rs = is_sr ? _rs_short : _rs_long;
     const uint32_t final_cid = batch_id * _contig_batch_size + _contig_batch_size;
     uint64_t num_invalid = 0, num_alns = 0;
-    constexpr size_t kBlock = 1 << 16;
+    constexpr size_t kBlock = 1 << 17;
     struct Slot { std::unique_ptr<Alignment> aln; int32_t cid; bool skip, bad_ref; };
-    std::vector<std::string> lines, ahead;                  // current block; block a reader thread fetches meanwhile
     std::vector<Slot> slots;
-    bool more = true, stop = false, have_ahead = false, more_ahead = true;
-    double t_read = 0, t_par = 0; auto now = []{ return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    bool stop = false, more_ahead = true;
+    double t_wait = 0, t_par = 0; auto now = []{ return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     while (!stop) {
-        double t0 = now();
-        lines.clear();
-        if (!carry.empty()) lines.swap(carry);
-        else if (have_ahead) { lines.swap(ahead); have_ahead = false; }
-        else if (more) more = sf.read_lines(lines, kBlock);
-        if (lines.empty()) break;
-        std::thread reader;                                  // inflate + line splitting of the next block overlap the parsing of this one
-        if (more && !have_ahead) { ahead.clear(); reader = std::thread([&] { more_ahead = sf.read_lines(ahead, kBlock); }); }
-        slots.clear(); slots.resize(lines.size());
-        double t1 = now(); t_read += t1 - t0;
-#pragma omp parallel for schedule(dynamic, 256)
-        for (int64_t i = 0; i < (int64_t)lines.size(); ++i) {
-            Slot& sl = slots[(size_t)i];
-            sl.skip = false; sl.bad_ref = false; sl.cid = -1;
-            SamRecord rec;
-            sf.parse(lines[(size_t)i], rec);
-            if ((rec.flag & (SAM_FUNMAP | SAM_FSECONDARY | SAM_FQCFAIL | SAM_FDUP)) || rec.mapq < mq) { sl.skip = true; continue; }
-            auto it = rec.tid < 0 ? _cname_to_id.end() : _cname_to_id.find(sf.tid2name(rec.tid));
-            if (it == _cname_to_id.end()) { sl.bad_ref = true; continue; }
-            sl.cid = (int32_t)it->second;
-            if (is_sr) sl.aln.reset(new Alignment(*_contigs[it->second], rec));
-            else sl.aln.reset(new Alignment(*_contigs[it->second], _cFlags.norm_edit_th, rec));
+        const double t0 = now();
+        if (rs.pos >= rs.cur.n()) {                          // current block used up: take the prefetched one or read one
+            if (rs.have_ahead) { std::swap(rs.cur, rs.ahead); rs.have_ahead = false; }
+            else if (rs.more) rs.more = sf.read_block(rs.cur, kBlock);
+            else break;
+            rs.pos = 0;
+            if (rs.cur.n() == 0) { if (!rs.more) break; continue; }
         }
-        double t2 = now(); t_par += t2 - t1;
-        for (size_t i = 0; i < slots.size(); ++i) {
+        std::thread reader;                                  // inflate + record splitting of the next block overlap the parsing of this one
+        if (rs.more && !rs.have_ahead) reader = std::thread([&] { more_ahead = sf.read_block(rs.ahead, kBlock); });
+        const size_t first = rs.pos, count = rs.cur.n() - first;
+        slots.clear(); slots.resize(count);
+        const double t1 = now(); t_wait += t1 - t0;
+#pragma omp parallel
+        {
+            SamRecord rec;                                   // one per thread: its strings and CIGAR vector are reused
+#pragma omp for schedule(dynamic, 256)
+            for (int64_t i = 0; i < (int64_t)count; ++i) {
+                Slot& sl = slots[(size_t)i];
+                sl.skip = false; sl.bad_ref = false; sl.cid = -1;
+                sf.parse(rs.cur.rec(first + (size_t)i), rs.cur.len(first + (size_t)i), rec);
+                if ((rec.flag & (SAM_FUNMAP | SAM_FSECONDARY | SAM_FQCFAIL | SAM_FDUP)) || rec.mapq < mq) { sl.skip = true; continue; }
+                auto it = rec.tid < 0 ? _cname_to_id.end() : _cname_to_id.find(sf.tid2name(rec.tid));
+                if (it == _cname_to_id.end()) { sl.bad_ref = true; continue; }
+                sl.cid = (int32_t)it->second;
+                if (is_sr) sl.aln.reset(new Alignment(*_contigs[it->second], rec));
+                else sl.aln.reset(new Alignment(*_contigs[it->second], _cFlags.norm_edit_th, rec));
+            }
+        }
+        t_par += now() - t1;
+        rs.pos = rs.cur.n();
+        for (size_t i = 0; i < count; ++i) {
             Slot& sl = slots[i];
             if (sl.skip) continue;
             if (sl.bad_ref) {
                 std::fprintf(stderr, "[Hypo::Hypo] Error: Alignment File error: Contig-reference of record %s does not exist in the draft!\n",
-                             sf.record_name(lines[i]).c_str());
+                             sf.record_name(rs.cur.rec(first + i), rs.cur.len(first + i)).c_str());
                 std::exit(1);
             }
             if (sl.aln->is_valid) { _alignment_store[(size_t)sl.cid].emplace_back(std::move(sl.aln)); ++num_alns; } else ++num_invalid;
-            if ((uint32_t)sl.cid >= final_cid) {            // first record of the next batch has been consumed (as in the reference)
-                carry.assign(std::make_move_iterator(lines.begin() + (long)i + 1), std::make_move_iterator(lines.end()));
+            if ((uint32_t)sl.cid >= final_cid) {            // first record of the next batch has been consumed (as in the reference);
+                rs.pos = first + i + 1;                     // the rest of the block waits for that batch
                 stop = true;
                 break;
             }
         }
-        if (reader.joinable()) { reader.join(); more = more_ahead; have_ahead = !ahead.empty(); }
-        if (stop && have_ahead) {                            // the prefetched block belongs to the next contig batch as well
-            carry.insert(carry.end(), std::make_move_iterator(ahead.begin()), std::make_move_iterator(ahead.end()));
-            ahead.clear(); have_ahead = false;
-        }
+        if (reader.joinable()) { reader.join(); rs.more = more_ahead; rs.have_ahead = rs.ahead.n() > 0; }
     }
-    if (std::getenv("HYPO_HOST_TIMING")) std::fprintf(stderr, "[timing] create_alignments: read %.3f parse+construct %.3f (file pass included)\n", t_read, t_par);
+    if (std::getenv("HYPO_HOST_TIMING")) std::fprintf(stderr, "[timing] create_alignments: waiting for records %.3f s, parse + construct %.3f s\n", t_wait, t_par);
     std::fprintf(stdout, "[Hypo::Hypo] Info: Number of alignments (Batch %u): loaded (%lu) invalid (%lu)\n", batch_id,
                  (unsigned long)num_alns, (unsigned long)num_invalid);
 }

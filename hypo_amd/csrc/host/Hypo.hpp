@@ -32,7 +32,10 @@ private:
     std::vector<std::vector<std::unique_ptr<Alignment>>> _alignment_store;
     uint32_t _contig_batch_size = 0;
     std::unique_ptr<SamReader> _sf_short, _sf_long;
-    std::vector<std::string> _carry_short, _carry_long;   // lines read past the end of a contig batch
+    // per alignment file: the block of raw records being consumed (a contig batch may end in the middle of it), the block a
+    // reader thread fetched meanwhile, and whether the file has more
+    struct RecordStream { SamReader::RecordBlock cur, ahead; size_t pos = 0; bool have_ahead = false, more = true; };
+    RecordStream _rs_short, _rs_long;
     PhaseTimes _times;
     std::string _region_dump;
     std::chrono::steady_clock::time_point _t0, _tstart;

@@ -46,6 +46,30 @@ public:
             _pos = _end;
         }
     }
+    // next line appended to dst WITHOUT its line end (so that a block of records can live in one buffer); false at end of file
+    bool append_line(std::vector<char>& dst) {
+        if (!_fp) return false;
+        bool any = false;
+        for (;;) {
+            if (_pos == _end) {
+                if (_eof) return any;
+                const int n = gzread(_fp, _buf.data(), (unsigned)kBuf);
+                if (n <= 0) { _eof = true; return any; }
+                _pos = 0; _end = (size_t)n;
+            }
+            const char* b = _buf.data() + _pos;
+            const char* nl = (const char*)std::memchr(b, '\n', _end - _pos);
+            any = true;
+            if (nl) {
+                dst.insert(dst.end(), b, nl);
+                _pos += (size_t)(nl - b) + 1;
+                if (!dst.empty() && dst.back() == '\r') dst.pop_back();
+                return true;
+            }
+            dst.insert(dst.end(), b, b + (_end - _pos));
+            _pos = _end;
+        }
+    }
     // exactly n raw bytes of the (inflated) stream; false at end of file
     bool read_bytes(void* dst, size_t n) {
         char* d = (char*)dst;
@@ -140,52 +164,56 @@ public:
     }
     bool ok() const { return _lr.ok(); }
     const std::string& tid2name(int32_t tid) const { return _names[(size_t)tid]; }
-    bool next(SamRecord& r) {
-        std::string line;
-        if (!next_line(line)) return false;
-        parse(line, r);
-        return true;
-    }
-    // next non-empty alignment line (I/O and inflate are serial; parsing is not, see parse())
-    bool next_line(std::string& line) {
-        if (_bam) {                                   // one BAM alignment block (without its 4-byte size) as an opaque "line"
-            int32_t bs = 0;
-            if (!_bam_ok || !_lr.read_bytes(&bs, 4) || bs < 32) return false;
-            line.resize((size_t)bs);
-            if (!_lr.read_bytes(&line[0], (size_t)bs)) { std::fprintf(stderr, "[Hypo::SamReader] Error: truncated BAM record\n"); std::exit(1); }
-            return true;
+    // A block of raw records in one buffer: record i = bytes [off[i], off[i + 1] - 1), followed by a NUL.  SAM: the text of
+    // one alignment line; BAM: one alignment block without its 4-byte size.  I/O and inflate are serial (one reader thread),
+    // parse() is const and re-entrant: Hypo::create_alignments parses the records of a block on all threads.
+    struct RecordBlock {
+        std::vector<char> buf;
+        std::vector<uint64_t> off;
+        size_t n() const { return off.empty() ? 0 : off.size() - 1; }
+        const char* rec(size_t i) const { return buf.data() + off[i]; }
+        size_t len(size_t i) const { return (size_t)(off[i + 1] - off[i] - 1); }
+        void clear() { buf.clear(); off.clear(); }
+    };
+    // fills b with up to max_records records (or ~max_bytes); false once the end of the file has been reached
+    bool read_block(RecordBlock& b, size_t max_records, size_t max_bytes = 32u << 20) {
+        b.clear();
+        b.off.push_back(0);
+        while (b.n() < max_records && b.buf.size() < max_bytes) {
+            const size_t start = b.buf.size();
+            if (_bam) {
+                int32_t bs = 0;
+                if (!_bam_ok || !_lr.read_bytes(&bs, 4) || bs < 32) return false;
+                b.buf.resize(start + (size_t)bs);
+                if (!_lr.read_bytes(b.buf.data() + start, (size_t)bs)) { std::fprintf(stderr, "[Hypo::SamReader] Error: truncated BAM record\n"); std::exit(1); }
+            } else if (_have_pending) {
+                b.buf.insert(b.buf.end(), _pending.begin(), _pending.end());
+                _have_pending = false;
+            } else if (!_lr.append_line(b.buf)) {
+                return false;
+            }
+            if (b.buf.size() == start) continue;                       // empty line
+            b.buf.push_back('\0');
+            b.off.push_back(b.buf.size());
         }
-        if (_have_pending) { line.swap(_pending); _have_pending = false; }
-        else if (!_lr.next(line)) return false;
-        while (line.empty()) if (!_lr.next(line)) return false;
         return true;
     }
-    // up to `max` lines appended to `out`; false at end of file
-    bool read_lines(std::vector<std::string>& out, size_t max) {
-        std::string line;
-        for (size_t i = 0; i < max; ++i) {
-            if (!next_line(line)) return false;
-            out.emplace_back(std::move(line));
-            line.clear();
-        }
-        return true;
-    }
-    // one alignment line -> record; const and re-entrant (Hypo::create_alignments parses blocks of lines in parallel)
-    void parse(const std::string& line, SamRecord& r) const {
-        if (_bam) { parse_bam(line, r); return; }
+    // one raw record (NUL-terminated, n bytes) -> fields
+    void parse(const char* line, size_t n, SamRecord& r) const {
+        if (_bam) { parse_bam(line, n, r); return; }
         size_t f[12]; int nf = 0; f[0] = 0;
-        for (size_t i = 0; i < line.size() && nf < 11; ++i) if (line[i] == '\t') f[++nf] = i + 1;
-        if (nf < 10) { std::fprintf(stderr, "[Hypo::SamReader] Error: malformed SAM record: %s\n", line.substr(0, 60).c_str()); std::exit(1); }
-        auto field = [&](int k) { const size_t b = f[k], e = (k < nf ? f[k + 1] - 1 : line.size()); return line.substr(b, e - b); };
-        r.qname = field(0);
-        r.flag = (uint32_t)std::strtoul(line.c_str() + f[1], nullptr, 10);
-        const std::string rname = field(2);
-        auto it = _tid.find(rname);
+        for (size_t i = 0; i < n && nf < 11; ++i) if (line[i] == '\t') f[++nf] = i + 1;
+        if (nf < 10) { std::fprintf(stderr, "[Hypo::SamReader] Error: malformed SAM record: %.60s\n", line); std::exit(1); }
+        auto fbeg = [&](int k) { return line + f[k]; };
+        auto flen = [&](int k) { return (k < nf ? f[k + 1] - 1 : n) - f[k]; };
+        r.qname.assign(fbeg(0), flen(0));
+        r.flag = (uint32_t)std::strtoul(fbeg(1), nullptr, 10);
+        auto it = _tid.find(std::string(fbeg(2), flen(2)));
         r.tid = it == _tid.end() ? -1 : it->second;
-        r.pos = (uint32_t)(std::strtoul(line.c_str() + f[3], nullptr, 10) - 1);
-        r.mapq = (uint32_t)std::strtoul(line.c_str() + f[4], nullptr, 10);
+        r.pos = (uint32_t)(std::strtoul(fbeg(3), nullptr, 10) - 1);
+        r.mapq = (uint32_t)std::strtoul(fbeg(4), nullptr, 10);
         r.cigar.clear();
-        const char* c = line.c_str() + f[5];
+        const char* c = fbeg(5);
         if (*c != '*') {
             while (*c && *c != '\t') {
                 char* e;
@@ -197,17 +225,18 @@ public:
                 c = e + 1;
             }
         }
-        r.seq = field(9);
+        r.seq.assign(fbeg(9), flen(9));
         r.has_nm = false;
         if (nf >= 11) {
-            const size_t p = line.find("\tNM:i:", f[10] - 1);
-            if (p != std::string::npos) { r.has_nm = true; r.nm = std::strtoll(line.c_str() + p + 6, nullptr, 10); }
+            const char* p = std::strstr(line + f[10] - 1, "\tNM:i:");
+            if (p) { r.has_nm = true; r.nm = std::strtoll(p + 6, nullptr, 10); }
         }
     }
-    // read name of a raw record as handed out by next_line() (for messages)
-    std::string record_name(const std::string& line) const {
-        if (_bam) return line.size() > 32 ? std::string(line.c_str() + 32) : std::string("?");
-        return line.substr(0, line.find('\t'));
+    // read name of a raw record (for messages)
+    std::string record_name(const char* line, size_t n) const {
+        if (_bam) return n > 32 ? std::string(line + 32) : std::string("?");
+        const char* t = (const char*)std::memchr(line, '\t', n);
+        return std::string(line, t ? (size_t)(t - line) : n);
     }
 private:
     static int32_t le32(const char* p) { int32_t v; std::memcpy(&v, p, 4); return v; }
@@ -229,9 +258,7 @@ private:
         }
         if (!_bam_ok) { std::fprintf(stderr, "[Hypo::SamReader] Error: malformed BAM header\n"); std::exit(1); }
     }
-    void parse_bam(const std::string& b, SamRecord& r) const {      // SAM spec 4.2.1; fields after block_size
-        const char* p = b.data();
-        const size_t n = b.size();
+    void parse_bam(const char* p, size_t n, SamRecord& r) const {   // SAM spec 4.2.1; fields after block_size
         const int32_t ref = le32(p), pos = le32(p + 4), l_seq = le32(p + 16);
         const unsigned l_name = (unsigned char)p[8], mapq = (unsigned char)p[9];
         const unsigned n_cig = le16(p + 12), flag = le16(p + 14);
