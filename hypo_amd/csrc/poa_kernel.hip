@@ -347,8 +347,8 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
     // issue, so sharing the CUs fills issue slots either would leave idle (measured: ~11 % per step).  Each gets a
     // share of a CU's LDS through a waves-per-CU cap.  A window re-queued by a class that ran next to its successor
     // is picked up by a small mop-up launch afterwards; the rare classes 3 and 4 follow on the caller's stream.
-    static hipStream_t aux[2] = {nullptr, nullptr};
-    static hipEvent_t fork_ev = nullptr, join_ev[2] = {nullptr, nullptr};
+    static hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+    static hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
     int caps[kNumPoaClasses] = {3, 3, 6, 0, 0};
     if (const char* cs = getenv("HYPO_POA_CAPS")) sscanf(cs, "%d,%d,%d,%d,%d", &caps[0], &caps[1], &caps[2], &caps[3], &caps[4]);
     const char* seq_env = getenv("HYPO_POA_SEQUENTIAL");
@@ -365,7 +365,7 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
 #undef HYPO_LAUNCH
     } else {
         if (!aux[0]) {
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < 3; ++i) {
                 if ((e = hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking)) != hipSuccess) return e;
                 if ((e = hipEventCreateWithFlags(&join_ev[i], hipEventDisableTiming)) != hipSuccess) return e;
             }
@@ -374,6 +374,7 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
         (void)hipEventRecord(fork_ev, stream);
         (void)hipStreamWaitEvent(aux[0], fork_ev, 0);
         (void)hipStreamWaitEvent(aux[1], fork_ev, 0);
+        (void)hipStreamWaitEvent(aux[2], fork_ev, 0);
         rec(2 + 2 * 2, stream);
         if ((e = launch_class<PoaClass2, true>(P, Q, 2, n_windows, scratch, num_cus, 0, stream, caps[2])) != hipSuccess) return e;
         rec(3 + 2 * 2, stream);
@@ -393,14 +394,29 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
         (void)hipEventRecord(join_ev[1], aux[1]);
         (void)hipStreamWaitEvent(stream, join_ev[0], 0);
         (void)hipStreamWaitEvent(stream, join_ev[1], 0);
-        // then the rare classes (the host waits here for the plan's counts only; the big kernels are already queued)
+        // then the rare classes (the host waits here for the plan's counts only; the big kernels are already queued).
+        // LONG windows are planned straight into class 4, so its first pass does not have to wait for anybody: it runs on a
+        // third stream next to the short-window kernels (a LONG window occupies one wave for ~0.1 s; its latency is the floor of
+        // the whole call), and only the few windows escalated into class 4 later wait for the mop-up pass at the end.
         if ((e = hipEventSynchronize(planned_ev)) != hipSuccess) return e;
+        const bool long_first_pass = planned_host[4] > 0;
+        if (long_first_pass) {
+            rec(2 + 2 * 4, aux[2]);
+            if ((e = launch_class<PoaClass4, false>(P, Q, 4, rare_grid_hint(4), scratch, num_cus, max_global_groups(4, n_windows), aux[2], 8)) != hipSuccess) return e;
+            rec(3 + 2 * 4, aux[2]);
+            (void)hipEventRecord(join_ev[2], aux[2]);
+        }
         rec(2 + 2 * 3, stream);
         if ((e = launch_class<PoaClass3, true>(P, Q, 3, rare_grid_hint(3), scratch, num_cus, 0, stream)) != hipSuccess) return e;
         rec(3 + 2 * 3, stream);
-        rec(2 + 2 * 4, stream);
-        if ((e = launch_class<PoaClass4, false>(P, Q, 4, rare_grid_hint(4), scratch, num_cus, max_global_groups(4, n_windows), stream)) != hipSuccess) return e;
-        rec(3 + 2 * 4, stream);
+        if (long_first_pass) {
+            (void)hipStreamWaitEvent(stream, join_ev[2], 0);
+            if ((e = launch_class<PoaClass4, false>(P, Q, 4, 64, scratch, num_cus, max_global_groups(4, n_windows), stream, 1, true)) != hipSuccess) return e;
+        } else {
+            rec(2 + 2 * 4, stream);
+            if ((e = launch_class<PoaClass4, false>(P, Q, 4, rare_grid_hint(4), scratch, num_cus, max_global_groups(4, n_windows), stream)) != hipSuccess) return e;
+            rec(3 + 2 * 4, stream);
+        }
         rec(2 + 2 * 5, stream);
         if ((e = launch_class<PoaClass5, false>(P, Q, 5, rare_grid_hint(5), scratch, num_cus, max_global_groups(5, n_windows), stream)) != hipSuccess) return e;
         rec(3 + 2 * 5, stream);
