@@ -34,6 +34,51 @@ K = 11                     # -s 5m => k = 11 (src/main.cpp:490-528)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def end_to_end_leg():
+    """Runs hypo_amd/_build/hypo on the 5 Mbp golden set; returns the JSON object for the bench line (or an error note)."""
+    import hashlib
+    import importlib.util
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    binp = os.path.join(ROOT, "hypo_amd", "_build", "hypo")
+    manp = os.path.join(ROOT, "tests", "golden", "e2e_5m_s11.manifest.json")
+    if not (os.path.exists(binp) and os.path.exists(manp)):
+        return {"error": "hypo binary or golden manifest missing"}
+    man = json.load(open(manp))
+    spec = importlib.util.spec_from_file_location("gen_e2e", os.path.join(ROOT, "tests", "golden", "gen_e2e.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    d = tempfile.mkdtemp(prefix="hypo_bench_e2e_")
+    try:
+        a = man["args"]
+        gen.generate(d, a["seed"], a["G"], a["long"], a["k"])
+        for f, want in man["inputs_md5"].items():
+            if hashlib.md5(open(os.path.join(d, f), "rb").read()).hexdigest() != want:
+                return {"error": f"regenerated {f} differs from the golden's input"}
+        threads = min(32, os.cpu_count() or 1)
+        argv = [binp] + man["command"].split()[1:]
+        argv[argv.index("-t") + 1] = str(threads)
+        best = None
+        for _ in range(2):
+            p = subprocess.run(argv, cwd=d, capture_output=True, text=True, timeout=600)
+            if p.returncode != 0:
+                return {"error": (p.stdout + p.stderr)[-300:]}
+            m = re.search(r"Overall\. \): TIME= ([0-9.eE+-]+) sec", p.stdout)
+            t = float(m.group(1)) if m else None
+            if t is not None and (best is None or t < best):
+                best = t
+        got = hashlib.md5(open(os.path.join(d, "hypo_draft.fasta"), "rb").read()).hexdigest()
+        if got != man["expected_fasta_md5"]:
+            raise SystemExit("bench: end-to-end FASTA differs from the real reference's — refusing to report a number")
+        return {"mbp_per_s": round(a["G"] / 1e6 / best, 2), "seconds": round(best, 4), "host_threads": threads,
+                "workload": "C2 end to end: 5 Mbp draft, 30x 150-bp reads (1 M records of SAM text), k = 11, hypo binary = host pipeline + device, best of 2",
+                "fasta": "md5 identical to the real reference's output for these inputs"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -42,6 +87,7 @@ def main():
     ap.add_argument("--windows", type=int, default=N_WINDOWS, help="windows per GPU (default: the C2 configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
     args = ap.parse_args()
 
     import torch
@@ -212,6 +258,13 @@ def main():
             except (OSError, RuntimeError) as ex:            # stale or unloadable prebuilt library: keep the port
                 extra["cpu_reference_error"] = str(ex)[:200]
 
+    # ---- end-to-end leg (the second half of BASELINE's metric): the `hypo` binary of this repo — host pipeline + device —
+    # on the 5 Mbp / 30x C2 set regenerated by the committed generator (~20 s of Python); its FASTA must have the md5 the REAL
+    # reference produced for these inputs (tests/golden/e2e_5m_s11.manifest.json).  Wall time = the run's own "Overall" timer, like the reference's.
+    e2e = None
+    if rank == 0 and world == 1 and not args.no_e2e:
+        e2e = end_to_end_leg()
+
     total_windows = n_w * world * args.steps
     value = total_windows / dt
     if rank == 0:
@@ -225,7 +278,7 @@ def main():
                        "windows_per_gpu": n_w, "arms_per_gpu": batch.n_arms, "contig_bases": CONTIG_BASES, "k": K,
                        "parallelism": f"window sharding x{world}" + (" + RCCL all-gather of consensus" if world > 1 else "")},
             "mbp_per_s": round(CONTIG_BASES * world * args.steps / dt / 1e6, 2),
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "e2e": e2e,
         }
         out.update(extra)
         print(json.dumps(out))
