@@ -1,7 +1,7 @@
 // poa_classes.hpp — size classes of the POA kernel (one template instantiation + launch each).
 //
 //   class lanes/window (windows/wave) cols/lane max seq nodes in-edges dir cells(bits) ring cells arm B seqs scores ids  memory / window
-//   0     16 (4)                      4         47      48    4        2208 (4)       384        384   48   int16  u8   LDS  3.7 KB
+//   0     16 (4)                      4         47      48    4        2208 (4)       384        384   64   int16  u8   LDS  3.8 KB
 //   1     32 (2)                      4         79      84    4        6720 (4)       640        768   64   int16  u8   LDS  7.9 KB
 //   2     64 (1)                      2         127     126   6        13440 (4)      1024       1024  96   int16  u8   LDS  13.9 KB
 //   3     64 (1)                      2         127     254   8        32768 (8)      4096       4096  254  int16  u8   LDS  55.8 KB
@@ -19,7 +19,7 @@
 
 namespace hypo {
 //              GW CPL LCAP NMAX KIN DIRCELLS RINGCELLS ARMBYTES SEQMAX
-typedef PoaCfg<16, 4, 47, 48, 4, 2208, 384, 384, 48, int16_t, uint8_t> PoaClass0;
+typedef PoaCfg<16, 4, 47, 48, 4, 2208, 384, 384, 64, int16_t, uint8_t> PoaClass0;
 typedef PoaCfg<32, 4, 79, 84, 4, 6720, 640, 768, 64, int16_t, uint8_t> PoaClass1;
 #ifndef HYPO_C2_GW
 #define HYPO_C2_GW 64
