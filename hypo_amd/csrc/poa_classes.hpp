@@ -4,7 +4,8 @@
 //   0     16 (4)                      4         47      48    4        2208 (4)       384        384   64   int16  u8   LDS  3.8 KB
 //   1     32 (2)                      4         79      84    4        6720 (4)       640        768   64   int16  u8   LDS  7.9 KB
 //   2     64 (1)                      2         127     126   6        13440 (4)      1024       1024  96   int16  u8   LDS  13.9 KB
-//   3     64 (1)                      2         127     254   8        32768 (8)      4096       4096  254  int16  u8   LDS  55.8 KB
+//   3     64 (1)                      4         255     254   7        49152 (4)      2048       1024  192  int16  u8   LDS  40 KB (4 waves per CU): the wide SHORT windows (the reference cuts a weak region only
+//                                                                                                                     above 2 x 100 bp, src/Contig.cpp:526-711) and small windows with large graphs
 //   4     64 (1)                      10        639     2400  12       1536000 (8)    491520     16384 256  int16  u16  HBM scratch 3.3 MB / resident group: the LONG windows (<= 500 bp, arms ~ window length,
 //                                                                                                                     graphs ~1.3 k nodes; src/Window.cpp:156-236), up to 2048 groups resident
 //   5     64 (1)                      16        1023    4000  16       4194304 (8)    2097152    16384 1024 int32  u16  HBM scratch 13.5 MB / resident group: whatever overflows everything else (64 groups)
@@ -26,7 +27,7 @@ typedef PoaCfg<32, 4, 79, 84, 4, 6720, 640, 768, 64, int16_t, uint8_t> PoaClass1
 #define HYPO_C2_CPL 2
 #endif
 typedef PoaCfg<HYPO_C2_GW, HYPO_C2_CPL, 127, 126, 6, 13440, 1024, 1024, 96, int16_t, uint8_t> PoaClass2;
-typedef PoaCfg<64, 2, 127, 254, 8, 32768, 4096, 4096, 254, int16_t, uint8_t> PoaClass3;
+typedef PoaCfg<64, 4, 255, 254, 7, 49152, 2048, 1024, 192, int16_t, uint8_t> PoaClass3;
 typedef PoaCfg<64, 10, 639, 2400, 12, 1536000, 491520, 16384, 256, int16_t, uint16_t, 1 << 18, true> PoaClass4;          // + 256 K path ids: runs LONG windows
 typedef PoaCfg<64, 16, 1023, 4000, 16, 1 << 22, 1 << 21, 16384, 1024, int32_t, uint16_t, 1 << 18> PoaClass5;    // last resort, also runs LONG windows
 constexpr int kNumPoaClasses = 6;
