@@ -3,7 +3,7 @@
 //   class lanes/window (windows/wave) cols/lane max seq nodes in-edges dir cells(bits) ring cells arm B seqs scores ids  memory / window
 //   0     16 (4)                      4         47      48    4        2208 (4)       384        384   64   int16  u8   LDS  3.8 KB
 //   1     32 (2)                      4         79      84    4        6720 (4)       640        768   64   int16  u8   LDS  7.9 KB
-//   2     64 (1)                      2         127     126   6        13440 (4)      1024       1024  96   int16  u8   LDS  13.9 KB
+//   2     64 (1)                      2         127     126   6        13440 (4)      1024       1024  127  int16  u8   LDS  14.1 KB
 //   3     64 (1)                      4         255     254   7        49152 (4)      2048       1024  192  int16  u8   LDS  40 KB (4 waves per CU): the wide SHORT windows (the reference cuts a weak region only
 //                                                                                                                     above 2 x 100 bp, src/Contig.cpp:526-711) and small windows with large graphs
 //   4     64 (1)                      10        639     2400  12       1536000 (8)    491520     16384 256  int16  u16  HBM scratch 3.3 MB / resident group: the LONG windows (<= 500 bp, arms ~ window length,
@@ -26,7 +26,7 @@ typedef PoaCfg<32, 4, 79, 84, 4, 6720, 640, 768, 64, int16_t, uint8_t> PoaClass1
 #define HYPO_C2_GW 64
 #define HYPO_C2_CPL 2
 #endif
-typedef PoaCfg<HYPO_C2_GW, HYPO_C2_CPL, 127, 126, 6, 13440, 1024, 1024, 96, int16_t, uint8_t> PoaClass2;
+typedef PoaCfg<HYPO_C2_GW, HYPO_C2_CPL, 127, 126, 6, 13440, 1024, 1024, 127, int16_t, uint8_t> PoaClass2;
 typedef PoaCfg<64, 4, 255, 254, 7, 49152, 2048, 1024, 192, int16_t, uint8_t> PoaClass3;
 typedef PoaCfg<64, 10, 639, 2400, 12, 1536000, 491520, 16384, 256, int16_t, uint16_t, 1 << 18, true> PoaClass4;          // + 256 K path ids: runs LONG windows
 typedef PoaCfg<64, 16, 1023, 4000, 16, 1 << 22, 1 << 21, 16384, 1024, int32_t, uint16_t, 1 << 18> PoaClass5;    // last resort, also runs LONG windows
