@@ -201,8 +201,8 @@ def main():
         tr = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tr):
             try:
-                j = json.load(open(tr))
-                if j.get("kernel") == roofline["kernel"] and j.get("windows") == roofline["windows_per_launch"]:
+                j = json.load(open(tr)).get(roofline["kernel"], {})      # one entry per size-class kernel
+                if j.get("windows") == roofline["windows_per_launch"]:
                     roofline["traffic"] = j.get("hbm_bytes_per_launch")
             except Exception:
                 pass
