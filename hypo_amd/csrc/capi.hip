@@ -21,7 +21,7 @@ int fail(int code, const char* fmt, ...) {
 }
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(HYPO_E_HIP, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
 
-struct Ctx { bool ready = false; int device = -1; int num_cus = 0; hipStream_t stream = nullptr; };
+struct Ctx { bool ready = false; int device = -1; int num_cus = 0; hipStream_t stream = nullptr; hypo::PoaAux poa_aux; };
 Ctx g_ctx;
 
 // HIP-event recorder for the next calls (hypo_gpu_profile_*)
@@ -70,19 +70,24 @@ int hypo_gpu_init(int device_id) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(HYPO_E_NODEVICE, "no HIP device visible");
     if (device_id < 0 || device_id >= n) return fail(HYPO_E_INVALID, "device %d out of range (0..%d)", device_id, n - 1);
+    if (g_ctx.ready) (void)hypo_gpu_shutdown();          // re-initialisation: streams and events belong to the previous device
     HIP_TRY(hipSetDevice(device_id));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(HYPO_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
-    if (g_ctx.ready && g_ctx.stream) { (void)hipStreamDestroy(g_ctx.stream); g_ctx.stream = nullptr; }
     HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
     g_ctx.device = device_id; g_ctx.num_cus = prop.multiProcessorCount; g_ctx.ready = true;
     return HYPO_OK;
 }
 
 int hypo_gpu_shutdown(void) {
-    if (g_ctx.ready && g_ctx.stream) (void)hipStreamDestroy(g_ctx.stream);
+    if (g_ctx.ready) {
+        (void)hipSetDevice(g_ctx.device);
+        (void)hipDeviceSynchronize();
+        hypo::poa_release(&g_ctx.poa_aux);
+        if (g_ctx.stream) (void)hipStreamDestroy(g_ctx.stream);
+    }
     g_ctx = Ctx();
     return HYPO_OK;
 }
@@ -142,7 +147,7 @@ int hypo_gpu_poa_batch_device(const HypoScoreParams* scores, const HypoWindowBat
     hypo::PoaParams P = make_params(scores, in, out);
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_ctx.stream;
     ProfCall* pc = prof_next(1);
-    HIP_TRY(hypo::poa_run(P, in->n_windows, workspace, workspace_bytes, g_ctx.num_cus, st, pc ? &pc->ke : nullptr));
+    HIP_TRY(hypo::poa_run(P, in->n_windows, workspace, workspace_bytes, g_ctx.num_cus, st, pc ? &pc->ke : nullptr, &g_ctx.poa_aux));
     return HYPO_OK;
 }
 

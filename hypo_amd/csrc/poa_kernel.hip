@@ -294,8 +294,9 @@ size_t poa_workspace_bytes(uint32_t n_windows) {
 }
 
 hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size_t workspace_bytes,
-                   int num_cus, hipStream_t stream, KernelEvents* prof) {
+                   int num_cus, hipStream_t stream, KernelEvents* prof, PoaAux* A) {
     if (n_windows == 0) return hipSuccess;
+    if (!A) return hipErrorInvalidValue;
     if (workspace_bytes < poa_workspace_bytes(n_windows)) return hipErrorInvalidValue;
     char* ws = (char*)workspace;
     PoaQueues Q;
@@ -327,12 +328,12 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
     // the three big kernels run; their grids are then sized for it.  A grid of 2 048 single-wave workgroups costs ~0.1 ms of
     // dispatch even if every wave leaves at once, and these classes are empty in most batches (a few escalated windows still
     // find a small grid waiting).
-    static uint32_t* planned_host = nullptr;
-    static hipEvent_t planned_ev = nullptr;
-    if (!planned_host) {
-        if ((e = hipHostMalloc((void**)&planned_host, 8 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return e;
-        if ((e = hipEventCreateWithFlags(&planned_ev, hipEventDisableTiming)) != hipSuccess) return e;
+    if (!A->planned_host) {
+        if ((e = hipHostMalloc((void**)&A->planned_host, 8 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return e;
+        if ((e = hipEventCreateWithFlags(&A->planned_ev, hipEventDisableTiming)) != hipSuccess) return e;
     }
+    uint32_t* const planned_host = A->planned_host;
+    const hipEvent_t planned_ev = A->planned_ev;
     if ((e = hipMemcpyAsync(planned_host, Q.planned, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
     (void)hipEventRecord(planned_ev, stream);
     auto rare_grid_hint = [&](int cls) -> uint32_t {         // windows to size the grid of a rare class for
@@ -347,8 +348,9 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
     // issue, so sharing the CUs fills issue slots either would leave idle (measured: ~11 % per step).  Each gets a
     // share of a CU's LDS through a waves-per-CU cap.  A window re-queued by a class that ran next to its successor
     // is picked up by a small mop-up launch afterwards; the rare classes 3 and 4 follow on the caller's stream.
-    static hipStream_t aux[3] = {nullptr, nullptr, nullptr};
-    static hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr};
+    hipStream_t* const aux = A->aux;
+    hipEvent_t* const join_ev = A->join_ev;
+    hipEvent_t& fork_ev = A->fork_ev;
     int caps[kNumPoaClasses] = {3, 3, 6, 0, 0};
     if (const char* cs = getenv("HYPO_POA_CAPS")) sscanf(cs, "%d,%d,%d,%d,%d", &caps[0], &caps[1], &caps[2], &caps[3], &caps[4]);
     const char* seq_env = getenv("HYPO_POA_SEQUENTIAL");
@@ -425,6 +427,18 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
     pe = 3 + 2 * kNumPoaClasses;
     if (prof) prof->n = pe;
     return hipSuccess;
+}
+
+void poa_release(PoaAux* a) {
+    if (!a) return;
+    for (int i = 0; i < 3; ++i) {
+        if (a->aux[i]) (void)hipStreamDestroy(a->aux[i]);
+        if (a->join_ev[i]) (void)hipEventDestroy(a->join_ev[i]);
+    }
+    if (a->fork_ev) (void)hipEventDestroy(a->fork_ev);
+    if (a->planned_ev) (void)hipEventDestroy(a->planned_ev);
+    if (a->planned_host) (void)hipHostFree(a->planned_host);
+    *a = PoaAux();
 }
 
 }  // namespace hypo

@@ -38,8 +38,17 @@ struct PoaQueues {
 // (recorded on the stream that kernel runs on), ev[2+2*classes] after everything has joined the caller's stream
 struct KernelEvents { hipEvent_t ev[16]; int n; };
 
+// Streams, events and the pinned readback buffer poa_run() needs beyond the caller's stream.  Owned by the library context
+// (capi.hip): created on first use on the current device, released by poa_release() at shutdown / device change.
+struct PoaAux {
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr}, planned_ev = nullptr;
+    uint32_t* planned_host = nullptr;
+};
+void poa_release(PoaAux* a);
+
 size_t poa_workspace_bytes(uint32_t n_windows);
 hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size_t workspace_bytes,
-                   int num_cus, hipStream_t stream, KernelEvents* prof);
+                   int num_cus, hipStream_t stream, KernelEvents* prof, PoaAux* aux_state);
 
 }  // namespace hypo
