@@ -21,7 +21,25 @@ int fail(int code, const char* fmt, ...) {
 }
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(HYPO_E_HIP, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
 
-struct Ctx { bool ready = false; int device = -1; int num_cus = 0; hipStream_t stream = nullptr; hypo::PoaAux poa_aux; };
+// Device buffers of the host-pointer entry points: grow-only arenas owned by the context (no allocation in the
+// steady-state path); released at shutdown.  Slot numbers are local to each entry point.
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t alloc(size_t n) {
+        n = n ? n : 16;
+        if (n <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = n + n / 4;                       // head room: the next batch is rarely exactly this size
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { e = hipMalloc(&p, n); if (e != hipSuccess) return e; cap = n; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Ctx { bool ready = false; int device = -1; int num_cus = 0; hipStream_t stream = nullptr; hypo::PoaAux poa_aux; DevBuf arena[16]; };
 Ctx g_ctx;
 
 // HIP-event recorder for the next calls (hypo_gpu_profile_*)
@@ -35,12 +53,6 @@ ProfCall* prof_next(int kind) {
     c->kind = kind; c->ke.n = 0;
     return c;
 }
-
-struct DevBuf {
-    void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
-};
 
 int check_scores(const HypoScoreParams* s) {
     if (!s) return fail(HYPO_E_INVALID, "scores == NULL");
@@ -86,6 +98,7 @@ int hypo_gpu_shutdown(void) {
         (void)hipSetDevice(g_ctx.device);
         (void)hipDeviceSynchronize();
         hypo::poa_release(&g_ctx.poa_aux);
+        for (auto& a : g_ctx.arena) a.release();
         if (g_ctx.stream) (void)hipStreamDestroy(g_ctx.stream);
     }
     g_ctx = Ctx();
@@ -142,8 +155,9 @@ int hypo_gpu_poa_batch_device(const HypoScoreParams* scores, const HypoWindowBat
     if (!in->windows || !in->draft4 || !out->bases || !out->off || !out->len || !out->status ||
         (in->n_arms && (!in->arm_off || !in->arm_len || !in->arms2)))
         return fail(HYPO_E_INVALID, "NULL buffer in batch");
-    if (!workspace || workspace_bytes < hypo::poa_workspace_bytes(in->n_windows))
-        return fail(HYPO_E_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, hypo::poa_workspace_bytes(in->n_windows));
+    if (!workspace || workspace_bytes < hypo::poa_workspace_bytes(in->n_windows, hypo::kMinGlobalGroups))
+        return fail(HYPO_E_WORKSPACE, "workspace %zu < minimum %zu (hypo_gpu_poa_workspace_bytes recommends %zu)", workspace_bytes,
+                    hypo::poa_workspace_bytes(in->n_windows, hypo::kMinGlobalGroups), hypo::poa_workspace_bytes(in->n_windows));
     hypo::PoaParams P = make_params(scores, in, out);
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_ctx.stream;
     ProfCall* pc = prof_next(1);
@@ -192,8 +206,12 @@ int hypo_gpu_poa_batch(const HypoScoreParams* scores, const HypoWindowBatch* in,
     if (!in->windows || !in->draft4 || !out->bases || !out->off || !out->len || !out->status)
         return fail(HYPO_E_INVALID, "NULL buffer in batch");
     const uint64_t out_bytes = out->off[n];
-    DevBuf dW, dD, dAO, dAL, dA, dB, dO, dL, dS, dWS;
-    const size_t wsb = hypo::poa_workspace_bytes(n);
+    DevBuf &dW = g_ctx.arena[0], &dD = g_ctx.arena[1], &dAO = g_ctx.arena[2], &dAL = g_ctx.arena[3], &dA = g_ctx.arena[4],
+           &dB = g_ctx.arena[5], &dO = g_ctx.arena[6], &dL = g_ctx.arena[7], &dS = g_ctx.arena[8], &dWS = g_ctx.arena[9];
+    // the host sees the window types: scratch for as many resident LONG groups as there are LONG windows (+ escalations)
+    uint32_t n_long = 0;
+    for (uint32_t w = 0; w < n; ++w) n_long += in->windows[w].type != HYPO_WIN_SHORT;
+    const size_t wsb = hypo::poa_workspace_bytes(n, (int)(n_long + 64 < 2048u ? n_long + 64 : 2048u));
     HIP_TRY(dW.alloc((size_t)n * sizeof(HypoWindow))); HIP_TRY(dD.alloc(in->draft4_bytes));
     HIP_TRY(dAO.alloc((size_t)na * 8)); HIP_TRY(dAL.alloc((size_t)na * 4)); HIP_TRY(dA.alloc(in->arms2_bytes));
     HIP_TRY(dB.alloc(out_bytes)); HIP_TRY(dO.alloc((size_t)(n + 1) * 8)); HIP_TRY(dL.alloc((size_t)n * 4));
@@ -251,7 +269,8 @@ int hypo_gpu_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k, co
     if (k < 2 || k > 31) return fail(HYPO_E_INVALID, "k=%u out of range 2..31", k);
     if ((n_bases && !packed4) || !bits || (n_bases && !solid_pos_words)) return fail(HYPO_E_INVALID, "NULL buffer");
     const uint64_t nw = (n_bases + 63) / 64, nbytes = (n_bases + 1) / 2, bit_words = (1ull << (2 * k)) / 64 ? (1ull << (2 * k)) / 64 : 1;
-    DevBuf dP, dBits, dWords, dKids, dRank, dN, dWS;
+    DevBuf &dP = g_ctx.arena[10], &dBits = g_ctx.arena[11], &dWords = g_ctx.arena[12], &dKids = g_ctx.arena[13],
+           &dRank = g_ctx.arena[14], &dN = g_ctx.arena[15], &dWS = g_ctx.arena[9];
     const size_t wsb = hypo::scan_workspace_bytes(n_bases);
     HIP_TRY(dP.alloc(nbytes)); HIP_TRY(dBits.alloc(bit_words * 8)); HIP_TRY(dWords.alloc(nw * 8));
     HIP_TRY(dKids.alloc(kids_cap * 8)); HIP_TRY(dRank.alloc((nw + 1) * 8)); HIP_TRY(dN.alloc(8)); HIP_TRY(dWS.alloc(wsb));

@@ -280,24 +280,35 @@ static hipError_t launch_class(const PoaParams& P, const PoaQueues& Q, int cls, 
     return hipGetLastError();
 }
 
-size_t poa_workspace_bytes(uint32_t n_windows) {
+static size_t poa_workspace_prefix(uint32_t n_windows) {       // header, class queues, plan keys
     size_t b = kPoaHeaderBytes;
     b += (size_t)kNumPoaClasses * n_windows * sizeof(uint32_t);
     b = (b + 255) / 256 * 256;
-    b += ((size_t)n_windows * 2 + 255) / 256 * 256;        // plan keys
-    size_t big = 0;                                         // the HBM-scratch classes run one after the other and share the region
-#define HYPO_BIG(ID, CFG) if (ID >= kFirstGlobalClass) { const size_t x = (size_t)max_global_groups(ID, n_windows) * PoaLayout<CFG>::BYTES; big = x > big ? x : big; }
-    HYPO_FOR_EACH_CLASS(HYPO_BIG)
-#undef HYPO_BIG
-    b += big;
+    b += ((size_t)n_windows * 2 + 255) / 256 * 256;
     return b;
+}
+
+size_t poa_workspace_bytes(uint32_t n_windows, int long_groups) {
+    size_t big = 0;                                         // the HBM-scratch classes run one after the other and share the region
+    int g4 = long_groups > 0 ? long_groups : max_global_groups(4, n_windows);
+    g4 = g4 < kMinGlobalGroups ? kMinGlobalGroups : (g4 > kMaxGlobalGroups4 ? kMaxGlobalGroups4 : g4);
+    int g5 = max_global_groups(5, n_windows);
+    g5 = g5 < kMinGlobalGroups ? kMinGlobalGroups : g5;
+    const size_t x4 = (size_t)g4 * PoaLayout<PoaClass4>::BYTES, x5 = (size_t)g5 * PoaLayout<PoaClass5>::BYTES;
+    big = x4 > x5 ? x4 : x5;
+    return poa_workspace_prefix(n_windows) + big;
 }
 
 hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size_t workspace_bytes,
                    int num_cus, hipStream_t stream, KernelEvents* prof, PoaAux* A) {
     if (n_windows == 0) return hipSuccess;
     if (!A) return hipErrorInvalidValue;
-    if (workspace_bytes < poa_workspace_bytes(n_windows)) return hipErrorInvalidValue;
+    if (workspace_bytes < poa_workspace_bytes(n_windows, kMinGlobalGroups)) return hipErrorInvalidValue;
+    // resident groups of the HBM-scratch classes = what the provided scratch holds
+    const size_t scratch_bytes = workspace_bytes - poa_workspace_prefix(n_windows);
+    const size_t fit4 = scratch_bytes / PoaLayout<PoaClass4>::BYTES, fit5 = scratch_bytes / PoaLayout<PoaClass5>::BYTES;
+    const int groups4 = (int)(fit4 < (size_t)max_global_groups(4, n_windows) ? fit4 : (size_t)max_global_groups(4, n_windows));
+    const int groups5 = (int)(fit5 < (size_t)max_global_groups(5, n_windows) ? fit5 : (size_t)max_global_groups(5, n_windows));
     char* ws = (char*)workspace;
     PoaQueues Q;
     Q.count = (uint32_t*)ws;
@@ -361,7 +372,7 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
         if (ID == 3 && (e = hipEventSynchronize(planned_ev)) != hipSuccess) return e;                     \
         rec(2 + 2 * ID, stream);                                                                          \
         if ((e = launch_class<CFG, (ID < kFirstGlobalClass)>(P, Q, ID, ID >= 3 ? rare_grid_hint(ID) : n_windows, scratch, num_cus, \
-                                                             max_global_groups(ID, n_windows), stream)) != hipSuccess) return e; \
+                                                             (ID == 4 ? groups4 : groups5), stream)) != hipSuccess) return e; \
         rec(3 + 2 * ID, stream);
         HYPO_FOR_EACH_CLASS(HYPO_LAUNCH)
 #undef HYPO_LAUNCH
@@ -404,7 +415,7 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
         const bool long_first_pass = planned_host[4] > 0;
         if (long_first_pass) {
             rec(2 + 2 * 4, aux[2]);
-            if ((e = launch_class<PoaClass4, false>(P, Q, 4, rare_grid_hint(4), scratch, num_cus, max_global_groups(4, n_windows), aux[2], 8)) != hipSuccess) return e;
+            if ((e = launch_class<PoaClass4, false>(P, Q, 4, rare_grid_hint(4), scratch, num_cus, groups4, aux[2], 8)) != hipSuccess) return e;
             rec(3 + 2 * 4, aux[2]);
             (void)hipEventRecord(join_ev[2], aux[2]);
         }
@@ -413,14 +424,14 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
         rec(3 + 2 * 3, stream);
         if (long_first_pass) {
             (void)hipStreamWaitEvent(stream, join_ev[2], 0);
-            if ((e = launch_class<PoaClass4, false>(P, Q, 4, 64, scratch, num_cus, max_global_groups(4, n_windows), stream, 1, true)) != hipSuccess) return e;
+            if ((e = launch_class<PoaClass4, false>(P, Q, 4, 64, scratch, num_cus, groups4, stream, 1, true)) != hipSuccess) return e;
         } else {
             rec(2 + 2 * 4, stream);
-            if ((e = launch_class<PoaClass4, false>(P, Q, 4, rare_grid_hint(4), scratch, num_cus, max_global_groups(4, n_windows), stream)) != hipSuccess) return e;
+            if ((e = launch_class<PoaClass4, false>(P, Q, 4, rare_grid_hint(4), scratch, num_cus, groups4, stream)) != hipSuccess) return e;
             rec(3 + 2 * 4, stream);
         }
         rec(2 + 2 * 5, stream);
-        if ((e = launch_class<PoaClass5, false>(P, Q, 5, rare_grid_hint(5), scratch, num_cus, max_global_groups(5, n_windows), stream)) != hipSuccess) return e;
+        if ((e = launch_class<PoaClass5, false>(P, Q, 5, rare_grid_hint(5), scratch, num_cus, groups5, stream)) != hipSuccess) return e;
         rec(3 + 2 * 5, stream);
     }
     rec(2 + 2 * kNumPoaClasses, stream);

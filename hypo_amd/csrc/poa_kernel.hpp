@@ -16,7 +16,8 @@ inline int max_global_groups(int cls, uint32_t n_windows) {
     const int want = n_windows < 16u ? 16 : (n_windows > (uint32_t)cap ? cap : (int)n_windows);   // no batch needs more groups than windows
     return want < cap ? want : cap;
 }
-constexpr size_t kPoaHeaderBytes = 8192; // count[8] | head[8] @64 | HypoPoaStats @128 | phase cycles @512 | hist @2048 | start @4096 | cursor @6144
+constexpr int kMinGlobalGroups = 16;     // the smallest scratch poa_run accepts holds this many groups of either HBM-scratch class
+constexpr size_t kPoaHeaderBytes = 8192; // count[8] | head[8] @64 | HypoPoaStats @128 | phase cycles @512 | hist @2048 | start @4096 | cursor @6144 | planned @7680 | head2 @7744
 
 constexpr int kPlanBuckets = 64;         // cost buckets per class of the plan's counting sort
 
@@ -47,7 +48,9 @@ struct PoaAux {
 };
 void poa_release(PoaAux* a);
 
-size_t poa_workspace_bytes(uint32_t n_windows);
+// Bytes for a batch of n_windows windows.  long_groups = resident groups of the LONG class the scratch is provisioned for
+// (0 = as many as the batch could use, up to kMaxGlobalGroups4); poa_run derives the group counts from the size it is given.
+size_t poa_workspace_bytes(uint32_t n_windows, int long_groups = 0);
 hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size_t workspace_bytes,
                    int num_cus, hipStream_t stream, KernelEvents* prof, PoaAux* aux_state);
 

@@ -152,6 +152,9 @@ int hypo_gpu_solid_scan_device(const uint8_t* packed4, uint64_t n_bases, uint32_
 int hypo_gpu_poa_batch(const HypoScoreParams* scores, const HypoWindowBatch* in,
                        HypoConsensusBatch* out);
 
+/* Recommended workspace: queues for n_windows plus HBM scratch for as many resident groups of the LONG-window class as the
+ * batch could use (up to 2048 x 3.3 MB).  A smaller workspace is accepted down to 16 resident groups (HYPO_E_WORKSPACE
+ * below that); it only limits how many LONG / oversized windows are in flight at once. */
 size_t hypo_gpu_poa_workspace_bytes(uint32_t n_windows, uint32_t n_arms);
 int hypo_gpu_poa_batch_device(const HypoScoreParams* scores, const HypoWindowBatch* in,
                               HypoConsensusBatch* out, void* workspace, size_t workspace_bytes,
