@@ -103,19 +103,18 @@ poa_plan_count_kernel(PoaParams P, PoaQueues Q, uint32_t n_windows) {
     if (threadIdx.x == 0 && ntriv) atomicAdd((unsigned long long*)&Q.stats->n_trivial, (unsigned long long)ntriv);
 }
 
-__global__ void poa_plan_scan_kernel(PoaQueues Q) {       // one small workgroup: kNumPoaClasses x kPlanBuckets entries
-    if (threadIdx.x == 0) {
-        for (int c = 0; c < kNumPoaClasses; ++c) {
-            uint32_t acc = 0;
-            for (int b = 0; b < kPlanBuckets; ++b) {
-                const int k = c * kPlanBuckets + b;
-                Q.start[k] = acc;
-                acc += Q.hist[k];
-            }
-            Q.count[c] = acc;
-            Q.planned[c] = acc;          // windows the plan put into the class (before any re-queue)
-            Q.head2[c] = acc;
+__global__ void poa_plan_scan_kernel(PoaQueues Q) {       // one wave: lane c scans the kPlanBuckets entries of class c
+    const int c = threadIdx.x;
+    if (c < kNumPoaClasses) {
+        uint32_t acc = 0;
+        for (int b = 0; b < kPlanBuckets; ++b) {
+            const int k = c * kPlanBuckets + b;
+            Q.start[k] = acc;
+            acc += Q.hist[k];
         }
+        Q.count[c] = acc;
+        Q.planned[c] = acc;          // windows the plan put into the class (before any re-queue)
+        Q.head2[c] = acc;
     }
 }
 
