@@ -170,6 +170,7 @@ void Hypo::polish() {
                     if (win) e = b + (uint32_t)win->get_window_len();           // a LONG window spans the arm-less regions that follow it
                     dump << _contigs[i]->get_name() << '\t' << b << '\t' << e << '\t' << region_name(t);
                     if (win) dump << '\t' << win->dump_counts() << '\t' << win->arms_crc32() << '\t' << win->get_consensus();
+                    if (win && std::getenv("HYPO_REGION_DUMP_ARMS")) dump << '\t' << (win->is_long() ? "L" : "S") << '\t' << win->dump_text();
                     else if (t != RegionType::SR && t != RegionType::MSR) dump << "\t0\t0\t0\t0\t0\t" << _contigs[i]->draft_segment(b, e);   // no arms: draft kept
                     dump << '\n';
                 }

@@ -101,6 +101,17 @@ int Window::generate_consensus_batch(const std::vector<Window*>& windows) {
     return HYPO_OK;
 }
 
+std::string Window::dump_text() const {
+    std::string t = _draft.unpack();
+    const char* tag[3] = {"|I:", "|P:", "|S:"};
+    int gi = 0;
+    for (const auto* group : {&_internal_arms, &_pre_arms, &_suf_arms}) {
+        for (const auto& a : *group) { t += tag[gi]; t += a.unpack(); }
+        ++gi;
+    }
+    return t;
+}
+
 uint32_t Window::arms_crc32() const {
     uint32_t crc = 0xffffffffu;
     auto feed = [&crc](unsigned char c) { crc ^= c; for (int k = 0; k < 8; ++k) crc = (crc >> 1) ^ (0xedb88320u & (0u - (crc & 1u))); };

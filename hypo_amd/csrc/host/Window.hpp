@@ -69,6 +69,8 @@ public:
     std::string dump_counts() const {
         return std::to_string(_num_internal) + "\t" + std::to_string(_num_pre) + "\t" + std::to_string(_num_suf) + "\t" + std::to_string(_num_empty);
     }
+    bool is_long() const { return _wtype == WindowType::LONG; }
+    std::string dump_text() const;            // draft and arms as text (debugging aid of the region dump: HYPO_REGION_DUMP_ARMS=1)
     uint32_t arms_crc32() const;             // crc32 of the arms (internal, prefix, suffix; insertion order) joined by '\n'
     void clear_pre_suf() {
         _num_pre = 0; _num_suf = 0;

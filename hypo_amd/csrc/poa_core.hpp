@@ -373,7 +373,11 @@ struct Poa {
                 const int k = (int)((rowmeta[r] >> 8) & 0xff);
                 for (int p = 0; p < k; ++p) {
                     const int pr = pred_row(r, p);
-                    if (pr > 0 && r + 1 - pr > Cfg::RING1) atomic_or(&rowmeta[pr - 1], META_DEEP);
+                    // plain read-modify-write on purpose: every writer ORs the same bit into a word nobody else changes here, so
+                    // colliding lanes store identical values; an atomic would execute in L2 and leave a stale copy of the word
+                    // in this CU's vector L1, which the row loop's ordinary loads could then hit (seen on hardware, never in
+                    // the emulator)
+                    if (pr > 0 && r + 1 - pr > Cfg::RING1) rowmeta[pr - 1] |= META_DEEP;
                 }
             }
             g.sync();
@@ -381,14 +385,6 @@ struct Poa {
     }
     static constexpr uint32_t META_DEEP = 0x80000000u;     // rowmeta bit 31: a row further than RING1 ahead reads this row
     HD static int meta_p0(uint32_t meta) { return (int)((meta >> 17) & 0x3fffu); }
-    HD static void atomic_or(uint32_t* p, uint32_t v) {
-#ifdef HYPO_EMU
-        *p |= v;
-#else
-        atomicOr(p, v);
-#endif
-    }
-
     static constexpr bool PRED_TABLE = Cfg::PATHCAP > 0;    // the HBM-scratch classes tabulate pred rows in build_rowmeta
     HD int pred_row(int r, int p) const {                   // matrix row of pred p of rank r
         if (PRED_TABLE) return (int)predrows[r * KIN + p];
@@ -1040,13 +1036,20 @@ struct Poa {
                 for (int r = (int)n2r[max_id] + 1; r < n_nodes; ++r) {
                     const int u = r2n[r];
                     const int k = nin[u];
-                    int s = -1, pd = -1;
+                    // graph.cpp:683-696.  The chosen predecessor's score travels in a register: written as
+                    // `s < w || (s == w && score[pd] <= score[b])` this loop came out of hipcc (ROCm 7.2, gfx950) keeping the
+                    // first of two equal-weight, equal-score in-edges on the device while the same source is right on the CPU
+                    // (found by the messy end-to-end seeds; pinned by tests/test_gpu_poa.py::test_branch_completion_tie).
+                    int s = -1, pd = -1, spd = 0;
                     for (int p = 0; p < k; ++p) {
                         const int w = inw[u * KIN + p], b = inp[u * KIN + p];
-                        if (score[b] == -1) continue;
-                        if (s < w || (s == w && score[pd] <= score[b])) { s = w; pd = b; }
+                        const int sb = score[b];
+                        if (sb == -1) continue;
+                        bool take = s < w;
+                        if (!take && s == w) take = spd <= sb;
+                        if (take) { s = w; pd = b; spd = sb; }
                     }
-                    if (pd != -1) s += score[pd];
+                    if (pd != -1) s += spd;
                     score[u] = s; pred[u] = (int16_t)pd;
                     if (ms < s) { ms = s; nxt = u; }
                 }
@@ -1067,6 +1070,15 @@ struct Poa {
     }
 
     // ---- LONG windows: Window::generate_consensus_long + curate (src/Window.cpp:156-254) ----------------
+    // reads a counter that atomics have updated: the atomics execute in L2, an ordinary load could hit an older copy in this
+    // CU's vector L1
+    HD static uint32_t counter_load(const uint32_t* p) {
+#ifdef HYPO_EMU
+        return *p;
+#else
+        return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    }
     HD static void atomic_inc(uint32_t* p, uint32_t v) {
 #ifdef HYPO_EMU
         *p += v;
@@ -1173,7 +1185,7 @@ struct Poa {
             int o = 0;
             for (int base = 0; base < len; base += GW) {
                 const int c = base + g.lane;
-                const bool keep = c < len && dstcnt[c] >= thr;
+                const bool keep = c < len && counter_load(&dstcnt[c]) >= thr;
                 const uint64_t kb = g.ballot(keep);
                 // consbuf may alias nothing else; positions only move left, chunk by chunk
                 const int cd = c < len ? (int)code[path[len - 1 - c]] : 0;

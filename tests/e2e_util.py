@@ -98,3 +98,27 @@ def check_outputs(name, outdir, man):
     assert hashlib.md5(got).hexdigest() == man["expected_fasta_md5"]
     assert got == want
     return len(regions)
+
+
+def messy_seeds():
+    """{seed: {"args": [...], "fasta_md5": ...}}: what the REAL reference binary produced for gen_e2e.generate_messy(seed)
+    (tests/golden/fuzz_e2e.py, build container)."""
+    return {int(k): v for k, v in json.load(open(os.path.join(GOLD, "e2e_messy_md5.json"))).items()}
+
+
+def run_messy_seed(seed, rec, outdir, device, threads=4):
+    spec = importlib.util.spec_from_file_location("gen_e2e", os.path.join(GOLD, "gen_e2e.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    argv, _, _ = gen.generate_messy(str(outdir), seed)
+    assert argv == rec["args"], f"seed {seed}: the generator's options changed"
+    argv = [BIN] + argv
+    argv[argv.index("-t") + 1] = str(threads)
+    env = dict(os.environ)
+    if device == "shim":
+        env["LD_LIBRARY_PATH"] = SHIM_DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    p = subprocess.run(argv, cwd=str(outdir), env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    assert ("oracle_device_shim" in p.stderr) == (device == "shim")
+    got = hashlib.md5(open(os.path.join(str(outdir), "hypo_draft.fasta"), "rb").read()).hexdigest()
+    assert got == rec["fasta_md5"], f"messy seed {seed} ({' '.join(rec['args'][10:])}): FASTA differs from the reference's"

@@ -137,9 +137,11 @@ int run_cfg(const hypo::PoaParams& P, uint32_t n_windows, uint8_t* res, uint64_t
     job.eg.gw = Cfg::GW; job.eg.yield = yield_cb; job.eg.sched = &s;
     for (uint32_t w = 0; w < n_windows; ++w) {
         job.mem = (char*)malloc(hypo::PoaLayout<Cfg>::BYTES);       // exact size: ASan sees overruns
-        memset(job.mem, 0xA5, hypo::PoaLayout<Cfg>::BYTES);         // LDS is not zero-initialised
+        // LDS / scratch are not initialised on the device: HYPO_EMU_FILL selects the garbage (default 0xA5; tests also use 0x00 / 0xFF)
+        const int fill = getenv("HYPO_EMU_FILL") ? (int)strtol(getenv("HYPO_EMU_FILL"), nullptr, 0) : 0xA5;
+        memset(job.mem, fill, hypo::PoaLayout<Cfg>::BYTES);
         job.fast = (char*)malloc(hypo::PoaLayout<Cfg>::FAST_BYTES);
-        memset(job.fast, 0x5A, hypo::PoaLayout<Cfg>::FAST_BYTES);
+        memset(job.fast, fill ^ 0xFF, hypo::PoaLayout<Cfg>::FAST_BYTES);
         job.w = w; job.cells = job.aligns = 0;
         run_group(s, Cfg::GW, lane_body<Cfg>, &job);
         for (int l = 1; l < Cfg::GW; ++l) if (job.rc[l] != job.rc[0]) { fprintf(stderr, "[emu] lanes disagree on the result of window %u\n", w); abort(); }

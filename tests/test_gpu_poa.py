@@ -164,3 +164,14 @@ def test_long_windows_vs_oracle(gpu, oracle_lib):
     ocons, ost, _, _ = oracle_lib.poa_batch(b)
     assert list(st) == list(ost) == [0] * len(ws)
     assert cons == ocons
+
+
+def test_branch_completion_tie(gpu):
+    """LONG window whose heaviest-bundle end node is not a sink: branch completion (graph.cpp:660-705) meets two in-edges of
+    equal weight whose sources score the same, and the later one must win.  An earlier form of that loop was compiled wrongly
+    for the device (right in the CPU emulator); found by the messy end-to-end seeds."""
+    doc = gu.load_json("windows_branch_completion.json.gz")
+    for c in doc["windows"]:
+        w = TextWindow(c["draft"], c["internal"], c["prefix"], c["suffix"], n_empty=c["n_empty"], is_long=c["long"])
+        cons, st = gpu.poa_consensus(build_batch([w]), tuple(c["scores"]))
+        assert st[0] == 0 and cons[0] == c["consensus"], c["tag"]

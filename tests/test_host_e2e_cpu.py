@@ -32,3 +32,8 @@ def test_e2e_bam_input_gives_the_same_result(built, name, tmp_path):
     """alignments as BAM (BGZF blocks, binary records, NM as a small-integer tag) instead of SAM text"""
     man, _ = eu.run_case(name, tmp_path, "shim", as_bam=True)
     eu.check_outputs(name, tmp_path, man)
+
+
+@pytest.mark.parametrize("seed", sorted(eu.messy_seeds())[:12])
+def test_e2e_messy_seeds_match_reference(built, seed, tmp_path):
+    eu.run_messy_seed(seed, eu.messy_seeds()[seed], tmp_path, "shim")

@@ -85,3 +85,12 @@ def test_consensus_slot_overflow(oracle_lib):
     off = np.array([0, 4], dtype=np.uint64)
     cons, st, _, _ = oracle_lib.poa_batch(b, off=off)
     assert st[0] == 1 and cons[0] is None
+
+
+def test_oracle_branch_completion_windows(oracle_lib):
+    """the LONG windows that exercise branch completion with a score tie (expected values from the real reference)"""
+    from hypo_amd.batch import TextWindow, build_batch
+    doc = gu.load_json("windows_branch_completion.json.gz")
+    for c in doc["windows"]:
+        w = TextWindow(c["draft"], c["internal"], c["prefix"], c["suffix"], n_empty=c["n_empty"], is_long=c["long"])
+        assert oracle_lib.poa_batch(build_batch([w]), scores=tuple(c["scores"]))[0][0] == c["consensus"], c["tag"]
