@@ -1,0 +1,80 @@
+"""Randomised windows far from the benchmark shapes, device against the oracle: arms much shorter or longer than the window,
+0-15 % error, no internal arms, prefix/suffix only, N in the draft, LONG windows of every flavour, odd score sets.  These
+shapes reach the rarely taken paths (branch completion, weight ties, literal toposort, class escalation, curate)."""
+import numpy as np
+import pytest
+
+from hypo_amd import capi
+from hypo_amd.batch import TextWindow, build_batch
+
+pytestmark = pytest.mark.gpu
+A = "ACGT"
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import os
+    return capi.HypoGpu(0, path=os.environ["HYPO_GPU_LIB"]) if os.environ.get("HYPO_GPU_LIB") else capi.HypoGpu(0)
+
+
+def _mutate(rng, s, err):
+    out = []
+    for ch in s:
+        r = rng.random()
+        if r < err / 3:
+            continue                                            # deletion
+        if r < 2 * err / 3:
+            out.append(A[rng.integers(4)])                      # substitution (may be silent)
+        else:
+            out.append(ch)
+        if rng.random() < err / 3:
+            out.append(A[rng.integers(4)])                      # insertion
+    return "".join(out) or "A"
+
+
+def _window(rng, is_long):
+    L = int(rng.choice([6, 12, 25, 40, 70, 100, 140, 190])) if not is_long else int(rng.choice([120, 200, 330, 480]))
+    truth = "".join(A[i] for i in rng.integers(0, 4, size=L))
+    draft = list(_mutate(rng, truth, 0.02))
+    if rng.random() < 0.15 and not is_long:
+        draft[rng.integers(len(draft))] = "N"
+    draft = "".join(draft)
+    err = float(rng.choice([0.0, 0.01, 0.05, 0.15]))
+    narm = int(rng.integers(2, 14 if is_long else 40))
+    kind = rng.choice(["internal", "mixed", "prefix", "suffix", "presuf"])
+    internal, prefix, suffix = [], [], []
+    for _ in range(narm):
+        k = kind if kind != "mixed" else rng.choice(["internal", "prefix", "suffix"])
+        if kind == "presuf":
+            k = rng.choice(["prefix", "suffix"])
+        if k == "internal":
+            internal.append(_mutate(rng, truth, err))
+        elif k == "prefix":
+            cut = int(rng.integers(max(1, L // 10), L + 1))
+            prefix.append(_mutate(rng, truth[:cut], err))
+        else:
+            cut = int(rng.integers(0, L - max(1, L // 10) + 1))
+            suffix.append(_mutate(rng, truth[cut:], err))
+    n_empty = int(rng.integers(0, 3)) if rng.random() < 0.1 else 0
+    return TextWindow(draft, internal, prefix, suffix, n_empty=n_empty, is_long=is_long)
+
+
+@pytest.mark.parametrize("seed,is_long,n,scores", [
+    (1, False, 3000, (5, -4, -8, 3, -5, -4)),
+    (2, False, 1500, (3, -6, -5, 3, -5, -4)),
+    (3, False, 800, (1, -1, -1, 1, -1, -1)),
+    (4, True, 400, (5, -4, -8, 3, -5, -4)),
+    (5, True, 300, (5, -4, -8, 2, -3, -2)),
+    (6, True, 200, (5, -4, -8, 1, -1, -1)),
+])
+def test_random_windows_vs_oracle(gpu, oracle_lib, seed, is_long, n, scores):
+    rng = np.random.default_rng(seed)
+    wins = [_window(rng, is_long) for _ in range(n)]
+    b = build_batch(wins)
+    cons, st = gpu.poa_consensus(b, scores)
+    ocons, ost = oracle_lib.poa_batch(b, scores=scores)[:2]
+    bad = [i for i in range(n) if cons[i] != ocons[i] or st[i] != ost[i]]
+    assert not bad, (f"{len(bad)} of {n} windows differ; first: window {bad[0]} draft {len(wins[bad[0]].draft)} bp, "
+                     f"{len(wins[bad[0]].internal)}/{len(wins[bad[0]].prefix)}/{len(wins[bad[0]].suffix)} arms, long={is_long}")
+    s = gpu.last_stats()
+    assert s["n_failed"] == 0
