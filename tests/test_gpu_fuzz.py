@@ -32,8 +32,8 @@ def _mutate(rng, s, err):
     return "".join(out) or "A"
 
 
-def _window(rng, is_long):
-    L = int(rng.choice([6, 12, 25, 40, 70, 100, 140, 190])) if not is_long else int(rng.choice([120, 200, 330, 480]))
+def _window(rng, is_long, huge=False):
+    L = int(rng.choice([6, 12, 25, 40, 70, 100, 140, 190])) if not is_long else int(rng.choice([700, 900] if huge else [120, 200, 330, 480]))
     truth = "".join(A[i] for i in rng.integers(0, 4, size=L))
     draft = list(_mutate(rng, truth, 0.02))
     if rng.random() < 0.15 and not is_long:
@@ -78,3 +78,16 @@ def test_random_windows_vs_oracle(gpu, oracle_lib, seed, is_long, n, scores):
                      f"{len(wins[bad[0]].internal)}/{len(wins[bad[0]].prefix)}/{len(wins[bad[0]].suffix)} arms, long={is_long}")
     s = gpu.last_stats()
     assert s["n_failed"] == 0
+
+
+def test_windows_beyond_the_long_class(gpu, oracle_lib):
+    """LONG windows of 700-900 bp (more than the LONG class's 639 columns) and short windows with 300 arms: the catch-all class."""
+    rng = np.random.default_rng(77)
+    wins = [_window(rng, True, huge=True) for _ in range(48)]
+    truth = "".join(A[i] for i in rng.integers(0, 4, size=60))
+    wins += [TextWindow(truth, [_mutate(rng, truth, 0.05) for _ in range(300)], [], []) for _ in range(4)]
+    b = build_batch(wins)
+    cons, st = gpu.poa_consensus(b, (5, -4, -8, 3, -5, -4))
+    ocons, ost = oracle_lib.poa_batch(b)[:2]
+    assert [i for i in range(len(wins)) if cons[i] != ocons[i] or st[i] != ost[i]] == []
+    assert gpu.last_stats()["n_class"][5] >= 48
