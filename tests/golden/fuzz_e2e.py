@@ -2,7 +2,7 @@
 """Differential fuzz (build container only): `gen_e2e.generate_messy(seed)` inputs through the REAL reference binary
 (HYPO_REF_BIN, built per SURVEY.md Appendix B; HYPO_REF_LD = its htslib directory) and through this repo's `hypo` over
 the oracle shim; the polished FASTA must be byte-identical.   usage: fuzz_e2e.py <first seed> <last seed (exclusive)>
-Seeds 100-169 were run in round 1 without a mismatch; two of them are committed as `e2e_messy_*` goldens."""
+Seeds 100-259 were run in round 1 without a mismatch; two of them are committed as `e2e_messy_*` goldens."""
 import os
 import shutil
 import subprocess
