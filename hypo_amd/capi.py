@@ -138,8 +138,9 @@ class HypoGpu:
         return out
 
     # ---- device-resident entry points (torch tensors own the HBM) --------------------------------------
-    def device_batch(self, b: HostBatch, off=None):
-        return DeviceBatch(self, b, off)
+    def device_batch(self, b: HostBatch, off=None, workspace_bytes=None):
+        """workspace_bytes: None = the size hypo_gpu_poa_workspace_bytes recommends"""
+        return DeviceBatch(self, b, off, workspace_bytes)
 
     def device_scan(self, packed4: np.ndarray, n_bases: int, k: int, bits: np.ndarray, kids_cap=None):
         return DeviceScan(self, packed4, n_bases, k, bits, kids_cap)
@@ -169,7 +170,7 @@ def _t(arr, dev):
 class DeviceBatch:
     """A window batch resident in HBM + its output buffers and workspace (torch owns the memory)."""
 
-    def __init__(self, gpu: HypoGpu, b: HostBatch, off=None):
+    def __init__(self, gpu: HypoGpu, b: HostBatch, off=None, workspace_bytes=None):
         import torch
         self.gpu, self.host = gpu, b
         dev = torch.device("cuda", gpu.device)
@@ -185,6 +186,8 @@ class DeviceBatch:
         self.len = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
         self.status = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)
         wsb = int(gpu.lib.hypo_gpu_poa_workspace_bytes(C.c_uint32(n), C.c_uint32(b.n_arms)))
+        if workspace_bytes is not None:
+            wsb = int(workspace_bytes)
         self.workspace = torch.zeros(wsb, dtype=torch.uint8, device=dev)
         s = abi.WindowBatch()
         s.n_windows, s.n_arms = n, b.n_arms

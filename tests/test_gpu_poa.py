@@ -175,3 +175,25 @@ def test_branch_completion_tie(gpu):
         w = TextWindow(c["draft"], c["internal"], c["prefix"], c["suffix"], n_empty=c["n_empty"], is_long=c["long"])
         cons, st = gpu.poa_consensus(build_batch([w]), tuple(c["scores"]))
         assert st[0] == 0 and cons[0] == c["consensus"], c["tag"]
+
+
+def test_smaller_workspace_limits_only_residency(gpu, oracle_lib):
+    """The HBM scratch follows the workspace the caller gives: the 16-group minimum still polishes 150 LONG windows correctly,
+    anything smaller is refused with HYPO_E_WORKSPACE (include/hypo_gpu.h)."""
+    longs = [gu.to_window(r) for r in gu.load_jsonl("windows_real_long.jsonl.gz") if r["long"]]
+    b = build_batch((longs * 13)[:150])
+    n = b.n_windows
+    rec = int(gpu.lib.hypo_gpu_poa_workspace_bytes(C.c_uint32(n), C.c_uint32(0)))
+    prefix = 8192 + (6 * n * 4 + 255) // 256 * 256 + (2 * n + 255) // 256 * 256
+    # the error message of a hopelessly small workspace names the minimum
+    with pytest.raises(capi.HypoGpuError) as ei:
+        gpu.device_batch(b, workspace_bytes=prefix).run()
+    minimal = int(str(ei.value).split("minimum ")[1].split(" ")[0])
+    assert prefix < minimal < rec
+    db = gpu.device_batch(b, workspace_bytes=minimal)
+    db.run()
+    bases, off, ln, st = db.results()
+    ob, _, oln, ost, _, _ = oracle_lib.poa_batch_raw(b, off=off)
+    assert (st == ost).all() and (ln == oln).all() and _same_consensus(bases, ob, off, ln)
+    with pytest.raises(capi.HypoGpuError):
+        gpu.device_batch(b, workspace_bytes=minimal - 4096).run()
