@@ -216,6 +216,7 @@ struct Poa {
     // group-uniform state
     int n_nodes; int L; bool topo_dirty; bool meta_dirty; int maxdelta;
     int tb_steps; int tb_fv;
+    int need_nodes;                                          // after RES_OVERFLOW of a SHORT window: projected node count (0 = unknown)
     bool last_changed;         // did the most recent add_alignment change the graph topology?
     uint64_t cells, aligns, reused, rows_done, topo_runs, cons_serial;
     uint64_t tphase[PH_N]; uint64_t tlast;
@@ -1229,6 +1230,18 @@ struct Poa {
         if (rc != RES_OK) return rc;
         bool prev_aligned = false;                           // the previous non-reused sequence went through align()
         int s = 0;
+        need_nodes = 0;
+        // A window that outgrows this class's node table says how many nodes it will probably need, so that it is re-queued
+        // straight into a class that holds it instead of climbing one class at a time: the sequences added so far grew the
+        // graph from its first chain of `chain0` nodes to n_nodes, the remaining ones are assumed to add as many each.
+        int chain0 = 0;
+        auto project = [&](int rc_) -> int {
+            if (rc_ == RES_OVERFLOW && s > 0 && n_nodes > 0) {
+                const int grown = n_nodes - chain0 > 0 ? n_nodes - chain0 : 0;
+                need_nodes = n_nodes + (int)(((int64_t)grown * (n_seq - s) + s - 1) / s) + 4;
+            }
+            return rc_;
+        };
         while (s < n_seq) {
             if (prev_aligned && !last_changed && tb_steps != 0 && tb_fv == 0) {
                 // run of arms identical to the one just aligned: L and posnode[] are still its path
@@ -1236,7 +1249,7 @@ struct Poa {
                 while (s < n_seq && same_as_previous(s)) { ++c; ++s; }
                 if (c) {
                     cells += (uint64_t)c * (uint64_t)(n_nodes + 1) * (L + 1); aligns += c; reused += c;   // work the reference does
-                    if ((rc = readd_alignment(c)) != RES_OK) return rc;
+                    if ((rc = readd_alignment(c)) != RES_OK) return project(rc);
                     HYPO_TICK(PH_ADD);
                     if (s >= n_seq) break;
                 }
@@ -1245,7 +1258,8 @@ struct Poa {
             if ((rc = load_seq(W, s, &mode)) != RES_OK) return rc;
             ++s;
             if (L == 0) { prev_aligned = false; continue; }  // zero-length arms are skipped (Window.cpp:100,113,124)
-            if ((rc = add_sequence_step(mode, m, n, gp)) != RES_OK) return rc;
+            if ((rc = add_sequence_step(mode, m, n, gp)) != RES_OK) return project(rc);
+            if (chain0 == 0) chain0 = n_nodes;
             prev_aligned = true;
         }
         if (!added) return emit_draft(w, d4, (int)W.draft_len);
@@ -1266,7 +1280,7 @@ struct Poa {
     HD int run(uint32_t w) {
         // the object outlives the window (one per persistent group): per-window counters and flags start over here
         cells = 0; aligns = 0; reused = 0; rows_done = 0; topo_runs = 0; cons_serial = 0; last_changed = true;
-        n_paths = 0; path_used = 0; head_first = 0; L = 0; maxdelta = 0; tb_steps = 0; tb_fv = 0;
+        n_paths = 0; path_used = 0; head_first = 0; L = 0; maxdelta = 0; tb_steps = 0; tb_fv = 0; need_nodes = 0;
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
         HYPO_TICK_RESET();
         const HypoWindow W = P->windows[w];

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include "poa_classes.hpp"
 #include "poa_kernel.hpp"
+#include <cstring>
 
 namespace hypo {
 
@@ -193,9 +194,20 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through t
                 abytes += a;
             }
         } else if ((rc == RES_OVERFLOW || rc == RES_UNSUPPORTED) && cls + 1 < kNumPoaClasses) {
+            // next class, or the first later SHORT class whose node table holds what the window projects to need
+            // (every later class is finished after this one: see the launch order in poa_run)
+            int to = cls + 1;
+            if (rc == RES_OVERFLOW && poa.need_nodes > 0) {
+                constexpr int nmax[kNumPoaClasses] = {
+#define HYPO_NMAX(ID, CFG) CFG::NMAX,
+                    HYPO_FOR_EACH_CLASS(HYPO_NMAX)
+#undef HYPO_NMAX
+                };
+                while (to + 1 < kFirstLongClass && nmax[to] < poa.need_nodes) ++to;
+            }
             if (g.lane == 0) {
-                const uint32_t slot = atomicAdd(&fresh(ka)->Q.count[cls + 1], 1u);
-                fresh(ka)->Q.items[(size_t)(cls + 1) * fresh(ka)->Q.stride + slot] = w;
+                const uint32_t slot = atomicAdd(&fresh(ka)->Q.count[to], 1u);
+                fresh(ka)->Q.items[(size_t)to * fresh(ka)->Q.stride + slot] = w;
             }
             ++n_esc;
         } else {
@@ -339,16 +351,31 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
     // dispatch even if every wave leaves at once, and these classes are empty in most batches (a few escalated windows still
     // find a small grid waiting).
     if (!A->planned_host) {
-        if ((e = hipHostMalloc((void**)&A->planned_host, 8 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return e;
+        if ((e = hipHostMalloc((void**)&A->planned_host, 24 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return e;
+        memset(A->planned_host, 0, 24 * sizeof(uint32_t));
         if ((e = hipEventCreateWithFlags(&A->planned_ev, hipEventDisableTiming)) != hipSuccess) return e;
     }
     uint32_t* const planned_host = A->planned_host;
     const hipEvent_t planned_ev = A->planned_ev;
     if ((e = hipMemcpyAsync(planned_host, Q.planned, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
     (void)hipEventRecord(planned_ev, stream);
+    // Windows re-queued into a class are only known on the device.  The grids of the mop-up passes and of the rare classes
+    // are sized from what the plan put there plus what the LAST finished call saw arrive later (its counters come back
+    // asynchronously at the end of every call): batches of one run look alike, and noisier reads re-queue many windows (at 1 %
+    // read error 3 % of the windows outgrow their class).  Without history a floor of a few hundred waves applies.
+    const uint32_t* const last_count = planned_host + 8;
+    const uint32_t* const last_planned = planned_host + 16;
+    auto late_arrivals = [&](int cls) -> uint32_t {
+        const uint32_t seen = last_count[cls] > last_planned[cls] ? last_count[cls] - last_planned[cls] : 0u;
+        // the mop-up passes of classes 1 and 2 are launched on the side streams, where the dispatch of idle waves (they leave
+        // after one look at the queue) costs nothing: they get a generous floor.  Class 3 and later start on the caller's stream.
+        const uint32_t floor = cls < 3 ? (n_windows / 8 > 256 ? n_windows / 8 : 256) : 256;
+        const uint32_t want = seen + seen / 2 + floor;
+        return want < n_windows ? want : n_windows;
+    };
     auto rare_grid_hint = [&](int cls) -> uint32_t {         // windows to size the grid of a rare class for
-        const uint32_t planned = planned_host[cls];
-        return planned ? (planned + 64 < n_windows ? planned + 64 : n_windows) : 64u;
+        const uint64_t want = (uint64_t)planned_host[cls] + late_arrivals(cls);
+        return (uint32_t)(want < n_windows ? want : n_windows);
     };
     // Every class is launched with a grid sized for the whole batch: how many windows a class receives is only
     // known on the device (plan + escalations), and an idle persistent wave exits after one failed dequeue.
@@ -399,10 +426,10 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
         // Mop-up of re-queued windows (normally a handful): a class's mop-up pass only needs its PREDECESSOR to be finished
         // (its own first pass works on the disjoint slot range [0, planned)), so it runs behind the predecessor on that
         // stream and hides under the longer first passes instead of forming a serial tail.
-        if ((e = launch_class<PoaClass1, true>(P, Q, 1, 1024, scratch, num_cus, 0, aux[0], 1, true)) != hipSuccess) return e;
+        if ((e = launch_class<PoaClass1, true>(P, Q, 1, late_arrivals(1), scratch, num_cus, 0, aux[0], 4, true)) != hipSuccess) return e;
         (void)hipEventRecord(join_ev[0], aux[0]);
         (void)hipStreamWaitEvent(aux[1], join_ev[0], 0);
-        if ((e = launch_class<PoaClass2, true>(P, Q, 2, 1024, scratch, num_cus, 0, aux[1], 1, true)) != hipSuccess) return e;
+        if ((e = launch_class<PoaClass2, true>(P, Q, 2, late_arrivals(2), scratch, num_cus, 0, aux[1], 6, true)) != hipSuccess) return e;
         (void)hipEventRecord(join_ev[1], aux[1]);
         (void)hipStreamWaitEvent(stream, join_ev[0], 0);
         (void)hipStreamWaitEvent(stream, join_ev[1], 0);
@@ -414,7 +441,7 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
         const bool long_first_pass = planned_host[4] > 0;
         if (long_first_pass) {
             rec(2 + 2 * 4, aux[2]);
-            if ((e = launch_class<PoaClass4, false>(P, Q, 4, rare_grid_hint(4), scratch, num_cus, groups4, aux[2], 8)) != hipSuccess) return e;
+            if ((e = launch_class<PoaClass4, false>(P, Q, 4, planned_host[4], scratch, num_cus, groups4, aux[2], 8)) != hipSuccess) return e;
             rec(3 + 2 * 4, aux[2]);
             (void)hipEventRecord(join_ev[2], aux[2]);
         }
@@ -423,7 +450,7 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
         rec(3 + 2 * 3, stream);
         if (long_first_pass) {
             (void)hipStreamWaitEvent(stream, join_ev[2], 0);
-            if ((e = launch_class<PoaClass4, false>(P, Q, 4, 64, scratch, num_cus, groups4, stream, 1, true)) != hipSuccess) return e;
+            if ((e = launch_class<PoaClass4, false>(P, Q, 4, late_arrivals(4), scratch, num_cus, groups4, stream, 8, true)) != hipSuccess) return e;
         } else {
             rec(2 + 2 * 4, stream);
             if ((e = launch_class<PoaClass4, false>(P, Q, 4, rare_grid_hint(4), scratch, num_cus, groups4, stream)) != hipSuccess) return e;
@@ -433,6 +460,9 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
         if ((e = launch_class<PoaClass5, false>(P, Q, 5, rare_grid_hint(5), scratch, num_cus, groups5, stream)) != hipSuccess) return e;
         rec(3 + 2 * 5, stream);
     }
+    // this call's final and planned counts for the next call's grid sizes (no wait: whoever reads them gets the last finished call)
+    (void)hipMemcpyAsync(planned_host + 8, Q.count, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    (void)hipMemcpyAsync(planned_host + 16, Q.planned, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
     rec(2 + 2 * kNumPoaClasses, stream);
     pe = 3 + 2 * kNumPoaClasses;
     if (prof) prof->n = pe;

@@ -44,7 +44,7 @@ struct KernelEvents { hipEvent_t ev[16]; int n; };
 struct PoaAux {
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr}, planned_ev = nullptr;
-    uint32_t* planned_host = nullptr;
+    uint32_t* planned_host = nullptr;     // [0..7] planned counts of this call, [8..15] final counts and [16..23] planned counts of the last finished call
 };
 void poa_release(PoaAux* a);
 
