@@ -162,4 +162,48 @@ HD int popc64(uint64_t x) { return __popcll(x); }
 HD int ctz64(uint64_t x) { return __ffsll((unsigned long long)x) - 1; }
 #endif
 
+// ---- packed pairs of int16 (two neighbouring DP columns in one register) -------------------------------------
+// Device: VOP3P packed math (v_pk_add_u16, v_pk_max_i16, v_pk_min_u16, v_pk_mad_u16), v_alignbit / v_perm to move halves.
+// All arithmetic wraps modulo 2^16.  The emulator restates every operation on two scalars.
+#ifdef HYPO_EMU
+struct P2 { int16_t lo, hi; };
+HD P2 pk_make(int lo, int hi) { return P2{(int16_t)lo, (int16_t)hi}; }
+HD P2 pk_splat(int x) { return P2{(int16_t)x, (int16_t)x}; }
+HD int pk_lo(P2 a) { return a.lo; }
+HD int pk_hi(P2 a) { return a.hi; }
+HD int pk_bits(P2 a) { return (int)((uint32_t)(uint16_t)a.lo | ((uint32_t)(uint16_t)a.hi << 16)); }
+HD P2 pk_from_bits(int b) { return P2{(int16_t)(uint16_t)((uint32_t)b & 0xffffu), (int16_t)(uint16_t)((uint32_t)b >> 16)}; }
+HD P2 pk_add(P2 a, P2 b) { return P2{(int16_t)(uint16_t)((uint16_t)a.lo + (uint16_t)b.lo), (int16_t)(uint16_t)((uint16_t)a.hi + (uint16_t)b.hi)}; }
+HD P2 pk_sub(P2 a, P2 b) { return P2{(int16_t)(uint16_t)((uint16_t)a.lo - (uint16_t)b.lo), (int16_t)(uint16_t)((uint16_t)a.hi - (uint16_t)b.hi)}; }
+HD P2 pk_max(P2 a, P2 b) { return P2{a.lo > b.lo ? a.lo : b.lo, a.hi > b.hi ? a.hi : b.hi}; }
+HD P2 pk_minu(P2 a, P2 b) { return P2{(int16_t)((uint16_t)a.lo < (uint16_t)b.lo ? a.lo : b.lo), (int16_t)((uint16_t)a.hi < (uint16_t)b.hi ? a.hi : b.hi)}; }
+HD P2 pk_mad(P2 a, P2 b, P2 c) {
+    return P2{(int16_t)(uint16_t)((uint32_t)(uint16_t)a.lo * (uint16_t)b.lo + (uint16_t)c.lo), (int16_t)(uint16_t)((uint32_t)(uint16_t)a.hi * (uint16_t)b.hi + (uint16_t)c.hi)};
+}
+HD P2 pk_xor(P2 a, P2 b) { return pk_from_bits(pk_bits(a) ^ pk_bits(b)); }
+// (lo, hi) = (a.hi, b.lo): the pair one column to the left of b, a being the pair before it
+HD P2 pk_shift_in(P2 a, P2 b) { return P2{a.hi, b.lo}; }
+HD P2 pk_hi_splat(P2 a) { return P2{a.hi, a.hi}; }
+// hi = max(hi, lo), lo unchanged
+HD P2 pk_fold_hi(P2 a) { return P2{a.lo, a.hi > a.lo ? a.hi : a.lo}; }
+#else
+typedef short P2 __attribute__((ext_vector_type(2)));
+typedef unsigned short P2u __attribute__((ext_vector_type(2)));
+HD P2 pk_from_bits(int b) { return __builtin_bit_cast(P2, b); }
+HD int pk_bits(P2 a) { return __builtin_bit_cast(int, a); }
+HD P2 pk_make(int lo, int hi) { return pk_from_bits((int)(((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16))); }
+HD P2 pk_splat(int x) { return pk_make(x, x); }
+HD int pk_lo(P2 a) { return (int)a.x; }
+HD int pk_hi(P2 a) { return (int)a.y; }
+HD P2 pk_add(P2 a, P2 b) { return a + b; }
+HD P2 pk_sub(P2 a, P2 b) { return a - b; }
+HD P2 pk_max(P2 a, P2 b) { return __builtin_elementwise_max(a, b); }
+HD P2 pk_minu(P2 a, P2 b) { return __builtin_bit_cast(P2, __builtin_elementwise_min(__builtin_bit_cast(P2u, a), __builtin_bit_cast(P2u, b))); }
+HD P2 pk_mad(P2 a, P2 b, P2 c) { return a * b + c; }
+HD P2 pk_xor(P2 a, P2 b) { return pk_from_bits(pk_bits(a) ^ pk_bits(b)); }
+HD P2 pk_shift_in(P2 a, P2 b) { return pk_from_bits((int)__builtin_amdgcn_alignbit((uint32_t)pk_bits(b), (uint32_t)pk_bits(a), 16)); }
+HD P2 pk_hi_splat(P2 a) { return pk_from_bits((int)__builtin_amdgcn_perm((uint32_t)pk_bits(a), (uint32_t)pk_bits(a), 0x07060706u)); }
+HD P2 pk_fold_hi(P2 a) { return pk_max(a, pk_from_bits((int)(((uint32_t)pk_bits(a) << 16) | 0x8000u))); }
+#endif
+
 }  // namespace hypo

@@ -184,6 +184,11 @@ struct Poa {
     static constexpr int GW = Cfg::GW, CPL = Cfg::CPL, KIN = Cfg::KIN, NMAX = Cfg::NMAX, AL = Cfg::AL;
     static constexpr bool NIB = Cfg::NIB;
     static constexpr int NEG = -(1 << 29);
+    // int16 score rows as packed pairs of columns (rows_pk below); HYPO_PACKED=0 builds the one-column-per-register loop everywhere
+#ifndef HYPO_PACKED
+#define HYPO_PACKED 1
+#endif
+    static constexpr bool PK = HYPO_PACKED && sizeof(typename Cfg::score_t) == 2 && Cfg::CPL % 2 == 0 && Cfg::CPL <= 8 && !Cfg::HYBRID && Cfg::NIB;
     // direction codes
     static constexpr int DIR_FAST = NIB ? 15 : 0xFF;     // diagonal via pred 0 and pred 0 is the previous row
     static constexpr int DIR_HORIZ = NIB ? 14 : 0xFE;
@@ -408,6 +413,191 @@ struct Poa {
 
     // ---- engine->align (sisd_alignment_engine.cpp:246-439), linear gaps -----------------------------
     // Leaves posnode[q] (graph node aligned to sequence position q, -1 = insertion) for q in
+    // ---- the row loop on packed pairs of int16 columns (classes with int16 rows, nibble codes, even CPL) ------------
+    // Same recurrence, same tie rules and same direction codes as the loop in align(); two neighbouring columns share one
+    // register and every select is arithmetic (t = min_u16(a - b, 1) is 0 where a == b and 1 where a > b), so a row costs
+    // about 2/3 of the one-column-per-register form.  Values stay exact because align() admits only windows whose scores
+    // and `H - j*g` terms fit 16 bits.  NEG16 + a score never wraps and stays below every real cell.
+    struct alignas(pow2_of(CPL * 2) < 4 ? 4 : pow2_of(CPL * 2)) PackP { P2 v[CPL / 2 ? CPL / 2 : 1]; };
+    HD int rows_pk(int mode, int m, int n, int gp, int S, int R) {
+        constexpr int NP = CPL / 2;
+        const int j0 = CPL * g.lane;
+        int amax = m < 0 ? -m : m; { const int b = n < 0 ? -n : n, c2 = gp < 0 ? -gp : gp; amax = amax > b ? amax : b; amax = amax > c2 ? amax : c2; }
+        const int NEG16 = -32768 + amax;
+        P2 SQ[NP], JG[NP], LAST[NP];
+        HYPO_UNROLL
+        for (int q = 0; q < NP; ++q) {
+            const int j = j0 + 2 * q;
+            const int s0 = (j >= 1 && j <= L) ? (int)seq[j - 1] : (int)C_NONE;
+            const int s1 = (j + 1 <= L) ? (int)seq[j] : (int)C_NONE;
+            SQ[q] = pk_make(s0, s1);
+            JG[q] = pk_make(j * gp, (j + 1) * gp);           // row 0: H[0][j] = j*g (sisd..cpp:197-199,230-232)
+            LAST[q] = JG[q];
+        }
+        int vM = pk_bits(pk_splat(m)), vMN = pk_bits(pk_splat(n - m)), vGP = pk_bits(pk_splat(gp)), vONE = pk_bits(pk_splat(1));
+        HYPO_IN_VGPR(vM); HYPO_IN_VGPR(vMN); HYPO_IN_VGPR(vGP); HYPO_IN_VGPR(vONE);
+        const P2 M = pk_from_bits(vM), MN = pk_from_bits(vMN), GP = pk_from_bits(vGP), ONE = pk_from_bits(vONE);
+        const int negfill = pk_bits(pk_splat(NEG16));
+        // kROV: first column is 0 (sisd..cpp:200-211,237-239): lane 0 clears the low half of its first pair
+        const int keep0 = (g.lane == 0 && mode == MODE_ROV) ? (int)0xffff0000u : -1;
+
+        const int le = L / CPL, ce = L % CPL;               // owner of the last column
+        int best = NEG, best_i = -1;
+        int slot = 0, slotS = 0, rowS = 0;
+        const int RS = R * S;
+        constexpr int MREG = (NMAX + GW - 1) / GW;
+        constexpr bool META_IN_REGS = (GW == 64) && (MREG <= 4);
+        uint32_t mreg[META_IN_REGS ? MREG : 1];
+        if (META_IN_REGS) {
+            HYPO_UNROLL
+            for (int q = 0; q < (META_IN_REGS ? MREG : 1); ++q) {
+                const int rr = q * GW + g.lane;
+                mreg[q] = rr < n_nodes ? rowmeta[rr] : 0u;
+            }
+            HYPO_UNROLL
+            for (int q = 0; q < (META_IN_REGS ? MREG : 1); ++q) HYPO_ARRIVED(mreg[q]);
+        }
+        constexpr bool META_CHUNKED = (GW == 64) && !META_IN_REGS;
+        uint32_t mchunk = 0u;
+        uint32_t meta_a = (META_IN_REGS || META_CHUNKED) ? 0u : rowmeta[0];
+        uint32_t meta_b = (!META_IN_REGS && !META_CHUNKED && n_nodes > 1) ? rowmeta[1] : 0u;
+        auto load_pk = [&](int off, P2 (&out)[NP]) {
+            if (j0 < S) {
+                const PackP pk = *(const PackP*)(ring + off + j0);
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) out[q] = pk.v[q];
+            } else {
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) out[q] = pk_from_bits(negfill);
+            }
+        };
+        for (int r = 0; r < n_nodes; ++r) {
+            const int i = r + 1;
+            uint32_t meta;
+            if (META_CHUNKED) {
+                if ((r & 63) == 0) { mchunk = r + g.lane < n_nodes ? rowmeta[r + g.lane] : 0u; HYPO_ARRIVED(mchunk); }
+                meta = (uint32_t)g.shfl((int)mchunk, r & 63);
+            } else if (META_IN_REGS) {
+                uint32_t mv = mreg[0];
+                HYPO_UNROLL
+                for (int q = 1; q < (META_IN_REGS ? MREG : 1); ++q) if ((r / GW) == q) mv = mreg[q];
+                meta = (uint32_t)g.shfl((int)mv, r % GW);
+            } else {
+                meta = meta_a;
+                meta_a = meta_b;
+                if (r + 2 < n_nodes) meta_b = rowmeta[r + 2];
+            }
+            const int cd = (int)(meta & 0xff), k = (int)((meta >> 8) & 0xff);
+            const bool sink = (meta >> 16) & 1;
+            const int p0 = meta_p0(meta);                    // 0 when k == 0 (virtual source row)
+            const bool fastrow = p0 == i - 1;
+            const int fastcode = fastrow ? (int)DIR_FAST : dir_diag(0);
+            P2 MV[NP];                                       // match / mismatch score per column
+            {
+                const P2 CD = pk_splat(cd);
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) MV[q] = pk_mad(pk_minu(pk_xor(SQ[q], CD), ONE), MN, M);
+            }
+            P2 D[NP], U[NP], cD[NP], cU[NP];
+            {
+                P2 hp[NP];
+                if (fastrow) { HYPO_UNROLL for (int q = 0; q < NP; ++q) hp[q] = LAST[q]; }
+                else if (p0 == 0) { HYPO_UNROLL for (int q = 0; q < NP; ++q) hp[q] = JG[q]; }
+                else { int ps = slotS - (i - p0) * S; ps = ps < 0 ? ps + RS : ps; load_pk(ps, hp); }
+                const P2 nb = pk_from_bits(g.shfl_up1(pk_bits(hp[NP - 1]), negfill));
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) {
+                    D[q] = pk_add(pk_shift_in(q ? hp[q - 1] : nb, hp[q]), MV[q]);
+                    U[q] = pk_add(hp[q], GP);
+                }
+            }
+            if (k > 1) {                                     // several predecessors: remember which one reaches each maximum first
+                P2 pD[NP], pU[NP];
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) { pD[q] = pk_splat(0); pU[q] = pk_splat(0); }
+                for (int p = 1; p < k; ++p) {
+                    P2 hp[NP];
+                    const int pr = g.uniform(pred_row(r, p));
+                    { int ps = slotS - (i - pr) * S; ps = ps < 0 ? ps + RS : ps; load_pk(ps, hp); }
+                    const P2 nb = pk_from_bits(g.shfl_up1(pk_bits(hp[NP - 1]), negfill));
+                    const P2 PP = pk_splat(p);
+                    HYPO_UNROLL
+                    for (int q = 0; q < NP; ++q) {
+                        const P2 d = pk_add(pk_shift_in(q ? hp[q - 1] : nb, hp[q]), MV[q]);
+                        const P2 u = pk_add(hp[q], GP);
+                        const P2 nd = pk_max(D[q], d), nu = pk_max(U[q], u);
+                        // strict: the first pred reaching the maximum wins
+                        pD[q] = pk_mad(pk_minu(pk_sub(nd, D[q]), ONE), pk_sub(PP, pD[q]), pD[q]);
+                        pU[q] = pk_mad(pk_minu(pk_sub(nu, U[q]), ONE), pk_sub(PP, pU[q]), pU[q]);
+                        D[q] = nd; U[q] = nu;
+                    }
+                }
+                const P2 FC = pk_splat(fastcode), V0 = pk_splat(dir_vert(0));
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) {               // nibble codes: dir_diag(p) = p, dir_vert(p) = dir_vert(0) + p
+                    cD[q] = pk_mad(pk_sub(ONE, pk_minu(pD[q], ONE)), FC, pD[q]);
+                    cU[q] = pk_add(pU[q], V0);
+                }
+            } else {
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) { cD[q] = pk_splat(fastcode); cU[q] = pk_splat(dir_vert(0)); }
+            }
+            P2 v[NP];
+            HYPO_UNROLL
+            for (int q = 0; q < NP; ++q) v[q] = pk_max(D[q], U[q]);
+            if (mode == MODE_ROV) v[0] = pk_from_bits(pk_bits(v[0]) & keep0);
+            // horizontal term H[i][j] = max(H[i][j], H[i][j-1] + g): prefix max of H[i][j] - j*g
+            {
+                P2 x[NP];
+                x[0] = pk_fold_hi(pk_sub(v[0], JG[0]));
+                HYPO_UNROLL
+                for (int q = 1; q < NP; ++q) x[q] = pk_fold_hi(pk_max(pk_sub(v[q], JG[q]), pk_hi_splat(x[q - 1])));
+                // the lane scan compares whole registers: the running maximum sits in the high half and decides, the low half
+                // only orders equal maxima and is dropped afterwards; INT_MIN, the scan's identity, reads as -32768 there
+                const int ex = g.scan_max_excl(pk_bits(x[NP - 1]), (int)0x80000000);
+                const P2 EX = pk_hi_splat(pk_from_bits(ex));
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) v[q] = pk_add(pk_max(x[q], EX), JG[q]);
+            }
+            if (j0 < S) {
+                // the reference's traceback preference (sisd..cpp:370-428): diagonal, else vertical, else horizontal
+                const P2 HZ = pk_splat(DIR_HORIZ);
+                uint32_t codes = 0;
+                PackP pk;
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) {
+                    const P2 tD = pk_minu(pk_sub(v[q], D[q]), ONE), tU = pk_minu(pk_sub(v[q], U[q]), ONE);
+                    const P2 dc = pk_mad(tD, pk_mad(tU, pk_sub(HZ, cU[q]), pk_sub(cU[q], cD[q])), cD[q]);
+                    const uint32_t b = (uint32_t)pk_bits(dc);
+                    codes |= ((b | (b >> 12)) & 0xffu) << (8 * q);
+                    pk.v[q] = v[q];
+                }
+                uint8_t* dst = dir + (rowS >> 1) + (j0 >> 1);         // S and j0 are even
+                if (NP == 1) *dst = (uint8_t)codes;
+                else if (NP == 2) *(uint16_t*)dst = (uint16_t)codes;
+                else *(uint32_t*)dst = codes;                // NP == 4 (NP == 3 is not instantiated)
+                *(PackP*)(ring + slotS + j0) = pk;
+            }
+            slot = slot + 1 == R ? 0 : slot + 1;
+            slotS = slot == 0 ? 0 : slotS + S;
+            rowS += S;
+            HYPO_UNROLL
+            for (int q = 0; q < NP; ++q) LAST[q] = v[q];
+            // end cell: first strictly greater in rank order (sisd..cpp:279-288,332-339)
+            if (mode == MODE_LOV || sink) {                  // group-uniform: most rows of kNW / kROV skip it
+                HYPO_NO_IFCVT();
+                if (g.lane == le) {
+                    int val = pk_lo(v[0]);
+                    HYPO_UNROLL
+                    for (int c = 1; c < CPL; ++c) if (c == ce) val = (c & 1) ? pk_hi(v[c / 2]) : pk_lo(v[c / 2]);
+                    if (val > best) { best = val; best_i = i; }
+                }
+            }
+            g.sync();
+        }
+        return g.shfl(best_i, le);
+    }
+
     // [tb_fv, L) and tb_steps (number of traceback steps; 0 = "empty alignment").
     HD int align(int mode, int m, int n, int gp) {
         tb_steps = 0; tb_fv = L;
@@ -420,12 +610,17 @@ struct Poa {
             int a = m < 0 ? -m : m, b = n < 0 ? -n : n, c2 = gp < 0 ? -gp : gp;
             a = a > b ? a : b; a = a > c2 ? a : c2;
             if (a * (n_nodes + L + 1) >= 32767) return RES_OVERFLOW;
+            if (PK && a * (n_nodes + 2 * L + CPL + 8) >= 32767) return RES_OVERFLOW;   // rows_pk: H - j*g and NEG16 + score in 16 bits
         }
         if (meta_dirty) { build_rowmeta(); HYPO_TICK(PH_META); }
         const int R = g.uniform(Cfg::RINGCELLS / S);        // ring rows; row i can still see rows i-R .. i-1
         if (R < maxdelta + 1 || R < 1) return RES_OVERFLOW;
         cells += (uint64_t)(n_nodes + 1) * W; aligns += 1; rows_done += (uint64_t)n_nodes;
 
+        int best_i = -1;
+        if constexpr (PK) {
+            best_i = rows_pk(mode, m, n, gp, S, R);
+        } else {
         HYPO_IN_VGPR(m); HYPO_IN_VGPR(n); HYPO_IN_VGPR(gp);
         const int j0 = CPL * g.lane;
         int sq[CPL];                                        // sq[c] = code of seq[j-1] for column j = j0+c
@@ -437,7 +632,7 @@ struct Poa {
         for (int c = 0; c < CPL; ++c) { jg[c] = (j0 + c) * gp; last[c] = jg[c]; }   // row 0: H[0][j] = j*g (sisd..cpp:197-199,230-232)
 
         const int le = L / CPL, ce = L % CPL;               // owner of the last column
-        int best = NEG, best_i = -1;
+        int best = NEG;
 
         int slot = 0;                                        // ring slot of row i (no integer division in the loop)
         int slotS = 0, rowS = 0;                             // slot * S and r * S, advanced by addition (group-uniform)
@@ -596,6 +791,7 @@ struct Poa {
             g.sync();
         }
         best_i = g.shfl(best_i, le);
+        }
         HYPO_TICK(PH_DP);
 
         // ---- traceback over direction codes ----

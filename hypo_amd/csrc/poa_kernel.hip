@@ -462,7 +462,7 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
     }
     // this call's final and planned counts for the next call's grid sizes (no wait: whoever reads them gets the last finished call)
     (void)hipMemcpyAsync(planned_host + 8, Q.count, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-    (void)hipMemcpyAsync(planned_host + 16, Q.planned, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    memcpy(planned_host + 16, planned_host, 8 * sizeof(uint32_t));
     rec(2 + 2 * kNumPoaClasses, stream);
     pe = 3 + 2 * kNumPoaClasses;
     if (prof) prof->n = pe;

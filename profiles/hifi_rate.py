@@ -8,7 +8,7 @@ rng = np.random.default_rng(5)
 wl = rng.choice([3, 5, 8, 12, 16, 24, 32, 48, 64, 99], size=n, p=[.15, .15, .15, .13, .13, .1, .1, .05, .03, .01])
 shapes = np.stack([wl, rng.integers(44, 58, size=n), np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.int64)], axis=1)
 b = sim.window_batch(n, seed=9, shapes=shapes, read_sub=0.001)
-gpu = capi.HypoGpu(0)
+gpu = capi.HypoGpu(0, path=os.environ["HYPO_GPU_LIB"]) if os.environ.get("HYPO_GPU_LIB") else capi.HypoGpu(0)
 db = gpu.device_batch(b)
 for _ in range(2): db.run()
 torch.cuda.synchronize()

@@ -16,7 +16,7 @@ def main():
     arms = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
     b = sim.grid_batch(length, arms, n, 0.005, seed=3)
-    gpu = capi.HypoGpu(0)
+    gpu = capi.HypoGpu(0, path=os.environ["HYPO_GPU_LIB"]) if os.environ.get("HYPO_GPU_LIB") else capi.HypoGpu(0)
     db = gpu.device_batch(b)
     db.run(); torch.cuda.synchronize()
     t0 = time.perf_counter()
