@@ -388,7 +388,9 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
     hipStream_t* const aux = A->aux;
     hipEvent_t* const join_ev = A->join_ev;
     hipEvent_t& fork_ev = A->fork_ev;
-    int caps[kNumPoaClasses] = {3, 4, 6, 0, 0, 0};    // re-swept after the kernels changed: {3,3,6} 4.33 ms, {3,4,6} 4.06 ms, {3,5,6} 4.06 ms
+    // waves per CU of the three concurrent kernels.  Swept on C2 (ms per call): {4,4,6} 3.89, {4,5,6} 3.94, {3,4,6} 4.15, {5,4,6} 4.19,
+    // {4,4,5} 4.49, {4,4,7} 4.34 with two class-0 groups per wave; {3,4,6} 4.08 with four.  Class 0 is set below.
+    int caps[kNumPoaClasses] = {4, 4, 6, 0, 0, 0};
     if (const char* cs = getenv("HYPO_POA_CAPS")) sscanf(cs, "%d,%d,%d,%d,%d", &caps[0], &caps[1], &caps[2], &caps[3], &caps[4]);
     const char* seq_env = getenv("HYPO_POA_SEQUENTIAL");
     const bool sequential = seq_env && atoi(seq_env) > 0;
@@ -410,6 +412,13 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
             }
             if ((e = hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming)) != hipSuccess) return e;
         }
+        // The host looks at the plan before it launches anything: a batch made of tiny windows almost only (dense short reads
+        // on a large genome) runs class 0 with twice the waves (the default split starves it: 44 -> 55 M windows/s there).
+        if ((e = hipEventSynchronize(planned_ev)) != hipSuccess) return e;
+        const uint64_t lds_windows = (uint64_t)planned_host[0] + planned_host[1] + planned_host[2];
+        bool four_groups = (uint64_t)planned_host[0] * 100 > lds_windows * 85;
+        if (const char* g0 = getenv("HYPO_POA_CLASS0")) four_groups = atoi(g0) == 16;      // 16 | 32: lanes per group (tests)
+        if (!getenv("HYPO_POA_CAPS")) caps[0] = four_groups ? 6 : 4;
         (void)hipEventRecord(fork_ev, stream);
         (void)hipStreamWaitEvent(aux[0], fork_ev, 0);
         (void)hipStreamWaitEvent(aux[1], fork_ev, 0);
@@ -418,7 +427,9 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
         if ((e = launch_class<PoaClass2, true>(P, Q, 2, n_windows, scratch, num_cus, 0, stream, caps[2])) != hipSuccess) return e;
         rec(3 + 2 * 2, stream);
         rec(2 + 2 * 0, aux[0]);
-        if ((e = launch_class<PoaClass0, true>(P, Q, 0, n_windows, scratch, num_cus, 0, aux[0], caps[0])) != hipSuccess) return e;
+        e = four_groups ? launch_class<PoaClass0, true>(P, Q, 0, n_windows, scratch, num_cus, 0, aux[0], caps[0])
+                        : launch_class<PoaClass0W, true>(P, Q, 0, n_windows, scratch, num_cus, 0, aux[0], caps[0]);
+        if (e != hipSuccess) return e;
         rec(3 + 2 * 0, aux[0]);
         rec(2 + 2 * 1, aux[1]);
         if ((e = launch_class<PoaClass1, true>(P, Q, 1, n_windows, scratch, num_cus, 0, aux[1], caps[1])) != hipSuccess) return e;

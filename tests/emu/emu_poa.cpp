@@ -171,6 +171,7 @@ extern "C" int emu_poa_batch(const HypoScoreParams* sp, const HypoWindowBatch* i
     switch (cfg_id) {
 #define HYPO_CLASS_CASE(ID, CFG) case ID: return run_cfg<hypo::CFG>(P, in->n_windows, res, cells, aligns);
         HYPO_FOR_EACH_CLASS(HYPO_CLASS_CASE)
+        HYPO_FOR_EACH_ALT_CLASS(HYPO_CLASS_CASE)
 #undef HYPO_CLASS_CASE
         default: return -1;
     }
@@ -180,6 +181,7 @@ extern "C" int emu_class_bytes(int cfg_id) {
     switch (cfg_id) {
 #define HYPO_CLASS_CASE(ID, CFG) case ID: return hypo::PoaLayout<hypo::CFG>::BYTES;
         HYPO_FOR_EACH_CLASS(HYPO_CLASS_CASE)
+        HYPO_FOR_EACH_ALT_CLASS(HYPO_CLASS_CASE)
 #undef HYPO_CLASS_CASE
         default: return -1;
     }

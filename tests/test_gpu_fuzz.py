@@ -91,3 +91,23 @@ def test_windows_beyond_the_long_class(gpu, oracle_lib):
     ocons, ost = oracle_lib.poa_batch(b)[:2]
     assert [i for i in range(len(wins)) if cons[i] != ocons[i] or st[i] != ost[i]] == []
     assert gpu.last_stats()["n_class"][5] >= 48
+
+
+@pytest.mark.parametrize("lanes", ["16", "32"])
+def test_both_class0_geometries(gpu, oracle_lib, lanes, monkeypatch):
+    """Class 0 runs as four 16-lane or two 32-lane groups per wave, picked per call from the batch's mix (poa_run);
+    HYPO_POA_CLASS0 forces one.  Same windows, both geometries, against the oracle."""
+    monkeypatch.setenv("HYPO_POA_CLASS0", lanes)
+    rng = np.random.default_rng(900)
+    wins = []
+    while len(wins) < 4000:
+        w = _window(rng, False)
+        if len(w.draft) <= 44:
+            wins.append(w)
+    b = build_batch(wins)
+    scores = (5, -4, -8, 3, -5, -4)
+    cons, st = gpu.poa_consensus(b, scores)
+    ocons, ost = oracle_lib.poa_batch(b, scores=scores)[:2]
+    assert [i for i in range(len(wins)) if cons[i] != ocons[i] or st[i] != ost[i]] == []
+    s = gpu.last_stats()
+    assert s["n_failed"] == 0 and s["n_class"][0] > 2000

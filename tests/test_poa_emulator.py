@@ -34,6 +34,11 @@ def test_class0_synth(emu):
     assert _check(emu, 0, "windows_synth.jsonl.gz", 120, True) > 50
 
 
+def test_class0_two_groups_per_wave(emu):
+    # the 32-lane x 2-column geometry of class 0 (PoaClass0W, emulator id 6)
+    assert _check(emu, 6, "windows_synth.jsonl.gz", 120, True) > 50
+
+
 def test_class1_synth(emu):
     assert _check(emu, 1, "windows_synth.jsonl.gz", 120, True) > 100
 
