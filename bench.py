@@ -272,7 +272,7 @@ def main():
             "metric": "polished windows/sec (whole node)", "value": round(value, 1), "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "int16", "data": "synthetic",   # exact int16 score rows (guarded; int32 in the catch-all class)
             "config": {"workload": "C2: E. coli-sized 5 Mbp draft, 30x 150-bp short reads, k=11 — solid-kmer scan + POA "
                                    f"of {n_w} C1-shaped windows per GPU (mean 38.5 bp, 18.7 arms)",
                        "windows_per_gpu": n_w, "arms_per_gpu": batch.n_arms, "contig_bases": CONTIG_BASES, "k": K,

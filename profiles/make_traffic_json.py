@@ -10,12 +10,13 @@ import json
 import os
 import sys
 
-CLASS_CFG = {0: "16;4;47", 1: "32;4;79", 2: "64;2;127;126", 3: "64;4;255", 4: "64;10;639", 5: "64;16;1023"}
+# class 0 runs as 32;2;47 (two groups per wave) or 16;4;47 (four), whichever poa_run picked for the profiled batch
+CLASS_CFG = {0: ("32;2;47", "16;4;47"), 1: ("32;4;79",), 2: ("64;2;127;126",), 3: ("64;4;255",), 4: ("64;10;639",), 5: ("64;16;1023",)}
 
 
 def entry(path, cls, n_windows):
-    rows = [r for r in csv.DictReader(open(path)) if r["kernel"].startswith("poa_class_kernel<" + CLASS_CFG[cls])]
-    rows.sort(key=lambda r: -int(r["kernel"].rsplit("grid=", 1)[1]))       # main launch = largest grid (mop-up launches are tiny)
+    rows = [r for r in csv.DictReader(open(path)) if any(r["kernel"].startswith("poa_class_kernel<" + c) for c in CLASS_CFG[cls])
+            and r["kernel"].endswith("pass=0")]                           # main launch (pass 1 = mop-up launch of the same kernel)
     if not rows:
         raise SystemExit(f"class {cls}: kernel not found")
     row = rows[0]
