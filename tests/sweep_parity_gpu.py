@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Opt-in long parity sweep on a GPU box (not collected by pytest): many seeded batches through libhypo_gpu and through the
+oracle, compared byte for byte.  Shapes: the C1-shaped simulator batch at several read error rates (re-queue paths, both
+class-0 geometries), and the randomised windows of test_gpu_fuzz.py.
+usage: sweep_parity_gpu.py [minutes]      exit code 1 on the first mismatch"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from hypo_amd import capi, sim  # noqa: E402
+from hypo_amd.batch import build_batch  # noqa: E402
+import oracle  # noqa: E402
+from test_gpu_fuzz import _window  # noqa: E402
+
+
+def compare(gpu, orc, b, scores, tag):
+    bases, off, ln, st = gpu.poa_batch(b, scores)
+    ob, ooff, oln, ost = orc.poa_batch_raw(b, scores=scores)[:4]
+    bad = np.nonzero((ln != oln) | (st != ost))[0]
+    if len(bad) == 0:
+        for i in np.nonzero(st == 0)[0]:
+            a, o = int(off[i]), int(ooff[i])
+            if bases[a:a + int(ln[i])].tobytes() != ob[o:o + int(oln[i])].tobytes():
+                bad = np.array([i])
+                break
+    if len(bad):
+        print(f"MISMATCH {tag}: window {int(bad[0])} ({len(bad)} differ)", flush=True)
+        sys.exit(1)
+    return b.n_windows
+
+
+def main():
+    minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 5.0
+    gpu = capi.HypoGpu(0)
+    orc = oracle.Oracle()
+    t_end = time.time() + 60 * minutes
+    total, rnd = 0, 0
+    default = (5, -4, -8, 3, -5, -4)
+    while time.time() < t_end:
+        rnd += 1
+        for sub in (0.002, 0.01, 0.03):
+            for lanes in ("16", "32"):
+                os.environ["HYPO_POA_CLASS0"] = lanes
+                total += compare(gpu, orc, sim.window_batch(60000, seed=5000 + rnd, read_sub=sub), default, f"sim sub={sub} lanes={lanes} round={rnd}")
+        os.environ.pop("HYPO_POA_CLASS0", None)
+        rng = np.random.default_rng(7000 + rnd)
+        for scores in (default, (3, -6, -5, 3, -5, -4), (1, -1, -1, 1, -1, -1)):
+            wins = [_window(rng, False) for _ in range(6000)] + [_window(rng, True) for _ in range(150)]
+            total += compare(gpu, orc, build_batch(wins), scores, f"fuzz scores={scores} round={rnd}")
+        print(f"round {rnd}: {total} windows identical so far", flush=True)
+    print(f"OK: {total} windows, 0 mismatches")
+
+
+if __name__ == "__main__":
+    main()
