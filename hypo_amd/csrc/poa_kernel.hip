@@ -346,8 +346,9 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
     hipLaunchKernelGGL(poa_plan_scatter_kernel, dim3((n_windows + PLAN_THREADS - 1) / PLAN_THREADS), dim3(PLAN_THREADS), 0, stream, Q, n_windows);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (prof) (void)hipEventRecord(prof->ev[1], stream);
-    // How many windows the plan put into the rare classes (3: oversized, 4: LONG, 5: catch-all) comes back to the host while
-    // the three big kernels run; their grids are then sized for it.  A grid of 2 048 single-wave workgroups costs ~0.1 ms of
+    // The plan's class counts come back to the host before anything else is launched (the wait costs nothing measurable: the
+    // class kernels cannot start before the plan anyway).  They decide class 0's geometry and wave share and size the grids
+    // of the rare classes (3: oversized, 4: LONG, 5: catch-all): a grid of 2 048 single-wave workgroups costs ~0.1 ms of
     // dispatch even if every wave leaves at once, and these classes are empty in most batches (a few escalated windows still
     // find a small grid waiting).
     if (!A->planned_host) {
@@ -377,14 +378,13 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
         const uint64_t want = (uint64_t)planned_host[cls] + late_arrivals(cls);
         return (uint32_t)(want < n_windows ? want : n_windows);
     };
-    // Every class is launched with a grid sized for the whole batch: how many windows a class receives is only
-    // known on the device (plan + escalations), and an idle persistent wave exits after one failed dequeue.
+    // An idle persistent wave exits after one failed dequeue, so grids may be generous.
     //
     // The three LDS classes run CONCURRENTLY on the caller's stream and two auxiliary streams: the small-window
     // kernels are latency bound (most sequences reuse an alignment) while the large-window kernel saturates VALU
     // issue, so sharing the CUs fills issue slots either would leave idle (measured: ~11 % per step).  Each gets a
     // share of a CU's LDS through a waves-per-CU cap.  A window re-queued by a class that ran next to its successor
-    // is picked up by a small mop-up launch afterwards; the rare classes 3 and 4 follow on the caller's stream.
+    // is picked up by a mop-up launch afterwards; the rare classes follow on the caller's stream.
     hipStream_t* const aux = A->aux;
     hipEvent_t* const join_ev = A->join_ev;
     hipEvent_t& fork_ev = A->fork_ev;
@@ -444,11 +444,10 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
         (void)hipEventRecord(join_ev[1], aux[1]);
         (void)hipStreamWaitEvent(stream, join_ev[0], 0);
         (void)hipStreamWaitEvent(stream, join_ev[1], 0);
-        // then the rare classes (the host waits here for the plan's counts only; the big kernels are already queued).
-        // LONG windows are planned straight into class 4, so its first pass does not have to wait for anybody: it runs on a
-        // third stream next to the short-window kernels (a LONG window occupies one wave for ~0.1 s; its latency is the floor of
-        // the whole call), and only the few windows escalated into class 4 later wait for the mop-up pass at the end.
-        if ((e = hipEventSynchronize(planned_ev)) != hipSuccess) return e;
+        // then the rare classes.  LONG windows are planned straight into class 4, so its first pass does not have to wait for
+        // anybody: it runs on a third stream next to the short-window kernels (a LONG window occupies one wave for ~0.1 s; its
+        // latency is the floor of the whole call), and only the few windows escalated into class 4 later wait for the mop-up
+        // pass at the end.
         const bool long_first_pass = planned_host[4] > 0;
         if (long_first_pass) {
             rec(2 + 2 * 4, aux[2]);
