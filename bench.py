@@ -124,16 +124,17 @@ def main():
     ds = gpu.device_scan(packed4, CONTIG_BASES, K, bits)
     n_w = batch.n_windows
 
-    # exchange step: sizes agreed once (all_reduce MAX), then two fixed-size all-gathers per batch
+    # exchange step: sizes agreed once (all_reduce MAX), then one fixed-size all-gather per batch from preallocated buffers
     if world > 1:
         from hypo_amd import dist as hd
         max_bytes, max_windows = hd.agree_sizes(int(off[-1]), n_w, dev)
+        exchange = hd.ConsensusExchange(max_bytes, max_windows, dev)
 
     def step():
         ds.run()
         db.run()
         if world > 1:
-            hd.gather_consensus(db.bases, db.len[:n_w], max_bytes, max_windows)
+            exchange.gather(db.bases, db.len[:n_w])
 
     def fence():
         if world > 1:

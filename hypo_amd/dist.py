@@ -67,6 +67,33 @@ def gather_consensus(bases, lens, max_bytes: int, max_windows: int, group=None):
     return ab.view(world, max_bytes), al.view(world, max_windows)
 
 
+class ConsensusExchange:
+    """The same exchange with nothing allocated or filled per batch: one send buffer [lens as bytes | consensus bytes],
+    one receive buffer, ONE all-gather per batch (the two collectives of gather_consensus cost their launch latency twice).
+    Sizes come from agree_sizes.  gather() returns views into the receive buffer, valid until the next gather()."""
+
+    def __init__(self, max_bytes: int, max_windows: int, device, group=None):
+        import torch
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.max_bytes, self.max_windows = max_bytes, max_windows
+        self.len_bytes = (4 * max_windows + 255) // 256 * 256
+        self.slot = self.len_bytes + max_bytes
+        self.send = torch.zeros(self.slot, dtype=torch.uint8, device=device)
+        self.recv = torch.empty(self.world * self.slot, dtype=torch.uint8, device=device)
+
+    def gather(self, bases, lens):
+        import torch
+        import torch.distributed as dist
+        nb = min(bases.numel(), self.max_bytes)
+        self.send[self.len_bytes:self.len_bytes + nb].copy_(bases[:nb])
+        self.send[:4 * lens.numel()].copy_(lens.contiguous().view(torch.uint8))
+        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+        r = self.recv.view(self.world, self.slot)
+        return r[:, self.len_bytes:], r[:, :4 * self.max_windows].contiguous().view(torch.int32).view(self.world, self.max_windows)
+
+
 def agree_sizes(n_bytes: int, n_windows: int, device, group=None) -> Tuple[int, int]:
     import torch
     import torch.distributed as dist

@@ -14,6 +14,10 @@ from hypo_amd import dist as hd
 from hypo_amd import sim
 
 
+def offs_of(batch, ranges, r):
+    return hd.take_windows(batch, *ranges[r]).slot_layout()
+
+
 def _worker(rank, world, port, n_windows, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -30,6 +34,14 @@ def _worker(rank, world, port, n_windows, ret):
     dev = torch.device("cpu")
     max_bytes, max_windows = hd.agree_sizes(int(off[-1]), mine.n_windows, dev)
     ab, al = hd.gather_consensus(torch.from_numpy(bases), torch.from_numpy(ln.view(np.int32)), max_bytes, max_windows)
+    # the preallocated single-collective form bench.py uses must hand back the same bytes, batch after batch
+    ex = hd.ConsensusExchange(max_bytes, max_windows, dev)
+    for _ in range(2):
+        xb, xl = ex.gather(torch.from_numpy(bases), torch.from_numpy(ln.view(np.int32)))
+        assert torch.equal(xl, al)
+        for r in range(world):
+            nbytes = int(offs_of(batch, ranges, r)[-1])
+            assert torch.equal(xb[r, :nbytes], ab[r, :nbytes])
     # every rank needs the slot layouts of the other ranks to cut the gathered buffers: they are a pure
     # function of the shared batch (slot_layout), so no extra communication
     offs = [hd.take_windows(batch, *ranges[r]).slot_layout() for r in range(world)]
