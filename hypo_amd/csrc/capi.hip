@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 #include <vector>
 #include "../../include/hypo_gpu.h"
 #include "poa_kernel.hpp"
@@ -40,6 +41,10 @@ struct DevBuf {
 };
 
 struct Ctx { bool ready = false; int device = -1; int num_cus = 0; hipStream_t stream = nullptr; hypo::PoaAux poa_aux; DevBuf arena[16]; };
+// One context per process: its side streams, events, plan read-back buffer and arenas are shared, so the entry points that
+// use them take this lock for their host part (recursive: the host-buffer variants call the device variants).
+std::recursive_mutex g_mu;
+#define HYPO_LOCKED() std::lock_guard<std::recursive_mutex> hypo_lock_(g_mu)
 Ctx g_ctx;
 
 // HIP-event recorder for the next calls (hypo_gpu_profile_*)
@@ -79,6 +84,7 @@ const char* hypo_gpu_last_error(void) { return tl_err; }
 int hypo_gpu_num_cus(void) { return g_ctx.ready ? g_ctx.num_cus : 0; }
 
 int hypo_gpu_init(int device_id) {
+    HYPO_LOCKED();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(HYPO_E_NODEVICE, "no HIP device visible");
     if (device_id < 0 || device_id >= n) return fail(HYPO_E_INVALID, "device %d out of range (0..%d)", device_id, n - 1);
@@ -94,6 +100,7 @@ int hypo_gpu_init(int device_id) {
 }
 
 int hypo_gpu_shutdown(void) {
+    HYPO_LOCKED();
     if (g_ctx.ready) {
         (void)hipSetDevice(g_ctx.device);
         (void)hipDeviceSynchronize();
@@ -107,6 +114,7 @@ int hypo_gpu_shutdown(void) {
 
 // ---- profiling ---------------------------------------------------------------------------------------
 int hypo_gpu_profile_begin(int max_calls) {
+    HYPO_LOCKED();
     if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
     if (max_calls < 0 || max_calls > 256) return fail(HYPO_E_INVALID, "max_calls out of range 0..256");
     for (auto& c : g_prof.calls) for (auto& e : c.ke.ev) (void)hipEventDestroy(e);
@@ -117,6 +125,7 @@ int hypo_gpu_profile_begin(int max_calls) {
 }
 int hypo_gpu_profile_calls(void) { return g_prof.used; }
 int hypo_gpu_profile_read(int call, float* ms, int n) {
+    HYPO_LOCKED();
     if (call < 0 || call >= g_prof.used || !ms) return fail(HYPO_E_INVALID, "no such profiled call");
     ProfCall& c = g_prof.calls[(size_t)call];
     if (c.ke.n < 2) return 0;
@@ -147,6 +156,7 @@ size_t hypo_gpu_poa_workspace_bytes(uint32_t n_windows, uint32_t /*n_arms*/) {
 
 int hypo_gpu_poa_batch_device(const HypoScoreParams* scores, const HypoWindowBatch* in, HypoConsensusBatch* out,
                               void* workspace, size_t workspace_bytes, void* hip_stream) {
+    HYPO_LOCKED();
     if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
     int rc = check_scores(scores);
     if (rc) return rc;
@@ -196,6 +206,7 @@ int hypo_gpu_poa_slot_layout(const HypoWindowBatch* in, uint64_t* off) {
 }
 
 int hypo_gpu_poa_batch(const HypoScoreParams* scores, const HypoWindowBatch* in, HypoConsensusBatch* out) {
+    HYPO_LOCKED();
     if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
     int rc = check_scores(scores);
     if (rc) return rc;
@@ -249,6 +260,7 @@ int hypo_gpu_solid_scan_device(const uint8_t* packed4, uint64_t n_bases, uint32_
                                uint64_t* solid_pos_words, uint64_t* kids, uint64_t kids_cap,
                                uint64_t* word_rank, uint64_t* n_solid,
                                void* workspace, size_t workspace_bytes, void* hip_stream) {
+    HYPO_LOCKED();
     if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
     if (k < 2 || k > 31) return fail(HYPO_E_INVALID, "k=%u out of range 2..31", k);
     if ((n_bases && !packed4) || !bits || (n_bases && !solid_pos_words)) return fail(HYPO_E_INVALID, "NULL buffer");
@@ -265,6 +277,7 @@ int hypo_gpu_solid_scan_device(const uint8_t* packed4, uint64_t n_bases, uint32_
 int hypo_gpu_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k, const uint64_t* bits,
                         uint64_t* solid_pos_words, uint64_t* kids, uint64_t kids_cap,
                         uint64_t* word_rank, uint64_t* n_solid) {
+    HYPO_LOCKED();
     if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
     if (k < 2 || k > 31) return fail(HYPO_E_INVALID, "k=%u out of range 2..31", k);
     if ((n_bases && !packed4) || !bits || (n_bases && !solid_pos_words)) return fail(HYPO_E_INVALID, "NULL buffer");

@@ -14,6 +14,8 @@
  *    given hipStream_t (passed as void*); plain variants take HOST pointers and do H2D/D2H themselves.
  *    (hypo_gpu_poa_batch_device returns once all kernels are queued; on the way it waits for its own plan
  *    step, ~0.1 ms of device time, to size the launches of the rare size classes.)
+ *  - one device context per process (hypo_gpu_init).  Entry points may be called from several host threads; the host part
+ *    of a call (enqueueing, the plan wait, the copies of the host-buffer variants) is serialised inside the library.
  *  - sequences are packed exactly like the reference's PackedSeq<NB> (src/PackedSeq.cpp:58-89):
  *    MSB-first inside a byte, 2 bases/byte for NB=4 (codes A0 C1 G2 T3 N4), 4 bases/byte for NB=2.
  *    Every sequence starts on a byte boundary of its buffer.

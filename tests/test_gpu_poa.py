@@ -197,3 +197,34 @@ def test_smaller_workspace_limits_only_residency(gpu, oracle_lib):
     assert (st == ost).all() and (ln == oln).all() and _same_consensus(bases, ob, off, ln)
     with pytest.raises(capi.HypoGpuError):
         gpu.device_batch(b, workspace_bytes=minimal - 4096).run()
+
+
+def test_concurrent_host_threads(gpu, oracle_lib):
+    """Four host threads, each with its own batch, workspace and stream, call the device entry point at the same time
+    (ctypes releases the GIL): the context's shared side streams and plan read-back are serialised inside the library."""
+    import threading
+    import torch
+    batches = [sim.window_batch(3000, seed=300 + t, read_sub=0.002 + 0.004 * t) for t in range(4)]
+    dbs = [gpu.device_batch(b) for b in batches]
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    torch.cuda.synchronize()
+    errs = []
+
+    def work(t):
+        try:
+            for _ in range(6):
+                dbs[t].run(stream=streams[t])
+            streams[t].synchronize()
+        except Exception as e:        # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+    for t in range(4):
+        bases, off, ln, st = dbs[t].results()
+        ob, _, oln, ost, _, _ = oracle_lib.poa_batch_raw(batches[t], off=off)
+        assert (st == ost).all() and (ln == oln).all() and _same_consensus(bases, ob, off, ln), t
