@@ -3,6 +3,7 @@
 #include <getopt.h>
 #include <malloc.h>
 #include <sys/stat.h>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -144,9 +145,17 @@ int main(int argc, char** argv) {
         std::cout << "Stagenum found is " << st << std::endl;
     }
     std::fprintf(stdout, "[Hypo::Utils] Info: Beginning from stage: %u\n", flags.done_stage);
+    const bool timing = std::getenv("HYPO_HOST_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     if (hypo_gpu_init(flags.device) != HYPO_OK) { std::fprintf(stderr, "[Hypo::] Error: %s\n", hypo_gpu_last_error()); return 1; }
-    hypo::Hypo h(flags);
-    if (const char* d = std::getenv("HYPO_REGION_DUMP")) h.set_region_dump(d);
-    h.polish();
+    if (timing) std::fprintf(stderr, "[timing] main: device initialised at %.3f s\n", since());
+    {
+        hypo::Hypo h(flags);
+        if (const char* d = std::getenv("HYPO_REGION_DUMP")) h.set_region_dump(d);
+        h.polish();
+        if (timing) std::fprintf(stderr, "[timing] main: polish() returned at %.3f s\n", since());
+    }
+    if (timing) std::fprintf(stderr, "[timing] main: pipeline objects released at %.3f s\n", since());
     return 0;
 }
