@@ -60,20 +60,25 @@ def end_to_end_leg():
         threads = min(32, os.cpu_count() or 1)
         argv = [binp] + man["command"].split()[1:]
         argv[argv.index("-t") + 1] = str(threads)
-        best = None
+        best, best_wall = None, None
         for _ in range(2):
+            tw = time.perf_counter()
             p = subprocess.run(argv, cwd=d, capture_output=True, text=True, timeout=600)
+            wall = time.perf_counter() - tw
             if p.returncode != 0:
                 return {"error": (p.stdout + p.stderr)[-300:]}
             m = re.search(r"Overall\. \): TIME= ([0-9.eE+-]+) sec", p.stdout)
             t = float(m.group(1)) if m else None
             if t is not None and (best is None or t < best):
                 best = t
+            best_wall = wall if best_wall is None else min(best_wall, wall)
         got = hashlib.md5(open(os.path.join(d, "hypo_draft.fasta"), "rb").read()).hexdigest()
         if got != man["expected_fasta_md5"]:
             raise SystemExit("bench: end-to-end FASTA differs from the real reference's — refusing to report a number")
-        return {"mbp_per_s": round(a["G"] / 1e6 / best, 2), "seconds": round(best, 4), "host_threads": threads,
-                "workload": "C2 end to end: 5 Mbp draft, 30x 150-bp reads (1 M records of SAM text), k = 11, hypo binary = host pipeline + device, best of 2",
+        return {"mbp_per_s": round(a["G"] / 1e6 / best, 2), "seconds": round(best, 4), "process_wall_seconds": round(best_wall, 4),
+                "host_threads": threads,
+                "workload": "C2 end to end: 5 Mbp draft, 30x 150-bp reads (1 M records of SAM text), k = 11, hypo binary = host pipeline + device, best of 2; "
+                            "seconds = the binary's Overall timer (the reference's own measure), process_wall_seconds adds process start, device init and teardown",
                 "fasta": "md5 identical to the real reference's output for these inputs"}
     finally:
         shutil.rmtree(d, ignore_errors=True)

@@ -45,6 +45,8 @@ struct Ctx { bool ready = false; int device = -1; int num_cus = 0; hipStream_t s
 // use them take this lock for their host part (recursive: the host-buffer variants call the device variants).
 std::recursive_mutex g_mu;
 #define HYPO_LOCKED() std::lock_guard<std::recursive_mutex> hypo_lock_(g_mu)
+// the device of the context is made current for the calling thread (hypo_gpu_init did that for its own thread only)
+#define HYPO_ON_DEVICE() do { if (g_ctx.ready) HIP_TRY(hipSetDevice(g_ctx.device)); } while (0)
 Ctx g_ctx;
 
 // HIP-event recorder for the next calls (hypo_gpu_profile_*)
@@ -157,6 +159,7 @@ size_t hypo_gpu_poa_workspace_bytes(uint32_t n_windows, uint32_t /*n_arms*/) {
 int hypo_gpu_poa_batch_device(const HypoScoreParams* scores, const HypoWindowBatch* in, HypoConsensusBatch* out,
                               void* workspace, size_t workspace_bytes, void* hip_stream) {
     HYPO_LOCKED();
+    HYPO_ON_DEVICE();
     if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
     int rc = check_scores(scores);
     if (rc) return rc;
@@ -207,6 +210,7 @@ int hypo_gpu_poa_slot_layout(const HypoWindowBatch* in, uint64_t* off) {
 
 int hypo_gpu_poa_batch(const HypoScoreParams* scores, const HypoWindowBatch* in, HypoConsensusBatch* out) {
     HYPO_LOCKED();
+    HYPO_ON_DEVICE();
     if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
     int rc = check_scores(scores);
     if (rc) return rc;
@@ -261,6 +265,7 @@ int hypo_gpu_solid_scan_device(const uint8_t* packed4, uint64_t n_bases, uint32_
                                uint64_t* word_rank, uint64_t* n_solid,
                                void* workspace, size_t workspace_bytes, void* hip_stream) {
     HYPO_LOCKED();
+    HYPO_ON_DEVICE();
     if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
     if (k < 2 || k > 31) return fail(HYPO_E_INVALID, "k=%u out of range 2..31", k);
     if ((n_bases && !packed4) || !bits || (n_bases && !solid_pos_words)) return fail(HYPO_E_INVALID, "NULL buffer");
@@ -278,6 +283,7 @@ int hypo_gpu_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k, co
                         uint64_t* solid_pos_words, uint64_t* kids, uint64_t kids_cap,
                         uint64_t* word_rank, uint64_t* n_solid) {
     HYPO_LOCKED();
+    HYPO_ON_DEVICE();
     if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
     if (k < 2 || k > 31) return fail(HYPO_E_INVALID, "k=%u out of range 2..31", k);
     if ((n_bases && !packed4) || !bits || (n_bases && !solid_pos_words)) return fail(HYPO_E_INVALID, "NULL buffer");
