@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Opt-in long parity sweep on a GPU box (not collected by pytest): many seeded batches through libhypo_gpu and through the
 oracle, compared byte for byte.  Shapes: the C1-shaped simulator batch at several read error rates (re-queue paths, both
-class-0 geometries), and the randomised windows of test_gpu_fuzz.py.
+class-0 geometries), tiny-window batches (dense short reads, HiFi-like depth), wide windows, and the randomised windows of
+test_gpu_fuzz.py.
 usage: sweep_parity_gpu.py [minutes]      exit code 1 on the first mismatch"""
 import os
 import sys
@@ -48,6 +49,15 @@ def main():
                 os.environ["HYPO_POA_CLASS0"] = lanes
                 total += compare(gpu, orc, sim.window_batch(60000, seed=5000 + rnd, read_sub=sub), default, f"sim sub={sub} lanes={lanes} round={rnd}")
         os.environ.pop("HYPO_POA_CLASS0", None)
+        # tiny windows almost only (the rule picks four class-0 groups per wave), many arms per window, wide windows
+        rs = np.random.default_rng(9000 + rnd)
+        n = 80000
+        wl = rs.choice([3, 5, 8, 12, 16, 24, 32, 48, 64, 99], size=n, p=[.15, .15, .15, .13, .13, .1, .1, .05, .03, .01])
+        for lo, hi, tag in ((3, 45, "dense"), (44, 58, "hifi")):
+            shapes = np.stack([wl, rs.integers(lo, hi, size=n), np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.int64)], axis=1)
+            total += compare(gpu, orc, sim.window_batch(n, seed=9100 + rnd, shapes=shapes, read_sub=0.004), default, f"{tag} round={rnd}")
+        for length in (130, 160, 200):
+            total += compare(gpu, orc, sim.grid_batch(length, 20, 1500, 0.01, seed=9200 + rnd), default, f"wide {length} round={rnd}")
         rng = np.random.default_rng(7000 + rnd)
         for scores in (default, (3, -6, -5, 3, -5, -4), (1, -1, -1, 1, -1, -1)):
             wins = [_window(rng, False) for _ in range(6000)] + [_window(rng, True) for _ in range(150)]
