@@ -3,7 +3,7 @@
 oracle, compared byte for byte.  Shapes: the C1-shaped simulator batch at several read error rates (re-queue paths, both
 class-0 geometries), tiny-window batches (dense short reads, HiFi-like depth), wide windows, and the randomised windows of
 test_gpu_fuzz.py.
-usage: sweep_parity_gpu.py [minutes]      exit code 1 on the first mismatch"""
+usage: sweep_parity_gpu.py [minutes] [first_round]      exit code 1 on the first mismatch (rounds seed the data)"""
 import os
 import sys
 import time
@@ -40,7 +40,7 @@ def main():
     gpu = capi.HypoGpu(0)
     orc = oracle.Oracle()
     t_end = time.time() + 60 * minutes
-    total, rnd = 0, 0
+    total, rnd = 0, (int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     default = (5, -4, -8, 3, -5, -4)
     while time.time() < t_end:
         rnd += 1
