@@ -5,7 +5,7 @@ Reference types mirrored: ScoreParams (include/globalDefs.hpp:58-66), hypo::Wind
 """
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 HYPO_OK = 0
 HYPO_E_INVALID = -1
@@ -18,6 +18,7 @@ ST_OK = 0
 ST_CONS_OVERFLOW = 1
 ST_CAPACITY = 2
 ST_UNDEFINED = 3
+ST_INVALID = 4
 
 WIN_SHORT = 0
 WIN_LONG = 1

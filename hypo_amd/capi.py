@@ -21,6 +21,7 @@ EXPORTS = [
     "hypo_gpu_solid_scan_device", "hypo_gpu_poa_batch", "hypo_gpu_poa_workspace_bytes",
     "hypo_gpu_poa_batch_device", "hypo_gpu_poa_slot_layout", "hypo_gpu_poa_last_stats",
     "hypo_gpu_poa_read_stats", "hypo_gpu_profile_begin", "hypo_gpu_profile_calls", "hypo_gpu_profile_read",
+    "hypo_gpu_num_devices", "hypo_gpu_use_device", "hypo_gpu_build_id", "hypo_gpu_solid_set_upload",
 ]
 
 
@@ -44,6 +45,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     import torch  # noqa: F401
     lib = C.CDLL(path)
     lib.hypo_gpu_last_error.restype = C.c_char_p
+    lib.hypo_gpu_build_id.restype = C.c_char_p
     lib.hypo_gpu_poa_workspace_bytes.restype = C.c_size_t
     lib.hypo_gpu_solid_scan_workspace_bytes.restype = C.c_size_t
     lib.hypo_gpu_solid_scan_workspace_bytes.argtypes = [C.c_uint64]
@@ -73,7 +75,8 @@ class HypoGpu:
         if self.lib.hypo_gpu_abi_version() != abi.ABI_VERSION:
             raise HypoGpuError("ABI version mismatch between hypo_amd/abi.py and libhypo_gpu.so")
         self.device = device
-        self._check(self.lib.hypo_gpu_init(C.c_int(device)))
+        ids = (C.c_int * 1)(device)
+        self._check(self.lib.hypo_gpu_init(ids, C.c_int(1)))
         self.num_cus = int(self.lib.hypo_gpu_num_cus())
 
     def _check(self, rc):

@@ -40,19 +40,32 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-struct Ctx { bool ready = false; int device = -1; int num_cus = 0; hipStream_t stream = nullptr; hypo::PoaAux poa_aux; DevBuf arena[16]; };
-// One context per process: its side streams, events, plan read-back buffer and arenas are shared, so the entry points that
-// use them take this lock for their host part (recursive: the host-buffer variants call the device variants).
-std::recursive_mutex g_mu;
-#define HYPO_LOCKED() std::lock_guard<std::recursive_mutex> hypo_lock_(g_mu)
-// the device of the context is made current for the calling thread (hypo_gpu_init did that for its own thread only)
-#define HYPO_ON_DEVICE() do { if (g_ctx.ready) HIP_TRY(hipSetDevice(g_ctx.device)); } while (0)
-Ctx g_ctx;
-
 // HIP-event recorder for the next calls (hypo_gpu_profile_*)
 struct ProfCall { int kind = 0; hypo::KernelEvents ke; };      // kind 1 = POA, 2 = scan
 struct Prof { std::vector<ProfCall> calls; int used = 0; };
-Prof g_prof;
+
+// One context per device handed to hypo_gpu_init ("one context per device inside one process").  Each owns its
+// stream, the POA side streams / events / plan read-back buffer, the grow-only arenas of the host-pointer entry points and
+// the uploaded solid-kmer set.  A calling thread works on the context it selected with hypo_gpu_use_device (slot 0 by
+// default); entry points lock that context only, so threads driving different devices never wait for each other.
+struct Ctx {
+    bool ready = false; int device = -1; int num_cus = 0; hipStream_t stream = nullptr;
+    hypo::PoaAux poa_aux; DevBuf arena[16];
+    DevBuf solid_set; uint32_t solid_k = 0;            // hypo_gpu_solid_set_upload
+    Prof prof;
+    std::recursive_mutex mu;                           // recursive: the host-buffer variants call the device variants
+};
+constexpr int kMaxDevices = HYPO_MAX_DEVICES;
+Ctx g_ctxs[kMaxDevices];
+int g_nctx = 0;
+std::mutex g_init_mu;                                  // init / shutdown only
+thread_local int tl_slot = 0;
+Ctx& cur() { return g_ctxs[(tl_slot >= 0 && tl_slot < kMaxDevices) ? tl_slot : 0]; }
+#define g_ctx (cur())
+#define g_prof (cur().prof)
+#define HYPO_LOCKED() std::lock_guard<std::recursive_mutex> hypo_lock_(cur().mu)
+// the device of the context is made current for the calling thread (hypo_gpu_init did that for its own thread only)
+#define HYPO_ON_DEVICE() do { if (g_ctx.ready) HIP_TRY(hipSetDevice(g_ctx.device)); } while (0)
 
 ProfCall* prof_next(int kind) {
     if (g_prof.used >= (int)g_prof.calls.size()) return nullptr;
@@ -74,6 +87,7 @@ hypo::PoaParams make_params(const HypoScoreParams* s, const HypoWindowBatch* in,
     P.out_bases = out->bases; P.out_off = out->off; P.out_len = out->len; P.out_status = out->status;
     P.sr_m = s->sr_match; P.sr_n = s->sr_mismatch; P.sr_g = s->sr_gap;
     P.lr_m = s->lr_match; P.lr_n = s->lr_mismatch; P.lr_g = s->lr_gap;
+    P.n_arms = in->n_arms; P.draft4_bytes = in->draft4_bytes; P.arms2_bytes = in->arms2_bytes;
     return P;
 }
 
@@ -84,33 +98,66 @@ extern "C" {
 int hypo_gpu_abi_version(void) { return HYPO_GPU_ABI_VERSION; }
 const char* hypo_gpu_last_error(void) { return tl_err; }
 int hypo_gpu_num_cus(void) { return g_ctx.ready ? g_ctx.num_cus : 0; }
+int hypo_gpu_num_devices(void) { return g_nctx; }
+#ifndef HYPO_BUILD_ID
+#define HYPO_BUILD_ID "unknown"
+#endif
+const char* hypo_gpu_build_id(void) { return HYPO_BUILD_ID; }
 
-int hypo_gpu_init(int device_id) {
-    HYPO_LOCKED();
+static void release_ctx(Ctx& c) {
+    if (c.ready) {
+        (void)hipSetDevice(c.device);
+        (void)hipDeviceSynchronize();
+        for (auto& pc : c.prof.calls) for (auto& e : pc.ke.ev) if (e) (void)hipEventDestroy(e);
+        c.prof.calls.clear(); c.prof.used = 0;
+        hypo::poa_release(&c.poa_aux);
+        for (auto& a : c.arena) a.release();
+        c.solid_set.release(); c.solid_k = 0;
+        if (c.stream) (void)hipStreamDestroy(c.stream);
+    }
+    c.ready = false; c.device = -1; c.num_cus = 0; c.stream = nullptr;
+}
+
+int hypo_gpu_init(const int* device_ids, int n_devices) {
+    std::lock_guard<std::mutex> lk(g_init_mu);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(HYPO_E_NODEVICE, "no HIP device visible");
-    if (device_id < 0 || device_id >= n) return fail(HYPO_E_INVALID, "device %d out of range (0..%d)", device_id, n - 1);
-    if (g_ctx.ready) (void)hypo_gpu_shutdown();          // re-initialisation: streams and events belong to the previous device
-    HIP_TRY(hipSetDevice(device_id));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(HYPO_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
-    HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
-    g_ctx.device = device_id; g_ctx.num_cus = prop.multiProcessorCount; g_ctx.ready = true;
+    const int zero = 0;
+    if (!device_ids || n_devices <= 0) { device_ids = &zero; n_devices = 1; }       // (NULL, 0): device 0
+    if (n_devices > kMaxDevices) return fail(HYPO_E_INVALID, "%d devices requested, at most %d", n_devices, kMaxDevices);
+    for (int i = 0; i < n_devices; ++i) {
+        if (device_ids[i] < 0 || device_ids[i] >= n) return fail(HYPO_E_INVALID, "device %d out of range (0..%d)", device_ids[i], n - 1);
+        for (int j = 0; j < i; ++j) if (device_ids[j] == device_ids[i]) return fail(HYPO_E_INVALID, "device %d listed twice", device_ids[i]);
+    }
+    for (int i = 0; i < g_nctx; ++i) release_ctx(g_ctxs[i]);   // re-initialisation: streams and events belong to the previous devices
+    g_nctx = 0;
+    for (int i = 0; i < n_devices; ++i) {
+        Ctx& c = g_ctxs[i];
+        HIP_TRY(hipSetDevice(device_ids[i]));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device_ids[i]));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(HYPO_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device_ids[i], prop.gcnArchName);
+        HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        c.device = device_ids[i]; c.num_cus = prop.multiProcessorCount; c.ready = true;
+        g_nctx = i + 1;
+    }
+    HIP_TRY(hipSetDevice(g_ctxs[0].device));
+    tl_slot = 0;
+    return HYPO_OK;
+}
+
+int hypo_gpu_use_device(int slot) {
+    if (slot < 0 || slot >= g_nctx) return fail(HYPO_E_INVALID, "context %d out of range (hypo_gpu_init created %d)", slot, g_nctx);
+    tl_slot = slot;
+    HIP_TRY(hipSetDevice(g_ctxs[slot].device));
     return HYPO_OK;
 }
 
 int hypo_gpu_shutdown(void) {
-    HYPO_LOCKED();
-    if (g_ctx.ready) {
-        (void)hipSetDevice(g_ctx.device);
-        (void)hipDeviceSynchronize();
-        hypo::poa_release(&g_ctx.poa_aux);
-        for (auto& a : g_ctx.arena) a.release();
-        if (g_ctx.stream) (void)hipStreamDestroy(g_ctx.stream);
-    }
-    g_ctx = Ctx();
+    std::lock_guard<std::mutex> lk(g_init_mu);
+    for (int i = 0; i < g_nctx; ++i) release_ctx(g_ctxs[i]);
+    g_nctx = 0;
     return HYPO_OK;
 }
 
@@ -119,7 +166,7 @@ int hypo_gpu_profile_begin(int max_calls) {
     HYPO_LOCKED();
     if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
     if (max_calls < 0 || max_calls > 256) return fail(HYPO_E_INVALID, "max_calls out of range 0..256");
-    for (auto& c : g_prof.calls) for (auto& e : c.ke.ev) (void)hipEventDestroy(e);
+    for (auto& c : g_prof.calls) for (auto& e : c.ke.ev) if (e) (void)hipEventDestroy(e);
     g_prof.calls.assign((size_t)max_calls, ProfCall());
     g_prof.used = 0;
     for (auto& c : g_prof.calls) for (auto& e : c.ke.ev) HIP_TRY(hipEventCreate(&e));
@@ -199,8 +246,9 @@ int hypo_gpu_poa_slot_layout(const HypoWindowBatch* in, uint64_t* off) {
     for (uint32_t w = 0; w < in->n_windows; ++w) {
         const HypoWindow& W = in->windows[w];
         uint64_t longest = W.draft_len;
-        const uint32_t narm = W.n_internal + W.n_prefix + W.n_suffix;
-        for (uint32_t a = 0; a < narm; ++a) if (in->arm_len[W.first_arm + a] > longest) longest = in->arm_len[W.first_arm + a];
+        const uint64_t narm = (uint64_t)W.n_internal + W.n_prefix + W.n_suffix;
+        if (W.first_arm + narm > in->n_arms) return fail(HYPO_E_INVALID, "window %u: arms [%u, %llu) outside the batch's %u arms", w, W.first_arm, (unsigned long long)(W.first_arm + narm), in->n_arms);
+        for (uint64_t a = 0; a < narm; ++a) if (in->arm_len[W.first_arm + a] > longest) longest = in->arm_len[W.first_arm + a];
         off[w] = acc;
         acc += (2 * longest + 64 + 7) / 8 * 8;
     }
@@ -279,6 +327,21 @@ int hypo_gpu_solid_scan_device(const uint8_t* packed4, uint64_t n_bases, uint32_
     return HYPO_OK;
 }
 
+int hypo_gpu_solid_set_upload(const uint64_t* bits, uint32_t k) {
+    HYPO_LOCKED();
+    HYPO_ON_DEVICE();
+    if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
+    if (k < 2 || k > 31) return fail(HYPO_E_INVALID, "k=%u out of range 2..31", k);
+    if (!bits) return fail(HYPO_E_INVALID, "NULL buffer");
+    const uint64_t bit_words = (1ull << (2 * k)) / 64 ? (1ull << (2 * k)) / 64 : 1;
+    g_ctx.solid_k = 0;
+    HIP_TRY(g_ctx.solid_set.alloc(bit_words * 8));
+    HIP_TRY(hipMemcpyAsync(g_ctx.solid_set.p, bits, bit_words * 8, hipMemcpyHostToDevice, g_ctx.stream));
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    g_ctx.solid_k = k;
+    return HYPO_OK;
+}
+
 int hypo_gpu_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k, const uint64_t* bits,
                         uint64_t* solid_pos_words, uint64_t* kids, uint64_t kids_cap,
                         uint64_t* word_rank, uint64_t* n_solid) {
@@ -286,17 +349,18 @@ int hypo_gpu_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k, co
     HYPO_ON_DEVICE();
     if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
     if (k < 2 || k > 31) return fail(HYPO_E_INVALID, "k=%u out of range 2..31", k);
-    if ((n_bases && !packed4) || !bits || (n_bases && !solid_pos_words)) return fail(HYPO_E_INVALID, "NULL buffer");
+    if ((n_bases && !packed4) || (n_bases && !solid_pos_words)) return fail(HYPO_E_INVALID, "NULL buffer");
+    if (!bits && g_ctx.solid_k != k) return fail(HYPO_E_INVALID, "bitset_words == NULL but no %u-mer set was uploaded (hypo_gpu_solid_set_upload)", k);
     const uint64_t nw = (n_bases + 63) / 64, nbytes = (n_bases + 1) / 2, bit_words = (1ull << (2 * k)) / 64 ? (1ull << (2 * k)) / 64 : 1;
     DevBuf &dP = g_ctx.arena[10], &dBits = g_ctx.arena[11], &dWords = g_ctx.arena[12], &dKids = g_ctx.arena[13],
            &dRank = g_ctx.arena[14], &dN = g_ctx.arena[15], &dWS = g_ctx.arena[9];
     const size_t wsb = hypo::scan_workspace_bytes(n_bases);
-    HIP_TRY(dP.alloc(nbytes)); HIP_TRY(dBits.alloc(bit_words * 8)); HIP_TRY(dWords.alloc(nw * 8));
+    HIP_TRY(dP.alloc(nbytes)); if (bits) HIP_TRY(dBits.alloc(bit_words * 8)); HIP_TRY(dWords.alloc(nw * 8));
     HIP_TRY(dKids.alloc(kids_cap * 8)); HIP_TRY(dRank.alloc((nw + 1) * 8)); HIP_TRY(dN.alloc(8)); HIP_TRY(dWS.alloc(wsb));
     hipStream_t st = g_ctx.stream;
     if (nbytes) HIP_TRY(hipMemcpyAsync(dP.p, packed4, nbytes, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(dBits.p, bits, bit_words * 8, hipMemcpyHostToDevice, st));
-    int rc = hypo_gpu_solid_scan_device((const uint8_t*)dP.p, n_bases, k, (const uint64_t*)dBits.p, (uint64_t*)dWords.p,
+    if (bits) HIP_TRY(hipMemcpyAsync(dBits.p, bits, bit_words * 8, hipMemcpyHostToDevice, st));
+    int rc = hypo_gpu_solid_scan_device((const uint8_t*)dP.p, n_bases, k, (const uint64_t*)(bits ? dBits.p : g_ctx.solid_set.p), (uint64_t*)dWords.p,
                                         kids ? (uint64_t*)dKids.p : nullptr, kids ? kids_cap : 0, (uint64_t*)dRank.p,
                                         (uint64_t*)dN.p, dWS.p, wsb, st);
     if (rc) return rc;

@@ -136,7 +136,8 @@ void Alignment::update_minimisers_support(Contig& contig) {
     // forward-strand window minimizers of the read (position = start of the k-mer), duplicates by position removed
     const uint32_t mask = (uint32_t)((1ULL << (2 * K)) - 1);
     struct Item { uint32_t kmer, pos; };
-    Item ring[32]; const uint32_t cap = W + 1; uint32_t head = 0, tail = cap - 1, count = 0;
+    if (W + 1 > kMinimizerRingCap) { std::fprintf(stderr, "[Hypo] Error: minimizer window %u exceeds the queue capacity %u\n", W, kMinimizerRingCap - 1); std::exit(1); }
+    Item ring[kMinimizerRingCap]; const uint32_t cap = W + 1; uint32_t head = 0, tail = cap - 1, count = 0;
     uint32_t kmer = 0, run = 0, processed = 0;
     uint32_t last_found = (uint32_t)_apseq.get_seq_size() + 1;
     std::unordered_multimap<uint32_t, uint32_t> found;

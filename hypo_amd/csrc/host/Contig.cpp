@@ -44,11 +44,12 @@ Contig::Contig(uint32_t id, const std::string& name, const std::string& seq)
       _solid_pos(seq.size()), _reg_pos(seq.size() + 1) {}
 
 // ---- Contig::find_solid_pos (src/Contig.cpp:40-74): on the device -------------------------------------------------
-int Contig::find_solid_pos(const SolidKmers& sk) {
+// `set_on_device`: the caller has sent sk's bit set to the device with hypo_gpu_solid_set_upload (once per run)
+int Contig::find_solid_pos(const SolidKmers& sk, bool set_on_device) {
     const uint64_t nw = ((uint64_t)_len + 63) / 64;
     std::vector<uint64_t> words(nw ? nw : 1), rank(nw + 1), kids(_len ? _len : 1);
     uint64_t n = 0;
-    const int rc = hypo_gpu_solid_scan(_pseq.data(), _len, sk.get_k(), sk.words.data(), words.data(), kids.data(), kids.size(),
+    const int rc = hypo_gpu_solid_scan(_pseq.data(), _len, sk.get_k(), set_on_device ? nullptr : sk.words.data(), words.data(), kids.data(), kids.size(),
                                        rank.data(), &n);
     if (rc != HYPO_OK) return rc;
     adopt_solid_scan(words.data(), rank.data(), kids.data(), n);
@@ -139,7 +140,8 @@ void Contig::initialise_minimserinfo(const std::string& draft_seq, uint32_t minf
     const uint32_t K = Minimizer_settings.k, W = Minimizer_settings.w;
     const uint32_t mask = (uint32_t)((1ULL << (2 * K)) - 1);
     struct Item { uint32_t kmer, pos; };
-    Item ring[32]; uint32_t cap = W + 1, head = 0, tail = cap - 1, count = 0;
+    if (W + 1 > kMinimizerRingCap) { std::fprintf(stderr, "[Hypo] Error: minimizer window %u exceeds the queue capacity %u\n", W, kMinimizerRingCap - 1); std::exit(1); }
+    Item ring[kMinimizerRingCap]; uint32_t cap = W + 1, head = 0, tail = cap - 1, count = 0;
     uint32_t kmer = 0, run = 0, processed = 0;
     uint32_t last_found_position = (uint32_t)draft_seq.size() + 1;
     std::vector<uint32_t> found, found_pos;

@@ -40,7 +40,7 @@ class Contig {
 public:
     Contig(uint32_t id, const std::string& name, const std::string& seq);
 
-    int find_solid_pos(const SolidKmers& sk);                        // device scan; HYPO_OK or C-ABI error
+    int find_solid_pos(const SolidKmers& sk, bool set_on_device = false);                        // device scan; HYPO_OK or C-ABI error
     void adopt_solid_scan(const uint64_t* words, const uint64_t* rank, const uint64_t* kids, uint64_t n_solid);
     void prepare_for_division(unsigned k);
     void divide_into_regions();

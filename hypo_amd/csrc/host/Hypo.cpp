@@ -60,9 +60,11 @@ void Hypo::polish() {
     _alignment_store.resize(_contigs.size());
 
     // ---- solid positions: device scan, one contig after the other (the C-ABI call is serialised on one stream) ------
+    // the 4^k-bit set goes to the device once (2 GiB at the default k = 17), not once per contig
     start();
+    if (hypo_gpu_solid_set_upload(sk.words.data(), sk.get_k()) != HYPO_OK) { std::fprintf(stderr, "[Hypo::Hypo] Error: %s\n", hypo_gpu_last_error()); std::exit(1); }
     for (auto& c : _contigs) {
-        if (c->find_solid_pos(sk) != HYPO_OK) { std::fprintf(stderr, "[Hypo::Contig] Error: %s\n", hypo_gpu_last_error()); std::exit(1); }
+        if (c->find_solid_pos(sk, true) != HYPO_OK) { std::fprintf(stderr, "[Hypo::Contig] Error: %s\n", hypo_gpu_last_error()); std::exit(1); }
     }
     stop("[Hypo:Hypo]: Found Solid pos in contigs. ");
 

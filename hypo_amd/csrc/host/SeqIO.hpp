@@ -278,6 +278,11 @@ private:
         for (int32_t i = 0; i < l_seq; ++i) { const unsigned char v = (unsigned char)p[o + (size_t)i / 2]; r.seq[(size_t)i] = kBase[(i & 1) ? (v & 15) : (v >> 4)]; }
         o += ((size_t)l_seq + 1) / 2 + (size_t)l_seq;                // seq, qual
         r.has_nm = false;
+        // Long-CIGAR convention (SAM spec 4.2.2): a record with more than 65535 operations stores `<l_seq>S<ref_len>N` in the
+        // CIGAR field and the real operations in the CG:B,I tag; htslib restores them on read (bam_tag2cigar), so the
+        // reference sees the real CIGAR.
+        const bool cg_placeholder = n_cig == 2 && (r.cigar[0] & 0xf) == 4 && (r.cigar[0] >> 4) == (uint32_t)l_seq && (r.cigar[1] & 0xf) == 3;
+        bool cg_found = false;
         while (o + 3 <= n) {                                          // optional fields: tag[2] type value
             const char t0 = p[o], t1 = p[o + 1], ty = p[o + 2];
             o += 3;
@@ -298,11 +303,22 @@ private:
                     const size_t es = (st == 'c' || st == 'C') ? 1 : ((st == 's' || st == 'S') ? 2 : 4);
                     adv = 5 + es * cnt; break;
                 }
-                default: return;                                      // unknown type: stop scanning
+                default: adv = n; break;                              // unknown type: stop scanning
             }
-            if (o + adv > n) return;
-            if (t0 == 'N' && t1 == 'M' && is_int) { r.has_nm = true; r.nm = iv; return; }
+            if (o + adv > n) break;
+            if (t0 == 'N' && t1 == 'M' && is_int) { r.has_nm = true; r.nm = iv; if (!cg_placeholder || cg_found) return; }
+            if (cg_placeholder && t0 == 'C' && t1 == 'G' && ty == 'B' && p[o] == 'I') {
+                const uint32_t cnt = (uint32_t)le32(p + o + 1);
+                r.cigar.resize(cnt);
+                for (uint32_t i = 0; i < cnt; ++i) { const uint32_t c = (uint32_t)le32(p + o + 5 + 4ull * i); r.cigar[i] = (c & 0xf) | ((c >> 4) << 4); }
+                cg_found = true;
+                if (r.has_nm) return;
+            }
             o += adv;
+        }
+        if (cg_placeholder && !cg_found) {
+            std::fprintf(stderr, "[Hypo::SamReader] Error: BAM record %s has a long-CIGAR placeholder but no CG:B,I tag\n", r.qname.c_str());
+            std::exit(1);
         }
     }
     bool _bam = false, _bam_ok = true;

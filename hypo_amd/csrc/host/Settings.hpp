@@ -36,6 +36,7 @@ struct MinimizerSettings { uint32_t k = 10, w = 10, cov_th = 5; double supp_frac
 struct WindowSettings { uint32_t ideal_swind_size = 100, ideal_lwind_size = 500, wind_size_search_th = 80; };
 struct ArmsSettings { uint32_t min_short_num = 3, min_internal_num1 = 20, min_internal_num2 = 5, min_internal_num3 = 10,
                       min_contrib = 10; double min_internal_contrib = 0.4; uint32_t short_arm_coef = 10; };
+constexpr uint32_t kMinimizerRingCap = 32;        // monotone-queue slots of the minimizer scans (need w + 1)
 static const SrSettings Sr_settings;
 static const MinimizerSettings Minimizer_settings;
 static const WindowSettings Window_settings;     // `-k ccs` never changes it in the reference (src/main.cpp:312)

@@ -79,7 +79,8 @@ public:
     }
 
 private:
-    friend struct WindowFlattener;
+    static int consensus_call(const ScoreParams& sp, const std::vector<Window*>& windows, const std::vector<uint32_t>* slot_hint,
+                              std::vector<uint8_t>& st, std::vector<uint32_t>& len);
     WindowType _wtype = WindowType::SHORT;
     uint32_t _num_internal = 0, _num_pre = 0, _num_suf = 0, _num_empty = 0;
     uint32_t _longest_pre_len = 0, _longest_suf_len = 0;

@@ -148,7 +148,7 @@ int main(int argc, char** argv) {
     const bool timing = std::getenv("HYPO_HOST_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
-    if (hypo_gpu_init(flags.device) != HYPO_OK) { std::fprintf(stderr, "[Hypo::] Error: %s\n", hypo_gpu_last_error()); return 1; }
+    if (hypo_gpu_init(&flags.device, 1) != HYPO_OK) { std::fprintf(stderr, "[Hypo::] Error: %s\n", hypo_gpu_last_error()); return 1; }
     if (timing) std::fprintf(stderr, "[timing] main: device initialised at %.3f s\n", since());
     {
         hypo::Hypo h(flags);

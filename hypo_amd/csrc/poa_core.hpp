@@ -57,7 +57,7 @@ enum { PH_LOAD = 0, PH_DP = 1, PH_TRACE = 2, PH_ADD = 3, PH_TOPO = 4, PH_CONS = 
 #define HYPO_TICK_RESET() do { } while (0)
 #endif
 
-enum { RES_OK = 0, RES_OVERFLOW = 1, RES_UNDEFINED = 2, RES_CONS_OVERFLOW = 3, RES_UNSUPPORTED = 4 };
+enum { RES_OK = 0, RES_OVERFLOW = 1, RES_UNDEFINED = 2, RES_CONS_OVERFLOW = 3, RES_UNSUPPORTED = 4, RES_INVALID = 5 };
 
 struct PoaParams {
     const HypoWindow* windows;
@@ -70,6 +70,7 @@ struct PoaParams {
     uint32_t* out_len;
     uint8_t* out_status;
     int sr_m, sr_n, sr_g, lr_m, lr_n, lr_g;
+    uint64_t n_arms, draft4_bytes, arms2_bytes;          // buffer sizes: descriptors are checked against them (RES_INVALID)
 };
 
 // How the per-window code reaches PoaParams.  On the device it is a pointer into the kernel-argument segment
@@ -265,7 +266,7 @@ struct Poa {
         if ((int)W.draft_len + (is_long ? 0 : 2) > Cfg::LMAX && base) return RES_OVERFLOW;
         g.sync();
         if (base && g.lane == 0) seqtab[0] = seq_ent(0, W.draft_len, !is_long, !is_long, MODE_NW, true, 2);
-        bool over = false, any_len = false;
+        bool over = false, any_len = false, bad = false;
         for (int t = g.lane; t < narm; t += GW) {
             int a, mode; bool head, tail;                  // consumption slot t -> arm index
             if (is_long) { a = t; mode = MODE_NW; head = false; tail = false; }   // all kNW, insertion order, no markers (Window.cpp:179-206)
@@ -273,10 +274,12 @@ struct Poa {
             else if (t < ni + np) { a = ni + (np - 1 - (t - ni)); mode = MODE_LOV; head = true; tail = false; }
             else { a = t; mode = MODE_ROV; head = false; tail = true; }
             const uint32_t len = P->arm_len[a0 + a];
+            { const uint64_t ao = P->arm_off[a0 + a], ab = P->arms2_bytes; if (ao > ab || ((uint64_t)len + 3) / 4 > ab - ao) { bad = true; continue; } }
             if (len + (is_long ? 0u : 2u) > (uint32_t)Cfg::LMAX) { over = true; continue; }
             if (len) any_len = true;
             seqtab[base + t] = seq_ent((uint32_t)a, len, head, tail, mode, false, 1);
         }
+        if (g.any(bad)) return RES_INVALID;
         if (g.any(over)) return RES_OVERFLOW;
         any_len = g.any(any_len);
         g.sync();
@@ -1481,6 +1484,9 @@ struct Poa {
         HYPO_TICK_RESET();
         const HypoWindow W = P->windows[w];
         const uint32_t ne = W.n_internal + W.n_prefix + W.n_suffix;
+        // a descriptor that points outside the batch's buffers is answered with HYPO_ST_INVALID, never followed
+        if ((uint64_t)W.n_internal + W.n_prefix + W.n_suffix > P->n_arms || (uint64_t)W.first_arm + ne > P->n_arms ||
+            W.draft_off > P->draft4_bytes || ((uint64_t)W.draft_len + 1) / 2 > P->draft4_bytes - W.draft_off) return RES_INVALID;
         if (W.n_empty > ne) { finish(w, HYPO_ST_OK, 0); return RES_OK; }
         if (ne < 2) return emit_draft(w, P->draft4 + W.draft_off, (int)W.draft_len);
         if (W.type != HYPO_WIN_SHORT) {

@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through t
         } else {
             if (g.lane == 0) {
                 P->out_len[w] = 0;
-                P->out_status[w] = (uint8_t)(rc == RES_UNDEFINED ? HYPO_ST_UNDEFINED : HYPO_ST_CAPACITY);
+                P->out_status[w] = (uint8_t)(rc == RES_UNDEFINED ? HYPO_ST_UNDEFINED : (rc == RES_INVALID ? HYPO_ST_INVALID : HYPO_ST_CAPACITY));
             }
             ++n_fail;
         }

@@ -14,8 +14,9 @@
  *    given hipStream_t (passed as void*); plain variants take HOST pointers and do H2D/D2H themselves.
  *    (hypo_gpu_poa_batch_device returns once all kernels are queued; on the way it waits for its own plan
  *    step, ~0.1 ms of device time, to size the launches of the rare size classes.)
- *  - one device context per process (hypo_gpu_init).  Entry points may be called from several host threads; the host part
- *    of a call (enqueueing, the plan wait, the copies of the host-buffer variants) is serialised inside the library.
+ *  - one device context per device handed to hypo_gpu_init.  A host thread works on the context it selected with
+ *    hypo_gpu_use_device (slot 0 until then); calls on different contexts run concurrently, the host part of calls on
+ *    the same context (enqueueing, the copies of the host-buffer variants) is serialised inside the library.
  *  - sequences are packed exactly like the reference's PackedSeq<NB> (src/PackedSeq.cpp:58-89):
  *    MSB-first inside a byte, 2 bases/byte for NB=4 (codes A0 C1 G2 T3 N4), 4 bases/byte for NB=2.
  *    Every sequence starts on a byte boundary of its buffer.
@@ -30,7 +31,8 @@
 extern "C" {
 #endif
 
-#define HYPO_GPU_ABI_VERSION 3
+#define HYPO_GPU_ABI_VERSION 4
+#define HYPO_MAX_DEVICES 16      /* contexts one process can hold (an MI355X node has 8 GPUs) */
 
 /* error codes */
 #define HYPO_OK              0
@@ -46,6 +48,8 @@ extern "C" {
 #define HYPO_ST_CAPACITY      2  /* window exceeds the largest device size class */
 #define HYPO_ST_UNDEFINED     3  /* input hits behaviour that is undefined in the reference
                                     (graph.cpp:184-200: alignment without any sequence position) */
+#define HYPO_ST_INVALID       4  /* the window's descriptor points outside the batch's buffers (first_arm + arms > n_arms,
+                                    draft_off / arm_off + bytes beyond draft4_bytes / arms2_bytes); nothing was read there */
 
 /* Reference: ScoreParams, include/globalDefs.hpp:58-66 (same field order, INT8 each). */
 typedef struct HypoScoreParams {
@@ -104,13 +108,21 @@ typedef struct HypoConsensusBatch {
 
 /* Runtime ------------------------------------------------------------------------------------- */
 
-/* Selects the HIP device, creates the library's stream and device arenas.  Replaces nothing in the
- * reference (there is no device there); closest analogue Hypo::Hypo, src/Hypo.cpp:34-36. */
-int hypo_gpu_init(int device_id);
+/* Creates one context (stream, device arenas) per listed HIP device; (NULL, 0) = device 0 only.  The calling thread is left
+ * on context 0.  Replaces nothing in the reference (there is no device there); closest analogue Hypo::Hypo,
+ * src/Hypo.cpp:34-36.  Calling it again releases the previous contexts first. */
+int hypo_gpu_init(const int* device_ids, int n_devices);
 int hypo_gpu_shutdown(void);
 int hypo_gpu_abi_version(void);
 const char* hypo_gpu_last_error(void);
-/* Number of compute units of the selected device (0 before init). */
+/* Contexts created by hypo_gpu_init (0 before). */
+int hypo_gpu_num_devices(void);
+/* Makes context `slot` (index into the device list of hypo_gpu_init) the one this THREAD's later calls work on. */
+int hypo_gpu_use_device(int slot);
+/* First 16 hex digits of the SHA-256 over the library's sources (the .hip and .hpp files of hypo_amd/csrc and this header, in sorted
+ * order), embedded at build time: says which sources a prebuilt libhypo_gpu.so came from (tests/test_abi.py checks it). */
+const char* hypo_gpu_build_id(void);
+/* Number of compute units of the calling thread's device (0 before init). */
 int hypo_gpu_num_cus(void);
 
 /* Solid-kmer scan --------------------------------------------------------------------------------
@@ -127,7 +139,11 @@ int hypo_gpu_num_cus(void);
  *   word_rank        optional (may be NULL): ceil(n_bases/64)+1 exclusive prefix counts of set bits
  *                    per word = the directory behind sdsl rank_1/select_1 (Contig.cpp:72-73)
  *   n_solid          total number of marked positions (even if > kids_cap)
+ * bitset_words == NULL: use the set last uploaded to this context with hypo_gpu_solid_set_upload (same k), so that a run
+ * over many contigs sends the 4^k-bit set (2 GiB at k = 17) to the device once, like the reference loads it once
+ * (src/Hypo.cpp:70-77).
  */
+int hypo_gpu_solid_set_upload(const uint64_t* bitset_words, uint32_t k);
 int hypo_gpu_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k,
                         const uint64_t* bitset_words,
                         uint64_t* solid_pos_words, uint64_t* kids, uint64_t kids_cap,

@@ -201,3 +201,43 @@ class Ref:
         out = C.create_string_buffer(len(text) + 8)
         r = self.lib.hyporef_pack_roundtrip(C.c_int(nb), text.encode(), out, C.c_int(len(text) + 8))
         return out.raw[:r].decode()
+
+
+REF_SCAN_SO = os.path.join(HERE, "_ref", "libhyporef_scan.so")
+
+
+class RefScan:
+    """The real Contig::find_solid_pos over the real suk::SolidKmers / sdsl bit vector (oracle/ref_scan_harness.cpp)."""
+
+    def __init__(self, path: str = REF_SCAN_SO):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path + " (build it with `make -C oracle ref` where /root/reference exists)")
+        self.lib = C.CDLL(path)
+        self.lib.hyporef_solid_scan.restype = C.c_int
+
+    @staticmethod
+    def available() -> bool:
+        return os.path.exists(REF_SCAN_SO)
+
+    def solid_scan(self, text: bytes, k: int, bits: np.ndarray):
+        """text: ASCII contig; bits: 4^k-bit set as little-endian u64 words.  Returns (words, kids, rank, n_solid) like
+        Oracle.solid_scan.  The bit set travels through a temporary .bvsd file because SolidKmers only exposes load()."""
+        import tempfile
+        n = len(text)
+        nw = (n + 63) // 64
+        words = np.zeros(max(nw, 1), dtype=np.uint64)
+        kids = np.zeros(max(n, 1), dtype=np.uint64)
+        rank = np.zeros(nw + 1, dtype=np.uint64)
+        ns = C.c_uint64(0)
+        with tempfile.NamedTemporaryFile(suffix=".bvsd", delete=False) as f:
+            f.write(np.uint64(4 ** k).tobytes())
+            f.write(np.ascontiguousarray(bits, dtype=np.uint64).tobytes())
+            path = f.name
+        try:
+            rc = self.lib.hyporef_solid_scan(text, C.c_uint64(n), C.c_uint32(k), path.encode(), _ptr(words), _ptr(kids),
+                                             C.c_uint64(n), _ptr(rank), C.byref(ns))
+        finally:
+            os.unlink(path)
+        if rc != 0:
+            raise RuntimeError(f"hyporef_solid_scan rc={rc}")
+        return words[:nw], kids[:int(ns.value)], rank, int(ns.value)

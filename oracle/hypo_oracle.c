@@ -664,16 +664,16 @@ int oracle_replay(int m, int n, int gp, int n_seq, const char* const* seqs, cons
  * --------------------------------------------------------------------------------------------- */
 static inline unsigned enc4(const uint8_t* p, uint64_t i) { return (p[i >> 1] >> (4 - 4 * (i & 1))) & 15; }
 
-int oracle_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k,
-                      const uint64_t* bits,
-                      uint64_t* solid_pos_words, uint64_t* kids, uint64_t kids_cap,
-                      uint64_t* word_rank, uint64_t* n_solid) {
-    if (!packed4 || !bits || !solid_pos_words || k < 2 || k > 31) return HYPO_E_INVALID;
-    uint64_t nw = (n_bases + 63) / 64;
-    memset(solid_pos_words, 0, nw * 8);
+/* The reference's loop (Contig.cpp:46-71) restated once, for the k-mers that START in [beg0, beg1): the rolling state at
+ * position i depends only on the last k bases (an N resets it), so a chunk that starts rolling at beg0 sees exactly the
+ * k-mers the single loop sees there.  kids == NULL: count only. */
+static uint64_t scan_range(const uint8_t* packed4, uint64_t n_bases, uint32_t k, const uint64_t* bits,
+                           uint64_t beg0, uint64_t beg1, uint64_t* solid_pos_words, uint64_t* kids, uint64_t kids_at,
+                           uint64_t kids_cap) {
     const uint64_t kmask = (1ULL << (2 * k)) - 1;
     uint64_t kmer = 0, cnt = 0; uint32_t klen = 0;
-    for (uint64_t i = 0; i < n_bases; ++i) {
+    uint64_t iend = beg1 + k - 1; if (iend > n_bases) iend = n_bases;
+    for (uint64_t i = beg0; i < iend; ++i) {
         unsigned b = enc4(packed4, i);
         if (b < 4) { kmer = ((kmer << 2) | b) & kmask; if (klen < k) ++klen; }
         else { klen = 0; kmer = 0; }
@@ -683,12 +683,44 @@ int oracle_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k,
             uint64_t beg = i + 1 - k;
             if (beg > 0 && enc4(packed4, beg - 1) == enc4(packed4, beg)) add = 0;
             if (add) {
-                solid_pos_words[beg >> 6] |= 1ULL << (beg & 63);
-                if (kids && cnt < kids_cap) kids[cnt] = kmer;
+                if (solid_pos_words) solid_pos_words[beg >> 6] |= 1ULL << (beg & 63);
+                if (kids && kids_at + cnt < kids_cap) kids[kids_at + cnt] = kmer;
                 ++cnt;
             }
         }
     }
+    return cnt;
+}
+
+int oracle_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k,
+                      const uint64_t* bits,
+                      uint64_t* solid_pos_words, uint64_t* kids, uint64_t kids_cap,
+                      uint64_t* word_rank, uint64_t* n_solid) {
+    if (!packed4 || !bits || !solid_pos_words || k < 2 || k > 31) return HYPO_E_INVALID;
+    uint64_t nw = (n_bases + 63) / 64;
+    memset(solid_pos_words, 0, nw * 8);
+    /* chunks own whole output words; small contigs run as one chunk (= the reference's single loop) */
+    const uint64_t chunk_words = 1 << 14;
+    const uint64_t nchunk = nw ? (nw + chunk_words - 1) / chunk_words : 0;
+    uint64_t* ccnt = (uint64_t*)calloc(nchunk + 1, sizeof(uint64_t));
+    if (!ccnt) return HYPO_E_INVALID;
+    #pragma omp parallel for schedule(dynamic, 1)
+    for (uint64_t c = 0; c < nchunk; ++c) {
+        uint64_t b0 = c * chunk_words * 64, b1 = (c + 1) * chunk_words * 64;
+        if (b1 > n_bases) b1 = n_bases;
+        ccnt[c + 1] = scan_range(packed4, n_bases, k, bits, b0, b1, solid_pos_words, NULL, 0, 0);
+    }
+    for (uint64_t c = 0; c < nchunk; ++c) ccnt[c + 1] += ccnt[c];
+    const uint64_t cnt = ccnt[nchunk];
+    if (kids) {
+        #pragma omp parallel for schedule(dynamic, 1)
+        for (uint64_t c = 0; c < nchunk; ++c) {
+            uint64_t b0 = c * chunk_words * 64, b1 = (c + 1) * chunk_words * 64;
+            if (b1 > n_bases) b1 = n_bases;
+            if (ccnt[c] < kids_cap) scan_range(packed4, n_bases, k, bits, b0, b1, NULL, kids, ccnt[c], kids_cap);
+        }
+    }
+    free(ccnt);
     if (word_rank) {
         uint64_t acc = 0;
         for (uint64_t w = 0; w < nw; ++w) { word_rank[w] = acc; acc += (uint64_t)__builtin_popcountll(solid_pos_words[w]); }

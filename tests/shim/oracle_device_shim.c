@@ -12,7 +12,8 @@
 #include "../../oracle/hypo_oracle.h"
 
 static int g_ready = 0;
-int hypo_gpu_init(int device_id) { (void)device_id; g_ready = 1; fprintf(stderr, "[oracle_device_shim] TEST SHIM in use: CPU oracle behind the C-ABI\n"); return HYPO_OK; }
+static const uint64_t* g_set = 0; static uint32_t g_set_k = 0;
+int hypo_gpu_init(const int* device_ids, int n_devices) { (void)device_ids; (void)n_devices; g_ready = 1; fprintf(stderr, "[oracle_device_shim] TEST SHIM in use: CPU oracle behind the C-ABI\n"); return HYPO_OK; }
 int hypo_gpu_shutdown(void) { g_ready = 0; return HYPO_OK; }
 int hypo_gpu_abi_version(void) { return HYPO_GPU_ABI_VERSION; }
 const char* hypo_gpu_last_error(void) { return "oracle_device_shim"; }
@@ -21,8 +22,15 @@ int hypo_gpu_num_cus(void) { return 0; }
 int hypo_gpu_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k, const uint64_t* bitset_words,
                         uint64_t* solid_pos_words, uint64_t* kids, uint64_t kids_cap, uint64_t* word_rank, uint64_t* n_solid) {
     if (!g_ready) return HYPO_E_NOTINIT;
+    if (!bitset_words) { if (g_set_k != k) return HYPO_E_INVALID; bitset_words = g_set; }
     return oracle_solid_scan(packed4, n_bases, k, bitset_words, solid_pos_words, kids, kids_cap, word_rank, n_solid);
 }
+
+/* the caller's buffer outlives the scans of a run (host/Hypo.cpp keeps the SolidKmers object alive) */
+int hypo_gpu_solid_set_upload(const uint64_t* bitset_words, uint32_t k) { g_set = bitset_words; g_set_k = k; return HYPO_OK; }
+int hypo_gpu_num_devices(void) { return g_ready ? 1 : 0; }
+int hypo_gpu_use_device(int slot) { return slot == 0 ? HYPO_OK : HYPO_E_INVALID; }
+const char* hypo_gpu_build_id(void) { return "oracle_device_shim"; }
 
 int hypo_gpu_poa_slot_layout(const HypoWindowBatch* in, uint64_t* off) {
     uint64_t acc = 0;

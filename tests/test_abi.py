@@ -44,7 +44,7 @@ def test_fails_loudly_without_device(lib):
     import torch
     if torch.cuda.is_available():
         pytest.skip("a GPU is present")
-    assert lib.hypo_gpu_init(0) == abi.HYPO_E_NODEVICE
+    assert lib.hypo_gpu_init(None, 0) == abi.HYPO_E_NODEVICE
     assert b"no HIP device" in lib.hypo_gpu_last_error()
     sp = abi.ScoreParams(*abi.DEFAULT_SCORES)
     ins, out = abi.WindowBatch(), abi.ConsensusBatch()
@@ -56,3 +56,17 @@ def test_fails_loudly_without_device(lib):
 def test_missing_library_is_an_error(tmp_path):
     with pytest.raises(capi.HypoGpuError):
         capi.load_library(str(tmp_path / "nope.so"))
+
+
+def test_build_id_matches_sources(lib):
+    """hypo_gpu_build_id() = first 16 hex digits of sha256 over the library's sources (sorted paths), embedded by the
+    Makefile: a prebuilt libhypo_gpu.so that does not come from the sources in the tree fails here."""
+    import glob
+    import hashlib
+    csrc = os.path.join(ROOT, "hypo_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")) +
+                   [os.path.join(csrc, "..", "..", "include", "hypo_gpu.h")])
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(f, "rb").read())
+    assert lib.hypo_gpu_build_id().decode() == h.hexdigest()[:16]

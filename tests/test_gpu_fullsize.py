@@ -113,3 +113,73 @@ def test_scan_c3_c4_sizes_vs_oracle(gpu, oracle_lib, n_bases, k):
     ow, okids, orank, ons = oracle_lib.solid_scan(p4, n_bases, k, bits, kids_cap=cap)
     assert ns == ons and (w == ow).all() and (rank == orank).all() and (kids == okids).all()
     assert int(rank[-1]) == ns == int(np.unpackbits(w.view(np.uint8)).sum())
+
+
+# ---- C5 (BASELINE.json configs[4]): 3 Gbp draft => k = 17 (2 GiB bit set, src/main.cpp:490-528), 50x HiFi reads passed as
+# ---- "short" (44-57 internal arms per window), wide windows ----------------------------------------------------------------
+def test_scan_c5_k17_vs_oracle(gpu, oracle_lib):
+    """k = 17: the 4^17-bit set is 2 GiB (far beyond L2 and the Infinity Cache); 512 Mbp of contig, every probe a random
+    HBM sector."""
+    k, n_bases = 17, 512_000_000
+    rng = np.random.default_rng(k)
+    codes = rng.integers(0, 4, size=n_bases, dtype=np.uint8)
+    codes[rng.integers(0, n_bases, size=n_bases // 5000)] = 4
+    pad = codes.reshape(-1, 2)
+    p4 = ((pad[:, 0] << 4) | pad[:, 1]).astype(np.uint8)
+    del codes, pad
+    nw = (1 << (2 * k)) // 64
+    bits = rng.integers(0, 1 << 63, size=nw, dtype=np.int64).view(np.uint64)
+    bits &= rng.integers(0, 1 << 63, size=nw, dtype=np.int64).view(np.uint64)        # ~25 % of all 17-mers solid
+    cap = n_bases // 4
+    ds = gpu.device_scan(p4, n_bases, k, bits, kids_cap=cap)
+    ds.run()
+    w, kids, rank, ns = ds.results()
+    del ds
+    ow, okids, orank, ons = oracle_lib.solid_scan(p4, n_bases, k, bits, kids_cap=cap)
+    assert ns == ons and (w == ow).all() and (rank == orank).all() and (kids == okids).all()
+    assert int(rank[-1]) == ns
+
+
+def _tiny_lengths(rng, n):
+    return rng.choice([3, 5, 8, 12, 16, 24, 32, 48, 64, 99], size=n, p=[.15, .15, .15, .13, .13, .1, .1, .05, .03, .01])
+
+
+def test_c5_hifi_shape_million_windows_vs_oracle(gpu, oracle_lib):
+    """1.05 M windows of the dense shape with 44-57 internal arms each (50x HiFi reads given as -b): 53 M alignments in one
+    call, compared window by window with the oracle."""
+    n = 1_050_000
+    rng = np.random.default_rng(55)
+    shapes = np.stack([_tiny_lengths(rng, n), rng.integers(44, 58, size=n), np.zeros(n, np.int64), np.zeros(n, np.int64),
+                       np.zeros(n, np.int64)], axis=1)
+    b = sim.window_batch(n, seed=56, shapes=shapes, read_sub=0.001)
+    off = b.slot_layout()
+    db = gpu.device_batch(b, off=off)
+    db.run()
+    bases, _, ln, st = db.results()
+    s = db.stats()
+    ob, _, oln, ost, cells, aligns = oracle_lib.poa_batch_raw(b, off=off)
+    assert (st == ost).all() and (ln == oln).all() and s["n_failed"] == 0
+    assert s["dp_cells"] == cells and s["n_alignments"] == aligns
+    l64 = ln.astype(np.int64)
+    idx = np.repeat(off[:-1].astype(np.int64), l64) + (np.arange(int(l64.sum()), dtype=np.int64) - np.repeat(np.cumsum(l64) - l64, l64))
+    assert (bases[idx] == ob[idx]).all()
+
+
+def test_c5_wide_windows_full_batch_vs_oracle(gpu, oracle_lib):
+    """The LDS-pressure case: 60 000 windows of 160-200 bp (the reference cuts a weak region only above 2 x 100 bp,
+    src/Contig.cpp:526-711) with 30-56 arms, all in the 40 KB size class."""
+    n = 60_000
+    rng = np.random.default_rng(77)
+    ni = rng.integers(24, 44, size=n)
+    shapes = np.stack([rng.integers(160, 201, size=n), ni, rng.integers(3, 7, size=n), rng.integers(3, 7, size=n),
+                       np.zeros(n, np.int64)], axis=1)
+    b = sim.window_batch(n, seed=78, shapes=shapes, read_sub=0.003)
+    off = b.slot_layout()
+    db = gpu.device_batch(b, off=off)
+    db.run()
+    bases, _, ln, st = db.results()
+    s = db.stats()
+    ob, _, oln, ost, cells, aligns = oracle_lib.poa_batch_raw(b, off=off)
+    assert (st == ost).all() and (ln == oln).all() and s["n_failed"] == 0
+    assert s["dp_cells"] == cells and s["n_alignments"] == aligns
+    assert _cons_list(bases, off, ln) == _cons_list(ob, off, oln)

@@ -228,3 +228,36 @@ def test_concurrent_host_threads(gpu, oracle_lib):
         bases, off, ln, st = dbs[t].results()
         ob, _, oln, ost, _, _ = oracle_lib.poa_batch_raw(batches[t], off=off)
         assert (st == ost).all() and (ln == oln).all() and _same_consensus(bases, ob, off, ln), t
+
+
+def test_bad_descriptors_are_answered_not_followed(gpu, oracle_lib):
+    """Windows whose descriptor points outside the batch's buffers get HYPO_ST_INVALID; their neighbours are unaffected."""
+    b = sim.window_batch(300, seed=31)
+    good = oracle_lib.poa_batch(b)[0]
+    w = b.windows.copy()
+    w["first_arm"][5] = b.n_arms - 1                      # arms run past n_arms
+    w["draft_off"][9] = b.draft4.size + 100               # draft outside draft4
+    w["n_internal"][13] = 0xfffffff0                      # count overflow
+    ao = b.arm_off.copy()
+    a17 = int(w["first_arm"][17])
+    ao[a17] = np.uint64(b.arms2.size + 5)                 # one arm's bytes outside arms2
+    from hypo_amd.batch import HostBatch
+    bad = HostBatch(w, b.draft4, ao, b.arm_len, b.arms2)
+    off = b.slot_layout()
+    db = gpu.device_batch(bad, off=off)
+    db.run()
+    bases, _, ln, st = db.results()
+    for i in (5, 9, 13, 17):
+        assert st[i] == abi.ST_INVALID and ln[i] == 0, (i, st[i])
+    for i in range(300):
+        if i not in (5, 9, 13, 17):
+            assert st[i] == 0 and bases[int(off[i]):int(off[i]) + int(ln[i])].tobytes().decode() == good[i]
+    with pytest.raises(capi.HypoGpuError):                # the host-side helper refuses to index past the arm table
+        gpu.poa_batch(bad)
+
+
+def test_build_id_and_contexts(gpu):
+    import test_abi
+    test_abi.test_build_id_matches_sources(gpu.lib)
+    assert gpu.lib.hypo_gpu_num_devices() == 1
+    assert gpu.lib.hypo_gpu_use_device(0) == 0 and gpu.lib.hypo_gpu_use_device(1) == abi.HYPO_E_INVALID

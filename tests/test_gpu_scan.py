@@ -69,3 +69,38 @@ def test_scan_random_sizes_and_k(gpu, oracle_lib):
         w, kids, rank, ns = gpu.solid_scan(p4, n, k, bits)
         ow, okids, orank, ons = oracle_lib.solid_scan(p4, n, k, bits)
         assert ns == ons and (w == ow).all() and (kids == okids).all() and (rank == orank).all(), (it, n, k, nfrac, dens)
+
+
+def test_scan_vs_reference_fixture(gpu):
+    """G3: the device against the outputs of the REAL hypo::Contig::find_solid_pos (tests/golden/scan_cases.json.gz)."""
+    from test_scan_golden import scan_cases
+    for c, p4, bits, words, kids, rank in scan_cases():
+        w, gk, gr, ns = gpu.solid_scan(p4, c["n"], c["k"], bits)
+        assert ns == c["n_solid"], (c["n"], c["k"])
+        assert (w == words[:w.size]).all() and (gk == kids).all() and (gr == rank).all(), (c["n"], c["k"])
+
+
+def test_uploaded_solid_set_is_reused(gpu, oracle_lib):
+    """hypo_gpu_solid_set_upload once, then scans with bitset_words == NULL (how the host pipeline scans many contigs)."""
+    import ctypes as C
+    k = 11
+    codes0, _ = sim.random_contig(300000, seed=1)
+    bits = sim.solid_bitset(codes0, k)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert gpu.lib.hypo_gpu_solid_set_upload(p(bits), C.c_uint32(k)) == 0
+    for seed, n in [(1, 300000), (2, 12345)]:
+        codes, p4 = sim.random_contig(n, seed=seed)
+        nw = (n + 63) // 64
+        words = np.zeros(nw, np.uint64); kids = np.zeros(n, np.uint64); rank = np.zeros(nw + 1, np.uint64); ns = C.c_uint64(0)
+        rc = gpu.lib.hypo_gpu_solid_scan(p(p4), C.c_uint64(n), C.c_uint32(k), None, p(words), p(kids), C.c_uint64(n), p(rank), C.byref(ns))
+        assert rc == 0
+        ow, okids, orank, ons = oracle_lib.solid_scan(p4, n, k, bits)
+        assert ns.value == ons and (words == ow).all() and (kids[:ons] == okids).all() and (rank == orank).all()
+    # a different k without an upload is an error, not a stale set
+    rc = gpu.lib.hypo_gpu_solid_scan(p(p4), C.c_uint64(n), C.c_uint32(9), None, p(words), p(kids), C.c_uint64(n), p(rank), C.byref(ns))
+    assert rc == abi_invalid()
+
+
+def abi_invalid():
+    from hypo_amd import abi
+    return abi.HYPO_E_INVALID

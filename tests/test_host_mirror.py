@@ -71,3 +71,19 @@ def test_contig_scan_rank_select(mirror, device, oracle_lib):
     assert n == ons and (kids == okids).all()
     assert ra.tolist() == [int((pos < q).sum()) for q in rq]
     assert sa.tolist() == [int(pos[i - 1]) for i in sq]
+
+
+@pytest.mark.gpu
+def test_window_beyond_device_capacity_keeps_its_draft(mirror, device, capfd):
+    """A window deeper than the largest size class (1 100 arms > 1 023 sequences) must not stop the run: it keeps its
+    draft with a warning (the documented degraded path), its neighbours are polished as usual."""
+    import random
+    rng = random.Random(5)
+    truth = "".join(rng.choice("ACGT") for _ in range(40))
+    draft = truth[:10] + "A" + truth[11:]
+    deep = TextWindow(draft, [truth] * 1100)
+    normal = TextWindow(draft, [truth] * 8)
+    cons, _ = mirror.windows([normal, deep, normal], batched=True)
+    assert cons[0] == truth and cons[2] == truth
+    assert cons[1] == draft
+    assert "kept unpolished" in capfd.readouterr().err

@@ -57,3 +57,28 @@ def test_random_long_windows(oracle_lib, ref_lib):
     for w, c, s in zip(wins, cons, st):
         assert s == 0
         assert ref_lib.window(w)[0] == c
+
+
+def test_scan_vs_real_contig_find_solid_pos(oracle_lib):
+    """oracle_solid_scan against hypo::Contig::find_solid_pos itself (oracle/_ref/libhyporef_scan.so), incl. a contig that
+    spans several of the oracle's OpenMP chunks."""
+    import numpy as np
+    import pytest
+    import oracle
+    from hypo_amd import sim
+    if not oracle.RefScan.available():
+        pytest.skip("oracle/_ref/libhyporef_scan.so not built (the real reference only exists in the build container)")
+    ref = oracle.RefScan()
+    rng = np.random.default_rng(11)
+    for n, k, nfrac in [(1, 2, 0.0), (9, 5, 0.0), (777, 4, 0.05), (70000, 9, 0.002), (1_300_001, 10, 0.0005), (250000, 11, 0.0)]:
+        codes, p4 = sim.random_contig(n, seed=n + k, n_frac=nfrac)
+        for _ in range(n // 150):
+            s = int(rng.integers(0, max(n - 8, 1)))
+            codes[s:s + int(rng.integers(2, 8))] = rng.integers(0, 4)
+        pad = np.concatenate([codes, np.zeros((-n) % 2, np.uint8)]).reshape(-1, 2)
+        p4 = ((pad[:, 0] << 4) | pad[:, 1]).astype(np.uint8)
+        bits = sim.solid_bitset(codes, k, max_count=25 if k < 11 else 1)
+        text = np.frombuffer(b"ACGTN", dtype=np.uint8)[codes].tobytes()
+        rw, rk, rr, rn = ref.solid_scan(text, k, bits)
+        ow, ok, orank, on = oracle_lib.solid_scan(p4, n, k, bits)
+        assert rn == on and (rw == ow).all() and (rk == ok).all() and (rr == orank).all(), (n, k)
