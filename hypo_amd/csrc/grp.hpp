@@ -90,6 +90,8 @@ struct Grp {
         sync();
         return r;
     }
+    // same with the identity handed in as a loop-carried value (device: lane 0 of the final shift keeps what it had)
+    HD int scan_max_excl_c(int v, int carry) const { const int r = scan_max_excl(v, (int)0x80000000); return lane ? r : carry; }
     HD int uniform(int v) const { return v; }
 };
 HD int popc64(uint64_t x) { return __builtin_popcountll(x); }
@@ -154,6 +156,19 @@ struct Grp {
         if (GW >= 32) { t = dpp_mov<0x142, 0xa>(ID, x); x = t > x ? t : x; }   // row_bcast:15 -> rows 1,3
         if (GW == 64) { t = dpp_mov<0x143, 0xc>(ID, x); x = t > x ? t : x; }   // row_bcast:31 -> rows 2,3
         return shfl_up1(x, ID);
+    }
+    // Same scan for a loop: `carry` is the previous iteration's result.  The final shift never writes lane 0 of a group, so
+    // that lane keeps the identity it started with and no constant has to be re-materialised per iteration.
+    HD int scan_max_excl_c(int v, int carry) const {
+        constexpr int ID = (int)0x80000000;
+        int x = v, t;
+        t = dpp_mov<0x111>(ID, x); x = t > x ? t : x;
+        t = dpp_mov<0x112>(ID, x); x = t > x ? t : x;
+        t = dpp_mov<0x114>(ID, x); x = t > x ? t : x;
+        t = dpp_mov<0x118>(ID, x); x = t > x ? t : x;
+        if (GW >= 32) { t = dpp_mov<0x142, 0xa>(ID, x); x = t > x ? t : x; }
+        if (GW == 64) { t = dpp_mov<0x143, 0xc>(ID, x); x = t > x ? t : x; }
+        return shfl_up1(x, carry);
     }
     // hint: value is identical in every lane of the WAVE (only true for GW == 64)
     HD int uniform(int v) const { return GW == 64 ? __builtin_amdgcn_readfirstlane(v) : v; }

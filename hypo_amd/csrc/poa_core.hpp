@@ -89,9 +89,19 @@ struct PoaParamRef {
 };
 #endif
 
+// exact threading of sequences that spell a path (Poa::rows_exact); HYPO_EXACT=0 sends every alignment through the score rows
+#ifndef HYPO_EXACT
+#define HYPO_EXACT 1
+#endif
+// int16 score rows as packed pairs of columns (Poa::rows_pk); HYPO_PACKED=0 builds the one-column-per-register loop everywhere
+#ifndef HYPO_PACKED
+#define HYPO_PACKED 1
+#endif
 template <int GW_, int CPL_, int LCAP_, int NMAX_, int KIN_, int DIRCELLS_, int RINGCELLS_, int ARMBYTES_,
           int SEQMAX_, class ScoreT, class IdT, int PATHCAP_ = 0, bool HYBRID_ = false>
 struct PoaCfg {
+    // the packed row loop: int16 rows, 4-bit direction codes, an even number of columns per lane, state in LDS
+    static constexpr bool PACKED = HYPO_PACKED && sizeof(ScoreT) == 2 && CPL_ % 2 == 0 && CPL_ <= 8 && !HYBRID_ && (KIN_ <= 7);
     static constexpr bool HYBRID = HYBRID_;     // state in HBM scratch except the arrays the graph walks hammer (PoaLayout::FAST_BYTES of LDS)
     static constexpr int PATHCAP = PATHCAP_;    // node ids of the sequences' paths (LONG windows only; 0 = class cannot run them)
     static constexpr int GW = GW_;              // lanes per window
@@ -131,13 +141,16 @@ struct PoaLayout {   // byte offsets inside a group's memory slice
     typedef typename Cfg::id_t id_t;
     static constexpr int oRing = 0;                                                     // ring, then dir: contiguous
     static constexpr int oDir = oRing + align_up<16>(Cfg::RINGCELLS * (int)sizeof(score_t));   // (consensus scratch aliases both)
-    static constexpr int oRowmeta = oDir + align_up<16>(Cfg::DIRBYTES);
+    // posnode (alignment -> graph update) and the DFS stack (toposort, arm staging) are never live together, and neither is
+    // live during the row loop: the packed loop lets lanes beyond a row's width store their (unused) direction codes, which
+    // land in the following rows' cells or, behind the last row, at most GW * CPL / 2 bytes into this region
+    static constexpr int POS_BYTES = (Cfg::LMAX + 1) * 2 > Cfg::STK * (int)sizeof(id_t) ? (Cfg::LMAX + 1) * 2 : Cfg::STK * (int)sizeof(id_t);
+    static_assert(!Cfg::PACKED || POS_BYTES >= Cfg::GW * Cfg::CPL / 2, "slack behind the direction codes");
+    static constexpr int oPosnode = oDir + align_up<16>(Cfg::DIRBYTES);
+    static constexpr int oRowmeta = oPosnode + align_up<16>(POS_BYTES);
     static constexpr int oSeqtab = oRowmeta + align_up<16>(Cfg::NMAX * 4);
     static constexpr int oInw = oSeqtab + align_up<16>(Cfg::SEQMAX * 4);
-    static constexpr int oPosnode = oInw + align_up<16>(Cfg::NMAX * Cfg::KIN * (int)sizeof(typename Cfg::wt_t));
-    // posnode (alignment -> graph update) and the DFS stack (toposort, arm staging) are never live together
-    static constexpr int POS_BYTES = (Cfg::LMAX + 1) * 2 > Cfg::STK * (int)sizeof(id_t) ? (Cfg::LMAX + 1) * 2 : Cfg::STK * (int)sizeof(id_t);
-    static constexpr int oInp = oPosnode + align_up<16>(POS_BYTES);
+    static constexpr int oInp = oInw + align_up<16>(Cfg::NMAX * Cfg::KIN * (int)sizeof(typename Cfg::wt_t));
     static constexpr int oAl = oInp + align_up<16>(Cfg::NMAX * Cfg::KIN * (int)sizeof(id_t));
     static constexpr int oR2n = oAl + align_up<16>(Cfg::NMAX * Cfg::AL * (int)sizeof(id_t));
     static constexpr int oN2r = oR2n + align_up<16>(Cfg::NMAX * (int)sizeof(id_t));
@@ -185,11 +198,8 @@ struct Poa {
     static constexpr int GW = Cfg::GW, CPL = Cfg::CPL, KIN = Cfg::KIN, NMAX = Cfg::NMAX, AL = Cfg::AL;
     static constexpr bool NIB = Cfg::NIB;
     static constexpr int NEG = -(1 << 29);
-    // int16 score rows as packed pairs of columns (rows_pk below); HYPO_PACKED=0 builds the one-column-per-register loop everywhere
-#ifndef HYPO_PACKED
-#define HYPO_PACKED 1
-#endif
-    static constexpr bool PK = HYPO_PACKED && sizeof(typename Cfg::score_t) == 2 && Cfg::CPL % 2 == 0 && Cfg::CPL <= 8 && !Cfg::HYBRID && Cfg::NIB;
+    static constexpr bool PK = Cfg::PACKED;
+    static_assert(!PK || Cfg::NIB, "packed rows store nibble codes");
     // direction codes
     static constexpr int DIR_FAST = NIB ? 15 : 0xFF;     // diagonal via pred 0 and pred 0 is the previous row
     static constexpr int DIR_HORIZ = NIB ? 14 : 0xFE;
@@ -217,6 +227,7 @@ struct Poa {
     score_t* ring; uint8_t* dir; uint32_t* rowmeta; uint32_t* seqtab; wt_t* inw; int16_t* posnode;
     id_t *inp, *al, *r2n, *n2r, *stack;
     uint8_t *code, *nin, *nout, *nal, *mark, *seq, *armbuf;
+    uint8_t* sidx;                                           // packed classes: SAVEd rows before each row (aliases mark: toposort and the row loop never overlap)
     id_t* pathnodes; uint32_t* pathoff; uint16_t *pathlen, *pathmult, *msa; uint32_t* dstcnt; uint8_t* consbuf; id_t* predrows; score_t* ring1;
     int n_paths, path_used, head_first;
     // group-uniform state
@@ -224,7 +235,7 @@ struct Poa {
     int tb_steps; int tb_fv;
     int need_nodes;                                          // after RES_OVERFLOW of a SHORT window: projected node count (0 = unknown)
     bool last_changed;         // did the most recent add_alignment change the graph topology?
-    uint64_t cells, aligns, reused, rows_done, topo_runs, cons_serial;
+    uint64_t cells, aligns, reused, rows_done, topo_runs, cons_serial, rows_slow, exact_tries, exact_hits;
     uint64_t tphase[PH_N]; uint64_t tlast;
 
     // `fast`: the LDS slice of a hybrid class (ignored otherwise: one slice, LDS or HBM, holds everything)
@@ -240,6 +251,7 @@ struct Poa {
         nin = (uint8_t*)(HYB ? fast + Lay::fNin : mem + Lay::oNin); nout = (uint8_t*)(mem + Lay::oNout);
         nal = (uint8_t*)(HYB ? fast + Lay::fNal : mem + Lay::oNal); mark = (uint8_t*)(HYB ? fast + Lay::fMark : mem + Lay::oMark);
         seq = (uint8_t*)(HYB ? fast + Lay::fSeq : mem + Lay::oSeq); armbuf = (uint8_t*)(mem + Lay::oArms);
+        sidx = mark;
         pathnodes = (id_t*)(mem + Lay::oPathNodes); pathoff = (uint32_t*)(mem + Lay::oPathOff);
         pathlen = (uint16_t*)(mem + Lay::oPathLen); pathmult = (uint16_t*)(mem + Lay::oPathMult);
         msa = (uint16_t*)(mem + Lay::oMsa); dstcnt = (uint32_t*)(mem + Lay::oDst); consbuf = (uint8_t*)(mem + Lay::oCons);
@@ -247,7 +259,7 @@ struct Poa {
         ring1 = (score_t*)(HYB ? fast + Lay::fRing1 : mem + Lay::oRing);
         n_paths = 0; path_used = 0; head_first = 0;
         n_nodes = 0; L = 0; topo_dirty = false; meta_dirty = true; maxdelta = 0; tb_steps = 0; tb_fv = 0;
-        cells = 0; aligns = 0; reused = 0; rows_done = 0; topo_runs = 0; cons_serial = 0; last_changed = true;
+        cells = 0; aligns = 0; reused = 0; rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; exact_hits = 0; last_changed = true;
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
         tlast = 0;
         HYPO_TICK_RESET();
@@ -356,8 +368,27 @@ struct Poa {
     }
 
     // ---- per-row metadata in rank order (rebuilt only when the graph topology changed) -----------
-    // rowmeta[r]: bits 0-7 code, 8-15 in-degree, 16 sink flag, 17-31 matrix row of pred 0 (further preds are rare
-    // and looked up through pred_row()); maxdelta = largest (row - pred row) over real preds.
+    // rowmeta[r]: bits 0-2 node code, 3 SLOW, 4 SAVE, 5 sink, 8-15 in-degree (8-11 in the packed classes), 16-18 code again (the
+    // packed row loop XORs the word, masked, with a pair of sequence codes), 19-30 matrix row of pred 0 (further preds are rare
+    // and looked up through pred_row()), 31 DEEP (hybrid classes).  Packed classes (<= 254 nodes, <= 7 in-edges) also keep the
+    // ring distances of preds 0 and 1 here: bits 27-31 and bits 12-15 + 6.
+    // Packed classes: a row is FAST when its only predecessor is the previous row (whose scores are still in registers), it is
+    // no end-cell candidate and no later row reads it from the ring; everything else is SLOW.  Only rows that a later row
+    // reads as something other than "pred 0 = the previous row" are SAVEd to the ring, in order: the ring then has to span
+    // the SAVEd rows between a row and its furthest predecessor (maxdelta), not all rows in between.  sidx[r] = number of
+    // SAVEd rows before row r.
+    static constexpr uint32_t META_SLOW = 8u, META_SAVE = 16u, META_SINK = 32u;
+    static constexpr uint32_t META_DEEP = 0x80000000u;     // rowmeta bit 31: a row further than RING1 ahead reads this row
+    HD static int meta_code(uint32_t meta) { return (int)(meta & 7u); }
+    HD static int meta_k(uint32_t meta) { return (int)((meta >> 8) & (PK ? 0xfu : 0xffu)); }
+    // packed classes: how many SAVEd rows back the rows of pred 0 / pred 1 sit in the ring (0 = not read from the ring)
+    static constexpr int RING_BACK_MAX = 31;
+    HD static int meta_back0(uint32_t meta) { return (int)(meta >> 27); }
+    HD static int meta_back1(uint32_t meta) { return (int)(((meta >> 12) & 0xfu) | ((meta >> 2) & 0x10u)); }
+    HD static uint32_t meta_backs(int b0, int b1) { return ((uint32_t)b0 << 27) | (((uint32_t)b1 & 0xfu) << 12) | (((uint32_t)b1 & 0x10u) << 2); }
+    HD static bool meta_sink(uint32_t meta) { return (meta & META_SINK) != 0; }
+    HD static int meta_p0(uint32_t meta) { return (int)((meta >> 19) & (PK ? 0xffu : 0xfffu)); }
+    static_assert(NMAX <= (PK ? 255 : 4095) && (!PK || KIN <= 15), "field widths of rowmeta");
     HD void build_rowmeta() {
         int md = 0;
         for (int r = g.lane; r < n_nodes; r += GW) {
@@ -371,29 +402,74 @@ struct Poa {
                 const int d = r + 1 - pr;
                 md = d > md ? d : md;
             }
-            rowmeta[r] = (uint32_t)code[u] | ((uint32_t)k << 8) | ((nout[u] == 0 ? 1u : 0u) << 16) | ((uint32_t)p0 << 17);
+            const bool sink = nout[u] == 0;
+            const bool slow = !(k == 1 && p0 == r) || sink;
+            const uint32_t c = code[u];
+#ifdef HYPO_DBG_SAVEALL
+            rowmeta[r] = c | META_SLOW | META_SAVE | (sink ? META_SINK : 0u) | ((uint32_t)k << 8) | (c << 16) | ((uint32_t)p0 << 19);
+#else
+            rowmeta[r] = c | (slow ? META_SLOW : 0u) | (sink ? META_SINK : 0u) | ((uint32_t)k << 8) | (c << 16) | ((uint32_t)p0 << 19);
+#endif
+        }
+        meta_dirty = false;
+        if (PK) {
+            g.sync();
+            // Plain read-modify-write on purpose (also below for DEEP): every writer ORs the same bits into a word nobody else
+            // changes in this pass, so colliding lanes store identical values.
+            for (int r = g.lane; r < n_nodes; r += GW) {
+                const int k = meta_k(rowmeta[r]);
+                for (int p = 0; p < k; ++p) {
+                    const int pr = pred_row(r, p);
+                    if (pr > 0 && !(p == 0 && pr == r)) rowmeta[pr - 1] |= META_SAVE | META_SLOW;
+                }
+            }
+            g.sync();
+            int total = 0;
+            for (int base = 0; base < n_nodes; base += GW) {
+                const int r = base + g.lane;
+                const bool sv = r < n_nodes && (rowmeta[r] & META_SAVE);
+                const uint64_t b = g.ballot(sv);
+                if (r < n_nodes) sidx[r] = (uint8_t)(total + popc64(b & ((1ull << g.lane) - 1ull)));
+                total += popc64(b);
+            }
+            g.sync();
+            // ring distances of preds 0 and 1 into rowmeta[r] (0 = not in the ring: the previous row as pred 0, or the virtual
+            // source row); the row loop needs no other lookup for these preds
+            int mds = 0;
+            for (int r = g.lane; r < n_nodes; r += GW) {
+                const int k = meta_k(rowmeta[r]);
+                int b0 = 0, b1 = 0;
+                for (int p = 0; p < k; ++p) {
+                    const int pr = pred_row(r, p);
+                    if (pr > 0 && !(p == 0 && pr == r)) {
+                        const int d = (int)sidx[r] - (int)sidx[pr - 1];
+                        mds = d > mds ? d : mds;
+                        if (p == 0) b0 = d; else if (p == 1) b1 = d;
+                    }
+                }
+                if (b0 > RING_BACK_MAX || b1 > RING_BACK_MAX) mds = 1 << 20;       // does not fit the fields: the window moves up a class
+                else rowmeta[r] |= meta_backs(b0, b1);
+            }
+            maxdelta = g.reduce_max(mds);
+            g.sync();
+            return;
         }
         maxdelta = g.reduce_max(md);
-        meta_dirty = false;
         g.sync();
         if (Cfg::RING1 > 0 && maxdelta > Cfg::RING1) {
             // hybrid classes: only rows that some later row reads from further back than the LDS ring reaches go to the HBM ring
             for (int r = g.lane; r < n_nodes; r += GW) {
-                const int k = (int)((rowmeta[r] >> 8) & 0xff);
+                const int k = meta_k(rowmeta[r]);
                 for (int p = 0; p < k; ++p) {
                     const int pr = pred_row(r, p);
-                    // plain read-modify-write on purpose: every writer ORs the same bit into a word nobody else changes here, so
-                    // colliding lanes store identical values; an atomic would execute in L2 and leave a stale copy of the word
-                    // in this CU's vector L1, which the row loop's ordinary loads could then hit (seen on hardware, never in
-                    // the emulator)
+                    // plain read-modify-write: an atomic would execute in L2 and leave a stale copy of the word in this CU's
+                    // vector L1, which the row loop's ordinary loads could then hit (seen on hardware, never in the emulator)
                     if (pr > 0 && r + 1 - pr > Cfg::RING1) rowmeta[pr - 1] |= META_DEEP;
                 }
             }
             g.sync();
         }
     }
-    static constexpr uint32_t META_DEEP = 0x80000000u;     // rowmeta bit 31: a row further than RING1 ahead reads this row
-    HD static int meta_p0(uint32_t meta) { return (int)((meta >> 17) & 0x3fffu); }
     static constexpr bool PRED_TABLE = Cfg::PATHCAP > 0;    // the HBM-scratch classes tabulate pred rows in build_rowmeta
     HD int pred_row(int r, int p) const {                   // matrix row of pred p of rank r
         if (PRED_TABLE) return (int)predrows[r * KIN + p];
@@ -422,6 +498,9 @@ struct Poa {
     // about 2/3 of the one-column-per-register form.  Values stay exact because align() admits only windows whose scores
     // and `H - j*g` terms fit 16 bits.  NEG16 + a score never wraps and stays below every real cell.
     struct alignas(pow2_of(CPL * 2) < 4 ? 4 : pow2_of(CPL * 2)) PackP { P2 v[CPL / 2 ? CPL / 2 : 1]; };
+    // Two bodies per row.  FAST (kNW, one predecessor = the previous row, not a sink, not read from the ring later: ~95 % of
+    // the rows): everything the row needs is in registers or a constant, the only memory operation is the store of its
+    // direction codes.  SLOW: any predecessors (ring reads located through sidx[]), end-cell bookkeeping, ring save.
     HD int rows_pk(int mode, int m, int n, int gp, int S, int R) {
         constexpr int NP = CPL / 2;
         const int j0 = CPL * g.lane;
@@ -440,30 +519,28 @@ struct Poa {
         int vM = pk_bits(pk_splat(m)), vMN = pk_bits(pk_splat(n - m)), vGP = pk_bits(pk_splat(gp)), vONE = pk_bits(pk_splat(1));
         HYPO_IN_VGPR(vM); HYPO_IN_VGPR(vMN); HYPO_IN_VGPR(vGP); HYPO_IN_VGPR(vONE);
         const P2 M = pk_from_bits(vM), MN = pk_from_bits(vMN), GP = pk_from_bits(vGP), ONE = pk_from_bits(vONE);
+        // direction codes of a FAST row, the high column's already shifted into the upper nibble:
+        // code = 15 (FAST) - 8 tD + 7 tD tU with tD = [v > D], tU = [v > U]  ->  15 diagonal, 7 vertical via pred 0, 14 horizontal
+        int vK7 = pk_bits(pk_make(7, 7 << 4)), vKM8 = pk_bits(pk_make(-8, -(8 << 4))), vK15 = pk_bits(pk_make(15, 15 << 4));
+        HYPO_IN_VGPR(vK7); HYPO_IN_VGPR(vKM8); HYPO_IN_VGPR(vK15);
+        const P2 K7 = pk_from_bits(vK7), KM8 = pk_from_bits(vKM8), K15 = pk_from_bits(vK15);
+        static_assert(DIR_FAST == 15 && DIR_HORIZ == 14, "fast-row code constants");
         const int negfill = pk_bits(pk_splat(NEG16));
         // kROV: first column is 0 (sisd..cpp:200-211,237-239): lane 0 clears the low half of its first pair
         const int keep0 = (g.lane == 0 && mode == MODE_ROV) ? (int)0xffff0000u : -1;
 
         const int le = L / CPL, ce = L % CPL;               // owner of the last column
+        const int ce_shift = 16 * (ce & 1);
         int best = NEG, best_i = -1;
-        int slot = 0, slotS = 0, rowS = 0;
+        int wslotS = 0, scount = 0, rowS = 0;               // ring write slot * S, rows saved so far, r * S
         const int RS = R * S;
-        constexpr int MREG = (NMAX + GW - 1) / GW;
-        constexpr bool META_IN_REGS = (GW == 64) && (MREG <= 4);
-        uint32_t mreg[META_IN_REGS ? MREG : 1];
-        if (META_IN_REGS) {
-            HYPO_UNROLL
-            for (int q = 0; q < (META_IN_REGS ? MREG : 1); ++q) {
-                const int rr = q * GW + g.lane;
-                mreg[q] = rr < n_nodes ? rowmeta[rr] : 0u;
-            }
-            HYPO_UNROLL
-            for (int q = 0; q < (META_IN_REGS ? MREG : 1); ++q) HYPO_ARRIVED(mreg[q]);
-        }
-        constexpr bool META_CHUNKED = (GW == 64) && !META_IN_REGS;
+        const bool lov = mode == MODE_LOV;                   // kLOV: every row's column L is an end-cell candidate
+        // loop-carried results of the two lane shifts: lane 0 of a group is never written, it keeps the fill value
+        int nbreg = negfill, exreg = (int)0x80000000;
+        constexpr bool META_CHUNKED = (GW == 64);
         uint32_t mchunk = 0u;
-        uint32_t meta_a = (META_IN_REGS || META_CHUNKED) ? 0u : rowmeta[0];
-        uint32_t meta_b = (!META_IN_REGS && !META_CHUNKED && n_nodes > 1) ? rowmeta[1] : 0u;
+        uint32_t meta_a = META_CHUNKED ? 0u : rowmeta[0];
+        uint32_t meta_b = (!META_CHUNKED && n_nodes > 1) ? rowmeta[1] : 0u;
         auto load_pk = [&](int off, P2 (&out)[NP]) {
             if (j0 < S) {
                 const PackP pk = *(const PackP*)(ring + off + j0);
@@ -474,24 +551,82 @@ struct Poa {
                 for (int q = 0; q < NP; ++q) out[q] = pk_from_bits(negfill);
             }
         };
+        // ring offset of the row saved `back` SAVEd rows ago
+        auto ring_back = [&](int back) -> int {
+            int ps = wslotS - back * S;
+            return ps < 0 ? ps + RS : ps;
+        };
+        // horizontal term H[i][j] = max(H[i][j], H[i][j-1] + g): prefix max of H[i][j] - j*g.  The lane scan compares whole
+        // registers: the running maximum sits in the high half and decides, the low half only orders equal maxima and is
+        // dropped afterwards; INT_MIN, the scan's identity, reads as -32768 there
+        auto hscan = [&](P2 (&v)[NP]) {
+            P2 x[NP];
+            x[0] = pk_fold_hi(pk_sub(v[0], JG[0]));
+            HYPO_UNROLL
+            for (int q = 1; q < NP; ++q) x[q] = pk_fold_hi(pk_max(pk_sub(v[q], JG[q]), pk_hi_splat(x[q - 1])));
+            exreg = g.scan_max_excl_c(pk_bits(x[NP - 1]), exreg);
+            const P2 EX = pk_hi_splat(pk_from_bits(exreg));
+            HYPO_UNROLL
+            for (int q = 0; q < NP; ++q) v[q] = pk_add(pk_max(x[q], EX), JG[q]);
+        };
         for (int r = 0; r < n_nodes; ++r) {
             const int i = r + 1;
             uint32_t meta;
             if (META_CHUNKED) {
                 if ((r & 63) == 0) { mchunk = r + g.lane < n_nodes ? rowmeta[r + g.lane] : 0u; HYPO_ARRIVED(mchunk); }
                 meta = (uint32_t)g.shfl((int)mchunk, r & 63);
-            } else if (META_IN_REGS) {
-                uint32_t mv = mreg[0];
-                HYPO_UNROLL
-                for (int q = 1; q < (META_IN_REGS ? MREG : 1); ++q) if ((r / GW) == q) mv = mreg[q];
-                meta = (uint32_t)g.shfl((int)mv, r % GW);
             } else {
                 meta = meta_a;
                 meta_a = meta_b;
                 if (r + 2 < n_nodes) meta_b = rowmeta[r + 2];
             }
-            const int cd = (int)(meta & 0xff), k = (int)((meta >> 8) & 0xff);
-            const bool sink = (meta >> 16) & 1;
+            if (!(meta & META_SLOW)) {
+                // ---- FAST row ----
+                const P2 CD = pk_from_bits((int)(meta & 0x00070007u));
+                const int nb = nbreg = g.shfl_up1(pk_bits(LAST[NP - 1]), nbreg);
+                P2 D[NP], U[NP], v[NP];
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) {
+                    const P2 MV = pk_mad(pk_minu(pk_xor(SQ[q], CD), ONE), MN, M);      // match / mismatch score per column
+                    D[q] = pk_add(pk_shift_in(q ? LAST[q - 1] : pk_from_bits(nb), LAST[q]), MV);
+                    U[q] = pk_add(LAST[q], GP);
+                    v[q] = pk_max(D[q], U[q]);
+                }
+                v[0] = pk_from_bits(pk_bits(v[0]) & keep0);
+                hscan(v);
+                // the reference's traceback preference (sisd..cpp:370-428): diagonal, else vertical, else horizontal.  Lanes
+                // beyond the row's width store into the slack behind the row (PoaLayout::oRowmeta).
+                uint32_t codes = 0;
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) {
+                    const P2 tD = pk_minu(pk_sub(v[q], D[q]), ONE), tU = pk_minu(pk_sub(v[q], U[q]), ONE);
+                    const uint32_t b = (uint32_t)pk_bits(pk_mad(tD, pk_mad(tU, K7, KM8), K15));
+                    codes |= ((b | (b >> 16)) & 0xffu) << (8 * q);
+                    LAST[q] = v[q];
+                }
+                uint8_t* dst = dir + (rowS >> 1) + (j0 >> 1);         // S and j0 are even
+                if (NP == 1) *dst = (uint8_t)codes;
+                else if (NP == 2) *(uint16_t*)dst = (uint16_t)codes;
+                else *(uint32_t*)dst = codes;                // NP == 4 (NP == 3 is not instantiated)
+                if (lov) {                                   // end cell: first strictly greater in rank order; only lane `le` counts
+                    HYPO_NO_IFCVT();
+                    int w = pk_bits(v[0]);
+                    HYPO_UNROLL
+                    for (int q = 1; q < NP; ++q) if (ce / 2 == q) w = pk_bits(v[q]);
+                    const int val = (int)(int16_t)(uint16_t)((uint32_t)w >> ce_shift);
+                    best_i = val > best ? i : best_i;
+                    best = val > best ? val : best;
+                }
+                rowS += S;
+                g.sync();
+                continue;
+            }
+            // ---- SLOW row ----
+            HYPO_NO_IFCVT();
+#ifdef HYPO_PHASE_TIMERS
+            rows_slow += 1;
+#endif
+            const int cd = meta_code(meta), k = meta_k(meta);
             const int p0 = meta_p0(meta);                    // 0 when k == 0 (virtual source row)
             const bool fastrow = p0 == i - 1;
             const int fastcode = fastrow ? (int)DIR_FAST : dir_diag(0);
@@ -506,11 +641,11 @@ struct Poa {
                 P2 hp[NP];
                 if (fastrow) { HYPO_UNROLL for (int q = 0; q < NP; ++q) hp[q] = LAST[q]; }
                 else if (p0 == 0) { HYPO_UNROLL for (int q = 0; q < NP; ++q) hp[q] = JG[q]; }
-                else { int ps = slotS - (i - p0) * S; ps = ps < 0 ? ps + RS : ps; load_pk(ps, hp); }
-                const P2 nb = pk_from_bits(g.shfl_up1(pk_bits(hp[NP - 1]), negfill));
+                else load_pk(ring_back(meta_back0(meta)), hp);
+                const int nb = nbreg = g.shfl_up1(pk_bits(hp[NP - 1]), nbreg);
                 HYPO_UNROLL
                 for (int q = 0; q < NP; ++q) {
-                    D[q] = pk_add(pk_shift_in(q ? hp[q - 1] : nb, hp[q]), MV[q]);
+                    D[q] = pk_add(pk_shift_in(q ? hp[q - 1] : pk_from_bits(nb), hp[q]), MV[q]);
                     U[q] = pk_add(hp[q], GP);
                 }
             }
@@ -520,13 +655,14 @@ struct Poa {
                 for (int q = 0; q < NP; ++q) { pD[q] = pk_splat(0); pU[q] = pk_splat(0); }
                 for (int p = 1; p < k; ++p) {
                     P2 hp[NP];
-                    const int pr = g.uniform(pred_row(r, p));
-                    { int ps = slotS - (i - pr) * S; ps = ps < 0 ? ps + RS : ps; load_pk(ps, hp); }
-                    const P2 nb = pk_from_bits(g.shfl_up1(pk_bits(hp[NP - 1]), negfill));
+                    // pred 1: distance from rowmeta; beyond that (0.02 % of the nodes) through the graph tables
+                    const int back = p == 1 ? meta_back1(meta) : scount - (int)sidx[g.uniform(pred_row(r, p)) - 1];
+                    load_pk(ring_back(back), hp);
+                    const int nb = nbreg = g.shfl_up1(pk_bits(hp[NP - 1]), nbreg);
                     const P2 PP = pk_splat(p);
                     HYPO_UNROLL
                     for (int q = 0; q < NP; ++q) {
-                        const P2 d = pk_add(pk_shift_in(q ? hp[q - 1] : nb, hp[q]), MV[q]);
+                        const P2 d = pk_add(pk_shift_in(q ? hp[q - 1] : pk_from_bits(nb), hp[q]), MV[q]);
                         const P2 u = pk_add(hp[q], GP);
                         const P2 nd = pk_max(D[q], d), nu = pk_max(U[q], u);
                         // strict: the first pred reaching the maximum wins
@@ -548,22 +684,9 @@ struct Poa {
             P2 v[NP];
             HYPO_UNROLL
             for (int q = 0; q < NP; ++q) v[q] = pk_max(D[q], U[q]);
-            if (mode == MODE_ROV) v[0] = pk_from_bits(pk_bits(v[0]) & keep0);
-            // horizontal term H[i][j] = max(H[i][j], H[i][j-1] + g): prefix max of H[i][j] - j*g
-            {
-                P2 x[NP];
-                x[0] = pk_fold_hi(pk_sub(v[0], JG[0]));
-                HYPO_UNROLL
-                for (int q = 1; q < NP; ++q) x[q] = pk_fold_hi(pk_max(pk_sub(v[q], JG[q]), pk_hi_splat(x[q - 1])));
-                // the lane scan compares whole registers: the running maximum sits in the high half and decides, the low half
-                // only orders equal maxima and is dropped afterwards; INT_MIN, the scan's identity, reads as -32768 there
-                const int ex = g.scan_max_excl(pk_bits(x[NP - 1]), (int)0x80000000);
-                const P2 EX = pk_hi_splat(pk_from_bits(ex));
-                HYPO_UNROLL
-                for (int q = 0; q < NP; ++q) v[q] = pk_add(pk_max(x[q], EX), JG[q]);
-            }
+            v[0] = pk_from_bits(pk_bits(v[0]) & keep0);
+            hscan(v);
             if (j0 < S) {
-                // the reference's traceback preference (sisd..cpp:370-428): diagonal, else vertical, else horizontal
                 const P2 HZ = pk_splat(DIR_HORIZ);
                 uint32_t codes = 0;
                 PackP pk;
@@ -578,17 +701,15 @@ struct Poa {
                 uint8_t* dst = dir + (rowS >> 1) + (j0 >> 1);         // S and j0 are even
                 if (NP == 1) *dst = (uint8_t)codes;
                 else if (NP == 2) *(uint16_t*)dst = (uint16_t)codes;
-                else *(uint32_t*)dst = codes;                // NP == 4 (NP == 3 is not instantiated)
-                *(PackP*)(ring + slotS + j0) = pk;
+                else *(uint32_t*)dst = codes;
+                if (meta & META_SAVE) *(PackP*)(ring + wslotS + j0) = pk;
             }
-            slot = slot + 1 == R ? 0 : slot + 1;
-            slotS = slot == 0 ? 0 : slotS + S;
+            if (meta & META_SAVE) { scount += 1; wslotS = wslotS + S == RS ? 0 : wslotS + S; }
             rowS += S;
             HYPO_UNROLL
             for (int q = 0; q < NP; ++q) LAST[q] = v[q];
             // end cell: first strictly greater in rank order (sisd..cpp:279-288,332-339)
-            if (mode == MODE_LOV || sink) {                  // group-uniform: most rows of kNW / kROV skip it
-                HYPO_NO_IFCVT();
+            if (mode == MODE_LOV || meta_sink(meta)) {
                 if (g.lane == le) {
                     int val = pk_lo(v[0]);
                     HYPO_UNROLL
@@ -601,11 +722,175 @@ struct Poa {
         return g.shfl(best_i, le);
     }
 
+    // ---- exact threading: the alignment of a sequence that spells a path of the graph, without scores ----------------------
+    // With m > 0, n < m and g < 0 no cell can exceed H[i][j] <= m * j, and H[i][j] == m * j exactly when some path that ends
+    // in node i spells seq[0..j) with j matches and nothing else (kNW / kLOV: starting at a node without in-edges, because
+    // the first column costs g per node, sisd..cpp:200-211; kROV: starting anywhere, the first column being 0, :237-239).
+    // Call such a cell PERFECT.  perfect(i, j) = letter(i) == seq[j-1] and perfect(p, j-1) for some pred p of i: a one-bit
+    // recurrence over the same rows, predecessors and ring as the score rows, without the horizontal scan.  If an end-cell
+    // candidate (kNW / kROV: a sink, kLOV: any node; column L) is perfect, its score m * L is the maximum, so the reference
+    // starts its traceback at the FIRST such row in rank order (strictly-greater rule, sisd..cpp:279-288,332-339) and at
+    // every perfect cell takes the diagonal through the first pred (in-edge order) whose cell (p, j-1) is perfect: diagonals
+    // are tried before anything else (:370-428) and H[p][j-1] + m == m * j holds for exactly those preds.  The direction
+    // codes of that walk are written in the usual format, so the traceback and the graph update below run unchanged.
+    // Returns the end row, or -1 when no candidate is perfect (the sequence spells no path: the caller runs the score rows).
+    HD int rows_exact(int mode, int S, int R) {
+        constexpr int NP = CPL / 2;
+        const int j0 = CPL * g.lane;
+        P2 SQ[NP], P0[NP], LAST[NP];
+        HYPO_UNROLL
+        for (int q = 0; q < NP; ++q) {
+            const int j = j0 + 2 * q;
+            const int s0 = (j >= 1 && j <= L) ? (int)seq[j - 1] : (int)C_NONE;
+            const int s1 = (j + 1 <= L) ? (int)seq[j] : (int)C_NONE;
+            SQ[q] = pk_make(s0, s1);
+            P0[q] = pk_make(j == 0 ? 1 : 0, 0);              // virtual source row: only H[0][0] = 0 is perfect
+            LAST[q] = P0[q];
+        }
+        int vONE = pk_bits(pk_splat(1));
+        HYPO_IN_VGPR(vONE);
+        const P2 ONE = pk_from_bits(vONE);
+        // kROV: H[i][0] = 0 = m * 0 in every row: column 0 (lane 0, low half) is perfect everywhere
+        const int col0 = (g.lane == 0 && mode == MODE_ROV) ? 1 : 0;
+        const bool lov = mode == MODE_LOV;
+        const int le = L / CPL, ce = L % CPL;               // owner of the last column
+        unsigned first = 0xffffffffu;                        // first row (rank order) whose end-cell candidate is perfect (lane `le`)
+        int wslotS = 0, scount = 0, rowS = 0;
+        const int RS = R * S;
+        int nbreg = 0;                                       // lane 0 keeps 0: there is no column -1
+        constexpr bool META_CHUNKED = (GW == 64);
+        uint32_t mchunk = 0u;
+        uint32_t meta_a = META_CHUNKED ? 0u : rowmeta[0];
+        uint32_t meta_b = (!META_CHUNKED && n_nodes > 1) ? rowmeta[1] : 0u;
+        auto load_pk = [&](int off, P2 (&out)[NP]) {
+            if (j0 < S) {
+                const PackP pk = *(const PackP*)(ring + off + j0);
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) out[q] = pk.v[q];
+            } else {
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) out[q] = pk_splat(0);
+            }
+        };
+        auto ring_back = [&](int back) -> int {
+            int ps = wslotS - back * S;
+            return ps < 0 ? ps + RS : ps;
+        };
+        // end-cell bookkeeping without selects: column L's bit (0 / 1) minus one is 0 or all ones
+        const int ce_shift = 16 * (ce & 1);
+        auto note_end = [&](const P2 (&v)[NP], int i) {
+            int w = pk_bits(v[0]);
+            HYPO_UNROLL
+            for (int q = 1; q < NP; ++q) if (ce / 2 == q) w = pk_bits(v[q]);
+            const unsigned cand = (unsigned)i | ((((unsigned)w >> ce_shift) & 1u) - 1u);
+            first = cand < first ? cand : first;
+        };
+        for (int r = 0; r < n_nodes; ++r) {
+            const int i = r + 1;
+            uint32_t meta;
+            if (META_CHUNKED) {
+                if ((r & 63) == 0) { mchunk = r + g.lane < n_nodes ? rowmeta[r + g.lane] : 0u; HYPO_ARRIVED(mchunk); }
+                meta = (uint32_t)g.shfl((int)mchunk, r & 63);
+            } else {
+                meta = meta_a;
+                meta_a = meta_b;
+                if (r + 2 < n_nodes) meta_b = rowmeta[r + 2];
+            }
+            const P2 CD = pk_from_bits((int)(meta & 0x00070007u));
+            if (!(meta & META_SLOW)) {
+                // ---- FAST row: one predecessor, the previous row ----
+                const int nb = nbreg = g.shfl_up1(pk_bits(LAST[NP - 1]), nbreg);
+                int d[NP];
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) d[q] = pk_bits(pk_shift_in(q ? LAST[q - 1] : pk_from_bits(nb), LAST[q]));   // perfect(pred, j-1)
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) LAST[q] = pk_from_bits(d[q] & ~pk_bits(pk_minu(pk_xor(SQ[q], CD), ONE)));    // and the letters agree
+                LAST[0] = pk_from_bits(pk_bits(LAST[0]) | col0);
+                uint8_t* dst = dir + (rowS >> 1) + (j0 >> 1);
+                if (NP == 1) *dst = (uint8_t)0xffu;          // DIR_FAST in both nibbles
+                else if (NP == 2) *(uint16_t*)dst = (uint16_t)0xffffu;
+                else *(uint32_t*)dst = 0xffffffffu;
+                if (lov) { HYPO_NO_IFCVT(); note_end(LAST, i); }
+                rowS += S;
+                g.sync();
+                continue;
+            }
+            // ---- SLOW row ----
+            HYPO_NO_IFCVT();
+            const int k = meta_k(meta);
+            const int p0 = meta_p0(meta);                    // 0 when k == 0 (virtual source row)
+            const bool fastrow = p0 == i - 1;
+            const int fastcode = fastrow ? (int)DIR_FAST : dir_diag(0);
+            P2 D[NP], cD[NP];
+            {
+                P2 hp[NP];
+                if (fastrow) { HYPO_UNROLL for (int q = 0; q < NP; ++q) hp[q] = LAST[q]; }
+                else if (p0 == 0) { HYPO_UNROLL for (int q = 0; q < NP; ++q) hp[q] = P0[q]; }
+                else load_pk(ring_back(meta_back0(meta)), hp);
+                const int nb = nbreg = g.shfl_up1(pk_bits(hp[NP - 1]), nbreg);
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) D[q] = pk_shift_in(q ? hp[q - 1] : pk_from_bits(nb), hp[q]);
+            }
+            if (k > 1) {                                     // the first pred (in-edge order) with a perfect cell wins
+                P2 pD[NP];
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) pD[q] = pk_splat(0);
+                for (int p = 1; p < k; ++p) {
+                    P2 hp[NP];
+                    const int back = p == 1 ? meta_back1(meta) : scount - (int)sidx[g.uniform(pred_row(r, p)) - 1];
+                    load_pk(ring_back(back), hp);
+                    const int nb = nbreg = g.shfl_up1(pk_bits(hp[NP - 1]), nbreg);
+                    const P2 PP = pk_splat(p);
+                    HYPO_UNROLL
+                    for (int q = 0; q < NP; ++q) {
+                        const P2 d = pk_shift_in(q ? hp[q - 1] : pk_from_bits(nb), hp[q]);
+                        const P2 nd = pk_from_bits(pk_bits(D[q]) | pk_bits(d));
+                        pD[q] = pk_mad(pk_sub(nd, D[q]), pk_sub(PP, pD[q]), pD[q]);       // newly perfect through pred p
+                        D[q] = nd;
+                    }
+                }
+                const P2 FC = pk_splat(fastcode);
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) cD[q] = pk_mad(pk_sub(ONE, pk_minu(pD[q], ONE)), FC, pD[q]);
+            } else {
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) cD[q] = pk_splat(fastcode);
+            }
+            P2 v[NP];
+            HYPO_UNROLL
+            for (int q = 0; q < NP; ++q) v[q] = pk_from_bits(pk_bits(D[q]) & ~pk_bits(pk_minu(pk_xor(SQ[q], CD), ONE)));
+            v[0] = pk_from_bits(pk_bits(v[0]) | col0);
+            if (j0 < S) {
+                uint32_t codes = 0;
+                PackP pk;
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) {
+                    const uint32_t b = (uint32_t)pk_bits(cD[q]);
+                    codes |= ((b | (b >> 12)) & 0xffu) << (8 * q);
+                    pk.v[q] = v[q];
+                }
+                uint8_t* dst = dir + (rowS >> 1) + (j0 >> 1);
+                if (NP == 1) *dst = (uint8_t)codes;
+                else if (NP == 2) *(uint16_t*)dst = (uint16_t)codes;
+                else *(uint32_t*)dst = codes;
+                if (meta & META_SAVE) *(PackP*)(ring + wslotS + j0) = pk;
+            }
+            if (meta & META_SAVE) { scount += 1; wslotS = wslotS + S == RS ? 0 : wslotS + S; }
+            rowS += S;
+            HYPO_UNROLL
+            for (int q = 0; q < NP; ++q) LAST[q] = v[q];
+            if (lov || meta_sink(meta)) note_end(v, i);
+            g.sync();
+        }
+        return g.shfl((int)first, le);                       // -1: no perfect candidate
+    }
+
     // [tb_fv, L) and tb_steps (number of traceback steps; 0 = "empty alignment").
     HD int align(int mode, int m, int n, int gp) {
         tb_steps = 0; tb_fv = L;
         if (n_nodes == 0 || L == 0) return RES_OK;
         n_nodes = g.uniform(n_nodes);
+        mode = g.uniform(mode);                             // group-uniform by construction (one sequence per group at a time)
         const int W = g.uniform(L) + 1;
         const int S = (W + CPL - 1) / CPL * CPL;           // row stride (even when NIB)
         if (n_nodes * S > Cfg::DIRCELLS) return RES_OVERFLOW;
@@ -622,7 +907,10 @@ struct Poa {
 
         int best_i = -1;
         if constexpr (PK) {
-            best_i = rows_pk(mode, m, n, gp, S, R);
+            // a sequence that spells a path of the graph (most reads do) is threaded without scores; what spells none goes
+            // through the score rows
+            if (HYPO_EXACT && m > 0 && n < m && gp < 0) { best_i = rows_exact(mode, S, R); exact_tries += 1; if (best_i > 0) exact_hits += 1; }
+            if (best_i <= 0) best_i = rows_pk(mode, m, n, gp, S, R);
         } else {
         HYPO_IN_VGPR(m); HYPO_IN_VGPR(n); HYPO_IN_VGPR(gp);
         const int j0 = CPL * g.lane;
@@ -680,8 +968,8 @@ struct Poa {
                 meta_a = meta_b;
                 if (r + 2 < n_nodes) meta_b = rowmeta[r + 2];
             }
-            const int cd = (int)(meta & 0xff), k = (int)((meta >> 8) & 0xff);
-            const bool sink = (meta >> 16) & 1;
+            const int cd = meta_code(meta), k = meta_k(meta);
+            const bool sink = meta_sink(meta);
             const int p0 = meta_p0(meta);                    // 0 when k == 0 (virtual source row)
             int D[CPL], U[CPL];
             int codeD[CPL], codeU[CPL];                      // direction codes if the cell's value comes from D / U
@@ -824,7 +1112,7 @@ struct Poa {
                 --j;
             } else {
                 const int p = dir_pred(d);
-                const int k = (int)((rowmeta[i - 1] >> 8) & 0xff);
+                const int k = meta_k(rowmeta[i - 1]);
                 const int pi = k ? pred_row(i - 1, p) : 0;
                 if (!is_vert(d)) {
                     if (j == 0) return RES_UNDEFINED;
@@ -1112,7 +1400,7 @@ struct Poa {
             int a = 0, pr = n;
             if (r < n) {
                 const uint32_t meta = rowmeta[r];
-                const int k = (int)((meta >> 8) & 0xff);
+                const int k = meta_k(meta);
                 a = -255;                                    // a source scores -1 and is one node
                 if (k != 0) {
                     const int u = r2n[r];
@@ -1199,7 +1487,7 @@ struct Poa {
             for (int r = 0; r < n_nodes; ++r) {
                 const uint32_t meta = meta_n; const int w0 = w_n; const int u = u_n;
                 if (r + 1 < n_nodes) { meta_n = rowmeta[r + 1]; w_n = w0r[r + 1]; u_n = r2n[r + 1]; }
-                const int k = (int)((meta >> 8) & 0xff), p0 = meta_p0(meta);
+                const int k = meta_k(meta), p0 = meta_p0(meta);
                 int sc = -1, pd = -1;
                 if (k != 0) {
                     int bw = w0, bs = p0 == r ? prev_s : rs[p0 - 1], bp = p0;
@@ -1478,7 +1766,7 @@ struct Poa {
     // Window::generate_consensus (src/Window.cpp:44-61)
     HD int run(uint32_t w) {
         // the object outlives the window (one per persistent group): per-window counters and flags start over here
-        cells = 0; aligns = 0; reused = 0; rows_done = 0; topo_runs = 0; cons_serial = 0; last_changed = true;
+        cells = 0; aligns = 0; reused = 0; rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; exact_hits = 0; last_changed = true;
         n_paths = 0; path_used = 0; head_first = 0; L = 0; maxdelta = 0; tb_steps = 0; tb_fv = 0; need_nodes = 0;
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
         HYPO_TICK_RESET();

@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through t
     uint32_t n_ok = 0, n_esc = 0, n_fail = 0;
 #ifdef HYPO_PHASE_TIMERS
     uint64_t tph[PH_N] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t dbg[5] = {0, 0, 0, 0, 0};
+    uint64_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const uint64_t tstart = (uint64_t)clock64();
 #endif
     // what happens to a window once Poa::run / step has returned something other than RES_CONTINUE
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through t
         if (rc == RES_OK) { cells += poa.cells; aligns += poa.aligns; }   // reference-equivalent work of FINISHED windows only
 #ifdef HYPO_PHASE_TIMERS
         for (int i = 0; i < PH_N; ++i) tph[i] += poa.tphase[i];
-        dbg[0] += poa.rows_done; dbg[1] += poa.aligns - poa.reused; dbg[2] += poa.reused; dbg[3] += poa.topo_runs; dbg[4] += poa.cons_serial;
+        dbg[0] += poa.rows_done; dbg[1] += poa.aligns - poa.reused; dbg[2] += poa.reused; dbg[3] += poa.topo_runs; dbg[4] += poa.cons_serial; dbg[5] += poa.rows_slow; dbg[6] += poa.exact_tries; dbg[7] += poa.exact_hits;
 #endif
         if (rc == RES_OK) {
             ++n_ok;
@@ -244,11 +244,11 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through t
         atomicAdd((unsigned long long*)&st->n_alignments, (unsigned long long)aligns);
         atomicAdd((unsigned long long*)&st->alg_bytes[cls], (unsigned long long)abytes);
 #ifdef HYPO_PHASE_TIMERS
-        unsigned long long* ph = (unsigned long long*)((char*)fresh(ka)->Q.count + 512) + (size_t)cls * 16;   // header + 512: [class][16]
+        unsigned long long* ph = (unsigned long long*)((char*)fresh(ka)->Q.count + 512) + (size_t)cls * 24;   // header + 512: [class][24]
         for (int i = 0; i < PH_N; ++i) atomicAdd(&ph[i], (unsigned long long)tph[i]);
         atomicAdd(&ph[PH_N], (unsigned long long)((uint64_t)clock64() - tstart));                // wave lifetime
         atomicAdd(&ph[PH_N + 1], 1ull);                                                           // waves
-        for (int i = 0; i < 5; ++i) atomicAdd(&ph[PH_N + 2 + i], (unsigned long long)dbg[i]);      // rows, real alignments, reused, toposorts, serial consensus passes
+        for (int i = 0; i < 8; ++i) atomicAdd(&ph[PH_N + 2 + i], (unsigned long long)dbg[i]);      // rows, real alignments, reused, toposorts, serial consensus passes, slow rows, exact tries / hits
 #endif
     }
 }

@@ -23,10 +23,10 @@ def main():
         db.run()
     torch.cuda.synchronize()
     st = db.stats()
-    ph = db.workspace[512:512 + 8 * 16 * 8].cpu().numpy().view(np.uint64).reshape(8, 16)
+    ph = db.workspace[512:512 + 8 * 24 * 8].cpu().numpy().view(np.uint64).reshape(8, 24)
     print("windows per class", st["n_class"], "escalated", st["n_escalated"])
     for c in range(8):
-        if ph[c, 9] == 0:
+        if ph[c, 9] == 0 or st['n_class'][c] == 0:
             continue
         tot = float(ph[c, :8].sum())
         life = float(ph[c, 8])
@@ -34,7 +34,8 @@ def main():
               f"accounted={100 * tot / life:.1f}%  cycles/window={life / max(st['n_class'][c], 1) / 1e3:.1f}k")
         nw = max(st['n_class'][c], 1)
         print(f"    per window: DP rows={ph[c, 10] / nw:.1f} real alignments={ph[c, 11] / nw:.2f} reused={ph[c, 12] / nw:.2f} "
-              f"toposorts={ph[c, 13] / nw:.2f} serial consensus={ph[c, 14] / nw:.3f}; dp cycles/row={ph[c, 1] / max(ph[c, 10], 1):.0f}")
+              f"toposorts={ph[c, 13] / nw:.2f} serial consensus={ph[c, 14] / nw:.3f}; dp cycles/row={ph[c, 1] / max(ph[c, 10], 1):.0f}; "
+              f"slow rows={100 * ph[c, 15] / max(ph[c, 10], 1):.1f}%; exact threading {ph[c, 17] / nw:.2f} of {ph[c, 16] / nw:.2f} tries")
         for i in range(8):
             print(f"    {NAMES[i]:14s} {100 * ph[c, i] / tot:6.2f}%   {ph[c, i] / max(st['n_class'][c], 1) / 1e3:9.2f} kcycles/window")
 

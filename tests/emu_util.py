@@ -19,9 +19,9 @@ def build():
 
 
 class Emu:
-    def __init__(self, asan=False):
+    def __init__(self, asan=False, exact=True):
         build()
-        name = "libhypo_emu_asan.so" if asan else "libhypo_emu.so"
+        name = "libhypo_emu_asan.so" if asan else ("libhypo_emu.so" if exact else "libhypo_emu_noexact.so")
         self.lib = C.CDLL(os.path.join(BUILD, name))
         self.lib.emu_poa_batch.restype = C.c_int
         self.lib.emu_class_bytes.restype = C.c_int

@@ -73,3 +73,27 @@ def test_class4_long_windows(emu):
             assert r == emu_util.RES_OK and got == want, tag
             n += 1
     assert n >= 12
+
+
+@pytest.mark.parametrize("exact", [True, False])
+def test_random_batches_vs_oracle(exact):
+    """Seeded C1-shaped batches (0.2 - 3 % read error) and prefix/suffix-heavy grid windows through every LDS size class, with
+    exact threading (Poa::rows_exact) and with every alignment forced through the score rows (HYPO_EXACT=0)."""
+    import oracle
+    from hypo_amd import sim
+    emu = emu_util.Emu(exact=exact)
+    orc = oracle.Oracle()
+    n_ran = 0
+    cases = [(2, sim.window_batch(160, seed=5)), (1, sim.window_batch(200, seed=6)), (0, sim.window_batch(250, seed=7)),
+             (6, sim.window_batch(250, seed=8)), (3, sim.window_batch(80, seed=9)),
+             (2, sim.window_batch(120, seed=10, read_sub=0.02)), (1, sim.window_batch(160, seed=11, read_sub=0.03)),
+             (0, sim.grid_batch(30, 24, 60, 0.004, seed=30)), (1, sim.grid_batch(60, 24, 60, 0.004, seed=60)),
+             (2, sim.grid_batch(100, 24, 50, 0.004, seed=100)), (3, sim.grid_batch(180, 24, 30, 0.004, seed=180))]
+    for cfg, b in cases:
+        cons, st, res, _, _ = emu.poa_batch(b, cfg)
+        want = orc.poa_batch(b)[0]
+        for i in range(b.n_windows):
+            if res[i] == emu_util.RES_OK:
+                assert cons[i] == want[i], (cfg, i)
+                n_ran += 1
+    assert n_ran > 1000
