@@ -57,7 +57,9 @@ class ConsensusBatch(C.Structure):
 class PoaStats(C.Structure):
     _fields_ = [("n_windows", C.c_uint64), ("n_trivial", C.c_uint64), ("n_class", C.c_uint64 * 8),
                 ("n_escalated", C.c_uint64), ("n_failed", C.c_uint64), ("dp_cells", C.c_uint64),
-                ("n_alignments", C.c_uint64), ("alg_bytes", C.c_uint64 * 8)]
+                ("n_alignments", C.c_uint64), ("alg_bytes", C.c_uint64 * 8),
+                ("n_reused", C.c_uint64), ("n_threaded", C.c_uint64), ("cells_scored", C.c_uint64),
+                ("cells_threaded", C.c_uint64)]
 
 
 # numpy dtype equivalent of HypoWindow (40 bytes, same offsets)

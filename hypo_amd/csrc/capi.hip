@@ -219,7 +219,7 @@ int hypo_gpu_poa_batch_device(const HypoScoreParams* scores, const HypoWindowBat
         return fail(HYPO_E_WORKSPACE, "workspace %zu < minimum %zu (hypo_gpu_poa_workspace_bytes recommends %zu)", workspace_bytes,
                     hypo::poa_workspace_bytes(in->n_windows, hypo::kMinGlobalGroups), hypo::poa_workspace_bytes(in->n_windows));
     hypo::PoaParams P = make_params(scores, in, out);
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_ctx.stream;
+    hipStream_t st = (hipStream_t)hip_stream;                  // NULL is the HIP null stream itself (what torch calls its default stream)
     ProfCall* pc = prof_next(1);
     HIP_TRY(hypo::poa_run(P, in->n_windows, workspace, workspace_bytes, g_ctx.num_cus, st, pc ? &pc->ke : nullptr, &g_ctx.poa_aux));
     return HYPO_OK;
@@ -228,7 +228,7 @@ int hypo_gpu_poa_batch_device(const HypoScoreParams* scores, const HypoWindowBat
 // device-side stats of the last device call live at workspace + 128
 int hypo_gpu_poa_read_stats(const void* workspace, void* hip_stream, HypoPoaStats* out) {
     if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_ctx.stream;
+    hipStream_t st = (hipStream_t)hip_stream;                  // NULL is the HIP null stream itself (what torch calls its default stream)
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipMemcpy(out, (const char*)workspace + 128, sizeof(HypoPoaStats), hipMemcpyDeviceToHost));
     return HYPO_OK;
@@ -319,7 +319,7 @@ int hypo_gpu_solid_scan_device(const uint8_t* packed4, uint64_t n_bases, uint32_
     if ((n_bases && !packed4) || !bits || (n_bases && !solid_pos_words)) return fail(HYPO_E_INVALID, "NULL buffer");
     if (!workspace || workspace_bytes < hypo::scan_workspace_bytes(n_bases))
         return fail(HYPO_E_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, hypo::scan_workspace_bytes(n_bases));
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g_ctx.stream;
+    hipStream_t st = (hipStream_t)hip_stream;                  // NULL is the HIP null stream itself (what torch calls its default stream)
     ProfCall* pc = prof_next(2);
     if (pc) pc->ke.n = 4;
     HIP_TRY(hypo::scan_run(packed4, n_bases, k, bits, solid_pos_words, kids, kids_cap, word_rank, n_solid,

@@ -235,7 +235,7 @@ struct Poa {
     int tb_steps; int tb_fv;
     int need_nodes;                                          // after RES_OVERFLOW of a SHORT window: projected node count (0 = unknown)
     bool last_changed;         // did the most recent add_alignment change the graph topology?
-    uint64_t cells, aligns, reused, rows_done, topo_runs, cons_serial, rows_slow, exact_tries, exact_hits;
+    uint64_t cells, aligns, reused, rows_done, topo_runs, cons_serial, rows_slow, exact_tries, exact_hits, cells_scored, cells_exact;
     uint64_t tphase[PH_N]; uint64_t tlast;
 
     // `fast`: the LDS slice of a hybrid class (ignored otherwise: one slice, LDS or HBM, holds everything)
@@ -259,7 +259,7 @@ struct Poa {
         ring1 = (score_t*)(HYB ? fast + Lay::fRing1 : mem + Lay::oRing);
         n_paths = 0; path_used = 0; head_first = 0;
         n_nodes = 0; L = 0; topo_dirty = false; meta_dirty = true; maxdelta = 0; tb_steps = 0; tb_fv = 0;
-        cells = 0; aligns = 0; reused = 0; rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; exact_hits = 0; last_changed = true;
+        cells = 0; aligns = 0; reused = 0; rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; exact_hits = 0; cells_scored = 0; cells_exact = 0; last_changed = true;
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
         tlast = 0;
         HYPO_TICK_RESET();
@@ -909,9 +909,14 @@ struct Poa {
         if constexpr (PK) {
             // a sequence that spells a path of the graph (most reads do) is threaded without scores; what spells none goes
             // through the score rows
-            if (HYPO_EXACT && m > 0 && n < m && gp < 0) { best_i = rows_exact(mode, S, R); exact_tries += 1; if (best_i > 0) exact_hits += 1; }
-            if (best_i <= 0) best_i = rows_pk(mode, m, n, gp, S, R);
+            if (HYPO_EXACT && m > 0 && n < m && gp < 0) {
+                best_i = rows_exact(mode, S, R);
+                exact_tries += 1; cells_exact += (uint64_t)(n_nodes + 1) * W;
+                if (best_i > 0) exact_hits += 1;
+            }
+            if (best_i <= 0) { best_i = rows_pk(mode, m, n, gp, S, R); cells_scored += (uint64_t)(n_nodes + 1) * W; }
         } else {
+        cells_scored += (uint64_t)(n_nodes + 1) * W;
         HYPO_IN_VGPR(m); HYPO_IN_VGPR(n); HYPO_IN_VGPR(gp);
         const int j0 = CPL * g.lane;
         int sq[CPL];                                        // sq[c] = code of seq[j-1] for column j = j0+c
@@ -1766,7 +1771,7 @@ struct Poa {
     // Window::generate_consensus (src/Window.cpp:44-61)
     HD int run(uint32_t w) {
         // the object outlives the window (one per persistent group): per-window counters and flags start over here
-        cells = 0; aligns = 0; reused = 0; rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; exact_hits = 0; last_changed = true;
+        cells = 0; aligns = 0; reused = 0; rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; exact_hits = 0; cells_scored = 0; cells_exact = 0; last_changed = true;
         n_paths = 0; path_used = 0; head_first = 0; L = 0; maxdelta = 0; tb_steps = 0; tb_fv = 0; need_nodes = 0;
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
         HYPO_TICK_RESET();

@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through t
     const int cls = fresh(ka)->cls;
     const uint32_t count = *fresh(ka)->bound;   // queue slots [.., *bound) are final when this launch starts
     const PoaParamRef P{&ka->P};
-    uint64_t cells = 0, aligns = 0, abytes = 0;
+    uint64_t cells = 0, aligns = 0, abytes = 0, n_reused = 0, n_thr = 0, c_scored = 0, c_thr = 0;
     uint32_t n_ok = 0, n_esc = 0, n_fail = 0;
 #ifdef HYPO_PHASE_TIMERS
     uint64_t tph[PH_N] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -178,7 +178,8 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through t
 #endif
     // what happens to a window once Poa::run / step has returned something other than RES_CONTINUE
     auto account = [&](Poa<Cfg>& poa, uint32_t w, int rc) {
-        if (rc == RES_OK) { cells += poa.cells; aligns += poa.aligns; }   // reference-equivalent work of FINISHED windows only
+        if (rc == RES_OK) { cells += poa.cells; aligns += poa.aligns; n_reused += poa.reused; n_thr += poa.exact_hits; }   // reference-equivalent work of FINISHED windows only
+        c_scored += poa.cells_scored; c_thr += poa.cells_exact;                // executed work, finished or not
 #ifdef HYPO_PHASE_TIMERS
         for (int i = 0; i < PH_N; ++i) tph[i] += poa.tphase[i];
         dbg[0] += poa.rows_done; dbg[1] += poa.aligns - poa.reused; dbg[2] += poa.reused; dbg[3] += poa.topo_runs; dbg[4] += poa.cons_serial; dbg[5] += poa.rows_slow; dbg[6] += poa.exact_tries; dbg[7] += poa.exact_hits;
@@ -243,6 +244,10 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through t
         atomicAdd((unsigned long long*)&st->dp_cells, (unsigned long long)cells);
         atomicAdd((unsigned long long*)&st->n_alignments, (unsigned long long)aligns);
         atomicAdd((unsigned long long*)&st->alg_bytes[cls], (unsigned long long)abytes);
+        atomicAdd((unsigned long long*)&st->n_reused, (unsigned long long)n_reused);
+        atomicAdd((unsigned long long*)&st->n_threaded, (unsigned long long)n_thr);
+        atomicAdd((unsigned long long*)&st->cells_scored, (unsigned long long)c_scored);
+        atomicAdd((unsigned long long*)&st->cells_threaded, (unsigned long long)c_thr);
 #ifdef HYPO_PHASE_TIMERS
         unsigned long long* ph = (unsigned long long*)((char*)fresh(ka)->Q.count + 512) + (size_t)cls * 24;   // header + 512: [class][24]
         for (int i = 0; i < PH_N; ++i) atomicAdd(&ph[i], (unsigned long long)tph[i]);

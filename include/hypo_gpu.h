@@ -11,7 +11,8 @@
  *  - every function returns 0 on success, <0 = HYPO_E_* (never throws, never exits);
  *    hypo_gpu_last_error() gives a thread-local message.
  *  - "_device" variants take DEVICE pointers inside the batch structs and run asynchronously on the
- *    given hipStream_t (passed as void*); plain variants take HOST pointers and do H2D/D2H themselves.
+ *    given hipStream_t (passed as void*; NULL = the HIP null stream, ordered after everything the caller queued there);
+ *    plain variants take HOST pointers and do H2D/D2H themselves on a stream of the context.
  *    (hypo_gpu_poa_batch_device returns once all kernels are queued; on the way it waits for its own plan
  *    step, ~0.1 ms of device time, to size the launches of the rare size classes.)
  *  - one device context per device handed to hypo_gpu_init.  A host thread works on the context it selected with
@@ -193,6 +194,11 @@ typedef struct HypoPoaStats {
     uint64_t n_alignments;
     uint64_t alg_bytes[8];     /* algorithmic HBM bytes of the windows finished in class 0..7:
                                   ceil(Ld/2) + sum ceil(La/4) + Lcons + 16 + 8*(1+n_arms)   */
+    /* How the n_alignments were answered (dp_cells counts every one of them as the reference would compute it): */
+    uint64_t n_reused;         /* byte-identical to the alignment just made on an unchanged graph: weights only */
+    uint64_t n_threaded;       /* the sequence spells a path of the graph: one-bit recurrence, no scores */
+    uint64_t cells_scored;     /* matrix cells that went through the score rows (windows re-run after an overflow included) */
+    uint64_t cells_threaded;   /* matrix cells that went through the one-bit rows (failed attempts included) */
 } HypoPoaStats;
 int hypo_gpu_poa_last_stats(HypoPoaStats* out);
 /* Same for a _device call: synchronises the stream and copies the counters out of `workspace`. */
