@@ -22,6 +22,7 @@ EXPORTS = [
     "hypo_gpu_poa_batch_device", "hypo_gpu_poa_slot_layout", "hypo_gpu_poa_last_stats",
     "hypo_gpu_poa_read_stats", "hypo_gpu_profile_begin", "hypo_gpu_profile_calls", "hypo_gpu_profile_read",
     "hypo_gpu_num_devices", "hypo_gpu_use_device", "hypo_gpu_build_id", "hypo_gpu_solid_set_upload",
+    "hypo_gpu_poa_batch_sharded",
 ]
 
 
@@ -70,13 +71,16 @@ def host_struct(b: HostBatch) -> abi.WindowBatch:
 class HypoGpu:
     """One process = one GPU (rank-local), mirroring the reference's single Hypo object."""
 
-    def __init__(self, device: int = 0, path: str = LIB_PATH):
+    def __init__(self, device: int = 0, path: str = LIB_PATH, devices=None):
+        """devices: list of HIP device ids for several contexts in this process (hypo_gpu_poa_batch_sharded); the torch
+        plumbing of the *_device entry points uses context 0 = `device`."""
         self.lib = load_library(path)
         if self.lib.hypo_gpu_abi_version() != abi.ABI_VERSION:
             raise HypoGpuError("ABI version mismatch between hypo_amd/abi.py and libhypo_gpu.so")
-        self.device = device
-        ids = (C.c_int * 1)(device)
-        self._check(self.lib.hypo_gpu_init(ids, C.c_int(1)))
+        devices = [device] if devices is None else list(devices)
+        self.device = devices[0]
+        ids = (C.c_int * len(devices))(*devices)
+        self._check(self.lib.hypo_gpu_init(ids, C.c_int(len(devices))))
         self.num_cus = int(self.lib.hypo_gpu_num_cus())
 
     def _check(self, rc):
@@ -98,6 +102,20 @@ class HypoGpu:
         ins = host_struct(b)
         out = abi.ConsensusBatch(_p(bases), _p(off), _p(ln), _p(st))
         self._check(self.lib.hypo_gpu_poa_batch(C.byref(sp), C.byref(ins), C.byref(out)))
+        return bases, off, ln, st
+
+    def poa_batch_sharded(self, b: HostBatch, scores=abi.DEFAULT_SCORES, off=None):
+        """hypo_gpu_poa_batch over all contexts of this process.  Returns (bases u8, off u64, len u32, status u8)."""
+        sp = abi.ScoreParams(*scores)
+        n = b.n_windows
+        if off is None:
+            off = b.slot_layout()
+        bases = np.zeros(int(off[-1]) + 1, dtype=np.uint8)
+        ln = np.zeros(n, dtype=np.uint32)
+        st = np.zeros(n, dtype=np.uint8)
+        ins = host_struct(b)
+        out = abi.ConsensusBatch(_p(bases), _p(off), _p(ln), _p(st))
+        self._check(self.lib.hypo_gpu_poa_batch_sharded(C.byref(sp), C.byref(ins), C.byref(out)))
         return bases, off, ln, st
 
     def poa_consensus(self, b: HostBatch, scores=abi.DEFAULT_SCORES, off=None):

@@ -5,7 +5,9 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <dlfcn.h>
 #include <mutex>
+#include <thread>
 #include <vector>
 #include "../../include/hypo_gpu.h"
 #include "poa_kernel.hpp"
@@ -52,6 +54,7 @@ struct Ctx {
     bool ready = false; int device = -1; int num_cus = 0; hipStream_t stream = nullptr;
     hypo::PoaAux poa_aux; DevBuf arena[16];
     DevBuf solid_set; uint32_t solid_k = 0;            // hypo_gpu_solid_set_upload
+    std::vector<HypoWindow> sh_win; std::vector<uint64_t> sh_aoff, sh_off;   // rebased descriptors of this device's share (hypo_gpu_poa_batch_sharded)
     Prof prof;
     std::recursive_mutex mu;                           // recursive: the host-buffer variants call the device variants
 };
@@ -73,6 +76,37 @@ ProfCall* prof_next(int kind) {
     c->kind = kind; c->ke.n = 0;
     return c;
 }
+
+struct Rccl {
+    void* h = nullptr; bool tried = false; bool ok = false;
+    int (*CommInitAll)(void**, int, const int*) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    void* comms[kMaxDevices] = {};
+    int n_comms = 0; int devs[kMaxDevices] = {};
+    bool load() {
+        if (tried) return ok;
+        tried = true;
+        for (const char* name : {"librccl.so.1", "librccl.so"}) { h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        if (!h) return false;
+        CommInitAll = (int (*)(void**, int, const int*))dlsym(h, "ncclCommInitAll");
+        CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+        GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
+        GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
+        Broadcast = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclBroadcast");
+        GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+        ok = CommInitAll && CommDestroy && GroupStart && GroupEnd && Broadcast && GetErrorString;
+        return ok;
+    }
+    void release() { for (int i = 0; i < n_comms; ++i) if (comms[i] && CommDestroy) (void)CommDestroy(comms[i]); n_comms = 0; }
+};
+Rccl g_rccl;
+std::mutex g_shard_mu;                               // one sharded call at a time (it uses every context)
+constexpr int kNcclUint8 = 1;                         // ncclUint8 (rccl.h)
+
 
 int check_scores(const HypoScoreParams* s) {
     if (!s) return fail(HYPO_E_INVALID, "scores == NULL");
@@ -127,7 +161,8 @@ int hypo_gpu_init(const int* device_ids, int n_devices) {
     if (n_devices > kMaxDevices) return fail(HYPO_E_INVALID, "%d devices requested, at most %d", n_devices, kMaxDevices);
     for (int i = 0; i < n_devices; ++i) {
         if (device_ids[i] < 0 || device_ids[i] >= n) return fail(HYPO_E_INVALID, "device %d out of range (0..%d)", device_ids[i], n - 1);
-        for (int j = 0; j < i; ++j) if (device_ids[j] == device_ids[i]) return fail(HYPO_E_INVALID, "device %d listed twice", device_ids[i]);
+        // HYPO_ALLOW_DUP_DEVICES=1 (tests on a one-GPU box): several contexts on one device exercise the sharded path
+        for (int j = 0; j < i; ++j) if (device_ids[j] == device_ids[i] && !getenv("HYPO_ALLOW_DUP_DEVICES")) return fail(HYPO_E_INVALID, "device %d listed twice", device_ids[i]);
     }
     for (int i = 0; i < g_nctx; ++i) release_ctx(g_ctxs[i]);   // re-initialisation: streams and events belong to the previous devices
     g_nctx = 0;
@@ -156,6 +191,7 @@ int hypo_gpu_use_device(int slot) {
 
 int hypo_gpu_shutdown(void) {
     std::lock_guard<std::mutex> lk(g_init_mu);
+    g_rccl.release();
     for (int i = 0; i < g_nctx; ++i) release_ctx(g_ctxs[i]);
     g_nctx = 0;
     return HYPO_OK;
@@ -301,6 +337,198 @@ int hypo_gpu_poa_batch(const HypoScoreParams* scores, const HypoWindowBatch* in,
     HIP_TRY(hipMemcpyAsync(out->status, dS.p, n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&tl_stats, (char*)dWS.p + 128, sizeof(HypoPoaStats), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    tl_stats.n_windows = n;
+    return HYPO_OK;
+}
+
+// ---- POA over all contexts ----------------------------------------------------------------------------
+// Windows are independent (src/Hypo.cpp:238-247 is a parallel loop over them): the batch is cut into one contiguous,
+// cost-balanced range per device, every device polishes its range, and the consensus bytes, lengths and status bytes are
+// exchanged with ONE grouped RCCL all-gatherv over xGMI (ncclBroadcast per owner inside a group: the ranges differ in
+// size) so that every device, device 0 in particular, holds the whole result before it goes back to the host for contig
+// re-assembly (src/Contig.cpp:345-366).  RCCL is loaded on first use (a single-device run never touches it).
+namespace {
+struct Share { uint32_t w0 = 0, w1 = 0; uint64_t a0 = 0, a1 = 0, d0 = 0, d1 = 0, b0 = 0, b1 = 0; int rc = HYPO_OK; char err[256] = ""; HypoPoaStats st; };
+
+// cost of a window as the plan sees it (rows x sequences), LONG windows twice
+inline uint64_t window_cost(const HypoWindowBatch* in, uint32_t w) {
+    const HypoWindow& W = in->windows[w];
+    const uint64_t narm = (uint64_t)W.n_internal + W.n_prefix + W.n_suffix;
+    uint64_t s = 0;
+    if ((uint64_t)W.first_arm + narm <= in->n_arms) for (uint64_t a = 0; a < narm; ++a) s += in->arm_len[W.first_arm + a] + 1;
+    return ((uint64_t)W.draft_len + 2) * (s + 1) * (W.type != HYPO_WIN_SHORT ? 2 : 1) + 64;
+}
+}  // namespace
+
+int hypo_gpu_poa_batch_sharded(const HypoScoreParams* scores, const HypoWindowBatch* in, HypoConsensusBatch* out) {
+    const int nd = g_nctx;
+    if (nd <= 0) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
+    if (nd == 1 && !getenv("HYPO_MULTI_GATHER")) { const int keep = tl_slot; tl_slot = 0; const int rc = hypo_gpu_poa_batch(scores, in, out); tl_slot = keep; return rc; }
+    std::lock_guard<std::mutex> shard_lock(g_shard_mu);
+    int rc = check_scores(scores);
+    if (rc) return rc;
+    if (!in || !out) return fail(HYPO_E_INVALID, "NULL batch");
+    memset(&tl_stats, 0, sizeof(tl_stats));
+    const uint32_t n = in->n_windows;
+    if (n == 0) return HYPO_OK;
+    if (!in->windows || !in->draft4 || !out->bases || !out->off || !out->len || !out->status ||
+        (in->n_arms && (!in->arm_off || !in->arm_len || !in->arms2)))
+        return fail(HYPO_E_INVALID, "NULL buffer in batch");
+    // ---- 1. contiguous cost-balanced ranges: per-chunk costs on nd threads, then a short prefix walk ----
+    std::vector<uint64_t> cost(n);
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nd; ++t) th.emplace_back([&, t]() {
+            const uint32_t lo = (uint32_t)((uint64_t)n * t / nd), hi = (uint32_t)((uint64_t)n * (t + 1) / nd);
+            for (uint32_t w = lo; w < hi; ++w) cost[w] = window_cost(in, w);
+        });
+        for (auto& t : th) t.join();
+    }
+    uint64_t total = 0;
+    for (uint32_t w = 0; w < n; ++w) total += cost[w];
+    std::vector<Share> sh((size_t)nd);
+    {
+        uint64_t acc = 0; uint32_t w = 0;
+        for (int d = 0; d < nd; ++d) {
+            sh[d].w0 = w;
+            const uint64_t target = total / nd * (uint64_t)(d + 1) + (d + 1 == nd ? total % nd : 0);
+            while (w < n && (d + 1 == nd || acc + cost[w] / 2 < target)) acc += cost[w++];
+            sh[d].w1 = w;
+        }
+    }
+    // ---- 2. every device: rebase its descriptors, upload its slices, run ----
+    const bool want_rccl = nd > 1 ? !(getenv("HYPO_MULTI_GATHER") && !strcmp(getenv("HYPO_MULTI_GATHER"), "direct"))
+                                  : (getenv("HYPO_MULTI_GATHER") && !strcmp(getenv("HYPO_MULTI_GATHER"), "rccl"));
+    bool use_rccl = want_rccl && g_rccl.load();
+    if (use_rccl) {                                    // communicators for the current device list (created once)
+        bool same = g_rccl.n_comms == nd;
+        for (int d = 0; same && d < nd; ++d) same = g_rccl.devs[d] == g_ctxs[d].device;
+        if (!same) {
+            g_rccl.release();
+            int devs[kMaxDevices];
+            for (int d = 0; d < nd; ++d) devs[d] = g_rccl.devs[d] = g_ctxs[d].device;
+            const int r = g_rccl.CommInitAll(g_rccl.comms, nd, devs);
+            if (r != 0) { fprintf(stderr, "[hypo_gpu] RCCL unavailable for this device list (%s): results go back per device\n", g_rccl.GetErrorString(r)); use_rccl = false; }
+            else g_rccl.n_comms = nd;
+        }
+    }
+    const uint64_t out_bytes = out->off[n];
+    auto device_part = [&](int d) {
+        Share& S = sh[d];
+        Ctx& c = g_ctxs[d];
+        std::lock_guard<std::recursive_mutex> lk(c.mu);
+        auto bad = [&](int code, const char* what, hipError_t e) { S.rc = code; snprintf(S.err, sizeof(S.err), "device %d: %s: %s", c.device, what, hipGetErrorString(e)); };
+        hipError_t e = hipSetDevice(c.device);
+        if (e != hipSuccess) return bad(HYPO_E_HIP, "hipSetDevice", e);
+        const uint32_t nw = S.w1 - S.w0;
+        // result buffers of the WHOLE batch on every device (the gather fills the other devices' ranges)
+        DevBuf &dW = c.arena[0], &dD = c.arena[1], &dAO = c.arena[2], &dAL = c.arena[3], &dA = c.arena[4],
+               &dB = c.arena[5], &dO = c.arena[6], &dL = c.arena[7], &dS = c.arena[8], &dWS = c.arena[9];
+        if ((e = dB.alloc(out_bytes)) != hipSuccess || (e = dL.alloc((size_t)n * 4)) != hipSuccess || (e = dS.alloc(n)) != hipSuccess)
+            return bad(HYPO_E_HIP, "hipMalloc", e);
+        memset(&S.st, 0, sizeof(S.st));
+        if (nw == 0) return;
+        // ranges of the shared buffers this share touches
+        uint64_t a0 = ~0ull, a1 = 0, d0 = ~0ull, d1 = 0;
+        for (uint32_t w = S.w0; w < S.w1; ++w) {
+            const HypoWindow& W = in->windows[w];
+            const uint64_t narm = (uint64_t)W.n_internal + W.n_prefix + W.n_suffix;
+            if (narm && (uint64_t)W.first_arm + narm <= in->n_arms) { a0 = W.first_arm < a0 ? W.first_arm : a0; a1 = W.first_arm + narm > a1 ? W.first_arm + narm : a1; }
+            if (W.draft_off <= in->draft4_bytes) {
+                const uint64_t de = W.draft_off + ((uint64_t)W.draft_len + 1) / 2;
+                d0 = W.draft_off < d0 ? W.draft_off : d0; d1 = (de < in->draft4_bytes ? de : in->draft4_bytes) > d1 ? (de < in->draft4_bytes ? de : in->draft4_bytes) : d1;
+            }
+        }
+        if (a0 == ~0ull) { a0 = 0; a1 = 0; }
+        if (d0 == ~0ull) { d0 = 0; d1 = 0; }
+        uint64_t b0 = ~0ull, b1 = 0;
+        for (uint64_t a = a0; a < a1; ++a) {
+            const uint64_t o = in->arm_off[a], e2 = o + ((uint64_t)in->arm_len[a] + 3) / 4;
+            if (o > in->arms2_bytes) continue;                 // left as it is: the device answers the window with HYPO_ST_INVALID
+            b0 = o < b0 ? o : b0; b1 = (e2 < in->arms2_bytes ? e2 : in->arms2_bytes) > b1 ? (e2 < in->arms2_bytes ? e2 : in->arms2_bytes) : b1;
+        }
+        if (b0 == ~0ull) { b0 = 0; b1 = 0; }
+        S.a0 = a0; S.a1 = a1; S.d0 = d0; S.d1 = d1; S.b0 = b0; S.b1 = b1;
+        c.sh_win.assign(in->windows + S.w0, in->windows + S.w1);
+        for (auto& W : c.sh_win) { W.first_arm -= (uint32_t)(W.first_arm >= a0 ? a0 : 0); W.draft_off -= (W.draft_off >= d0 ? d0 : 0); }
+        c.sh_aoff.resize((size_t)(a1 - a0));
+        for (uint64_t a = a0; a < a1; ++a) c.sh_aoff[(size_t)(a - a0)] = in->arm_off[a] >= b0 ? in->arm_off[a] - b0 : in->arm_off[a];
+        c.sh_off.resize((size_t)nw + 1);
+        for (uint32_t i = 0; i <= nw; ++i) c.sh_off[i] = out->off[S.w0 + i];      // GLOBAL slot offsets: results land where the gather expects them
+        uint32_t n_long = 0;
+        for (const auto& W : c.sh_win) n_long += W.type != HYPO_WIN_SHORT;
+        const size_t wsb = hypo::poa_workspace_bytes(nw, (int)(n_long + 64 < 2048u ? n_long + 64 : 2048u));
+        if ((e = dW.alloc((size_t)nw * sizeof(HypoWindow))) != hipSuccess || (e = dD.alloc(d1 - d0)) != hipSuccess ||
+            (e = dAO.alloc((a1 - a0) * 8)) != hipSuccess || (e = dAL.alloc((a1 - a0) * 4)) != hipSuccess ||
+            (e = dA.alloc(b1 - b0)) != hipSuccess || (e = dO.alloc(((size_t)nw + 1) * 8)) != hipSuccess || (e = dWS.alloc(wsb)) != hipSuccess)
+            return bad(HYPO_E_HIP, "hipMalloc", e);
+        hipStream_t st = c.stream;
+        (void)hipMemcpyAsync(dW.p, c.sh_win.data(), (size_t)nw * sizeof(HypoWindow), hipMemcpyHostToDevice, st);
+        if (d1 > d0) (void)hipMemcpyAsync(dD.p, in->draft4 + d0, d1 - d0, hipMemcpyHostToDevice, st);
+        if (a1 > a0) {
+            (void)hipMemcpyAsync(dAO.p, c.sh_aoff.data(), (a1 - a0) * 8, hipMemcpyHostToDevice, st);
+            (void)hipMemcpyAsync(dAL.p, in->arm_len + a0, (a1 - a0) * 4, hipMemcpyHostToDevice, st);
+            if (b1 > b0) (void)hipMemcpyAsync(dA.p, in->arms2 + b0, b1 - b0, hipMemcpyHostToDevice, st);
+        }
+        (void)hipMemcpyAsync(dO.p, c.sh_off.data(), ((size_t)nw + 1) * 8, hipMemcpyHostToDevice, st);
+        (void)hipMemsetAsync((char*)dB.p + out->off[S.w0], 0, out->off[S.w1] - out->off[S.w0] ? out->off[S.w1] - out->off[S.w0] : 1, st);
+        if ((e = hipGetLastError()) != hipSuccess) return bad(HYPO_E_HIP, "upload", e);
+        hypo::PoaParams P;
+        P.windows = (const HypoWindow*)dW.p; P.draft4 = (const uint8_t*)dD.p; P.arm_off = (const uint64_t*)dAO.p;
+        P.arm_len = (const uint32_t*)dAL.p; P.arms2 = (const uint8_t*)dA.p;
+        P.out_bases = (char*)dB.p; P.out_off = (const uint64_t*)dO.p;
+        P.out_len = (uint32_t*)dL.p + S.w0; P.out_status = (uint8_t*)dS.p + S.w0;
+        P.sr_m = scores->sr_match; P.sr_n = scores->sr_mismatch; P.sr_g = scores->sr_gap;
+        P.lr_m = scores->lr_match; P.lr_n = scores->lr_mismatch; P.lr_g = scores->lr_gap;
+        P.n_arms = a1 - a0; P.draft4_bytes = d1 - d0; P.arms2_bytes = b1 - b0;
+        if ((e = hypo::poa_run(P, nw, dWS.p, wsb, c.num_cus, st, nullptr, &c.poa_aux)) != hipSuccess) return bad(HYPO_E_HIP, "poa_run", e);
+        (void)hipMemcpyAsync(&S.st, (char*)dWS.p + 128, sizeof(HypoPoaStats), hipMemcpyDeviceToHost, st);
+        if (!use_rccl) {                                   // results of this share straight back to the caller's buffers
+            (void)hipMemcpyAsync(out->bases + out->off[S.w0], (char*)dB.p + out->off[S.w0], out->off[S.w1] - out->off[S.w0], hipMemcpyDeviceToHost, st);
+            (void)hipMemcpyAsync(out->len + S.w0, (uint32_t*)dL.p + S.w0, (size_t)nw * 4, hipMemcpyDeviceToHost, st);
+            (void)hipMemcpyAsync(out->status + S.w0, (uint8_t*)dS.p + S.w0, nw, hipMemcpyDeviceToHost, st);
+            if ((e = hipStreamSynchronize(st)) != hipSuccess) return bad(HYPO_E_HIP, "hipStreamSynchronize", e);
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int d = 0; d < nd; ++d) th.emplace_back(device_part, d);
+        for (auto& t : th) t.join();
+    }
+    for (int d = 0; d < nd; ++d) if (sh[d].rc != HYPO_OK) return fail(sh[d].rc, "%s", sh[d].err);
+    if (use_rccl) {
+        // ---- 3. all-gatherv: owner r broadcasts its three ranges into the same places of every device's whole-batch buffers ----
+        int r = g_rccl.GroupStart();
+        for (int root = 0; r == 0 && root < nd; ++root) {
+            const Share& S = sh[root];
+            if (S.w1 == S.w0) continue;
+            for (int d = 0; r == 0 && d < nd; ++d) {
+                Ctx& c = g_ctxs[d];
+                char* B = (char*)c.arena[5].p; uint32_t* L = (uint32_t*)c.arena[7].p; uint8_t* St = (uint8_t*)c.arena[8].p;
+                const size_t nb = out->off[S.w1] - out->off[S.w0], nw = S.w1 - S.w0;
+                if (nb) r = g_rccl.Broadcast(B + out->off[S.w0], B + out->off[S.w0], nb, kNcclUint8, root, g_rccl.comms[d], c.stream);
+                if (r == 0) r = g_rccl.Broadcast(L + S.w0, L + S.w0, nw * 4, kNcclUint8, root, g_rccl.comms[d], c.stream);
+                if (r == 0) r = g_rccl.Broadcast(St + S.w0, St + S.w0, nw, kNcclUint8, root, g_rccl.comms[d], c.stream);
+            }
+        }
+        const int r2 = g_rccl.GroupEnd();
+        if (r != 0 || r2 != 0) return fail(HYPO_E_HIP, "RCCL all-gather of the consensus: %s", g_rccl.GetErrorString(r ? r : r2));
+        // ---- 4. device 0 holds everything: one copy back for contig re-assembly; the other devices only have to finish ----
+        Ctx& c0 = g_ctxs[0];
+        HIP_TRY(hipSetDevice(c0.device));
+        HIP_TRY(hipMemcpyAsync(out->bases, c0.arena[5].p, out_bytes, hipMemcpyDeviceToHost, c0.stream));
+        HIP_TRY(hipMemcpyAsync(out->len, c0.arena[7].p, (size_t)n * 4, hipMemcpyDeviceToHost, c0.stream));
+        HIP_TRY(hipMemcpyAsync(out->status, c0.arena[8].p, n, hipMemcpyDeviceToHost, c0.stream));
+        for (int d = nd - 1; d >= 0; --d) { HIP_TRY(hipSetDevice(g_ctxs[d].device)); HIP_TRY(hipStreamSynchronize(g_ctxs[d].stream)); }
+    }
+    HIP_TRY(hipSetDevice(g_ctx.device));
+    for (int d = 0; d < nd; ++d) {
+        const HypoPoaStats& s = sh[d].st;
+        tl_stats.n_trivial += s.n_trivial; tl_stats.n_escalated += s.n_escalated; tl_stats.n_failed += s.n_failed;
+        tl_stats.dp_cells += s.dp_cells; tl_stats.n_alignments += s.n_alignments;
+        tl_stats.n_reused += s.n_reused; tl_stats.n_threaded += s.n_threaded; tl_stats.cells_scored += s.cells_scored; tl_stats.cells_threaded += s.cells_threaded;
+        for (int k = 0; k < 8; ++k) { tl_stats.n_class[k] += s.n_class[k]; tl_stats.alg_bytes[k] += s.alg_bytes[k]; }
+    }
     tl_stats.n_windows = n;
     return HYPO_OK;
 }

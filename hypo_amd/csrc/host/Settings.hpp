@@ -18,6 +18,8 @@ struct InputFlags {                        // include/globalDefs.hpp:68-87
     uint32_t done_stage = 0;
     bool intermed = false;
     int device = 0;                        // new, opt-in: --device
+    int gpus = 1;                          // new, opt-in: --gpus N (devices 0..N-1)
+    std::vector<int> devices;              // new, opt-in: --devices a,b,c
 };
 
 enum class RegionType : uint8_t { SWS, SW, WS, MWM, MW, WM, SWM, MWS, OTHER, LONG, SR, MSR };   // globalDefs.hpp:95-108

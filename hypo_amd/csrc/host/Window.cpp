@@ -67,7 +67,8 @@ int Window::consensus_call(const ScoreParams& sp, const std::vector<Window*>& wi
     len.assign(win.size(), 0);
     st.assign(win.size(), 0);
     HypoConsensusBatch out{bases.data(), off.data(), len.data(), st.data()};
-    rc = hypo_gpu_poa_batch(&sp, &in, &out);
+    // all contexts of hypo_gpu_init share the batch (one context: the plain call)
+    rc = hypo_gpu_num_devices() > 1 ? hypo_gpu_poa_batch_sharded(&sp, &in, &out) : hypo_gpu_poa_batch(&sp, &in, &out);
     if (rc != HYPO_OK) return rc;
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < nw; ++i)

@@ -1,5 +1,5 @@
 // main.cpp — command line of the MI355X build: the reference's flags and defaults (src/main.cpp:46-67,100-113,
-// 124-358) plus one opt-in flag, --device.  Help text is this build's own.
+// 124-358) plus the opt-in flags --device / --gpus / --devices.  usage() keeps the reference's layout, the wording is this build's own.
 #include <getopt.h>
 #include <malloc.h>
 #include <sys/stat.h>
@@ -25,31 +25,46 @@ const struct option long_options[] = {
     {"mismatch-lr", required_argument, nullptr, 'X'}, {"gap-lr", required_argument, nullptr, 'G'},
     {"qual-map-th", required_argument, nullptr, 'q'}, {"ned-th", required_argument, nullptr, 'n'},
     {"intermed", no_argument, nullptr, 'i'}, {"help", no_argument, nullptr, 'h'},
-    {"device", required_argument, nullptr, 1000}, {nullptr, 0, nullptr, 0}};
+    {"device", required_argument, nullptr, 1000}, {"gpus", required_argument, nullptr, 1001},
+    {"devices", required_argument, nullptr, 1002}, {nullptr, 0, nullptr, 0}};
 
+// Same layout as the reference's usage() (src/main.cpp:363-430): "Usage: hypo <args>", the mandatory block, the optional
+// block, every flag as "-x, --long <type>" followed by what it does and its default.  The wording is this build's own.
+struct HelpEntry { const char* flag; const char* what; const char* dflt; };
 void usage() {
-    std::puts(
-        "hypo (MI355X build): polishes draft contigs with short reads (and optionally long reads)\n"
-        "usage: hypo -r <reads|@list> -d <draft.fa> -b <short-reads.sam> -c <coverage> -s <genome size[k|m|g|t]> [options]\n"
-        "  mandatory\n"
-        "    -r, --reads-short FILE     short reads file or @file-of-names (only checked for existence here)\n"
-        "    -d, --draft FILE           draft contigs, FASTA/FASTQ, plain or gzip\n"
-        "    -b, --bam-sr FILE          short reads mapped to the draft, coordinate sorted (BAM, or SAM text plain/gzip)\n"
-        "    -c, --coverage-short INT   approximate coverage of the short reads\n"
-        "    -s, --size-ref STR         approximate genome size: number with unit k/m/g/t; fixes the solid k-mer length\n"
-        "  optional\n"
-        "    -B, --bam-lr FILE          long reads mapped to the draft (BAM or SAM)       [none]\n"
-        "    -o, --output FILE          polished contigs                                  [hypo_<draft>.fasta]\n"
-        "    -t, --threads INT          host threads                                      [1]\n"
-        "    -p, --processing-size INT  contigs per batch, 0 = all                        [0]\n"
-        "    -k, --kind-sr STR          sr | ccs (accepted and, as in the reference, without effect) [sr]\n"
-        "    -m/-x/-g INT               short-read match / mismatch / gap (g < 0)         [5 / -4 / -8]\n"
-        "    -M/-X/-G INT               long-read match / mismatch / gap (G < 0)          [3 / -5 / -4]\n"
-        "    -n, --ned-th INT           long reads: max normalised edit distance          [20]\n"
-        "    -q, --qual-map-th INT      minimum mapping quality                           [2]\n"
-        "    -i, --intermed             keep / reuse aux/solid_kmers.bvsd (required here: k-mer counting is not built in)\n"
-        "        --device INT           HIP device                                        [0]\n"
-        "    -h, --help");
+    static const HelpEntry mandatory[] = {
+        {"-r, --reads-short <str>", "Short reads (fasta/fastq, plain or compressed), or @file holding one file name per line. Only its existence is checked: solid k-mers come from aux/solid_kmers.bvsd (see -i).", nullptr},
+        {"-d, --draft <str>", "Draft contigs to polish (fasta/fastq, plain or compressed).", nullptr},
+        {"-b, --bam-sr <str>", "Short reads aligned to the draft (bam, or sam plain/gzip; CIGAR required), sorted by coordinate.", nullptr},
+        {"-c, --coverage-short <int>", "Approximate mean coverage of the short reads.", nullptr},
+        {"-s, --size-ref <str>", "Approximate genome size: a number, optionally followed by k/m/g (10m, 2.3g). It fixes the solid k-mer length.", nullptr}};
+    static const HelpEntry optional[] = {
+        {"-B, --bam-lr <str>", "Long reads aligned to the draft (bam/sam with CIGAR).", "short-read polishing only"},
+        {"-o, --output <str>", "Output file.", "hypo_<draft_file_name>.fasta in the working directory"},
+        {"-t, --threads <int>", "Host threads.", "1"},
+        {"-p, --processing-size <int>", "Contigs per batch; fewer contigs per batch need less memory.", "all contigs of the draft"},
+        {"-k, --kind-sr <str>", "Kind of short reads: sr (Illumina-like) or ccs (HiFi). Accepted and, as in the reference (src/main.cpp:312), without effect.", "sr"},
+        {"-m, --match-sr <int>", "Match score, short reads.", "5"},
+        {"-x, --mismatch-sr <int>", "Mismatch score, short reads.", "-4"},
+        {"-g, --gap-sr <int>", "Gap penalty, short reads (negative).", "-8"},
+        {"-M, --match-lr <int>", "Match score, long reads.", "3"},
+        {"-X, --mismatch-lr <int>", "Mismatch score, long reads.", "-5"},
+        {"-G, --gap-lr <int>", "Gap penalty, long reads (negative).", "-4"},
+        {"-n, --ned-th <int>", "Largest normalised edit distance (in %) of a long arm that may enter a window.", "20"},
+        {"-q, --qual-map-th <int>", "Reads mapped with a quality below this are ignored.", "2"},
+        {"-i, --intermed", "Keep and reuse intermediate files (aux/solid_kmers.bvsd). Needed here: k-mer counting (KMC) is not part of this build.", nullptr},
+        {"    --device <int>", "[MI355X build] HIP device to run on.", "0"},
+        {"    --gpus <int>", "[MI355X build] Use devices 0..N-1: the windows of a contig batch are sharded over them, results gathered with RCCL.", "1"},
+        {"    --devices <list>", "[MI355X build] Comma-separated HIP device ids instead of --device / --gpus.", nullptr},
+        {"-h, --help", "Print the usage.", nullptr}};
+    std::printf("\n Usage: hypo <args>\n\n ** Mandatory args:\n");
+    for (const auto& e : mandatory) std::printf("\t%s\n\t%s\n\n", e.flag, e.what);
+    std::printf("\n ** Optional args:\n");
+    for (const auto& e : optional) {
+        std::printf("\t%s\n\t%s\n", e.flag, e.what);
+        if (e.dflt) std::printf("\t[Default] %s.\n", e.dflt);
+        std::printf("\n");
+    }
 }
 
 bool file_exists(const std::string& p) { struct stat st; return stat(p.c_str(), &st) == 0; }
@@ -122,6 +137,12 @@ int main(int argc, char** argv) {
             case 'n': flags.norm_edit_th = (uint32_t)std::max(0, std::atoi(optarg)); break;
             case 'i': flags.intermed = true; break;
             case 1000: flags.device = std::atoi(optarg); break;
+            case 1001: flags.gpus = std::max(1, std::atoi(optarg)); break;
+            case 1002: {
+                flags.devices.clear();
+                for (const char* c = optarg; *c;) { flags.devices.push_back(std::atoi(c)); while (*c && *c != ',') ++c; if (*c == ',') ++c; }
+                break;
+            }
             default: usage(); return 0;                                    // -h and unknown options alike (src/main.cpp:302-304)
         }
     }
@@ -148,7 +169,11 @@ int main(int argc, char** argv) {
     const bool timing = std::getenv("HYPO_HOST_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
-    if (hypo_gpu_init(&flags.device, 1) != HYPO_OK) { std::fprintf(stderr, "[Hypo::] Error: %s\n", hypo_gpu_last_error()); return 1; }
+    if (flags.devices.empty()) {                                           // --device D, or --gpus N = devices 0..N-1
+        if (flags.gpus > 1) for (int d = 0; d < flags.gpus; ++d) flags.devices.push_back(d);
+        else flags.devices.push_back(flags.device);
+    }
+    if (hypo_gpu_init(flags.devices.data(), (int)flags.devices.size()) != HYPO_OK) { std::fprintf(stderr, "[Hypo::] Error: %s\n", hypo_gpu_last_error()); return 1; }
     if (timing) std::fprintf(stderr, "[timing] main: device initialised at %.3f s\n", since());
     {
         hypo::Hypo h(flags);

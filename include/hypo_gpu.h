@@ -171,6 +171,14 @@ int hypo_gpu_solid_scan_device(const uint8_t* packed4, uint64_t n_bases, uint32_
 int hypo_gpu_poa_batch(const HypoScoreParams* scores, const HypoWindowBatch* in,
                        HypoConsensusBatch* out);
 
+/* The same batch over ALL contexts of hypo_gpu_init (src/Hypo.cpp:238-247 is a parallel loop over independent windows): the
+ * window list is cut into one contiguous cost-balanced range per device, every device polishes its range, and the consensus
+ * bytes, lengths and status bytes are exchanged with one grouped RCCL all-gatherv (ncclBroadcast per owner) over xGMI, so
+ * that device 0 holds the whole result before it returns to the host for contig re-assembly (src/Contig.cpp:345-366).
+ * One context: identical to hypo_gpu_poa_batch.  HYPO_MULTI_GATHER=direct skips RCCL (each device copies its range back). */
+int hypo_gpu_poa_batch_sharded(const HypoScoreParams* scores, const HypoWindowBatch* in,
+                               HypoConsensusBatch* out);
+
 /* Recommended workspace: queues for n_windows plus HBM scratch for as many resident groups of the LONG-window class as the
  * batch could use (up to 2048 x 3.3 MB).  A smaller workspace is accepted down to 16 resident groups (HYPO_E_WORKSPACE
  * below that); it only limits how many LONG / oversized windows are in flight at once. */

@@ -52,7 +52,7 @@ def make_inputs(name, outdir):
     return man
 
 
-def run_case(name, outdir, device, threads=4, extra_env=None, as_bam=False):
+def run_case(name, outdir, device, threads=4, extra_env=None, as_bam=False, extra_args=()):
     man = make_inputs(name, outdir)
     argv = shlex.split(man["command"])
     argv[0] = BIN
@@ -66,6 +66,7 @@ def run_case(name, outdir, device, threads=4, extra_env=None, as_bam=False):
                 os.remove(os.path.join(str(outdir), argv[i]))
                 argv[i] = bam
     argv[argv.index("-t") + 1] = str(threads)
+    argv += list(extra_args)
     env = dict(os.environ)
     env["HYPO_REGION_DUMP"] = os.path.join(str(outdir), "regions.tsv")
     if device == "shim":

@@ -12,8 +12,8 @@
 #include "../../oracle/hypo_oracle.h"
 
 static int g_ready = 0;
-static const uint64_t* g_set = 0; static uint32_t g_set_k = 0;
-int hypo_gpu_init(const int* device_ids, int n_devices) { (void)device_ids; (void)n_devices; g_ready = 1; fprintf(stderr, "[oracle_device_shim] TEST SHIM in use: CPU oracle behind the C-ABI\n"); return HYPO_OK; }
+static const uint64_t* g_set = 0; static uint32_t g_set_k = 0; static int g_ndev = 1;
+int hypo_gpu_init(const int* device_ids, int n_devices) { (void)device_ids; g_ndev = n_devices > 0 ? n_devices : 1; g_ready = 1; fprintf(stderr, "[oracle_device_shim] TEST SHIM in use: CPU oracle behind the C-ABI\n"); return HYPO_OK; }
 int hypo_gpu_shutdown(void) { g_ready = 0; return HYPO_OK; }
 int hypo_gpu_abi_version(void) { return HYPO_GPU_ABI_VERSION; }
 const char* hypo_gpu_last_error(void) { return "oracle_device_shim"; }
@@ -28,8 +28,8 @@ int hypo_gpu_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k, co
 
 /* the caller's buffer outlives the scans of a run (host/Hypo.cpp keeps the SolidKmers object alive) */
 int hypo_gpu_solid_set_upload(const uint64_t* bitset_words, uint32_t k) { g_set = bitset_words; g_set_k = k; return HYPO_OK; }
-int hypo_gpu_num_devices(void) { return g_ready ? 1 : 0; }
-int hypo_gpu_use_device(int slot) { return slot == 0 ? HYPO_OK : HYPO_E_INVALID; }
+int hypo_gpu_num_devices(void) { return g_ready ? g_ndev : 0; }
+int hypo_gpu_use_device(int slot) { return slot >= 0 && slot < g_ndev ? HYPO_OK : HYPO_E_INVALID; }
 const char* hypo_gpu_build_id(void) { return "oracle_device_shim"; }
 
 int hypo_gpu_poa_slot_layout(const HypoWindowBatch* in, uint64_t* off) {
@@ -49,4 +49,19 @@ int hypo_gpu_poa_slot_layout(const HypoWindowBatch* in, uint64_t* off) {
 int hypo_gpu_poa_batch(const HypoScoreParams* scores, const HypoWindowBatch* in, HypoConsensusBatch* out) {
     if (!g_ready) return HYPO_E_NOTINIT;
     return oracle_poa_batch(scores, in, out, 0, NULL, NULL);
+}
+/* two "devices": the window list in two contiguous halves, each answered separately into the caller's slots */
+int hypo_gpu_poa_batch_sharded(const HypoScoreParams* scores, const HypoWindowBatch* in, HypoConsensusBatch* out) {
+    if (!g_ready) return HYPO_E_NOTINIT;
+    if (g_ndev < 2 || in->n_windows < 2) return oracle_poa_batch(scores, in, out, 0, NULL, NULL);
+    fprintf(stderr, "[oracle_device_shim] sharded call over %d contexts\n", g_ndev);
+    const uint32_t h = in->n_windows / 2;
+    HypoWindowBatch a = *in, b = *in;
+    a.n_windows = h;
+    b.n_windows = in->n_windows - h; b.windows = in->windows + h;
+    HypoConsensusBatch oa = *out, ob = *out;
+    ob.off = out->off + h; ob.len = out->len + h; ob.status = out->status + h;
+    int rc = oracle_poa_batch(scores, &a, &oa, 0, NULL, NULL);
+    if (rc) return rc;
+    return oracle_poa_batch(scores, &b, &ob, 0, NULL, NULL);
 }

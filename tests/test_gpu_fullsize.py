@@ -183,3 +183,45 @@ def test_c5_wide_windows_full_batch_vs_oracle(gpu, oracle_lib):
     assert (st == ost).all() and (ln == oln).all() and s["n_failed"] == 0
     assert s["dp_cells"] == cells and s["n_alignments"] == aligns
     assert _cons_list(bases, off, ln) == _cons_list(ob, off, oln)
+
+
+def _fresh_contexts(devices, env):
+    """hypo_gpu_init for a device list, in a child process (the test process keeps its own single context)."""
+    import subprocess
+    import sys
+    import os
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from hypo_amd import capi, sim
+import oracle
+gpu = capi.HypoGpu(0, devices=%r)
+assert gpu.lib.hypo_gpu_num_devices() == %d
+for seed, n in ((41, 30000), (42, 7)):
+    b = sim.window_batch(n, seed=seed)
+    off = b.slot_layout()
+    bases, _, ln, st = gpu.poa_batch_sharded(b, off=off)
+    s = gpu.last_stats()
+    ob, _, oln, ost, cells, aligns = oracle.Oracle().poa_batch_raw(b, off=off)
+    assert (st == ost).all() and (ln == oln).all() and s["dp_cells"] == cells and s["n_alignments"] == aligns and sum(s["n_class"]) + s["n_trivial"] >= n - 0
+    l64 = ln.astype(np.int64)
+    idx = np.repeat(off[:-1].astype(np.int64), l64) + (np.arange(int(l64.sum()), dtype=np.int64) - np.repeat(np.cumsum(l64) - l64, l64))
+    assert (bases[idx] == ob[idx]).all()
+print("SHARDED-OK")
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), devices, len(devices))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "SHARDED-OK" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
+    return p
+
+
+def test_sharded_batch_over_three_contexts_direct_gather(gpu):
+    """hypo_gpu_poa_batch_sharded: cost-balanced contiguous ranges, rebased descriptors, per-device upload and run, results
+    written into the caller's slots.  On a one-GPU box three contexts share device 0 (HYPO_ALLOW_DUP_DEVICES), which RCCL
+    refuses, so the ranges come back per device."""
+    _fresh_contexts([0, 0, 0], {"HYPO_ALLOW_DUP_DEVICES": "1", "HYPO_MULTI_GATHER": "direct"})
+
+
+def test_sharded_batch_rccl_gather_single_rank(gpu):
+    """The RCCL leg of the same call (library loaded on demand, ncclCommInitAll, grouped broadcasts of bases / lengths /
+    status, copy back from device 0) with a communicator of one rank: everything but a second GPU."""
+    _fresh_contexts([0], {"HYPO_MULTI_GATHER": "rccl"})

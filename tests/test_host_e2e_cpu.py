@@ -37,3 +37,11 @@ def test_e2e_bam_input_gives_the_same_result(built, name, tmp_path):
 @pytest.mark.parametrize("seed", sorted(eu.messy_seeds())[:12])
 def test_e2e_messy_seeds_match_reference(built, seed, tmp_path):
     eu.run_messy_seed(seed, eu.messy_seeds()[seed], tmp_path, "shim")
+
+
+def test_e2e_two_device_contexts_shard_the_window_batch(built, tmp_path):
+    """`--gpus 2`: the host initialises two contexts and sends each contig batch through hypo_gpu_poa_batch_sharded (the shim
+    answers the two halves of the window list separately); the polished FASTA and the per-region records stay the reference's."""
+    man, p = eu.run_case("e2e_5ctg_long_s21", tmp_path, "shim", extra_args=["--gpus", "2"])
+    assert "sharded call over 2 contexts" in p.stderr
+    eu.check_outputs("e2e_5ctg_long_s21", tmp_path, man)
