@@ -7,10 +7,14 @@ One step = one pass of the hot path over one synthetic batch with the shape of B
 such a draft (window-shape table hypo_amd/shapes/c1_shape.npz, see hypo_amd/sim.py).  Inputs are resident
 in HBM before the timed region; each step runs entirely through the C-ABI of libhypo_gpu.so.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): windows are independent, so every rank
-polishes its own contig's batch (weak scaling: per-GPU work fixed) and the step ends with the one real
-exchange of the path: an RCCL all-gather of the per-window consensus lengths and bytes (what contig
-re-assembly needs).  value = windows of all ranks / max-over-ranks time.
+N > 1 (launched by torch.distributed.run, one rank per GPU) runs BASELINE.json configs[2] ("synthetic 100 Mbp contig set,
+30x short reads, 1 vs 2 vs 4 vs 8 MI355X window sharding over xGMI") as STRONG scaling: ONE batch of 20 x 97 078 C1-shaped
+windows (what 100 Mbp of draft yields) and the 100 contigs of 1 Mbp are the same whatever N is; the windows are
+cut into cost-balanced contiguous ranges (hypo_amd/dist.py: shard_contiguous, the cost model the C++ host uses), every rank
+scans its contigs and polishes its range, and the step ends with the one real exchange of the path: an RCCL all-gather of
+the per-window consensus lengths and bytes (what contig re-assembly needs).  value = windows of the whole
+batch / max-over-ranks time; `--workload c3` runs the same job on one GPU, `--workload c2 --gpus N` the weak-scaling
+variant of round 1 (one C2 batch per rank).
 
 Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events recorded by the library on
 the stream its kernels run on; `cpu_baseline` times oracle/ (this repo's bit-exact CPU restatement of the
@@ -84,26 +88,45 @@ def end_to_end_leg():
         shutil.rmtree(d, ignore_errors=True)
 
 
+C3_REPLICAS = 20           # 100 Mbp of draft = 20 x the windows of the 5 Mbp run
+C3_CONTIGS, C3_CONTIG_BASES, C3_K = 100, 1_000_000, 13     # -s 100m => k = 13
+
+
+def timed(fn, steps, fence):
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    fence()
+    return (time.perf_counter() - t0) / steps
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--windows", type=int, default=N_WINDOWS, help="windows per GPU (default: the C2 configuration)")
+    ap.add_argument("--workload", choices=["auto", "c2", "c3"], default="auto",
+                    help="auto: C2 (BASELINE configs[1]) on one GPU, C3 strong scaling (configs[2]) on several")
+    ap.add_argument("--windows", type=int, default=N_WINDOWS, help="windows per GPU of the C2 workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip value_at_1pct and host_api")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from hypo_amd import capi, sim
+    from hypo_amd import dist as hd
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    workload = args.workload if args.workload != "auto" else ("c2" if world == 1 else "c3")
+    strong = workload == "c3"
     # Debug knobs for a box with fewer GPUs than ranks (never set by the driver): all ranks on device 0 and a gloo
     # group exercise the whole N>1 code path except RCCL itself.
     share = os.environ.get("HYPO_BENCH_SHARE_GPU") == "1"
@@ -121,22 +144,52 @@ def main():
     gpu = capi.HypoGpu(dev_index)
 
     # ---- synthetic workload, resident in HBM ----------------------------------------------------------
-    batch = sim.window_batch(args.windows, seed=1000 + rank)
-    codes, packed4 = sim.random_contig(CONTIG_BASES, seed=2000 + rank, n_frac=0.0)
-    bits = sim.solid_bitset(codes, K)
+    imbalance = None
+    if strong:
+        # the same batch on every rank (fixed seed); each rank keeps its cost-balanced contiguous range
+        n_total = int(os.environ.get("HYPO_BENCH_C3_WINDOWS", C3_REPLICAS * N_WINDOWS))
+        whole = sim.window_batch(n_total, seed=3000)
+        costs = hd.window_costs(whole.windows, whole.arm_len)
+        ranges = hd.shard_contiguous(costs, world)
+        b, e = ranges[rank]
+        batch = hd.take_windows(whole, b, e, compact=True)
+        per = np.array([costs[x:y].sum() for x, y in ranges])
+        imbalance = {"planned_cost_max_over_mean": round(float(per.max() / per.mean()), 4)}
+        del whole, costs
+        contig_bases, k = C3_CONTIG_BASES, C3_K
+        my_contigs = [c for c in range(C3_CONTIGS) if c % world == rank]
+    else:
+        batch = sim.window_batch(args.windows, seed=1000 + rank)
+        contig_bases, k = CONTIG_BASES, K
+        my_contigs = [rank]
+    scans = []
+    bits = None
+    for c in my_contigs:                                  # one bit set per run, uploaded once per rank
+        codes, packed4 = sim.random_contig(contig_bases, seed=2000 + c, n_frac=0.0)
+        if bits is None:
+            bits = sim.solid_bitset(codes, k) if not strong else None
+            if bits is None:                              # C3: a random set of the right size and density (the scan's cost does not depend on which k-mers are solid)
+                rb = np.random.default_rng(7)
+                bits = rb.integers(0, 1 << 63, size=(1 << (2 * k)) // 64, dtype=np.int64).view(np.uint64) & \
+                    rb.integers(0, 1 << 63, size=(1 << (2 * k)) // 64, dtype=np.int64).view(np.uint64)
+            first = (packed4, codes.size)
+        scans.append(gpu.device_scan(packed4, contig_bases, k, bits, kids_cap=contig_bases // 2))
+    for s in scans[1:]:
+        s.bits = scans[0].bits                            # one device copy of the set
     off = batch.slot_layout()
     db = gpu.device_batch(batch, off=off)
-    ds = gpu.device_scan(packed4, CONTIG_BASES, K, bits)
+    ds = scans[0]
+    packed4 = first[0]
     n_w = batch.n_windows
 
     # exchange step: sizes agreed once (all_reduce MAX), then one fixed-size all-gather per batch from preallocated buffers
     if world > 1:
-        from hypo_amd import dist as hd
         max_bytes, max_windows = hd.agree_sizes(int(off[-1]), n_w, dev)
         exchange = hd.ConsensusExchange(max_bytes, max_windows, dev)
 
     def step():
-        ds.run()
+        for s in scans:
+            s.run()
         db.run()
         if world > 1:
             exchange.gather(db.bases, db.len[:n_w])
@@ -149,13 +202,14 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    gpu.profile_begin(min(256, 2 * args.steps))
+    gpu.profile_begin(min(256, (1 + len(scans)) * args.steps))
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    my_dt = dt
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -183,7 +237,7 @@ def main():
                 if not (sb[a:a + l] == ob[a:a + l]).all():
                     ok = False
                     break
-        ow, okids, orank, ons = orc.solid_scan(packed4, CONTIG_BASES, K, bits)
+        ow, okids, orank, ons = orc.solid_scan(packed4, contig_bases, k, bits, kids_cap=contig_bases // 2)
         ok = ok and ons == n_solid and bool((ow == words).all()) and bool((okids == kids).all())
         parity = "bit-exact vs oracle (4000 windows + full scan)" if ok else "MISMATCH"
         if not ok:
@@ -207,21 +261,54 @@ def main():
         tr = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tr):
             try:
-                j = json.load(open(tr)).get(roofline["kernel"], {})      # one entry per size-class kernel
+                j = json.load(open(tr)).get(roofline["kernel"], {})      # one entry per size-class kernel (profiles/make_traffic_json.py)
                 if j.get("windows") == roofline["windows_per_launch"]:
                     roofline["traffic"] = j.get("hbm_bytes_per_launch")
+                    # VALU issue of the same launch from the PMC pass: instructions, and the share of the chip's VALU issue
+                    # slots (256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles per SIMD, MI355X_MICROARCH.md) they
+                    # fill over the measured kernel time
+                    if j.get("valu_insts"):
+                        slots = 256 * 4 * (float(cls_ms[dom]) * 1e-3) * 2.4e9 / 2.0
+                        roofline["valu"] = {"insts": int(j["valu_insts"]), "salu_insts": int(j.get("salu_insts", 0)),
+                                            "issue_frac": round(j["valu_insts"] / slots, 4), "source": j.get("source", "profiles/")}
             except Exception:
                 pass
         poa_ms_total = float(ms[:, -1].mean())                    # whole POA call (the class kernels overlap)
         extra["poa_kernels_ms"] = [round(float(x), 4) for x in ms.mean(axis=0)]
-        extra["gcups"] = round(stats["dp_cells"] / (poa_ms_total * 1e-3) / 1e9, 3)
+        extra["gcups"] = round(stats["dp_cells"] / (poa_ms_total * 1e-3) / 1e9, 3)     # reference-equivalent cells
+        # cells the device really pushed through row loops: score rows + one-bit threading rows (failed attempts included)
+        extra["gcups_executed"] = round((stats["cells_scored"] + stats["cells_threaded"]) / (poa_ms_total * 1e-3) / 1e9, 3)
+        na = max(stats["n_alignments"], 1)
+        extra["alignments"] = {"total": stats["n_alignments"], "reused": round(stats["n_reused"] / na, 4),
+                               "threaded": round(stats["n_threaded"] / na, 4),
+                               "scored": round(1.0 - (stats["n_reused"] + stats["n_threaded"]) / na, 4),
+                               "cells_scored": stats["cells_scored"], "cells_threaded": stats["cells_threaded"]}
         extra["windows_per_class"] = stats["n_class"]
     if scan_calls:
         sm = np.array(scan_calls, dtype=np.float64).mean(axis=0)
         # A_scan = ceil(L/2) + ceil(L/8) + 8*n_solid + min(4^k/8, 32*(L-k+1))
-        a_scan = (CONTIG_BASES + 1) // 2 + (CONTIG_BASES + 7) // 8 + 8 * n_solid + min((1 << (2 * K)) // 8, 32 * (CONTIG_BASES - K + 1))
+        a_scan = (contig_bases + 1) // 2 + (contig_bases + 7) // 8 + 8 * n_solid + min((1 << (2 * k)) // 8, 32 * (contig_bases - k + 1))
         extra["scan_kernels_ms"] = [round(float(x), 4) for x in sm]
         extra["scan_gbs"] = round(a_scan / (float(sm.sum()) * 1e-3) / 1e9, 2)
+
+    # ---- the same POA call on noisier reads and through the host-pointer entry point (N = 1 only, a few calls each) ----
+    if rank == 0 and world == 1 and not args.no_extras:
+        nb = sim.window_batch(args.windows, seed=1000, read_sub=0.01)
+        ndb = gpu.device_batch(nb)
+        for _ in range(2):
+            ndb.run()
+        t1 = timed(ndb.run, 5, lambda: torch.cuda.synchronize(dev))
+        nst = ndb.stats()
+        extra["value_at_1pct"] = {"value": round(nb.n_windows / t1, 1), "unit": "windows/s", "ms_per_call": round(t1 * 1e3, 3),
+                                  "requeued_windows": nst["n_escalated"], "failed": nst["n_failed"],
+                                  "workload": "the C2 batch shape with 1 % substitutions in the reads instead of 0.2 %, POA call only"}
+        del ndb
+        hoff = batch.slot_layout()
+        for _ in range(2):
+            gpu.poa_batch(batch, off=hoff)
+        t2 = timed(lambda: gpu.poa_batch(batch, off=hoff), 5, lambda: None)
+        extra["host_api"] = {"value": round(n_w / t2, 1), "unit": "windows/s", "ms_per_call": round(t2 * 1e3, 3),
+                             "note": "hypo_gpu_poa_batch with host pointers: H2D of the batch + kernels + D2H of the consensus, PCIe-inclusive"}
 
     # ---- CPU baseline: the bit-exact port of the reference's OpenMP/spoa path on this box -----------------
     cpu = None
@@ -229,14 +316,22 @@ def main():
         import oracle
         orc = oracle.Oracle()
         thr = orc.num_threads()
+        cb, coff, cln, cst, cbases = batch, off, ln, st, bases
+        sample_note = f"the same {n_w}-window batch"
+        if n_w > 200000:                                   # C3 on one GPU: a bounded sample of the job for the CPU legs
+            cb = hd.take_windows(batch, 0, N_WINDOWS, compact=True)
+            coff = off[:N_WINDOWS + 1]
+            cln, cst = ln[:N_WINDOWS], st[:N_WINDOWS]
+            sample_note = f"the first {N_WINDOWS} windows of the batch"
+        cn = cb.n_windows
         best = None
         for _ in range(3):
             c0 = time.perf_counter()
-            orc.poa_batch_raw(batch, off=off, n_threads=thr)
+            orc.poa_batch_raw(cb, off=coff, n_threads=thr)
             c1 = time.perf_counter() - c0
             best = c1 if best is None or c1 < best else best
-        cpu = {"value": round(n_w / best, 1), "unit": "windows/s", "cores": thr, "kind": "port",
-               "sample": f"the same {n_w}-window batch, POA only, OpenMP schedule(static,1), best of 3"}
+        cpu = {"value": round(cn / best, 1), "unit": "windows/s", "cores": thr, "kind": "port",
+               "sample": f"{sample_note}, POA only, OpenMP schedule(static,1), best of 3"}
         # The real reference classes (hypo::Window + its spoa, compiled from /root/reference in the build container into
         # oracle/_ref/libhyporef.so, which travels prebuilt): the reference's own POA loop on the same batch.  When it is
         # there it is the baseline of record (kind "reference"), the port's rate stays beside it, and the device results of
@@ -246,21 +341,21 @@ def main():
                 ref = oracle.Ref()
                 rbest, rout = None, None
                 for _ in range(2):
-                    rb, _, rln, rst, sec = ref.poa_batch_raw(batch, off=off, n_threads=thr)
+                    rb, _, rln, rst, sec = ref.poa_batch_raw(cb, off=coff, n_threads=thr)
                     if rbest is None or sec < rbest:
                         rbest, rout = sec, (rb, rln, rst)
-                same = bool((rout[1] == ln).all() and (rout[2] == st).all())
+                same = bool((rout[1] == cln).all() and (rout[2] == cst).all())
                 if same:
-                    o64, l64 = off[:-1].astype(np.int64), ln.astype(np.int64)
+                    o64, l64 = coff[:-1].astype(np.int64), cln.astype(np.int64)
                     idx = np.repeat(o64, l64) + (np.arange(int(l64.sum()), dtype=np.int64) - np.repeat(np.cumsum(l64) - l64, l64))
-                    same = bool((rout[0][idx] == bases[idx]).all())
+                    same = bool((rout[0][idx] == cbases[idx]).all())
                 if not same:
                     raise SystemExit("bench: HIP results differ from the real reference — refusing to report a number")
                 extra["cpu_port"] = cpu
-                cpu = {"value": round(n_w / rbest, 1), "unit": "windows/s", "cores": thr, "kind": "reference",
-                       "sample": f"the same {n_w}-window batch through the reference's own Window::generate_consensus loop "
+                cpu = {"value": round(cn / rbest, 1), "unit": "windows/s", "cores": thr, "kind": "reference",
+                       "sample": f"{sample_note} through the reference's own Window::generate_consensus loop "
                                  "(OpenMP schedule(static,1), consensus loop only, best of 2)"}
-                parity = (parity or "") + f"; timed batch bit-exact vs the real reference classes ({n_w} windows)"
+                parity = (parity or "") + f"; timed batch bit-exact vs the real reference classes ({cn} windows)"
             except (OSError, RuntimeError) as ex:            # stale or unloadable prebuilt library: keep the port
                 extra["cpu_reference_error"] = str(ex)[:200]
 
@@ -268,24 +363,44 @@ def main():
     # on the 5 Mbp / 30x C2 set regenerated by the committed generator (~20 s of Python); its FASTA must have the md5 the REAL
     # reference produced for these inputs (tests/golden/e2e_5m_s11.manifest.json).  Wall time = the run's own "Overall" timer, like the reference's.
     e2e = None
-    if rank == 0 and world == 1 and not args.no_e2e:
+    if rank == 0 and world == 1 and not args.no_e2e and not strong:
         e2e = end_to_end_leg()
 
-    total_windows = n_w * world * args.steps
-    value = total_windows / dt
+    if strong and world > 1:                               # per-rank imbalance of the measured step
+        tt = torch.tensor([my_dt], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        per_rank = np.array([float(x.item()) for x in allt])
+        imbalance["step_time_max_over_mean"] = round(float(per_rank.max() / per_rank.mean()), 4)
+    if world > 1:
+        nt = torch.tensor([n_w], dtype=torch.int64, device=dev)
+        dist.all_reduce(nt)
+        total_per_step = int(nt.item())
+    else:
+        total_per_step = n_w
+    value = total_per_step * args.steps / dt
+    total_bases = contig_bases * (C3_CONTIGS if strong else world)
     if rank == 0:
+        if strong:
+            wl = (f"C3: synthetic 100 Mbp contig set ({C3_CONTIGS} x 1 Mbp, k=13), 30x 150-bp short reads — ONE batch of {total_per_step} "
+                  f"C1-shaped windows cut into {world} cost-balanced contiguous range(s), solid-kmer scan of every contig + POA + "
+                  "all-gather of the consensus")
+        else:
+            wl = ("C2: E. coli-sized 5 Mbp draft, 30x 150-bp short reads, k=11 — solid-kmer scan + POA "
+                  f"of {n_w} C1-shaped windows per GPU (mean 38.5 bp, 18.7 arms)")
         out = {
             "metric": "polished windows/sec (whole node)", "value": round(value, 1), "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "int16", "data": "synthetic",   # exact int16 score rows (guarded; int32 in the catch-all class)
-            "config": {"workload": "C2: E. coli-sized 5 Mbp draft, 30x 150-bp short reads, k=11 — solid-kmer scan + POA "
-                                   f"of {n_w} C1-shaped windows per GPU (mean 38.5 bp, 18.7 arms)",
-                       "windows_per_gpu": n_w, "arms_per_gpu": batch.n_arms, "contig_bases": CONTIG_BASES, "k": K,
+            "config": {"workload": wl, "windows_total": total_per_step, "windows_this_rank": n_w, "arms_this_rank": batch.n_arms,
+                       "contig_bases": total_bases, "k": k,
                        "parallelism": f"window sharding x{world}" + (" + RCCL all-gather of consensus" if world > 1 else "")},
-            "mbp_per_s": round(CONTIG_BASES * world * args.steps / dt / 1e6, 2),
+            "mbp_per_s": round(total_bases * args.steps / dt / 1e6, 2),
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "e2e": e2e,
         }
+        if imbalance:
+            out["imbalance"] = imbalance
         out.update(extra)
         print(json.dumps(out))
     if world > 1:

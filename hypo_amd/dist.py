@@ -33,8 +33,11 @@ def shard_contiguous(costs: np.ndarray, world: int) -> List[Tuple[int, int]]:
     return [(int(cuts[r]), int(cuts[r + 1])) for r in range(world)]
 
 
-def take_windows(batch, begin: int, end: int):
-    """Sub-batch of windows [begin, end) sharing the parent's packed buffers (first_arm re-based)."""
+def take_windows(batch, begin: int, end: int, compact: bool = False):
+    """Sub-batch of windows [begin, end) (first_arm re-based).  compact=False shares the parent's packed buffers;
+    compact=True also cuts draft4 / arms2 down to the range's bytes and re-bases draft_off / arm_off (what a rank uploads
+    when one batch is sharded over several GPUs).  Assumes the layout the simulator and the host pipeline produce: windows,
+    arms and packed bytes in the same order."""
     from .batch import HostBatch
     w = batch.windows[begin:end].copy()
     if end > begin:
@@ -44,7 +47,19 @@ def take_windows(batch, begin: int, end: int):
     else:
         a0 = a1 = 0
     w["first_arm"] -= a0
-    return HostBatch(w, batch.draft4, batch.arm_off[a0:a1].copy(), batch.arm_len[a0:a1].copy(), batch.arms2)
+    arm_off, arm_len = batch.arm_off[a0:a1].copy(), batch.arm_len[a0:a1].copy()
+    if not compact or end <= begin:
+        return HostBatch(w, batch.draft4, arm_off, arm_len, batch.arms2)
+    d0 = int(w["draft_off"][0])
+    d1 = int(w["draft_off"][-1]) + (int(w["draft_len"][-1]) + 1) // 2
+    w["draft_off"] -= d0
+    if a1 > a0:
+        b0 = int(arm_off[0])
+        b1 = int(arm_off[-1]) + (int(arm_len[-1]) + 3) // 4
+        arm_off -= np.uint64(b0)
+    else:
+        b0 = b1 = 0
+    return HostBatch(w, batch.draft4[d0:d1].copy(), arm_off, arm_len, batch.arms2[b0:b1].copy())
 
 
 def gather_consensus(bases, lens, max_bytes: int, max_windows: int, group=None):
