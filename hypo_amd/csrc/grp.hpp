@@ -15,6 +15,7 @@
 
 #ifdef HYPO_EMU
 #define HD inline
+#define HD_NOINLINE inline
 #define HYPO_UNROLL
 #define HYPO_IN_VGPR(x) do { } while (0)
 #define HYPO_NO_IFCVT() do { } while (0)
@@ -22,6 +23,8 @@
 #else
 #include <hip/hip_runtime.h>
 #define HD __device__ __forceinline__
+// a real call: the callee's registers do not add to what the (huge) caller keeps alive
+#define HD_NOINLINE __device__ __attribute__((noinline))
 #define HYPO_UNROLL _Pragma("unroll")
 // keeps a group-uniform value in a vector register (the row loop runs out of scalar registers and the compiler would
 // otherwise park it in a VGPR lane and v_readlane it back on every use)
@@ -34,6 +37,8 @@
 #endif
 
 namespace hypo {
+
+struct alignas(16) uint4v { uint32_t x, y, z, w; };       // 16-byte store unit
 
 #ifdef HYPO_EMU
 // ---- emulator back end -------------------------------------------------------------------------

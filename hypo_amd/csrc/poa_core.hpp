@@ -48,7 +48,7 @@ namespace hypo {
 enum { MODE_NW = 1, MODE_LOV = 3, MODE_ROV = 4 };
 enum { C_A = 0, C_C = 1, C_G = 2, C_T = 3, C_N = 4, C_J = 5, C_O = 6, C_NONE = 7 };
 // Optional per-phase cycle accounting (diagnostic build only: make -C hypo_amd/csrc prof).
-enum { PH_LOAD = 0, PH_DP = 1, PH_TRACE = 2, PH_ADD = 3, PH_TOPO = 4, PH_CONS = 5, PH_OUT = 6, PH_META = 7, PH_N = 8 };
+enum { PH_LOAD = 0, PH_DP = 1, PH_TRACE = 2, PH_ADD = 3, PH_TOPO = 4, PH_CONS = 5, PH_OUT = 6, PH_META = 7, PH_EXACT = 8, PH_N = 9 };
 #if defined(HYPO_PHASE_TIMERS) && !defined(HYPO_EMU)
 #define HYPO_TICK(k) do { const uint64_t t1_ = (uint64_t)clock64(); tphase[k] += t1_ - tlast; tlast = t1_; } while (0)
 #define HYPO_TICK_RESET() do { tlast = (uint64_t)clock64(); } while (0)
@@ -92,6 +92,10 @@ struct PoaParamRef {
 // exact threading of sequences that spell a path (Poa::rows_exact); HYPO_EXACT=0 sends every alignment through the score rows
 #ifndef HYPO_EXACT
 #define HYPO_EXACT 1
+#endif
+// ... run by run (Poa::rows_exact_runs) instead of row by row (Poa::rows_exact, kept as the plain form of the same recurrence)
+#ifndef HYPO_EXACT_RUNS
+#define HYPO_EXACT_RUNS 1
 #endif
 // int16 score rows as packed pairs of columns (Poa::rows_pk); HYPO_PACKED=0 builds the one-column-per-register loop everywhere
 #ifndef HYPO_PACKED
@@ -235,7 +239,15 @@ struct Poa {
     int tb_steps; int tb_fv;
     int need_nodes;                                          // after RES_OVERFLOW of a SHORT window: projected node count (0 = unknown)
     bool last_changed;         // did the most recent add_alignment change the graph topology?
-    uint64_t cells, aligns, reused, rows_done, topo_runs, cons_serial, rows_slow, exact_tries, exact_hits, cells_scored, cells_exact;
+    // per-window counters (group-uniform; in the sub-wave classes every one of them costs a vector register, hence 32 bits and
+    // the diagnostic ones only in the diagnostic build or the emulator)
+    uint32_t cells, aligns, reused, exact_hits, cells_scored, cells_exact;
+#if defined(HYPO_PHASE_TIMERS) || defined(HYPO_EMU)
+#define HYPO_DIAG(x) do { x; } while (0)
+    uint32_t rows_done, topo_runs, cons_serial, rows_slow, exact_tries, rows_exact_n, rows_scored_n;
+#else
+#define HYPO_DIAG(x) do { } while (0)
+#endif
     uint64_t tphase[PH_N]; uint64_t tlast;
 
     // `fast`: the LDS slice of a hybrid class (ignored otherwise: one slice, LDS or HBM, holds everything)
@@ -259,7 +271,8 @@ struct Poa {
         ring1 = (score_t*)(HYB ? fast + Lay::fRing1 : mem + Lay::oRing);
         n_paths = 0; path_used = 0; head_first = 0;
         n_nodes = 0; L = 0; topo_dirty = false; meta_dirty = true; maxdelta = 0; tb_steps = 0; tb_fv = 0;
-        cells = 0; aligns = 0; reused = 0; rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; exact_hits = 0; cells_scored = 0; cells_exact = 0; last_changed = true;
+        cells = 0; aligns = 0; reused = 0; exact_hits = 0; cells_scored = 0; cells_exact = 0; last_changed = true;
+        HYPO_DIAG(rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; rows_exact_n = 0; rows_scored_n = 0);
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
         tlast = 0;
         HYPO_TICK_RESET();
@@ -623,9 +636,7 @@ struct Poa {
             }
             // ---- SLOW row ----
             HYPO_NO_IFCVT();
-#ifdef HYPO_PHASE_TIMERS
-            rows_slow += 1;
-#endif
+            HYPO_DIAG(rows_slow += 1);
             const int cd = meta_code(meta), k = meta_k(meta);
             const int p0 = meta_p0(meta);                    // 0 when k == 0 (virtual source row)
             const bool fastrow = p0 == i - 1;
@@ -885,6 +896,225 @@ struct Poa {
         return g.shfl((int)first, le);                       // -1: no perfect candidate
     }
 
+    // ---- the same threading, run by run ------------------------------------------------------------------------------------
+    // Between two SLOW rows the graph is a chain (every row's only predecessor is the row before it), and along a chain a
+    // perfect cell can only continue down its diagonal: (rank a, column b) -> (a + 1, b + 1) -> ...  A run of T such rows
+    // therefore needs no row loop: every perfect column of the row before the run (there are one or two of them: perfect paths
+    // are nearly unique) is extended by comparing the run's node letters with the sequence, 64 characters per step, lanes =
+    // positions along the diagonal.  kROV adds the diagonals that are born in column 0 of every row of the run (a suffix
+    // may start anywhere): all births are screened together on their first characters (lanes = births), the few that pass
+    // are checked like any other candidate.  SLOW rows (several predecessors, ring traffic, end-cell candidates of kNW /
+    // kROV) are computed exactly as in rows_exact().  The direction codes of chain rows are all DIR_FAST: the code area is
+    // filled with it once, SLOW rows store theirs.
+    HD int rows_exact_runs(int mode, int S, int R) {
+        constexpr int NP = CPL / 2;
+        const int j0 = CPL * g.lane;
+        P2 SQ[NP], P0[NP], LAST[NP];
+        HYPO_UNROLL
+        for (int q = 0; q < NP; ++q) {
+            const int j = j0 + 2 * q;
+            const int s0 = (j >= 1 && j <= L) ? (int)seq[j - 1] : (int)C_NONE;
+            const int s1 = (j + 1 <= L) ? (int)seq[j] : (int)C_NONE;
+            SQ[q] = pk_make(s0, s1);
+            P0[q] = pk_make(j == 0 ? 1 : 0, 0);              // virtual source row: only H[0][0] = 0 is perfect
+            LAST[q] = P0[q];
+        }
+        int vONE = pk_bits(pk_splat(1));
+        HYPO_IN_VGPR(vONE);
+        const P2 ONE = pk_from_bits(vONE);
+        const bool rov = mode == MODE_ROV, lov = mode == MODE_LOV;
+        const int col0 = (g.lane == 0 && rov) ? 1 : 0;      // kROV: column 0 is perfect in every row
+        const int le = L / CPL, ce = L % CPL;
+        const int ce_shift = 16 * (ce & 1);
+        unsigned first = 0xffffffffu;                        // first row (rank order) whose end-cell candidate is perfect
+        int wslotS = 0, scount = 0;
+        const int RS = R * S;
+        int nbreg = 0;
+        {   // every chain row's codes
+            const int bytes = (n_nodes * S) >> 1;
+            for (int o = g.lane * 16; o < bytes; o += GW * 16) *(uint4v*)(dir + o) = uint4v{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        }
+        auto load_pk = [&](int off, P2 (&out)[NP]) {
+            if (j0 < S) {
+                const PackP pk = *(const PackP*)(ring + off + j0);
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) out[q] = pk.v[q];
+            } else {
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) out[q] = pk_splat(0);
+            }
+        };
+        auto ring_back = [&](int back) -> int {
+            int ps = wslotS - back * S;
+            return ps < 0 ? ps + RS : ps;
+        };
+        // letters of ranks rank0.. against seq[s0..], `len` of them: length of the common prefix (all arguments group-uniform)
+        auto lcp = [&](int rank0, int s0, int len) -> int {
+            int done = 0;
+            while (done < len) {
+                const int u = done + g.lane;
+                const bool mis = u < len && (int)(rowmeta[rank0 + u] & 7u) != (int)seq[s0 + u];
+                const uint64_t b = g.ballot(mis);
+                if (b) return done + ctz64(b);
+                done += GW;
+            }
+            return len;
+        };
+        int r = 0;
+        while (r < n_nodes) {
+            // ---- next SLOW row ----
+            int rs = r;
+            for (;;) {
+                const int x = rs + g.lane;
+                const bool stop = x >= n_nodes || (rowmeta[x] & META_SLOW) != 0;
+                const uint64_t b = g.ballot(stop);
+                if (b) { rs += ctz64(b); break; }
+                rs += GW;
+            }
+            const int T = rs - r;                            // chain rows: ranks r .. rs - 1
+            if (T > 0) {
+                // perfect columns of rank r - 1 (LAST): low halves = even columns of the lanes' pairs, high halves = odd ones.  One
+                // column class at a time (runtime loop: the candidate code exists once).
+                P2 NEWV[NP];
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) NEWV[q] = pk_splat(0);
+                auto survivor = [&](int c) {                  // column c is perfect in rank rs - 1
+                    const int w = 1 << (16 * (c & 1));
+                    HYPO_UNROLL
+                    for (int q = 0; q < NP; ++q) if (g.lane == c / CPL && (c % CPL) / 2 == q) NEWV[q] = pk_from_bits(pk_bits(NEWV[q]) | w);
+                };
+                // a diagonal that starts below (rank a - 1, column b): ranks a.. against seq[b..]
+                auto extend = [&](int a, int b) {
+                    const int rows_left = rs - a, cols_left = L - b;
+                    const int len = rows_left < cols_left ? rows_left : cols_left;
+                    if (len <= 0) return;
+                    const int l = lcp(a, b, len);
+                    if (lov && cols_left <= rows_left && l >= cols_left) {       // reaches column L inside the run: an end-cell candidate
+                        const unsigned row = (unsigned)(a + cols_left);          // matrix row of rank a + cols_left - 1
+                        first = row < first ? row : first;
+                    }
+                    if (rows_left <= cols_left && l >= rows_left) survivor(b + rows_left);
+                };
+                for (int c = 0; c < CPL; ++c) {
+                    int w = pk_bits(LAST[0]);
+                    HYPO_UNROLL
+                    for (int q = 1; q < NP; ++q) if (c / 2 == q) w = pk_bits(LAST[q]);
+                    uint64_t m = g.ballot((((uint32_t)w >> (16 * (c & 1))) & 1u) != 0);
+                    while (m) {
+                        const int ln = ctz64(m);
+                        m &= m - 1;
+                        const int b = ln * CPL + c;
+                        if (b <= L && !(rov && b == 0)) { HYPO_NO_IFCVT(); extend(r, b); }          // kROV's column 0 is a birth, below
+                    }
+                }
+                if (rov) {
+                    // births: column 0 of ranks r - 1 .. rs - 2 is perfect, so a diagonal may start with rank a = r + t matched to
+                    // seq[0] for every t in [0, T).  Screen on up to 4 characters, lanes = births.
+                    for (int base = 0; base < T; base += GW) {
+                        const int t = base + g.lane;
+                        bool ok = t < T;
+                        for (int u = 0; u < 4 && u < L; ++u) {               // (not unrolled: register pressure)
+                            HYPO_NO_IFCVT();
+                            const bool in = ok && t + u < T;
+                            const int cdx = in ? (int)(rowmeta[r + t + u] & 7u) : 0;
+                            ok = ok && (!in || cdx == (int)seq[u]);
+                        }
+                        uint64_t m = g.ballot(ok);
+                        while (m) {
+                            const int ln = ctz64(m);
+                            m &= m - 1;
+                            extend(r + base + ln, 0);
+                        }
+                    }
+                }
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) LAST[q] = NEWV[q];
+                LAST[0] = pk_from_bits(pk_bits(LAST[0]) | col0);
+                r = rs;
+                g.sync();
+            }
+            if (r >= n_nodes) break;
+            // ---- SLOW row (as in rows_exact) ----
+            {
+                const int i = r + 1;
+                const uint32_t meta = (uint32_t)g.uniform((int)rowmeta[r]);
+                const int rowS = r * S;
+                const P2 CD = pk_from_bits((int)(meta & 0x00070007u));
+                const int k = meta_k(meta);
+                const int p0 = meta_p0(meta);
+                const bool fastrow = p0 == i - 1;
+                const int fastcode = fastrow ? (int)DIR_FAST : dir_diag(0);
+                P2 D[NP], cD[NP];
+                {
+                    P2 hp[NP];
+                    if (fastrow) { HYPO_UNROLL for (int q = 0; q < NP; ++q) hp[q] = LAST[q]; }
+                    else if (p0 == 0) { HYPO_UNROLL for (int q = 0; q < NP; ++q) hp[q] = P0[q]; }
+                    else load_pk(ring_back(meta_back0(meta)), hp);
+                    const int nb = nbreg = g.shfl_up1(pk_bits(hp[NP - 1]), nbreg);
+                    HYPO_UNROLL
+                    for (int q = 0; q < NP; ++q) D[q] = pk_shift_in(q ? hp[q - 1] : pk_from_bits(nb), hp[q]);
+                }
+                if (k > 1) {
+                    P2 pD[NP];
+                    HYPO_UNROLL
+                    for (int q = 0; q < NP; ++q) pD[q] = pk_splat(0);
+                    for (int p = 1; p < k; ++p) {
+                        P2 hp[NP];
+                        const int back = p == 1 ? meta_back1(meta) : scount - (int)sidx[g.uniform(pred_row(r, p)) - 1];
+                        load_pk(ring_back(back), hp);
+                        const int nb = nbreg = g.shfl_up1(pk_bits(hp[NP - 1]), nbreg);
+                        const P2 PP = pk_splat(p);
+                        HYPO_UNROLL
+                        for (int q = 0; q < NP; ++q) {
+                            const P2 d = pk_shift_in(q ? hp[q - 1] : pk_from_bits(nb), hp[q]);
+                            const P2 nd = pk_from_bits(pk_bits(D[q]) | pk_bits(d));
+                            pD[q] = pk_mad(pk_sub(nd, D[q]), pk_sub(PP, pD[q]), pD[q]);
+                            D[q] = nd;
+                        }
+                    }
+                    const P2 FC = pk_splat(fastcode);
+                    HYPO_UNROLL
+                    for (int q = 0; q < NP; ++q) cD[q] = pk_mad(pk_sub(ONE, pk_minu(pD[q], ONE)), FC, pD[q]);
+                } else {
+                    HYPO_UNROLL
+                    for (int q = 0; q < NP; ++q) cD[q] = pk_splat(fastcode);
+                }
+                P2 v[NP];
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) v[q] = pk_from_bits(pk_bits(D[q]) & ~pk_bits(pk_minu(pk_xor(SQ[q], CD), ONE)));
+                v[0] = pk_from_bits(pk_bits(v[0]) | col0);
+                if (j0 < S) {
+                    uint32_t codes = 0;
+                    PackP pk;
+                    HYPO_UNROLL
+                    for (int q = 0; q < NP; ++q) {
+                        const uint32_t b = (uint32_t)pk_bits(cD[q]);
+                        codes |= ((b | (b >> 12)) & 0xffu) << (8 * q);
+                        pk.v[q] = v[q];
+                    }
+                    uint8_t* dst = dir + (rowS >> 1) + (j0 >> 1);
+                    if (NP == 1) *dst = (uint8_t)codes;
+                    else if (NP == 2) *(uint16_t*)dst = (uint16_t)codes;
+                    else *(uint32_t*)dst = codes;
+                    if (meta & META_SAVE) *(PackP*)(ring + wslotS + j0) = pk;
+                }
+                if (meta & META_SAVE) { scount += 1; wslotS = wslotS + S == RS ? 0 : wslotS + S; }
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) LAST[q] = v[q];
+                if (lov || meta_sink(meta)) {
+                    int w = pk_bits(v[0]);
+                    HYPO_UNROLL
+                    for (int q = 1; q < NP; ++q) if (ce / 2 == q) w = pk_bits(v[q]);
+                    const unsigned hit = (unsigned)g.shfl((int)(((unsigned)w >> ce_shift) & 1u), le);
+                    if (hit && (unsigned)i < first) first = (unsigned)i;
+                }
+                ++r;
+                g.sync();
+            }
+        }
+        return (int)first;                                   // group-uniform; -1: no perfect candidate
+    }
+
     // [tb_fv, L) and tb_steps (number of traceback steps; 0 = "empty alignment").
     HD int align(int mode, int m, int n, int gp) {
         tb_steps = 0; tb_fv = L;
@@ -903,20 +1133,21 @@ struct Poa {
         if (meta_dirty) { build_rowmeta(); HYPO_TICK(PH_META); }
         const int R = g.uniform(Cfg::RINGCELLS / S);        // ring rows; row i can still see rows i-R .. i-1
         if (R < maxdelta + 1 || R < 1) return RES_OVERFLOW;
-        cells += (uint64_t)(n_nodes + 1) * W; aligns += 1; rows_done += (uint64_t)n_nodes;
+        cells += (uint32_t)((n_nodes + 1) * W); aligns += 1; HYPO_DIAG(rows_done += (uint32_t)n_nodes);
 
         int best_i = -1;
         if constexpr (PK) {
             // a sequence that spells a path of the graph (most reads do) is threaded without scores; what spells none goes
             // through the score rows
             if (HYPO_EXACT && m > 0 && n < m && gp < 0) {
-                best_i = rows_exact(mode, S, R);
-                exact_tries += 1; cells_exact += (uint64_t)(n_nodes + 1) * W;
+                best_i = HYPO_EXACT_RUNS ? rows_exact_runs(mode, S, R) : rows_exact(mode, S, R);
+                HYPO_TICK(PH_EXACT);
+                cells_exact += (uint32_t)((n_nodes + 1) * W); HYPO_DIAG(exact_tries += 1; rows_exact_n += (uint32_t)n_nodes);
                 if (best_i > 0) exact_hits += 1;
             }
-            if (best_i <= 0) { best_i = rows_pk(mode, m, n, gp, S, R); cells_scored += (uint64_t)(n_nodes + 1) * W; }
+            if (best_i <= 0) { best_i = rows_pk(mode, m, n, gp, S, R); cells_scored += (uint32_t)((n_nodes + 1) * W); HYPO_DIAG(rows_scored_n += (uint32_t)n_nodes); }
         } else {
-        cells_scored += (uint64_t)(n_nodes + 1) * W;
+        cells_scored += (uint32_t)((n_nodes + 1) * W);
         HYPO_IN_VGPR(m); HYPO_IN_VGPR(n); HYPO_IN_VGPR(gp);
         const int j0 = CPL * g.lane;
         int sq[CPL];                                        // sq[c] = code of seq[j-1] for column j = j0+c
@@ -1377,7 +1608,7 @@ struct Poa {
         rc = add_alignment();
         HYPO_TICK(PH_ADD);
         if (rc != RES_OK) return rc;
-        if (topo_dirty) { rc = toposort(); topo_runs += 1; HYPO_TICK(PH_TOPO); }
+        if (topo_dirty) { rc = toposort(); HYPO_DIAG(topo_runs += 1); HYPO_TICK(PH_TOPO); }
         return rc;
     }
 
@@ -1469,7 +1700,7 @@ struct Poa {
         if (FAST_CONS) {
             const int fl = consensus_fast(path_out);
             if (fl != CONS_SERIAL) return fl;
-            cons_serial += 1;
+            HYPO_DIAG(cons_serial += 1);
         }
         int32_t* score = (int32_t*)ring;                   // by node id
         int16_t* pred = (int16_t*)(score + NMAX);
@@ -1601,7 +1832,7 @@ struct Poa {
         if ((rc = add_alignment()) != RES_OK) return rc;
         if ((rc = record_path(tb_steps == 0 ? L : tb_fv)) != RES_OK) return rc;   // before toposort: its stack aliases posnode
         HYPO_TICK(PH_ADD);
-        if (topo_dirty) { rc = toposort(); topo_runs += 1; HYPO_TICK(PH_TOPO); }
+        if (topo_dirty) { rc = toposort(); HYPO_DIAG(topo_runs += 1); HYPO_TICK(PH_TOPO); }
         return rc;
     }
     HD int run_long(uint32_t w, const HypoWindow& W) {
@@ -1629,7 +1860,7 @@ struct Poa {
                     int c = 0;
                     while (s < n_seq && same_as_previous(s)) { ++c; ++s; }
                     if (c) {
-                        cells += (uint64_t)c * (uint64_t)(n_nodes + 1) * (L + 1); aligns += c; reused += c;
+                        cells += (uint32_t)(c * (n_nodes + 1) * (L + 1)); aligns += c; reused += c;
                         if ((rc = readd_alignment(c)) != RES_OK) return rc;
                         if (g.lane == 0) pathmult[n_paths - 1] = (uint16_t)(pathmult[n_paths - 1] + c);
                         g.sync();
@@ -1740,7 +1971,7 @@ struct Poa {
                 int c = 0;
                 while (s < n_seq && same_as_previous(s)) { ++c; ++s; }
                 if (c) {
-                    cells += (uint64_t)c * (uint64_t)(n_nodes + 1) * (L + 1); aligns += c; reused += c;   // work the reference does
+                    cells += (uint32_t)(c * (n_nodes + 1) * (L + 1)); aligns += c; reused += c;   // work the reference does
                     if ((rc = readd_alignment(c)) != RES_OK) return project(rc);
                     HYPO_TICK(PH_ADD);
                     if (s >= n_seq) break;
@@ -1771,7 +2002,8 @@ struct Poa {
     // Window::generate_consensus (src/Window.cpp:44-61)
     HD int run(uint32_t w) {
         // the object outlives the window (one per persistent group): per-window counters and flags start over here
-        cells = 0; aligns = 0; reused = 0; rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; exact_hits = 0; cells_scored = 0; cells_exact = 0; last_changed = true;
+        cells = 0; aligns = 0; reused = 0; exact_hits = 0; cells_scored = 0; cells_exact = 0; last_changed = true;
+        HYPO_DIAG(rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; rows_exact_n = 0; rows_scored_n = 0);
         n_paths = 0; path_used = 0; head_first = 0; L = 0; maxdelta = 0; tb_steps = 0; tb_fv = 0; need_nodes = 0;
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
         HYPO_TICK_RESET();

@@ -169,11 +169,14 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through t
     const int cls = fresh(ka)->cls;
     const uint32_t count = *fresh(ka)->bound;   // queue slots [.., *bound) are final when this launch starts
     const PoaParamRef P{&ka->P};
-    uint64_t cells = 0, aligns = 0, abytes = 0, n_reused = 0, n_thr = 0, c_scored = 0, c_thr = 0;
+    // per-wave totals, flushed once at exit.  The LDS classes keep them in 32 bits (a wave of those sees at most a few thousand
+    // windows of < 1 M cells; in the sub-wave classes every group-uniform value is a vector register per lane)
+    typedef typename std::conditional<USE_LDS, uint32_t, uint64_t>::type acc_t;
+    acc_t cells = 0, aligns = 0, abytes = 0, n_reused = 0, n_thr = 0, c_scored = 0, c_thr = 0;
     uint32_t n_ok = 0, n_esc = 0, n_fail = 0;
 #ifdef HYPO_PHASE_TIMERS
-    uint64_t tph[PH_N] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tph[PH_N] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t dbg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const uint64_t tstart = (uint64_t)clock64();
 #endif
     // what happens to a window once Poa::run / step has returned something other than RES_CONTINUE
@@ -182,14 +185,14 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through t
         c_scored += poa.cells_scored; c_thr += poa.cells_exact;                // executed work, finished or not
 #ifdef HYPO_PHASE_TIMERS
         for (int i = 0; i < PH_N; ++i) tph[i] += poa.tphase[i];
-        dbg[0] += poa.rows_done; dbg[1] += poa.aligns - poa.reused; dbg[2] += poa.reused; dbg[3] += poa.topo_runs; dbg[4] += poa.cons_serial; dbg[5] += poa.rows_slow; dbg[6] += poa.exact_tries; dbg[7] += poa.exact_hits;
+        dbg[0] += poa.rows_done; dbg[1] += poa.aligns - poa.reused; dbg[2] += poa.reused; dbg[3] += poa.topo_runs; dbg[4] += poa.cons_serial; dbg[5] += poa.rows_slow; dbg[6] += poa.exact_tries; dbg[7] += poa.exact_hits; dbg[8] += poa.rows_exact_n; dbg[9] += poa.rows_scored_n;
 #endif
         if (rc == RES_OK) {
             ++n_ok;
             if (g.lane == 0) {                                  // algorithmic bytes, SURVEY.md 8(d)
                 const HypoWindow W = P->windows[w];
                 const uint32_t narm = W.n_internal + W.n_prefix + W.n_suffix;
-                uint64_t a = (W.draft_len + 1) / 2 + 16 + 8 * (1 + (uint64_t)narm) + P->out_len[w];
+                acc_t a = (acc_t)((W.draft_len + 1) / 2 + 16 + 8 * (1 + narm) + P->out_len[w]);
                 const uint32_t* alen = P->arm_len;
                 for (uint32_t t = 0; t < narm; ++t) a += (alen[W.first_arm + t] + 3) / 4;
                 abytes += a;
@@ -253,7 +256,7 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through t
         for (int i = 0; i < PH_N; ++i) atomicAdd(&ph[i], (unsigned long long)tph[i]);
         atomicAdd(&ph[PH_N], (unsigned long long)((uint64_t)clock64() - tstart));                // wave lifetime
         atomicAdd(&ph[PH_N + 1], 1ull);                                                           // waves
-        for (int i = 0; i < 8; ++i) atomicAdd(&ph[PH_N + 2 + i], (unsigned long long)dbg[i]);      // rows, real alignments, reused, toposorts, serial consensus passes, slow rows, exact tries / hits
+        for (int i = 0; i < 10; ++i) atomicAdd(&ph[PH_N + 2 + i], (unsigned long long)dbg[i]);      // rows, real alignments, reused, toposorts, serial consensus passes, slow rows, exact tries / hits
 #endif
     }
 }
@@ -393,9 +396,10 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
     hipStream_t* const aux = A->aux;
     hipEvent_t* const join_ev = A->join_ev;
     hipEvent_t& fork_ev = A->fork_ev;
-    // waves per CU of the three concurrent kernels.  Swept on C2 (ms per call): {4,4,6} 3.89, {4,5,6} 3.94, {3,4,6} 4.15, {5,4,6} 4.19,
-    // {4,4,5} 4.49, {4,4,7} 4.34 with two class-0 groups per wave; {3,4,6} 4.08 with four.  Class 0 is set below.
-    int caps[kNumPoaClasses] = {4, 4, 6, 0, 0, 0};
+    // waves per CU of the three concurrent kernels (they share the CU's 160 KB of LDS, which is what bounds residency).  Swept on C2
+    // with the round-2 kernels (ms per call, profiles/diag/caps_sweep.sh): {5,5,5} 3.29, {6,6,6} 3.31, {4,6,5} 3.47, {5,5,6} 3.52,
+    // {4,4,6} 3.69 (the round-1 optimum), {3,5,6} 3.80.  Class 0 is set below.
+    int caps[kNumPoaClasses] = {5, 5, 5, 0, 0, 0};
     if (const char* cs = getenv("HYPO_POA_CAPS")) sscanf(cs, "%d,%d,%d,%d,%d", &caps[0], &caps[1], &caps[2], &caps[3], &caps[4]);
     const char* seq_env = getenv("HYPO_POA_SEQUENTIAL");
     const bool sequential = seq_env && atoi(seq_env) > 0;
@@ -423,7 +427,7 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
         const uint64_t lds_windows = (uint64_t)planned_host[0] + planned_host[1] + planned_host[2];
         bool four_groups = (uint64_t)planned_host[0] * 100 > lds_windows * 85;
         if (const char* g0 = getenv("HYPO_POA_CLASS0")) four_groups = atoi(g0) == 16;      // 16 | 32: lanes per group (tests)
-        if (!getenv("HYPO_POA_CAPS")) caps[0] = four_groups ? 6 : 4;
+        if (!getenv("HYPO_POA_CAPS")) caps[0] = four_groups ? 6 : 5;
         (void)hipEventRecord(fork_ev, stream);
         (void)hipStreamWaitEvent(aux[0], fork_ev, 0);
         (void)hipStreamWaitEvent(aux[1], fork_ev, 0);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-phase cycle breakdown of the POA kernel (diagnostic library libhypo_gpu_prof.so, built with
--DHYPO_PHASE_TIMERS: s_memtime deltas accumulated per wave).  usage: phase_profile.py [n_windows]"""
+-DHYPO_PHASE_TIMERS: s_memtime deltas accumulated per wave).  usage: phase_profile.py [n_windows] [read_sub]      (HYPO_POA_SEQUENTIAL=1: one size class at a time)"""
 import os
 import sys
 
@@ -11,13 +11,16 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from hypo_amd import capi, sim  # noqa: E402
 
-NAMES = ["load_seq", "dp_rows", "traceback", "add_alignment", "toposort", "consensus", "output", "rowmeta", "wave_lifetime", "waves"]
+NAMES = ["load_seq", "score_rows", "traceback", "add_alignment", "toposort", "consensus", "output", "rowmeta", "exact_rows", "wave_lifetime", "waves"]
+NP = 9      # phases; then lifetime, waves, 10 counters (poa_kernel.hip)
 
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 97078
     gpu = capi.HypoGpu(0, path=os.path.join(ROOT, "hypo_amd", "_build", "libhypo_gpu_prof.so"))
-    b = sim.window_batch(n, seed=1000)
+    sub = float(sys.argv[2]) if len(sys.argv) > 2 else 0.002
+    b = sim.window_batch(n, seed=1000, read_sub=sub)
+    print(f"# {n} windows, read_sub={sub}, {'sequential' if os.environ.get('HYPO_POA_SEQUENTIAL') else 'concurrent'} schedule")
     db = gpu.device_batch(b)
     for _ in range(2):
         db.run()
@@ -26,17 +29,19 @@ def main():
     ph = db.workspace[512:512 + 8 * 24 * 8].cpu().numpy().view(np.uint64).reshape(8, 24)
     print("windows per class", st["n_class"], "escalated", st["n_escalated"])
     for c in range(8):
-        if ph[c, 9] == 0 or st['n_class'][c] == 0:
+        if ph[c, NP + 1] == 0 or st['n_class'][c] == 0:
             continue
-        tot = float(ph[c, :8].sum())
-        life = float(ph[c, 8])
-        print(f"class {c}: waves={int(ph[c, 9])} mean wave lifetime={life / ph[c, 9] / 1e3:.1f} kcycles "
+        tot = float(ph[c, :NP].sum())
+        life = float(ph[c, NP])
+        D = NP + 2
+        print(f"class {c}: waves={int(ph[c, NP + 1])} mean wave lifetime={life / ph[c, NP + 1] / 1e3:.1f} kcycles "
               f"accounted={100 * tot / life:.1f}%  cycles/window={life / max(st['n_class'][c], 1) / 1e3:.1f}k")
         nw = max(st['n_class'][c], 1)
-        print(f"    per window: DP rows={ph[c, 10] / nw:.1f} real alignments={ph[c, 11] / nw:.2f} reused={ph[c, 12] / nw:.2f} "
-              f"toposorts={ph[c, 13] / nw:.2f} serial consensus={ph[c, 14] / nw:.3f}; dp cycles/row={ph[c, 1] / max(ph[c, 10], 1):.0f}; "
-              f"slow rows={100 * ph[c, 15] / max(ph[c, 10], 1):.1f}%; exact threading {ph[c, 17] / nw:.2f} of {ph[c, 16] / nw:.2f} tries")
-        for i in range(8):
+        print(f"    per window: rows={ph[c, D] / nw:.1f} real alignments={ph[c, D + 1] / nw:.2f} reused={ph[c, D + 2] / nw:.2f} "
+              f"toposorts={ph[c, D + 3] / nw:.2f} serial consensus={ph[c, D + 4] / nw:.3f}; exact threading {ph[c, D + 7] / nw:.2f} of {ph[c, D + 6] / nw:.2f} tries")
+        print(f"    score rows: {ph[c, D + 9] / nw:.1f} per window at {ph[c, 1] / max(ph[c, D + 9], 1):.0f} cycles/row ({100 * ph[c, D + 5] / max(ph[c, D + 9], 1):.1f}% slow-path rows)   "
+              f"exact rows: {ph[c, D + 8] / nw:.1f} per window at {ph[c, NP - 1] / max(ph[c, D + 8], 1):.0f} cycles/row")
+        for i in range(NP):
             print(f"    {NAMES[i]:14s} {100 * ph[c, i] / tot:6.2f}%   {ph[c, i] / max(st['n_class'][c], 1) / 1e3:9.2f} kcycles/window")
 
 

@@ -109,6 +109,8 @@ void run_group(Sched& s, int gw, void (*body)(int, void*), void* arg) {
     for (int l = 0; l < gw; ++l) if (!s.done[l]) { fprintf(stderr, "[emu] lane %d did not finish\n", l); abort(); }
 }
 
+uint64_t g_exact[3] = {0, 0, 0};      // exact-threading attempts / successes / reused alignments since the last emu_exact_stats
+
 template <class Cfg>
 struct Job {
     hypo::EmuGroup eg;
@@ -126,7 +128,7 @@ void lane_body(int lane, void* arg) {
     hypo::Grp<Cfg::GW> g{lane, &j->eg};
     hypo::Poa<Cfg> poa(g, hypo::PoaParamRef{j->P}, j->mem, j->fast);
     j->rc[lane] = poa.run(j->w);
-    if (lane == 0) { j->cells = poa.cells; j->aligns = poa.aligns; }
+    if (lane == 0) { j->cells = poa.cells; j->aligns = poa.aligns; g_exact[0] += poa.exact_tries; g_exact[1] += poa.exact_hits; g_exact[2] += poa.reused; }
 }
 
 template <class Cfg>
@@ -177,6 +179,8 @@ extern "C" int emu_poa_batch(const HypoScoreParams* sp, const HypoWindowBatch* i
         default: return -1;
     }
 }
+
+extern "C" void emu_exact_stats(uint64_t* out) { for (int i = 0; i < 3; ++i) { out[i] = g_exact[i]; g_exact[i] = 0; } }
 
 extern "C" int emu_class_bytes(int cfg_id) {
     switch (cfg_id) {
