@@ -235,7 +235,7 @@ struct Poa {
     id_t* pathnodes; uint32_t* pathoff; uint16_t *pathlen, *pathmult, *msa; uint32_t* dstcnt; uint8_t* consbuf; id_t* predrows; score_t* ring1;
     int n_paths, path_used, head_first;
     // group-uniform state
-    int n_nodes; int L; bool topo_dirty; bool meta_dirty; int maxdelta;
+    int n_nodes; int L; bool topo_dirty; bool meta_dirty; int maxdelta; int last_source;
     int tb_steps; int tb_fv;
     int need_nodes;                                          // after RES_OVERFLOW of a SHORT window: projected node count (0 = unknown)
     bool last_changed;         // did the most recent add_alignment change the graph topology?
@@ -270,7 +270,7 @@ struct Poa {
         predrows = (id_t*)(mem + Lay::oPredRows);
         ring1 = (score_t*)(HYB ? fast + Lay::fRing1 : mem + Lay::oRing);
         n_paths = 0; path_used = 0; head_first = 0;
-        n_nodes = 0; L = 0; topo_dirty = false; meta_dirty = true; maxdelta = 0; tb_steps = 0; tb_fv = 0;
+        n_nodes = 0; L = 0; topo_dirty = false; meta_dirty = true; maxdelta = 0; last_source = 0; tb_steps = 0; tb_fv = 0;
         cells = 0; aligns = 0; reused = 0; exact_hits = 0; cells_scored = 0; cells_exact = 0; last_changed = true;
         HYPO_DIAG(rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; rows_exact_n = 0; rows_scored_n = 0);
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
@@ -464,6 +464,10 @@ struct Poa {
                 else rowmeta[r] |= meta_backs(b0, b1);
             }
             maxdelta = g.reduce_max(mds);
+            // last rank without in-edges: behind it no new perfect path can start in kNW / kLOV (Poa::rows_exact_runs gives up early)
+            int ls = -1;
+            for (int r = g.lane; r < n_nodes; r += GW) if (meta_k(rowmeta[r]) == 0) ls = r;
+            last_source = g.reduce_max(ls);
             g.sync();
             return;
         }
@@ -930,6 +934,7 @@ struct Poa {
         int wslotS = 0, scount = 0;
         const int RS = R * S;
         int nbreg = 0;
+        uint32_t nzsaved = 0;                                // bit t: the row saved t saves ago holds a perfect cell (ring reads reach back <= 31 saves)
         {   // every chain row's codes
             const int bytes = (n_nodes * S) >> 1;
             for (int o = g.lane * 16; o < bytes; o += GW * 16) *(uint4v*)(dir + o) = uint4v{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
@@ -1027,11 +1032,17 @@ struct Poa {
                         }
                     }
                 }
+                bool any = false;
                 HYPO_UNROLL
-                for (int q = 0; q < NP; ++q) LAST[q] = NEWV[q];
+                for (int q = 0; q < NP; ++q) { LAST[q] = NEWV[q]; any = any || pk_bits(NEWV[q]) != 0; }
                 LAST[0] = pk_from_bits(pk_bits(LAST[0]) | col0);
                 r = rs;
                 g.sync();
+                // Nothing perfect is left (no cell in this row, none in a ring row a later row could still read) and no path can
+                // start further down (kNW / kLOV start at nodes without in-edges only): the sequence spells no path.
+                if (!rov && r > last_source && nzsaved == 0 && !g.any(any)) return (int)first;      // (kLOV may have met its end cell already)
+                // kLOV: rows come in rank order and the first perfect end-cell candidate wins, so the rest of the matrix is not needed
+                if (lov && first != 0xffffffffu) return (int)first;
             }
             if (r >= n_nodes) break;
             // ---- SLOW row (as in rows_exact) ----
@@ -1098,7 +1109,13 @@ struct Poa {
                     else *(uint32_t*)dst = codes;
                     if (meta & META_SAVE) *(PackP*)(ring + wslotS + j0) = pk;
                 }
-                if (meta & META_SAVE) { scount += 1; wslotS = wslotS + S == RS ? 0 : wslotS + S; }
+                if (meta & META_SAVE) {
+                    scount += 1; wslotS = wslotS + S == RS ? 0 : wslotS + S;
+                    bool nz = false;
+                    HYPO_UNROLL
+                    for (int q = 0; q < NP; ++q) nz = nz || (j0 < S && pk_bits(v[q]) != 0);
+                    nzsaved = (nzsaved << 1) | (g.any(nz) ? 1u : 0u);
+                }
                 HYPO_UNROLL
                 for (int q = 0; q < NP; ++q) LAST[q] = v[q];
                 if (lov || meta_sink(meta)) {
@@ -1110,6 +1127,7 @@ struct Poa {
                 }
                 ++r;
                 g.sync();
+                if (lov && first != 0xffffffffu) return (int)first;
             }
         }
         return (int)first;                                   // group-uniform; -1: no perfect candidate

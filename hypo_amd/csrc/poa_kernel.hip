@@ -37,12 +37,15 @@ template <class Cfg> __host__ __device__ constexpr ClassLimits limits_of() {
 constexpr int PLAN_THREADS = 256;
 constexpr int PLAN_STAGE = 8192;          // arm lengths staged per workgroup (32 KiB of LDS)
 
-__device__ __forceinline__ uint32_t plan_key_from(const HypoWindow& W, uint32_t maxarm, bool* trivial) {
+__device__ __forceinline__ uint32_t plan_key_from(const HypoWindow& W, uint32_t maxarm, uint32_t changes, bool* trivial) {
     const uint32_t narm = W.n_internal + W.n_prefix + W.n_suffix;
-    // longest sequence the window will align (markers included) and a node estimate
+    // longest sequence the window will align (markers included) and a node estimate: the first sequence's chain plus what the
+    // arms that differ from their predecessor are expected to add (`changes`: differing packed bytes between consecutive internal
+    // arms of equal length, about two per new node).  The kernel re-queues a window that outgrows its class all the same.
     uint32_t maxlen = (W.n_internal == 0 || W.type != HYPO_WIN_SHORT) ? W.draft_len + 2 : 0;
     if (narm) maxlen = maxarm + 2 > maxlen ? maxarm + 2 : maxlen;
-    const uint32_t est_nodes = maxlen + maxlen / 16 + 3;   // near-linear graphs; the kernel re-queues on overflow
+    const uint32_t slack = maxlen / 16 + 3, grow = changes / 2 + 3;
+    const uint32_t est_nodes = maxlen + (grow > slack ? grow : slack);
     const ClassLimits lim[kNumPoaClasses] = {
 #define HYPO_LIM(ID, CFG) limits_of<CFG>(),
         HYPO_FOR_EACH_CLASS(HYPO_LIM)
@@ -92,8 +95,24 @@ poa_plan_count_kernel(PoaParams P, PoaQueues Q, uint32_t n_windows) {
         uint32_t maxarm = 0;
         if (staged) { for (uint32_t a = 0; a < narm; ++a) { const uint32_t l = lens[W.first_arm - a0 + a]; maxarm = l > maxarm ? l : maxarm; } }
         else { for (uint32_t a = 0; a < narm; ++a) { const uint32_t l = P.arm_len[W.first_arm + a]; maxarm = l > maxarm ? l : maxarm; } }
+        // arm diversity: packed bytes (4 bases each) in which an internal arm differs from the arm before it, equal lengths only.
+        // A read error changes one byte against the predecessor and one against the successor, at any error rate: about two
+        // differing bytes per node the window's graph will grow beyond its first chain.  (13.6 MB of arms on the C2 batch, read
+        // once here and once more by the size-class kernels.)
+        uint32_t changes = 0;
+        if (W.type == HYPO_WIN_SHORT && (uint64_t)W.first_arm + narm <= P.n_arms) {
+            const uint8_t* q = nullptr; uint32_t pl = 0xffffffffu;
+            for (uint32_t a = 0; a < W.n_internal; ++a) {
+                const uint32_t l = staged ? lens[W.first_arm - a0 + a] : P.arm_len[W.first_arm + a];
+                const uint64_t o = P.arm_off[W.first_arm + a];
+                const uint32_t nb = (l + 3) / 4;
+                const uint8_t* p = (o <= P.arms2_bytes && nb <= P.arms2_bytes - o) ? P.arms2 + o : nullptr;
+                if (p && q && l == pl) for (uint32_t b = 0; b < nb; ++b) changes += p[b] != q[b];
+                q = p; pl = l;
+            }
+        }
         bool trivial;
-        const uint32_t key = plan_key_from(W, maxarm, &trivial);
+        const uint32_t key = plan_key_from(W, maxarm, changes, &trivial);
         Q.keys[w] = (uint16_t)key;
         atomicAdd(&hist[key], 1u);
         if (trivial) atomicAdd(&ntriv, 1u);
