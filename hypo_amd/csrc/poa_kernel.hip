@@ -373,8 +373,7 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
     hipLaunchKernelGGL(poa_plan_scatter_kernel, dim3((n_windows + PLAN_THREADS - 1) / PLAN_THREADS), dim3(PLAN_THREADS), 0, stream, Q, n_windows);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (prof) (void)hipEventRecord(prof->ev[1], stream);
-    // The plan's class counts come back to the host before anything else is launched (the wait costs nothing measurable: the
-    // class kernels cannot start before the plan anyway).  They decide class 0's geometry and wave share and size the grids
+    // The plan's class counts decide class 0's geometry and wave share and size the grids
     // of the rare classes (3: oversized, 4: LONG, 5: catch-all): a grid of 2 048 single-wave workgroups costs ~0.1 ms of
     // dispatch even if every wave leaves at once, and these classes are empty in most batches (a few escalated windows still
     // find a small grid waiting).
@@ -383,10 +382,30 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
         memset(A->planned_host, 0, 24 * sizeof(uint32_t));
         if ((e = hipEventCreateWithFlags(&A->planned_ev, hipEventDisableTiming)) != hipSuccess) return e;
     }
-    uint32_t* const planned_host = A->planned_host;
+    // The FIRST call of a context waits for its own plan (nothing to go by yet).  Every later call is queued without a host wait:
+    // it sizes its grids and picks class 0's geometry from the plan of the previous call, scaled to this batch's size (the
+    // batches of one run look alike; a grid that turns out small only lowers the parallelism of that class, the persistent
+    // waves still drain the queue), and leaves its own counts behind for the next one.  HYPO_POA_SYNC_PLAN=1 waits every time.
+    uint32_t* const pinned = A->planned_host;          // [0..7] this call's plan (async copy), [8..15] final counts of the last finished call
     const hipEvent_t planned_ev = A->planned_ev;
-    if ((e = hipMemcpyAsync(planned_host, Q.planned, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    const bool wait_for_plan = !A->history_valid || getenv("HYPO_POA_SYNC_PLAN") != nullptr;
+    uint32_t hist[24];
+    if (!wait_for_plan) {
+        // what the previous call left in the pinned buffer (complete unless that call is still running: then the one before it)
+        for (int c = 0; c < 8; ++c) {
+            const uint64_t prev_planned = pinned[c], prev_count = pinned[8 + c];
+            hist[c] = (uint32_t)(prev_planned * n_windows / (A->history_windows ? A->history_windows : 1));
+            hist[8 + c] = (uint32_t)(prev_count * n_windows / (A->history_windows ? A->history_windows : 1));
+            hist[16 + c] = hist[c];
+        }
+    }
+    if ((e = hipMemcpyAsync(pinned, Q.planned, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
     (void)hipEventRecord(planned_ev, stream);
+    if (wait_for_plan) {
+        if ((e = hipEventSynchronize(planned_ev)) != hipSuccess) return e;
+        for (int c = 0; c < 8; ++c) { hist[c] = pinned[c]; hist[8 + c] = A->history_valid ? pinned[8 + c] : 0u; hist[16 + c] = A->history_valid ? A->last_planned[c] : 0u; }
+    }
+    const uint32_t* const planned_host = hist;
     // Windows re-queued into a class are only known on the device.  The grids of the mop-up passes and of the rare classes
     // are sized from what the plan put there plus what the LAST finished call saw arrive later (its counters come back
     // asynchronously at the end of every call): batches of one run look alike, and noisier reads re-queue many windows (at 1 %
@@ -425,7 +444,6 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
     auto rec = [&](int idx, hipStream_t st) { if (prof) (void)hipEventRecord(prof->ev[idx], st); };
     if (sequential) {
 #define HYPO_LAUNCH(ID, CFG)                                                                              \
-        if (ID == 3 && (e = hipEventSynchronize(planned_ev)) != hipSuccess) return e;                     \
         rec(2 + 2 * ID, stream);                                                                          \
         if ((e = launch_class<CFG, (ID < kFirstGlobalClass)>(P, Q, ID, ID >= 3 ? rare_grid_hint(ID) : n_windows, scratch, num_cus, \
                                                              (ID == 4 ? groups4 : groups5), stream)) != hipSuccess) return e; \
@@ -442,7 +460,6 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
         }
         // The host looks at the plan before it launches anything: a batch made of tiny windows almost only (dense short reads
         // on a large genome) runs class 0 with twice the waves (the default split starves it: 44 -> 55 M windows/s there).
-        if ((e = hipEventSynchronize(planned_ev)) != hipSuccess) return e;
         const uint64_t lds_windows = (uint64_t)planned_host[0] + planned_host[1] + planned_host[2];
         bool four_groups = (uint64_t)planned_host[0] * 100 > lds_windows * 85;
         if (const char* g0 = getenv("HYPO_POA_CLASS0")) four_groups = atoi(g0) == 16;      // 16 | 32: lanes per group (tests)
@@ -516,8 +533,10 @@ hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size
         rec(3 + 2 * 5, stream);
     }
     // this call's final and planned counts for the next call's grid sizes (no wait: whoever reads them gets the last finished call)
-    (void)hipMemcpyAsync(planned_host + 8, Q.count, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-    memcpy(planned_host + 16, planned_host, 8 * sizeof(uint32_t));
+    (void)hipMemcpyAsync(pinned + 8, Q.count, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    for (int c = 0; c < 8; ++c) A->last_planned[c] = hist[c];
+    A->history_valid = true;
+    A->history_windows = n_windows;
     rec(2 + 2 * kNumPoaClasses, stream);
     pe = 3 + 2 * kNumPoaClasses;
     if (prof) prof->n = pe;

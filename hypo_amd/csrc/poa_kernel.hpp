@@ -44,7 +44,10 @@ struct KernelEvents { hipEvent_t ev[16]; int n; };
 struct PoaAux {
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};
     hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr}, planned_ev = nullptr;
-    uint32_t* planned_host = nullptr;     // [0..7] planned counts of this call, [8..15] final counts and [16..23] planned counts of the last finished call
+    uint32_t* planned_host = nullptr;     // pinned: [0..7] planned counts of the call in flight, [8..15] final counts of the last finished call
+    uint32_t last_planned[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // planned counts the previous call worked with
+    bool history_valid = false;           // a call has been queued on this context before
+    uint32_t history_windows = 0;         // its batch size
 };
 void poa_release(PoaAux* a);
 

@@ -13,8 +13,8 @@
  *  - "_device" variants take DEVICE pointers inside the batch structs and run asynchronously on the
  *    given hipStream_t (passed as void*; NULL = the HIP null stream, ordered after everything the caller queued there);
  *    plain variants take HOST pointers and do H2D/D2H themselves on a stream of the context.
- *    (hypo_gpu_poa_batch_device returns once all kernels are queued; on the way it waits for its own plan
- *    step, ~0.1 ms of device time, to size the launches of the rare size classes.)
+ *    (hypo_gpu_poa_batch_device returns once all kernels are queued.  Only the first call of a context waits, for its own
+ *    plan step; later calls size their launches from the plan of the call before them.)
  *  - one device context per device handed to hypo_gpu_init.  A host thread works on the context it selected with
  *    hypo_gpu_use_device (slot 0 until then); calls on different contexts run concurrently, the host part of calls on
  *    the same context (enqueueing, the copies of the host-buffer variants) is serialised inside the library.

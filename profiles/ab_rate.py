@@ -24,6 +24,11 @@ def child(lib, sub):
         db.run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 10
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    db.run()
+    enq = time.perf_counter() - t0                      # the call itself: all kernels queued, nothing waited for
+    torch.cuda.synchronize()
     gpu.profile_begin(4)
     for _ in range(4):
         db.run()
@@ -32,7 +37,7 @@ def child(lib, sub):
     st = db.stats()
     mode = "sequential" if os.environ.get("HYPO_POA_SEQUENTIAL") else "concurrent"
     print(f"{os.path.basename(lib):24s} {mode:10s} sub={sub}: {dt * 1e3:6.3f} ms/call  kernels [plan, c0..c5, call] = "
-          f"{[round(float(x), 2) for x in prof]}  esc={st['n_escalated']}", flush=True)
+          f"{[round(float(x), 2) for x in prof]}  esc={st['n_escalated']}  host call returns after {enq * 1e3:.3f} ms", flush=True)
 
 
 if __name__ == "__main__":
