@@ -308,7 +308,32 @@ def main():
             gpu.poa_batch(batch, off=hoff)
         t2 = timed(lambda: gpu.poa_batch(batch, off=hoff), 5, lambda: None)
         extra["host_api"] = {"value": round(n_w / t2, 1), "unit": "windows/s", "ms_per_call": round(t2 * 1e3, 3),
-                             "note": "hypo_gpu_poa_batch with host pointers: H2D of the batch + kernels + D2H of the consensus, PCIe-inclusive"}
+                             "note": "hypo_gpu_poa_batch with host pointers (pageable memory): H2D of the batch + kernels + D2H of the consensus, one call at a time, PCIe-inclusive"}
+        # the same through hypo_gpu_poa_batch_begin / _end with two batches in flight: page-locked buffers, no arm_off upload
+        # (the arms lie back to back), batch i + 1 is uploaded while batch i computes
+        from hypo_amd.batch import HostBatch
+        pin = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).pin_memory().numpy()
+        pb = HostBatch(pin(batch.windows).view(batch.windows.dtype), pin(batch.draft4), batch.arm_off,
+                       pin(batch.arm_len).view(np.uint32), pin(batch.arms2))
+        poff = pin(hoff).view(np.uint64)
+        outs = [(torch.zeros(int(hoff[-1]) + 16, dtype=torch.uint8).pin_memory().numpy(), torch.zeros(n_w * 4, dtype=torch.uint8).pin_memory().numpy().view(np.uint32),
+                 torch.zeros(n_w, dtype=torch.uint8).pin_memory().numpy()) for _ in range(2)]
+        def pipelined(calls):
+            pending = []
+            for i in range(calls):
+                ob, ol, os_ = outs[i % 2]
+                if len(pending) == 2:
+                    gpu.poa_batch_end(pending.pop(0)[0])
+                pending.append(gpu.poa_batch_begin(pb, poff, ob, ol, os_, no_arm_off=True))
+            while pending:
+                gpu.poa_batch_end(pending.pop(0)[0])
+        pipelined(3)
+        t0 = time.perf_counter()
+        pipelined(8)
+        t3 = (time.perf_counter() - t0) / 8
+        same = bool((outs[1][1] == ln).all() and (outs[1][2] == st).all())
+        extra["host_api_pipelined"] = {"value": round(n_w / t3, 1), "unit": "windows/s", "ms_per_call": round(t3 * 1e3, 3), "results_equal": same,
+                                       "note": "hypo_gpu_poa_batch_begin/_end, two batches in flight, page-locked host buffers, arm offsets computed on the device"}
 
     # ---- CPU baseline: the bit-exact port of the reference's OpenMP/spoa path on this box -----------------
     cpu = None

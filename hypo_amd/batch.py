@@ -78,7 +78,7 @@ class HostBatch:
         return int(self.arm_len.shape[0])
 
     def slot_layout(self) -> np.ndarray:
-        """Same rule as hypo_gpu_poa_slot_layout: 2*max(draft, longest arm)+64 rounded up to 8."""
+        """Same rule as hypo_gpu_poa_slot_layout: 1.5*max(draft, longest arm)+24 rounded up to 8."""
         n = self.n_windows
         longest = self.windows["draft_len"].astype(np.int64).copy()
         if self.n_arms:
@@ -90,7 +90,7 @@ class HostBatch:
             idx = np.concatenate([np.arange(f, f + c) for f, c in zip(first, cnt)]) if n else np.zeros(0, np.int64)
             if idx.size:
                 np.maximum.at(longest, owner, self.arm_len[idx].astype(np.int64))
-        slot = (2 * longest + 64 + 7) // 8 * 8
+        slot = (longest + longest // 2 + 24 + 7) // 8 * 8
         off = np.zeros(n + 1, dtype=np.uint64)
         np.cumsum(slot, out=off[1:])
         return off

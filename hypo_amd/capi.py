@@ -22,7 +22,7 @@ EXPORTS = [
     "hypo_gpu_poa_batch_device", "hypo_gpu_poa_slot_layout", "hypo_gpu_poa_last_stats",
     "hypo_gpu_poa_read_stats", "hypo_gpu_profile_begin", "hypo_gpu_profile_calls", "hypo_gpu_profile_read",
     "hypo_gpu_num_devices", "hypo_gpu_use_device", "hypo_gpu_build_id", "hypo_gpu_solid_set_upload",
-    "hypo_gpu_poa_batch_sharded",
+    "hypo_gpu_poa_batch_sharded", "hypo_gpu_poa_batch_begin", "hypo_gpu_poa_batch_end",
 ]
 
 
@@ -117,6 +117,21 @@ class HypoGpu:
         out = abi.ConsensusBatch(_p(bases), _p(off), _p(ln), _p(st))
         self._check(self.lib.hypo_gpu_poa_batch_sharded(C.byref(sp), C.byref(ins), C.byref(out)))
         return bases, off, ln, st
+
+    def poa_batch_begin(self, b: HostBatch, off, bases, ln, st, scores=abi.DEFAULT_SCORES, no_arm_off=False):
+        """hypo_gpu_poa_batch_begin on caller-owned buffers; returns (ticket, keep-alive objects).  no_arm_off: the arms of `b`
+        lie back to back (HostBatch built by this package), let the device compute their offsets."""
+        sp = abi.ScoreParams(*scores)
+        ins = host_struct(b)
+        if no_arm_off:
+            ins.arm_off = None
+        out = abi.ConsensusBatch(_p(bases), _p(off), _p(ln), _p(st))
+        t = C.c_int(-1)
+        self._check(self.lib.hypo_gpu_poa_batch_begin(C.byref(sp), C.byref(ins), C.byref(out), C.byref(t)))
+        return int(t.value), (sp, ins, out)
+
+    def poa_batch_end(self, ticket: int):
+        self._check(self.lib.hypo_gpu_poa_batch_end(C.c_int(ticket)))
 
     def poa_consensus(self, b: HostBatch, scores=abi.DEFAULT_SCORES, off=None):
         bases, off, ln, st = self.poa_batch(b, scores, off)

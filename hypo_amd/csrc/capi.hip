@@ -52,7 +52,13 @@ struct Prof { std::vector<ProfCall> calls; int used = 0; };
 // default); entry points lock that context only, so threads driving different devices never wait for each other.
 struct Ctx {
     bool ready = false; int device = -1; int num_cus = 0; hipStream_t stream = nullptr;
-    hypo::PoaAux poa_aux; DevBuf arena[16];
+    // Two batches of the host-pointer POA entry points can be in flight (hypo_gpu_poa_batch_begin / _end): each has its own
+    // device buffers, workspace, stream and side streams, so the upload of one overlaps the kernels of the other.  Slot 0's
+    // stream is `stream` (also used by the scan and by hypo_gpu_poa_batch_sharded).
+    struct Slot {
+        DevBuf arena[10]; hypo::PoaAux aux; hipStream_t stream = nullptr; bool busy = false; uint32_t n = 0; HypoPoaStats stats;
+    } slots[2];
+    DevBuf scan_arena[7];
     DevBuf solid_set; uint32_t solid_k = 0;            // hypo_gpu_solid_set_upload
     std::vector<HypoWindow> sh_win; std::vector<uint64_t> sh_aoff, sh_off;   // rebased descriptors of this device's share (hypo_gpu_poa_batch_sharded)
     Prof prof;
@@ -144,8 +150,10 @@ static void release_ctx(Ctx& c) {
         (void)hipDeviceSynchronize();
         for (auto& pc : c.prof.calls) for (auto& e : pc.ke.ev) if (e) (void)hipEventDestroy(e);
         c.prof.calls.clear(); c.prof.used = 0;
-        hypo::poa_release(&c.poa_aux);
-        for (auto& a : c.arena) a.release();
+        for (auto& sl : c.slots) { hypo::poa_release(&sl.aux); for (auto& a : sl.arena) a.release(); sl.busy = false; }
+        if (c.slots[1].stream) (void)hipStreamDestroy(c.slots[1].stream);
+        c.slots[0].stream = c.slots[1].stream = nullptr;
+        for (auto& a : c.scan_arena) a.release();
         c.solid_set.release(); c.solid_k = 0;
         if (c.stream) (void)hipStreamDestroy(c.stream);
     }
@@ -174,6 +182,8 @@ int hypo_gpu_init(const int* device_ids, int n_devices) {
         if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
             return fail(HYPO_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device_ids[i], prop.gcnArchName);
         HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&c.slots[1].stream, hipStreamNonBlocking));
+        c.slots[0].stream = c.stream;
         c.device = device_ids[i]; c.num_cus = prop.multiProcessorCount; c.ready = true;
         g_nctx = i + 1;
     }
@@ -235,8 +245,8 @@ int hypo_gpu_profile_read(int call, float* ms, int n) {
 }
 
 // ---- POA -------------------------------------------------------------------------------------------
-size_t hypo_gpu_poa_workspace_bytes(uint32_t n_windows, uint32_t /*n_arms*/) {
-    return hypo::poa_workspace_bytes(n_windows);
+size_t hypo_gpu_poa_workspace_bytes(uint32_t n_windows, uint32_t n_arms) {
+    return hypo::poa_workspace_bytes(n_windows, 0, n_arms);       // room for arm offsets computed on the device (arm_off == NULL)
 }
 
 int hypo_gpu_poa_batch_device(const HypoScoreParams* scores, const HypoWindowBatch* in, HypoConsensusBatch* out,
@@ -249,15 +259,15 @@ int hypo_gpu_poa_batch_device(const HypoScoreParams* scores, const HypoWindowBat
     if (!in || !out) return fail(HYPO_E_INVALID, "NULL batch");
     if (in->n_windows == 0) return HYPO_OK;
     if (!in->windows || !in->draft4 || !out->bases || !out->off || !out->len || !out->status ||
-        (in->n_arms && (!in->arm_off || !in->arm_len || !in->arms2)))
+        (in->n_arms && (!in->arm_len || !in->arms2)))
         return fail(HYPO_E_INVALID, "NULL buffer in batch");
-    if (!workspace || workspace_bytes < hypo::poa_workspace_bytes(in->n_windows, hypo::kMinGlobalGroups))
+    if (!workspace || workspace_bytes < hypo::poa_workspace_bytes(in->n_windows, hypo::kMinGlobalGroups, in->arm_off ? 0 : in->n_arms))
         return fail(HYPO_E_WORKSPACE, "workspace %zu < minimum %zu (hypo_gpu_poa_workspace_bytes recommends %zu)", workspace_bytes,
-                    hypo::poa_workspace_bytes(in->n_windows, hypo::kMinGlobalGroups), hypo::poa_workspace_bytes(in->n_windows));
+                    hypo::poa_workspace_bytes(in->n_windows, hypo::kMinGlobalGroups, in->arm_off ? 0 : in->n_arms), hypo::poa_workspace_bytes(in->n_windows, 0, in->n_arms));
     hypo::PoaParams P = make_params(scores, in, out);
     hipStream_t st = (hipStream_t)hip_stream;                  // NULL is the HIP null stream itself (what torch calls its default stream)
     ProfCall* pc = prof_next(1);
-    HIP_TRY(hypo::poa_run(P, in->n_windows, workspace, workspace_bytes, g_ctx.num_cus, st, pc ? &pc->ke : nullptr, &g_ctx.poa_aux));
+    HIP_TRY(hypo::poa_run(P, in->n_windows, workspace, workspace_bytes, g_ctx.num_cus, st, pc ? &pc->ke : nullptr, &g_ctx.slots[0].aux));
     return HYPO_OK;
 }
 
@@ -286,59 +296,92 @@ int hypo_gpu_poa_slot_layout(const HypoWindowBatch* in, uint64_t* off) {
         if (W.first_arm + narm > in->n_arms) return fail(HYPO_E_INVALID, "window %u: arms [%u, %llu) outside the batch's %u arms", w, W.first_arm, (unsigned long long)(W.first_arm + narm), in->n_arms);
         for (uint64_t a = 0; a < narm; ++a) if (in->arm_len[W.first_arm + a] > longest) longest = in->arm_len[W.first_arm + a];
         off[w] = acc;
-        acc += (2 * longest + 64 + 7) / 8 * 8;
+        acc += (longest + longest / 2 + 24 + 7) / 8 * 8;
     }
     off[in->n_windows] = acc;
     return HYPO_OK;
 }
 
-int hypo_gpu_poa_batch(const HypoScoreParams* scores, const HypoWindowBatch* in, HypoConsensusBatch* out) {
+// Queues one batch: upload, kernels, download of the results into the caller's buffers, all on the slot's stream; returns
+// without waiting.  `in` and `out` buffers must stay untouched until hypo_gpu_poa_batch_end(ticket).
+int hypo_gpu_poa_batch_begin(const HypoScoreParams* scores, const HypoWindowBatch* in, HypoConsensusBatch* out, int* ticket) {
     HYPO_LOCKED();
     HYPO_ON_DEVICE();
     if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
     int rc = check_scores(scores);
     if (rc) return rc;
-    if (!in || !out) return fail(HYPO_E_INVALID, "NULL batch");
-    memset(&tl_stats, 0, sizeof(tl_stats));
+    if (!in || !out || !ticket) return fail(HYPO_E_INVALID, "NULL batch");
     const uint32_t n = in->n_windows, na = in->n_arms;
-    if (n == 0) return HYPO_OK;
-    if (!in->windows || !in->draft4 || !out->bases || !out->off || !out->len || !out->status)
+    if (n && (!in->windows || !in->draft4 || !out->bases || !out->off || !out->len || !out->status || (na && (!in->arm_len || !in->arms2))))
         return fail(HYPO_E_INVALID, "NULL buffer in batch");
+    int si = -1;
+    for (int i = 0; i < 2; ++i) if (!g_ctx.slots[i].busy) { si = i; break; }
+    if (si < 0) return fail(HYPO_E_INVALID, "two batches are already in flight on this context: call hypo_gpu_poa_batch_end first");
+    Ctx::Slot& S = g_ctx.slots[si];
+    S.n = n;
+    memset(&S.stats, 0, sizeof(S.stats));
+    *ticket = si;
+    S.busy = true;
+    if (n == 0) return HYPO_OK;
     const uint64_t out_bytes = out->off[n];
-    DevBuf &dW = g_ctx.arena[0], &dD = g_ctx.arena[1], &dAO = g_ctx.arena[2], &dAL = g_ctx.arena[3], &dA = g_ctx.arena[4],
-           &dB = g_ctx.arena[5], &dO = g_ctx.arena[6], &dL = g_ctx.arena[7], &dS = g_ctx.arena[8], &dWS = g_ctx.arena[9];
+    DevBuf &dW = S.arena[0], &dD = S.arena[1], &dAO = S.arena[2], &dAL = S.arena[3], &dA = S.arena[4],
+           &dB = S.arena[5], &dO = S.arena[6], &dL = S.arena[7], &dS = S.arena[8], &dWS = S.arena[9];
     // the host sees the window types: scratch for as many resident LONG groups as there are LONG windows (+ escalations)
     uint32_t n_long = 0;
     for (uint32_t w = 0; w < n; ++w) n_long += in->windows[w].type != HYPO_WIN_SHORT;
-    const size_t wsb = hypo::poa_workspace_bytes(n, (int)(n_long + 64 < 2048u ? n_long + 64 : 2048u));
-    HIP_TRY(dW.alloc((size_t)n * sizeof(HypoWindow))); HIP_TRY(dD.alloc(in->draft4_bytes));
-    HIP_TRY(dAO.alloc((size_t)na * 8)); HIP_TRY(dAL.alloc((size_t)na * 4)); HIP_TRY(dA.alloc(in->arms2_bytes));
-    HIP_TRY(dB.alloc(out_bytes)); HIP_TRY(dO.alloc((size_t)(n + 1) * 8)); HIP_TRY(dL.alloc((size_t)n * 4));
-    HIP_TRY(dS.alloc(n)); HIP_TRY(dWS.alloc(wsb));
-    hipStream_t st = g_ctx.stream;
-    HIP_TRY(hipMemcpyAsync(dW.p, in->windows, (size_t)n * sizeof(HypoWindow), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(dD.p, in->draft4, in->draft4_bytes, hipMemcpyHostToDevice, st));
+    const size_t wsb = hypo::poa_workspace_bytes(n, (int)(n_long + 64 < 2048u ? n_long + 64 : 2048u), in->arm_off ? 0 : na);
+    auto undo = [&](int code) { S.busy = false; return code; };
+#define HIP_TRY_S(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return undo(fail(HYPO_E_HIP, "%s: %s", #x, hipGetErrorString(e_))); } while (0)
+    HIP_TRY_S(dW.alloc((size_t)n * sizeof(HypoWindow))); HIP_TRY_S(dD.alloc(in->draft4_bytes));
+    if (in->arm_off) HIP_TRY_S(dAO.alloc((size_t)na * 8));
+    HIP_TRY_S(dAL.alloc((size_t)na * 4)); HIP_TRY_S(dA.alloc(in->arms2_bytes));
+    HIP_TRY_S(dB.alloc(out_bytes)); HIP_TRY_S(dO.alloc((size_t)(n + 1) * 8)); HIP_TRY_S(dL.alloc((size_t)n * 4));
+    HIP_TRY_S(dS.alloc(n)); HIP_TRY_S(dWS.alloc(wsb));
+    hipStream_t st = S.stream;
+    HIP_TRY_S(hipMemcpyAsync(dW.p, in->windows, (size_t)n * sizeof(HypoWindow), hipMemcpyHostToDevice, st));
+    HIP_TRY_S(hipMemcpyAsync(dD.p, in->draft4, in->draft4_bytes, hipMemcpyHostToDevice, st));
     if (na) {
-        HIP_TRY(hipMemcpyAsync(dAO.p, in->arm_off, (size_t)na * 8, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(dAL.p, in->arm_len, (size_t)na * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(dA.p, in->arms2, in->arms2_bytes, hipMemcpyHostToDevice, st));
+        if (in->arm_off) HIP_TRY_S(hipMemcpyAsync(dAO.p, in->arm_off, (size_t)na * 8, hipMemcpyHostToDevice, st));
+        HIP_TRY_S(hipMemcpyAsync(dAL.p, in->arm_len, (size_t)na * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY_S(hipMemcpyAsync(dA.p, in->arms2, in->arms2_bytes, hipMemcpyHostToDevice, st));
     }
-    HIP_TRY(hipMemcpyAsync(dO.p, out->off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(dB.p, 0, out_bytes ? out_bytes : 16, st));   // slack bytes of a slot come back as 0
+    HIP_TRY_S(hipMemcpyAsync(dO.p, out->off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY_S(hipMemsetAsync(dB.p, 0, out_bytes ? out_bytes : 16, st));   // slack bytes of a slot come back as 0
     HypoWindowBatch din = *in;
-    din.windows = (const HypoWindow*)dW.p; din.draft4 = (const uint8_t*)dD.p; din.arm_off = (const uint64_t*)dAO.p;
+    din.windows = (const HypoWindow*)dW.p; din.draft4 = (const uint8_t*)dD.p; din.arm_off = in->arm_off ? (const uint64_t*)dAO.p : nullptr;
     din.arm_len = (const uint32_t*)dAL.p; din.arms2 = (const uint8_t*)dA.p;
     HypoConsensusBatch dout;
     dout.bases = (char*)dB.p; dout.off = (const uint64_t*)dO.p; dout.len = (uint32_t*)dL.p; dout.status = (uint8_t*)dS.p;
-    rc = hypo_gpu_poa_batch_device(scores, &din, &dout, dWS.p, wsb, st);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(out->bases, dB.p, out_bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(out->len, dL.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(out->status, dS.p, n, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&tl_stats, (char*)dWS.p + 128, sizeof(HypoPoaStats), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    tl_stats.n_windows = n;
+    hypo::PoaParams P = make_params(scores, &din, &dout);
+    HIP_TRY_S(hypo::poa_run(P, n, dWS.p, wsb, g_ctx.num_cus, st, nullptr, &S.aux));
+    HIP_TRY_S(hipMemcpyAsync(out->bases, dB.p, out_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY_S(hipMemcpyAsync(out->len, dL.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY_S(hipMemcpyAsync(out->status, dS.p, n, hipMemcpyDeviceToHost, st));
+    HIP_TRY_S(hipMemcpyAsync(&S.stats, (char*)dWS.p + 128, sizeof(HypoPoaStats), hipMemcpyDeviceToHost, st));
+#undef HIP_TRY_S
     return HYPO_OK;
+}
+
+int hypo_gpu_poa_batch_end(int ticket) {
+    if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
+    if (ticket < 0 || ticket > 1 || !g_ctx.slots[ticket].busy) return fail(HYPO_E_INVALID, "no batch in flight under ticket %d", ticket);
+    Ctx::Slot& S = g_ctx.slots[ticket];
+    HYPO_ON_DEVICE();
+    const hipError_t e = S.n ? hipStreamSynchronize(S.stream) : hipSuccess;      // (no context lock while waiting: the other slot stays usable)
+    HYPO_LOCKED();
+    S.busy = false;
+    if (e != hipSuccess) return fail(HYPO_E_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
+    tl_stats = S.stats;
+    tl_stats.n_windows = S.n;
+    return HYPO_OK;
+}
+
+int hypo_gpu_poa_batch(const HypoScoreParams* scores, const HypoWindowBatch* in, HypoConsensusBatch* out) {
+    memset(&tl_stats, 0, sizeof(tl_stats));
+    int ticket = -1;
+    const int rc = hypo_gpu_poa_batch_begin(scores, in, out, &ticket);
+    if (rc) return rc;
+    return hypo_gpu_poa_batch_end(ticket);
 }
 
 // ---- POA over all contexts ----------------------------------------------------------------------------
@@ -422,8 +465,8 @@ int hypo_gpu_poa_batch_sharded(const HypoScoreParams* scores, const HypoWindowBa
         if (e != hipSuccess) return bad(HYPO_E_HIP, "hipSetDevice", e);
         const uint32_t nw = S.w1 - S.w0;
         // result buffers of the WHOLE batch on every device (the gather fills the other devices' ranges)
-        DevBuf &dW = c.arena[0], &dD = c.arena[1], &dAO = c.arena[2], &dAL = c.arena[3], &dA = c.arena[4],
-               &dB = c.arena[5], &dO = c.arena[6], &dL = c.arena[7], &dS = c.arena[8], &dWS = c.arena[9];
+        DevBuf* const ar = c.slots[0].arena;
+        DevBuf &dW = ar[0], &dD = ar[1], &dAO = ar[2], &dAL = ar[3], &dA = ar[4], &dB = ar[5], &dO = ar[6], &dL = ar[7], &dS = ar[8], &dWS = ar[9];
         if ((e = dB.alloc(out_bytes)) != hipSuccess || (e = dL.alloc((size_t)n * 4)) != hipSuccess || (e = dS.alloc(n)) != hipSuccess)
             return bad(HYPO_E_HIP, "hipMalloc", e);
         memset(&S.st, 0, sizeof(S.st));
@@ -481,7 +524,7 @@ int hypo_gpu_poa_batch_sharded(const HypoScoreParams* scores, const HypoWindowBa
         P.sr_m = scores->sr_match; P.sr_n = scores->sr_mismatch; P.sr_g = scores->sr_gap;
         P.lr_m = scores->lr_match; P.lr_n = scores->lr_mismatch; P.lr_g = scores->lr_gap;
         P.n_arms = a1 - a0; P.draft4_bytes = d1 - d0; P.arms2_bytes = b1 - b0;
-        if ((e = hypo::poa_run(P, nw, dWS.p, wsb, c.num_cus, st, nullptr, &c.poa_aux)) != hipSuccess) return bad(HYPO_E_HIP, "poa_run", e);
+        if ((e = hypo::poa_run(P, nw, dWS.p, wsb, c.num_cus, st, nullptr, &c.slots[0].aux)) != hipSuccess) return bad(HYPO_E_HIP, "poa_run", e);
         (void)hipMemcpyAsync(&S.st, (char*)dWS.p + 128, sizeof(HypoPoaStats), hipMemcpyDeviceToHost, st);
         if (!use_rccl) {                                   // results of this share straight back to the caller's buffers
             (void)hipMemcpyAsync(out->bases + out->off[S.w0], (char*)dB.p + out->off[S.w0], out->off[S.w1] - out->off[S.w0], hipMemcpyDeviceToHost, st);
@@ -504,7 +547,7 @@ int hypo_gpu_poa_batch_sharded(const HypoScoreParams* scores, const HypoWindowBa
             if (S.w1 == S.w0) continue;
             for (int d = 0; r == 0 && d < nd; ++d) {
                 Ctx& c = g_ctxs[d];
-                char* B = (char*)c.arena[5].p; uint32_t* L = (uint32_t*)c.arena[7].p; uint8_t* St = (uint8_t*)c.arena[8].p;
+                char* B = (char*)c.slots[0].arena[5].p; uint32_t* L = (uint32_t*)c.slots[0].arena[7].p; uint8_t* St = (uint8_t*)c.slots[0].arena[8].p;
                 const size_t nb = out->off[S.w1] - out->off[S.w0], nw = S.w1 - S.w0;
                 if (nb) r = g_rccl.Broadcast(B + out->off[S.w0], B + out->off[S.w0], nb, kNcclUint8, root, g_rccl.comms[d], c.stream);
                 if (r == 0) r = g_rccl.Broadcast(L + S.w0, L + S.w0, nw * 4, kNcclUint8, root, g_rccl.comms[d], c.stream);
@@ -516,9 +559,9 @@ int hypo_gpu_poa_batch_sharded(const HypoScoreParams* scores, const HypoWindowBa
         // ---- 4. device 0 holds everything: one copy back for contig re-assembly; the other devices only have to finish ----
         Ctx& c0 = g_ctxs[0];
         HIP_TRY(hipSetDevice(c0.device));
-        HIP_TRY(hipMemcpyAsync(out->bases, c0.arena[5].p, out_bytes, hipMemcpyDeviceToHost, c0.stream));
-        HIP_TRY(hipMemcpyAsync(out->len, c0.arena[7].p, (size_t)n * 4, hipMemcpyDeviceToHost, c0.stream));
-        HIP_TRY(hipMemcpyAsync(out->status, c0.arena[8].p, n, hipMemcpyDeviceToHost, c0.stream));
+        HIP_TRY(hipMemcpyAsync(out->bases, c0.slots[0].arena[5].p, out_bytes, hipMemcpyDeviceToHost, c0.stream));
+        HIP_TRY(hipMemcpyAsync(out->len, c0.slots[0].arena[7].p, (size_t)n * 4, hipMemcpyDeviceToHost, c0.stream));
+        HIP_TRY(hipMemcpyAsync(out->status, c0.slots[0].arena[8].p, n, hipMemcpyDeviceToHost, c0.stream));
         for (int d = nd - 1; d >= 0; --d) { HIP_TRY(hipSetDevice(g_ctxs[d].device)); HIP_TRY(hipStreamSynchronize(g_ctxs[d].stream)); }
     }
     HIP_TRY(hipSetDevice(g_ctx.device));
@@ -580,8 +623,8 @@ int hypo_gpu_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k, co
     if ((n_bases && !packed4) || (n_bases && !solid_pos_words)) return fail(HYPO_E_INVALID, "NULL buffer");
     if (!bits && g_ctx.solid_k != k) return fail(HYPO_E_INVALID, "bitset_words == NULL but no %u-mer set was uploaded (hypo_gpu_solid_set_upload)", k);
     const uint64_t nw = (n_bases + 63) / 64, nbytes = (n_bases + 1) / 2, bit_words = (1ull << (2 * k)) / 64 ? (1ull << (2 * k)) / 64 : 1;
-    DevBuf &dP = g_ctx.arena[10], &dBits = g_ctx.arena[11], &dWords = g_ctx.arena[12], &dKids = g_ctx.arena[13],
-           &dRank = g_ctx.arena[14], &dN = g_ctx.arena[15], &dWS = g_ctx.arena[9];
+    DevBuf* const sa = g_ctx.scan_arena;
+    DevBuf &dP = sa[0], &dBits = sa[1], &dWords = sa[2], &dKids = sa[3], &dRank = sa[4], &dN = sa[5], &dWS = sa[6];
     const size_t wsb = hypo::scan_workspace_bytes(n_bases);
     HIP_TRY(dP.alloc(nbytes)); if (bits) HIP_TRY(dBits.alloc(bit_words * 8)); HIP_TRY(dWords.alloc(nw * 8));
     HIP_TRY(dKids.alloc(kids_cap * 8)); HIP_TRY(dRank.alloc((nw + 1) * 8)); HIP_TRY(dN.alloc(8)); HIP_TRY(dWS.alloc(wsb));

@@ -318,6 +318,68 @@ static hipError_t launch_class(const PoaParams& P, const PoaQueues& Q, int cls, 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// arm offsets on the device: a caller whose arms lie back to back in arm order (each on a byte boundary) passes
+// arm_off == NULL and saves the upload of 8 bytes per arm (a third of the C2 batch's input); the offsets are an exclusive
+// prefix sum of ceil(len / 4), three small kernels into the tail of the workspace.
+// ------------------------------------------------------------------------------------------------
+constexpr int AO_THREADS = 256, AO_ITEMS = 1024;           // arms per workgroup
+__global__ void __launch_bounds__(AO_THREADS)
+arm_off_partial(const uint32_t* __restrict__ arm_len, uint64_t n_arms, uint64_t* __restrict__ bsum) {
+    __shared__ uint32_t red[AO_THREADS / 64];
+    const uint64_t b0 = (uint64_t)blockIdx.x * AO_ITEMS;
+    uint32_t s = 0;
+    for (int i = threadIdx.x; i < AO_ITEMS; i += AO_THREADS) { const uint64_t a = b0 + i; if (a < n_arms) s += (arm_len[a] + 3) >> 2; }
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint64_t t = 0; for (int i = 0; i < AO_THREADS / 64; ++i) t += red[i]; bsum[blockIdx.x] = t; }
+}
+__global__ void __launch_bounds__(1024) arm_off_blocksums(uint64_t* __restrict__ bsum, uint64_t n_blocks) {
+    __shared__ uint64_t sh[1024];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint64_t c0 = 0; c0 < n_blocks; c0 += 1024) {
+        const uint64_t i = c0 + threadIdx.x;
+        const uint64_t v = i < n_blocks ? bsum[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const uint64_t add = threadIdx.x >= (unsigned)d ? sh[threadIdx.x - d] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const uint64_t incl = sh[threadIdx.x];
+        if (i < n_blocks) bsum[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += incl;
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(AO_THREADS)
+arm_off_final(const uint32_t* __restrict__ arm_len, uint64_t n_arms, const uint64_t* __restrict__ bsum, uint64_t* __restrict__ arm_off) {
+    __shared__ uint32_t wsum[AO_THREADS / 64];
+    const uint64_t a0 = (uint64_t)blockIdx.x * AO_ITEMS + (uint64_t)threadIdx.x * 4;     // each lane owns 4 consecutive arms
+    uint32_t c[4], mine = 0;
+    for (int i = 0; i < 4; ++i) { c[i] = a0 + i < n_arms ? (arm_len[a0 + i] + 3) >> 2 : 0; mine += c[i]; }
+    uint32_t inc = mine;
+    const int lane = threadIdx.x & 63;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+    if (lane == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int i = 0; i < (int)(threadIdx.x >> 6); ++i) woff += wsum[i];
+    uint64_t run = bsum[blockIdx.x] + woff + (inc - mine);
+    for (int i = 0; i < 4; ++i) { if (a0 + i < n_arms) arm_off[a0 + i] = run; run += c[i]; }
+}
+static size_t arm_off_region_bytes(uint64_t n_arms) {        // offsets + block sums
+    if (!n_arms) return 0;
+    const uint64_t nb = (n_arms + AO_ITEMS - 1) / AO_ITEMS;
+    return ((size_t)n_arms * 8 + 255) / 256 * 256 + ((size_t)nb * 8 + 255) / 256 * 256;
+}
+
 static size_t poa_workspace_prefix(uint32_t n_windows) {       // header, class queues, plan keys
     size_t b = kPoaHeaderBytes;
     b += (size_t)kNumPoaClasses * n_windows * sizeof(uint32_t);
@@ -326,7 +388,7 @@ static size_t poa_workspace_prefix(uint32_t n_windows) {       // header, class 
     return b;
 }
 
-size_t poa_workspace_bytes(uint32_t n_windows, int long_groups) {
+size_t poa_workspace_bytes(uint32_t n_windows, int long_groups, uint64_t computed_arm_offsets) {
     size_t big = 0;                                         // the HBM-scratch classes run one after the other and share the region
     int g4 = long_groups > 0 ? long_groups : max_global_groups(4, n_windows);
     g4 = g4 < kMinGlobalGroups ? kMinGlobalGroups : (g4 > kMaxGlobalGroups4 ? kMaxGlobalGroups4 : g4);
@@ -334,16 +396,27 @@ size_t poa_workspace_bytes(uint32_t n_windows, int long_groups) {
     g5 = g5 < kMinGlobalGroups ? kMinGlobalGroups : g5;
     const size_t x4 = (size_t)g4 * PoaLayout<PoaClass4>::BYTES, x5 = (size_t)g5 * PoaLayout<PoaClass5>::BYTES;
     big = x4 > x5 ? x4 : x5;
-    return poa_workspace_prefix(n_windows) + big;
+    return poa_workspace_prefix(n_windows) + big + arm_off_region_bytes(computed_arm_offsets);
 }
 
-hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size_t workspace_bytes,
+hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, size_t workspace_bytes,
                    int num_cus, hipStream_t stream, KernelEvents* prof, PoaAux* A) {
     if (n_windows == 0) return hipSuccess;
     if (!A) return hipErrorInvalidValue;
-    if (workspace_bytes < poa_workspace_bytes(n_windows, kMinGlobalGroups)) return hipErrorInvalidValue;
+    PoaParams P = P_in;
+    const size_t ao_bytes = (!P.arm_off && P.n_arms) ? arm_off_region_bytes(P.n_arms) : 0;     // arm offsets to be computed here
+    if (workspace_bytes < poa_workspace_bytes(n_windows, kMinGlobalGroups, ao_bytes ? P.n_arms : 0)) return hipErrorInvalidValue;
+    if (ao_bytes) {                                           // tail of the workspace
+        uint64_t* ao = (uint64_t*)((char*)workspace + workspace_bytes - ao_bytes);
+        uint64_t* bsum = (uint64_t*)((char*)ao + ((size_t)P.n_arms * 8 + 255) / 256 * 256);
+        const uint64_t nb = (P.n_arms + AO_ITEMS - 1) / AO_ITEMS;
+        hipLaunchKernelGGL(arm_off_partial, dim3((unsigned)nb), dim3(AO_THREADS), 0, stream, P.arm_len, P.n_arms, bsum);
+        hipLaunchKernelGGL(arm_off_blocksums, dim3(1), dim3(1024), 0, stream, bsum, nb);
+        hipLaunchKernelGGL(arm_off_final, dim3((unsigned)nb), dim3(AO_THREADS), 0, stream, P.arm_len, P.n_arms, bsum, ao);
+        P.arm_off = ao;
+    }
     // resident groups of the HBM-scratch classes = what the provided scratch holds
-    const size_t scratch_bytes = workspace_bytes - poa_workspace_prefix(n_windows);
+    const size_t scratch_bytes = workspace_bytes - ao_bytes - poa_workspace_prefix(n_windows);
     const size_t fit4 = scratch_bytes / PoaLayout<PoaClass4>::BYTES, fit5 = scratch_bytes / PoaLayout<PoaClass5>::BYTES;
     const int groups4 = (int)(fit4 < (size_t)max_global_groups(4, n_windows) ? fit4 : (size_t)max_global_groups(4, n_windows));
     const int groups5 = (int)(fit5 < (size_t)max_global_groups(5, n_windows) ? fit5 : (size_t)max_global_groups(5, n_windows));

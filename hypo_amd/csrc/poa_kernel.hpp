@@ -53,7 +53,8 @@ void poa_release(PoaAux* a);
 
 // Bytes for a batch of n_windows windows.  long_groups = resident groups of the LONG class the scratch is provisioned for
 // (0 = as many as the batch could use, up to kMaxGlobalGroups4); poa_run derives the group counts from the size it is given.
-size_t poa_workspace_bytes(uint32_t n_windows, int long_groups = 0);
+// computed_arm_offsets = n_arms of a batch that comes without arm_off (the offsets are then computed into the workspace), else 0
+size_t poa_workspace_bytes(uint32_t n_windows, int long_groups = 0, uint64_t computed_arm_offsets = 0);
 hipError_t poa_run(const PoaParams& P, uint32_t n_windows, void* workspace, size_t workspace_bytes,
                    int num_cus, hipStream_t stream, KernelEvents* prof, PoaAux* aux_state);
 

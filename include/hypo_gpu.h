@@ -89,7 +89,8 @@ typedef struct HypoWindowBatch {
     const HypoWindow* windows;     /* [n_windows] */
     const uint8_t*    draft4;      /* 4-bit packed drafts (PackedSeq<4>) */
     uint64_t          draft4_bytes;
-    const uint64_t*   arm_off;     /* [n_arms] BYTE offset of each 2-bit packed arm in arms2 */
+    const uint64_t*   arm_off;     /* [n_arms] BYTE offset of each 2-bit packed arm in arms2; NULL = the arms lie back to back in
+                                      arm order, each on a byte boundary (the offsets are then computed on the device) */
     const uint32_t*   arm_len;     /* [n_arms] bases (0 allowed: skipped like Window.cpp:100,113,124) */
     const uint8_t*    arms2;       /* 2-bit packed arms (PackedSeq<2>) */
     uint64_t          arms2_bytes;
@@ -171,6 +172,14 @@ int hypo_gpu_solid_scan_device(const uint8_t* packed4, uint64_t n_bases, uint32_
 int hypo_gpu_poa_batch(const HypoScoreParams* scores, const HypoWindowBatch* in,
                        HypoConsensusBatch* out);
 
+/* The same call in two halves, so that two batches can be in flight on one context: _begin queues the upload, the kernels and
+ * the download of the results on a stream of its own and returns a ticket without waiting; _end(ticket) waits for that batch
+ * (hypo_gpu_poa_last_stats then describes it).  Buffers of `in` and `out` must stay untouched in between; page-locked host
+ * buffers (hipHostMalloc / hipHostRegister) make the copies true DMA.  A third _begin before an _end is refused. */
+int hypo_gpu_poa_batch_begin(const HypoScoreParams* scores, const HypoWindowBatch* in,
+                             HypoConsensusBatch* out, int* ticket);
+int hypo_gpu_poa_batch_end(int ticket);
+
 /* The same batch over ALL contexts of hypo_gpu_init (src/Hypo.cpp:238-247 is a parallel loop over independent windows): the
  * window list is cut into one contiguous cost-balanced range per device, every device polishes its range, and the consensus
  * bytes, lengths and status bytes are exchanged with one grouped RCCL all-gatherv (ncclBroadcast per owner) over xGMI, so
@@ -188,7 +197,8 @@ int hypo_gpu_poa_batch_device(const HypoScoreParams* scores, const HypoWindowBat
                               void* hip_stream);
 
 /* Fills off[0..n_windows] (HOST pointers) with the consensus slot layout the callee recommends:
- * slot(w) = round_up(2 * max(draft_len, longest arm) + 64, 8).  Pure host helper. */
+ * slot(w) = round_up(1.5 * max(draft_len, longest arm) + 24, 8).  Pure host helper.  A consensus that outgrows its slot
+ * comes back as HYPO_ST_CONS_OVERFLOW with len = the size it needs (the host mirror then asks again for those windows). */
 int hypo_gpu_poa_slot_layout(const HypoWindowBatch* host_in, uint64_t* off);
 
 /* Telemetry of the last POA call on this thread (windows per size class, escalations, DP cells). */

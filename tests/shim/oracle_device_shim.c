@@ -8,10 +8,23 @@
  */
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include "../../include/hypo_gpu.h"
 #include "../../oracle/hypo_oracle.h"
 
 static int g_ready = 0;
+/* arm_off == NULL (arms back to back): the oracle wants the offsets spelled out */
+static int with_offsets(const HypoScoreParams* scores, const HypoWindowBatch* in, HypoConsensusBatch* out) {
+    if (in->arm_off || !in->n_arms) return oracle_poa_batch(scores, in, out, 0, NULL, NULL);
+    uint64_t* ao = (uint64_t*)malloc((size_t)in->n_arms * 8);
+    uint64_t acc = 0;
+    for (uint32_t a = 0; a < in->n_arms; ++a) { ao[a] = acc; acc += ((uint64_t)in->arm_len[a] + 3) / 4; }
+    HypoWindowBatch b = *in;
+    b.arm_off = ao;
+    const int rc = oracle_poa_batch(scores, &b, out, 0, NULL, NULL);
+    free(ao);
+    return rc;
+}
 static const uint64_t* g_set = 0; static uint32_t g_set_k = 0; static int g_ndev = 1;
 int hypo_gpu_init(const int* device_ids, int n_devices) { (void)device_ids; g_ndev = n_devices > 0 ? n_devices : 1; g_ready = 1; fprintf(stderr, "[oracle_device_shim] TEST SHIM in use: CPU oracle behind the C-ABI\n"); return HYPO_OK; }
 int hypo_gpu_shutdown(void) { g_ready = 0; return HYPO_OK; }
@@ -40,7 +53,7 @@ int hypo_gpu_poa_slot_layout(const HypoWindowBatch* in, uint64_t* off) {
         const uint32_t narm = W->n_internal + W->n_prefix + W->n_suffix;
         for (uint32_t a = 0; a < narm; ++a) if (in->arm_len[W->first_arm + a] > longest) longest = in->arm_len[W->first_arm + a];
         off[w] = acc;
-        acc += (2 * longest + 64 + 7) / 8 * 8;
+        acc += (longest + longest / 2 + 24 + 7) / 8 * 8;
     }
     off[in->n_windows] = acc;
     return HYPO_OK;
@@ -48,12 +61,18 @@ int hypo_gpu_poa_slot_layout(const HypoWindowBatch* in, uint64_t* off) {
 
 int hypo_gpu_poa_batch(const HypoScoreParams* scores, const HypoWindowBatch* in, HypoConsensusBatch* out) {
     if (!g_ready) return HYPO_E_NOTINIT;
-    return oracle_poa_batch(scores, in, out, 0, NULL, NULL);
+    return with_offsets(scores, in, out);
 }
+static HypoConsensusBatch g_pending_out; static int g_pending = 0;
+int hypo_gpu_poa_batch_begin(const HypoScoreParams* scores, const HypoWindowBatch* in, HypoConsensusBatch* out, int* ticket) {
+    (void)g_pending_out; if (!g_ready) return HYPO_E_NOTINIT; if (g_pending) return HYPO_E_INVALID; g_pending = 1; *ticket = 0;
+    return with_offsets(scores, in, out);
+}
+int hypo_gpu_poa_batch_end(int ticket) { if (ticket != 0 || !g_pending) return HYPO_E_INVALID; g_pending = 0; return HYPO_OK; }
 /* two "devices": the window list in two contiguous halves, each answered separately into the caller's slots */
 int hypo_gpu_poa_batch_sharded(const HypoScoreParams* scores, const HypoWindowBatch* in, HypoConsensusBatch* out) {
     if (!g_ready) return HYPO_E_NOTINIT;
-    if (g_ndev < 2 || in->n_windows < 2) return oracle_poa_batch(scores, in, out, 0, NULL, NULL);
+    if (g_ndev < 2 || in->n_windows < 2 || !in->arm_off) return with_offsets(scores, in, out);
     fprintf(stderr, "[oracle_device_shim] sharded call over %d contexts\n", g_ndev);
     const uint32_t h = in->n_windows / 2;
     HypoWindowBatch a = *in, b = *in;

@@ -261,3 +261,23 @@ def test_build_id_and_contexts(gpu):
     test_abi.test_build_id_matches_sources(gpu.lib)
     assert gpu.lib.hypo_gpu_num_devices() == 1
     assert gpu.lib.hypo_gpu_use_device(0) == 0 and gpu.lib.hypo_gpu_use_device(1) == abi.HYPO_E_INVALID
+
+
+def test_two_batches_in_flight_and_computed_arm_offsets(gpu, oracle_lib):
+    """hypo_gpu_poa_batch_begin / _end: two batches queued back to back on one context (a third is refused), arm offsets
+    computed on the device (arm_off = NULL: the simulator lays arms back to back), results equal to the oracle's."""
+    bs = [sim.window_batch(3000, seed=61), sim.window_batch(2500, seed=62, read_sub=0.01)]
+    offs = [b.slot_layout() for b in bs]
+    outs = [(np.zeros(int(o[-1]) + 1, np.uint8), np.zeros(b.n_windows, np.uint32), np.zeros(b.n_windows, np.uint8)) for b, o in zip(bs, offs)]
+    t0, k0 = gpu.poa_batch_begin(bs[0], offs[0], *outs[0], no_arm_off=True)
+    t1, k1 = gpu.poa_batch_begin(bs[1], offs[1], *outs[1], no_arm_off=True)
+    assert {t0, t1} == {0, 1}
+    with pytest.raises(capi.HypoGpuError):
+        gpu.poa_batch_begin(bs[0], offs[0], *outs[0])
+    gpu.poa_batch_end(t1)
+    gpu.poa_batch_end(t0)
+    with pytest.raises(capi.HypoGpuError):
+        gpu.poa_batch_end(t0)
+    for b, off, (bases, ln, st) in zip(bs, offs, outs):
+        ob, _, oln, ost, _, _ = oracle_lib.poa_batch_raw(b, off=off)
+        assert (st == ost).all() and (ln == oln).all() and _same_consensus(bases, ob, off, ln)
