@@ -56,7 +56,7 @@ struct Ctx {
     // device buffers, workspace, stream and side streams, so the upload of one overlaps the kernels of the other.  Slot 0's
     // stream is `stream` (also used by the scan and by hypo_gpu_poa_batch_sharded).
     struct Slot {
-        DevBuf arena[10]; hypo::PoaAux aux; hipStream_t stream = nullptr; bool busy = false; uint32_t n = 0; HypoPoaStats stats;
+        DevBuf arena[10]; hypo::PoaAux aux; hipStream_t stream = nullptr; bool busy = false; uint32_t n = 0; HypoPoaStats* stats_pinned = nullptr;
     } slots[2];
     DevBuf scan_arena[7];
     DevBuf solid_set; uint32_t solid_k = 0;            // hypo_gpu_solid_set_upload
@@ -150,7 +150,7 @@ static void release_ctx(Ctx& c) {
         (void)hipDeviceSynchronize();
         for (auto& pc : c.prof.calls) for (auto& e : pc.ke.ev) if (e) (void)hipEventDestroy(e);
         c.prof.calls.clear(); c.prof.used = 0;
-        for (auto& sl : c.slots) { hypo::poa_release(&sl.aux); for (auto& a : sl.arena) a.release(); sl.busy = false; }
+        for (auto& sl : c.slots) { hypo::poa_release(&sl.aux); for (auto& a : sl.arena) a.release(); sl.busy = false; if (sl.stats_pinned) (void)hipHostFree(sl.stats_pinned); sl.stats_pinned = nullptr; }
         if (c.slots[1].stream) (void)hipStreamDestroy(c.slots[1].stream);
         c.slots[0].stream = c.slots[1].stream = nullptr;
         for (auto& a : c.scan_arena) a.release();
@@ -182,8 +182,7 @@ int hypo_gpu_init(const int* device_ids, int n_devices) {
         if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
             return fail(HYPO_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device_ids[i], prop.gcnArchName);
         HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&c.slots[1].stream, hipStreamNonBlocking));
-        c.slots[0].stream = c.stream;
+        c.slots[0].stream = c.stream;                      // (slot 1's stream is created when a second batch is first put in flight)
         c.device = device_ids[i]; c.num_cus = prop.multiProcessorCount; c.ready = true;
         g_nctx = i + 1;
     }
@@ -319,7 +318,6 @@ int hypo_gpu_poa_batch_begin(const HypoScoreParams* scores, const HypoWindowBatc
     if (si < 0) return fail(HYPO_E_INVALID, "two batches are already in flight on this context: call hypo_gpu_poa_batch_end first");
     Ctx::Slot& S = g_ctx.slots[si];
     S.n = n;
-    memset(&S.stats, 0, sizeof(S.stats));
     *ticket = si;
     S.busy = true;
     if (n == 0) return HYPO_OK;
@@ -337,6 +335,8 @@ int hypo_gpu_poa_batch_begin(const HypoScoreParams* scores, const HypoWindowBatc
     HIP_TRY_S(dAL.alloc((size_t)na * 4)); HIP_TRY_S(dA.alloc(in->arms2_bytes));
     HIP_TRY_S(dB.alloc(out_bytes)); HIP_TRY_S(dO.alloc((size_t)(n + 1) * 8)); HIP_TRY_S(dL.alloc((size_t)n * 4));
     HIP_TRY_S(dS.alloc(n)); HIP_TRY_S(dWS.alloc(wsb));
+    if (!S.stream) HIP_TRY_S(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
+    if (!S.stats_pinned) HIP_TRY_S(hipHostMalloc((void**)&S.stats_pinned, sizeof(HypoPoaStats), hipHostMallocDefault));
     hipStream_t st = S.stream;
     HIP_TRY_S(hipMemcpyAsync(dW.p, in->windows, (size_t)n * sizeof(HypoWindow), hipMemcpyHostToDevice, st));
     HIP_TRY_S(hipMemcpyAsync(dD.p, in->draft4, in->draft4_bytes, hipMemcpyHostToDevice, st));
@@ -353,11 +353,13 @@ int hypo_gpu_poa_batch_begin(const HypoScoreParams* scores, const HypoWindowBatc
     HypoConsensusBatch dout;
     dout.bases = (char*)dB.p; dout.off = (const uint64_t*)dO.p; dout.len = (uint32_t*)dL.p; dout.status = (uint8_t*)dS.p;
     hypo::PoaParams P = make_params(scores, &din, &dout);
-    HIP_TRY_S(hypo::poa_run(P, n, dWS.p, wsb, g_ctx.num_cus, st, nullptr, &S.aux));
+    // both slots share the side streams, events and plan history of slot 0: the runtime maps streams onto a handful of hardware
+    // queues, and every extra stream ends up sharing one with a size-class kernel (measured: classes 0 and 1 serialised)
+    HIP_TRY_S(hypo::poa_run(P, n, dWS.p, wsb, g_ctx.num_cus, st, nullptr, &g_ctx.slots[0].aux));
     HIP_TRY_S(hipMemcpyAsync(out->bases, dB.p, out_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY_S(hipMemcpyAsync(out->len, dL.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY_S(hipMemcpyAsync(out->status, dS.p, n, hipMemcpyDeviceToHost, st));
-    HIP_TRY_S(hipMemcpyAsync(&S.stats, (char*)dWS.p + 128, sizeof(HypoPoaStats), hipMemcpyDeviceToHost, st));
+    HIP_TRY_S(hipMemcpyAsync(S.stats_pinned, (char*)dWS.p + 128, sizeof(HypoPoaStats), hipMemcpyDeviceToHost, st));   // (page-locked: a copy into pageable memory would wait for the whole batch here)
 #undef HIP_TRY_S
     return HYPO_OK;
 }
@@ -371,7 +373,7 @@ int hypo_gpu_poa_batch_end(int ticket) {
     HYPO_LOCKED();
     S.busy = false;
     if (e != hipSuccess) return fail(HYPO_E_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
-    tl_stats = S.stats;
+    if (S.n && S.stats_pinned) tl_stats = *S.stats_pinned; else memset(&tl_stats, 0, sizeof(tl_stats));
     tl_stats.n_windows = S.n;
     return HYPO_OK;
 }
