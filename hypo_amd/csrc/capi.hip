@@ -60,6 +60,7 @@ struct Ctx {
     } slots[2];
     DevBuf scan_arena[7];
     DevBuf solid_set; uint32_t solid_k = 0;            // hypo_gpu_solid_set_upload
+    int poa_flags = 0;                                 // hypo_gpu_set_option
     std::vector<HypoWindow> sh_win; std::vector<uint64_t> sh_aoff, sh_off;   // rebased descriptors of this device's share (hypo_gpu_poa_batch_sharded)
     Prof prof;
     std::recursive_mutex mu;                           // recursive: the host-buffer variants call the device variants
@@ -128,6 +129,7 @@ hypo::PoaParams make_params(const HypoScoreParams* s, const HypoWindowBatch* in,
     P.sr_m = s->sr_match; P.sr_n = s->sr_mismatch; P.sr_g = s->sr_gap;
     P.lr_m = s->lr_match; P.lr_n = s->lr_mismatch; P.lr_g = s->lr_gap;
     P.n_arms = in->n_arms; P.draft4_bytes = in->draft4_bytes; P.arms2_bytes = in->arms2_bytes;
+    P.flags = g_ctx.poa_flags;
     return P;
 }
 
@@ -189,6 +191,15 @@ int hypo_gpu_init(const int* device_ids, int n_devices) {
     HIP_TRY(hipSetDevice(g_ctxs[0].device));
     tl_slot = 0;
     return HYPO_OK;
+}
+
+int hypo_gpu_set_option(const char* name, int value) {
+    if (!name) return fail(HYPO_E_INVALID, "NULL option name");
+    if (!strcmp(name, "native_klov")) {                  // all contexts: the mode belongs to the run, not to a device
+        for (int i = 0; i < kMaxDevices; ++i) g_ctxs[i].poa_flags = (g_ctxs[i].poa_flags & ~hypo::POA_NATIVE_KLOV) | (value ? hypo::POA_NATIVE_KLOV : 0);
+        return HYPO_OK;
+    }
+    return fail(HYPO_E_INVALID, "unknown option %s", name);
 }
 
 int hypo_gpu_use_device(int slot) {
@@ -525,7 +536,7 @@ int hypo_gpu_poa_batch_sharded(const HypoScoreParams* scores, const HypoWindowBa
         P.out_len = (uint32_t*)dL.p + S.w0; P.out_status = (uint8_t*)dS.p + S.w0;
         P.sr_m = scores->sr_match; P.sr_n = scores->sr_mismatch; P.sr_g = scores->sr_gap;
         P.lr_m = scores->lr_match; P.lr_n = scores->lr_mismatch; P.lr_g = scores->lr_gap;
-        P.n_arms = a1 - a0; P.draft4_bytes = d1 - d0; P.arms2_bytes = b1 - b0;
+        P.n_arms = a1 - a0; P.draft4_bytes = d1 - d0; P.arms2_bytes = b1 - b0; P.flags = c.poa_flags;
         if ((e = hypo::poa_run(P, nw, dWS.p, wsb, c.num_cus, st, nullptr, &c.slots[0].aux)) != hipSuccess) return bad(HYPO_E_HIP, "poa_run", e);
         (void)hipMemcpyAsync(&S.st, (char*)dWS.p + 128, sizeof(HypoPoaStats), hipMemcpyDeviceToHost, st);
         if (!use_rccl) {                                   // results of this share straight back to the caller's buffers

@@ -20,6 +20,8 @@ struct InputFlags {                        // include/globalDefs.hpp:68-87
     int device = 0;                        // new, opt-in: --device
     int gpus = 1;                          // new, opt-in: --gpus N (devices 0..N-1)
     std::vector<int> devices;              // new, opt-in: --devices a,b,c
+    bool native_klov = false;              // new, opt-in: --native-klov (match a -march=native build of the reference)
+    bool ccs_windows = false;              // new, opt-in: --ccs-windows (the window sizes -k ccs was meant to select)
 };
 
 enum class RegionType : uint8_t { SWS, SW, WS, MWM, MW, WM, SWM, MWS, OTHER, LONG, SR, MSR };   // globalDefs.hpp:95-108
@@ -41,7 +43,9 @@ struct ArmsSettings { uint32_t min_short_num = 3, min_internal_num1 = 20, min_in
 constexpr uint32_t kMinimizerRingCap = 32;        // monotone-queue slots of the minimizer scans (need w + 1)
 static const SrSettings Sr_settings;
 static const MinimizerSettings Minimizer_settings;
-static const WindowSettings Window_settings;     // `-k ccs` never changes it in the reference (src/main.cpp:312)
+// `-k ccs` never changes it in the reference (src/main.cpp:312 is a declaration, not a call); the opt-in --ccs-windows applies the
+// sizes set_kind("ccs") was meant to set (src/main.cpp:572-585)
+inline WindowSettings Window_settings;
 static const ArmsSettings Arms_settings;
 
 }  // namespace hypo

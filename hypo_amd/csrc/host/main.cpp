@@ -26,7 +26,8 @@ const struct option long_options[] = {
     {"qual-map-th", required_argument, nullptr, 'q'}, {"ned-th", required_argument, nullptr, 'n'},
     {"intermed", no_argument, nullptr, 'i'}, {"help", no_argument, nullptr, 'h'},
     {"device", required_argument, nullptr, 1000}, {"gpus", required_argument, nullptr, 1001},
-    {"devices", required_argument, nullptr, 1002}, {nullptr, 0, nullptr, 0}};
+    {"devices", required_argument, nullptr, 1002}, {"native-klov", no_argument, nullptr, 1003},
+    {"ccs-windows", no_argument, nullptr, 1004}, {nullptr, 0, nullptr, 0}};
 
 // Same layout as the reference's usage() (src/main.cpp:363-430): "Usage: hypo <args>", the mandatory block, the optional
 // block, every flag as "-x, --long <type>" followed by what it does and its default.  The wording is this build's own.
@@ -56,6 +57,8 @@ void usage() {
         {"    --device <int>", "[MI355X build] HIP device to run on.", "0"},
         {"    --gpus <int>", "[MI355X build] Use devices 0..N-1: the windows of a contig batch are sharded over them, results gathered with RCCL.", "1"},
         {"    --devices <list>", "[MI355X build] Comma-separated HIP device ids instead of --device / --gpus.", nullptr},
+        {"    --native-klov", "[MI355X build] Choose the end row of prefix arms like the AVX2 / SSE4.1 alignment engine of a -march=native build of the reference does (the default follows the scalar engine of the reference's default build; the two differ on noisy prefix arms).", "off"},
+        {"    --ccs-windows", "[MI355X build] Cut windows with the sizes -k ccs was meant to select (ideal length 500, search threshold 400; the reference parses -k but never applies it).", "off"},
         {"-h, --help", "Print the usage.", nullptr}};
     std::printf("\n Usage: hypo <args>\n\n ** Mandatory args:\n");
     for (const auto& e : mandatory) std::printf("\t%s\n\t%s\n\n", e.flag, e.what);
@@ -138,6 +141,8 @@ int main(int argc, char** argv) {
             case 'i': flags.intermed = true; break;
             case 1000: flags.device = std::atoi(optarg); break;
             case 1001: flags.gpus = std::max(1, std::atoi(optarg)); break;
+            case 1003: flags.native_klov = true; break;
+            case 1004: flags.ccs_windows = true; break;
             case 1002: {
                 flags.devices.clear();
                 for (const char* c = optarg; *c;) { flags.devices.push_back(std::atoi(c)); while (*c && *c != ',') ++c; if (*c == ',') ++c; }
@@ -174,6 +179,8 @@ int main(int argc, char** argv) {
         else flags.devices.push_back(flags.device);
     }
     if (hypo_gpu_init(flags.devices.data(), (int)flags.devices.size()) != HYPO_OK) { std::fprintf(stderr, "[Hypo::] Error: %s\n", hypo_gpu_last_error()); return 1; }
+    if (flags.native_klov && hypo_gpu_set_option("native_klov", 1) != HYPO_OK) { std::fprintf(stderr, "[Hypo::] Error: %s\n", hypo_gpu_last_error()); return 1; }
+    if (flags.ccs_windows) { hypo::Window_settings.ideal_swind_size = 500; hypo::Window_settings.wind_size_search_th = 400; }   // src/main.cpp:577-580
     if (timing) std::fprintf(stderr, "[timing] main: device initialised at %.3f s\n", since());
     {
         hypo::Hypo h(flags);

@@ -71,7 +71,11 @@ struct PoaParams {
     uint8_t* out_status;
     int sr_m, sr_n, sr_g, lr_m, lr_n, lr_g;
     uint64_t n_arms, draft4_bytes, arms2_bytes;          // buffer sizes: descriptors are checked against them (RES_INVALID)
+    int flags;                                           // POA_NATIVE_KLOV
 };
+// opt-in: rank kLOV end rows by the maximum over the whole row, like the AVX2 / SSE4.1 engine of a -march=native build of the
+// reference does (simd_alignment_engine.cpp:803,834-840; traceback still starts in column L, :859-861)
+enum { POA_NATIVE_KLOV = 1 };
 
 // How the per-window code reaches PoaParams.  On the device it is a pointer into the kernel-argument segment
 // (constant address space) that is made opaque at every use, so each use is a fresh scalar load instead of nine
@@ -549,6 +553,24 @@ struct Poa {
         const int le = L / CPL, ce = L % CPL;               // owner of the last column
         const int ce_shift = 16 * (ce & 1);
         int best = NEG, best_i = -1;
+        // native kLOV flavour: a row's end value is its maximum over columns 1..L (every lane then holds the same value)
+        const bool native_lov = mode == MODE_LOV && (P->flags & POA_NATIVE_KLOV) != 0;
+        auto end_value = [&](const P2 (&v)[NP]) -> int {
+            if (native_lov) {
+                int mx = NEG;
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) {
+                    const int c0 = j0 + 2 * q;
+                    if (c0 >= 1 && c0 <= L) { const int x = pk_lo(v[q]); mx = x > mx ? x : mx; }
+                    if (c0 + 1 >= 1 && c0 + 1 <= L) { const int x = pk_hi(v[q]); mx = x > mx ? x : mx; }
+                }
+                return g.reduce_max(mx);
+            }
+            int w = pk_bits(v[0]);
+            HYPO_UNROLL
+            for (int q = 1; q < NP; ++q) if (ce / 2 == q) w = pk_bits(v[q]);
+            return (int)(int16_t)(uint16_t)((uint32_t)w >> ce_shift);     // column L: meaningful in lane `le` only
+        };
         int wslotS = 0, scount = 0, rowS = 0;               // ring write slot * S, rows saved so far, r * S
         const int RS = R * S;
         const bool lov = mode == MODE_LOV;                   // kLOV: every row's column L is an end-cell candidate
@@ -627,10 +649,7 @@ struct Poa {
                 else *(uint32_t*)dst = codes;                // NP == 4 (NP == 3 is not instantiated)
                 if (lov) {                                   // end cell: first strictly greater in rank order; only lane `le` counts
                     HYPO_NO_IFCVT();
-                    int w = pk_bits(v[0]);
-                    HYPO_UNROLL
-                    for (int q = 1; q < NP; ++q) if (ce / 2 == q) w = pk_bits(v[q]);
-                    const int val = (int)(int16_t)(uint16_t)((uint32_t)w >> ce_shift);
+                    const int val = end_value(v);
                     best_i = val > best ? i : best_i;
                     best = val > best ? val : best;
                 }
@@ -725,12 +744,9 @@ struct Poa {
             for (int q = 0; q < NP; ++q) LAST[q] = v[q];
             // end cell: first strictly greater in rank order (sisd..cpp:279-288,332-339)
             if (mode == MODE_LOV || meta_sink(meta)) {
-                if (g.lane == le) {
-                    int val = pk_lo(v[0]);
-                    HYPO_UNROLL
-                    for (int c = 1; c < CPL; ++c) if (c == ce) val = (c & 1) ? pk_hi(v[c / 2]) : pk_lo(v[c / 2]);
-                    if (val > best) { best = val; best_i = i; }
-                }
+                const int val = end_value(v);                // (all lanes keep score; lane `le` is the one that is read)
+                best_i = val > best ? i : best_i;
+                best = val > best ? val : best;
             }
             g.sync();
         }
@@ -1326,7 +1342,13 @@ struct Poa {
             // end cell: first strictly greater in rank order (sisd..cpp:279-288,332-339)
             if (mode == MODE_LOV || sink) {                  // group-uniform: most rows of kNW / kROV skip it
                 HYPO_NO_IFCVT();
-                if (g.lane == le) {
+                if (mode == MODE_LOV && (P->flags & POA_NATIVE_KLOV)) {      // native flavour: maximum over columns 1..L of the row
+                    int mx = NEG;
+                    HYPO_UNROLL
+                    for (int c = 0; c < CPL; ++c) if (j0 + c >= 1 && j0 + c <= L) mx = v[c] > mx ? v[c] : mx;
+                    const int val = g.reduce_max(mx);
+                    if (val > best) { best = val; best_i = i; }
+                } else if (g.lane == le) {
                     int val = v[0];
                     HYPO_UNROLL
                     for (int c = 1; c < CPL; ++c) if (c == ce) val = v[c];

@@ -19,6 +19,8 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+
+static volatile int g_native_klov = 0;     /* oracle_set_native_klov */
 #endif
 
 /* ------------------------------------------------------------------------------------------------
@@ -373,7 +375,14 @@ static void eng_align(engine* E, const graph* g, const char* s, int L, int mode,
         int is_end = 0;
         if (mode == ORACLE_LOV) is_end = 1;                                     /* :338-339 */
         else if (g->out[u].n == 0) is_end = 1;                                   /* :332-334 */
-        if (is_end && max_score < row[W - 1]) { max_score = row[W - 1]; max_i = i; max_j = W - 1; }
+        int endval = row[W - 1];
+        if (mode == ORACLE_LOV && g_native_klov) {
+            /* the AVX2 / SSE4.1 engine of a -march=native reference build ranks kLOV rows by the maximum over the whole row
+             * (columns 1..L; its padding columns never exceed column L) and still starts the traceback in column L
+             * (simd_alignment_engine.cpp:803,834-840,859-861) */
+            for (int j = 1; j < W; ++j) if (row[j] > endval) endval = row[j];
+        }
+        if (is_end && max_score < endval) { max_score = endval; max_i = i; max_j = W - 1; }
     }
 
     /* backtrack, sisd..cpp:344-438 */
@@ -573,6 +582,9 @@ static int window_consensus(wctx* c, const HypoScoreParams* sp, int type,
     }
     return conslen;
 }
+
+/* opt-in "native flavour": reproduce the kLOV row choice of the reference's SIMD engine (see oracle_align) */
+void oracle_set_native_klov(int on) { g_native_klov = on ? 1 : 0; }
 
 int oracle_num_threads(void) {
 #ifdef _OPENMP

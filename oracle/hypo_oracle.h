@@ -55,6 +55,8 @@ void oracle_unpack2(const uint8_t* src, uint32_t len, char* dst);
 void oracle_unpack4(const uint8_t* src, uint32_t len, char* dst);
 
 int oracle_num_threads(void);
+/* 1: kLOV end rows are ranked like the SIMD engine of a -march=native reference build ranks them (process-wide switch) */
+void oracle_set_native_klov(int on);
 
 #ifdef __cplusplus
 }

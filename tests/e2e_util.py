@@ -46,7 +46,8 @@ def make_inputs(name, outdir):
     elif a.get("contigs", 1) > 1:
         gen.generate_multi(str(outdir), a["seed"], a["G"], a["long"], a["k"], a["contigs"])
     else:
-        gen.generate(str(outdir), a["seed"], a["G"], a["long"], a["k"])
+        kw = {k: a[k] for k in ("read_len", "read_sub") if k in a}            # HiFi-like reads of the --ccs-windows set
+        gen.generate(str(outdir), a["seed"], a["G"], a["long"], a["k"], **kw)
     for f, want in man["inputs_md5"].items():
         assert _md5(os.path.join(outdir, f)) == want, f"{name}: regenerated {f} differs from the golden's input"
     return man

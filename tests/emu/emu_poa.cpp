@@ -170,6 +170,7 @@ extern "C" int emu_poa_batch(const HypoScoreParams* sp, const HypoWindowBatch* i
     P.sr_m = sp->sr_match; P.sr_n = sp->sr_mismatch; P.sr_g = sp->sr_gap;
     P.lr_m = sp->lr_match; P.lr_n = sp->lr_mismatch; P.lr_g = sp->lr_gap;
     P.n_arms = in->n_arms; P.draft4_bytes = in->draft4_bytes; P.arms2_bytes = in->arms2_bytes;
+    P.flags = getenv("HYPO_EMU_NATIVE_KLOV") ? hypo::POA_NATIVE_KLOV : 0;
     *cells = 0; *aligns = 0;
     switch (cfg_id) {
 #define HYPO_CLASS_CASE(ID, CFG) case ID: return run_cfg<hypo::CFG>(P, in->n_windows, res, cells, aligns);

@@ -39,7 +39,8 @@ def rc(s):
     return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
 
 
-def generate(outdir, seed, G, with_long, K=11):
+def generate(outdir, seed, G, with_long, K=11, read_len=RL, read_sub=0.002):
+    """read_len / read_sub: HiFi-like reads for the --ccs-windows golden (defaults: the 150-bp short reads of every other set)"""
     random.seed(seed)
     truth = "".join(random.choice(A) for _ in range(G))
     ops = []                                     # (op, truth base, draft base)
@@ -59,11 +60,11 @@ def generate(outdir, seed, G, with_long, K=11):
     for i, o in enumerate(ops):
         dprefix[i + 1] = dprefix[i] + (1 if o[2] is not None else 0)
     gaps = [(g * G // 10 + 3000, g * G // 10 + 6000) for g in range(10)] if with_long else []
-    nreads = G * COV // RL
+    nreads = G * COV // read_len
     recs = []
     for n in range(nreads):
-        s = random.randrange(0, G - RL)
-        e = s + RL
+        s = random.randrange(0, G - read_len)
+        e = s + read_len
         if with_long and any(s < b and e > a for a, b in gaps):
             continue
         i0, i1 = tpos[s], tpos[e - 1] + 1
@@ -75,7 +76,7 @@ def generate(outdir, seed, G, with_long, K=11):
         for o in ops[i0:i1]:
             if o[0] in "MX":
                 b = o[1]
-                if random.random() < 0.002:
+                if random.random() < read_sub:
                     b = random.choice(A)
                 seq.append(b)
                 cig.append('M')

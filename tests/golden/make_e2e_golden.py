@@ -75,6 +75,9 @@ def main():
     extra = sys.argv[sys.argv.index("--extra") + 1] if "--extra" in sys.argv else ""        # e.g. "-p 2"
     ins = ["draft.fa", "sr.sam", "aux/solid_kmers.bvsd"] + (["lr.sam"] if is_long else [])
     args = {"seed": int(seed), "G": int(G), "k": int(k), "long": is_long}
+    if "--read-len" in sys.argv:                          # HiFi-like reads (gen_e2e.generate(read_len=, read_sub=))
+        args["read_len"] = int(sys.argv[sys.argv.index("--read-len") + 1])
+        args["read_sub"] = float(sys.argv[sys.argv.index("--read-sub") + 1])
     if nc > 1:
         args["contigs"] = nc
     man = {"generator": "tests/golden/gen_e2e.py", "args": args,

@@ -41,6 +41,7 @@ int hypo_gpu_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k, co
 
 /* the caller's buffer outlives the scans of a run (host/Hypo.cpp keeps the SolidKmers object alive) */
 int hypo_gpu_solid_set_upload(const uint64_t* bitset_words, uint32_t k) { g_set = bitset_words; g_set_k = k; return HYPO_OK; }
+int hypo_gpu_set_option(const char* name, int value) { if (name && !strcmp(name, "native_klov")) { oracle_set_native_klov(value); return HYPO_OK; } return HYPO_E_INVALID; }
 int hypo_gpu_num_devices(void) { return g_ready ? g_ndev : 0; }
 int hypo_gpu_use_device(int slot) { return slot >= 0 && slot < g_ndev ? HYPO_OK : HYPO_E_INVALID; }
 const char* hypo_gpu_build_id(void) { return "oracle_device_shim"; }

@@ -45,3 +45,11 @@ def test_e2e_two_device_contexts_shard_the_window_batch(built, tmp_path):
     man, p = eu.run_case("e2e_5ctg_long_s21", tmp_path, "shim", extra_args=["--gpus", "2"])
     assert "sharded call over 2 contexts" in p.stderr
     eu.check_outputs("e2e_5ctg_long_s21", tmp_path, man)
+
+
+def test_e2e_ccs_windows_match_the_reference_with_kind_ccs_applied(built, tmp_path):
+    """--ccs-windows: the window sizes `-k ccs` was meant to select (src/main.cpp:572-585; the reference parses -k and never
+    applies it, :312).  Golden from a scratch copy of the reference in which line 312 calls set_kind(kind), run with -k ccs on
+    3-kbp HiFi-like reads: 236 windows of ~ 500 bp, graphs of up to 546 nodes."""
+    man, _ = eu.run_case("e2e_120k_ccs_s47", tmp_path, "shim")
+    assert eu.check_outputs("e2e_120k_ccs_s47", tmp_path, man) > 200
