@@ -1,0 +1,32 @@
+#!/bin/bash
+# collect_round.sh <tag> — everything the round's DESIGN.md quotes, produced on the GPU box in one go:
+#   gpurun -- bash profiles/collect_round.sh r02
+# writes gpurun_out/<tag>/ (scratch); copy what should be judged into profiles/ (tracked).
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd $R
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+# kernel trace + counters of the bench's kernels (concurrent schedule = the product; sequential = every class alone)
+bash profiles/run_pmc.sh $TAG > /dev/null 2>&1
+python profiles/summarize_pmc.py gpurun_out/pmc_$TAG > $OUT/pmc_summary.csv
+python profiles/summarize_trace.py gpurun_out/pmc_$TAG/trace/trace_kernel_trace.csv > $OUT/kernel_launches.csv
+cp gpurun_out/pmc_$TAG/trace/trace_kernel_stats.csv $OUT/kernel_stats.csv
+HYPO_POA_SEQUENTIAL=1 bash profiles/run_pmc.sh ${TAG}_seq > /dev/null 2>&1
+python profiles/summarize_pmc.py gpurun_out/pmc_${TAG}_seq > $OUT/pmc_summary_sequential.csv
+python profiles/summarize_trace.py gpurun_out/pmc_${TAG}_seq/trace/trace_kernel_trace.csv > $OUT/kernel_launches_sequential.csv
+# per-phase cycle counters of the diagnostic build
+for sub in 0.002 0.01; do
+  python profiles/phase_profile.py 97078 $sub 2>&1 | grep -v "amdgpu.ids\|Warning\|print(" > $OUT/phase_profile_concurrent_$sub.txt
+  HYPO_POA_SEQUENTIAL=1 python profiles/phase_profile.py 97078 $sub 2>&1 | grep -v "amdgpu.ids\|Warning\|print(" > $OUT/phase_profile_sequential_$sub.txt
+done
+# rates on other shapes
+python profiles/err_rate.py hypo_amd/_build/libhypo_gpu.so 5 2>&1 | grep -v amdgpu.ids > $OUT/err_rate.txt
+python profiles/dense_rate.py 2>&1 | grep -v amdgpu.ids > $OUT/dense_rate.txt
+python profiles/hifi_rate.py 2>&1 | grep -v amdgpu.ids > $OUT/hifi_rate.txt
+python profiles/wide_rate.py 2>&1 | grep -v amdgpu.ids > $OUT/wide_rate.txt
+python profiles/long_rate.py 2>&1 | grep -v amdgpu.ids > $OUT/long_rate.txt
+(python profiles/scan_rate.py 100000000 13; python profiles/scan_rate.py 250000000 15; python profiles/scan_rate.py 512000000 17) 2>&1 | grep -v amdgpu.ids > $OUT/scan_rate.txt
+python profiles/diag/host_api_timeline.py 2>&1 | grep -v amdgpu.ids > $OUT/host_api_timeline.txt
+ls -la $OUT

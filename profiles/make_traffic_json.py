@@ -19,12 +19,17 @@ def entry(path, cls, n_windows):
             and r["kernel"].endswith("pass=0")]                           # main launch (pass 1 = mop-up launch of the same kernel)
     if not rows:
         raise SystemExit(f"class {cls}: kernel not found")
-    row = rows[0]
+    row = max(rows, key=lambda r: float(r.get("SQ_WAVE_CYCLES") or 0))      # the main launch (a mop-up launch with another grid size sorts first)
     f, w = float(row["FETCH_SIZE"]) * 1024, float(row["WRITE_SIZE"]) * 1024
     return {"kernel": f"poa_class_kernel<class {cls}>", "windows": n_windows,
             "hbm_bytes_per_launch": int(f + w), "fetch_bytes": int(f), "write_bytes": int(w),
             "fetch_bytes_if_wide_read_correction_applied": int(2 * f),
             "tcc_hit": float(row["TCC_HIT_sum"]), "tcc_miss": float(row["TCC_MISS_sum"]),
+            # issue side of the same launch (bench.py: roofline.valu)
+            "valu_insts": int(float(row.get("SQ_INSTS_VALU") or 0)), "salu_insts": int(float(row.get("SQ_INSTS_SALU") or 0)),
+            "lds_insts": int(float(row.get("SQ_INSTS_LDS") or 0)),
+            "wave_cycles_quad": int(float(row.get("SQ_WAVE_CYCLES") or 0)), "wait_any_quad": int(float(row.get("SQ_WAIT_ANY") or 0)),
+            "active_inst_any_quad": int(float(row.get("SQ_ACTIVE_INST_ANY") or 0)),
             "source": os.path.basename(path)}
 
 
