@@ -5,7 +5,7 @@ Reference types mirrored: ScoreParams (include/globalDefs.hpp:58-66), hypo::Wind
 """
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 HYPO_OK = 0
 HYPO_E_INVALID = -1
@@ -13,6 +13,8 @@ HYPO_E_NODEVICE = -2
 HYPO_E_HIP = -3
 HYPO_E_WORKSPACE = -4
 HYPO_E_NOTINIT = -5
+HYPO_E_CAPACITY = -6
+HYPO_E_UNSUPPORTED = -7
 
 ST_OK = 0
 ST_CONS_OVERFLOW = 1

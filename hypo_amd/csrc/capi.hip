@@ -11,6 +11,7 @@
 #include <vector>
 #include "../../include/hypo_gpu.h"
 #include "poa_kernel.hpp"
+#include "arms_kernel.hpp"
 #include "scan_kernel.hpp"
 
 namespace {
@@ -59,6 +60,8 @@ struct Ctx {
         DevBuf arena[10]; hypo::PoaAux aux; hipStream_t stream = nullptr; bool busy = false; uint32_t n = 0; HypoPoaStats* stats_pinned = nullptr;
     } slots[2];
     DevBuf scan_arena[7];
+    // resident window batch of hypo_gpu_arms_build (inputs, work arrays, the batch, consensus slots, POA workspace)
+    DevBuf arms_arena[5]; HypoArmsSummary arms_sum{}; bool arms_ready = false; hypo::ArmsOut arms_out{};
     DevBuf solid_set; uint32_t solid_k = 0;            // hypo_gpu_solid_set_upload
     int poa_flags = 0;                                 // hypo_gpu_set_option
     std::vector<HypoWindow> sh_win; std::vector<uint64_t> sh_aoff, sh_off;   // rebased descriptors of this device's share (hypo_gpu_poa_batch_sharded)
@@ -156,6 +159,8 @@ static void release_ctx(Ctx& c) {
         if (c.slots[1].stream) (void)hipStreamDestroy(c.slots[1].stream);
         c.slots[0].stream = c.slots[1].stream = nullptr;
         for (auto& a : c.scan_arena) a.release();
+        for (auto& a : c.arms_arena) a.release();
+        c.arms_ready = false;
         c.solid_set.release(); c.solid_k = 0;
         if (c.stream) (void)hipStreamDestroy(c.stream);
     }
@@ -658,6 +663,178 @@ int hypo_gpu_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k, co
         if (cnt) HIP_TRY(hipMemcpy(kids, dKids.p, cnt * 8, hipMemcpyDeviceToHost));
     }
     if (n_solid) *n_solid = ns;
+    return HYPO_OK;
+}
+
+// ---- arm selection on the device (kernels in arms_kernel.hip) ------------------------------------------
+namespace {
+struct Carver {                                       // lays arrays out in one device buffer, 256-byte aligned
+    size_t at = 0;
+    size_t take(size_t bytes) { const size_t o = at; at += (bytes + 255) / 256 * 256; return o; }
+};
+}
+
+int hypo_gpu_arms_build(const HypoArmsRegions* R, const HypoArmsReads* A, uint8_t* region_valid, HypoArmsSummary* sum) {
+    HYPO_LOCKED();
+    HYPO_ON_DEVICE();
+    if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
+    if (!R || !A || !region_valid || !sum) return fail(HYPO_E_INVALID, "NULL argument");
+    if (!R->n_regions || !R->start || !R->type || !R->info || !R->contig4 || (R->n_anchor_kmers && !R->anchor_kmers)) return fail(HYPO_E_INVALID, "NULL buffer in regions");
+    if (A->n_alignments && (!A->rb || !A->re || !A->qae || !A->seq_off || !A->reads2 || !A->cigar_off || !A->cigar)) return fail(HYPO_E_INVALID, "NULL buffer in reads");
+    if (R->k < 2 || R->k > 31) return fail(HYPO_E_INVALID, "k=%u out of range 2..31", R->k);
+    g_ctx.arms_ready = false;
+    const uint32_t nr = R->n_regions, na = A->n_alignments;
+    const uint64_t total_len = R->start[nr];
+    uint32_t max_span = 0;
+    for (uint32_t i = 0; i < nr; ++i) if (R->start[i] >= R->start[i + 1]) return fail(HYPO_E_INVALID, "region %u is empty or the starts are not increasing", i);
+    for (uint32_t a = 0; a < na; ++a) {
+        if (A->re[a] <= A->rb[a] || A->re[a] > total_len) return fail(HYPO_E_INVALID, "alignment %u: span [%u, %u) outside the %llu bases", a, A->rb[a], A->re[a], (unsigned long long)total_len);
+        if (a && A->rb[a - 1] > A->rb[a]) return fail(HYPO_E_INVALID, "alignments are not sorted by reference start (alignment %u)", a);
+        if (A->seq_off[a] + ((uint64_t)A->qae[a] + 3) / 4 > A->reads2_bytes) return fail(HYPO_E_INVALID, "alignment %u: read outside reads2", a);
+        if (A->cigar_off[a] > A->cigar_off[a + 1]) return fail(HYPO_E_INVALID, "alignment %u: cigar_off decreases", a);
+        const uint32_t span = A->re[a] - A->rb[a];
+        max_span = span > max_span ? span : max_span;
+    }
+    const uint64_t n_cig = na ? A->cigar_off[na] : 0;
+    hipStream_t st = g_ctx.stream;
+    DevBuf &dIn = g_ctx.arms_arena[0], &dWork = g_ctx.arms_arena[1], &dBatch = g_ctx.arms_arena[2];
+    // inputs
+    Carver ci;
+    const size_t o_start = ci.take((size_t)(nr + 1) * 4), o_type = ci.take(nr + 1), o_info = ci.take((size_t)(nr + 1) * 4),
+                 o_anchor = ci.take(R->n_anchor_kmers * 8), o_contig = ci.take((total_len + 1) / 2), o_rb = ci.take((size_t)na * 4), o_re = ci.take((size_t)na * 4),
+                 o_qae = ci.take((size_t)na * 4), o_soff = ci.take((size_t)na * 8), o_reads = ci.take(A->reads2_bytes), o_coff = ci.take((size_t)(na + 1) * 4),
+                 o_cig = ci.take(n_cig * 4);
+    HIP_TRY(dIn.alloc(ci.at));
+    char* in = (char*)dIn.p;
+#define UP(off, src, bytes) do { if (bytes) HIP_TRY(hipMemcpyAsync(in + (off), (src), (bytes), hipMemcpyHostToDevice, st)); } while (0)
+    UP(o_start, R->start, (size_t)(nr + 1) * 4); UP(o_type, R->type, (size_t)nr + 1); UP(o_info, R->info, (size_t)(nr + 1) * 4);
+    UP(o_anchor, R->anchor_kmers, R->n_anchor_kmers * 8); UP(o_contig, R->contig4, (total_len + 1) / 2);
+    UP(o_rb, A->rb, (size_t)na * 4); UP(o_re, A->re, (size_t)na * 4); UP(o_qae, A->qae, (size_t)na * 4); UP(o_soff, A->seq_off, (size_t)na * 8);
+    UP(o_reads, A->reads2, A->reads2_bytes); if (na) UP(o_coff, A->cigar_off, (size_t)(na + 1) * 4); UP(o_cig, A->cigar, n_cig * 4);
+#undef UP
+    hypo::ArmsIn I;
+    I.n_regions = nr; I.reg_start = (const uint32_t*)(in + o_start); I.reg_type = (const uint8_t*)(in + o_type); I.reg_info = (const uint32_t*)(in + o_info);
+    I.anchor_kmers = (const uint64_t*)(in + o_anchor); I.k = R->k; I.contig4 = (const uint8_t*)(in + o_contig);
+    I.n_alignments = na; I.rb = (const uint32_t*)(in + o_rb); I.re = (const uint32_t*)(in + o_re); I.qae = (const uint32_t*)(in + o_qae);
+    I.seq_off = (const uint64_t*)(in + o_soff); I.reads2 = (const uint8_t*)(in + o_reads); I.cigar_off = (const uint32_t*)(in + o_coff);
+    I.cigar = (const uint32_t*)(in + o_cig); I.max_span = max_span;
+    // work arrays that do not depend on the number of touched regions
+    Carver cw;
+    const size_t scan_n = nr > na ? nr : na;
+    const size_t w_bind = cw.take((size_t)na * 4), w_nt = cw.take((size_t)na * 4), w_toff = cw.take((size_t)na * 8), w_bsum = cw.take(hypo::scan32_scratch_bytes(scan_n)),
+                 w_tot = cw.take(64), w_flags = cw.take((size_t)nr * 4), w_valid = cw.take((size_t)nr * 4), w_counts = cw.take((size_t)nr * 16),
+                 w_arms = cw.take((size_t)nr * 4), w_bytes = cw.take((size_t)nr * 4), w_bint = cw.take((size_t)nr * 4), w_bpre = cw.take((size_t)nr * 4),
+                 w_dbytes = cw.take((size_t)nr * 4), w_slot = cw.take((size_t)nr * 4), w_winoff = cw.take((size_t)nr * 8), w_armoff = cw.take((size_t)nr * 8),
+                 w_byteoff = cw.take((size_t)nr * 8), w_droff = cw.take((size_t)nr * 8), w_slotoff = cw.take((size_t)nr * 8), w_widx = cw.take((size_t)nr * 4);
+    const size_t fixed_work = cw.at;
+    // the candidate arrays follow: a read of span s touches at most s / (shortest region) + 2 regions; sized after phase 1
+    HIP_TRY(dWork.alloc(fixed_work));
+    char* wk = (char*)dWork.p;
+    uint64_t* tot = (uint64_t*)(wk + w_tot);             // [0] touched regions, [1] windows, [2] arms, [3] arm bytes, [4] draft bytes, [5] slot bytes, [6] bad records
+    HIP_TRY(hipMemsetAsync(tot, 0, 64, st));
+    HIP_TRY(hypo::arms_phase1(I, (uint32_t*)(wk + w_bind), (uint32_t*)(wk + w_nt), (uint32_t*)(tot + 6), st));
+    HIP_TRY(hypo::scan32((const uint32_t*)(wk + w_nt), na, (uint64_t*)(wk + w_toff), (uint64_t*)(wk + w_bsum), tot + 0, st));
+    uint64_t h_tot[8] = {0};
+    HIP_TRY(hipMemcpyAsync(h_tot, tot, 64, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (h_tot[6]) return fail(HYPO_E_INVALID, "%llu alignment record(s) whose CIGAR disagrees with their span / aligned length", (unsigned long long)h_tot[6]);
+    const uint64_t n_touch = h_tot[0];
+    // candidates (in a buffer of their own: growing dWork would move the arrays phase 1 filled)
+    DevBuf& dCand = g_ctx.arms_arena[3];
+    Carver cc;
+    const size_t c_bp = cc.take(n_touch * 4), c_cand = cc.take(n_touch * 8);
+    HIP_TRY(dCand.alloc(cc.at));
+    char* cd = (char*)dCand.p;
+    hypo::ArmsOut O{};
+    O.reg_flags = (uint32_t*)(wk + w_flags); O.reg_valid = (uint32_t*)(wk + w_valid); O.reg_counts = (uint4*)(wk + w_counts); O.reg_arms = (uint32_t*)(wk + w_arms);
+    O.reg_bytes = (uint32_t*)(wk + w_bytes); O.reg_bytes_int = (uint32_t*)(wk + w_bint); O.reg_bytes_pre = (uint32_t*)(wk + w_bpre);
+    O.reg_draft_bytes = (uint32_t*)(wk + w_dbytes); O.reg_slot = (uint32_t*)(wk + w_slot);
+    O.reg_arm_off = (const uint64_t*)(wk + w_armoff); O.reg_byte_off = (const uint64_t*)(wk + w_byteoff); O.reg_draft_off = (const uint64_t*)(wk + w_droff);
+    O.reg_slot_off = (const uint64_t*)(wk + w_slotoff); O.win_index = (uint32_t*)(wk + w_widx);
+    HIP_TRY(hypo::arms_phase2(I, (const uint32_t*)(wk + w_bind), (const uint32_t*)(wk + w_nt), (const uint64_t*)(wk + w_toff), (uint32_t*)(cd + c_bp), (uint2*)(cd + c_cand), O, st));
+    uint64_t* bsum = (uint64_t*)(wk + w_bsum);
+    HIP_TRY(hypo::scan32(O.reg_valid, nr, (uint64_t*)(wk + w_winoff), bsum, tot + 1, st));
+    HIP_TRY(hypo::scan32(O.reg_arms, nr, (uint64_t*)(wk + w_armoff), bsum, tot + 2, st));
+    HIP_TRY(hypo::scan32(O.reg_bytes, nr, (uint64_t*)(wk + w_byteoff), bsum, tot + 3, st));
+    HIP_TRY(hypo::scan32(O.reg_draft_bytes, nr, (uint64_t*)(wk + w_droff), bsum, tot + 4, st));
+    HIP_TRY(hypo::scan32(O.reg_slot, nr, (uint64_t*)(wk + w_slotoff), bsum, tot + 5, st));
+    HIP_TRY(hipMemcpyAsync(h_tot, tot, 64, hipMemcpyDeviceToHost, st));
+    std::vector<uint32_t> valid32(nr);
+    HIP_TRY(hipMemcpyAsync(valid32.data(), O.reg_valid, (size_t)nr * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (uint32_t i = 0; i < nr; ++i) region_valid[i] = (uint8_t)valid32[i];
+    const uint64_t n_win = h_tot[1], n_arms = h_tot[2], arm_bytes = h_tot[3], draft_bytes = h_tot[4], slot_bytes = h_tot[5];
+    if (n_arms > 0xfff00000ull || n_win > 0x7fffffffull)
+        return fail(HYPO_E_CAPACITY, "%llu windows / %llu arms exceed the 32-bit counters of the boundary", (unsigned long long)n_win, (unsigned long long)n_arms);
+    // the batch
+    Carver cb;
+    const size_t b_win = cb.take(n_win * sizeof(HypoWindow)), b_wreg = cb.take(n_win * 4), b_alen = cb.take(n_arms * 4), b_aoff = cb.take(n_arms * 8),
+                 b_arms2 = cb.take(arm_bytes + 16), b_draft = cb.take(draft_bytes + 16), b_ooff = cb.take((n_win + 1) * 8);
+    HIP_TRY(dBatch.alloc(cb.at));
+    char* bt = (char*)dBatch.p;
+    O.windows = (HypoWindow*)(bt + b_win); O.win_region = (uint32_t*)(bt + b_wreg); O.arm_len = (uint32_t*)(bt + b_alen); O.arm_off = (uint64_t*)(bt + b_aoff);
+    O.arms2 = (uint8_t*)(bt + b_arms2); O.draft4 = (uint8_t*)(bt + b_draft); O.out_off = (uint64_t*)(bt + b_ooff);
+    if (n_win) {
+        HIP_TRY(hypo::arms_phase3(I, (const uint32_t*)(wk + w_bind), (const uint32_t*)(wk + w_nt), (const uint64_t*)(wk + w_toff), (const uint2*)(cd + c_cand), O,
+                                  (const uint64_t*)(wk + w_winoff), st));
+        HIP_TRY(hipMemcpyAsync(O.out_off + n_win, tot + 5, 8, hipMemcpyDeviceToDevice, st));
+    }
+    sum->n_windows = (uint32_t)n_win; sum->n_arms = (uint32_t)n_arms; sum->arms2_bytes = arm_bytes; sum->draft4_bytes = draft_bytes; sum->out_bytes = slot_bytes;
+    g_ctx.arms_sum = *sum; g_ctx.arms_out = O; g_ctx.arms_ready = true;
+    return HYPO_OK;
+}
+
+int hypo_gpu_arms_download(HypoWindow* windows, uint32_t* win_region, uint32_t* arm_len, uint64_t* arm_off, uint8_t* arms2, uint8_t* draft4) {
+    HYPO_LOCKED();
+    HYPO_ON_DEVICE();
+    if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
+    if (!g_ctx.arms_ready) return fail(HYPO_E_INVALID, "no resident batch: call hypo_gpu_arms_build first");
+    const HypoArmsSummary& S = g_ctx.arms_sum; const hypo::ArmsOut& O = g_ctx.arms_out;
+    hipStream_t st = g_ctx.stream;
+    if (windows && S.n_windows) HIP_TRY(hipMemcpyAsync(windows, O.windows, (size_t)S.n_windows * sizeof(HypoWindow), hipMemcpyDeviceToHost, st));
+    if (win_region && S.n_windows) HIP_TRY(hipMemcpyAsync(win_region, O.win_region, (size_t)S.n_windows * 4, hipMemcpyDeviceToHost, st));
+    if (arm_len && S.n_arms) HIP_TRY(hipMemcpyAsync(arm_len, O.arm_len, (size_t)S.n_arms * 4, hipMemcpyDeviceToHost, st));
+    if (arm_off && S.n_arms) HIP_TRY(hipMemcpyAsync(arm_off, O.arm_off, (size_t)S.n_arms * 8, hipMemcpyDeviceToHost, st));
+    if (arms2 && S.arms2_bytes) HIP_TRY(hipMemcpyAsync(arms2, O.arms2, S.arms2_bytes, hipMemcpyDeviceToHost, st));
+    if (draft4 && S.draft4_bytes) HIP_TRY(hipMemcpyAsync(draft4, O.draft4, S.draft4_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return HYPO_OK;
+}
+
+int hypo_gpu_arms_poa(const HypoScoreParams* scores, char* bases, uint64_t* off, uint32_t* len, uint8_t* status) {
+    HYPO_LOCKED();
+    HYPO_ON_DEVICE();
+    if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
+    int rc = check_scores(scores);
+    if (rc) return rc;
+    if (!g_ctx.arms_ready) return fail(HYPO_E_INVALID, "no resident batch: call hypo_gpu_arms_build first");
+    const HypoArmsSummary& S = g_ctx.arms_sum; const hypo::ArmsOut& O = g_ctx.arms_out;
+    memset(&tl_stats, 0, sizeof(tl_stats));
+    const uint32_t n = S.n_windows;
+    if (!n) return HYPO_OK;
+    if (!bases || !off || !len || !status) return fail(HYPO_E_INVALID, "NULL buffer");
+    hipStream_t st = g_ctx.stream;
+    DevBuf& dOut = g_ctx.arms_arena[4];
+    Carver co;
+    const size_t wsb = hypo::poa_workspace_bytes(n, 64, 0);
+    const size_t o_bases = co.take(S.out_bytes + 16), o_len = co.take((size_t)n * 4), o_st = co.take(n), o_ws = co.take(wsb);
+    HIP_TRY(dOut.alloc(co.at));
+    char* ob = (char*)dOut.p;
+    HIP_TRY(hipMemsetAsync(ob + o_bases, 0, S.out_bytes + 16, st));
+    HypoWindowBatch din;
+    din.n_windows = n; din.n_arms = S.n_arms; din.windows = O.windows; din.draft4 = O.draft4; din.draft4_bytes = S.draft4_bytes;
+    din.arm_off = O.arm_off; din.arm_len = O.arm_len; din.arms2 = O.arms2; din.arms2_bytes = S.arms2_bytes;
+    HypoConsensusBatch dout;
+    dout.bases = ob + o_bases; dout.off = O.out_off; dout.len = (uint32_t*)(ob + o_len); dout.status = (uint8_t*)(ob + o_st);
+    hypo::PoaParams P = make_params(scores, &din, &dout);
+    HIP_TRY(hypo::poa_run(P, n, ob + o_ws, wsb, g_ctx.num_cus, st, nullptr, &g_ctx.slots[0].aux));
+    HIP_TRY(hipMemcpyAsync(bases, ob + o_bases, S.out_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(off, O.out_off, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(len, ob + o_len, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(status, ob + o_st, n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&tl_stats, ob + o_ws + 128, sizeof(HypoPoaStats), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    tl_stats.n_windows = n;
     return HYPO_OK;
 }
 

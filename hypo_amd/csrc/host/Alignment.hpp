@@ -48,6 +48,7 @@ public:
     }
 
 private:
+    friend class DeviceArms;
     uint32_t _rb = 0, _re = 0, _qab = 0, _qae = 0;
     PackedSeq<2> _apseq;
     std::vector<uint32_t> _cigar;

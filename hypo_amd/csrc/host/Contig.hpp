@@ -59,6 +59,7 @@ public:
     static void set_no_long_reads() { _no_long_reads = true; }
     friend std::ostream& operator<<(std::ostream&, const Contig&);
     friend class Alignment;
+    friend class DeviceArms;
 
     // scan results (Contig::_solid_pos / _kmerinfo[i]->kid)
     uint64_t get_num_solid() const { return _kids.size(); }

@@ -1,0 +1,161 @@
+// DeviceArms.cpp — see DeviceArms.hpp.
+#include "DeviceArms.hpp"
+#include <omp.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace hypo {
+
+bool DeviceArms::build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1,
+                       std::vector<std::vector<std::unique_ptr<Alignment>>>& store, unsigned k) {
+    _active = false;
+    if (hypo_gpu_num_devices() != 1) return false;
+    // one coordinate space for the whole contig batch: every contig starts on an even position (its PackedSeq<4> bytes are
+    // copied as they are); an odd-length contig is followed by a 1-base filler region of type SR
+    uint64_t total = 0, n_reg = 0, n_anchor = 0, n_aln = 0, n_cig = 0, read_bytes = 0;
+    for (uint32_t c = c0; c < c1; ++c) {
+        const Contig& ctg = *contigs[c];
+        total += ctg._len + (ctg._len & 1);
+        n_reg += ctg.get_num_regions() + (ctg._len & 1);
+        n_anchor += ctg._anchor_kmers.size();
+        n_aln += store[c].size();
+        uint32_t prev = 0;
+        for (const auto& a : store[c]) {
+            if (a->_rb < prev) { std::fprintf(stdout, "[Hypo::Hypo] Info: alignments are not sorted by position: short arms are computed on the host\n"); return false; }
+            prev = a->_rb;
+            n_cig += a->_cigar.size();
+            read_bytes += a->_apseq.byte_size();
+        }
+    }
+    if (total >= 0xfffffff0ull || n_reg >= 0xfffffff0ull || n_aln >= 0xfffffff0ull || n_cig >= 0xfffffff0ull || n_reg == 0) return false;
+    std::vector<uint32_t> start(n_reg + 1), info(n_reg + 1, 0);
+    std::vector<uint8_t> type(n_reg + 1, (uint8_t)RegionType::SR);
+    std::vector<uint64_t> anchors; anchors.reserve(n_anchor);
+    std::vector<uint8_t> contig4((total + 1) / 2, 0);
+    std::vector<uint32_t> rb(n_aln), re(n_aln), qae(n_aln), cigar_off(n_aln + 1), cigar(n_cig);
+    std::vector<uint64_t> seq_off(n_aln);
+    std::vector<uint8_t> reads2(read_bytes ? read_bytes : 1);
+    _reg_window.assign(n_reg, nullptr);
+    uint64_t base = 0, r = 0, a_at = 0;
+    std::vector<uint64_t> aln_base(c1 - c0 + 1, 0);
+    for (uint32_t c = c0; c < c1; ++c) {
+        Contig& ctg = *contigs[c];
+        const uint32_t nr = (uint32_t)ctg.get_num_regions();
+        // Contig::_anchor_kmers is [dummy, first k-mer of SR 1, last k-mer of SR 1, first of SR 2, ...] and the SR ranks start at 1:
+        // one dummy for the whole coordinate space, the ranks of later contigs shifted by the SRs before them
+        if (anchors.empty()) anchors.push_back(0);
+        const uint32_t sr_before = (uint32_t)((anchors.size() - 1) / 2);
+        for (uint32_t i = 0; i < nr; ++i, ++r) {
+            start[r] = (uint32_t)(base + ctg._reg_pos.select((uint64_t)i + 1));
+            type[r] = (uint8_t)ctg._reg_type[i];
+            info[r] = ctg._reg_info[i] + (ctg._reg_type[i] == RegionType::SR ? sr_before : 0u);
+            _reg_window[r] = ctg._pwindows[i].get();
+            if (type[r] != (uint8_t)RegionType::SR && type[r] != (uint8_t)RegionType::MSR && !_reg_window[r]) return false;   // (never: every non-SR region has a window here)
+        }
+        if (ctg._anchor_kmers.size() > 1) anchors.insert(anchors.end(), ctg._anchor_kmers.begin() + 1, ctg._anchor_kmers.end());
+        std::memcpy(contig4.data() + base / 2, ctg._pseq.data(), ctg._pseq.byte_size());
+        if (ctg._len & 1) { start[r] = (uint32_t)(base + ctg._len); type[r] = (uint8_t)RegionType::SR; info[r] = 0; ++r; }
+        aln_base[c - c0] = a_at;
+        a_at += store[c].size();
+        base += ctg._len + (ctg._len & 1);
+    }
+    start[r] = (uint32_t)total;
+    {   // alignments: offsets first (serial), then the copies on all threads
+        uint64_t at = 0, cg = 0, bytes = 0;
+        for (uint32_t c = c0; c < c1; ++c)
+            for (const auto& a : store[c]) { seq_off[at] = bytes; cigar_off[at] = (uint32_t)cg; bytes += a->_apseq.byte_size(); cg += a->_cigar.size(); ++at; }
+        cigar_off[at] = (uint32_t)cg;
+        uint64_t cbase = 0;
+        for (uint32_t c = c0; c < c1; ++c) {
+            const auto& alns = store[c];
+            const uint64_t a0 = aln_base[c - c0];
+#pragma omp parallel for schedule(static)
+            for (int64_t t = 0; t < (int64_t)alns.size(); ++t) {
+                const Alignment& a = *alns[(size_t)t];
+                const uint64_t g = a0 + (uint64_t)t;
+                rb[g] = (uint32_t)(cbase + a._rb); re[g] = (uint32_t)(cbase + a._re); qae[g] = a._qae;
+                std::memcpy(reads2.data() + seq_off[g], a._apseq.data(), a._apseq.byte_size());
+                std::memcpy(cigar.data() + cigar_off[g], a._cigar.data(), a._cigar.size() * 4);
+            }
+            cbase += contigs[c]->_len + (contigs[c]->_len & 1);
+        }
+    }
+    HypoArmsRegions R;
+    R.n_regions = (uint32_t)n_reg; R.start = start.data(); R.type = type.data(); R.info = info.data();
+    R.n_anchor_kmers = anchors.size(); R.anchor_kmers = anchors.data(); R.k = k; R.contig4 = contig4.data();
+    HypoArmsReads A;
+    A.n_alignments = (uint32_t)n_aln; A.rb = rb.data(); A.re = re.data(); A.qae = qae.data(); A.seq_off = seq_off.data();
+    A.reads2 = reads2.data(); A.reads2_bytes = read_bytes; A.cigar_off = cigar_off.data(); A.cigar = cigar.data();
+    std::vector<uint8_t> valid(n_reg, 0);
+    const int rc = hypo_gpu_arms_build(&R, &A, valid.data(), &_sum);
+    if (rc != HYPO_OK) {
+        if (rc != HYPO_E_UNSUPPORTED) std::fprintf(stdout, "[Hypo::Hypo] Info: short arms are computed on the host (%s)\n", hypo_gpu_last_error());
+        return false;
+    }
+    // what Contig::fill_short_windows leaves behind (src/Contig.cpp:249-289): pruned windows are gone, the anchors are freed
+    r = 0;
+    for (uint32_t c = c0; c < c1; ++c) {
+        Contig& ctg = *contigs[c];
+        const uint32_t nr = (uint32_t)ctg.get_num_regions();
+        for (uint32_t i = 0; i < nr; ++i, ++r)
+            if (ctg._pwindows[i] && !valid[r]) { ctg._pwindows[i].reset(); _reg_window[r] = nullptr; }
+        if (ctg._len & 1) ++r;
+        std::vector<uint64_t>().swap(ctg._anchor_kmers);
+        std::vector<uint32_t>().swap(ctg._reg_info);
+        store[c].clear();
+    }
+    std::fprintf(stdout, "[Hypo::Hypo] Info: short arms cut on the device: %u windows, %u arms\n", _sum.n_windows, _sum.n_arms);
+    _active = true;
+    return true;
+}
+
+void DeviceArms::adopt_arms(const std::vector<uint32_t>& which, const std::vector<HypoWindow>& hw, const std::vector<uint32_t>& win_region) {
+    std::vector<uint32_t> arm_len(_sum.n_arms);
+    std::vector<uint64_t> arm_off(_sum.n_arms);
+    std::vector<uint8_t> arms2(_sum.arms2_bytes ? _sum.arms2_bytes : 1);
+    if (hypo_gpu_arms_download(nullptr, nullptr, arm_len.data(), arm_off.data(), arms2.data(), nullptr) != HYPO_OK) {
+        std::fprintf(stderr, "[Hypo::Window] Error: %s\n", hypo_gpu_last_error()); std::exit(1);
+    }
+    for (uint32_t wi : which) {
+        Window& w = *_reg_window[win_region[wi]];
+        const HypoWindow& d = hw[wi];
+        uint32_t a = d.first_arm;
+        auto take = [&](uint32_t arm) { return PackedSeq<2>(arms2.data() + arm_off[arm], arm_len[arm]); };
+        for (uint32_t i = 0; i < d.n_internal; ++i) w.add_internal(take(a++));
+        for (uint32_t i = 0; i < d.n_prefix; ++i) w.add_prefix(take(a++));
+        for (uint32_t i = 0; i < d.n_suffix; ++i) w.add_suffix(take(a++));
+        w._num_empty = d.n_empty;
+    }
+}
+
+int DeviceArms::polish(const ScoreParams& sp, bool keep_arms) {
+    if (!_active) return HYPO_OK;
+    _active = false;
+    const uint32_t n = _sum.n_windows;
+    if (!n) return HYPO_OK;
+    std::vector<char> bases(_sum.out_bytes ? _sum.out_bytes : 1);
+    std::vector<uint64_t> off((size_t)n + 1);
+    std::vector<uint32_t> len(n), win_region(n);
+    std::vector<uint8_t> st(n);
+    std::vector<HypoWindow> hw(n);
+    int rc = hypo_gpu_arms_poa(&sp, bases.data(), off.data(), len.data(), st.data());
+    if (rc != HYPO_OK) return rc;
+    rc = hypo_gpu_arms_download(hw.data(), win_region.data(), nullptr, nullptr, nullptr, nullptr);
+    if (rc != HYPO_OK) return rc;
+    std::vector<uint32_t> again, all;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; ++i)
+        if (st[(size_t)i] == HYPO_ST_OK) _reg_window[win_region[(size_t)i]]->_consensus.assign(bases.data() + off[(size_t)i], len[(size_t)i]);
+    for (uint32_t i = 0; i < n; ++i) { if (st[i] != HYPO_ST_OK) again.push_back(i); if (keep_arms) all.push_back(i); }
+    if (keep_arms) adopt_arms(all, hw, win_region);
+    else if (!again.empty()) adopt_arms(again, hw, win_region);
+    if (!again.empty()) {          // a consensus longer than its slot, a window beyond the size classes: the host's retry / degraded path
+        std::vector<Window*> ws;
+        for (uint32_t i : again) ws.push_back(_reg_window[win_region[i]]);
+        rc = Window::generate_consensus_batch(ws);
+    }
+    return rc;
+}
+
+}  // namespace hypo

@@ -1,0 +1,32 @@
+// DeviceArms.hpp — host side of arm selection on the device (include/hypo_gpu.h: hypo_gpu_arms_*).
+// Flattens the regions of a contig batch and its short-read alignments into the arrays the C-ABI takes, lets the device cut
+// the reads into arms and prune the windows (what Alignment::find_short_arms + Contig::fill_short_windows do on the host,
+// src/Alignment.cpp:222-259, src/Contig.cpp:249-289), and later hands the consensus of the resident batch back to the Window
+// objects.  The windows never see their arms unless somebody asks (region dump, a window that needs the host's retry path).
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <vector>
+#include "Contig.hpp"
+
+namespace hypo {
+
+class DeviceArms {
+public:
+    // true: the windows of contigs [c0, c1) are pruned, their arms lie on the device and `store` is consumed; false: nothing
+    // was changed and the host path must run (several devices, an unsorted alignment file, a batch beyond 32-bit coordinates)
+    bool build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1,
+               std::vector<std::vector<std::unique_ptr<Alignment>>>& store, unsigned k);
+    bool active() const { return _active; }
+    // consensus of every SHORT window of the resident batch; `keep_arms`: also copy the arms into the Window objects
+    int polish(const ScoreParams& sp, bool keep_arms);
+    uint64_t num_windows() const { return _sum.n_windows; }
+
+private:
+    bool _active = false;
+    HypoArmsSummary _sum{};
+    std::vector<Window*> _reg_window;        // region of the coordinate space -> its window (nullptr: SR, filler, pruned)
+    void adopt_arms(const std::vector<uint32_t>& which, const std::vector<HypoWindow>& hw, const std::vector<uint32_t>& win_region);
+};
+
+}  // namespace hypo

@@ -1,5 +1,6 @@
 // Hypo.cpp — orchestration of one polishing run (reference: src/Hypo.cpp).
 #include "Hypo.hpp"
+#include "DeviceArms.hpp"
 #include <omp.h>
 #include <sys/resource.h>
 #include <thread>
@@ -120,16 +121,23 @@ void Hypo::polish() {
         stop("[Hypo:Hypo]: Division into windows. ");
 
         start();
-        for (uint32_t cid = initial_cid; cid < final_cid; ++cid) {
-            auto& alns = _alignment_store[cid];
+        // The device cuts the reads into arms, prunes the windows and keeps the window batch in its memory (DeviceArms.hpp);
+        // --host-arms, several devices or an unsorted alignment file take the host loops of the reference instead.
+        DeviceArms device_arms;
+        const bool on_device = !_cFlags.host_arms && device_arms.build(_contigs, initial_cid, final_cid, _alignment_store, _cFlags.k);
+        if (!on_device)
+            for (uint32_t cid = initial_cid; cid < final_cid; ++cid) {
+                auto& alns = _alignment_store[cid];
 #pragma omp parallel for
-            for (int64_t t = 0; t < (int64_t)alns.size(); ++t) alns[(size_t)t]->find_short_arms(_cFlags.k, *_contigs[cid]);
-        }
+                for (int64_t t = 0; t < (int64_t)alns.size(); ++t) alns[(size_t)t]->find_short_arms(_cFlags.k, *_contigs[cid]);
+            }
         stop("[Hypo:Hypo]: Short arms computing. ");
         start();
         // few contigs: the parallelism is inside a contig (window ranges); many contigs: one contig per thread as in the reference
+        if (!on_device) {
 #pragma omp parallel for schedule(static, 1) if (over_contigs)
-        for (int64_t i = initial_cid; i < (int64_t)final_cid; ++i) { _contigs[(size_t)i]->fill_short_windows(_alignment_store[(size_t)i]); _alignment_store[(size_t)i].clear(); }
+            for (int64_t i = initial_cid; i < (int64_t)final_cid; ++i) { _contigs[(size_t)i]->fill_short_windows(_alignment_store[(size_t)i]); _alignment_store[(size_t)i].clear(); }
+        }
         stop("[Hypo:Hypo]: Short arms filling. ");
 
         if (!_cFlags.lr_bam_filename.empty()) {
@@ -157,9 +165,11 @@ void Hypo::polish() {
         std::vector<Window*> wins;
         for (uint32_t i = initial_cid; i < final_cid; ++i)
             for (uint64_t w = 0; w < _contigs[i]->get_num_regions(); ++w)
-                if (_contigs[i]->is_valid_window((uint32_t)w)) wins.push_back(_contigs[i]->window((uint32_t)w));
+                if (_contigs[i]->is_valid_window((uint32_t)w) && !(on_device && !_contigs[i]->window((uint32_t)w)->is_long())) wins.push_back(_contigs[i]->window((uint32_t)w));
+        const uint64_t n_resident = on_device ? device_arms.num_windows() : 0;
+        if (device_arms.polish(_cFlags.score_params, dump.is_open()) != HYPO_OK) { std::fprintf(stderr, "[Hypo::Window] Error: %s\n", hypo_gpu_last_error()); std::exit(1); }
         if (Window::generate_consensus_batch(wins) != HYPO_OK) { std::fprintf(stderr, "[Hypo::Window] Error: %s\n", hypo_gpu_last_error()); std::exit(1); }
-        std::fprintf(stdout, "[Hypo::Hypo] Info: polished windows (Batch %u): %lu\n", batch_id, (unsigned long)wins.size());
+        std::fprintf(stdout, "[Hypo::Hypo] Info: polished windows (Batch %u): %lu\n", batch_id, (unsigned long)(wins.size() + n_resident));
         stop("[Hypo:Hypo]: POA of windows. ");
 
         if (dump.is_open())

@@ -48,6 +48,9 @@ public:
         }
     }
 
+    // adopts n bases already packed in this layout (an arm cut on the device: hypo_gpu_arms_download)
+    PackedSeq(const uint8_t* bytes, size_t n) : _data(bytes, bytes + (n + PER_BYTE - 1) / PER_BYTE), _len(n) {}
+
     bool is_valid() const { return _valid; }
     size_t get_seq_size() const { return _len; }
     uint8_t enc_base_at(size_t i) const { return (uint8_t)((_data[i / PER_BYTE] >> (8 - NB - NB * (int)(i % PER_BYTE))) & MASK); }

@@ -79,6 +79,7 @@ public:
     }
 
 private:
+    friend class DeviceArms;
     static int consensus_call(const ScoreParams& sp, const std::vector<Window*>& windows, const std::vector<uint32_t>* slot_hint,
                               std::vector<uint8_t>& st, std::vector<uint32_t>& len);
     WindowType _wtype = WindowType::SHORT;

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HYPO_GPU_ABI_VERSION 4
+#define HYPO_GPU_ABI_VERSION 5
 #define HYPO_MAX_DEVICES 16      /* contexts one process can hold (an MI355X node has 8 GPUs) */
 
 /* error codes */
@@ -42,6 +42,8 @@ extern "C" {
 #define HYPO_E_HIP          -3   /* a HIP call failed (message in hypo_gpu_last_error) */
 #define HYPO_E_WORKSPACE    -4   /* caller-provided workspace too small */
 #define HYPO_E_NOTINIT      -5
+#define HYPO_E_CAPACITY     -6   /* more than the 32-bit counters of the boundary hold: split the work */
+#define HYPO_E_UNSUPPORTED  -7   /* this build of the library does not provide the entry point (test shims) */
 
 /* per-window status byte written by the POA entry points */
 #define HYPO_ST_OK            0
@@ -226,6 +228,58 @@ typedef struct HypoPoaStats {
 int hypo_gpu_poa_last_stats(HypoPoaStats* out);
 /* Same for a _device call: synchronises the stream and copies the counters out of `workspace`. */
 int hypo_gpu_poa_read_stats(const void* workspace, void* hip_stream, HypoPoaStats* out);
+
+/* ---- Arm selection on the device ----------------------------------------------------------------------
+ * Replaces, for SHORT windows, the host loops that cut every mapped short read at the region borders and hand the pieces
+ * to the windows:
+ *   Alignment::find_short_arms / find_bp / prepare_short_arm   src/Alignment.cpp:222-259, 321-406, 408-511
+ *   Alignment::add_arms + Contig::fill_short_windows (pruning)  src/Alignment.cpp:301-318, src/Contig.cpp:249-289
+ * hypo_gpu_arms_build takes the regions of the contigs of one batch and their short-read alignments as flat host arrays,
+ * builds the HypoWindowBatch of the surviving windows IN DEVICE MEMORY (arms in alignment order: internal, prefix, suffix)
+ * and returns which regions kept a window; hypo_gpu_arms_poa polishes that resident batch (same kernels as
+ * hypo_gpu_poa_batch) and returns the consensus sequences; hypo_gpu_arms_download copies the batch to the host (region dump,
+ * tests, the rare windows that need the host's retry path).  One resident batch per context; the next build replaces it.
+ *
+ * Several contigs go over as one coordinate space: the caller concatenates them (each contig starting on an even position,
+ * a 1-base filler region of type SR where it pads), shifts rb / re by the contig's offset and the SR ranks in `info` by the
+ * number of SRs before the contig.  Alignments must be sorted by rb (a coordinate-sorted BAM; HYPO_E_INVALID otherwise: the
+ * arm order inside a window is the alignment order and the kernels rely on the sort to find a window's alignments). */
+typedef struct HypoArmsRegions {
+    uint32_t        n_regions;
+    const uint32_t* start;         /* [n_regions + 1] region starts, then the total length */
+    const uint8_t*  type;          /* [n_regions + 1] RegionType (include/globalDefs.hpp:95-108): SWS SW WS MWM MW WM SWM MWS OTHER LONG SR MSR */
+    const uint32_t* info;          /* [n_regions + 1] SR: its rank among the SRs; MSR: its minimizer (Contig::_reg_info) */
+    uint64_t        n_anchor_kmers;
+    const uint64_t* anchor_kmers;  /* [1 + 2 * number of SRs] a dummy, then first and last k-mer of every SR (Contig::_anchor_kmers);
+                                      the SR of rank r >= 1 (info) owns entries 2r - 1 and 2r */
+    uint32_t        k;
+    const uint8_t*  contig4;       /* PackedSeq<4> of the coordinate space */
+} HypoArmsRegions;
+typedef struct HypoArmsReads {
+    uint32_t        n_alignments;
+    const uint32_t* rb;            /* reference span [rb, re) (Alignment::_rb, _re) */
+    const uint32_t* re;
+    const uint32_t* qae;           /* aligned query length, soft clips dropped (Alignment::_qae with _qab = 0) */
+    const uint64_t* seq_off;       /* BYTE offset of the aligned query as PackedSeq<2> in reads2 */
+    const uint8_t*  reads2;
+    uint64_t        reads2_bytes;
+    const uint32_t* cigar_off;     /* [n_alignments + 1] */
+    const uint32_t* cigar;         /* BAM encoding: len << 4 | op */
+} HypoArmsReads;
+typedef struct HypoArmsSummary {
+    uint32_t n_windows;            /* windows that survived Contig::fill_short_windows' pruning */
+    uint32_t n_arms;
+    uint64_t arms2_bytes, draft4_bytes;
+    uint64_t out_bytes;            /* consensus slots (hypo_gpu_poa_slot_layout's rule) */
+} HypoArmsSummary;
+/* region_valid: [n_regions] out, 1 where the region keeps a SHORT window.  HYPO_E_CAPACITY: the batch exceeds the 32-bit
+ * counters of the boundary (use the host path or smaller contig batches). */
+int hypo_gpu_arms_build(const HypoArmsRegions* regions, const HypoArmsReads* reads, uint8_t* region_valid, HypoArmsSummary* summary);
+/* Any pointer may be NULL.  windows [n_windows], win_region [n_windows] (region of every window), arm_len / arm_off [n_arms],
+ * arms2 [arms2_bytes], draft4 [draft4_bytes]. */
+int hypo_gpu_arms_download(HypoWindow* windows, uint32_t* win_region, uint32_t* arm_len, uint64_t* arm_off, uint8_t* arms2, uint8_t* draft4);
+/* bases [out_bytes], off [n_windows + 1] (OUT), len / status [n_windows]; stats through hypo_gpu_poa_last_stats. */
+int hypo_gpu_arms_poa(const HypoScoreParams* scores, char* bases, uint64_t* off, uint32_t* len, uint8_t* status);
 
 /* Kernel timing with HIP events on the stream the kernels run on ----------------------------------
  * hypo_gpu_profile_begin(max_calls) arms the next max_calls (<= 256) *_device calls: each records

@@ -45,6 +45,10 @@ int hypo_gpu_set_option(const char* name, int value) { if (name && !strcmp(name,
 int hypo_gpu_num_devices(void) { return g_ready ? g_ndev : 0; }
 int hypo_gpu_use_device(int slot) { return slot >= 0 && slot < g_ndev ? HYPO_OK : HYPO_E_INVALID; }
 const char* hypo_gpu_build_id(void) { return "oracle_device_shim"; }
+/* arm selection has no CPU restatement behind the boundary: the host runs its own (reference) loops (host/DeviceArms.cpp) */
+int hypo_gpu_arms_build(const HypoArmsRegions* r, const HypoArmsReads* a, uint8_t* v, HypoArmsSummary* s) { (void)r; (void)a; (void)v; (void)s; return HYPO_E_UNSUPPORTED; }
+int hypo_gpu_arms_download(HypoWindow* w, uint32_t* r, uint32_t* l, uint64_t* o, uint8_t* a, uint8_t* d) { (void)w; (void)r; (void)l; (void)o; (void)a; (void)d; return HYPO_E_UNSUPPORTED; }
+int hypo_gpu_arms_poa(const HypoScoreParams* sc, char* b, uint64_t* o, uint32_t* l, uint8_t* st) { (void)sc; (void)b; (void)o; (void)l; (void)st; return HYPO_E_UNSUPPORTED; }
 
 int hypo_gpu_poa_slot_layout(const HypoWindowBatch* in, uint64_t* off) {
     uint64_t acc = 0;
