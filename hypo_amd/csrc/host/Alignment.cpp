@@ -140,7 +140,8 @@ void Alignment::update_minimisers_support(Contig& contig) {
     Item ring[kMinimizerRingCap]; const uint32_t cap = W + 1; uint32_t head = 0, tail = cap - 1, count = 0;
     uint32_t kmer = 0, run = 0, processed = 0;
     uint32_t last_found = (uint32_t)_apseq.get_seq_size() + 1;
-    std::unordered_multimap<uint32_t, uint32_t> found;
+    std::vector<std::pair<uint32_t, uint32_t>> found;            // (minimizer, start): an unordered_multimap in the reference; only membership is used
+    found.reserve(_apseq.get_seq_size() / (W > 1 ? W / 2 : 1) + 4);
     for (size_t i = 0; i < _apseq.get_seq_size(); ++i) {
         const uint8_t c = _apseq.enc_base_at(i);
         if (c >= 4) { run = 0; continue; }
@@ -152,10 +153,11 @@ void Alignment::update_minimisers_support(Contig& contig) {
         while (ring[head].pos + W <= i) { head = (head + 1) % cap; --count; }
         if (++processed >= W) {
             const uint32_t start = ring[head].pos - K + 1;
-            if (start != last_found) found.insert({ring[head].kmer, start});
+            if (start != last_found) found.emplace_back(ring[head].kmer, start);
             last_found = start;
         }
     }
+    std::sort(found.begin(), found.end());
     const uint16_t num_cbases = (uint16_t)(_re - _rb);          // 16-bit in the reference (Alignment.cpp:188)
     for (int64_t i = first_w; i <= last_w; i += 2) {
         const uint32_t minfoidx = even ? (uint32_t)(i / 2) : (uint32_t)((i - 1) / 2);
@@ -169,8 +171,8 @@ void Alignment::update_minimisers_support(Contig& contig) {
             const uint32_t range_right = std::min<uint16_t>(num_cbases, (uint16_t)(c_dist + 3 * K));
             if (minimiser_pos >= _rb && minimiser_pos < _re) {
                 contig.increment_minimser_coverage(minfoidx, m);
-                auto r = found.equal_range(mi.minimisers[m]);
-                for (auto it = r.first; it != r.second; ++it)
+                const uint32_t want = mi.minimisers[m];
+                for (auto it = std::lower_bound(found.begin(), found.end(), std::make_pair(want, 0u)); it != found.end() && it->first == want; ++it)
                     if (it->second >= range_left && it->second <= range_right) contig.increment_minimser_support(minfoidx, m);
             }
             if (minimiser_pos >= _re) break;

@@ -1,9 +1,11 @@
 // DeviceArms.cpp — see DeviceArms.hpp.
 #include "DeviceArms.hpp"
 #include <omp.h>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 
 namespace hypo {
 
@@ -11,34 +13,52 @@ bool DeviceArms::build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c
                        std::vector<std::vector<std::unique_ptr<Alignment>>>& store, unsigned k) {
     _active = false;
     if (hypo_gpu_num_devices() != 1) return false;
+    const bool timing = std::getenv("HYPO_HOST_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const auto t0 = now();
     // one coordinate space for the whole contig batch: every contig starts on an even position (its PackedSeq<4> bytes are
     // copied as they are); an odd-length contig is followed by a 1-base filler region of type SR
     uint64_t total = 0, n_reg = 0, n_anchor = 0, n_aln = 0, n_cig = 0, read_bytes = 0;
+    std::vector<uint64_t> aln_base(c1 - c0 + 1, 0);
     for (uint32_t c = c0; c < c1; ++c) {
         const Contig& ctg = *contigs[c];
         total += ctg._len + (ctg._len & 1);
         n_reg += ctg.get_num_regions() + (ctg._len & 1);
         n_anchor += ctg._anchor_kmers.size();
+        aln_base[c - c0] = n_aln;
         n_aln += store[c].size();
-        uint32_t prev = 0;
-        for (const auto& a : store[c]) {
-            if (a->_rb < prev) { std::fprintf(stdout, "[Hypo::Hypo] Info: alignments are not sorted by position: short arms are computed on the host\n"); return false; }
-            prev = a->_rb;
-            n_cig += a->_cigar.size();
-            read_bytes += a->_apseq.byte_size();
+    }
+    if (n_aln >= 0xfffffff0ull) return false;
+    // per alignment: bytes of its read, CIGAR operations (exclusive prefix sums below), and the sort check
+    std::vector<uint64_t> seq_off(n_aln + 1);
+    std::vector<uint32_t> cigar_off(n_aln + 1);
+    bool sorted = true;
+    for (uint32_t c = c0; c < c1; ++c) {
+        const auto& alns = store[c];
+        const uint64_t a0 = aln_base[c - c0];
+#pragma omp parallel for schedule(static) reduction(&& : sorted)
+        for (int64_t t = 0; t < (int64_t)alns.size(); ++t) {
+            const Alignment& a = *alns[(size_t)t];
+            seq_off[a0 + (uint64_t)t + 1] = a._apseq.byte_size();
+            cigar_off[a0 + (uint64_t)t + 1] = (uint32_t)a._cigar.size();
+            if (t && alns[(size_t)t - 1]->_rb > a._rb) sorted = false;
         }
     }
+    if (!sorted) { std::fprintf(stdout, "[Hypo::Hypo] Info: alignments are not sorted by position: short arms are computed on the host\n"); return false; }
+    seq_off[0] = 0; cigar_off[0] = 0;
+    for (uint64_t g = 0; g < n_aln; ++g) { n_cig += cigar_off[g + 1]; if (n_cig >= 0xfffffff0ull) return false; seq_off[g + 1] += seq_off[g]; cigar_off[g + 1] += cigar_off[g]; }
+    read_bytes = seq_off[n_aln];
     if (total >= 0xfffffff0ull || n_reg >= 0xfffffff0ull || n_aln >= 0xfffffff0ull || n_cig >= 0xfffffff0ull || n_reg == 0) return false;
     std::vector<uint32_t> start(n_reg + 1), info(n_reg + 1, 0);
     std::vector<uint8_t> type(n_reg + 1, (uint8_t)RegionType::SR);
     std::vector<uint64_t> anchors; anchors.reserve(n_anchor);
     std::vector<uint8_t> contig4((total + 1) / 2, 0);
-    std::vector<uint32_t> rb(n_aln), re(n_aln), qae(n_aln), cigar_off(n_aln + 1), cigar(n_cig);
-    std::vector<uint64_t> seq_off(n_aln);
-    std::vector<uint8_t> reads2(read_bytes ? read_bytes : 1);
+    std::vector<uint32_t> rb(n_aln), re(n_aln), qae(n_aln);
+    std::unique_ptr<uint32_t[]> cigar(new uint32_t[n_cig ? n_cig : 1]);             // (not zero-filled: every element is written below)
+    std::unique_ptr<uint8_t[]> reads2(new uint8_t[read_bytes ? read_bytes : 1]);
     _reg_window.assign(n_reg, nullptr);
-    uint64_t base = 0, r = 0, a_at = 0;
-    std::vector<uint64_t> aln_base(c1 - c0 + 1, 0);
+    uint64_t base = 0, r = 0;
     for (uint32_t c = c0; c < c1; ++c) {
         Contig& ctg = *contigs[c];
         const uint32_t nr = (uint32_t)ctg.get_num_regions();
@@ -56,27 +76,21 @@ bool DeviceArms::build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c
         if (ctg._anchor_kmers.size() > 1) anchors.insert(anchors.end(), ctg._anchor_kmers.begin() + 1, ctg._anchor_kmers.end());
         std::memcpy(contig4.data() + base / 2, ctg._pseq.data(), ctg._pseq.byte_size());
         if (ctg._len & 1) { start[r] = (uint32_t)(base + ctg._len); type[r] = (uint8_t)RegionType::SR; info[r] = 0; ++r; }
-        aln_base[c - c0] = a_at;
-        a_at += store[c].size();
         base += ctg._len + (ctg._len & 1);
     }
     start[r] = (uint32_t)total;
-    {   // alignments: offsets first (serial), then the copies on all threads
-        uint64_t at = 0, cg = 0, bytes = 0;
-        for (uint32_t c = c0; c < c1; ++c)
-            for (const auto& a : store[c]) { seq_off[at] = bytes; cigar_off[at] = (uint32_t)cg; bytes += a->_apseq.byte_size(); cg += a->_cigar.size(); ++at; }
-        cigar_off[at] = (uint32_t)cg;
+    {   // the copies, on all threads; an alignment is released as soon as it is copied (its arms will never be cut on the host)
         uint64_t cbase = 0;
         for (uint32_t c = c0; c < c1; ++c) {
-            const auto& alns = store[c];
+            auto& alns = store[c];
             const uint64_t a0 = aln_base[c - c0];
 #pragma omp parallel for schedule(static)
             for (int64_t t = 0; t < (int64_t)alns.size(); ++t) {
                 const Alignment& a = *alns[(size_t)t];
                 const uint64_t g = a0 + (uint64_t)t;
                 rb[g] = (uint32_t)(cbase + a._rb); re[g] = (uint32_t)(cbase + a._re); qae[g] = a._qae;
-                std::memcpy(reads2.data() + seq_off[g], a._apseq.data(), a._apseq.byte_size());
-                std::memcpy(cigar.data() + cigar_off[g], a._cigar.data(), a._cigar.size() * 4);
+                std::memcpy(reads2.get() + seq_off[g], a._apseq.data(), a._apseq.byte_size());
+                std::memcpy(cigar.get() + cigar_off[g], a._cigar.data(), a._cigar.size() * 4);
             }
             cbase += contigs[c]->_len + (contigs[c]->_len & 1);
         }
@@ -86,9 +100,11 @@ bool DeviceArms::build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c
     R.n_anchor_kmers = anchors.size(); R.anchor_kmers = anchors.data(); R.k = k; R.contig4 = contig4.data();
     HypoArmsReads A;
     A.n_alignments = (uint32_t)n_aln; A.rb = rb.data(); A.re = re.data(); A.qae = qae.data(); A.seq_off = seq_off.data();
-    A.reads2 = reads2.data(); A.reads2_bytes = read_bytes; A.cigar_off = cigar_off.data(); A.cigar = cigar.data();
+    A.reads2 = reads2.get(); A.reads2_bytes = read_bytes; A.cigar_off = cigar_off.data(); A.cigar = cigar.get();
     std::vector<uint8_t> valid(n_reg, 0);
+    const auto t1 = now();
     const int rc = hypo_gpu_arms_build(&R, &A, valid.data(), &_sum);
+    const auto t2 = now();
     if (rc != HYPO_OK) {
         if (rc != HYPO_E_UNSUPPORTED) std::fprintf(stdout, "[Hypo::Hypo] Info: short arms are computed on the host (%s)\n", hypo_gpu_last_error());
         return false;
@@ -103,8 +119,22 @@ bool DeviceArms::build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c
         if (ctg._len & 1) ++r;
         std::vector<uint64_t>().swap(ctg._anchor_kmers);
         std::vector<uint32_t>().swap(ctg._reg_info);
+        _spent.emplace_back(std::move(store[c]));
         store[c].clear();
     }
+    // a million small objects: they are released behind the next phases of the run (joined in the destructor)
+    _releaser = std::thread([this] {
+        constexpr size_t kHelpers = 8;
+        for (auto& alns : _spent) {
+            std::vector<std::thread> helpers;
+            const size_t n = alns.size(), per = (n + kHelpers - 1) / kHelpers;
+            for (size_t h = 0; h < kHelpers; ++h)
+                helpers.emplace_back([&alns, h, per, n] { for (size_t t = h * per; t < n && t < (h + 1) * per; ++t) alns[t].reset(); });
+            for (auto& th : helpers) th.join();
+        }
+        std::vector<std::vector<std::unique_ptr<Alignment>>>().swap(_spent);
+    });
+    if (timing) std::fprintf(stderr, "[timing] device arms: flatten %.3f s, hypo_gpu_arms_build %.3f s, prune + release %.3f s\n", secs(t0, t1), secs(t1, t2), secs(t2, now()));
     std::fprintf(stdout, "[Hypo::Hypo] Info: short arms cut on the device: %u windows, %u arms\n", _sum.n_windows, _sum.n_arms);
     _active = true;
     return true;

@@ -6,6 +6,7 @@
 #pragma once
 #include <cstdint>
 #include <memory>
+#include <thread>
 #include <vector>
 #include "Contig.hpp"
 
@@ -13,6 +14,10 @@ namespace hypo {
 
 class DeviceArms {
 public:
+    DeviceArms() = default;
+    DeviceArms(const DeviceArms&) = delete;
+    DeviceArms& operator=(const DeviceArms&) = delete;
+    ~DeviceArms() { if (_releaser.joinable()) _releaser.join(); }
     // true: the windows of contigs [c0, c1) are pruned, their arms lie on the device and `store` is consumed; false: nothing
     // was changed and the host path must run (several devices, an unsorted alignment file, a batch beyond 32-bit coordinates)
     bool build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1,
@@ -25,6 +30,8 @@ public:
 private:
     bool _active = false;
     HypoArmsSummary _sum{};
+    std::vector<std::vector<std::unique_ptr<Alignment>>> _spent;   // the alignments of the batch, on their way out
+    std::thread _releaser;
     std::vector<Window*> _reg_window;        // region of the coordinate space -> its window (nullptr: SR, filler, pruned)
     void adopt_arms(const std::vector<uint32_t>& which, const std::vector<HypoWindow>& hw, const std::vector<uint32_t>& win_region);
 };

@@ -4,6 +4,10 @@
 // the NM:i tag (src/Alignment.cpp:514-571, :51-58).  Alignment files may be SAM text (plain or gzip) or BAM: BGZF is a
 // series of gzip members, which zlib's gz* layer inflates as one stream, and the BAM records are decoded here.
 #pragma once
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 #include <cstdint>
 #include <cstdio>
@@ -17,14 +21,28 @@ namespace hypo {
 
 class LineReader {                           // lines of a plain or gzip file: block reads through zlib, memchr for the line ends
 public:
-    explicit LineReader(const std::string& path) : _fp(gzopen(path.c_str(), "r")), _buf(kBuf) { if (_fp) gzbuffer(_fp, 1 << 20); }
-    ~LineReader() { if (_fp) gzclose(_fp); }
+    // A plain (not gzip) regular file is mapped and consumed in place: no read() copies, no zlib pass-through; everything else
+    // goes through zlib's gz* layer in 4 MiB blocks.
+    explicit LineReader(const std::string& path) {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd >= 0) {
+            struct stat sb;
+            unsigned char magic[2] = {0, 0};
+            if (::fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && ::pread(fd, magic, 2, 0) == 2 && !(magic[0] == 0x1f && magic[1] == 0x8b)) {
+                void* m = ::mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) { _map = (const char*)m; _map_len = (size_t)sb.st_size; (void)::madvise(m, _map_len, MADV_SEQUENTIAL); _src = _map; _end = _map_len; _eof = true; }
+            }
+            ::close(fd);
+        }
+        if (!_map) { _fp = gzopen(path.c_str(), "r"); if (_fp) { gzbuffer(_fp, 1 << 20); _buf.resize(kBuf); _src = _buf.data(); } }
+    }
+    ~LineReader() { if (_fp) gzclose(_fp); if (_map) ::munmap((void*)_map, _map_len); }
     LineReader(const LineReader&) = delete;
     LineReader& operator=(const LineReader&) = delete;
-    bool ok() const { return _fp != nullptr; }
+    bool ok() const { return _fp != nullptr || _map != nullptr; }
     bool next(std::string& line) {
         line.clear();
-        if (!_fp) return false;
+        if (!ok()) return false;
         bool any = false;
         for (;;) {
             if (_pos == _end) {
@@ -33,7 +51,7 @@ public:
                 if (n <= 0) { _eof = true; return any; }
                 _pos = 0; _end = (size_t)n;
             }
-            const char* b = _buf.data() + _pos;
+            const char* b = _src + _pos;
             const char* nl = (const char*)std::memchr(b, '\n', _end - _pos);
             any = true;
             if (nl) {
@@ -48,7 +66,7 @@ public:
     }
     // next line appended to dst WITHOUT its line end (so that a block of records can live in one buffer); false at end of file
     bool append_line(std::vector<char>& dst) {
-        if (!_fp) return false;
+        if (!ok()) return false;
         bool any = false;
         for (;;) {
             if (_pos == _end) {
@@ -57,7 +75,7 @@ public:
                 if (n <= 0) { _eof = true; return any; }
                 _pos = 0; _end = (size_t)n;
             }
-            const char* b = _buf.data() + _pos;
+            const char* b = _src + _pos;
             const char* nl = (const char*)std::memchr(b, '\n', _end - _pos);
             any = true;
             if (nl) {
@@ -81,23 +99,30 @@ public:
                 _pos = 0; _end = (size_t)got;
             }
             const size_t take = n < _end - _pos ? n : _end - _pos;
-            std::memcpy(d, _buf.data() + _pos, take);
+            std::memcpy(d, _src + _pos, take);
             d += take; _pos += take; n -= take;
         }
         return true;
     }
+    // a mapped plain file: the unread bytes in place (SamReader cuts records out of them without copying)
+    bool mapped() const { return _map != nullptr && _map[_map_len - 1] == '\n'; }   // (in-place parsing wants every record terminated)
+    const char* unread() const { return _src + _pos; }
+    size_t unread_bytes() const { return _end - _pos; }
+    void consume(size_t n) { _pos += n; }
     // first bytes of the stream without consuming them (used once, right after opening)
     bool starts_with(const char* magic, size_t n) {
         if (_pos == _end && !_eof && _fp) {
             const int got = gzread(_fp, _buf.data(), (unsigned)kBuf);
             if (got <= 0) _eof = true; else { _pos = 0; _end = (size_t)got; }
         }
-        return _end - _pos >= n && std::memcmp(_buf.data() + _pos, magic, n) == 0;
+        return _end - _pos >= n && std::memcmp(_src + _pos, magic, n) == 0;
     }
 private:
     static constexpr size_t kBuf = 4u << 20;
-    gzFile _fp;
+    gzFile _fp = nullptr;
     std::vector<char> _buf;
+    const char* _map = nullptr; size_t _map_len = 0;
+    const char* _src = nullptr;                        // the bytes being consumed: _buf or the mapping
     size_t _pos = 0, _end = 0;
     bool _eof = false;
 };
@@ -167,18 +192,36 @@ public:
     // A block of raw records in one buffer: record i = bytes [off[i], off[i + 1] - 1), followed by a NUL.  SAM: the text of
     // one alignment line; BAM: one alignment block without its 4-byte size.  I/O and inflate are serial (one reader thread),
     // parse() is const and re-entrant: Hypo::create_alignments parses the records of a block on all threads.
+    // A plain SAM file is mapped (LineReader) and its records stay where they are: `base` points into the mapping and a record
+    // ends with its line feed instead of a NUL (parse() never reads past the n bytes it is given).
     struct RecordBlock {
         std::vector<char> buf;
         std::vector<uint64_t> off;
+        const char* base = nullptr;
         size_t n() const { return off.empty() ? 0 : off.size() - 1; }
-        const char* rec(size_t i) const { return buf.data() + off[i]; }
+        const char* rec(size_t i) const { return (base ? base : buf.data()) + off[i]; }
         size_t len(size_t i) const { return (size_t)(off[i + 1] - off[i] - 1); }
-        void clear() { buf.clear(); off.clear(); }
+        void clear() { buf.clear(); off.clear(); base = nullptr; }
     };
     // fills b with up to max_records records (or ~max_bytes); false once the end of the file has been reached
     bool read_block(RecordBlock& b, size_t max_records, size_t max_bytes = 32u << 20) {
         b.clear();
         b.off.push_back(0);
+        if (!_bam && !_have_pending && _lr.mapped()) {                   // records in place: only the line ends are located here
+            const char* const p0 = _lr.unread();
+            const size_t avail = _lr.unread_bytes();
+            size_t at = 0;
+            b.base = p0;
+            while (b.n() < max_records && at < max_bytes && at < avail) {
+                const char* nl = (const char*)std::memchr(p0 + at, '\n', avail - at);
+                const size_t stop = nl ? (size_t)(nl - p0) : avail;         // (a last line without a line feed ends at the end of the file)
+                if (stop == at) { if (b.off.size() == 1) { b.off[0] = ++at; continue; } break; }   // empty line: leading ones are skipped, one inside ends the block
+                b.off.push_back(stop + 1);
+                at = stop + 1;
+            }
+            _lr.consume(at < avail ? at : avail);
+            return at < avail;
+        }
         while (b.n() < max_records && b.buf.size() < max_bytes) {
             const size_t start = b.buf.size();
             if (_bam) {
@@ -201,6 +244,7 @@ public:
     // one raw record (NUL-terminated, n bytes) -> fields
     void parse(const char* line, size_t n, SamRecord& r) const {
         if (_bam) { parse_bam(line, n, r); return; }
+        if (n && line[n - 1] == '\r') --n;                               // (a record cut out of a mapped file keeps its CR)
         size_t f[12]; int nf = 0; f[0] = 0;
         for (size_t i = 0; i < n && nf < 11; ++i) if (line[i] == '\t') f[++nf] = i + 1;
         if (nf < 10) { std::fprintf(stderr, "[Hypo::SamReader] Error: malformed SAM record: %.60s\n", line); std::exit(1); }
@@ -228,7 +272,7 @@ public:
         r.seq.assign(fbeg(9), flen(9));
         r.has_nm = false;
         if (nf >= 11) {
-            const char* p = std::strstr(line + f[10] - 1, "\tNM:i:");
+            const char* p = (const char*)memmem(line + f[10] - 1, n - (f[10] - 1), "\tNM:i:", 6);
             if (p) { r.has_nm = true; r.nm = std::strtoll(p + 6, nullptr, 10); }
         }
     }
