@@ -7,6 +7,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
+make -s -C hypo_amd/csrc prof >/dev/null 2>&1   # the diagnostic build must match the sources (it is not built by the default target)
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 # kernel trace + counters of the bench's kernels (concurrent schedule = the product; sequential = every class alone)
 bash profiles/run_pmc.sh $TAG > /dev/null 2>&1
