@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <dlfcn.h>
+#include <chrono>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -136,6 +137,52 @@ hypo::PoaParams make_params(const HypoScoreParams* s, const HypoWindowBatch* in,
     return P;
 }
 
+struct Carver {                                       // lays arrays out in one device buffer, 256-byte aligned
+    size_t at = 0;
+    size_t take(size_t bytes) { const size_t o = at; at += (bytes + 255) / 256 * 256; return o; }
+};
+
+
+// First-use costs of a HIP process — loading this library's code objects onto the device, the occupancy queries, the side
+// streams and events of the POA call — come to ≈ 20–40 ms, several steady-state POA calls of the C2 batch, and used to land in
+// whichever call came first.  hypo_gpu_init pays them once per context: a two-window batch, a 64-base scan and a four-element
+// prefix sum on throw-away buffers.  HYPO_NO_WARMUP=1 leaves them to the first calls (profiles/diag/first_call.py measures
+// the difference).
+void warm_up(Ctx* c) {
+    if (hipSetDevice(c->device) != hipSuccess) return;
+    hipStream_t st = c->stream;
+    const uint32_t nw = 2, na = 4;
+    const size_t wsb = hypo::poa_workspace_bytes(nw, hypo::kMinGlobalGroups, 0), swb = hypo::scan_workspace_bytes(64);
+    Carver cv;
+    const size_t o_win = cv.take(nw * sizeof(HypoWindow)), o_dr = cv.take(64), o_aoff = cv.take(na * 8), o_alen = cv.take(na * 4), o_arms = cv.take(64),
+                 o_bases = cv.take(256), o_off = cv.take((nw + 1) * 8), o_len = cv.take(nw * 4), o_st = cv.take(64), o_p4 = cv.take(64), o_bits = cv.take(64),
+                 o_words = cv.take(64), o_kids = cv.take(64 * 8), o_rank = cv.take(64), o_n = cv.take(64), o_sws = cv.take(swb), o_scan = cv.take(64 * 8), o_ws = cv.take(wsb);
+    char* d = nullptr;
+    if (hipMalloc((void**)&d, cv.at) != hipSuccess) return;
+    (void)hipMemsetAsync(d, 0, o_ws, st);                  // all-A drafts and arms, an empty 2-mer set
+    HypoWindow hw[nw] = {};
+    uint64_t aoff[na] = {0, 8, 16, 24}, off[nw + 1] = {0, 64, 128};
+    uint32_t alen[na] = {24, 24, 24, 24};
+    for (uint32_t w = 0; w < nw; ++w) { hw[w].type = HYPO_WIN_SHORT; hw[w].draft_len = 24; hw[w].draft_off = 16 * w; hw[w].first_arm = 2 * w; hw[w].n_internal = 2; }
+    (void)hipMemcpyAsync(d + o_win, hw, sizeof(hw), hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(d + o_aoff, aoff, sizeof(aoff), hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(d + o_alen, alen, sizeof(alen), hipMemcpyHostToDevice, st);
+    (void)hipMemcpyAsync(d + o_off, off, sizeof(off), hipMemcpyHostToDevice, st);
+    (void)hypo::scan_run((const uint8_t*)(d + o_p4), 64, 2, (const uint64_t*)(d + o_bits), (uint64_t*)(d + o_words), (uint64_t*)(d + o_kids), 64, (uint64_t*)(d + o_rank),
+                         (uint64_t*)(d + o_n), d + o_sws, swb, st, nullptr);
+    hypo::PoaParams P;
+    P.windows = (const HypoWindow*)(d + o_win); P.draft4 = (const uint8_t*)(d + o_dr); P.arm_off = (const uint64_t*)(d + o_aoff); P.arm_len = (const uint32_t*)(d + o_alen);
+    P.arms2 = (const uint8_t*)(d + o_arms); P.out_bases = d + o_bases; P.out_off = (const uint64_t*)(d + o_off); P.out_len = (uint32_t*)(d + o_len); P.out_status = (uint8_t*)(d + o_st);
+    P.sr_m = 5; P.sr_n = -4; P.sr_g = -8; P.lr_m = 3; P.lr_n = -5; P.lr_g = -4;
+    P.n_arms = na; P.draft4_bytes = 64; P.arms2_bytes = 64; P.flags = 0;
+    (void)hypo::poa_run(P, nw, d + o_ws, wsb, c->num_cus, st, nullptr, &c->slots[0].aux);
+    (void)hypo::scan32((const uint32_t*)(d + o_alen), na, (uint64_t*)(d + o_scan), (uint64_t*)(d + o_sws), (uint64_t*)(d + o_n), st);
+    (void)hipStreamSynchronize(st);
+    c->slots[0].aux.history_valid = false;                // the first real batch plans for itself
+    (void)hipFree(d);
+    (void)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" {
@@ -193,6 +240,7 @@ int hypo_gpu_init(const int* device_ids, int n_devices) {
         c.device = device_ids[i]; c.num_cus = prop.multiProcessorCount; c.ready = true;
         g_nctx = i + 1;
     }
+    if (!getenv("HYPO_NO_WARMUP")) for (int i = 0; i < g_nctx; ++i) warm_up(&g_ctxs[i]);
     HIP_TRY(hipSetDevice(g_ctxs[0].device));
     tl_slot = 0;
     return HYPO_OK;
@@ -667,12 +715,6 @@ int hypo_gpu_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k, co
 }
 
 // ---- arm selection on the device (kernels in arms_kernel.hip) ------------------------------------------
-namespace {
-struct Carver {                                       // lays arrays out in one device buffer, 256-byte aligned
-    size_t at = 0;
-    size_t take(size_t bytes) { const size_t o = at; at += (bytes + 255) / 256 * 256; return o; }
-};
-}
 
 int hypo_gpu_arms_build(const HypoArmsRegions* R, const HypoArmsReads* A, uint8_t* region_valid, HypoArmsSummary* sum) {
     HYPO_LOCKED();
@@ -816,9 +858,13 @@ int hypo_gpu_arms_poa(const HypoScoreParams* scores, char* bases, uint64_t* off,
     hipStream_t st = g_ctx.stream;
     DevBuf& dOut = g_ctx.arms_arena[4];
     Carver co;
-    const size_t wsb = hypo::poa_workspace_bytes(n, 64, 0);
+    // SHORT windows only: the HBM-scratch classes see the odd escalated window, their smallest scratch (16 resident groups) will do
+    const size_t wsb = hypo::poa_workspace_bytes(n, hypo::kMinGlobalGroups, 0);
     const size_t o_bases = co.take(S.out_bytes + 16), o_len = co.take((size_t)n * 4), o_st = co.take(n), o_ws = co.take(wsb);
+    const bool timing = getenv("HYPO_HOST_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(dOut.alloc(co.at));
+    const auto t1 = std::chrono::steady_clock::now();
     char* ob = (char*)dOut.p;
     HIP_TRY(hipMemsetAsync(ob + o_bases, 0, S.out_bytes + 16, st));
     HypoWindowBatch din;
@@ -828,12 +874,18 @@ int hypo_gpu_arms_poa(const HypoScoreParams* scores, char* bases, uint64_t* off,
     dout.bases = ob + o_bases; dout.off = O.out_off; dout.len = (uint32_t*)(ob + o_len); dout.status = (uint8_t*)(ob + o_st);
     hypo::PoaParams P = make_params(scores, &din, &dout);
     HIP_TRY(hypo::poa_run(P, n, ob + o_ws, wsb, g_ctx.num_cus, st, nullptr, &g_ctx.slots[0].aux));
+    if (timing) HIP_TRY(hipStreamSynchronize(st));
+    const auto t2 = std::chrono::steady_clock::now();
     HIP_TRY(hipMemcpyAsync(bases, ob + o_bases, S.out_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(off, O.out_off, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(len, ob + o_len, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(status, ob + o_st, n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&tl_stats, ob + o_ws + 128, sizeof(HypoPoaStats), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (timing) {
+        auto d = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count() * 1e3; };
+        fprintf(stderr, "[timing] hypo_gpu_arms_poa: device buffers (%zu MB) %.2f ms, kernels %.2f ms, results to the host %.2f ms\n", co.at >> 20, d(t0, t1), d(t1, t2), d(t2, std::chrono::steady_clock::now()));
+    }
     tl_stats.n_windows = n;
     return HYPO_OK;
 }

@@ -4,9 +4,11 @@
 // per-k-mer heap nodes.
 #include "Contig.hpp"
 #include <omp.h>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <ostream>
 #include <unordered_map>
@@ -47,12 +49,19 @@ Contig::Contig(uint32_t id, const std::string& name, const std::string& seq)
 // `set_on_device`: the caller has sent sk's bit set to the device with hypo_gpu_solid_set_upload (once per run)
 int Contig::find_solid_pos(const SolidKmers& sk, bool set_on_device) {
     const uint64_t nw = ((uint64_t)_len + 63) / 64;
-    std::vector<uint64_t> words(nw ? nw : 1), rank(nw + 1), kids(_len ? _len : 1);
+    std::vector<uint64_t> words(nw ? nw : 1), rank(nw + 1);
+    const uint64_t cap = _len ? _len : 1;                             // at most one k-mer id per position; only n of them are written
+    std::unique_ptr<uint64_t[]> kids(new uint64_t[cap]);              // (not zero-filled: 8 bytes per base)
     uint64_t n = 0;
-    const int rc = hypo_gpu_solid_scan(_pseq.data(), _len, sk.get_k(), set_on_device ? nullptr : sk.words.data(), words.data(), kids.data(), kids.size(),
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = hypo_gpu_solid_scan(_pseq.data(), _len, sk.get_k(), set_on_device ? nullptr : sk.words.data(), words.data(), kids.get(), cap,
                                        rank.data(), &n);
     if (rc != HYPO_OK) return rc;
-    adopt_solid_scan(words.data(), rank.data(), kids.data(), n);
+    const auto t1 = std::chrono::steady_clock::now();
+    adopt_solid_scan(words.data(), rank.data(), kids.get(), n);
+    if (std::getenv("HYPO_HOST_TIMING"))
+        std::fprintf(stderr, "[timing] find_solid_pos: hypo_gpu_solid_scan %.3f s, adoption %.3f s\n", std::chrono::duration<double>(t1 - t0).count(),
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
     return HYPO_OK;
 }
 void Contig::adopt_solid_scan(const uint64_t* words, const uint64_t* rank, const uint64_t* kids, uint64_t n_solid) {
@@ -115,19 +124,18 @@ void Contig::prepare_for_division(unsigned k) {
     _reg_pos.set(0);
     sr_pos.push_back(_len);                                      // dummy SR at the end
     _reg_pos.set(_len);
-    uint32_t windex = 0;
-    if (_is_win_even) {
-        _minimserinfo.emplace_back();
-        if (sr_pos[0] > Window_settings.ideal_swind_size) initialise_minimserinfo(_pseq.unpack(0, sr_pos[0]), 0);
-        ++windex;
-    }
-    for (uint32_t ind = 0; ind < _numSR; ++ind, ++windex) {
-        _reg_pos.set(sr_pos[ind]);
+    // region borders first (bit sets into shared words: serial), then the minimizers of every mega-window on all threads
+    // (each mega-window fills its own MWMinimiserInfo; the reference does both in one serial loop)
+    const uint32_t first_w = _is_win_even ? 1u : 0u;
+    _minimserinfo.resize((size_t)_numSR + first_w);
+    for (uint32_t ind = 0; ind < _numSR; ++ind) { _reg_pos.set(sr_pos[ind]); _reg_pos.set(sr_pos[ind] + sr_len[ind]); }
+    if (_is_win_even && sr_pos[0] > Window_settings.ideal_swind_size) initialise_minimserinfo(_pseq.unpack(0, sr_pos[0]), 0);
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t ii = 0; ii < (int64_t)_numSR; ++ii) {
+        const uint32_t ind = (uint32_t)ii;
         const uint32_t mw_start = sr_pos[ind] + sr_len[ind];
-        _reg_pos.set(mw_start);
-        _minimserinfo.emplace_back();
         const uint32_t mw_len = sr_pos[ind + 1] - mw_start;
-        if (mw_len > Window_settings.ideal_swind_size) initialise_minimserinfo(_pseq.unpack(mw_start, sr_pos[ind + 1]), windex);
+        if (mw_len > Window_settings.ideal_swind_size) initialise_minimserinfo(_pseq.unpack(mw_start, sr_pos[ind + 1]), ind + first_w);
     }
     _reg_pos.init_support();
     _mreg_ready = true;
@@ -389,14 +397,29 @@ void Contig::fill_long_windows(std::vector<std::unique_ptr<Alignment>>& alignmen
 std::ostream& operator<<(std::ostream& os, const Contig& ctg) {
     os << ">" << ctg._name << std::endl;
     const size_t num_reg = ctg._reg_type.size() - 1;
-    uint64_t curr = ctg._reg_pos.select(1);
+    // the record is put together in one string: where every region's text goes is a prefix sum over the regions, the pieces are
+    // copied on all threads (the reference streams them one by one; the bytes are the same)
+    std::vector<uint64_t> starts(num_reg + 1), at(num_reg + 1, 0);
+    for (size_t i = 0; i <= num_reg; ++i) starts[i] = ctg._reg_pos.select(i + 1);
+    auto kind = [&](size_t i) {                        // 0: draft text, 1: consensus, 2: nothing
+        if (ctg._reg_type[i] == RegionType::SR || ctg._reg_type[i] == RegionType::MSR) return 0;
+        if (ctg._pwindows[i]) return 1;
+        return Contig::_no_long_reads ? 0 : 2;
+    };
     for (size_t i = 0; i < num_reg; ++i) {
-        const uint64_t next = ctg._reg_pos.select(i + 2);
-        if (ctg._reg_type[i] == RegionType::SR || ctg._reg_type[i] == RegionType::MSR) os << ctg._pseq.unpack(curr, next);
-        else if (ctg._pwindows[i]) os << ctg._pwindows[i]->get_consensus();
-        else if (Contig::_no_long_reads) os << ctg._pseq.unpack(curr, next);
-        curr = next;
+        const int kd = kind(i);
+        at[i + 1] = at[i] + (kd == 0 ? starts[i + 1] - starts[i] : kd == 1 ? ctg._pwindows[i]->consensus_ref().size() : 0);
     }
+    std::string text(at[num_reg], 'N');
+#pragma omp parallel for schedule(static, 256)
+    for (int64_t ii = 0; ii < (int64_t)num_reg; ++ii) {
+        const size_t i = (size_t)ii;
+        const int kd = kind(i);
+        char* dst = &text[at[i]];
+        if (kd == 0) { for (uint64_t p = starts[i]; p < starts[i + 1]; ++p) *dst++ = ctg._pseq.base_at(p); }
+        else if (kd == 1) { const std::string& c = ctg._pwindows[i]->consensus_ref(); std::memcpy(dst, c.data(), c.size()); }
+    }
+    os << text;
     os << std::endl;
     return os;
 }

@@ -12,6 +12,7 @@ namespace hypo {
 bool DeviceArms::build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1,
                        std::vector<std::vector<std::unique_ptr<Alignment>>>& store, unsigned k) {
     _active = false;
+    wait_released();
     if (hypo_gpu_num_devices() != 1) return false;
     const bool timing = std::getenv("HYPO_HOST_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -124,7 +125,7 @@ bool DeviceArms::build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c
     }
     // a million small objects: they are released behind the next phases of the run (joined in the destructor)
     _releaser = std::thread([this] {
-        constexpr size_t kHelpers = 8;
+        constexpr size_t kHelpers = 24;
         for (auto& alns : _spent) {
             std::vector<std::thread> helpers;
             const size_t n = alns.size(), per = (n + kHelpers - 1) / kHelpers;
@@ -164,15 +165,22 @@ int DeviceArms::polish(const ScoreParams& sp, bool keep_arms) {
     _active = false;
     const uint32_t n = _sum.n_windows;
     if (!n) return HYPO_OK;
+    const auto tp = std::chrono::steady_clock::now();
     std::vector<char> bases(_sum.out_bytes ? _sum.out_bytes : 1);
     std::vector<uint64_t> off((size_t)n + 1);
     std::vector<uint32_t> len(n), win_region(n);
     std::vector<uint8_t> st(n);
     std::vector<HypoWindow> hw(n);
+    const bool timing = std::getenv("HYPO_HOST_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const auto t0 = now();
     int rc = hypo_gpu_arms_poa(&sp, bases.data(), off.data(), len.data(), st.data());
     if (rc != HYPO_OK) return rc;
+    const auto t1 = now();
     rc = hypo_gpu_arms_download(hw.data(), win_region.data(), nullptr, nullptr, nullptr, nullptr);
     if (rc != HYPO_OK) return rc;
+    if (timing) std::fprintf(stderr, "[timing] device arms: buffers %.3f s, hypo_gpu_arms_poa %.3f s, descriptors %.3f s\n", secs(tp, t0), secs(t0, t1), secs(t1, now()));
     std::vector<uint32_t> again, all;
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < (int64_t)n; ++i)

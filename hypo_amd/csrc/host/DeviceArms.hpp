@@ -17,7 +17,8 @@ public:
     DeviceArms() = default;
     DeviceArms(const DeviceArms&) = delete;
     DeviceArms& operator=(const DeviceArms&) = delete;
-    ~DeviceArms() { if (_releaser.joinable()) _releaser.join(); }
+    ~DeviceArms() { wait_released(); }
+    void wait_released() { if (_releaser.joinable()) _releaser.join(); }
     // true: the windows of contigs [c0, c1) are pruned, their arms lie on the device and `store` is consumed; false: nothing
     // was changed and the host path must run (several devices, an unsorted alignment file, a batch beyond 32-bit coordinates)
     bool build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1,

@@ -82,6 +82,7 @@ void Hypo::polish() {
     std::ofstream dump;
     if (!_region_dump.empty()) dump.open(_region_dump);
 
+    DeviceArms device_arms;                                   // outlives the batches: spent alignments are released behind the phases that follow
     for (uint32_t batch_id = 0; batch_id < num_batches; ++batch_id) {
         std::fprintf(stdout, "********** [Hypo::Hypo] Info: BATCH-ID: %u\n", batch_id);
         const uint32_t initial_cid = batch_id * _contig_batch_size;
@@ -100,7 +101,7 @@ void Hypo::polish() {
         stop("[Hypo:Hypo]: Solid kmers support update. ");
 
         start();
-#pragma omp parallel for schedule(static, 1)
+#pragma omp parallel for schedule(static, 1) if (over_contigs)   // few contigs: the threads work inside a contig (mega-window minimizers)
         for (int64_t i = initial_cid; i < (int64_t)final_cid; ++i) _contigs[(size_t)i]->prepare_for_division(_cFlags.k);
         uint64_t num_sr = 0, len_sr = 0;
         for (uint32_t i = initial_cid; i < final_cid; ++i) { num_sr += _contigs[i]->get_num_sr(); len_sr += _contigs[i]->get_len_sr(); }
@@ -123,7 +124,7 @@ void Hypo::polish() {
         start();
         // The device cuts the reads into arms, prunes the windows and keeps the window batch in its memory (DeviceArms.hpp);
         // --host-arms, several devices or an unsorted alignment file take the host loops of the reference instead.
-        DeviceArms device_arms;
+        device_arms.wait_released();                          // (the previous batch's alignments, still on their way out)
         const bool on_device = !_cFlags.host_arms && device_arms.build(_contigs, initial_cid, final_cid, _alignment_store, _cFlags.k);
         if (!on_device)
             for (uint32_t cid = initial_cid; cid < final_cid; ++cid) {
@@ -198,6 +199,7 @@ void Hypo::polish() {
     for (auto& c : _contigs) ofile << *c;
     ofile.close();
     stop("[Hypo:Hypo]: Writing results. ");
+    device_arms.wait_released();                              // inside the Overall timer, like the reference's own clear() of its alignment store
     _times.overall = std::chrono::duration<double>(std::chrono::steady_clock::now() - _tstart).count();
     std::fprintf(stdout, "RESOURCES ([Hypo:Hypo]: Overall. ): TIME= %g sec.\n", _times.overall);
     _contigs.clear();

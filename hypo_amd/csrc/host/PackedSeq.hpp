@@ -97,6 +97,13 @@ private:
     void assign(const char* s, size_t n) {
         if (n > 0xffffffffu) { std::fprintf(stderr, "[Hypo::PackedSeq] Error: Length exceed limit: The length of a sequence is %zu which exceeds the limit of %u !\n", n, 0xffffffffu); std::exit(1); }
         resize(n);
+        if (NB == 4 && n >= (1u << 20)) {            // a contig: whole bytes on all threads (4-bit packing cannot fail)
+            const int64_t nb = (int64_t)(n / 2);
+#pragma omp parallel for schedule(static)
+            for (int64_t j = 0; j < nb; ++j) _data[(size_t)j] = (uint8_t)((nt4((unsigned char)s[2 * j]) << 4) | nt4((unsigned char)s[2 * j + 1]));
+            if (n & 1) _data[n / 2] = (uint8_t)(nt4((unsigned char)s[n - 1]) << 4);
+            return;
+        }
         for (size_t i = 0; i < n; ++i) {
             const uint8_t b = nt4((unsigned char)s[i]);
             if (NB == 2 && b > 3) {       // PackedSeq.cpp:75-79: marks the sequence invalid and stops packing

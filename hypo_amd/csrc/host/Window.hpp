@@ -34,6 +34,7 @@ public:
     // polishes every window of the list with ONE device call; returns HYPO_OK or the C-ABI error
     static int generate_consensus_batch(const std::vector<Window*>& windows);
     std::string get_consensus() const { return _consensus; }
+    const std::string& consensus_ref() const { return _consensus; }
     size_t get_window_len() const { return _draft.get_seq_size(); }
 
     // The reference takes const references and copies (Window.hpp:66-101); an rvalue is adopted without a second copy.
