@@ -179,8 +179,8 @@ class HypoGpu:
         """workspace_bytes: None = the size hypo_gpu_poa_workspace_bytes recommends"""
         return DeviceBatch(self, b, off, workspace_bytes)
 
-    def device_scan(self, packed4: np.ndarray, n_bases: int, k: int, bits: np.ndarray, kids_cap=None):
-        return DeviceScan(self, packed4, n_bases, k, bits, kids_cap)
+    def device_scan(self, packed4: np.ndarray, n_bases: int, k: int, bits: np.ndarray, kids_cap=None, misalign=0):
+        return DeviceScan(self, packed4, n_bases, k, bits, kids_cap, misalign)
 
 
 def _stats_dict(s: abi.PoaStats) -> dict:
@@ -273,7 +273,7 @@ class DeviceBatch:
 class DeviceScan:
     """A contig + solid-kmer set resident in HBM and the scan outputs."""
 
-    def __init__(self, gpu: HypoGpu, packed4: np.ndarray, n_bases: int, k: int, bits: np.ndarray, kids_cap=None):
+    def __init__(self, gpu: HypoGpu, packed4: np.ndarray, n_bases: int, k: int, bits: np.ndarray, kids_cap=None, misalign=0):
         import torch
         self.gpu, self.n_bases, self.k = gpu, n_bases, k
         dev = torch.device("cuda", gpu.device)
@@ -281,6 +281,10 @@ class DeviceScan:
         self.nw = (n_bases + 63) // 64
         self.kids_cap = n_bases if kids_cap is None else kids_cap
         self.packed4, self.bits = _t(packed4, dev), _t(bits, dev)
+        if misalign:                 # the contig at an address that is not a multiple of 8 (a view into a larger buffer)
+            self._backing = torch.zeros(self.packed4.numel() + misalign, dtype=torch.uint8, device=dev)
+            self._backing[misalign:] = self.packed4
+            self.packed4 = self._backing[misalign:]
         self.words = torch.zeros(max(self.nw, 1), dtype=torch.int64, device=dev)
         self.kids = torch.zeros(max(self.kids_cap, 1), dtype=torch.int64, device=dev)
         self.rank = torch.zeros(self.nw + 1, dtype=torch.int64, device=dev)

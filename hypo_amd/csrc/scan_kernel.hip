@@ -27,58 +27,76 @@ constexpr int SCAN_LDS_BYTES = SCAN_BYTES_PER_BLOCK + 32;         // + 1 byte be
 
 __device__ __forceinline__ unsigned nib(const uint8_t* p, long i) { return (p[i >> 1] >> (4 - 4 * (i & 1))) & 15; }
 
+// Stages the workgroup's 8 KiB of packed bases (+ one byte before, 16 after) into LDS: sb[16 + x] = packed4[blk_byte0 + x] for
+// x in [-1, 8192 + 16); out of range -> 0x44 ("NN").
+__device__ __forceinline__ void stage_block(const uint8_t* __restrict__ packed4, uint64_t n_bytes, uint64_t blk_byte0, uint8_t* sb) {
+    const int t = threadIdx.x;
+    for (int c = t; c < SCAN_BYTES_PER_BLOCK / 16 + 1; c += SCAN_THREADS) {
+        const uint64_t gb = blk_byte0 + (uint64_t)c * 16;
+        uint4 v;
+        if (gb + 16 <= n_bytes && ((uintptr_t)(packed4 + gb) & 15) == 0) {
+            v = *(const uint4*)(packed4 + gb);
+        } else {
+            uint8_t tmp[16];
+            for (int b = 0; b < 16; ++b) tmp[b] = (gb + b < n_bytes) ? packed4[gb + b] : (uint8_t)0x44;
+            v = *(uint4*)tmp;
+        }
+        *(uint4*)(sb + 16 + c * 16) = v;
+    }
+    if (t == 0) sb[15] = blk_byte0 > 0 ? packed4[blk_byte0 - 1] : (uint8_t)0x44;
+}
+
+// The k-mers that START at the lane's 64 positions (local nibble indices l0 .. l0 + 63 of the staged block), in position order:
+// emit(p, kmer, ok) with p = 0..63, ok = the k-mer has no N, lies inside the contig and passes the reference's two
+// homopolymer-edge tests (next base != last base, Contig.cpp:59; previous base != first base, Contig.cpp:63).  Bases come
+// out of LDS 8 at a time (one 32-bit read); the 2-bit k-mer, the run length since the last N and a history of "equals its
+// predecessor" bits roll in registers.  Fillers beyond the contig are N, so k-mers that would run over the end are never ok,
+// and a filler never equals a real base; `n_left` = bases of the contig from the lane's first position on (the pad nibble of an
+// odd-length contig is not a base).
+template <class Emit>
+__device__ __forceinline__ void roll64(const uint8_t* base, long l0, uint32_t k, int64_t n_left, Emit&& emit) {
+    const uint64_t kmask = (1ull << (2 * k)) - 1ull;     // k <= 31
+    uint64_t kmer = 0;
+    uint32_t klen = 0, eh = 0;
+    unsigned pb = (base[(l0 - 1) >> 1] >> (4 - 4 * ((l0 - 1) & 1))) & 15u;        // base before the first position
+    const uint8_t* src = base + (l0 >> 1);               // l0 is even: the lane's bases start on a byte
+    const int last = 63 + (int)k;                        // step t looks at base t: the k-mer ending at t - 1 starts at t - k
+    for (int w = 0; w * 8 <= last; ++w) {
+        const uint32_t word = __builtin_bswap32(*(const uint32_t*)(src + 4 * w));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = 8 * w + j;
+            const unsigned b = t < n_left ? (word >> (28 - 4 * j)) & 15u : 4u;
+            eh = (eh << 1) | (b == pb ? 1u : 0u);        // bit i: base t - i equals base t - i - 1
+            const int p = t - (int)k;
+            if (p >= 0 && p < 64) {
+                // reject: base t == base t - 1 (the k-mer's last), or base p == base p - 1 (bit t - p = k of the history)
+                const bool ok = klen >= k && ((eh | (eh >> k)) & 1u) == 0;
+                emit(p, kmer, ok);
+            }
+            if (b < 4) { kmer = ((kmer << 2) | b) & kmask; klen += klen < k ? 1u : 0u; }
+            else { kmer = 0; klen = 0; }
+            pb = b;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(SCAN_THREADS)
 scan_mark_kernel(const uint8_t* __restrict__ packed4, uint64_t n_bases, uint32_t k,
                  const uint64_t* __restrict__ bits, uint64_t* __restrict__ words,
                  uint32_t* __restrict__ wcount, uint64_t n_words) {
     __shared__ __attribute__((aligned(16))) uint8_t sb[SCAN_LDS_BYTES + 16];
-    const uint64_t n_bytes = (n_bases + 1) / 2;
-    const uint64_t blk_byte0 = (uint64_t)blockIdx.x * SCAN_BYTES_PER_BLOCK;
-    // sb[16 + x] = packed4[blk_byte0 + x] for x in [-1, 8192 + 16); out of range -> 0x44 ("NN")
-    {
-        const int t = threadIdx.x;
-        // main body: 8192 bytes = 512 x 16 B, two per lane
-        for (int c = t; c < SCAN_BYTES_PER_BLOCK / 16 + 1; c += SCAN_THREADS) {
-            const uint64_t gb = blk_byte0 + (uint64_t)c * 16;
-            uint4 v;
-            if (gb + 16 <= n_bytes && ((uintptr_t)(packed4 + gb) & 15) == 0) {
-                v = *(const uint4*)(packed4 + gb);
-            } else {
-                uint8_t tmp[16];
-                for (int b = 0; b < 16; ++b) tmp[b] = (gb + b < n_bytes) ? packed4[gb + b] : (uint8_t)0x44;
-                v = *(uint4*)tmp;
-            }
-            *(uint4*)(sb + 16 + c * 16) = v;
-        }
-        if (t == 0) sb[15] = blk_byte0 > 0 ? packed4[blk_byte0 - 1] : (uint8_t)0x44;
-    }
+    stage_block(packed4, (n_bases + 1) / 2, (uint64_t)blockIdx.x * SCAN_BYTES_PER_BLOCK, sb);
     __syncthreads();
     const uint64_t word = (uint64_t)blockIdx.x * SCAN_THREADS + threadIdx.x;
     if (word >= n_words) return;
-    const uint8_t* base = sb + 16;                       // base[-1] valid
-    const long l0 = (long)threadIdx.x * 64;              // local index of my first position
-    const uint64_t g0 = word * 64;                       // global index of my first position
-    const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
-    uint64_t kmer = 0, out = 0;
-    uint32_t klen = 0;
-    const int steps = 64 + (int)k - 1;
-    for (int s = 0; s < steps; ++s) {
-        const uint64_t gi = g0 + (uint64_t)s;            // k-mer END position i (Contig.cpp:46)
-        if (gi >= n_bases) break;
-        const unsigned b = nib(base, l0 + s);
-        if (b < 4) { kmer = ((kmer << 2) | b) & kmask; if (klen < k) ++klen; }
-        else { klen = 0; kmer = 0; }
-        if (klen == k) {
-            const long lbeg = l0 + s + 1 - (long)k;      // local k-mer start
-            const uint64_t gbeg = gi + 1 - k;
-            if ((bits[kmer >> 6] >> (kmer & 63)) & 1ull) {
-                bool add = true;
-                if (gi + 1 < n_bases && nib(base, l0 + s + 1) == b) add = false;          // Contig.cpp:59
-                if (gbeg > 0 && nib(base, lbeg - 1) == nib(base, lbeg)) add = false;      // Contig.cpp:63
-                if (add) out |= 1ull << (gbeg - g0);
-            }
-        }
-    }
+    uint64_t out = 0;
+    // the probe is issued for every position (word 0 of the set where the k-mer is not a candidate): no branch between the
+    // loads, so many of them are in flight per lane
+    roll64(sb + 16, (long)threadIdx.x * 64, k, (int64_t)n_bases - (int64_t)(word * 64), [&](int p, uint64_t kmer, bool ok) {
+        const uint64_t wd = bits[ok ? (kmer >> 6) : 0];
+        out |= (uint64_t)(ok && ((wd >> (kmer & 63)) & 1ull)) << p;
+    });
     words[word] = out;
     wcount[word] = (uint32_t)__popcll(out);
 }
@@ -153,21 +171,56 @@ scan_rank_final(const uint32_t* __restrict__ wcount, uint64_t n_words, const uin
 }
 
 // ---- k-mer ids of the marked positions, in position order --------------------------------------
+// 16 bases (one big-endian 64-bit word of nibbles) -> 32 bits, first base on top.  The nibbles of a marked k-mer are 0..3; the
+// ones after it in the word may be N and are cut down to two bits so that they cannot spill into their neighbour.
+__device__ __forceinline__ uint32_t squeeze16(uint64_t x) {
+    x &= 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+    return (uint32_t)x;
+}
+
+// One lane per output word.  A marked position reads the two or three aligned 8-byte words that hold its k bases (neighbouring
+// marks share them in L2), lines the nibbles up with two funnel shifts and squeezes them to 2 bits each.  The words are
+// aligned in memory: a contig that does not start on an 8-byte boundary is read from the boundary before it (same 8-byte
+// word, so same page), the bytes after the last whole word one by one.
+__device__ __forceinline__ uint64_t be_qword(const uint64_t* q8, uint64_t q, uint64_t n_full, uint64_t n_total_bytes) {
+    if (q < n_full) return __builtin_bswap64(q8[q]);
+    uint64_t v = 0;
+    const uint8_t* p = (const uint8_t*)q8;
+    for (int i = 0; i < 8; ++i) { const uint64_t at = q * 8 + (uint64_t)i; v = (v << 8) | (at < n_total_bytes ? p[at] : 0u); }
+    return v;
+}
 __global__ void __launch_bounds__(256)
-scan_kids_kernel(const uint8_t* __restrict__ packed4, uint32_t k, const uint64_t* __restrict__ words,
+scan_kids_kernel(const uint8_t* __restrict__ packed4, uint64_t n_bytes, uint32_t k, const uint64_t* __restrict__ words,
                  const uint64_t* __restrict__ word_rank, uint64_t n_words,
                  uint64_t* __restrict__ kids, uint64_t kids_cap) {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_words) return;
     uint64_t m = words[w];
     uint64_t r = word_rank[w];
+    const uint64_t mis = (uint64_t)((uintptr_t)packed4 & 7);
+    const uint64_t* q8 = (const uint64_t*)(packed4 - mis);
+    const uint64_t n_total = mis + n_bytes, n_full = n_total / 8;
     while (m) {
         const int b = __ffsll((unsigned long long)m) - 1;
         m &= m - 1;
         if (r < kids_cap) {
-            const uint64_t beg = w * 64 + (uint64_t)b;
-            uint64_t kmer = 0;
-            for (uint32_t t = 0; t < k; ++t) kmer = (kmer << 2) | (nib(packed4, (long)(beg + t)) & 3);
+            const uint64_t beg = w * 64 + (uint64_t)b + 2 * mis;          // nibble index of the first base, from the aligned boundary
+            const uint64_t q = beg >> 4;                                 // 16 nibbles per 8-byte word
+            const int sh = 4 * (int)(beg & 15);
+            const uint64_t w0 = be_qword(q8, q, n_full, n_total);
+            const uint64_t w1 = be_qword(q8, q + 1, n_full, n_total);
+            const uint64_t hi = sh ? (w0 << sh) | (w1 >> (64 - sh)) : w0;                 // bases 0..15
+            uint64_t kmer;
+            if (k <= 16) kmer = (uint64_t)squeeze16(hi) >> (2 * (16 - k));
+            else {
+                const uint64_t w2 = be_qword(q8, q + 2, n_full, n_total);
+                const uint64_t lo = sh ? (w1 << sh) | (w2 >> (64 - sh)) : w1;             // bases 16..31
+                kmer = (((uint64_t)squeeze16(hi) << 32) | squeeze16(lo)) >> (2 * (32 - k));
+            }
             kids[r] = kmer;
         }
         ++r;
@@ -215,7 +268,7 @@ hipError_t scan_run(const uint8_t* packed4, uint64_t n_bases, uint32_t k, const 
     if (prof_ev) (void)hipEventRecord(prof_ev[2], stream);
     if (kids && kids_cap)
         hipLaunchKernelGGL(scan_kids_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, stream,
-                           packed4, k, words, word_rank, n_words, kids, kids_cap);
+                           packed4, (n_bases + 1) / 2, k, words, word_rank, n_words, kids, kids_cap);
     if (prof_ev) (void)hipEventRecord(prof_ev[3], stream);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (n_solid) return hipMemcpyAsync(n_solid, total, 8, hipMemcpyDeviceToDevice, stream);

@@ -71,6 +71,22 @@ def test_scan_random_sizes_and_k(gpu, oracle_lib):
         assert ns == ons and (w == ow).all() and (kids == okids).all() and (rank == orank).all(), (it, n, k, nfrac, dens)
 
 
+@pytest.mark.parametrize("mis", [1, 3, 4, 7])
+def test_scan_contig_not_8_byte_aligned(gpu, oracle_lib, mis):
+    """The k-mer id kernel reads the contig in aligned 8-byte words: a contig that starts anywhere inside such a word, lengths
+    that end anywhere inside one."""
+    for n, k in ((100003 + mis, 13), (4099, 16), (77, 9), (16, 16)):
+        codes, p4 = sim.random_contig(n, seed=n + mis, n_frac=0.001)
+        nwords = max(1, (1 << (2 * k)) // 64)
+        rng = np.random.default_rng(n)
+        bits = rng.integers(0, 1 << 63, size=nwords, dtype=np.int64).view(np.uint64) | np.uint64(1 << 63)      # ~ half of all k-mers
+        ds = gpu.device_scan(p4, n, k, bits, misalign=mis)
+        ds.run()
+        w, kids, rank, ns = ds.results()
+        ow, okids, orank, ons = oracle_lib.solid_scan(p4, n, k, bits)
+        assert ns == ons and (w == ow).all() and (kids == okids).all() and (rank == orank).all(), (n, k, mis)
+
+
 def test_scan_vs_reference_fixture(gpu):
     """G3: the device against the outputs of the REAL hypo::Contig::find_solid_pos (tests/golden/scan_cases.json.gz)."""
     from test_scan_golden import scan_cases
