@@ -123,7 +123,10 @@ struct PoaCfg {
     static constexpr int SEQMAX = SEQMAX_;      // sequences (arms + backbone) per window
     static constexpr int AL = 6;                // aligned clique partners (alphabet ACGTNJO -> at most 6)
     static constexpr int STK = HYBRID_ ? 1536 : 2 * NMAX_;   // DFS stack entries (hybrid: the LDS copy is smaller; deeper DFS -> next class)
-    static constexpr int RING1 = HYBRID_ ? 6 : 0;  // hybrid: this many most recent score rows are also kept in LDS
+    #ifndef HYPO_RING1
+#define HYPO_RING1 6
+#endif
+    static constexpr int RING1 = HYBRID_ ? HYPO_RING1 : 0;  // hybrid: this many most recent score rows are also kept in LDS
     // direction codes: 4 bits when the pred index fits (diag p = p, vert p = 7+p, horiz = 14, fast = 15)
     static constexpr bool NIB = (KIN_ <= 7) && (CPL_ % 2 == 0);
     static constexpr int DIRBYTES = NIB ? DIRCELLS_ / 2 : DIRCELLS_;
@@ -248,7 +251,7 @@ struct Poa {
     uint32_t cells, aligns, reused, exact_hits, cells_scored, cells_exact;
 #if defined(HYPO_PHASE_TIMERS) || defined(HYPO_EMU)
 #define HYPO_DIAG(x) do { x; } while (0)
-    uint32_t rows_done, topo_runs, cons_serial, rows_slow, exact_tries, rows_exact_n, rows_scored_n;
+    uint32_t rows_done, topo_runs, cons_serial, rows_slow, exact_tries, rows_exact_n, rows_scored_n, topo_dfs, topo_fast;
 #else
 #define HYPO_DIAG(x) do { } while (0)
 #endif
@@ -276,7 +279,7 @@ struct Poa {
         n_paths = 0; path_used = 0; head_first = 0;
         n_nodes = 0; L = 0; topo_dirty = false; meta_dirty = true; maxdelta = 0; last_source = 0; tb_steps = 0; tb_fv = 0;
         cells = 0; aligns = 0; reused = 0; exact_hits = 0; cells_scored = 0; cells_exact = 0; last_changed = true;
-        HYPO_DIAG(rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; rows_exact_n = 0; rows_scored_n = 0);
+        HYPO_DIAG(rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; rows_exact_n = 0; rows_scored_n = 0; topo_dfs = 0; topo_fast = 0);
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
         tlast = 0;
         HYPO_TICK_RESET();
@@ -1580,6 +1583,7 @@ struct Poa {
             const uint64_t cb = g.ballot(clq);
             const bool has_clq = run < GW && ((cb >> run) & 1ull);
             if (run > 0 || has_clq) {
+                HYPO_DIAG(topo_fast += 1);
                 const bool em = g.lane < run && !isdone;       // lanes < run have r < n_nodes (pre is false beyond)
                 const uint64_t eb = g.ballot(em);
                 if (em) { r2n[cnt + popc64(eb & ((1ull << g.lane) - 1ull))] = (id_t)r; mark[r] = 1; }
@@ -1603,6 +1607,7 @@ struct Poa {
             g.sync();
             while (sp > 0) {
                 if (++guard > 8 * Cfg::STK + 64) return RES_UNDEFINED;
+                HYPO_DIAG(topo_dfs += 1);
                 const int v = stack[sp - 1];
                 const int mv = mark[v];
                 if (mv & 1) { --sp; continue; }
@@ -2043,7 +2048,7 @@ struct Poa {
     HD int run(uint32_t w) {
         // the object outlives the window (one per persistent group): per-window counters and flags start over here
         cells = 0; aligns = 0; reused = 0; exact_hits = 0; cells_scored = 0; cells_exact = 0; last_changed = true;
-        HYPO_DIAG(rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; rows_exact_n = 0; rows_scored_n = 0);
+        HYPO_DIAG(rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; rows_exact_n = 0; rows_scored_n = 0; topo_dfs = 0; topo_fast = 0);
         n_paths = 0; path_used = 0; head_first = 0; L = 0; maxdelta = 0; tb_steps = 0; tb_fv = 0; need_nodes = 0;
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
         HYPO_TICK_RESET();

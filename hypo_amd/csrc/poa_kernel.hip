@@ -173,8 +173,12 @@ struct PoaKArgs {
 typedef const PoaKArgs __attribute__((address_space(4)))* PoaKArgPtr;
 __device__ __forceinline__ PoaKArgPtr fresh(PoaKArgPtr p) { asm volatile("" : "+s"(p)); return p; }
 
+#ifndef HYPO_C4_WAVES
+#define HYPO_C4_WAVES 2
+#endif
+template <class Cfg> struct PoaMinWaves { static constexpr int value = Cfg::HYBRID ? HYPO_C4_WAVES : 1; };
 template <class Cfg, bool USE_LDS>
-__global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through the kernarg segment*/) {
+__global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(PoaKArgs /*read through the kernarg segment*/) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const PoaKArgPtr ka = (PoaKArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
     constexpr int GW = Cfg::GW;
@@ -195,7 +199,7 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through t
     uint32_t n_ok = 0, n_esc = 0, n_fail = 0;
 #ifdef HYPO_PHASE_TIMERS
     uint64_t tph[PH_N] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t dbg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t dbg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const uint64_t tstart = (uint64_t)clock64();
 #endif
     // what happens to a window once Poa::run / step has returned something other than RES_CONTINUE
@@ -204,7 +208,7 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through t
         c_scored += poa.cells_scored; c_thr += poa.cells_exact;                // executed work, finished or not
 #ifdef HYPO_PHASE_TIMERS
         for (int i = 0; i < PH_N; ++i) tph[i] += poa.tphase[i];
-        dbg[0] += poa.rows_done; dbg[1] += poa.aligns - poa.reused; dbg[2] += poa.reused; dbg[3] += poa.topo_runs; dbg[4] += poa.cons_serial; dbg[5] += poa.rows_slow; dbg[6] += poa.exact_tries; dbg[7] += poa.exact_hits; dbg[8] += poa.rows_exact_n; dbg[9] += poa.rows_scored_n;
+        dbg[0] += poa.rows_done; dbg[1] += poa.aligns - poa.reused; dbg[2] += poa.reused; dbg[3] += poa.topo_runs; dbg[4] += poa.cons_serial; dbg[5] += poa.rows_slow; dbg[6] += poa.exact_tries; dbg[7] += poa.exact_hits; dbg[8] += poa.rows_exact_n; dbg[9] += poa.rows_scored_n; dbg[10] += poa.topo_dfs; dbg[11] += poa.topo_fast;
 #endif
         if (rc == RES_OK) {
             ++n_ok;
@@ -275,7 +279,7 @@ __global__ void __launch_bounds__(64) poa_class_kernel(PoaKArgs /*read through t
         for (int i = 0; i < PH_N; ++i) atomicAdd(&ph[i], (unsigned long long)tph[i]);
         atomicAdd(&ph[PH_N], (unsigned long long)((uint64_t)clock64() - tstart));                // wave lifetime
         atomicAdd(&ph[PH_N + 1], 1ull);                                                           // waves
-        for (int i = 0; i < 10; ++i) atomicAdd(&ph[PH_N + 2 + i], (unsigned long long)dbg[i]);      // rows, real alignments, reused, toposorts, serial consensus passes, slow rows, exact tries / hits
+        for (int i = 0; i < 12; ++i) atomicAdd(&ph[PH_N + 2 + i], (unsigned long long)dbg[i]);      // rows, real alignments, reused, toposorts, serial consensus passes, slow rows, exact tries / hits
 #endif
     }
 }

@@ -9,7 +9,10 @@ constexpr int kFirstGlobalClass = 4;     // classes >= this keep their state in 
 constexpr int kFirstLongClass = 4;       // LONG windows (<= 500 bp, ~1.3 k nodes) start here
 // resident groups of the HBM-scratch classes (one wavefront each; the scratch is provisioned for this many).  The LONG class
 // is register-bound at 2 waves per SIMD: 8 per CU x 256 CUs; the last class is a rare safety net.
-constexpr int kMaxGlobalGroups4 = 2048;
+#ifndef HYPO_C4_GROUPS
+#define HYPO_C4_GROUPS 2048
+#endif
+constexpr int kMaxGlobalGroups4 = HYPO_C4_GROUPS;
 constexpr int kMaxGlobalGroups5 = 64;
 inline int max_global_groups(int cls, uint32_t n_windows) {
     const int cap = cls == 4 ? kMaxGlobalGroups4 : kMaxGlobalGroups5;

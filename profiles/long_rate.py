@@ -25,15 +25,26 @@ def main():
     db.run(); torch.cuda.synchronize()
     t0 = time.perf_counter(); db.run(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     st = db.stats()
+    gpu.profile_begin(2)
+    for _ in range(2):
+        db.run()
+    torch.cuda.synchronize()
+    print("kernel times of a call, ms [plan, class 0..5, call]:", [round(float(x), 2) for x in gpu.profile_read()[-1]], "escalated", st["n_escalated"])
     print(f"GPU: {len(wins)} LONG windows in {dt * 1e3:.1f} ms = {len(wins) / dt:.0f} windows/s; cells {st['dp_cells'] / 1e9:.2f} G -> {st['dp_cells'] / dt / 1e9:.1f} GCUPS; classes {st['n_class'][:5]} failed {st['n_failed']}")
     if lib and "prof" in lib:
         import numpy as np
-        names = ["load_seq", "dp_rows", "traceback", "add_alignment", "toposort", "consensus", "output", "rowmeta"]
-        ph = db.workspace[512:512 + 8 * 16 * 8].cpu().numpy().view(np.uint64).reshape(8, 16)
+        names = ["load_seq", "dp_rows", "traceback", "add_alignment", "toposort", "consensus", "output", "rowmeta", "exact_rows"]
+        NP = len(names)                                   # then lifetime, waves, 10 counters (poa_kernel.hip)
+        ph = db.workspace[512:512 + 8 * 24 * 8].cpu().numpy().view(np.uint64).reshape(8, 24)
         c = 4
-        tot = float(ph[c, :8].sum())
-        print("class 4 phases: " + ", ".join(f"{n} {100 * ph[c, i] / tot:.1f}%" for i, n in enumerate(names)),
-              f"; rows/window {ph[c, 10] / max(st['n_class'][c], 1) / 2:.0f} (per run), cycles/row {ph[c, 1] / max(ph[c, 10], 1):.0f}")
+        tot = float(ph[c, :NP].sum())
+        nw = max(st['n_class'][c], 1)
+        D = NP + 2
+        print(f"class 4: waves={int(ph[c, NP + 1])} cycles/window={ph[c, NP] / nw / 1e3:.0f}k accounted={100 * tot / float(ph[c, NP]):.1f}%")
+        print("class 4 phases: " + ", ".join(f"{n} {100 * ph[c, i] / tot:.1f}%" for i, n in enumerate(names)))
+        print(f"    per window: rows={ph[c, D] / nw:.0f} alignments={ph[c, D + 1] / nw:.1f} reused={ph[c, D + 2] / nw:.1f} toposorts={ph[c, D + 3] / nw:.1f}"
+              f" serial consensus={ph[c, D + 4] / nw:.2f}; score rows {ph[c, D + 9] / nw:.0f} at {ph[c, 1] / max(ph[c, D + 9], 1):.0f} cycles/row;"
+              f" toposort {ph[c, 4] / max(ph[c, D + 3], 1) / 1e3:.1f} kcycles each, {ph[c, D + 10] / max(ph[c, D + 3], 1):.0f} DFS steps + {ph[c, D + 11] / max(ph[c, D + 3], 1):.0f} run steps")
     import oracle
     orc = oracle.Oracle()
     sub = build_batch(wins[:len(recs) * min(rep, 2)])
