@@ -150,7 +150,16 @@ struct Carver {                                       // lays arrays out in one 
 // the difference).
 void warm_up(Ctx* c) {
     if (hipSetDevice(c->device) != hipSuccess) return;
-    hipStream_t st = c->stream;
+    // On the HIP null stream, with side streams of its own that are destroyed again: a process gets four hardware queues by
+    // default (GPU_MAX_HW_QUEUES), the POA call uses four streams (the caller's + three side streams), and a warm-up on a fifth
+    // stream made two of them share a queue for the rest of the run — measured as a shifted balance of the three concurrent class
+    // kernels, C2 step 3.70 -> 4.27 ms.  HYPO_WARMUP_STREAM=0 (diagnostic) runs it on the context's stream as before, 2 on a
+    // stream that is created and destroyed here.
+    const char* ws_env = getenv("HYPO_WARMUP_STREAM");
+    const int ws_mode = ws_env ? atoi(ws_env) : 1;
+    hipStream_t st = nullptr, own = nullptr;
+    if (ws_mode == 0) st = c->stream;
+    if (ws_mode == 2 && hipStreamCreateWithFlags(&own, hipStreamNonBlocking) == hipSuccess) st = own;
     const uint32_t nw = 2, na = 4;
     const size_t wsb = hypo::poa_workspace_bytes(nw, hypo::kMinGlobalGroups, 0), swb = hypo::scan_workspace_bytes(64);
     Carver cv;
@@ -175,10 +184,12 @@ void warm_up(Ctx* c) {
     P.arms2 = (const uint8_t*)(d + o_arms); P.out_bases = d + o_bases; P.out_off = (const uint64_t*)(d + o_off); P.out_len = (uint32_t*)(d + o_len); P.out_status = (uint8_t*)(d + o_st);
     P.sr_m = 5; P.sr_n = -4; P.sr_g = -8; P.lr_m = 3; P.lr_n = -5; P.lr_g = -4;
     P.n_arms = na; P.draft4_bytes = 64; P.arms2_bytes = 64; P.flags = 0;
-    (void)hypo::poa_run(P, nw, d + o_ws, wsb, c->num_cus, st, nullptr, &c->slots[0].aux);
+    hypo::PoaAux tmp;
+    (void)hypo::poa_run(P, nw, d + o_ws, wsb, c->num_cus, st, nullptr, &tmp);
     (void)hypo::scan32((const uint32_t*)(d + o_alen), na, (uint64_t*)(d + o_scan), (uint64_t*)(d + o_sws), (uint64_t*)(d + o_n), st);
     (void)hipStreamSynchronize(st);
-    c->slots[0].aux.history_valid = false;                // the first real batch plans for itself
+    hypo::poa_release(&tmp);
+    if (own) (void)hipStreamDestroy(own);
     (void)hipFree(d);
     (void)hipGetLastError();
 }

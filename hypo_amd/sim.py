@@ -48,12 +48,14 @@ def load_shape(name: str = "c1_shape"):
 
 
 def window_batch(n_windows: int, seed: int = 1, shape: str = "c1_shape", read_sub: float = 0.002,
-                 draft_err: float = 0.012, shapes=None) -> HostBatch:
+                 draft_err: float = 0.012, shapes=None, long_mask=None, long_err: float = 0.10) -> HostBatch:
     """Synthetic SHORT-window batch.  Each window: random truth; draft = truth with `draft_err`
     (1/3 substitutions, 1/3 deletions, 1/3 insertions); internal arms = truth with `read_sub`
     substitutions; prefix arms = truth prefixes of increasing length, suffix arms = truth suffixes of
     decreasing length (BAM order, cf. Window.cpp:110).  `shapes` (array [n,5] of
-    (window_len, n_internal, n_prefix, n_suffix, n_empty)) overrides sampling from the shape table."""
+    (window_len, n_internal, n_prefix, n_suffix, n_empty)) overrides sampling from the shape table.
+    `long_mask` (bool [n]): these windows are LONG windows (Window.cpp:156-254) whose arms are noisy long-read
+    segments: `long_err` errors per base, a third each substitutions, deletions and insertions."""
     rng = np.random.default_rng(seed)
     if shapes is None:
         tab, cnt = load_shape(shape)
@@ -111,9 +113,34 @@ def window_batch(n_windows: int, seed: int = 1, shape: str = "c1_shape", read_su
     acodes = truth[src]
     e = rng.random(acodes.size) < read_sub
     acodes[e] = (acodes[e] + rng.integers(1, 4, size=int(e.sum()), dtype=np.uint8)) % 4
+    if long_mask is not None and np.any(long_mask):
+        # indels in the arms of the LONG windows: per base keep / delete, plus an inserted random base behind it
+        is_long_base = np.repeat(np.asarray(long_mask, dtype=bool)[arm_win], alen)
+        r2 = rng.random(acodes.size)
+        sub2 = is_long_base & (r2 < long_err / 3)
+        dele = is_long_base & (r2 >= long_err / 3) & (r2 < 2 * long_err / 3)
+        ins2 = is_long_base & (rng.random(acodes.size) < long_err / 3)
+        acodes[sub2] = (acodes[sub2] + rng.integers(1, 4, size=int(sub2.sum()), dtype=np.uint8)) % 4
+        rep2 = (~dele).astype(np.int64) + ins2.astype(np.int64)
+        arm_of_base = np.repeat(np.arange(A), alen)
+        new_len = np.bincount(arm_of_base, weights=rep2, minlength=A).astype(np.int64)
+        gone = (new_len == 0) & (alen > 0)                 # never delete an arm completely
+        if gone.any():
+            astart0 = np.zeros(A + 1, dtype=np.int64)
+            np.cumsum(alen, out=astart0[1:])
+            rep2[astart0[:-1][gone]] = 1
+            new_len[gone] = 1
+        out = np.repeat(acodes, rep2)
+        cum2 = np.cumsum(rep2)
+        second = np.zeros(out.size, dtype=bool)
+        second[cum2[rep2 == 2] - 1] = True
+        out[second] = rng.integers(0, 4, size=int(second.sum()), dtype=np.uint8)
+        acodes, alen = out, new_len
     arms2, aoff, alen32 = _pack_codes(acodes, alen, 4)
     wd = np.zeros(n, dtype=abi.WINDOW_DTYPE)
     wd["type"] = abi.WIN_SHORT
+    if long_mask is not None:
+        wd["type"][np.asarray(long_mask, dtype=bool)] = abi.WIN_LONG
     wd["draft_len"] = dlen32
     wd["draft_off"] = doff
     wd["first_arm"] = first_arm[:-1]
@@ -177,3 +204,18 @@ def solid_bitset(codes: np.ndarray, k: int, max_count: int = 1) -> np.ndarray:
     ids = np.concatenate([sel, r]).astype(np.uint64)
     np.bitwise_or.at(words, (ids >> np.uint64(6)).astype(np.int64), np.uint64(1) << (ids & np.uint64(63)))
     return words
+
+
+def c4_batch(n_short: int, n_long: int, seed: int = 1, long_err: float = 0.10) -> HostBatch:
+    """The window mix of BASELINE config C4 (short reads + noisy long reads, `-B`): C1-shaped SHORT windows and LONG windows
+    (120-500 bp, 12-45 long-read arms of about the window's length with `long_err` errors incl. indels, up to two empty arms),
+    shuffled into one batch as Hypo::polish hands them over."""
+    rng = np.random.default_rng(seed)
+    tab, cnt = load_shape("c1_shape")
+    sh = tab[rng.choice(tab.shape[0], size=n_short, p=cnt / cnt.sum())]
+    zeros = np.zeros(n_long, np.int64)
+    lg = np.stack([rng.integers(120, 500, size=n_long), rng.integers(12, 45, size=n_long), zeros, zeros, rng.integers(0, 3, size=n_long)], axis=1)
+    shapes = np.concatenate([sh, lg])
+    mask = np.concatenate([np.zeros(n_short, bool), np.ones(n_long, bool)])
+    perm = rng.permutation(shapes.shape[0])
+    return window_batch(0, seed=seed + 1, shapes=shapes[perm], long_mask=mask[perm], long_err=long_err)

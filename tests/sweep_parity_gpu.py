@@ -35,33 +35,40 @@ def compare(gpu, orc, b, scores, tag):
     return b.n_windows
 
 
+def one_round(gpu, orc, rnd):
+    """One round of the sweep (seeded by `rnd`): ~0.54 M windows through libhypo_gpu and the oracle; exits on the first mismatch."""
+    total = 0
+    default = (5, -4, -8, 3, -5, -4)
+    for sub in (0.002, 0.01, 0.03):
+        for lanes in ("16", "32"):
+            os.environ["HYPO_POA_CLASS0"] = lanes
+            total += compare(gpu, orc, sim.window_batch(60000, seed=5000 + rnd, read_sub=sub), default, f"sim sub={sub} lanes={lanes} round={rnd}")
+    os.environ.pop("HYPO_POA_CLASS0", None)
+    # tiny windows almost only (the rule picks four class-0 groups per wave), many arms per window, wide windows
+    rs = np.random.default_rng(9000 + rnd)
+    n = 80000
+    wl = rs.choice([3, 5, 8, 12, 16, 24, 32, 48, 64, 99], size=n, p=[.15, .15, .15, .13, .13, .1, .1, .05, .03, .01])
+    for lo, hi, tag in ((3, 45, "dense"), (44, 58, "hifi")):
+        shapes = np.stack([wl, rs.integers(lo, hi, size=n), np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.int64)], axis=1)
+        total += compare(gpu, orc, sim.window_batch(n, seed=9100 + rnd, shapes=shapes, read_sub=0.004), default, f"{tag} round={rnd}")
+    for length in (130, 160, 200):
+        total += compare(gpu, orc, sim.grid_batch(length, 20, 1500, 0.01, seed=9200 + rnd), default, f"wide {length} round={rnd}")
+    rng = np.random.default_rng(7000 + rnd)
+    for scores in (default, (3, -6, -5, 3, -5, -4), (1, -1, -1, 1, -1, -1)):
+        wins = [_window(rng, False) for _ in range(6000)] + [_window(rng, True) for _ in range(150)]
+        total += compare(gpu, orc, build_batch(wins), scores, f"fuzz scores={scores} round={rnd}")
+    return total
+
+
 def main():
     minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 5.0
     gpu = capi.HypoGpu(0)
     orc = oracle.Oracle()
     t_end = time.time() + 60 * minutes
     total, rnd = 0, (int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-    default = (5, -4, -8, 3, -5, -4)
     while time.time() < t_end:
         rnd += 1
-        for sub in (0.002, 0.01, 0.03):
-            for lanes in ("16", "32"):
-                os.environ["HYPO_POA_CLASS0"] = lanes
-                total += compare(gpu, orc, sim.window_batch(60000, seed=5000 + rnd, read_sub=sub), default, f"sim sub={sub} lanes={lanes} round={rnd}")
-        os.environ.pop("HYPO_POA_CLASS0", None)
-        # tiny windows almost only (the rule picks four class-0 groups per wave), many arms per window, wide windows
-        rs = np.random.default_rng(9000 + rnd)
-        n = 80000
-        wl = rs.choice([3, 5, 8, 12, 16, 24, 32, 48, 64, 99], size=n, p=[.15, .15, .15, .13, .13, .1, .1, .05, .03, .01])
-        for lo, hi, tag in ((3, 45, "dense"), (44, 58, "hifi")):
-            shapes = np.stack([wl, rs.integers(lo, hi, size=n), np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.int64)], axis=1)
-            total += compare(gpu, orc, sim.window_batch(n, seed=9100 + rnd, shapes=shapes, read_sub=0.004), default, f"{tag} round={rnd}")
-        for length in (130, 160, 200):
-            total += compare(gpu, orc, sim.grid_batch(length, 20, 1500, 0.01, seed=9200 + rnd), default, f"wide {length} round={rnd}")
-        rng = np.random.default_rng(7000 + rnd)
-        for scores in (default, (3, -6, -5, 3, -5, -4), (1, -1, -1, 1, -1, -1)):
-            wins = [_window(rng, False) for _ in range(6000)] + [_window(rng, True) for _ in range(150)]
-            total += compare(gpu, orc, build_batch(wins), scores, f"fuzz scores={scores} round={rnd}")
+        total += one_round(gpu, orc, rnd)
         print(f"round {rnd}: {total} windows identical so far", flush=True)
     print(f"OK: {total} windows, 0 mismatches")
 

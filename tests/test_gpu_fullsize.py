@@ -225,3 +225,30 @@ def test_sharded_batch_rccl_gather_single_rank(gpu):
     """The RCCL leg of the same call (library loaded on demand, ncclCommInitAll, grouped broadcasts of bases / lengths /
     status, copy back from device 0) with a communicator of one rank: everything but a second GPU."""
     _fresh_contexts([0], {"HYPO_MULTI_GATHER": "rccl"})
+
+
+def test_parity_sweep_one_round(gpu, oracle_lib):
+    """One seeded round of tests/sweep_parity_gpu.py inside -m gpu (~0.54 M windows: simulator batches at 0.2 / 1 / 3 % read error
+    in both class-0 geometries, dense and HiFi-depth tiny windows, wide windows, fuzzed windows under three score sets), every
+    consensus compared byte for byte with the oracle.  The open-ended sweep stays opt-in (110 M windows in round 1)."""
+    import sweep_parity_gpu as sweep
+    try:
+        n = sweep.one_round(gpu, oracle_lib, 424242)
+    except SystemExit as e:                         # compare() exits on the first mismatch after printing it
+        pytest.fail(f"parity sweep mismatch (exit {e.code})")
+    assert n > 500000
+
+
+def test_c4_mixed_short_and_long_batch_vs_oracle(gpu, oracle_lib):
+    """BASELINE config C4's window mix at size: 150 000 C1-shaped SHORT windows and 4 000 LONG windows (120-500 bp, 12-45 arms with
+    10 % errors incl. indels, two rounds + curate) shuffled into ONE batch; every consensus equals the oracle's."""
+    b = sim.c4_batch(150000, 4000, seed=404)
+    off = b.slot_layout()
+    bases, _, ln, st = gpu.poa_batch(b, off=off)
+    ob, _, oln, ost = oracle_lib.poa_batch_raw(b, off=off)[:4]
+    assert (st == ost).all() and (ln == oln).all() and (st == 0).all()
+    want, got = _cons_list(ob, off, oln), _cons_list(bases, off, ln)
+    bad = [i for i in range(len(want)) if want[i] != got[i]]
+    assert not bad, f"{len(bad)} windows differ, first {bad[0]} (type {int(b.windows['type'][bad[0]])})"
+    is_long = b.windows["type"] == abi.WIN_LONG
+    assert int(is_long.sum()) == 4000 and (ln[is_long] > 60).all()
