@@ -511,10 +511,13 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     hipStream_t* const aux = A->aux;
     hipEvent_t* const join_ev = A->join_ev;
     hipEvent_t& fork_ev = A->fork_ev;
-    // waves per CU of the three concurrent kernels (they share the CU's 160 KB of LDS, which is what bounds residency).  Swept on C2
-    // with the round-2 kernels (ms per call, profiles/diag/caps_sweep.sh): {5,5,5} 3.29, {6,6,6} 3.31, {4,6,5} 3.47, {5,5,6} 3.52,
-    // {4,4,6} 3.69 (the round-1 optimum), {3,5,6} 3.80.  Class 0 is set below.
-    int caps[kNumPoaClasses] = {5, 5, 5, 0, 0, 0};
+    // waves per CU of the three concurrent kernels (they share the CU's 160 KB of LDS, which is what bounds residency: 7.6 / 15.8 /
+    // 14.1 KB per wave of classes 0 / 1 / 2).  Caps whose footprints add up to about one CU's LDS make the split independent of
+    // which kernel the dispatcher happens to serve first — with {5,5,5} (187 KB) the last one to arrive got what was left until
+    // another finished, and which one that was depended on the stream -> hardware queue mapping of the process (C2 call 3.5 - 4.2 ms
+    // for the same code).  Swept on C2 under two mappings (profiles/diag/caps_fit_sweep.sh, ms per call): {4,4,5} 3.48 / 3.48,
+    // {3,4,5} 3.64 / 3.55, {4,3,5} 3.60 / 3.71, {4,4,4} 3.64 / 3.94, {5,5,5} 3.61 / 3.78, {5,4,4} 3.58 / 4.13.  Class 0 is set below.
+    int caps[kNumPoaClasses] = {4, 4, 5, 0, 0, 0};
     if (const char* cs = getenv("HYPO_POA_CAPS")) sscanf(cs, "%d,%d,%d,%d,%d", &caps[0], &caps[1], &caps[2], &caps[3], &caps[4]);
     const char* seq_env = getenv("HYPO_POA_SEQUENTIAL");
     const bool sequential = seq_env && atoi(seq_env) > 0;
@@ -540,7 +543,7 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
         const uint64_t lds_windows = (uint64_t)planned_host[0] + planned_host[1] + planned_host[2];
         bool four_groups = (uint64_t)planned_host[0] * 100 > lds_windows * 85;
         if (const char* g0 = getenv("HYPO_POA_CLASS0")) four_groups = atoi(g0) == 16;      // 16 | 32: lanes per group (tests)
-        if (!getenv("HYPO_POA_CAPS")) caps[0] = four_groups ? 6 : 5;
+        if (!getenv("HYPO_POA_CAPS")) caps[0] = four_groups ? 7 : 4;      // (dense shape: {7,4,5} 53.8 M windows/s, {6,5,5} 50.8 M)
         (void)hipEventRecord(fork_ev, stream);
         (void)hipStreamWaitEvent(aux[0], fork_ev, 0);
         (void)hipStreamWaitEvent(aux[1], fork_ev, 0);

@@ -30,5 +30,8 @@ python profiles/wide_rate.py 2>&1 | grep -v amdgpu.ids > $OUT/wide_rate.txt
 (python profiles/long_rate.py 12; python profiles/long_rate.py 400; HYPO_GPU_LIB=hypo_amd/_build/libhypo_gpu_prof.so python profiles/long_rate.py 200) 2>&1 | grep -v "amdgpu.ids\|^CPU oracle" > $OUT/long_rate.txt
 (python profiles/scan_rate.py 5000000 11; python profiles/scan_rate.py 100000000 13; python profiles/scan_rate.py 250000000 15; python profiles/scan_rate.py 512000000 17) 2>&1 | grep -v amdgpu.ids > $OUT/scan_rate.txt
 python profiles/diag/host_api_timeline.py 2>&1 | grep -v amdgpu.ids > $OUT/host_api_timeline.txt
+python profiles/c4_rate.py 2>&1 | grep -v amdgpu.ids > $OUT/c4_rate.txt
+PMC_CMD="python $R/profiles/long_rate.py 200" bash profiles/run_pmc.sh ${TAG}_long > /dev/null 2>&1
+python profiles/summarize_pmc.py gpurun_out/pmc_${TAG}_long | grep "^kernel\|131072" > $OUT/pmc_long.csv
 bash profiles/kernel_registers.sh > $OUT/kernel_registers.csv 2>/dev/null
 ls -la $OUT
