@@ -126,7 +126,13 @@ struct PoaCfg {
     #ifndef HYPO_RING1
 #define HYPO_RING1 6
 #endif
-    static constexpr int RING1 = HYBRID_ ? HYPO_RING1 : 0;  // hybrid: this many most recent score rows are also kept in LDS
+// LONG windows in the hybrid class: the rank order is kept valid incrementally and the literal DFS order of the reference is
+// computed only where it can be observed (Poa::lazy_update); 0: literal sort after every alignment that changed the graph
+#ifndef HYPO_LAZY_TOPO
+#define HYPO_LAZY_TOPO 1
+#endif
+    static constexpr int RING1 = HYBRID_ ? HYPO_RING1 : 0;
+    static constexpr bool LAZY = HYBRID_ && (HYPO_LAZY_TOPO != 0) && PATHCAP_ > 0;  // hybrid: this many most recent score rows are also kept in LDS
     // direction codes: 4 bits when the pred index fits (diag p = p, vert p = 7+p, horiz = 14, fast = 15)
     static constexpr bool NIB = (KIN_ <= 7) && (CPL_ % 2 == 0);
     static constexpr int DIRBYTES = NIB ? DIRCELLS_ / 2 : DIRCELLS_;
@@ -185,7 +191,16 @@ struct PoaLayout {   // byte offsets inside a group's memory slice
     // HBM-scratch classes: matrix row of every in-edge source by rank, so that the row loop needs one load per extra
     // predecessor instead of the r2n -> inp -> n2r chain (three dependent HBM round trips per predecessor)
     static constexpr int oPredRows = oCons + align_up<16>(LONGN);
-    static constexpr int BYTES = oPredRows + align_up<16>(LONGN * Cfg::KIN * (int)sizeof(id_t));
+    // lazy rank order (Cfg::LAZY): a second rank -> node array (the update writes the new order beside the old one; the literal
+    // order of an end-row tie goes there as well), a second node -> rank array for the latter, and the new nodes of the
+    // alignment in hand with the rank they are inserted behind
+    static constexpr int LAZYN = Cfg::LAZY ? Cfg::NMAX : 0;
+    static constexpr int LAZYL = Cfg::LAZY ? Cfg::LMAX + 1 : 0;
+    static constexpr int oR2nAlt = oPredRows + align_up<16>(LONGN * Cfg::KIN * (int)sizeof(id_t));
+    static constexpr int oN2rAlt = oR2nAlt + align_up<16>(LAZYN * (int)sizeof(id_t));
+    static constexpr int oNewId = oN2rAlt + align_up<16>(LAZYN * (int)sizeof(id_t));
+    static constexpr int oNewSlot = oNewId + align_up<16>(LAZYL * 2);
+    static constexpr int BYTES = oNewSlot + align_up<16>(LAZYL * 2);
     // Hybrid classes (Cfg::HYBRID) keep everything above in HBM scratch except what the topological sort and the graph update
     // chase with dependent loads: DFS stack / posnode, in-degree, clique size, marks, current sequence.  These live in a
     // second, small slice in LDS (their slots in the big slice stay unused).
@@ -240,6 +255,8 @@ struct Poa {
     uint8_t *code, *nin, *nout, *nal, *mark, *seq, *armbuf;
     uint8_t* sidx;                                           // packed classes: SAVEd rows before each row (aliases mark: toposort and the row loop never overlap)
     id_t* pathnodes; uint32_t* pathoff; uint16_t *pathlen, *pathmult, *msa; uint32_t* dstcnt; uint8_t* consbuf; id_t* predrows; score_t* ring1;
+    id_t *r2n_alt, *n2r_alt, *newid; int16_t* newslot;       // lazy rank order (Cfg::LAZY)
+    bool lazy_on; int n_new;                                 // lazy_on: this window keeps its order lazily (LONG windows); n_new: new nodes of the alignment in hand
     int n_paths, path_used, head_first;
     // group-uniform state
     int n_nodes; int L; bool topo_dirty; bool meta_dirty; int maxdelta; int last_source;
@@ -275,6 +292,8 @@ struct Poa {
         pathlen = (uint16_t*)(mem + Lay::oPathLen); pathmult = (uint16_t*)(mem + Lay::oPathMult);
         msa = (uint16_t*)(mem + Lay::oMsa); dstcnt = (uint32_t*)(mem + Lay::oDst); consbuf = (uint8_t*)(mem + Lay::oCons);
         predrows = (id_t*)(mem + Lay::oPredRows);
+        r2n_alt = (id_t*)(mem + Lay::oR2nAlt); n2r_alt = (id_t*)(mem + Lay::oN2rAlt); newid = (id_t*)(mem + Lay::oNewId); newslot = (int16_t*)(mem + Lay::oNewSlot);
+        lazy_on = false; n_new = 0;
         ring1 = (score_t*)(HYB ? fast + Lay::fRing1 : mem + Lay::oRing);
         n_paths = 0; path_used = 0; head_first = 0;
         n_nodes = 0; L = 0; topo_dirty = false; meta_dirty = true; maxdelta = 0; last_source = 0; tb_steps = 0; tb_fv = 0;
@@ -1197,6 +1216,9 @@ struct Poa {
 
         const int le = L / CPL, ce = L % CPL;               // owner of the last column
         int best = NEG;
+        int ntie = 0;                                        // lazy rank order: rows tied for the end row (in newslot[], dead until add_alignment)
+        constexpr int TIECAP = 48;
+        static_assert(TIECAP <= 64 && TIECAP <= GW, "one lane per tied row, its index in 6 bits");
 
         int slot = 0;                                        // ring slot of row i (no integer division in the loop)
         int slotS = 0, rowS = 0;                             // slot * S and r * S, advanced by addition (group-uniform)
@@ -1355,12 +1377,43 @@ struct Poa {
                     int val = v[0];
                     HYPO_UNROLL
                     for (int c = 1; c < CPL; ++c) if (c == ce) val = v[c];
+                    if constexpr (Cfg::LAZY) {               // lazy rank order: rows that tie for the end row are remembered
+                        if (lazy_on) {
+                            if (val > best) { ntie = 1; newslot[0] = (int16_t)i; }
+                            else if (val == best) { if (ntie < TIECAP) newslot[ntie] = (int16_t)i; ++ntie; }
+                        }
+                    }
                     if (val > best) { best = val; best_i = i; }
                 }
             }
             g.sync();
         }
         best_i = g.shfl(best_i, le);
+        if constexpr (Cfg::LAZY) {
+            if (lazy_on) {
+                ntie = g.shfl(ntie, le);
+                if (ntie > 1) {
+                    // several sinks share the best score: the reference takes the first of them in ITS rank order
+                    if (ntie > TIECAP) return RES_OVERFLOW;      // (the next class sorts literally every time)
+#ifdef HYPO_EMU_TRACE
+                    if (g.lane == 0) fprintf(stderr, "tie %d n=%d\n", ntie, n_nodes);
+#endif
+                    g.sync();
+                    id_t* const sr = r2n; id_t* const sn = n2r;
+                    const bool td = topo_dirty;
+                    r2n = r2n_alt; n2r = n2r_alt;
+                    const int rc = toposort();
+                    r2n = sr; n2r = sn; topo_dirty = td;
+                    HYPO_DIAG(topo_runs += 1);
+                    if (rc != RES_OK) return rc;
+                    int key = 0x7fffffff;
+                    if (g.lane < ntie) key = ((int)n2r_alt[r2n[(int)newslot[g.lane] - 1]] << 6) | g.lane;
+                    const int kmin = -g.reduce_max(-key);
+                    best_i = (int)newslot[kmin & 63];
+                    g.sync();
+                }
+            }
+        }
         }
         HYPO_TICK(PH_DP);
 
@@ -1427,6 +1480,8 @@ struct Poa {
         const int fv = tb_steps == 0 ? L : tb_fv;          // empty alignment -> the whole sequence is a fresh chain
         if (tb_steps != 0 && fv == L) return RES_UNDEFINED; // graph.cpp:184-200: no sequence position aligned
         bool changed = false;
+        const int n_old = n_nodes;                         // (lazy rank order: nodes from here on are new)
+        n_new = 0;
         // unaligned head [0, fv): new chain (graph.cpp:194-196,273-291)
         int head = -1;
         if (fv > 0) {
@@ -1436,7 +1491,9 @@ struct Poa {
                 new_node(id, seq[t]);
                 if (t > 0) { nin[id] = 1; inp[id * KIN] = (id_t)(id - 1); inw[id * KIN] = 2; }
                 if (t < fv - 1) nout[id] = 1;
+                if constexpr (Cfg::LAZY) { if (lazy_on) { newid[t] = (id_t)id; newslot[t] = -1; } }    // the unaligned head goes in front of everything
             }
+            n_new = fv;
             head = n_nodes + fv - 1;
             head_first = n_nodes;
             n_nodes += fv;
@@ -1446,10 +1503,31 @@ struct Poa {
         // aligned part [fv, L): every position owns a distinct node / clique.  posnode[q] is rewritten
         // in place from "node the position is aligned to" to "node the position becomes".
         bool over = false;
+        int slot_carry = -1;                               // lazy rank order: rank the new nodes of the positions so far go behind
         for (int base = fv; base < L; base += GW) {
             const int q = base + g.lane;
             const bool act = q < L;
             int kind = 0, tgt = -1, nd = -1, c = 0;      // kind 0 reuse, 1 new unaligned, 2 new aligned to nd
+            int slot = -1;
+            if constexpr (Cfg::LAZY) {
+                if (lazy_on) {
+                    // A position aligned to node nd sits in nd's clique, whose members are neighbours in the order; what the
+                    // position and the unaligned positions after it add goes right behind that block (Poa::lazy_update).
+                    int v = -1;
+                    if (act) {
+                        const int nd0 = posnode[q];
+                        if (nd0 >= 0) {
+                            v = (int)n2r[nd0];
+                            const int ka0 = nal[nd0];
+                            for (int a = 0; a < ka0; ++a) { const int rx = (int)n2r[al[nd0 * AL + a]]; v = rx > v ? rx : v; }
+                        }
+                    }
+                    const int ex = g.scan_max_excl(v, (int)0x80000000);
+                    slot = ex > v ? ex : v;
+                    slot = slot > slot_carry ? slot : slot_carry;
+                    slot_carry = g.shfl(slot, GW - 1);
+                }
+            }
             if (act) {
                 nd = posnode[q]; c = seq[q];
                 if (nd < 0) kind = 1;
@@ -1467,8 +1545,10 @@ struct Poa {
             const int tot = popc64(nb);
             if (n_nodes + tot > NMAX) { over = true; break; }
             if (act && kind != 0) {
-                const int id = n_nodes + popc64(nb & ((1ull << g.lane) - 1ull));
+                const int below = popc64(nb & ((1ull << g.lane) - 1ull));
+                const int id = n_nodes + below;
                 new_node(id, c);
+                if constexpr (Cfg::LAZY) { if (lazy_on) { newid[n_new + below] = (id_t)id; newslot[n_new + below] = (int16_t)slot; } }
                 if (kind == 2) {                           // join nd's clique (graph.cpp:229-238)
                     const int ka = nal[nd];
                     if (ka + 1 > AL) over = true;
@@ -1486,6 +1566,7 @@ struct Poa {
             }
             if (act) posnode[q] = (int16_t)tgt;
             n_nodes = g.uniform(n_nodes + tot);
+            n_new += tot;
             if (tot) changed = true;
         }
         if (g.any(over)) return RES_OVERFLOW;
@@ -1505,7 +1586,61 @@ struct Poa {
         g.sync();
         if (changed) { topo_dirty = true; meta_dirty = true; }
         last_changed = changed;
+#ifdef HYPO_EMU_TRACE
+        if (g.lane == 0 && lazy_on) fprintf(stderr, "add new=%d\n", n_new);
+#endif
+        if constexpr (Cfg::LAZY) {
+            if (lazy_on) {                                 // the order stays valid: new edges follow it, new nodes are slotted in
+                if (n_new > 0) lazy_update(n_old);
+                topo_dirty = false;
+            }
+        }
         return RES_OK;
+    }
+
+    // ---- lazy rank order (LONG windows of the hybrid class) --------------------------------------------------------------------
+    // The reference sorts the graph again after every alignment (graph.cpp:293-353, a DFS whose order is 43 % of a LONG window
+    // here), but the DP values and the traceback do not depend on WHICH topological order the rows are visited in: the
+    // traceback prefers predecessors in in-edge order, not in rank order.  The reference's order can be observed in three
+    // places only: the kNW end row (first sink in rank order among equal scores, sisd..cpp:279-288), the heaviest-bundle pass
+    // and the MSA columns.  So a LONG window keeps A valid order with the cliques of aligned nodes as blocks of neighbours
+    // (what the reference's order has too, and what makes "prev precedes the clique-mate the sequence continues on" true),
+    // sorts literally before the consensus of a round, and into spare arrays when an end row is tied (Poa::align).
+    // Update after add_alignment: a new node goes behind the block of the clique its position was aligned to; new nodes of
+    // unaligned positions follow the previous position's.  New nodes come in sequence order with non-decreasing slots
+    // (newslot[i] = rank they go behind, -1 = in front), so new rank of new node i = slot + 1 + i and an old rank r moves up
+    // by the number of new nodes with slot < r: a running maximum over `cum` (kept where the recent score rows live, dead here).
+    HD void lazy_update(int n_old) {
+        static_assert(!Cfg::LAZY || (Cfg::RING1 * Lay::SMAX * (int)sizeof(score_t)) / 2 >= NMAX + 1, "the shift table fits the LDS row ring");
+        int16_t* cum = (int16_t*)ring1;
+        const int k = n_new;
+        for (int r = g.lane; r <= n_old; r += GW) cum[r] = 0;
+        g.sync();
+        for (int i = g.lane; i < k; i += GW) {
+            const int sl = newslot[i];
+            if (i == k - 1 || (int)newslot[i + 1] != sl) cum[sl + 1] = (int16_t)(i + 1);     // new nodes with slot <= sl
+        }
+        g.sync();
+        const int chunk = (n_old + 1 + GW - 1) / GW;
+        const int r0 = g.lane * chunk, r1 = r0 + chunk < n_old + 1 ? r0 + chunk : n_old + 1;
+        int run = 0;
+        for (int r = r0; r < r1; ++r) run = (int)cum[r] > run ? (int)cum[r] : run;
+        const int ex = g.scan_max_excl(run, (int)0x80000000);
+        run = ex > 0 ? ex : 0;
+        for (int r = r0; r < r1; ++r) { run = (int)cum[r] > run ? (int)cum[r] : run; cum[r] = (int16_t)run; }
+        g.sync();
+        for (int r = g.lane; r < n_old; r += GW) {
+            const int u = r2n[r];
+            const int nr = r + (int)cum[r];
+            r2n_alt[nr] = (id_t)u; n2r[u] = (id_t)nr;
+        }
+        for (int i = g.lane; i < k; i += GW) {
+            const int u = newid[i];
+            const int nr = (int)newslot[i] + 1 + i;
+            r2n_alt[nr] = (id_t)u; n2r[u] = (id_t)nr;
+        }
+        id_t* t = r2n; r2n = r2n_alt; r2n_alt = t;
+        g.sync();
     }
 
     // ---- exact reuse of the previous alignment -------------------------------------------------------
@@ -1874,6 +2009,9 @@ struct Poa {
     HD int long_step(int m, int n, int gp) {
         int rc = align(MODE_NW, m, n, gp);
         if (rc != RES_OK) return rc;
+#ifdef HYPO_EMU_TRACE
+        if (g.lane == 0) { unsigned h = 0; for (int q = tb_fv; q < L; ++q) h = h * 31u + (unsigned)(posnode[q] + 7); fprintf(stderr, "aln n=%d L=%d fv=%d steps=%d pathhash=%u\n", n_nodes, L, tb_fv, tb_steps, h); }
+#endif
         if ((rc = add_alignment()) != RES_OK) return rc;
         if ((rc = record_path(tb_steps == 0 ? L : tb_fv)) != RES_OK) return rc;   // before toposort: its stack aliases posnode
         HYPO_TICK(PH_ADD);
@@ -1891,6 +2029,7 @@ struct Poa {
         int conslen = 0;
         for (int round = 0; round < 2; ++round) {
             n_nodes = 0; topo_dirty = false; meta_dirty = true; n_paths = 0; path_used = 0; last_changed = true;
+            lazy_on = Cfg::LAZY;
             bool prev_aligned = false;
             int s = 0;
             if (round == 1) {                                // backbone = round-1 consensus (skipped when empty)
@@ -1920,6 +2059,10 @@ struct Poa {
                 prev_aligned = true;
             }
             // generate_consensus_custom (graph.cpp:533-568)
+            if constexpr (Cfg::LAZY) {                       // the heaviest bundle and the MSA columns see the reference's own order
+                if (n_nodes > 0) { if ((rc = toposort()) != RES_OK) return rc; meta_dirty = true; HYPO_DIAG(topo_runs += 1); HYPO_TICK(PH_TOPO); }   // (row metadata is by rank)
+                lazy_on = false;
+            }
             int16_t* path;
             const int len = consensus(&path);
             if (len < 1) return RES_UNDEFINED;
@@ -2050,6 +2193,7 @@ struct Poa {
         cells = 0; aligns = 0; reused = 0; exact_hits = 0; cells_scored = 0; cells_exact = 0; last_changed = true;
         HYPO_DIAG(rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; rows_exact_n = 0; rows_scored_n = 0; topo_dfs = 0; topo_fast = 0);
         n_paths = 0; path_used = 0; head_first = 0; L = 0; maxdelta = 0; tb_steps = 0; tb_fv = 0; need_nodes = 0;
+        lazy_on = false; n_new = 0;
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
         HYPO_TICK_RESET();
         const HypoWindow W = P->windows[w];

@@ -97,3 +97,28 @@ def test_random_batches_vs_oracle(exact):
                 assert cons[i] == want[i], (cfg, i)
                 n_ran += 1
     assert n_ran > 1000
+
+
+def test_class4_long_windows_lazy_rank_order_vs_oracle():
+    """LONG windows in the hybrid class keep a valid rank order incrementally and sort literally only before a round's consensus
+    and when a kNW end row is tied (Poa::lazy_update, HYPO_LAZY_TOPO): fuzzed LONG windows of every flavour (internal / prefix /
+    suffix arms, 0-15 % errors, empty arms) under two score sets and the noisy-long-read windows of the C4 mix, against the
+    oracle."""
+    import numpy as np
+    import oracle
+    from hypo_amd import sim
+    from test_gpu_fuzz import _window
+    orc = oracle.Oracle()
+    rng = np.random.default_rng(77)
+    cases = [(build_batch([_window(rng, True) for _ in range(60)]), (5, -4, -8, 3, -5, -4)),
+             (build_batch([_window(rng, True) for _ in range(30)]), (5, -4, -8, 1, -1, -1)),
+             (sim.c4_batch(0, 12, seed=5), (5, -4, -8, 3, -5, -4))]
+    n = 0
+    e = emu_util.Emu()
+    for b, scores in cases:
+        cons, st, res, _, _ = e.poa_batch(b, 4, scores)
+        want = orc.poa_batch(b, scores=scores)[0]
+        for i in range(b.n_windows):
+            assert res[i] == emu_util.RES_OK and cons[i] == want[i], i
+            n += 1
+    assert n >= 100
