@@ -1429,26 +1429,36 @@ struct Poa {
             }
             // run of FAST cells along the diagonal: lane t looks at (i-t, j-t)
             const int ii = i - g.lane, jj = j - g.lane;
-            const bool fast = (ii >= 1 && jj >= 1) && read_dir((ii - 1) * S + jj) == DIR_FAST;
+            // HBM-scratch classes: every step of this loop is a chain of dependent HBM reads (code -> node of the row -> row
+            // metadata -> pred row), so what the step may need is fetched together with the codes: one round trip for a run
+            // instead of two, two for a single move instead of three
+            constexpr bool AHEAD = Cfg::PATHCAP > 0;
+            int dv = -1, nodev = 0; uint32_t meta0 = 0;
+            if (AHEAD) {
+                if (ii >= 1 && jj >= 1) { dv = read_dir((ii - 1) * S + jj); nodev = (int)r2n[ii - 1]; }
+                else if (g.lane == 0) dv = read_dir((i - 1) * S + j);          // (i >= 1 here; j == 0: the code of column 0)
+                meta0 = rowmeta[i - 1];
+            }
+            const bool fast = AHEAD ? ((ii >= 1 && jj >= 1) && dv == DIR_FAST) : ((ii >= 1 && jj >= 1) && read_dir((ii - 1) * S + jj) == DIR_FAST);
             const uint64_t stop = g.ballot(!fast);
             const int run = stop ? ctz64(stop) : GW;
             if (run > 0) {
-                if (g.lane < run) posnode[jj - 1] = (int16_t)r2n[ii - 1];
+                if (g.lane < run) posnode[jj - 1] = (int16_t)(AHEAD ? nodev : (int)r2n[ii - 1]);
                 i -= run; j -= run; steps += run;
                 continue;
             }
-            const int d = read_dir((i - 1) * S + j);
+            const int d = AHEAD ? g.shfl(dv, 0) : read_dir((i - 1) * S + j);
             if (d == DIR_HORIZ) {
                 if (j == 0) return RES_UNDEFINED;
                 if (g.lane == 0) posnode[j - 1] = -1;
                 --j;
             } else {
                 const int p = dir_pred(d);
-                const int k = meta_k(rowmeta[i - 1]);
+                const int k = meta_k(AHEAD ? meta0 : rowmeta[i - 1]);
                 const int pi = k ? pred_row(i - 1, p) : 0;
                 if (!is_vert(d)) {
                     if (j == 0) return RES_UNDEFINED;
-                    if (g.lane == 0) posnode[j - 1] = (int16_t)r2n[i - 1];
+                    if (g.lane == 0) posnode[j - 1] = (int16_t)(AHEAD ? nodev : (int)r2n[i - 1]);
                     --j;
                 }
                 i = pi;
