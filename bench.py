@@ -26,6 +26,10 @@ import os
 import sys
 import time
 
+# The library runs up to seven HIP streams (two batches in flight + three side streams of a POA call + the caller's); a
+# ROCm process gets four hardware queues unless this is set before the runtime initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -5,6 +5,10 @@ missing or no gfx950 device is present, loading / init raises.
 """
 import ctypes as C
 import os
+
+# more hardware queues than ROCm's default of four per process (the library runs up to seven streams); only effective when the
+# HIP runtime has not been initialised yet — see INTEGRATION.md
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import subprocess
 
 import numpy as np

@@ -99,6 +99,9 @@ int main(int argc, char** argv) {
     // The host stages allocate millions of small objects (alignments, arms) from all threads.  glibc grows a thread arena in
     // small mprotect steps and trims it eagerly; with > 32 threads those system calls serialise on the address-space lock
     // (measured: -t 64 took 2.1 s instead of 1.05 s on the 5 Mbp set).  Grow in 64 MB steps, give memory back late.
+    // the device library runs up to seven HIP streams; a ROCm process gets four hardware queues unless told otherwise before the
+    // runtime initialises (two streams sharing a queue serialise: DESIGN.md 3.1)
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     mallopt(M_TOP_PAD, 64 << 20);
     mallopt(M_TRIM_THRESHOLD, 1 << 30);
     hypo::InputFlags flags;
