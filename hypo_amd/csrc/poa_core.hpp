@@ -1245,13 +1245,25 @@ struct Poa {
         // row's own stores included) once per row, which was most of the row time of the HBM-scratch classes.
         constexpr bool META_CHUNKED = (GW == 64) && !META_IN_REGS;
         uint32_t mchunk = 0u;
+        // ... and, in the classes that tabulate pred rows in HBM scratch, the matrix row of pred 1 of the same 64 rows: nearly every
+        // row with several predecessors has two, and looking the second one up inside the loop was an HBM load whose wait also
+        // drained the rows' outstanding stores
+#ifndef HYPO_P1_CHUNK
+#define HYPO_P1_CHUNK 1
+#endif
+        constexpr bool P1_CHUNKED = (HYPO_P1_CHUNK != 0) && META_CHUNKED && PRED_TABLE && KIN >= 2;
+        int p1chunk = 0;
         uint32_t meta_a = (META_IN_REGS || META_CHUNKED) ? 0u : rowmeta[0];
         uint32_t meta_b = (!META_IN_REGS && !META_CHUNKED && n_nodes > 1) ? rowmeta[1] : 0u;
         for (int r = 0; r < n_nodes; ++r) {
             const int i = r + 1;
             uint32_t meta;
             if (META_CHUNKED) {
-                if ((r & 63) == 0) { mchunk = r + g.lane < n_nodes ? rowmeta[r + g.lane] : 0u; HYPO_ARRIVED(mchunk); }
+                if ((r & 63) == 0) {
+                    mchunk = r + g.lane < n_nodes ? rowmeta[r + g.lane] : 0u;
+                    if (P1_CHUNKED) { p1chunk = r + g.lane < n_nodes ? (int)predrows[(r + g.lane) * KIN + 1] : 0; HYPO_ARRIVED(p1chunk); }
+                    HYPO_ARRIVED(mchunk);
+                }
                 meta = (uint32_t)g.shfl((int)mchunk, r & 63);
             } else if (META_IN_REGS) {
                 uint32_t mv = mreg[0];
@@ -1290,7 +1302,7 @@ struct Poa {
                 for (int c = 0; c < CPL; ++c) { pD[c] = 0; pU[c] = 0; }
                 for (int p = 1; p < k; ++p) {
                     int hp[CPL];
-                    const int pr = g.uniform(pred_row(r, p));
+                    const int pr = (P1_CHUNKED && p == 1) ? g.shfl(p1chunk, r & 63) : g.uniform(pred_row(r, p));
                     if (R1 > 0 && i - pr <= R1) { int ps = slot1S - (i - pr) * S; ps = ps < 0 ? ps + R1S : ps; load_ring_at(ring1, ps, S, hp); }
                     else { int ps = slotS - (i - pr) * S; ps = ps < 0 ? ps + RS : ps; load_ring_at(ring, ps, S, hp); }
                     const int left = g.shfl_up1(hp[CPL - 1], NEG);
@@ -1395,9 +1407,6 @@ struct Poa {
                 if (ntie > 1) {
                     // several sinks share the best score: the reference takes the first of them in ITS rank order
                     if (ntie > TIECAP) return RES_OVERFLOW;      // (the next class sorts literally every time)
-#ifdef HYPO_EMU_TRACE
-                    if (g.lane == 0) fprintf(stderr, "tie %d n=%d\n", ntie, n_nodes);
-#endif
                     g.sync();
                     id_t* const sr = r2n; id_t* const sn = n2r;
                     const bool td = topo_dirty;
@@ -1596,9 +1605,6 @@ struct Poa {
         g.sync();
         if (changed) { topo_dirty = true; meta_dirty = true; }
         last_changed = changed;
-#ifdef HYPO_EMU_TRACE
-        if (g.lane == 0 && lazy_on) fprintf(stderr, "add new=%d\n", n_new);
-#endif
         if constexpr (Cfg::LAZY) {
             if (lazy_on) {                                 // the order stays valid: new edges follow it, new nodes are slotted in
                 if (n_new > 0) lazy_update(n_old);
@@ -2019,9 +2025,6 @@ struct Poa {
     HD int long_step(int m, int n, int gp) {
         int rc = align(MODE_NW, m, n, gp);
         if (rc != RES_OK) return rc;
-#ifdef HYPO_EMU_TRACE
-        if (g.lane == 0) { unsigned h = 0; for (int q = tb_fv; q < L; ++q) h = h * 31u + (unsigned)(posnode[q] + 7); fprintf(stderr, "aln n=%d L=%d fv=%d steps=%d pathhash=%u\n", n_nodes, L, tb_fv, tb_steps, h); }
-#endif
         if ((rc = add_alignment()) != RES_OK) return rc;
         if ((rc = record_path(tb_steps == 0 ? L : tb_fv)) != RES_OK) return rc;   // before toposort: its stack aliases posnode
         HYPO_TICK(PH_ADD);
