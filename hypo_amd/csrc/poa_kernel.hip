@@ -590,7 +590,11 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
         // anybody: it runs on a third stream next to the short-window kernels (a LONG window occupies one wave for ~0.1 s; its
         // latency is the floor of the whole call), and only the few windows escalated into class 4 later wait for the mop-up
         // pass at the end.
-        const bool long_first_pass = planned_host[4] > 0;
+        // (only while every LONG window of the batch gets a wave of its own: the kernel is then bound by the latency of its
+        // windows and leaves room.  A batch with more LONG windows keeps the whole chip busy for many window lifetimes, and
+        // running it next to the short-window kernels was measured slower than after them — C4 mix, 400 000 SHORT + 8 000 LONG
+        // windows: 313 ms against 285 ms — once the two really overlapped, which depends on the process's hardware queues)
+        const bool long_first_pass = planned_host[4] > 0 && planned_host[4] <= (uint32_t)groups4;
         if (long_first_pass) {
             rec(2 + 2 * 4, aux[2]);
             if ((e = launch_class<PoaClass4, false>(P, Q, 4, planned_host[4], scratch, num_cus, groups4, aux[2], 8)) != hipSuccess) return e;
