@@ -101,6 +101,13 @@ struct PoaParamRef {
 #ifndef HYPO_EXACT_RUNS
 #define HYPO_EXACT_RUNS 1
 #endif
+// ... also in the class of wide windows (class 3): off, see Poa::align
+#ifndef HYPO_EXACT_WIDE
+#define HYPO_EXACT_WIDE 0
+#endif
+#ifndef HYPO_EXACT_ADAPT
+#define HYPO_EXACT_ADAPT 6
+#endif
 // int16 score rows as packed pairs of columns (Poa::rows_pk); HYPO_PACKED=0 builds the one-column-per-register loop everywhere
 #ifndef HYPO_PACKED
 #define HYPO_PACKED 1
@@ -256,6 +263,7 @@ struct Poa {
     uint8_t* sidx;                                           // packed classes: SAVEd rows before each row (aliases mark: toposort and the row loop never overlap)
     id_t* pathnodes; uint32_t* pathoff; uint16_t *pathlen, *pathmult, *msa; uint32_t* dstcnt; uint8_t* consbuf; id_t* predrows; score_t* ring1;
     id_t *r2n_alt, *n2r_alt, *newid; int16_t* newslot;       // lazy rank order (Cfg::LAZY)
+    int x_tries, x_hits;                                     // threading attempts / hits of the window in hand (HYPO_EXACT_ADAPT)
     bool lazy_on; int n_new;                                 // lazy_on: this window keeps its order lazily (LONG windows); n_new: new nodes of the alignment in hand
     int n_paths, path_used, head_first;
     // group-uniform state
@@ -293,7 +301,7 @@ struct Poa {
         msa = (uint16_t*)(mem + Lay::oMsa); dstcnt = (uint32_t*)(mem + Lay::oDst); consbuf = (uint8_t*)(mem + Lay::oCons);
         predrows = (id_t*)(mem + Lay::oPredRows);
         r2n_alt = (id_t*)(mem + Lay::oR2nAlt); n2r_alt = (id_t*)(mem + Lay::oN2rAlt); newid = (id_t*)(mem + Lay::oNewId); newslot = (int16_t*)(mem + Lay::oNewSlot);
-        lazy_on = false; n_new = 0;
+        lazy_on = false; n_new = 0; x_tries = 0; x_hits = 0;
         ring1 = (score_t*)(HYB ? fast + Lay::fRing1 : mem + Lay::oRing);
         n_paths = 0; path_used = 0; head_first = 0;
         n_nodes = 0; L = 0; topo_dirty = false; meta_dirty = true; maxdelta = 0; last_source = 0; tb_steps = 0; tb_fv = 0;
@@ -1195,8 +1203,17 @@ struct Poa {
         if constexpr (PK) {
             // a sequence that spells a path of the graph (most reads do) is threaded without scores; what spells none goes
             // through the score rows
-            if (HYPO_EXACT && m > 0 && n < m && gp < 0) {
+            // (not in the class of wide windows, Cfg::LMAX > 127: with four columns per lane a threaded row costs 734 cycles
+            // against 818 for a scored one, so a failed attempt is pure loss and a read of 130+ bases rarely spells a path —
+            // 160-bp windows with 1 % read error: 20 % of the attempts hit)
+            constexpr bool EXACT_HERE = HYPO_EXACT && (Cfg::LMAX <= 127 || HYPO_EXACT_WIDE);
+            // ... and not in a window whose reads keep failing to thread: an attempt costs about half a scored alignment, so below
+            // one hit in two it is a loss (HYPO_EXACT_ADAPT: tries before the rate counts)
+            const bool worth = HYPO_EXACT_ADAPT == 0 || x_tries < HYPO_EXACT_ADAPT || 2 * x_hits >= x_tries;
+            if (EXACT_HERE && worth && m > 0 && n < m && gp < 0) {
+                x_tries += 1;
                 best_i = HYPO_EXACT_RUNS ? rows_exact_runs(mode, S, R) : rows_exact(mode, S, R);
+                if (best_i > 0) x_hits += 1;
                 HYPO_TICK(PH_EXACT);
                 cells_exact += (uint32_t)((n_nodes + 1) * W); HYPO_DIAG(exact_tries += 1; rows_exact_n += (uint32_t)n_nodes);
                 if (best_i > 0) exact_hits += 1;
@@ -2206,7 +2223,7 @@ struct Poa {
         cells = 0; aligns = 0; reused = 0; exact_hits = 0; cells_scored = 0; cells_exact = 0; last_changed = true;
         HYPO_DIAG(rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; rows_exact_n = 0; rows_scored_n = 0; topo_dfs = 0; topo_fast = 0);
         n_paths = 0; path_used = 0; head_first = 0; L = 0; maxdelta = 0; tb_steps = 0; tb_fv = 0; need_nodes = 0;
-        lazy_on = false; n_new = 0;
+        lazy_on = false; n_new = 0; x_tries = 0; x_hits = 0;
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
         HYPO_TICK_RESET();
         const HypoWindow W = P->windows[w];
