@@ -1425,6 +1425,35 @@ struct Poa {
                     // several sinks share the best score: the reference takes the first of them in ITS rank order
                     if (ntie > TIECAP) return RES_OVERFLOW;      // (the next class sorts literally every time)
                     g.sync();
+                    // The usual tie: the tied sinks are members of ONE aligned clique all of whose members are sinks (the last
+                    // column of the window).  Nothing depends on a sink, so the reference's DFS reaches that clique from its
+                    // member with the smallest id, as a root, and emits that member followed by its aligned list in list order
+                    // (graph.cpp:311-349): the winner follows from ids and that list, without sorting.
+                    {
+                        const int u0 = (int)r2n[(int)newslot[0] - 1];
+                        const int ka0 = (int)nal[u0];
+                        int cmin = u0; bool all_sinks = nout[u0] == 0;
+                        for (int a = 0; a < ka0; ++a) { const int x = (int)al[u0 * AL + a]; cmin = x < cmin ? x : cmin; all_sinks = all_sinks && nout[x] == 0; }
+                        int pos = 0x7fff; bool member = true;
+                        if (g.lane < ntie) {
+                            const int u = (int)r2n[(int)newslot[g.lane] - 1];
+                            if (u == cmin) pos = 0;
+                            else {
+                                member = false;
+                                const int kc = (int)nal[cmin];
+                                for (int a = 0; a < kc; ++a) if ((int)al[cmin * AL + a] == u) { pos = 1 + a; member = true; }
+                            }
+                        }
+                        if (all_sinks && !g.any(!member)) {
+                            const int key = g.lane < ntie ? ((pos << 6) | g.lane) : 0x7fffffff;
+                            const int kmin = -g.reduce_max(-key);
+                            best_i = (int)newslot[kmin & 63];
+                            ntie = 0;
+                            g.sync();
+                        }
+                    }
+                }
+                if (ntie > 1) {
                     id_t* const sr = r2n; id_t* const sn = n2r;
                     const bool td = topo_dirty;
                     r2n = r2n_alt; n2r = n2r_alt;
