@@ -2195,6 +2195,10 @@ struct Poa {
         const int m = P->sr_m, n = P->sr_n, gp = P->sr_g;
         const uint8_t* d4 = P->draft4 + W.draft_off;
         n_nodes = 0; topo_dirty = false; meta_dirty = true;
+        // SHORT windows that ended up in the hybrid class (wide windows of --ccs-windows, large graphs) keep their rank order
+        // lazily as well: kLOV's end row (first row in rank order among equal maxima of the last column) goes through the same
+        // list of tied rows as the sinks of kNW / kROV.  Not with the native kLOV flavour, whose end row is ranked differently.
+        lazy_on = Cfg::LAZY && !(P->flags & POA_NATIVE_KLOV);
         int n_seq = 0; bool added = false;
         int rc = build_seqtab(W, false, &n_seq, &added);
         if (rc != RES_OK) return rc;
@@ -2233,6 +2237,10 @@ struct Poa {
             prev_aligned = true;
         }
         if (!added) return emit_draft(w, d4, (int)W.draft_len);
+        if constexpr (Cfg::LAZY) {                           // the heaviest bundle sees the reference's own order
+            if (lazy_on && n_nodes > 0) { if ((rc = toposort()) != RES_OK) return rc; meta_dirty = true; HYPO_TICK(PH_TOPO); }
+            lazy_on = false;
+        }
         int16_t* path;
         const int len = consensus(&path);
         HYPO_TICK(PH_CONS);
