@@ -133,6 +133,12 @@ void Alignment::update_minimisers_support(Contig& contig) {
     const int64_t first_w = ((even && first % 2 == 0) || (!even && first % 2 == 1)) ? (int64_t)first : (int64_t)first + 1;
     const int64_t last_w = ((even && last % 2 == 0) || (!even && last % 2 == 1)) ? (int64_t)last : (int64_t)last - 1;
     if (last_w < first_w) return;
+    {   // nothing to vote on when none of the mega-windows the read touches kept a minimizer (most are shorter than the window
+        // size and have none): the read's own minimizers are then never looked at
+        bool any = false;
+        for (int64_t i = first_w; i <= last_w && !any; i += 2) any = !contig._minimserinfo[even ? (size_t)(i / 2) : (size_t)((i - 1) / 2)].rel_pos.empty();
+        if (!any) return;
+    }
     // forward-strand window minimizers of the read (position = start of the k-mer), duplicates by position removed
     const uint32_t mask = (uint32_t)((1ULL << (2 * K)) - 1);
     struct Item { uint32_t kmer, pos; };
