@@ -83,31 +83,37 @@ void Alignment::update_solidkmers_support(unsigned k, Contig& contig) {
         if (contig._solid_pos.select(i) + k <= _re) { last = i; break; }
     if (last <= first) return;
     const uint32_t n = (uint32_t)(last - first);
-    // the reference keeps (kid -> index) in an unordered_multimap and walks equal_range(): with libstdc++ that is
-    // reverse insertion order, and the order matters below (pvs_supp_* state).  Made explicit: sort by (kid, index
-    // descending).
-    std::vector<std::pair<uint64_t, uint32_t>> kmap(n);
-    std::vector<uint64_t> spos(n);
+    // The reference keeps (kid -> index) in an unordered_multimap and walks equal_range(kmer) for every k-mer of the read: with
+    // libstdc++ that is reverse insertion order (index descending), and the order matters below (pvs_supp_* state).  Entries
+    // outside [left, right] are skipped without effect, and those inside have their contig k-mer within k bases of the read
+    // k-mer's offset — so the same visits, in the same order, come from a window over the (position-sorted) solid k-mers of the
+    // span that slides along with the read position: no map, no sort, no allocation for reads of ordinary length.
+    constexpr uint32_t kStack = 512;
+    uint64_t spos_stack[kStack];
+    std::vector<uint64_t> spos_heap;
+    uint64_t* spos = spos_stack;
+    if (n > kStack) { spos_heap.resize(n); spos = spos_heap.data(); }
     for (uint32_t t = 0; t < n; ++t) {
         contig.increment_coverage((uint32_t)(first + t));
-        kmap[t] = {contig._kids[first + t], t};
         spos[t] = contig._solid_pos.select(first + t + 1);
     }
-    std::sort(kmap.begin(), kmap.end(), [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& b) {
-        return a.first != b.first ? a.first < b.first : a.second > b.second; });
+    const uint64_t* kids = contig._kids.data() + first;
     uint64_t kmer = 0; unsigned kmer_len = 0;
     const uint64_t kmask = (1ULL << (2 * k)) - 1;
     const size_t nq = _apseq.get_seq_size();
     const uint32_t num_cbases = _re - _rb;
     int64_t pvs_supp_kpos = -1; uint32_t pvs_supp_r_bind = 0;
+    uint32_t lo = 0, hi = 0;                                  // solid k-mers [lo, hi): offset within k of the read k-mer's
     for (size_t r_ind = 0; r_ind < nq; ++r_ind) {
         kmer = ((kmer << 2) | _apseq.enc_base_at(r_ind)) & kmask;
         if (kmer_len < k) ++kmer_len;
         if (kmer_len != k) continue;
         const uint32_t r_bind = (uint32_t)(r_ind + 1 - k);
-        auto it = std::lower_bound(kmap.begin(), kmap.end(), kmer, [](const std::pair<uint64_t, uint32_t>& a, uint64_t key) { return a.first < key; });
-        for (; it != kmap.end() && it->first == kmer; ++it) {
-            const uint32_t c_ind = it->second;
+        while (hi < n && (int64_t)spos[hi] - (int64_t)_rb <= (int64_t)r_bind + (int64_t)k) ++hi;
+        while (lo < hi && (int64_t)spos[lo] - (int64_t)_rb + (int64_t)k < (int64_t)r_bind) ++lo;
+        for (uint32_t c = hi; c-- > lo;) {
+            if (kids[c] != kmer) continue;
+            const uint32_t c_ind = c;
             const int64_t c_dist = (int64_t)spos[c_ind] - (int64_t)_rb;
             const uint32_t left = c_dist > (int64_t)k ? (uint32_t)(c_dist - k) : 0u;
             const uint32_t right = (uint32_t)std::min<int64_t>((int64_t)num_cbases, c_dist + (int64_t)k);
