@@ -5,7 +5,7 @@ Reference types mirrored: ScoreParams (include/globalDefs.hpp:58-66), hypo::Wind
 """
 import ctypes as C
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 HYPO_OK = 0
 HYPO_E_INVALID = -1
@@ -61,7 +61,7 @@ class PoaStats(C.Structure):
                 ("n_escalated", C.c_uint64), ("n_failed", C.c_uint64), ("dp_cells", C.c_uint64),
                 ("n_alignments", C.c_uint64), ("alg_bytes", C.c_uint64 * 8),
                 ("n_reused", C.c_uint64), ("n_threaded", C.c_uint64), ("cells_scored", C.c_uint64),
-                ("cells_threaded", C.c_uint64)]
+                ("cells_threaded", C.c_uint64), ("n_carried", C.c_uint64)]
 
 
 # numpy dtype equivalent of HypoWindow (40 bytes, same offsets)

@@ -192,7 +192,7 @@ def _stats_dict(s: abi.PoaStats) -> dict:
             "n_class": [int(x) for x in s.n_class], "n_escalated": int(s.n_escalated),
             "n_failed": int(s.n_failed), "dp_cells": int(s.dp_cells), "n_alignments": int(s.n_alignments),
             "alg_bytes": [int(x) for x in s.alg_bytes], "n_reused": int(s.n_reused), "n_threaded": int(s.n_threaded),
-            "cells_scored": int(s.cells_scored), "cells_threaded": int(s.cells_threaded)}
+            "cells_scored": int(s.cells_scored), "cells_threaded": int(s.cells_threaded), "n_carried": int(s.n_carried)}
 
 
 def _t(arr, dev):

@@ -570,7 +570,13 @@ int hypo_gpu_poa_batch_sharded(const HypoScoreParams* scores, const HypoWindowBa
         if (b0 == ~0ull) { b0 = 0; b1 = 0; }
         S.a0 = a0; S.a1 = a1; S.d0 = d0; S.d1 = d1; S.b0 = b0; S.b1 = b1;
         c.sh_win.assign(in->windows + S.w0, in->windows + S.w1);
-        for (auto& W : c.sh_win) { W.first_arm -= (uint32_t)(W.first_arm >= a0 ? a0 : 0); W.draft_off -= (W.draft_off >= d0 ? d0 : 0); }
+        for (auto& W : c.sh_win) {
+            // a window without arms does not take part in [a0, a1): its first_arm is rebased to 0 when it was valid in the whole
+            // batch (the single-device call answers it with an empty consensus or its draft) and stays out of range otherwise
+            if ((uint64_t)W.n_internal + W.n_prefix + W.n_suffix == 0) W.first_arm = (uint64_t)W.first_arm <= in->n_arms ? 0u : 0xffffffffu;
+            else W.first_arm -= (uint32_t)(W.first_arm >= a0 ? a0 : 0);
+            W.draft_off -= (W.draft_off >= d0 ? d0 : 0);
+        }
         c.sh_aoff.resize((size_t)(a1 - a0));
         for (uint64_t a = a0; a < a1; ++a) c.sh_aoff[(size_t)(a - a0)] = in->arm_off[a] >= b0 ? in->arm_off[a] - b0 : in->arm_off[a];
         c.sh_off.resize((size_t)nw + 1);
@@ -646,7 +652,7 @@ int hypo_gpu_poa_batch_sharded(const HypoScoreParams* scores, const HypoWindowBa
         const HypoPoaStats& s = sh[d].st;
         tl_stats.n_trivial += s.n_trivial; tl_stats.n_escalated += s.n_escalated; tl_stats.n_failed += s.n_failed;
         tl_stats.dp_cells += s.dp_cells; tl_stats.n_alignments += s.n_alignments;
-        tl_stats.n_reused += s.n_reused; tl_stats.n_threaded += s.n_threaded; tl_stats.cells_scored += s.cells_scored; tl_stats.cells_threaded += s.cells_threaded;
+        tl_stats.n_reused += s.n_reused; tl_stats.n_threaded += s.n_threaded; tl_stats.cells_scored += s.cells_scored; tl_stats.cells_threaded += s.cells_threaded; tl_stats.n_carried += s.n_carried;
         for (int k = 0; k < 8; ++k) { tl_stats.n_class[k] += s.n_class[k]; tl_stats.alg_bytes[k] += s.alg_bytes[k]; }
     }
     tl_stats.n_windows = n;
@@ -739,6 +745,7 @@ int hypo_gpu_arms_build(const HypoArmsRegions* R, const HypoArmsReads* A, uint8_
     const uint32_t nr = R->n_regions, na = A->n_alignments;
     const uint64_t total_len = R->start[nr];
     uint32_t max_span = 0;
+    uint64_t sum_span = 0;
     for (uint32_t i = 0; i < nr; ++i) if (R->start[i] >= R->start[i + 1]) return fail(HYPO_E_INVALID, "region %u is empty or the starts are not increasing", i);
     for (uint32_t a = 0; a < na; ++a) {
         if (A->re[a] <= A->rb[a] || A->re[a] > total_len) return fail(HYPO_E_INVALID, "alignment %u: span [%u, %u) outside the %llu bases", a, A->rb[a], A->re[a], (unsigned long long)total_len);
@@ -747,7 +754,14 @@ int hypo_gpu_arms_build(const HypoArmsRegions* R, const HypoArmsReads* A, uint8_
         if (A->cigar_off[a] > A->cigar_off[a + 1]) return fail(HYPO_E_INVALID, "alignment %u: cigar_off decreases", a);
         const uint32_t span = A->re[a] - A->rb[a];
         max_span = span > max_span ? span : max_span;
+        sum_span += span;
     }
+    // arms_window_kernel looks, per window, at every alignment that starts within max_span bases before it: one record with a
+    // huge reference span (a 100 kb D / N operation) would make every window walk a 100 kb neighbourhood.  Such input takes the
+    // host loops (the caller falls back on any error of this call).
+    if (na && max_span > 16384u && (uint64_t)max_span * na > 64ull * sum_span)
+        return fail(HYPO_E_CAPACITY, "an alignment spans %u reference bases, more than 64 x the mean span (%llu): arm selection stays on the host",
+                    max_span, (unsigned long long)(sum_span / na));
     const uint64_t n_cig = na ? A->cigar_off[na] : 0;
     hipStream_t st = g_ctx.stream;
     DevBuf &dIn = g_ctx.arms_arena[0], &dWork = g_ctx.arms_arena[1], &dBatch = g_ctx.arms_arena[2];

@@ -17,6 +17,7 @@
 #define HD inline
 #define HD_NOINLINE inline
 #define HYPO_UNROLL
+#define HYPO_NOUNROLL
 #define HYPO_IN_VGPR(x) do { } while (0)
 #define HYPO_NO_IFCVT() do { } while (0)
 #define HYPO_ARRIVED(x) do { } while (0)
@@ -26,6 +27,8 @@
 // a real call: the callee's registers do not add to what the (huge) caller keeps alive
 #define HD_NOINLINE __device__ __attribute__((noinline))
 #define HYPO_UNROLL _Pragma("unroll")
+// cold loops (spill / restore of a re-queued window's graph): unrolled copies of them would set the kernel's register count
+#define HYPO_NOUNROLL _Pragma("clang loop unroll(disable)")
 // keeps a group-uniform value in a vector register (the row loop runs out of scalar registers and the compiler would
 // otherwise park it in a VGPR lane and v_readlane it back on every use)
 #define HYPO_IN_VGPR(x) asm volatile("" : "+v"(x))

@@ -215,7 +215,9 @@ public:
             while (b.n() < max_records && at < max_bytes && at < avail) {
                 const char* nl = (const char*)std::memchr(p0 + at, '\n', avail - at);
                 const size_t stop = nl ? (size_t)(nl - p0) : avail;         // (a last line without a line feed ends at the end of the file)
-                if (stop == at) { if (b.off.size() == 1) { b.off[0] = ++at; continue; } break; }   // empty line: leading ones are skipped, one inside ends the block
+                // empty line (also one that holds a carriage return only, as the gz / append_line path treats it): leading ones are
+                // skipped, one inside ends the block
+                if (stop == at || (stop == at + 1 && p0[at] == '\r')) { if (b.off.size() == 1) { at = stop + 1; b.off[0] = at; continue; } break; }
                 b.off.push_back(stop + 1);
                 at = stop + 1;
             }
@@ -247,7 +249,7 @@ public:
         if (n && line[n - 1] == '\r') --n;                               // (a record cut out of a mapped file keeps its CR)
         size_t f[12]; int nf = 0; f[0] = 0;
         for (size_t i = 0; i < n && nf < 11; ++i) if (line[i] == '\t') f[++nf] = i + 1;
-        if (nf < 10) { std::fprintf(stderr, "[Hypo::SamReader] Error: malformed SAM record: %.60s\n", line); std::exit(1); }
+        if (nf < 10) { std::fprintf(stderr, "[Hypo::SamReader] Error: malformed SAM record: %.*s\n", (int)(n < 60 ? n : 60), line); std::exit(1); }
         auto fbeg = [&](int k) { return line + f[k]; };
         auto flen = [&](int k) { return (k < nf ? f[k + 1] - 1 : n) - f[k]; };
         r.qname.assign(fbeg(0), flen(0));

@@ -112,9 +112,18 @@ int Window::generate_consensus_batch(const std::vector<Window*>& windows) {
         // Degraded path (documented in DESIGN.md): a window beyond the largest device size class (more than 1 023
         // sequences, a graph of more than 4 000 nodes or 16 in-edges, an arm longer than 1 021 bases), or one whose
         // alignment is undefined in the reference itself, keeps its draft; the run goes on.
+        // Anything else is a defect of the flattening / sharding above, not a property of the window (HYPO_ST_INVALID: a descriptor
+        // that points outside the batch; a slot overflow that survived the retry): fatal, as every non-OK status was before the
+        // degraded path existed.
         for (size_t i = 0; i < part.size(); ++i) {
             if (st[i] == HYPO_ST_OK) continue;
-            if (st[i] == HYPO_ST_UNDEFINED) ++n_undefined; else ++n_capacity;
+            if (st[i] == HYPO_ST_UNDEFINED) ++n_undefined;
+            else if (st[i] == HYPO_ST_CAPACITY) ++n_capacity;
+            else {
+                std::fprintf(stderr, "[Hypo::Window] Error: window %llu of the batch came back with status %d (%s)\n", (unsigned long long)(beg + i),
+                             (int)st[i], st[i] == HYPO_ST_INVALID ? "descriptor outside the batch" : "unexpected");
+                return HYPO_E_INVALID;
+            }
             part[i]->_consensus = part[i]->_draft.unpack();
         }
         beg = end;

@@ -26,13 +26,14 @@ typedef PoaCfg<16, 4, 47, 48, 4, 2208, 384, 384, 64, int16_t, uint8_t> PoaClass0
 // two per call: four groups when the batch is tiny windows almost only (dense short reads: 56 vs 46 M windows/s), two groups
 // otherwise (C2: 3.89 vs 4.08 ms).
 typedef PoaCfg<32, 2, 47, 48, 4, 2208, 384, 384, 64, int16_t, uint8_t> PoaClass0W;
-typedef PoaCfg<32, 4, 79, 84, 4, 6720, 640, 768, 64, int16_t, uint8_t> PoaClass1;
+typedef PoaCfg<32, 4, 79, 84, 4, 6720, 640, 704, 64, int16_t, uint8_t> PoaClass1;     // (704 staged arm bytes: two groups + their stat blocks stay within 32 LDS granules of 512 B)
 #ifndef HYPO_C2_GW
 #define HYPO_C2_GW 64
 #define HYPO_C2_CPL 2
 #endif
 typedef PoaCfg<HYPO_C2_GW, HYPO_C2_CPL, 127, 126, 6, 13440, 1024, 1024, 127, int16_t, uint8_t> PoaClass2;
-typedef PoaCfg<64, 4, 255, 254, 7, 49152, 2048, 1024, 192, int16_t, uint8_t> PoaClass3;
+// class 3 keeps its direction codes (up to 254 x 256 cells) in HBM scratch (Cfg::DIRG): 16 KB of LDS per window instead of 40
+typedef PoaCfg<64, 4, 255, 254, 7, 65536, 2048, 1024, 192, int16_t, uint8_t, 0, false, true> PoaClass3;
 typedef PoaCfg<64, 10, 639, 2400, 12, 1536000, 491520, 16384, 256, int16_t, uint16_t, 1 << 18, true> PoaClass4;          // + 256 K path ids: runs LONG windows
 typedef PoaCfg<64, 16, 1023, 4000, 16, 1 << 22, 1 << 21, 16384, 1024, int32_t, uint16_t, 1 << 18> PoaClass5;    // last resort, also runs LONG windows
 constexpr int kNumPoaClasses = 6;

@@ -112,9 +112,20 @@ struct PoaParamRef {
 #ifndef HYPO_PACKED
 #define HYPO_PACKED 1
 #endif
+// experiments (register pressure): parts of the carry-over that can be compiled out
+#ifndef HYPO_CARRY_RESTORE
+#define HYPO_CARRY_RESTORE 1
+#endif
+#ifndef HYPO_CARRY_SPILL
+#define HYPO_CARRY_SPILL 1
+#endif
 template <int GW_, int CPL_, int LCAP_, int NMAX_, int KIN_, int DIRCELLS_, int RINGCELLS_, int ARMBYTES_,
-          int SEQMAX_, class ScoreT, class IdT, int PATHCAP_ = 0, bool HYBRID_ = false>
+          int SEQMAX_, class ScoreT, class IdT, int PATHCAP_ = 0, bool HYBRID_ = false, bool DIRG_ = false>
 struct PoaCfg {
+    // DIRG: an LDS class whose direction codes (the one array that grows with nodes x length) live in a per-group slice of HBM
+    // scratch instead: they are written once per row (fire and forget) and read by the traceback only, so the window's LDS
+    // footprint is the graph + the ring and the class can run next to the others (PoaLayout::DIRG_BYTES per resident group)
+    static constexpr bool DIRG = DIRG_;
     // the packed row loop: int16 rows, 4-bit direction codes, an even number of columns per lane, state in LDS
     static constexpr bool PACKED = HYPO_PACKED && sizeof(ScoreT) == 2 && CPL_ % 2 == 0 && CPL_ <= 8 && !HYBRID_ && (KIN_ <= 7);
     static constexpr bool HYBRID = HYBRID_;     // state in HBM scratch except the arrays the graph walks hammer (PoaLayout::FAST_BYTES of LDS)
@@ -152,7 +163,8 @@ struct PoaCfg {
     static_assert(LCAP_ <= 1023 && ARMBYTES_ <= 32767 && SEQMAX_ <= 32767, "sequence table entry is 32 bits");
     static_assert(KIN_ + 6 <= GW_, "dependency lanes");
     static_assert(KIN_ <= 62, "direction byte holds the pred index in 6 bits");
-    static_assert((int)sizeof(ScoreT) * RINGCELLS_ + DIRBYTES >= 14 * NMAX_, "consensus scratch aliases ring+dir");
+    static constexpr int DIRBYTES_LDS = DIRG_ ? 0 : DIRBYTES;      // what the direction codes take of the group's own slice
+    static_assert((int)sizeof(ScoreT) * RINGCELLS_ + DIRBYTES_LDS >= 14 * NMAX_, "consensus scratch aliases ring+dir");
     static_assert(NMAX_ < ID_NONE, "id range");
     static_assert(SEQMAX_ <= STK && SEQMAX_ <= ID_NONE, "arm indices are parked in the DFS stack while staging");
 };
@@ -170,7 +182,9 @@ struct PoaLayout {   // byte offsets inside a group's memory slice
     // land in the following rows' cells or, behind the last row, at most GW * CPL / 2 bytes into this region
     static constexpr int POS_BYTES = (Cfg::LMAX + 1) * 2 > Cfg::STK * (int)sizeof(id_t) ? (Cfg::LMAX + 1) * 2 : Cfg::STK * (int)sizeof(id_t);
     static_assert(!Cfg::PACKED || POS_BYTES >= Cfg::GW * Cfg::CPL / 2, "slack behind the direction codes");
-    static constexpr int oPosnode = oDir + align_up<16>(Cfg::DIRBYTES);
+    static constexpr int oPosnode = oDir + align_up<16>(Cfg::DIRBYTES_LDS);
+    // Cfg::DIRG: bytes of HBM scratch per resident group (the codes + the slack the packed loop's unguarded stores need)
+    static constexpr int DIRG_BYTES = Cfg::DIRG ? align_up<256>(Cfg::DIRBYTES + Cfg::GW * Cfg::CPL + 16) : 0;
     static constexpr int oRowmeta = oPosnode + align_up<16>(POS_BYTES);
     static constexpr int oSeqtab = oRowmeta + align_up<16>(Cfg::NMAX * 4);
     static constexpr int oInw = oSeqtab + align_up<16>(Cfg::SEQMAX * 4);
@@ -207,7 +221,12 @@ struct PoaLayout {   // byte offsets inside a group's memory slice
     static constexpr int oN2rAlt = oR2nAlt + align_up<16>(LAZYN * (int)sizeof(id_t));
     static constexpr int oNewId = oN2rAlt + align_up<16>(LAZYN * (int)sizeof(id_t));
     static constexpr int oNewSlot = oNewId + align_up<16>(LAZYL * 2);
-    static constexpr int BYTES = oNewSlot + align_up<16>(LAZYL * 2);
+    // rarely touched group-uniform scalars (Poa::stat): per-window counters, what a re-queued window takes along, and the
+    // per-wave totals of the kernel.  In registers they were live across the whole window — a vector register each in the
+    // sub-wave classes, spilled scalars in the others; here they cost an LDS access where they change.
+    static constexpr int STAT_BYTES = 96;
+    static constexpr int oStat = oNewSlot + align_up<16>(LAZYL * 2);
+    static constexpr int BYTES = oStat + STAT_BYTES;
     // Hybrid classes (Cfg::HYBRID) keep everything above in HBM scratch except what the topological sort and the graph update
     // chase with dependent loads: DFS stack / posnode, in-degree, clique size, marks, current sequence.  These live in a
     // second, small slice in LDS (their slots in the big slice stay unused).
@@ -218,7 +237,8 @@ struct PoaLayout {   // byte offsets inside a group's memory slice
     static constexpr int fSeq = fMark + align_up<16>(Cfg::NMAX);
     static constexpr int SMAX = (Cfg::LMAX + 1 + Cfg::CPL - 1) / Cfg::CPL * Cfg::CPL;          // largest row stride
     static constexpr int fRing1 = fSeq + align_up<16>(Cfg::LMAX + 1);                              // RING1 recent score rows
-    static constexpr int FAST_BYTES = fRing1 + align_up<16>(Cfg::RING1 * SMAX * (int)sizeof(score_t));   // (row metadata in LDS as well was measured: fewer resident
+    static constexpr int fStat = fRing1 + align_up<16>(Cfg::RING1 * SMAX * (int)sizeof(score_t));
+    static constexpr int FAST_BYTES = fStat + STAT_BYTES;   // (row metadata in LDS as well was measured: fewer resident
                                                                              // waves cost more than the shorter row loop gains)
 };
 
@@ -263,17 +283,34 @@ struct Poa {
     uint8_t* sidx;                                           // packed classes: SAVEd rows before each row (aliases mark: toposort and the row loop never overlap)
     id_t* pathnodes; uint32_t* pathoff; uint16_t *pathlen, *pathmult, *msa; uint32_t* dstcnt; uint8_t* consbuf; id_t* predrows; score_t* ring1;
     id_t *r2n_alt, *n2r_alt, *newid; int16_t* newslot;       // lazy rank order (Cfg::LAZY)
-    int x_tries, x_hits;                                     // threading attempts / hits of the window in hand (HYPO_EXACT_ADAPT)
     bool lazy_on; int n_new;                                 // lazy_on: this window keeps its order lazily (LONG windows); n_new: new nodes of the alignment in hand
     int n_paths, path_used, head_first;
     // group-uniform state
     int n_nodes; int L; bool topo_dirty; bool meta_dirty; int maxdelta; int last_source;
     int tb_steps; int tb_fv;
-    int need_nodes;                                          // after RES_OVERFLOW of a SHORT window: projected node count (0 = unknown)
     bool last_changed;         // did the most recent add_alignment change the graph topology?
-    // per-window counters (group-uniform; in the sub-wave classes every one of them costs a vector register, hence 32 bits and
-    // the diagnostic ones only in the diagnostic build or the emulator)
-    uint32_t cells, aligns, reused, exact_hits, cells_scored, cells_exact;
+    // Group-uniform scalars that change rarely live in a small block of the group's LDS slice (PoaLayout::oStat) instead of
+    // registers; lane 0 writes, everybody may read after the next sync.
+    //   ST_CELLS .. ST_CEXACT  per-window counters: reference-equivalent cells / alignments, reused alignments, threaded ones,
+    //                          cells through the score rows / the one-bit rows
+    //   ST_XT, ST_XH           threading attempts / hits of the window in hand (HYPO_EXACT_ADAPT)
+    //   ST_NEED                after RES_OVERFLOW of a SHORT window: projected node count (0 = unknown)
+    //   ST_CKIND .. ST_CPASS   after RES_OVERFLOW of a SHORT window: what of the work so far can travel to the next class (Poa::
+    //                          spill).  CARRY_BEFORE: the graph is exactly what the sequences before ST_CS left (the failed step
+    //                          changed nothing); CARRY_UNSORTED: sequence ST_CS - 1 is in the graph but its topological sort did not
+    //                          fit (the next class sorts first); ST_CPASS: nothing newer to spill, but the spill the window came
+    //                          with is still valid and travels on
+    //   ACC_*                  per-wave totals of poa_class_kernel (LDS classes)
+    enum { ST_CELLS = 0, ST_ALIGNS, ST_REUSED, ST_XHITS, ST_CSCORED, ST_CEXACT, ST_XT, ST_XH, ST_NEED, ST_CKIND, ST_CS, ST_CCHAIN0, ST_CPASS, ST_N,
+           ST_LASTX = ST_CPASS,   // while a window runs: did its latest alignment thread?  (ST_CPASS is written after the window's last step only)
+           ACC_CELLS = ST_N, ACC_ALIGNS, ACC_ABYTES, ACC_REUSED, ACC_THR, ACC_CSCORED, ACC_CTHR, ACC_NOK, ACC_NESC, ACC_NFAIL, ACC_NCARRIED, ACC_END };
+    static_assert(ACC_END <= Lay::STAT_BYTES / 4 && ST_N <= GW, "stat block");
+    enum { CARRY_NONE = 0, CARRY_BEFORE = 1, CARRY_UNSORTED = 2 };
+    static constexpr int RES_OVERFLOW_CLEAN = 64;            // add_alignment: RES_OVERFLOW before anything was changed (internal)
+    uint32_t* stat;
+    HD void stat_add(int k, uint32_t v) const { if (g.lane == 0) stat[k] += v; }
+    HD void stat_set(int k, uint32_t v) const { if (g.lane == 0) stat[k] = v; }
+    HD uint32_t stat_get(int k) const { return stat[k]; }
 #if defined(HYPO_PHASE_TIMERS) || defined(HYPO_EMU)
 #define HYPO_DIAG(x) do { x; } while (0)
     uint32_t rows_done, topo_runs, cons_serial, rows_slow, exact_tries, rows_exact_n, rows_scored_n, topo_dfs, topo_fast;
@@ -283,8 +320,9 @@ struct Poa {
     uint64_t tphase[PH_N]; uint64_t tlast;
 
     // `fast`: the LDS slice of a hybrid class (ignored otherwise: one slice, LDS or HBM, holds everything)
-    HD Poa(const Grp<GW>& g_, const PoaParamRef& P_, char* mem, char* fast = nullptr) : g(g_), P(P_) {
-        ring = (score_t*)(mem + Lay::oRing); dir = (uint8_t*)(mem + Lay::oDir);
+    // `dirg`: the group's direction-code slice in HBM scratch (Cfg::DIRG; PoaLayout::DIRG_BYTES)
+    HD Poa(const Grp<GW>& g_, const PoaParamRef& P_, char* mem, char* fast = nullptr, char* dirg = nullptr) : g(g_), P(P_) {
+        ring = (score_t*)(mem + Lay::oRing); dir = Cfg::DIRG ? (uint8_t*)dirg : (uint8_t*)(mem + Lay::oDir);
         rowmeta = (uint32_t*)(mem + Lay::oRowmeta); seqtab = (uint32_t*)(mem + Lay::oSeqtab);
         inw = (wt_t*)(mem + Lay::oInw);
         constexpr bool HYB = Cfg::HYBRID;
@@ -301,11 +339,13 @@ struct Poa {
         msa = (uint16_t*)(mem + Lay::oMsa); dstcnt = (uint32_t*)(mem + Lay::oDst); consbuf = (uint8_t*)(mem + Lay::oCons);
         predrows = (id_t*)(mem + Lay::oPredRows);
         r2n_alt = (id_t*)(mem + Lay::oR2nAlt); n2r_alt = (id_t*)(mem + Lay::oN2rAlt); newid = (id_t*)(mem + Lay::oNewId); newslot = (int16_t*)(mem + Lay::oNewSlot);
-        lazy_on = false; n_new = 0; x_tries = 0; x_hits = 0;
+        lazy_on = false; n_new = 0;
+        stat = (uint32_t*)(HYB ? fast + Lay::fStat : mem + Lay::oStat);
+        for (int t = g.lane; t < Lay::STAT_BYTES / 4; t += GW) stat[t] = 0;
         ring1 = (score_t*)(HYB ? fast + Lay::fRing1 : mem + Lay::oRing);
         n_paths = 0; path_used = 0; head_first = 0;
         n_nodes = 0; L = 0; topo_dirty = false; meta_dirty = true; maxdelta = 0; last_source = 0; tb_steps = 0; tb_fv = 0;
-        cells = 0; aligns = 0; reused = 0; exact_hits = 0; cells_scored = 0; cells_exact = 0; last_changed = true;
+        last_changed = true;
         HYPO_DIAG(rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; rows_exact_n = 0; rows_scored_n = 0; topo_dfs = 0; topo_fast = 0);
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
         tlast = 0;
@@ -1197,7 +1237,7 @@ struct Poa {
         if (meta_dirty) { build_rowmeta(); HYPO_TICK(PH_META); }
         const int R = g.uniform(Cfg::RINGCELLS / S);        // ring rows; row i can still see rows i-R .. i-1
         if (R < maxdelta + 1 || R < 1) return RES_OVERFLOW;
-        cells += (uint32_t)((n_nodes + 1) * W); aligns += 1; HYPO_DIAG(rows_done += (uint32_t)n_nodes);
+        if (g.lane == 0) { stat[ST_CELLS] += (uint32_t)((n_nodes + 1) * W); stat[ST_ALIGNS] += 1; } HYPO_DIAG(rows_done += (uint32_t)n_nodes);
 
         int best_i = -1;
         if constexpr (PK) {
@@ -1209,18 +1249,22 @@ struct Poa {
             constexpr bool EXACT_HERE = HYPO_EXACT && (Cfg::LMAX <= 127 || HYPO_EXACT_WIDE);
             // ... and not in a window whose reads keep failing to thread: an attempt costs about half a scored alignment, so below
             // one hit in two it is a loss (HYPO_EXACT_ADAPT: tries before the rate counts)
+            stat_set(ST_LASTX, 0u);
+            const int x_tries = (int)stat[ST_XT], x_hits = (int)stat[ST_XH];
             const bool worth = HYPO_EXACT_ADAPT == 0 || x_tries < HYPO_EXACT_ADAPT || 2 * x_hits >= x_tries;
             if (EXACT_HERE && worth && m > 0 && n < m && gp < 0) {
-                x_tries += 1;
                 best_i = HYPO_EXACT_RUNS ? rows_exact_runs(mode, S, R) : rows_exact(mode, S, R);
-                if (best_i > 0) x_hits += 1;
                 HYPO_TICK(PH_EXACT);
-                cells_exact += (uint32_t)((n_nodes + 1) * W); HYPO_DIAG(exact_tries += 1; rows_exact_n += (uint32_t)n_nodes);
-                if (best_i > 0) exact_hits += 1;
+                if (g.lane == 0) {
+                    stat[ST_XT] += 1; stat[ST_CEXACT] += (uint32_t)((n_nodes + 1) * W);
+                    stat[ST_LASTX] = best_i > 0 ? 1u : 0u;
+                    if (best_i > 0) { stat[ST_XH] += 1; stat[ST_XHITS] += 1; }
+                }
+                HYPO_DIAG(exact_tries += 1; rows_exact_n += (uint32_t)n_nodes);
             }
-            if (best_i <= 0) { best_i = rows_pk(mode, m, n, gp, S, R); cells_scored += (uint32_t)((n_nodes + 1) * W); HYPO_DIAG(rows_scored_n += (uint32_t)n_nodes); }
+            if (best_i <= 0) { best_i = rows_pk(mode, m, n, gp, S, R); stat_add(ST_CSCORED, (uint32_t)((n_nodes + 1) * W)); HYPO_DIAG(rows_scored_n += (uint32_t)n_nodes); }
         } else {
-        cells_scored += (uint32_t)((n_nodes + 1) * W);
+        stat_add(ST_CSCORED, (uint32_t)((n_nodes + 1) * W));
         HYPO_IN_VGPR(m); HYPO_IN_VGPR(n); HYPO_IN_VGPR(gp);
         const int j0 = CPL * g.lane;
         int sq[CPL];                                        // sq[c] = code of seq[j-1] for column j = j0+c
@@ -1550,7 +1594,7 @@ struct Poa {
         // unaligned head [0, fv): new chain (graph.cpp:194-196,273-291)
         int head = -1;
         if (fv > 0) {
-            if (n_nodes + fv > NMAX) return RES_OVERFLOW;
+            if (n_nodes + fv > NMAX) return RES_OVERFLOW_CLEAN;           // nothing touched yet
             for (int t = g.lane; t < fv; t += GW) {
                 const int id = n_nodes + t;
                 new_node(id, seq[t]);
@@ -1567,7 +1611,7 @@ struct Poa {
         g.sync();
         // aligned part [fv, L): every position owns a distinct node / clique.  posnode[q] is rewritten
         // in place from "node the position is aligned to" to "node the position becomes".
-        bool over = false;
+        bool over = false, node_over = false;
         int slot_carry = -1;                               // lazy rank order: rank the new nodes of the positions so far go behind
         for (int base = fv; base < L; base += GW) {
             const int q = base + g.lane;
@@ -1608,7 +1652,7 @@ struct Poa {
             }
             const uint64_t nb = g.ballot(act && kind != 0);
             const int tot = popc64(nb);
-            if (n_nodes + tot > NMAX) { over = true; break; }
+            if (n_nodes + tot > NMAX) { node_over = true; break; }
             if (act && kind != 0) {
                 const int below = popc64(nb & ((1ull << g.lane) - 1ull));
                 const int id = n_nodes + below;
@@ -1635,6 +1679,21 @@ struct Poa {
             if (tot) changed = true;
         }
         if (g.any(over)) return RES_OVERFLOW;
+        if (node_over) {
+            // The node table is full.  What the positions so far did to the OLD graph is undone, so that the window can take this
+            // graph to the next class (Poa::spill): the new nodes are dropped with the node count, and the only other change is
+            // that new nodes joined cliques — their ids sit at the tail of the old members' aligned lists.
+            n_nodes = g.uniform(n_old);
+            g.sync();
+            HYPO_NOUNROLL
+            for (int u = g.lane; u < n_old; u += GW) {
+                int k = nal[u];
+                while (k > 0 && (int)al[u * AL + k - 1] >= n_old) --k;
+                nal[u] = (uint8_t)k;
+            }
+            g.sync();
+            return RES_OVERFLOW_CLEAN;
+        }
         g.sync();
         // edges between consecutive positions (graph.cpp:250-258)
         int st = 0;
@@ -1846,12 +1905,104 @@ struct Poa {
 
     HD int add_sequence_step(int mode, int m, int n, int gp) {
         int rc = align(mode, m, n, gp);
-        if (rc != RES_OK) return rc;
+        if (rc != RES_OK) { if (rc == RES_OVERFLOW) stat_set(ST_CKIND, CARRY_BEFORE); return rc; }       // align() never changes the graph
         rc = add_alignment();
         HYPO_TICK(PH_ADD);
+        if (rc == RES_OVERFLOW_CLEAN) {
+            // the alignment just made is made again by the class that takes the window over: it is counted there
+            if (g.lane == 0) {
+                stat[ST_CKIND] = CARRY_BEFORE;
+                stat[ST_CELLS] -= (uint32_t)((n_nodes + 1) * (L + 1)); stat[ST_ALIGNS] -= 1; stat[ST_XHITS] -= stat[ST_LASTX];
+            }
+            return RES_OVERFLOW;
+        }
         if (rc != RES_OK) return rc;
-        if (topo_dirty) { rc = toposort(); HYPO_DIAG(topo_runs += 1); HYPO_TICK(PH_TOPO); }
+        if (topo_dirty) {
+            rc = toposort(); HYPO_DIAG(topo_runs += 1); HYPO_TICK(PH_TOPO);
+            if (rc == RES_OVERFLOW) stat_set(ST_CKIND, CARRY_UNSORTED);                                 // (the DFS stack: the graph itself is complete)
+        }
         return rc;
+    }
+
+    // ---- carrying a SHORT window's graph to the class it is re-queued to ------------------------------------------------------
+    // A window that outgrows its class used to start again from its first sequence in the next one.  The graph after the
+    // sequences added so far is the same in every class (node ids, letters, in-edge order, aligned lists, rank order are what
+    // the reference would have at that point), so it travels: spill() writes it in a class-independent form (16-bit ids and
+    // weights, the source class's in-edge stride), restore() reads it into the receiving class's tables, and run_short()
+    // continues with sequence `carry_s`.  Layout: 32-byte header ({magic, n_nodes, carry_s, chain0, kind | kin << 8, x_tries,
+    // x_hits, 0} as uint16, {cells, alignments, reused, threaded} so far as uint32), then code / nin / nout / nal (n bytes each, the block padded to 16), r2n, n2r (n x u16 each), inp, inw
+    // (n x kin x u16 each), al (n x AL x u16).
+    static constexpr uint32_t CARRY_MAGIC = 0x4879u;
+    HD static uint32_t spill_bytes(int n, int kin) {
+        return (uint32_t)(32 + align_up<16>(4 * n) + 2 * align_up<16>(2 * n) + 2 * align_up<16>(2 * n * kin) + align_up<16>(2 * n * AL));
+    }
+    HD uint32_t spill_size() const { return spill_bytes(n_nodes, KIN); }
+    HD void spill(uint8_t* out) const {
+        const int n = n_nodes;
+        uint16_t* h = (uint16_t*)out;
+        if (g.lane == 0) {
+            h[0] = (uint16_t)CARRY_MAGIC; h[1] = (uint16_t)n; h[2] = (uint16_t)stat[ST_CS]; h[3] = (uint16_t)stat[ST_CCHAIN0];
+            h[4] = (uint16_t)(stat[ST_CKIND] | (KIN << 8)); h[5] = (uint16_t)stat[ST_XT]; h[6] = (uint16_t)stat[ST_XH]; h[7] = 0;
+            // the reference-equivalent work of the sequences behind the cursor is accounted by whoever finishes the window
+            uint32_t* c = (uint32_t*)(out + 16);
+            c[0] = stat[ST_CELLS]; c[1] = stat[ST_ALIGNS]; c[2] = stat[ST_REUSED]; c[3] = stat[ST_XHITS];
+        }
+        uint8_t* b = out + 32;
+        HYPO_NOUNROLL
+        for (int u = g.lane; u < n; u += GW) { b[u] = code[u]; b[n + u] = nin[u]; b[2 * n + u] = nout[u]; b[3 * n + u] = nal[u]; }
+        uint16_t* o_r2n = (uint16_t*)(b + align_up<16>(4 * n));
+        uint16_t* o_n2r = o_r2n + align_up<16>(2 * n) / 2;
+        uint16_t* o_inp = o_n2r + align_up<16>(2 * n) / 2;
+        uint16_t* o_inw = o_inp + align_up<16>(2 * n * KIN) / 2;
+        uint16_t* o_al = o_inw + align_up<16>(2 * n * KIN) / 2;
+        HYPO_NOUNROLL
+        for (int u = g.lane; u < n; u += GW) { o_r2n[u] = (uint16_t)r2n[u]; o_n2r[u] = (uint16_t)n2r[u]; }
+        HYPO_NOUNROLL
+        for (int t = g.lane; t < n * KIN; t += GW) { o_inp[t] = (uint16_t)inp[t]; o_inw[t] = (uint16_t)inw[t]; }   // (slots beyond nin[u] hold garbage: never read)
+        HYPO_NOUNROLL
+        for (int t = g.lane; t < n * AL; t += GW) o_al[t] = (uint16_t)al[t];
+    }
+    // RES_OK, or RES_OVERFLOW when the graph does not fit this class either (the caller passes the window on with the same spill)
+    HD int restore(const uint8_t* in, int* s_out, int* chain0_out) {
+        const uint16_t* h = (const uint16_t*)in;
+        if (h[0] != (uint16_t)CARRY_MAGIC) return RES_INVALID;
+        const int n = h[1], kin = h[4] >> 8, kind = h[4] & 0xff;
+        if (n > NMAX || n < 1) return RES_OVERFLOW;
+        const uint8_t* b = in + 32;
+        bool over = false;
+        HYPO_NOUNROLL
+        for (int u = g.lane; u < n; u += GW) {
+            const int k = b[n + u];
+            if (k > KIN) over = true;
+            code[u] = b[u]; nin[u] = (uint8_t)k; nout[u] = b[2 * n + u]; nal[u] = b[3 * n + u];
+        }
+        if (g.any(over)) return RES_OVERFLOW;
+        const uint16_t* i_r2n = (const uint16_t*)(b + align_up<16>(4 * n));
+        const uint16_t* i_n2r = i_r2n + align_up<16>(2 * n) / 2;
+        const uint16_t* i_inp = i_n2r + align_up<16>(2 * n) / 2;
+        const uint16_t* i_inw = i_inp + align_up<16>(2 * n * kin) / 2;
+        const uint16_t* i_al = i_inw + align_up<16>(2 * n * kin) / 2;
+        g.sync();
+        HYPO_NOUNROLL
+        for (int u = g.lane; u < n; u += GW) {
+            r2n[u] = (id_t)i_r2n[u]; n2r[u] = (id_t)i_n2r[u];
+            const int k = nin[u];
+            HYPO_NOUNROLL
+            for (int p = 0; p < k; ++p) { inp[u * KIN + p] = (id_t)i_inp[u * kin + p]; inw[u * KIN + p] = (wt_t)i_inw[u * kin + p]; }
+            const int ka = nal[u];
+            HYPO_NOUNROLL
+            for (int a = 0; a < ka; ++a) al[u * AL + a] = (id_t)i_al[u * AL + a];
+        }
+        n_nodes = g.uniform(n);
+        *s_out = h[2]; *chain0_out = h[3];
+        if (g.lane == 0) {
+            stat[ST_XT] = h[5]; stat[ST_XH] = h[6];
+            const uint32_t* c = (const uint32_t*)(in + 16);
+            stat[ST_CELLS] = c[0]; stat[ST_ALIGNS] = c[1]; stat[ST_REUSED] = c[2]; stat[ST_XHITS] = c[3];
+        }
+        topo_dirty = kind == CARRY_UNSORTED; meta_dirty = true; last_changed = true;
+        g.sync();
+        return RES_OK;
     }
 
     // ---- heaviest bundle, all lanes (graph.cpp:610-658 when no tie rule and no branch completion is involved) ------
@@ -1867,7 +2018,7 @@ struct Poa {
     static constexpr int LV = NN <= 64 ? 6 : (NN <= 128 ? 7 : 8);
     static constexpr int RPL = (NN + GW - 1) / GW;          // ranks per lane
     static constexpr bool FAST_CONS = sizeof(id_t) == 1 && NN <= 255 && RPL <= 16;
-    static_assert(!FAST_CONS || 4 * NN + LV * NN + 1 + 2 * NMAX <= (int)sizeof(score_t) * Cfg::RINGCELLS + Cfg::DIRBYTES, "fast consensus scratch aliases ring+dir");
+    static_assert(!FAST_CONS || 4 * NN + LV * NN + 1 + 2 * NMAX <= (int)sizeof(score_t) * Cfg::RINGCELLS + Cfg::DIRBYTES_LDS, "fast consensus scratch aliases ring+dir");
     HD int consensus_fast(int16_t** path_out) {
         int32_t* acc = (int32_t*)ring;                       // (sum of chosen weights << 8) + nodes on the chain, by rank
         uint8_t* up = (uint8_t*)(acc + NN);                  // up[lv][r]: 2^lv-th ancestor of rank r (n = none)
@@ -2071,7 +2222,7 @@ struct Poa {
     HD int long_step(int m, int n, int gp) {
         int rc = align(MODE_NW, m, n, gp);
         if (rc != RES_OK) return rc;
-        if ((rc = add_alignment()) != RES_OK) return rc;
+        if ((rc = add_alignment()) != RES_OK) return rc == RES_OVERFLOW_CLEAN ? (int)RES_OVERFLOW : rc;      // (LONG windows start over in the last class)
         if ((rc = record_path(tb_steps == 0 ? L : tb_fv)) != RES_OK) return rc;   // before toposort: its stack aliases posnode
         HYPO_TICK(PH_ADD);
         if (topo_dirty) { rc = toposort(); HYPO_DIAG(topo_runs += 1); HYPO_TICK(PH_TOPO); }
@@ -2103,7 +2254,7 @@ struct Poa {
                     int c = 0;
                     while (s < n_seq && same_as_previous(s)) { ++c; ++s; }
                     if (c) {
-                        cells += (uint32_t)(c * (n_nodes + 1) * (L + 1)); aligns += c; reused += c;
+                        if (g.lane == 0) { stat[ST_CELLS] += (uint32_t)(c * (n_nodes + 1) * (L + 1)); stat[ST_ALIGNS] += c; stat[ST_REUSED] += c; }
                         if ((rc = readd_alignment(c)) != RES_OK) return rc;
                         if (g.lane == 0) pathmult[n_paths - 1] = (uint16_t)(pathmult[n_paths - 1] + c);
                         g.sync();
@@ -2191,7 +2342,7 @@ struct Poa {
     }
 
     // Window::generate_consensus_short (src/Window.cpp:87-154)
-    HD int run_short(uint32_t w, const HypoWindow& W) {
+    HD int run_short(uint32_t w, const HypoWindow& W, const uint8_t* carry_in) {
         const int m = P->sr_m, n = P->sr_n, gp = P->sr_g;
         const uint8_t* d4 = P->draft4 + W.draft_off;
         n_nodes = 0; topo_dirty = false; meta_dirty = true;
@@ -2204,16 +2355,29 @@ struct Poa {
         if (rc != RES_OK) return rc;
         bool prev_aligned = false;                           // the previous non-reused sequence went through align()
         int s = 0;
-        need_nodes = 0;
+        int chain0_in = 0;
+        if (HYPO_CARRY_RESTORE && carry_in) {                                      // the graph another class built from sequences [0, s): continue from there
+            if ((rc = restore(carry_in, &s, &chain0_in)) != RES_OK) return rc;
+            if (s > n_seq) return RES_INVALID;
+            if (topo_dirty) { if ((rc = toposort()) != RES_OK) return rc; HYPO_DIAG(topo_runs += 1); HYPO_TICK(PH_TOPO); }
+        }
         // A window that outgrows this class's node table says how many nodes it will probably need, so that it is re-queued
         // straight into a class that holds it instead of climbing one class at a time: the sequences added so far grew the
         // graph from its first chain of `chain0` nodes to n_nodes, the remaining ones are assumed to add as many each.
-        int chain0 = 0;
+        int chain0 = chain0_in;
         auto project = [&](int rc_) -> int {
             if (rc_ == RES_OVERFLOW && s > 0 && n_nodes > 0) {
                 const int grown = n_nodes - chain0 > 0 ? n_nodes - chain0 : 0;
-                need_nodes = n_nodes + (int)(((int64_t)grown * (n_seq - s) + s - 1) / s) + 4;
-            }
+                if (g.lane == 0) {
+                    stat[ST_NEED] = (uint32_t)(n_nodes + (int)(((int64_t)grown * (n_seq - s) + s - 1) / s) + 4);
+                    // what travels (Poa::spill): the sequence in hand is s - 1; it is aligned again by the receiving class unless
+                    // only its topological sort is missing
+                    const uint32_t kind = stat[ST_CKIND];
+                    stat[ST_CS] = (uint32_t)(kind == CARRY_UNSORTED ? s : s - 1);
+                    stat[ST_CCHAIN0] = (uint32_t)(chain0 ? chain0 : (kind == CARRY_UNSORTED ? n_nodes : 0));
+                }
+            } else stat_set(ST_CKIND, CARRY_NONE);
+            g.sync();
             return rc_;
         };
         while (s < n_seq) {
@@ -2222,7 +2386,7 @@ struct Poa {
                 int c = 0;
                 while (s < n_seq && same_as_previous(s)) { ++c; ++s; }
                 if (c) {
-                    cells += (uint32_t)(c * (n_nodes + 1) * (L + 1)); aligns += c; reused += c;   // work the reference does
+                    if (g.lane == 0) { stat[ST_CELLS] += (uint32_t)(c * (n_nodes + 1) * (L + 1)); stat[ST_ALIGNS] += c; stat[ST_REUSED] += c; }   // work the reference does
                     if ((rc = readd_alignment(c)) != RES_OK) return project(rc);
                     HYPO_TICK(PH_ADD);
                     if (s >= n_seq) break;
@@ -2255,12 +2419,15 @@ struct Poa {
     }
 
     // Window::generate_consensus (src/Window.cpp:44-61)
-    HD int run(uint32_t w) {
+    HD int run(uint32_t w, const uint8_t* carry_in = nullptr) {
         // the object outlives the window (one per persistent group): per-window counters and flags start over here
-        cells = 0; aligns = 0; reused = 0; exact_hits = 0; cells_scored = 0; cells_exact = 0; last_changed = true;
+        last_changed = true;
+        g.sync();
+        if (g.lane < ST_N) stat[g.lane] = 0;
+        g.sync();
         HYPO_DIAG(rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; rows_exact_n = 0; rows_scored_n = 0; topo_dfs = 0; topo_fast = 0);
-        n_paths = 0; path_used = 0; head_first = 0; L = 0; maxdelta = 0; tb_steps = 0; tb_fv = 0; need_nodes = 0;
-        lazy_on = false; n_new = 0; x_tries = 0; x_hits = 0;
+        n_paths = 0; path_used = 0; head_first = 0; L = 0; maxdelta = 0; tb_steps = 0; tb_fv = 0;
+        lazy_on = false; n_new = 0;
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
         HYPO_TICK_RESET();
         const HypoWindow W = P->windows[w];
@@ -2274,7 +2441,13 @@ struct Poa {
             if (Cfg::PATHCAP == 0) return RES_UNSUPPORTED;   // re-queued to a class that keeps sequence paths
             return run_long(w, W);
         }
-        return run_short(w, W);
+        const int rc = run_short(w, W, carry_in);
+        // a window that came with a spill and overflows where nothing newer can be saved (its graph does not fit this class either,
+        // an in-edge list ran full halfway through an update) keeps the spill it came with: the graph after the sequences before
+        // that spill's cursor is as valid as it was
+        if (g.lane == 0) stat[ST_CPASS] = (rc == RES_OVERFLOW && carry_in && stat[ST_CKIND] == CARRY_NONE) ? 1u : 0u;
+        g.sync();
+        return rc;
     }
 };
 

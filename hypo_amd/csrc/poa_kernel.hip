@@ -114,6 +114,7 @@ poa_plan_count_kernel(PoaParams P, PoaQueues Q, uint32_t n_windows) {
         bool trivial;
         const uint32_t key = plan_key_from(W, maxarm, changes, &trivial);
         Q.keys[w] = (uint16_t)key;
+        Q.carry[w] = 0;                                       // no spill yet (poa_class_kernel sets it when it re-queues the window)
         atomicAdd(&hist[key], 1u);
         if (trivial) atomicAdd(&ntriv, 1u);
     }
@@ -169,6 +170,8 @@ struct PoaKArgs {
     char* scratch;
     uint32_t* head;
     const uint32_t* bound;
+    char* dirg;             // Cfg::DIRG: direction-code slices, one per resident group
+    uint32_t expected;      // POLL: lane groups of the producing classes' launches (Q.done[0 .. cls) reach this when all have exited)
 };
 typedef const PoaKArgs __attribute__((address_space(4)))* PoaKArgPtr;
 __device__ __forceinline__ PoaKArgPtr fresh(PoaKArgPtr p) { asm volatile("" : "+s"(p)); return p; }
@@ -177,7 +180,12 @@ __device__ __forceinline__ PoaKArgPtr fresh(PoaKArgPtr p) { asm volatile("" : "+
 #define HYPO_C4_WAVES 2
 #endif
 template <class Cfg> struct PoaMinWaves { static constexpr int value = Cfg::HYBRID ? HYPO_C4_WAVES : 1; };
-template <class Cfg, bool USE_LDS>
+// POLL: the kernel runs NEXT to the classes that feed it and takes re-queued windows as they arrive: it leaves when every lane
+// group of every launch of the lower classes has exited (Q.done) and the queue is drained.  Every launch it waits for is
+// submitted BEFORE it, so whatever the streams' mapping to hardware queues is, nothing it depends on can be stuck behind it; a
+// time limit without progress (kPollLimitTicks) is the belt to those braces, and a regular launch of the class follows anyway.
+constexpr uint64_t kPollLimitTicks = 50u * 1000u * 1000u;     // wall_clock64() runs at 100 MHz: 0.5 s
+template <class Cfg, bool USE_LDS, bool POLL = false>
 __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(PoaKArgs /*read through the kernarg segment*/) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const PoaKArgPtr ka = (PoaKArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -189,14 +197,20 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
     char* mem = USE_LDS ? smem + (size_t)grp * PoaLayout<Cfg>::BYTES
                         : fresh(ka)->scratch + ((size_t)blockIdx.x * GPW + grp) * PoaLayout<Cfg>::BYTES;
     char* fast = smem + (size_t)grp * PoaLayout<Cfg>::FAST_BYTES;     // hybrid classes only
+    char* dirg = Cfg::DIRG ? fresh(ka)->dirg + ((size_t)blockIdx.x * GPW + grp) * PoaLayout<Cfg>::DIRG_BYTES : nullptr;
     const int cls = fresh(ka)->cls;
-    const uint32_t count = *fresh(ka)->bound;   // queue slots [.., *bound) are final when this launch starts
+    const uint32_t count = POLL ? 0u : *fresh(ka)->bound;   // queue slots [.., *bound) are final when this launch starts (POLL: the queue grows)
+    const uint32_t planned = fresh(ka)->Q.planned[cls];      // slots from here on hold re-queued windows (they may come with a spill)
     const PoaParamRef P{&ka->P};
     // per-wave totals, flushed once at exit.  The LDS classes keep them in 32 bits (a wave of those sees at most a few thousand
     // windows of < 1 M cells; in the sub-wave classes every group-uniform value is a vector register per lane)
-    typedef typename std::conditional<USE_LDS, uint32_t, uint64_t>::type acc_t;
-    acc_t cells = 0, aligns = 0, abytes = 0, n_reused = 0, n_thr = 0, c_scored = 0, c_thr = 0;
-    uint32_t n_ok = 0, n_esc = 0, n_fail = 0;
+    // The LDS classes keep the totals in the group's stat block in LDS (Poa::ACC_*, 32 bits: a wave of those sees at most a few
+    // thousand windows of < 1 M cells); in registers they were live across every window — a vector register each in the sub-wave
+    // classes.  The HBM-scratch classes (two waves per SIMD anyway) keep 64-bit registers.
+    typedef Poa<Cfg> PoaT;
+    uint64_t cells = 0, aligns = 0, abytes = 0, n_reused = 0, n_thr = 0, c_scored = 0, c_thr = 0;
+    uint32_t n_ok = 0, n_esc = 0, n_fail = 0, n_carried = 0;
+    uint32_t carry_in = 0;                                      // Q.carry value of the window in hand
 #ifdef HYPO_PHASE_TIMERS
     uint64_t tph[PH_N] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t dbg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -204,66 +218,133 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
 #endif
     // what happens to a window once Poa::run / step has returned something other than RES_CONTINUE
     auto account = [&](Poa<Cfg>& poa, uint32_t w, int rc) {
-        if (rc == RES_OK) { cells += poa.cells; aligns += poa.aligns; n_reused += poa.reused; n_thr += poa.exact_hits; }   // reference-equivalent work of FINISHED windows only
-        c_scored += poa.cells_scored; c_thr += poa.cells_exact;                // executed work, finished or not
+        uint32_t* const stt = poa.stat;
+        if constexpr (USE_LDS) {
+            if (g.lane == 0) {
+                if (rc == RES_OK) {      // reference-equivalent work of FINISHED windows only
+                    stt[PoaT::ACC_CELLS] += stt[PoaT::ST_CELLS]; stt[PoaT::ACC_ALIGNS] += stt[PoaT::ST_ALIGNS];
+                    stt[PoaT::ACC_REUSED] += stt[PoaT::ST_REUSED]; stt[PoaT::ACC_THR] += stt[PoaT::ST_XHITS];
+                }
+                stt[PoaT::ACC_CSCORED] += stt[PoaT::ST_CSCORED]; stt[PoaT::ACC_CTHR] += stt[PoaT::ST_CEXACT];     // executed work, finished or not
+            }
+        } else {
+            if (rc == RES_OK) { cells += stt[PoaT::ST_CELLS]; aligns += stt[PoaT::ST_ALIGNS]; n_reused += stt[PoaT::ST_REUSED]; n_thr += stt[PoaT::ST_XHITS]; }
+            c_scored += stt[PoaT::ST_CSCORED]; c_thr += stt[PoaT::ST_CEXACT];
+        }
 #ifdef HYPO_PHASE_TIMERS
         for (int i = 0; i < PH_N; ++i) tph[i] += poa.tphase[i];
-        dbg[0] += poa.rows_done; dbg[1] += poa.aligns - poa.reused; dbg[2] += poa.reused; dbg[3] += poa.topo_runs; dbg[4] += poa.cons_serial; dbg[5] += poa.rows_slow; dbg[6] += poa.exact_tries; dbg[7] += poa.exact_hits; dbg[8] += poa.rows_exact_n; dbg[9] += poa.rows_scored_n; dbg[10] += poa.topo_dfs; dbg[11] += poa.topo_fast;
+        dbg[0] += poa.rows_done; dbg[1] += stt[PoaT::ST_ALIGNS] - stt[PoaT::ST_REUSED]; dbg[2] += stt[PoaT::ST_REUSED]; dbg[3] += poa.topo_runs; dbg[4] += poa.cons_serial; dbg[5] += poa.rows_slow; dbg[6] += poa.exact_tries; dbg[7] += stt[PoaT::ST_XHITS]; dbg[8] += poa.rows_exact_n; dbg[9] += poa.rows_scored_n; dbg[10] += poa.topo_dfs; dbg[11] += poa.topo_fast;
 #endif
         if (rc == RES_OK) {
-            ++n_ok;
             if (g.lane == 0) {                                  // algorithmic bytes, SURVEY.md 8(d)
                 const HypoWindow W = P->windows[w];
                 const uint32_t narm = W.n_internal + W.n_prefix + W.n_suffix;
-                acc_t a = (acc_t)((W.draft_len + 1) / 2 + 16 + 8 * (1 + narm) + P->out_len[w]);
+                uint32_t a = (uint32_t)((W.draft_len + 1) / 2 + 16 + 8 * (1 + narm) + P->out_len[w]);
                 const uint32_t* alen = P->arm_len;
                 for (uint32_t t = 0; t < narm; ++t) a += (alen[W.first_arm + t] + 3) / 4;
-                abytes += a;
+                if constexpr (USE_LDS) { stt[PoaT::ACC_ABYTES] += a; stt[PoaT::ACC_NOK] += 1; } else abytes += a;
             }
+            if constexpr (!USE_LDS) ++n_ok;
         } else if ((rc == RES_OVERFLOW || rc == RES_UNSUPPORTED) && cls + 1 < kNumPoaClasses) {
-            // next class, or the first later SHORT class whose node table holds what the window projects to need
-            // (every later class is finished after this one: see the launch order in poa_run)
-            int to = cls + 1;
-            if (rc == RES_OVERFLOW && poa.need_nodes > 0) {
-                constexpr int nmax[kNumPoaClasses] = {
-#define HYPO_NMAX(ID, CFG) CFG::NMAX,
-                    HYPO_FOR_EACH_CLASS(HYPO_NMAX)
-#undef HYPO_NMAX
-                };
-                while (to + 1 < kFirstLongClass && nmax[to] < poa.need_nodes) ++to;
-            }
+            // Where to: every SHORT class hands over to class 3 (kRequeueClass), the one SHORT class that runs next to the others and
+            // polls its queue — a window re-queued from class 0 used to wait for class 0 to finish, run in class 1's mop-up pass,
+            // and, if it outgrew that too, wait again.  Class 3 and later hand over to the next class; a window that projects
+            // to more nodes than class 3 holds goes straight to the LONG class.
+            // (The projection Poa::run_short leaves in ST_NEED no longer picks the class: an estimate beyond class 3's node table
+            // sent windows to the LONG class, 20 x slower per row, that class 3 would have finished; a window that really
+            // outgrows class 3 arrives there with its graph all the same.)
+            const int to = cls < kRequeueClass ? kRequeueClass : cls + 1;
+            // what the window takes along: the graph of the sequences it has been through (Poa::spill) when the step that failed
+            // left one, else the spill it came with
+            uint32_t cv = 0;
+            if (HYPO_CARRY_SPILL && rc == RES_OVERFLOW && stt[PoaT::ST_CKIND] != PoaT::CARRY_NONE) {
+                const uint32_t sz16 = poa.spill_size() >> 4;
+                uint32_t off = 0;
+                if (g.lane == 0) off = atomicAdd(fresh(ka)->Q.spill_used, sz16);
+                off = (uint32_t)g.shfl((int)off, 0);
+                if ((uint64_t)off + sz16 <= (uint64_t)fresh(ka)->Q.spill_cap16) {
+                    poa.spill((uint8_t*)fresh(ka)->Q.spill + (size_t)off * 16);
+                    cv = off + 1;
+                    if constexpr (USE_LDS) { if (g.lane == 0) stt[PoaT::ACC_NCARRIED] += 1; } else ++n_carried;
+                }
+            } else if (rc == RES_OVERFLOW && stt[PoaT::ST_CPASS]) cv = carry_in;
             if (g.lane == 0) {
+                fresh(ka)->Q.carry[w] = cv;
+                __threadfence();                                // the spill and carry[w] are visible before the queue entry is
                 const uint32_t slot = atomicAdd(&fresh(ka)->Q.count[to], 1u);
-                fresh(ka)->Q.items[(size_t)to * fresh(ka)->Q.stride + slot] = w;
+                __hip_atomic_store(&fresh(ka)->Q.items[(size_t)to * fresh(ka)->Q.stride + slot], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            ++n_esc;
+            if constexpr (USE_LDS) { if (g.lane == 0) stt[PoaT::ACC_NESC] += 1; } else ++n_esc;
         } else {
             if (g.lane == 0) {
                 P->out_len[w] = 0;
                 P->out_status[w] = (uint8_t)(rc == RES_UNDEFINED ? HYPO_ST_UNDEFINED : (rc == RES_INVALID ? HYPO_ST_INVALID : HYPO_ST_CAPACITY));
             }
-            ++n_fail;
+            if constexpr (USE_LDS) { if (g.lane == 0) stt[PoaT::ACC_NFAIL] += 1; } else ++n_fail;
         }
     };
+    auto aload = [](const uint32_t* p) -> uint32_t { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
     auto dequeue = [&](uint32_t* w) -> bool {
-        // a plain look first: the waves of an empty class (most launches of the rare classes) leave without queueing up
-        // on one atomic counter
-        if (__atomic_load_n(fresh(ka)->head, __ATOMIC_RELAXED) >= count) return false;
         uint32_t idx = 0;
-        if (g.lane == 0) idx = atomicAdd(fresh(ka)->head, 1u);
-        idx = (uint32_t)g.shfl((int)idx, 0);
-        if (idx >= count) return false;
-        *w = fresh(ka)->Q.items[(size_t)cls * fresh(ka)->Q.stride + idx];
+        if constexpr (POLL) {
+            const uint32_t* const cnt = fresh(ka)->Q.count + cls;
+            const uint32_t* const done = fresh(ka)->Q.done;
+            const uint32_t expected = fresh(ka)->expected;
+            auto producers_done = [&]() -> bool {
+                uint32_t d = 0;
+                for (int c = 0; c < cls; ++c) d += aload(done + c);
+                return d >= expected;
+            };
+            uint64_t t0 = wall_clock64();
+            for (;;) {
+                // once the classes that feed this one are done, what is left is the regular launch's (full width, no polling)
+                if (producers_done()) return false;
+                if (aload(fresh(ka)->head) < aload(cnt)) {
+                    if (g.lane == 0) idx = atomicAdd(fresh(ka)->head, 1u);
+                    idx = (uint32_t)g.shfl((int)idx, 0);
+                    // the slot is this group's now; its entry may still be on its way (the producer bumps the count first)
+                    const uint32_t* const slot = fresh(ka)->Q.items + (size_t)cls * fresh(ka)->Q.stride + idx;
+                    t0 = wall_clock64();
+                    for (;;) {
+                        const uint32_t v = aload(slot);
+                        if (v != kQueueUnpublished) { *w = v; break; }
+                        if (producers_done() && aload(cnt) <= idx) return false;      // claimed a slot behind the last entry
+                        if (wall_clock64() - t0 > kPollLimitTicks) return false;       // (a producer that died between count and entry)
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // carry[w] and the spill were written before the entry
+                    break;
+                }
+                if (wall_clock64() - t0 > kPollLimitTicks) return false;
+                __builtin_amdgcn_s_sleep(127);
+            }
+        } else {
+            // a plain look first: the waves of an empty class (most launches of the rare classes) leave without queueing up
+            // on one atomic counter
+            if (__atomic_load_n(fresh(ka)->head, __ATOMIC_RELAXED) >= count) return false;
+            if (g.lane == 0) idx = atomicAdd(fresh(ka)->head, 1u);
+            idx = (uint32_t)g.shfl((int)idx, 0);
+            if (idx >= count) return false;
+            *w = fresh(ka)->Q.items[(size_t)cls * fresh(ka)->Q.stride + idx];
+        }
+        carry_in = idx >= planned ? fresh(ka)->Q.carry[*w] : 0u;
         return true;
     };
-    Poa<Cfg> poa(g, P, mem, fast);
+    Poa<Cfg> poa(g, P, mem, fast, dirg);
     // The groups of a wavefront (GPW > 1) take windows in lock step: all dequeue, all run, all write their consensus.
     // (Letting a finished group open its next window while its neighbours are still aligning was measured and is
     // slower: the dequeue + descriptor + arm staging round trips of one group then stall the other three, 4x as often.)
     uint32_t w;
-    while (dequeue(&w)) account(poa, w, poa.run(w));
+    while (dequeue(&w)) account(poa, w, poa.run(w, carry_in ? (const uint8_t*)fresh(ka)->Q.spill + (size_t)(carry_in - 1) * 16 : nullptr));
     if (g.lane == 0) {
         HypoPoaStats* st = fresh(ka)->Q.stats;
+        if constexpr (USE_LDS) {
+            const uint32_t* const stt = poa.stat;
+            cells = stt[PoaT::ACC_CELLS]; aligns = stt[PoaT::ACC_ALIGNS]; abytes = stt[PoaT::ACC_ABYTES]; n_reused = stt[PoaT::ACC_REUSED];
+            n_thr = stt[PoaT::ACC_THR]; c_scored = stt[PoaT::ACC_CSCORED]; c_thr = stt[PoaT::ACC_CTHR]; n_ok = stt[PoaT::ACC_NOK];
+            n_esc = stt[PoaT::ACC_NESC]; n_fail = stt[PoaT::ACC_NFAIL]; n_carried = stt[PoaT::ACC_NCARRIED];
+        }
+        atomicAdd((unsigned long long*)&st->n_carried, (unsigned long long)n_carried);
         atomicAdd((unsigned long long*)&st->n_class[cls], (unsigned long long)n_ok);
         atomicAdd((unsigned long long*)&st->n_escalated, (unsigned long long)n_esc);
         atomicAdd((unsigned long long*)&st->n_failed, (unsigned long long)n_fail);
@@ -281,17 +362,25 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
         atomicAdd(&ph[PH_N + 1], 1ull);                                                           // waves
         for (int i = 0; i < 12; ++i) atomicAdd(&ph[PH_N + 2 + i], (unsigned long long)dbg[i]);      // rows, real alignments, reused, toposorts, serial consensus passes, slow rows, exact tries / hits
 #endif
+        // this group will push nothing more: what it re-queued is in the queues (a polling kernel of a later class counts these)
+        __threadfence();
+        atomicAdd(fresh(ka)->Q.done + cls, 1u);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // launch
 // ------------------------------------------------------------------------------------------------
-template <class Cfg, bool USE_LDS>
+// what a launch needs beyond the queues: the HBM scratch of the class (state slices of the HBM-scratch classes, direction-code
+// slices of a Cfg::DIRG class) and how many resident groups it is provisioned for
+struct ClassScratch { char* base; int groups; };
+template <class Cfg, bool USE_LDS, bool POLL = false>
 static hipError_t launch_class(const PoaParams& P, const PoaQueues& Q, int cls, uint32_t n_windows,
-                               char* scratch, int num_cus, int group_cap, hipStream_t stream,
-                               int waves_per_cu_cap = 0, bool mop_up = false) {
-    auto kern = poa_class_kernel<Cfg, USE_LDS>;
+                               ClassScratch scr, int num_cus, hipStream_t stream,
+                               int waves_per_cu_cap = 0, bool mop_up = false, uint32_t* groups_launched = nullptr, uint32_t expected = 0) {
+    auto kern = poa_class_kernel<Cfg, USE_LDS, POLL>;
+    char* const scratch = scr.base;
+    const int group_cap = scr.groups;
     constexpr int GPW = 64 / Cfg::GW;
     const size_t lds = USE_LDS ? (size_t)GPW * PoaLayout<Cfg>::BYTES : (Cfg::HYBRID ? (size_t)GPW * PoaLayout<Cfg>::FAST_BYTES : 0);
     hipError_t e;
@@ -309,7 +398,7 @@ static hipError_t launch_class(const PoaParams& P, const PoaQueues& Q, int cls, 
     }
     if (waves_per_cu_cap >= 1 && waves_per_cu_cap < per_cu) per_cu = waves_per_cu_cap;
     long grid = (long)per_cu * num_cus;
-    if (!USE_LDS && grid * GPW > group_cap) grid = group_cap / GPW;
+    if ((!USE_LDS || Cfg::DIRG) && grid * GPW > group_cap) grid = group_cap / GPW;
     const long need = ((long)n_windows + GPW - 1) / GPW;      // never more waves than windows
     if (grid > need) grid = need;
     if (grid < 1) grid = 1;
@@ -317,8 +406,10 @@ static hipError_t launch_class(const PoaParams& P, const PoaQueues& Q, int cls, 
     uint32_t* head = mop_up ? Q.head2 + cls : Q.head + cls;
     const uint32_t* bound = (mop_up || waves_per_cu_cap == 0) ? Q.count + cls : Q.planned + cls;
     PoaKArgs a;
-    a.P = P; a.Q = Q; a.cls = cls; a.scratch = scratch; a.head = head; a.bound = bound;
+    a.P = P; a.Q = Q; a.cls = cls; a.scratch = Cfg::DIRG ? nullptr : scratch; a.head = head; a.bound = bound;
+    a.dirg = Cfg::DIRG ? scratch : nullptr; a.expected = expected;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, stream, a);
+    if (groups_launched) *groups_launched += (uint32_t)(grid * GPW);
     return hipGetLastError();
 }
 
@@ -384,11 +475,23 @@ static size_t arm_off_region_bytes(uint64_t n_arms) {        // offsets + block 
     return ((size_t)n_arms * 8 + 255) / 256 * 256 + ((size_t)nb * 8 + 255) / 256 * 256;
 }
 
-static size_t poa_workspace_prefix(uint32_t n_windows) {       // header, class queues, plan keys
+// spill pool of the re-queued windows' graphs (Poa::spill: 1.5 KB for a class-0 window, 12 KB for a full class-3 one): a bump
+// allocator, a window that finds it full starts again from its first sequence as before
+static size_t poa_spill_bytes(uint32_t n_windows) {
+    size_t b = (size_t)n_windows * 256;
+    const size_t lo = (size_t)1 << 20, hi = (size_t)1 << 30;
+    b = b < lo ? lo : (b > hi ? hi : b);
+    return b;
+}
+static int groups3_for(uint32_t n_windows) { return n_windows < (uint32_t)kMaxGroups3 ? (n_windows < 16u ? 16 : (int)n_windows) : kMaxGroups3; }
+static size_t poa_workspace_prefix(uint32_t n_windows) {       // header, class queues, plan keys, carry words, spill pool, class 3's direction codes
     size_t b = kPoaHeaderBytes;
     b += (size_t)kNumPoaClasses * n_windows * sizeof(uint32_t);
     b = (b + 255) / 256 * 256;
     b += ((size_t)n_windows * 2 + 255) / 256 * 256;
+    b += ((size_t)n_windows * 4 + 255) / 256 * 256;
+    b += poa_spill_bytes(n_windows);
+    b += (size_t)groups3_for(n_windows) * PoaLayout<PoaClass3>::DIRG_BYTES;
     return b;
 }
 
@@ -440,9 +543,21 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     off = (off + 255) / 256 * 256;
     Q.keys = (uint16_t*)(ws + off);
     off += ((size_t)n_windows * 2 + 255) / 256 * 256;
+    Q.carry = (uint32_t*)(ws + off);
+    off += ((size_t)n_windows * 4 + 255) / 256 * 256;
+    Q.spill = ws + off;
+    Q.spill_cap16 = (uint32_t)(poa_spill_bytes(n_windows) / 16);
+    off += poa_spill_bytes(n_windows);
+    Q.spill_used = (uint32_t*)(ws + 7872);
+    Q.done = (uint32_t*)(ws + 7808);
+    const ClassScratch scr3{ws + off, groups3_for(n_windows)};
+    off += (size_t)scr3.groups * PoaLayout<PoaClass3>::DIRG_BYTES;
     char* scratch = ws + off;
+    const ClassScratch scr4{scratch, groups4}, scr5{scratch, groups5}, scr_lds{nullptr, 0};
     hipError_t e = hipMemsetAsync(ws, 0, kPoaHeaderBytes, stream);
     if (e != hipSuccess) return e;
+    // class 3 is polled (poa_class_kernel<.., POLL>): its queue slots read "unpublished" until the plan or a re-queue fills them
+    if ((e = hipMemsetAsync(Q.items + (size_t)3 * n_windows, 0xff, (size_t)n_windows * sizeof(uint32_t), stream)) != hipSuccess) return e;
     int pe = 0;
     if (prof) (void)hipEventRecord(prof->ev[0], stream);
     hipLaunchKernelGGL(poa_plan_count_kernel, dim3((n_windows + PLAN_THREADS - 1) / PLAN_THREADS), dim3(PLAN_THREADS), 0, stream, P, Q, n_windows);
@@ -525,14 +640,14 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     if (sequential) {
 #define HYPO_LAUNCH(ID, CFG)                                                                              \
         rec(2 + 2 * ID, stream);                                                                          \
-        if ((e = launch_class<CFG, (ID < kFirstGlobalClass)>(P, Q, ID, ID >= 3 ? rare_grid_hint(ID) : n_windows, scratch, num_cus, \
-                                                             (ID == 4 ? groups4 : groups5), stream)) != hipSuccess) return e; \
+        if ((e = launch_class<CFG, (ID < kFirstGlobalClass)>(P, Q, ID, ID >= 3 ? rare_grid_hint(ID) : n_windows,                   \
+                                                             (ID == 3 ? scr3 : (ID == 4 ? scr4 : (ID == 5 ? scr5 : scr_lds))), num_cus, stream)) != hipSuccess) return e; \
         rec(3 + 2 * ID, stream);
         HYPO_FOR_EACH_CLASS(HYPO_LAUNCH)
 #undef HYPO_LAUNCH
     } else {
         if (!aux[0]) {
-            for (int i = 0; i < 3; ++i) {
+            for (int i = 0; i < 3; ++i) {          // (aux[3] only when a batch needs it, below: a stream that merely exists changes how the others map to hardware queues)
                 if ((e = hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking)) != hipSuccess) return e;
                 if ((e = hipEventCreateWithFlags(&join_ev[i], hipEventDisableTiming)) != hipSuccess) return e;
             }
@@ -548,22 +663,23 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
         (void)hipStreamWaitEvent(aux[0], fork_ev, 0);
         (void)hipStreamWaitEvent(aux[1], fork_ev, 0);
         (void)hipStreamWaitEvent(aux[2], fork_ev, 0);
+        uint32_t producers = 0;                              // lane groups of every launch of classes 0 - 2 (what class 3's polling pass waits for)
         auto first2 = [&]() -> hipError_t {
             rec(2 + 2 * 2, stream);
-            hipError_t r = launch_class<PoaClass2, true>(P, Q, 2, n_windows, scratch, num_cus, 0, stream, caps[2]);
+            hipError_t r = launch_class<PoaClass2, true>(P, Q, 2, n_windows, scr_lds, num_cus, stream, caps[2], false, &producers);
             rec(3 + 2 * 2, stream);
             return r;
         };
         auto first0 = [&]() -> hipError_t {
             rec(2 + 2 * 0, aux[0]);
-            hipError_t r = four_groups ? launch_class<PoaClass0, true>(P, Q, 0, n_windows, scratch, num_cus, 0, aux[0], caps[0])
-                                       : launch_class<PoaClass0W, true>(P, Q, 0, n_windows, scratch, num_cus, 0, aux[0], caps[0]);
+            hipError_t r = four_groups ? launch_class<PoaClass0, true>(P, Q, 0, n_windows, scr_lds, num_cus, aux[0], caps[0], false, &producers)
+                                       : launch_class<PoaClass0W, true>(P, Q, 0, n_windows, scr_lds, num_cus, aux[0], caps[0], false, &producers);
             rec(3 + 2 * 0, aux[0]);
             return r;
         };
         auto first1 = [&]() -> hipError_t {
             rec(2 + 2 * 1, aux[1]);
-            hipError_t r = launch_class<PoaClass1, true>(P, Q, 1, n_windows, scratch, num_cus, 0, aux[1], caps[1]);
+            hipError_t r = launch_class<PoaClass1, true>(P, Q, 1, n_windows, scr_lds, num_cus, aux[1], caps[1], false, &producers);
             rec(3 + 2 * 1, aux[1]);
             return r;
         };
@@ -576,13 +692,8 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
             e = order[i] == '2' ? first2() : (order[i] == '0' ? first0() : first1());
             if (e != hipSuccess) return e;
         }
-        // Mop-up of re-queued windows (normally a handful): a class's mop-up pass only needs its PREDECESSOR to be finished
-        // (its own first pass works on the disjoint slot range [0, planned)), so it runs behind the predecessor on that
-        // stream and hides under the longer first passes instead of forming a serial tail.
-        if ((e = launch_class<PoaClass1, true>(P, Q, 1, late_arrivals(1), scratch, num_cus, 0, aux[0], 4, true)) != hipSuccess) return e;
+        // (Classes 1 and 2 receive no re-queued windows: every SHORT class hands over to class 3, see poa_class_kernel.)
         (void)hipEventRecord(join_ev[0], aux[0]);
-        (void)hipStreamWaitEvent(aux[1], join_ev[0], 0);
-        if ((e = launch_class<PoaClass2, true>(P, Q, 2, late_arrivals(2), scratch, num_cus, 0, aux[1], 6, true)) != hipSuccess) return e;
         (void)hipEventRecord(join_ev[1], aux[1]);
         (void)hipStreamWaitEvent(stream, join_ev[0], 0);
         (void)hipStreamWaitEvent(stream, join_ev[1], 0);
@@ -597,23 +708,55 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
         const bool long_first_pass = planned_host[4] > 0 && planned_host[4] <= (uint32_t)groups4;
         if (long_first_pass) {
             rec(2 + 2 * 4, aux[2]);
-            if ((e = launch_class<PoaClass4, false>(P, Q, 4, planned_host[4], scratch, num_cus, groups4, aux[2], 8)) != hipSuccess) return e;
+            if ((e = launch_class<PoaClass4, false>(P, Q, 4, planned_host[4], scr4, num_cus, aux[2], 8)) != hipSuccess) return e;
             rec(3 + 2 * 4, aux[2]);
             (void)hipEventRecord(join_ev[2], aux[2]);
         }
-        rec(2 + 2 * 3, stream);
-        if ((e = launch_class<PoaClass3, true>(P, Q, 3, rare_grid_hint(3), scratch, num_cus, 0, stream)) != hipSuccess) return e;
-        rec(3 + 2 * 3, stream);
+        // Class 3 (what outgrows class 2, and the wide SHORT windows) runs NEXT to the classes that feed it: a polling launch on a
+        // stream of its own takes the windows the plan put there and every re-queued window as it arrives (with its graph, Poa::
+        // spill), instead of starting when classes 0 - 2 are done — at 0.5 % read error ONE window re-queued into class 3 used to
+        // run 2.7 ms on its own behind 5.2 ms of first passes.  It is submitted after every launch it waits for (see
+        // poa_class_kernel), sized by what the plan and the last call's late arrivals say; HYPO_POA_POLL=0 turns it off.
+        // The regular launch behind the join takes what is left (nothing, unless the polling pass was cut short).
+        // A polling wave holds its 16 KB of LDS while it waits, and the launches it waits for must always find room: at most two
+        // per CU (one unless the last call saw many windows in the class), and a handful of waves when the history says the class
+        // stays empty (HYPO_POA_POLL_WAVES overrides the count).
+        const char* poll_env = getenv("HYPO_POA_POLL");
+        const bool poll3 = !(poll_env && atoi(poll_env) == 0);
+        const uint32_t seen3 = last_count[3];                     // windows class 3 ended up with in the last finished call, scaled
+        uint32_t poll_waves = (seen3 > planned_host[3] ? seen3 : planned_host[3]);
+        poll_waves += poll_waves / 4 + 16;
+        const int poll_cap = poll_waves > 512u ? 2 : 1;
+        if (const char* pw = getenv("HYPO_POA_POLL_WAVES")) poll_waves = (uint32_t)atoi(pw);
+        // its stream: the third side stream, unless the LONG first pass is on it (then a fourth one, created on first use)
+        hipStream_t poll_stream = aux[2];
+        if (long_first_pass) {
+            if (!aux[3]) {
+                if ((e = hipStreamCreateWithFlags(&aux[3], hipStreamNonBlocking)) != hipSuccess) return e;
+                if ((e = hipEventCreateWithFlags(&join_ev[3], hipEventDisableTiming)) != hipSuccess) return e;
+            }
+            (void)hipStreamWaitEvent(aux[3], fork_ev, 0);
+            poll_stream = aux[3];
+        }
+        rec(2 + 2 * 3, poll_stream);
+        if (poll3 && poll_waves > 0) {
+            if ((e = launch_class<PoaClass3, true, true>(P, Q, 3, poll_waves, scr3, num_cus, poll_stream, poll_cap, false, nullptr, producers)) != hipSuccess) return e;
+        }
+        rec(3 + 2 * 3, poll_stream);
+        hipEvent_t& poll_join = long_first_pass ? join_ev[3] : join_ev[2];
+        (void)hipEventRecord(poll_join, poll_stream);
+        (void)hipStreamWaitEvent(stream, poll_join, 0);
+        if ((e = launch_class<PoaClass3, true>(P, Q, 3, rare_grid_hint(3), scr3, num_cus, stream)) != hipSuccess) return e;
         if (long_first_pass) {
             (void)hipStreamWaitEvent(stream, join_ev[2], 0);
-            if ((e = launch_class<PoaClass4, false>(P, Q, 4, late_arrivals(4), scratch, num_cus, groups4, stream, 8, true)) != hipSuccess) return e;
+            if ((e = launch_class<PoaClass4, false>(P, Q, 4, late_arrivals(4), scr4, num_cus, stream, 8, true)) != hipSuccess) return e;
         } else {
             rec(2 + 2 * 4, stream);
-            if ((e = launch_class<PoaClass4, false>(P, Q, 4, rare_grid_hint(4), scratch, num_cus, groups4, stream)) != hipSuccess) return e;
+            if ((e = launch_class<PoaClass4, false>(P, Q, 4, rare_grid_hint(4), scr4, num_cus, stream)) != hipSuccess) return e;
             rec(3 + 2 * 4, stream);
         }
         rec(2 + 2 * 5, stream);
-        if ((e = launch_class<PoaClass5, false>(P, Q, 5, rare_grid_hint(5), scratch, num_cus, groups5, stream)) != hipSuccess) return e;
+        if ((e = launch_class<PoaClass5, false>(P, Q, 5, rare_grid_hint(5), scr5, num_cus, stream)) != hipSuccess) return e;
         rec(3 + 2 * 5, stream);
     }
     // this call's final and planned counts for the next call's grid sizes (no wait: whoever reads them gets the last finished call)
@@ -629,7 +772,7 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
 
 void poa_release(PoaAux* a) {
     if (!a) return;
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 4; ++i) {
         if (a->aux[i]) (void)hipStreamDestroy(a->aux[i]);
         if (a->join_ev[i]) (void)hipEventDestroy(a->join_ev[i]);
     }

@@ -7,6 +7,7 @@ namespace hypo {
 
 constexpr int kFirstGlobalClass = 4;     // classes >= this keep their state in HBM scratch, not LDS
 constexpr int kFirstLongClass = 4;       // LONG windows (<= 500 bp, ~1.3 k nodes) start here
+constexpr int kRequeueClass = 3;         // where a SHORT window goes that outgrows classes 0 - 2 (the class that polls its queue)
 // resident groups of the HBM-scratch classes (one wavefront each; the scratch is provisioned for this many).  The LONG class
 // is register-bound at 2 waves per SIMD: 8 per CU x 256 CUs; the last class is a rare safety net.
 #ifndef HYPO_C4_GROUPS
@@ -20,7 +21,10 @@ inline int max_global_groups(int cls, uint32_t n_windows) {
     return want < cap ? want : cap;
 }
 constexpr int kMinGlobalGroups = 16;     // the smallest scratch poa_run accepts holds this many groups of either HBM-scratch class
-constexpr size_t kPoaHeaderBytes = 8192; // count[8] | head[8] @64 | HypoPoaStats @128 | phase cycles @512 | hist @2048 | start @4096 | cursor @6144 | planned @7680 | head2 @7744
+constexpr size_t kPoaHeaderBytes = 8192; // count[8] | head[8] @64 | HypoPoaStats @128 | phase cycles @512 | hist @2048 | start @4096 | cursor @6144 | planned @7680 | head2 @7744 | done[8] @7808 | spill_used @7872
+// resident groups of class 3 (direction codes in HBM scratch, PoaLayout::DIRG_BYTES each): what 256 CUs hold at 10 waves per CU
+constexpr int kMaxGroups3 = 2560;
+constexpr uint32_t kQueueUnpublished = 0xffffffffu;   // queue slot of a polled class that no producer has filled yet
 
 constexpr int kPlanBuckets = 64;         // cost buckets per class of the plan's counting sort
 
@@ -36,6 +40,13 @@ struct PoaQueues {
     uint16_t* keys;         // [n_windows] class * kPlanBuckets + bucket
     uint32_t* items;        // [classes][stride] window indices, each class ordered by decreasing cost
     uint32_t stride;
+    // re-queued SHORT windows take their graph along (Poa::spill): carry[w] = 1 + offset of the window's spill in `spill`, in
+    // 16-byte units (0 = none: the window starts from its first sequence); spill_used = bump cursor in the same units
+    uint32_t* carry;        // [n_windows]
+    char* spill;
+    uint32_t spill_cap16;   // pool size in 16-byte units
+    uint32_t* spill_used;
+    uint32_t* done;         // [classes] lane groups of class c's kernels that have exited (what a polling kernel waits for)
 };
 
 // optional event recorder: ev[0]/ev[1] around the plan kernels, ev[2+2c]/ev[3+2c] around size-class kernel c
@@ -45,8 +56,8 @@ struct KernelEvents { hipEvent_t ev[16]; int n; };
 // Streams, events and the pinned readback buffer poa_run() needs beyond the caller's stream.  Owned by the library context
 // (capi.hip): created on first use on the current device, released by poa_release() at shutdown / device change.
 struct PoaAux {
-    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t fork_ev = nullptr, join_ev[3] = {nullptr, nullptr, nullptr}, planned_ev = nullptr;
+    hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork_ev = nullptr, join_ev[4] = {nullptr, nullptr, nullptr, nullptr}, planned_ev = nullptr;
     uint32_t* planned_host = nullptr;     // pinned: [0..7] planned counts of the call in flight, [8..15] final counts of the last finished call
     uint32_t last_planned[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // planned counts the previous call worked with
     bool history_valid = false;           // a call has been queued on this context before

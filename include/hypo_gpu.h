@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HYPO_GPU_ABI_VERSION 5
+#define HYPO_GPU_ABI_VERSION 6
 #define HYPO_MAX_DEVICES 16      /* contexts one process can hold (an MI355X node has 8 GPUs) */
 
 /* error codes */
@@ -224,6 +224,7 @@ typedef struct HypoPoaStats {
     uint64_t n_threaded;       /* the sequence spells a path of the graph: one-bit recurrence, no scores */
     uint64_t cells_scored;     /* matrix cells that went through the score rows (windows re-run after an overflow included) */
     uint64_t cells_threaded;   /* matrix cells that went through the one-bit rows (failed attempts included) */
+    uint64_t n_carried;        /* of n_escalated: re-queued together with the graph of the sequences added so far (ABI 6) */
 } HypoPoaStats;
 int hypo_gpu_poa_last_stats(HypoPoaStats* out);
 /* Same for a _device call: synchronises the stream and copies the counters out of `workspace`. */

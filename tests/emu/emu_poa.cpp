@@ -111,13 +111,24 @@ void run_group(Sched& s, int gw, void (*body)(int, void*), void* arg) {
 
 uint64_t g_exact[3] = {0, 0, 0};      // exact-threading attempts / successes / reused alignments since the last emu_exact_stats
 
+// what a re-queued window takes along (Poa::spill), as the kernel's queue entry would
+struct Carry {
+    std::vector<uint8_t> blob;      // empty = the window starts from its first sequence
+    int need_nodes = 0;
+};
+
 template <class Cfg>
 struct Job {
     hypo::EmuGroup eg;
     const hypo::PoaParams* P;
     char* mem;
     char* fast;           // second slice of a hybrid class (PoaLayout::FAST_BYTES)
+    char* dirg;           // direction codes of a Cfg::DIRG class (PoaLayout::DIRG_BYTES)
     uint32_t w;
+    const uint8_t* carry_in;
+    uint8_t* carry_out;   // room for the largest spill of this class
+    uint32_t carry_len;   // 0 = nothing spilled; ~0u = the incoming spill travels on unchanged
+    int need_nodes;
     int rc[64];
     uint64_t cells, aligns;
 };
@@ -126,32 +137,61 @@ template <class Cfg>
 void lane_body(int lane, void* arg) {
     Job<Cfg>* j = (Job<Cfg>*)arg;
     hypo::Grp<Cfg::GW> g{lane, &j->eg};
-    hypo::Poa<Cfg> poa(g, hypo::PoaParamRef{j->P}, j->mem, j->fast);
-    j->rc[lane] = poa.run(j->w);
-    if (lane == 0) { j->cells = poa.cells; j->aligns = poa.aligns; g_exact[0] += poa.exact_tries; g_exact[1] += poa.exact_hits; g_exact[2] += poa.reused; }
+    hypo::Poa<Cfg> poa(g, hypo::PoaParamRef{j->P}, j->mem, j->fast, j->dirg);
+    const int rc = poa.run(j->w, j->carry_in);
+    j->rc[lane] = rc;
+    typedef hypo::Poa<Cfg> PoaT;
+    if (rc == hypo::RES_OVERFLOW && poa.stat_get(PoaT::ST_CKIND) != PoaT::CARRY_NONE) {
+        poa.spill(j->carry_out);                    // every lane writes its share
+        if (lane == 0) j->carry_len = poa.spill_size();
+    } else if (rc == hypo::RES_OVERFLOW && poa.stat_get(PoaT::ST_CPASS) && lane == 0) j->carry_len = ~0u;
+    if (lane == 0) {
+        j->need_nodes = (int)poa.stat_get(PoaT::ST_NEED); j->cells = poa.stat_get(PoaT::ST_CELLS); j->aligns = poa.stat_get(PoaT::ST_ALIGNS);
+        g_exact[0] += poa.exact_tries; g_exact[1] += poa.stat_get(PoaT::ST_XHITS); g_exact[2] += poa.stat_get(PoaT::ST_REUSED);
+    }
+}
+
+// one window through one class; `carry` is consumed and, on RES_OVERFLOW, replaced by what the window takes to the next class
+template <class Cfg>
+int run_window(Sched& s, const hypo::PoaParams& P, uint32_t w, Carry* carry, uint64_t* cells, uint64_t* aligns) {
+    Job<Cfg> job;
+    job.P = &P;
+    job.eg.gw = Cfg::GW; job.eg.yield = yield_cb; job.eg.sched = &s;
+    job.mem = (char*)malloc(hypo::PoaLayout<Cfg>::BYTES);       // exact size: ASan sees overruns
+    // LDS / scratch are not initialised on the device: HYPO_EMU_FILL selects the garbage (default 0xA5; tests also use 0x00 / 0xFF)
+    const int fill = getenv("HYPO_EMU_FILL") ? (int)strtol(getenv("HYPO_EMU_FILL"), nullptr, 0) : 0xA5;
+    memset(job.mem, fill, hypo::PoaLayout<Cfg>::BYTES);
+    job.fast = (char*)malloc(hypo::PoaLayout<Cfg>::FAST_BYTES);
+    memset(job.fast, fill ^ 0xFF, hypo::PoaLayout<Cfg>::FAST_BYTES);
+    job.dirg = (char*)malloc(hypo::PoaLayout<Cfg>::DIRG_BYTES ? hypo::PoaLayout<Cfg>::DIRG_BYTES : 1);
+    memset(job.dirg, fill ^ 0x3C, hypo::PoaLayout<Cfg>::DIRG_BYTES ? hypo::PoaLayout<Cfg>::DIRG_BYTES : 1);
+    const uint32_t cap = hypo::Poa<Cfg>::spill_bytes(Cfg::NMAX, Cfg::KIN);
+    std::vector<uint8_t> out(cap);
+    job.carry_in = (carry && !carry->blob.empty()) ? carry->blob.data() : nullptr;
+    job.carry_out = out.data(); job.carry_len = 0; job.need_nodes = 0;
+    job.w = w; job.cells = job.aligns = 0;
+    run_group(s, Cfg::GW, lane_body<Cfg>, &job);
+    for (int l = 1; l < Cfg::GW; ++l) if (job.rc[l] != job.rc[0]) { fprintf(stderr, "[emu] lanes disagree on the result of window %u\n", w); abort(); }
+    if (carry) {
+        if (job.carry_len == ~0u) { /* keeps its blob */ }
+        else if (job.carry_len) { if (job.carry_len > cap) abort(); carry->blob.assign(out.begin(), out.begin() + job.carry_len); }
+        else carry->blob.clear();
+        carry->need_nodes = job.need_nodes;
+    }
+    *cells += job.cells; *aligns += job.aligns;
+    free(job.mem);
+    free(job.fast);
+    free(job.dirg);
+    return job.rc[0];
 }
 
 template <class Cfg>
 int run_cfg(const hypo::PoaParams& P, uint32_t n_windows, uint8_t* res, uint64_t* cells, uint64_t* aligns) {
     Sched s;
-    Job<Cfg> job;
-    job.P = &P;
-    job.eg.gw = Cfg::GW; job.eg.yield = yield_cb; job.eg.sched = &s;
     for (uint32_t w = 0; w < n_windows; ++w) {
-        job.mem = (char*)malloc(hypo::PoaLayout<Cfg>::BYTES);       // exact size: ASan sees overruns
-        // LDS / scratch are not initialised on the device: HYPO_EMU_FILL selects the garbage (default 0xA5; tests also use 0x00 / 0xFF)
-        const int fill = getenv("HYPO_EMU_FILL") ? (int)strtol(getenv("HYPO_EMU_FILL"), nullptr, 0) : 0xA5;
-        memset(job.mem, fill, hypo::PoaLayout<Cfg>::BYTES);
-        job.fast = (char*)malloc(hypo::PoaLayout<Cfg>::FAST_BYTES);
-        memset(job.fast, fill ^ 0xFF, hypo::PoaLayout<Cfg>::FAST_BYTES);
-        job.w = w; job.cells = job.aligns = 0;
-        run_group(s, Cfg::GW, lane_body<Cfg>, &job);
-        for (int l = 1; l < Cfg::GW; ++l) if (job.rc[l] != job.rc[0]) { fprintf(stderr, "[emu] lanes disagree on the result of window %u\n", w); abort(); }
-        res[w] = (uint8_t)job.rc[0];
-        if (job.rc[0] != hypo::RES_OK) { P.out_len[w] = 0; P.out_status[w] = 0xFF; }
-        *cells += job.cells; *aligns += job.aligns;
-        free(job.mem);
-        free(job.fast);
+        const int rc = run_window<Cfg>(s, P, w, nullptr, cells, aligns);
+        res[w] = (uint8_t)rc;
+        if (rc != hypo::RES_OK) { P.out_len[w] = 0; P.out_status[w] = 0xFF; }
     }
     free(s.stacks);
     return 0;
@@ -179,6 +219,55 @@ extern "C" int emu_poa_batch(const HypoScoreParams* sp, const HypoWindowBatch* i
 #undef HYPO_CLASS_CASE
         default: return -1;
     }
+}
+
+// The kernel's re-queue chain on the CPU: every window starts in class `cfg_from`; a window that answers RES_OVERFLOW /
+// RES_UNSUPPORTED moves to the class poa_class_kernel would pick (the next one, or the first later SHORT class whose node table
+// holds what it projects to need) and takes its spill along.  hops[w] = classes visited, carried[w] = hops that started from a spill.
+extern "C" int emu_poa_chain(const HypoScoreParams* sp, const HypoWindowBatch* in, HypoConsensusBatch* out,
+                             int cfg_from, uint8_t* res, uint8_t* hops, uint8_t* carried, int use_carry) {
+    hypo::PoaParams P;
+    P.windows = in->windows; P.draft4 = in->draft4; P.arm_off = in->arm_off; P.arm_len = in->arm_len; P.arms2 = in->arms2;
+    P.out_bases = out->bases; P.out_off = out->off; P.out_len = out->len; P.out_status = out->status;
+    P.sr_m = sp->sr_match; P.sr_n = sp->sr_mismatch; P.sr_g = sp->sr_gap;
+    P.lr_m = sp->lr_match; P.lr_n = sp->lr_mismatch; P.lr_g = sp->lr_gap;
+    P.n_arms = in->n_arms; P.draft4_bytes = in->draft4_bytes; P.arms2_bytes = in->arms2_bytes;
+    P.flags = getenv("HYPO_EMU_NATIVE_KLOV") ? hypo::POA_NATIVE_KLOV : 0;
+    constexpr int nmax[hypo::kNumPoaClasses] = {
+#define HYPO_NMAX(ID, CFG) hypo::CFG::NMAX,
+        HYPO_FOR_EACH_CLASS(HYPO_NMAX)
+#undef HYPO_NMAX
+    };
+    constexpr int kFirstLong = 4, kRequeue = 3;           // poa_kernel.hpp: kFirstLongClass, kRequeueClass
+    Sched s;
+    uint64_t cells = 0, aligns = 0;
+    for (uint32_t w = 0; w < in->n_windows; ++w) {
+        Carry carry;
+        int cls = cfg_from, rc = hypo::RES_OVERFLOW;
+        hops[w] = 0; carried[w] = 0;
+        for (;;) {
+            if (!carry.blob.empty()) carried[w] += 1;
+            hops[w] += 1;
+            switch (cls) {
+#define HYPO_CLASS_CASE(ID, CFG) case ID: rc = run_window<hypo::CFG>(s, P, w, &carry, &cells, &aligns); break;
+                HYPO_FOR_EACH_CLASS(HYPO_CLASS_CASE)
+#undef HYPO_CLASS_CASE
+                default: return -1;
+            }
+            if (!use_carry) carry.blob.clear();
+            if ((rc == hypo::RES_OVERFLOW || rc == hypo::RES_UNSUPPORTED) && cls + 1 < hypo::kNumPoaClasses) {
+                int to = cls < kRequeue ? kRequeue : cls + 1;
+                if (rc == hypo::RES_OVERFLOW && carry.need_nodes > 0) while (to + 1 < hypo::kNumPoaClasses && to < kFirstLong && nmax[to] < carry.need_nodes) ++to;
+                cls = to;
+                continue;
+            }
+            break;
+        }
+        res[w] = (uint8_t)rc;
+        if (rc != hypo::RES_OK) { P.out_len[w] = 0; P.out_status[w] = 0xFF; }
+    }
+    free(s.stacks);
+    return 0;
 }
 
 extern "C" void emu_exact_stats(uint64_t* out) { for (int i = 0; i < 3; ++i) { out[i] = g_exact[i]; g_exact[i] = 0; } }

@@ -48,3 +48,27 @@ class Emu:
         cons = [bases[int(off[i]):int(off[i]) + int(ln[i])].tobytes().decode()
                 if (res[i] == RES_OK and st[i] == 0) else None for i in range(n)]
         return cons, st, res, int(cells.value), int(aligns.value)
+
+    def poa_chain(self, b, cfg_from, scores=abi.DEFAULT_SCORES, off=None, use_carry=True):
+        """Every window starts in class cfg_from and follows the kernel's re-queue chain (emu_poa_chain), taking its graph along
+        when use_carry.  Returns (consensus strings, result codes, classes visited, hops that started from a spill)."""
+        sp = abi.ScoreParams(*scores)
+        if off is None:
+            off = b.slot_layout()
+        n = b.n_windows
+        bases = np.zeros(int(off[-1]) + 1, dtype=np.uint8)
+        ln = np.zeros(n, dtype=np.uint32)
+        st = np.zeros(n, dtype=np.uint8)
+        res = np.zeros(n, dtype=np.uint8)
+        hops = np.zeros(n, dtype=np.uint8)
+        carried = np.zeros(n, dtype=np.uint8)
+        ins = _oracle.batch_struct(b)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        out = abi.ConsensusBatch(p(bases), p(off), p(ln), p(st))
+        self.lib.emu_poa_chain.restype = C.c_int
+        rc = self.lib.emu_poa_chain(C.byref(sp), C.byref(ins), C.byref(out), C.c_int(cfg_from), p(res), p(hops), p(carried),
+                                    C.c_int(1 if use_carry else 0))
+        assert rc == 0
+        cons = [bases[int(off[i]):int(off[i]) + int(ln[i])].tobytes().decode()
+                if (res[i] == RES_OK and st[i] == 0) else None for i in range(n)]
+        return cons, res, hops, carried

@@ -122,3 +122,51 @@ def test_class4_long_windows_lazy_rank_order_vs_oracle():
             assert res[i] == emu_util.RES_OK and cons[i] == want[i], i
             n += 1
     assert n >= 100
+
+
+def _requeue_cases(small):
+    from hypo_amd import sim
+    n = 40 if small else 200
+    return [(0, sim.window_batch(n, seed=21, read_sub=0.03)), (0, sim.window_batch(n, seed=22, read_sub=0.06)),
+            (1, sim.window_batch(n, seed=23, read_sub=0.05)), (2, sim.window_batch(n * 3 // 4, seed=24, read_sub=0.05)),
+            (0, sim.grid_batch(45, 40, 12 if small else 40, 0.08, seed=8)), (2, sim.grid_batch(120, 60, 6 if small else 20, 0.06, seed=9))]
+
+
+def _requeue_check(asan):
+    import oracle
+    orc = oracle.Oracle()
+    e = emu_util.Emu(asan=asan)
+    n_carried = 0
+    for cfg, b in _requeue_cases(asan):
+        want = orc.poa_batch(b)[0]
+        cons, res, hops, carried = e.poa_chain(b, cfg)
+        for i in range(b.n_windows):
+            assert res[i] == emu_util.RES_OK and cons[i] == want[i], (cfg, i, int(hops[i]), int(carried[i]))
+        n_carried += int((carried > 0).sum())
+        if not asan:
+            cons0, res0, _, carried0 = e.poa_chain(b, cfg, use_carry=False)
+            assert int(carried0.sum()) == 0 and cons0 == cons
+    assert n_carried > (20 if asan else 100)
+    return n_carried
+
+
+def test_requeue_chain_carries_the_graph():
+    """A SHORT window that outgrows its class is re-queued to class 3 together with the graph of the sequences added so far
+    (Poa::spill / Poa::restore, poa_class_kernel's account()): the kernel's chain on the CPU, noisy batches started in every LDS
+    class, against the oracle — with the spill and, for comparison, with every window starting over as before round 3."""
+    _requeue_check(False)
+
+
+def test_requeue_chain_under_asan():
+    """The same chain (smaller batches) with the AddressSanitizer build of the emulator: spill and restore stay inside the
+    group's slice and the spill buffer (run in a child process: the sanitizer runtime has to be loaded first)."""
+    import os
+    import subprocess
+    import sys
+    emu_util.build()
+    libasan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:verify_asan_link_order=0")
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = "import sys; sys.path[:0] = [%r, %r]; import test_poa_emulator as t; print('carried', t._requeue_check(True))" % (os.path.dirname(here), here)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "carried" in p.stdout, (p.stdout[-400:], p.stderr[-1200:])
