@@ -13,7 +13,7 @@ bool DeviceArms::build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c
                        std::vector<std::vector<std::unique_ptr<Alignment>>>& store, unsigned k) {
     _active = false;
     wait_released();
-    if (hypo_gpu_num_devices() != 1) return false;
+    if (hypo_gpu_use_device(_slot) != HYPO_OK) return false;
     const bool timing = std::getenv("HYPO_HOST_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
@@ -160,9 +160,10 @@ void DeviceArms::adopt_arms(const std::vector<uint32_t>& which, const std::vecto
     }
 }
 
-int DeviceArms::polish(const ScoreParams& sp, bool keep_arms) {
+int DeviceArms::polish(const ScoreParams& sp, bool keep_arms, std::vector<Window*>* retry) {
     if (!_active) return HYPO_OK;
     _active = false;
+    if (hypo_gpu_use_device(_slot) != HYPO_OK) return HYPO_E_INVALID;
     const uint32_t n = _sum.n_windows;
     if (!n) return HYPO_OK;
     const auto tp = std::chrono::steady_clock::now();
@@ -191,7 +192,8 @@ int DeviceArms::polish(const ScoreParams& sp, bool keep_arms) {
     if (!again.empty()) {          // a consensus longer than its slot, a window beyond the size classes: the host's retry / degraded path
         std::vector<Window*> ws;
         for (uint32_t i : again) ws.push_back(_reg_window[win_region[i]]);
-        rc = Window::generate_consensus_batch(ws);
+        if (retry) retry->insert(retry->end(), ws.begin(), ws.end());
+        else rc = Window::generate_consensus_batch(ws);
     }
     return rc;
 }

@@ -14,7 +14,9 @@ namespace hypo {
 
 class DeviceArms {
 public:
-    DeviceArms() = default;
+    // slot: the device context (index into the device list of hypo_gpu_init) this object's batches live on; with several
+    // devices the contigs of a batch are dealt out to one DeviceArms per context (Hypo::polish)
+    explicit DeviceArms(int slot = 0) : _slot(slot) {}
     DeviceArms(const DeviceArms&) = delete;
     DeviceArms& operator=(const DeviceArms&) = delete;
     ~DeviceArms() { wait_released(); }
@@ -24,11 +26,15 @@ public:
     bool build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1,
                std::vector<std::vector<std::unique_ptr<Alignment>>>& store, unsigned k);
     bool active() const { return _active; }
-    // consensus of every SHORT window of the resident batch; `keep_arms`: also copy the arms into the Window objects
-    int polish(const ScoreParams& sp, bool keep_arms);
+    // consensus of every SHORT window of the resident batch; `keep_arms`: also copy the arms into the Window objects.  Windows
+    // whose status asks for the host's retry / degraded path (a consensus longer than its slot, a window beyond the size classes)
+    // get their arms and are appended to `retry` (the caller runs Window::generate_consensus_batch on them: one call for all
+    // contexts); retry == nullptr: done here.  May be called from a thread of its own per context.
+    int polish(const ScoreParams& sp, bool keep_arms, std::vector<Window*>* retry = nullptr);
     uint64_t num_windows() const { return _sum.n_windows; }
 
 private:
+    int _slot = 0;
     bool _active = false;
     HypoArmsSummary _sum{};
     std::vector<std::vector<std::unique_ptr<Alignment>>> _spent;   // the alignments of the batch, on their way out

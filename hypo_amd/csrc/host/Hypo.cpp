@@ -82,7 +82,10 @@ void Hypo::polish() {
     std::ofstream dump;
     if (!_region_dump.empty()) dump.open(_region_dump);
 
-    DeviceArms device_arms;                                   // outlives the batches: spent alignments are released behind the phases that follow
+    // one per device context (they outlive the batches: spent alignments are released behind the phases that follow)
+    const int n_ctx = std::max(1, hypo_gpu_num_devices());
+    std::vector<std::unique_ptr<DeviceArms>> device_arms;
+    for (int d = 0; d < n_ctx; ++d) device_arms.emplace_back(new DeviceArms(d));
     for (uint32_t batch_id = 0; batch_id < num_batches; ++batch_id) {
         std::fprintf(stdout, "********** [Hypo::Hypo] Info: BATCH-ID: %u\n", batch_id);
         const uint32_t initial_cid = batch_id * _contig_batch_size;
@@ -124,20 +127,46 @@ void Hypo::polish() {
         start();
         // The device cuts the reads into arms, prunes the windows and keeps the window batch in its memory (DeviceArms.hpp);
         // --host-arms, several devices or an unsorted alignment file take the host loops of the reference instead.
-        device_arms.wait_released();                          // (the previous batch's alignments, still on their way out)
-        const bool on_device = !_cFlags.host_arms && device_arms.build(_contigs, initial_cid, final_cid, _alignment_store, _cFlags.k);
-        if (!on_device)
-            for (uint32_t cid = initial_cid; cid < final_cid; ++cid) {
-                auto& alns = _alignment_store[cid];
-#pragma omp parallel for
-                for (int64_t t = 0; t < (int64_t)alns.size(); ++t) alns[(size_t)t]->find_short_arms(_cFlags.k, *_contigs[cid]);
+        // With several devices the contigs of the batch are dealt out to the contexts in contiguous ranges of about equal
+        // numbers of alignments (a batch with fewer contigs than devices stays on the first one): every context cuts the arms of
+        // its contigs and polishes its own resident windows, no window travels between devices.
+        for (auto& da : device_arms) da->wait_released();      // (the previous batch's alignments, still on their way out)
+        std::vector<char> on_dev(final_cid - initial_cid, 0);  // per contig of the batch: its short arms were cut on a device
+        std::vector<uint32_t> ctx_cut((size_t)n_ctx + 1, final_cid);
+        ctx_cut[0] = initial_cid;
+        if (!_cFlags.host_arms) {
+            if ((uint32_t)n_ctx > 1 && final_cid - initial_cid >= (uint32_t)n_ctx) {
+                uint64_t total = 0, acc = 0;
+                for (uint32_t c = initial_cid; c < final_cid; ++c) total += _alignment_store[c].size() + 1;
+                int d = 1;
+                for (uint32_t c = initial_cid; c < final_cid && d < n_ctx; ++c) {
+                    acc += _alignment_store[c].size() + 1;
+                    // the cut behind contig c belongs to context d when the first d shares are full (every context gets >= 1 contig)
+                    while (d < n_ctx && acc * (uint64_t)n_ctx >= total * (uint64_t)d && final_cid - (c + 1) >= (uint32_t)(n_ctx - d)) ctx_cut[(size_t)d++] = c + 1;
+                }
+                for (; d < n_ctx; ++d) ctx_cut[(size_t)d] = std::max(ctx_cut[(size_t)d - 1] + 1, final_cid - (uint32_t)(n_ctx - d));
             }
+            for (int d = 0; d < n_ctx; ++d) {
+                const uint32_t c0 = ctx_cut[(size_t)d], c1 = ctx_cut[(size_t)d + 1];
+                if (c0 >= c1) continue;
+                if (device_arms[(size_t)d]->build(_contigs, c0, c1, _alignment_store, _cFlags.k))
+                    for (uint32_t c = c0; c < c1; ++c) on_dev[c - initial_cid] = 1;
+            }
+            hypo_gpu_use_device(0);
+        }
+        for (uint32_t cid = initial_cid; cid < final_cid; ++cid) {
+            if (on_dev[cid - initial_cid]) continue;
+            auto& alns = _alignment_store[cid];
+#pragma omp parallel for
+            for (int64_t t = 0; t < (int64_t)alns.size(); ++t) alns[(size_t)t]->find_short_arms(_cFlags.k, *_contigs[cid]);
+        }
         stop("[Hypo:Hypo]: Short arms computing. ");
         start();
         // few contigs: the parallelism is inside a contig (window ranges); many contigs: one contig per thread as in the reference
-        if (!on_device) {
 #pragma omp parallel for schedule(static, 1) if (over_contigs)
-            for (int64_t i = initial_cid; i < (int64_t)final_cid; ++i) { _contigs[(size_t)i]->fill_short_windows(_alignment_store[(size_t)i]); _alignment_store[(size_t)i].clear(); }
+        for (int64_t i = initial_cid; i < (int64_t)final_cid; ++i) {
+            if (on_dev[(size_t)i - initial_cid]) continue;
+            _contigs[(size_t)i]->fill_short_windows(_alignment_store[(size_t)i]); _alignment_store[(size_t)i].clear();
         }
         stop("[Hypo:Hypo]: Short arms filling. ");
 
@@ -166,9 +195,29 @@ void Hypo::polish() {
         std::vector<Window*> wins;
         for (uint32_t i = initial_cid; i < final_cid; ++i)
             for (uint64_t w = 0; w < _contigs[i]->get_num_regions(); ++w)
-                if (_contigs[i]->is_valid_window((uint32_t)w) && !(on_device && !_contigs[i]->window((uint32_t)w)->is_long())) wins.push_back(_contigs[i]->window((uint32_t)w));
-        const uint64_t n_resident = on_device ? device_arms.num_windows() : 0;
-        if (device_arms.polish(_cFlags.score_params, dump.is_open()) != HYPO_OK) { std::fprintf(stderr, "[Hypo::Window] Error: %s\n", hypo_gpu_last_error()); std::exit(1); }
+                if (_contigs[i]->is_valid_window((uint32_t)w) && !(on_dev[i - initial_cid] && !_contigs[i]->window((uint32_t)w)->is_long())) wins.push_back(_contigs[i]->window((uint32_t)w));
+        uint64_t n_resident = 0;
+        {   // the resident batches: every context polishes its own, side by side; what needs the host's retry path joins `wins`
+            std::vector<std::vector<Window*>> retry((size_t)n_ctx);
+            std::vector<int> prc((size_t)n_ctx, HYPO_OK);
+            std::vector<std::string> perr((size_t)n_ctx);
+            std::vector<std::thread> th;
+            for (int d = 0; d < n_ctx; ++d) {
+                if (!device_arms[(size_t)d]->active()) continue;
+                n_resident += device_arms[(size_t)d]->num_windows();
+                auto work = [&, d] {
+                    prc[(size_t)d] = device_arms[(size_t)d]->polish(_cFlags.score_params, dump.is_open(), &retry[(size_t)d]);
+                    if (prc[(size_t)d] != HYPO_OK) perr[(size_t)d] = hypo_gpu_last_error();
+                };
+                if (n_ctx == 1) work(); else th.emplace_back(work);
+            }
+            for (auto& t : th) t.join();
+            hypo_gpu_use_device(0);
+            for (int d = 0; d < n_ctx; ++d) {
+                if (prc[(size_t)d] != HYPO_OK) { std::fprintf(stderr, "[Hypo::Window] Error: %s\n", perr[(size_t)d].c_str()); std::exit(1); }
+                wins.insert(wins.end(), retry[(size_t)d].begin(), retry[(size_t)d].end());
+            }
+        }
         if (Window::generate_consensus_batch(wins) != HYPO_OK) { std::fprintf(stderr, "[Hypo::Window] Error: %s\n", hypo_gpu_last_error()); std::exit(1); }
         std::fprintf(stdout, "[Hypo::Hypo] Info: polished windows (Batch %u): %lu\n", batch_id, (unsigned long)(wins.size() + n_resident));
         stop("[Hypo:Hypo]: POA of windows. ");
@@ -199,7 +248,7 @@ void Hypo::polish() {
     for (auto& c : _contigs) ofile << *c;
     ofile.close();
     stop("[Hypo:Hypo]: Writing results. ");
-    device_arms.wait_released();                              // inside the Overall timer, like the reference's own clear() of its alignment store
+    for (auto& da : device_arms) da->wait_released();      // inside the Overall timer, like the reference's own clear() of its alignment store
     _times.overall = std::chrono::duration<double>(std::chrono::steady_clock::now() - _tstart).count();
     std::fprintf(stdout, "RESOURCES ([Hypo:Hypo]: Overall. ): TIME= %g sec.\n", _times.overall);
     _contigs.clear();

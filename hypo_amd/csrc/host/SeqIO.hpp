@@ -108,7 +108,18 @@ public:
     bool mapped() const { return _map != nullptr && _map[_map_len - 1] == '\n'; }   // (in-place parsing wants every record terminated)
     const char* unread() const { return _src + _pos; }
     size_t unread_bytes() const { return _end - _pos; }
-    void consume(size_t n) { _pos += n; }
+    void consume(size_t n) {
+        _pos += n;
+        // a mapped file: pages far behind the read position are handed back (every record in flight — the block being parsed and
+        // the one read ahead, 32 MB each at most — lies within the last 256 MB), so that a 4 GB alignment file does not sit in
+        // the process's resident set
+        constexpr size_t kKeep = (size_t)256 << 20, kStep = (size_t)64 << 20;
+        if (_map && _pos > kKeep && _pos - kKeep >= _released + kStep) {
+            const size_t upto = (_pos - kKeep) & ~(size_t)4095;
+            (void)::madvise((void*)(_map + _released), upto - _released, MADV_DONTNEED);
+            _released = upto;
+        }
+    }
     // first bytes of the stream without consuming them (used once, right after opening)
     bool starts_with(const char* magic, size_t n) {
         if (_pos == _end && !_eof && _fp) {
@@ -121,7 +132,7 @@ private:
     static constexpr size_t kBuf = 4u << 20;
     gzFile _fp = nullptr;
     std::vector<char> _buf;
-    const char* _map = nullptr; size_t _map_len = 0;
+    const char* _map = nullptr; size_t _map_len = 0, _released = 0;
     const char* _src = nullptr;                        // the bytes being consumed: _buf or the mapping
     size_t _pos = 0, _end = 0;
     bool _eof = false;

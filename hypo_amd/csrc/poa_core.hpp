@@ -45,7 +45,7 @@
 
 namespace hypo {
 
-enum { MODE_NW = 1, MODE_LOV = 3, MODE_ROV = 4 };
+enum { MODE_NW = 1, MODE_LOV = 3, MODE_ROV = 4, MODE_SEEN = 0x100 /* flag beside the mode: sequence table bit 14 */ };
 enum { C_A = 0, C_C = 1, C_G = 2, C_T = 3, C_N = 4, C_J = 5, C_O = 6, C_NONE = 7 };
 // Optional per-phase cycle accounting (diagnostic build only: make -C hypo_amd/csrc prof).
 enum { PH_LOAD = 0, PH_DP = 1, PH_TRACE = 2, PH_ADD = 3, PH_TOPO = 4, PH_CONS = 5, PH_OUT = 6, PH_META = 7, PH_EXACT = 8, PH_N = 9 };
@@ -160,7 +160,7 @@ struct PoaCfg {
     typedef typename std::conditional<(SEQMAX_ <= 127), uint8_t, uint16_t>::type wt_t;
     static constexpr int ID_NONE = (IdT)~(IdT)0;
     static_assert(LCAP_ <= GW_ * CPL_ - 1, "columns 0..L must fit the group");
-    static_assert(LCAP_ <= 1023 && ARMBYTES_ <= 32767 && SEQMAX_ <= 32767, "sequence table entry is 32 bits");
+    static_assert(LCAP_ <= 1023 && ARMBYTES_ <= 16384 && SEQMAX_ <= 16383, "sequence table entry is 32 bits");
     static_assert(KIN_ + 6 <= GW_, "dependency lanes");
     static_assert(KIN_ <= 62, "direction byte holds the pred index in 6 bits");
     static constexpr int DIRBYTES_LDS = DIRG_ ? 0 : DIRBYTES;      // what the direction codes take of the group's own slice
@@ -224,7 +224,7 @@ struct PoaLayout {   // byte offsets inside a group's memory slice
     // rarely touched group-uniform scalars (Poa::stat): per-window counters, what a re-queued window takes along, and the
     // per-wave totals of the kernel.  In registers they were live across the whole window — a vector register each in the
     // sub-wave classes, spilled scalars in the others; here they cost an LDS access where they change.
-    static constexpr int STAT_BYTES = 96;
+    static constexpr int STAT_BYTES = 112;
     static constexpr int oStat = oNewSlot + align_up<16>(LAZYL * 2);
     static constexpr int BYTES = oStat + STAT_BYTES;
     // Hybrid classes (Cfg::HYBRID) keep everything above in HBM scratch except what the topological sort and the graph update
@@ -265,12 +265,13 @@ struct Poa {
     static constexpr int pow2_of(int x) { return x & -x; }
     struct alignas(pow2_of((int)sizeof(score_t) * CPL)) Pack { score_t v[CPL]; };
     struct alignas(pow2_of(NIB ? CPL / 2 : CPL)) DPack { uint8_t v[NIB ? CPL / 2 : CPL]; };
-    // sequence table entry: bits 0-14 src (LDS offset of the staged bytes, or arm index), 15 "byte-identical to
+    // sequence table entry: bits 0-13 src (LDS offset of the staged bytes, or arm index), 14 "an earlier sequence of the window
+    // has the same bytes, length, markers and mode" (a hint, from a hash: such a sequence spells a path of the graph), 15 "byte-identical to
     // the previous entry" (set for staged arms only), 16-25 length, 26 head marker J, 27 tail marker O,
     // 28-29 mode (0 NW, 1 LOV, 2 ROV), 30-31 where (0 staged in LDS, 1 arms2 in HBM, 2 draft4 in HBM: 4-bit packed)
     HD static uint32_t seq_ent(uint32_t src, uint32_t len, bool head, bool tail, int mode, bool /*four*/, int where) {
         const uint32_t mc = mode == MODE_NW ? 0u : (mode == MODE_LOV ? 1u : 2u);
-        return (src & 0x7fffu) | (len << 16) | ((head ? 1u : 0u) << 26) | ((tail ? 1u : 0u) << 27) | (mc << 28) |
+        return (src & 0x3fffu) | (len << 16) | ((head ? 1u : 0u) << 26) | ((tail ? 1u : 0u) << 27) | (mc << 28) |
                ((uint32_t)where << 30);
     }
 
@@ -286,7 +287,7 @@ struct Poa {
     bool lazy_on; int n_new;                                 // lazy_on: this window keeps its order lazily (LONG windows); n_new: new nodes of the alignment in hand
     int n_paths, path_used, head_first;
     // group-uniform state
-    int n_nodes; int L; bool topo_dirty; bool meta_dirty; int maxdelta; int last_source;
+    int n_nodes; int L; bool topo_dirty; bool meta_dirty;
     int tb_steps; int tb_fv;
     bool last_changed;         // did the most recent add_alignment change the graph topology?
     // Group-uniform scalars that change rarely live in a small block of the group's LDS slice (PoaLayout::oStat) instead of
@@ -303,7 +304,8 @@ struct Poa {
     //   ACC_*                  per-wave totals of poa_class_kernel (LDS classes)
     enum { ST_CELLS = 0, ST_ALIGNS, ST_REUSED, ST_XHITS, ST_CSCORED, ST_CEXACT, ST_XT, ST_XH, ST_NEED, ST_CKIND, ST_CS, ST_CCHAIN0, ST_CPASS, ST_N,
            ST_LASTX = ST_CPASS,   // while a window runs: did its latest alignment thread?  (ST_CPASS is written after the window's last step only)
-           ACC_CELLS = ST_N, ACC_ALIGNS, ACC_ABYTES, ACC_REUSED, ACC_THR, ACC_CSCORED, ACC_CTHR, ACC_NOK, ACC_NESC, ACC_NFAIL, ACC_NCARRIED, ACC_END };
+           ST_MAXD = ST_N, ST_LSRC,   // of the rank order in hand (Poa::build_rowmeta): ring rows the furthest predecessor needs; last rank without in-edges
+           ACC_CELLS, ACC_ALIGNS, ACC_ABYTES, ACC_REUSED, ACC_THR, ACC_CSCORED, ACC_CTHR, ACC_NOK, ACC_NESC, ACC_NFAIL, ACC_NCARRIED, ACC_END };
     static_assert(ACC_END <= Lay::STAT_BYTES / 4 && ST_N <= GW, "stat block");
     enum { CARRY_NONE = 0, CARRY_BEFORE = 1, CARRY_UNSORTED = 2 };
     static constexpr int RES_OVERFLOW_CLEAN = 64;            // add_alignment: RES_OVERFLOW before anything was changed (internal)
@@ -344,7 +346,7 @@ struct Poa {
         for (int t = g.lane; t < Lay::STAT_BYTES / 4; t += GW) stat[t] = 0;
         ring1 = (score_t*)(HYB ? fast + Lay::fRing1 : mem + Lay::oRing);
         n_paths = 0; path_used = 0; head_first = 0;
-        n_nodes = 0; L = 0; topo_dirty = false; meta_dirty = true; maxdelta = 0; last_source = 0; tb_steps = 0; tb_fv = 0;
+        n_nodes = 0; L = 0; topo_dirty = false; meta_dirty = true; tb_steps = 0; tb_fv = 0;
         last_changed = true;
         HYPO_DIAG(rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; rows_exact_n = 0; rows_scored_n = 0; topo_dfs = 0; topo_fast = 0);
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
@@ -389,7 +391,7 @@ struct Poa {
                 const int nb = (int)(((e >> 16) & 0x3ff) + 3) >> 2;
                 if (used + nb <= Cfg::ARMBYTES) {
                     // keep the arm index in posnode-free scratch: staged entries remember it via `stack`
-                    stack[t] = (id_t)(e & 0x7fff);
+                    stack[t] = (id_t)(e & 0x3fff);
                     seqtab[base + t] = (e & 0x3fff0000u) | (uint32_t)used;        // where = 0 (bits 30-31 cleared)
                     used += nb;
                 }
@@ -401,7 +403,7 @@ struct Poa {
             if ((e >> 30) == 0) {
                 const int nb = (int)(((e >> 16) & 0x3ff) + 3) >> 2;
                 const uint8_t* src = P->arms2 + P->arm_off[a0 + (uint32_t)stack[t]];
-                uint8_t* dst = armbuf + (e & 0x7fff);
+                uint8_t* dst = armbuf + (e & 0x3fff);
                 for (int b = 0; b < nb; ++b) dst[b] = src[b];
             }
         }
@@ -411,14 +413,44 @@ struct Poa {
             const uint32_t a = seqtab[base + t], b = seqtab[base + t - 1];
             if (((a ^ b) & 0xffff0000u) == 0 && (a >> 30) == 0) {
                 const int nb = (int)(((a >> 16) & 0x3ff) + 3) >> 2;
-                const uint8_t* pa = armbuf + (a & 0x7fff);
-                const uint8_t* pb = armbuf + (b & 0x7fff);
+                const uint8_t* pa = armbuf + (a & 0x3fff);
+                const uint8_t* pb = armbuf + (b & 0x3fff);
                 bool same = true;
                 for (int k = 0; k < nb; ++k) same &= pa[k] == pb[k];
                 if (same) seqtab[base + t] = a | 0x8000u;
             }
         }
         g.sync();
+        if constexpr (PK) {
+            // ... and arms that repeat ANY earlier arm of the window (not only their neighbour): a hash per staged arm, parked in
+            // the ring (idle until the first alignment), every lane looks its arm up among the earlier ones.  Such an arm spells
+            // the path the earlier copy was threaded along or created, so threading it cannot fail (Poa::align attempts it whatever
+            // the hit rate of the window's other arms is); a hash collision only costs a wasted attempt.
+            uint32_t* const hs = (uint32_t*)ring;
+            static_assert((int)sizeof(score_t) * Cfg::RINGCELLS >= 4 * Cfg::SEQMAX, "arm hashes fit the ring");
+            for (int t = g.lane; t < narm; t += GW) {
+                const uint32_t e = seqtab[base + t];
+                uint32_t h = 0;
+                if ((e >> 30) == 0 && ((e >> 16) & 0x3ff) != 0) {
+                    const int nb = (int)(((e >> 16) & 0x3ff) + 3) >> 2;
+                    const uint8_t* pa = armbuf + (e & 0x3fff);
+                    h = 2166136261u ^ (e & 0x3fff0000u);
+                    HYPO_NOUNROLL
+                    for (int k = 0; k < nb; ++k) h = (h ^ pa[k]) * 16777619u;
+                    h |= 1u;
+                }
+                hs[t] = h;
+            }
+            g.sync();
+            for (int t = g.lane; t < narm; t += GW) {
+                const uint32_t h = hs[t];
+                bool seen = false;
+                HYPO_NOUNROLL
+                for (int u = 0; u < t; ++u) seen |= hs[u] == h;
+                if (seen && h) seqtab[base + t] |= 0x4000u;
+            }
+            g.sync();
+        }
         *n_seq_out = narm + base;
         *added_out = any_len;
         return RES_OK;
@@ -429,14 +461,14 @@ struct Poa {
         const bool head = (e >> 26) & 1, tail = (e >> 27) & 1;
         const int mc = (int)((e >> 28) & 3), where = (int)(e >> 30);
         const bool four = where == 2;
-        *mode_out = mc == 0 ? MODE_NW : (mc == 1 ? MODE_LOV : MODE_ROV);
+        *mode_out = (mc == 0 ? MODE_NW : (mc == 1 ? MODE_LOV : MODE_ROV)) | ((e & 0x4000u) ? (int)MODE_SEEN : 0);
         const int len = (int)((e >> 16) & 0x3ff);
         if (len == 0) { L = 0; return RES_OK; }
         L = g.uniform(len + (head ? 1 : 0) + (tail ? 1 : 0));   // group-uniform by construction; tells the compiler (scalar control flow for 64-lane groups)
         if (L > Cfg::LMAX) return RES_OVERFLOW;
         const uint8_t* p;
-        if (where == 0) p = armbuf + (e & 0x7fff);
-        else if (where == 1) p = P->arms2 + P->arm_off[W.first_arm + (e & 0x7fff)];
+        if (where == 0) p = armbuf + (e & 0x3fff);
+        else if (where == 1) p = P->arms2 + P->arm_off[W.first_arm + (e & 0x3fff)];
         else p = P->draft4 + W.draft_off;
         for (int t = g.lane; t < L; t += GW) {
             int c;
@@ -537,15 +569,16 @@ struct Poa {
                 if (b0 > RING_BACK_MAX || b1 > RING_BACK_MAX) mds = 1 << 20;       // does not fit the fields: the window moves up a class
                 else rowmeta[r] |= meta_backs(b0, b1);
             }
-            maxdelta = g.reduce_max(mds);
+            stat_set(ST_MAXD, (uint32_t)g.reduce_max(mds));
             // last rank without in-edges: behind it no new perfect path can start in kNW / kLOV (Poa::rows_exact_runs gives up early)
             int ls = -1;
             for (int r = g.lane; r < n_nodes; r += GW) if (meta_k(rowmeta[r]) == 0) ls = r;
-            last_source = g.reduce_max(ls);
+            stat_set(ST_LSRC, (uint32_t)g.reduce_max(ls));
             g.sync();
             return;
         }
-        maxdelta = g.reduce_max(md);
+        const int maxdelta = g.reduce_max(md);
+        stat_set(ST_MAXD, (uint32_t)maxdelta);
         g.sync();
         if (Cfg::RING1 > 0 && maxdelta > Cfg::RING1) {
             // hybrid classes: only rows that some later row reads from further back than the LDS ring reaches go to the HBM ring
@@ -1126,7 +1159,7 @@ struct Poa {
                 g.sync();
                 // Nothing perfect is left (no cell in this row, none in a ring row a later row could still read) and no path can
                 // start further down (kNW / kLOV start at nodes without in-edges only): the sequence spells no path.
-                if (!rov && r > last_source && nzsaved == 0 && !g.any(any)) return (int)first;      // (kLOV may have met its end cell already)
+                if (!rov && r > (int)stat[ST_LSRC] && nzsaved == 0 && !g.any(any)) return (int)first;      // (kLOV may have met its end cell already)
                 // kLOV: rows come in rank order and the first perfect end-cell candidate wins, so the rest of the matrix is not needed
                 if (lov && first != 0xffffffffu) return (int)first;
             }
@@ -1225,6 +1258,8 @@ struct Poa {
         if (n_nodes == 0 || L == 0) return RES_OK;
         n_nodes = g.uniform(n_nodes);
         mode = g.uniform(mode);                             // group-uniform by construction (one sequence per group at a time)
+        const bool seen_before = (mode & MODE_SEEN) != 0;
+        mode &= 0xff;
         const int W = g.uniform(L) + 1;
         const int S = (W + CPL - 1) / CPL * CPL;           // row stride (even when NIB)
         if (n_nodes * S > Cfg::DIRCELLS) return RES_OVERFLOW;
@@ -1236,7 +1271,7 @@ struct Poa {
         }
         if (meta_dirty) { build_rowmeta(); HYPO_TICK(PH_META); }
         const int R = g.uniform(Cfg::RINGCELLS / S);        // ring rows; row i can still see rows i-R .. i-1
-        if (R < maxdelta + 1 || R < 1) return RES_OVERFLOW;
+        if (R < (int)stat[ST_MAXD] + 1 || R < 1) return RES_OVERFLOW;
         if (g.lane == 0) { stat[ST_CELLS] += (uint32_t)((n_nodes + 1) * W); stat[ST_ALIGNS] += 1; } HYPO_DIAG(rows_done += (uint32_t)n_nodes);
 
         int best_i = -1;
@@ -1251,14 +1286,16 @@ struct Poa {
             // one hit in two it is a loss (HYPO_EXACT_ADAPT: tries before the rate counts)
             stat_set(ST_LASTX, 0u);
             const int x_tries = (int)stat[ST_XT], x_hits = (int)stat[ST_XH];
-            const bool worth = HYPO_EXACT_ADAPT == 0 || x_tries < HYPO_EXACT_ADAPT || 2 * x_hits >= x_tries;
+            // (a copy of an earlier arm threads for sure and does not count: the rate is that of the window's OTHER arms)
+            const bool worth = seen_before || HYPO_EXACT_ADAPT == 0 || x_tries < HYPO_EXACT_ADAPT || 2 * x_hits >= x_tries;
             if (EXACT_HERE && worth && m > 0 && n < m && gp < 0) {
                 best_i = HYPO_EXACT_RUNS ? rows_exact_runs(mode, S, R) : rows_exact(mode, S, R);
                 HYPO_TICK(PH_EXACT);
                 if (g.lane == 0) {
-                    stat[ST_XT] += 1; stat[ST_CEXACT] += (uint32_t)((n_nodes + 1) * W);
+                    stat[ST_CEXACT] += (uint32_t)((n_nodes + 1) * W);
                     stat[ST_LASTX] = best_i > 0 ? 1u : 0u;
-                    if (best_i > 0) { stat[ST_XH] += 1; stat[ST_XHITS] += 1; }
+                    if (!seen_before) { stat[ST_XT] += 1; if (best_i > 0) stat[ST_XH] += 1; }
+                    if (best_i > 0) stat[ST_XHITS] += 1;
                 }
                 HYPO_DIAG(exact_tries += 1; rows_exact_n += (uint32_t)n_nodes);
             }
@@ -2426,7 +2463,7 @@ struct Poa {
         if (g.lane < ST_N) stat[g.lane] = 0;
         g.sync();
         HYPO_DIAG(rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; rows_exact_n = 0; rows_scored_n = 0; topo_dfs = 0; topo_fast = 0);
-        n_paths = 0; path_used = 0; head_first = 0; L = 0; maxdelta = 0; tb_steps = 0; tb_fv = 0;
+        n_paths = 0; path_used = 0; head_first = 0; L = 0; tb_steps = 0; tb_fv = 0;
         lazy_on = false; n_new = 0;
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
         HYPO_TICK_RESET();

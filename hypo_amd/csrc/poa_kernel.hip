@@ -719,13 +719,13 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
         // poa_class_kernel), sized by what the plan and the last call's late arrivals say; HYPO_POA_POLL=0 turns it off.
         // The regular launch behind the join takes what is left (nothing, unless the polling pass was cut short).
         // A polling wave holds its 16 KB of LDS while it waits, and the launches it waits for must always find room: at most two
-        // per CU (one unless the last call saw many windows in the class), and a handful of waves when the history says the class
+        // per CU (one unless the last call saw many windows in the class), and no polling launch at all when the history says the class
         // stays empty (HYPO_POA_POLL_WAVES overrides the count).
         const char* poll_env = getenv("HYPO_POA_POLL");
         const bool poll3 = !(poll_env && atoi(poll_env) == 0);
         const uint32_t seen3 = last_count[3];                     // windows class 3 ended up with in the last finished call, scaled
         uint32_t poll_waves = (seen3 > planned_host[3] ? seen3 : planned_host[3]);
-        poll_waves += poll_waves / 4 + 16;
+        poll_waves += poll_waves / 4;                             // (none: no polling launch; the regular one below still takes what turns up)
         const int poll_cap = poll_waves > 512u ? 2 : 1;
         if (const char* pw = getenv("HYPO_POA_POLL_WAVES")) poll_waves = (uint32_t)atoi(pw);
         // its stream: the third side stream, unless the LONG first pass is on it (then a fourth one, created on first use)

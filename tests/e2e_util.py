@@ -124,3 +124,49 @@ def run_messy_seed(seed, rec, outdir, device, threads=4):
     assert ("oracle_device_shim" in p.stderr) == (device == "shim")
     got = hashlib.md5(open(os.path.join(str(outdir), "hypo_draft.fasta"), "rb").read()).hexdigest()
     assert got == rec["fasta_md5"], f"messy seed {seed} ({' '.join(rec['args'][10:])}): FASTA differs from the reference's"
+
+
+# ---- sets made by the C++ generator (tests/golden/gen_e2e_fast.cpp): BASELINE config C3 and larger ------------------------------
+FAST_GEN_SRC = os.path.join(GOLD, "gen_e2e_fast.cpp")
+FAST_GEN_BIN = os.path.join(HERE, "_build", "gen_e2e_fast")
+
+
+def build_fast_generator():
+    if not os.path.exists(FAST_GEN_BIN) or os.path.getmtime(FAST_GEN_BIN) < os.path.getmtime(FAST_GEN_SRC):
+        os.makedirs(os.path.dirname(FAST_GEN_BIN), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-fopenmp", "-o", FAST_GEN_BIN, FAST_GEN_SRC])
+    return FAST_GEN_BIN
+
+
+def run_fast_case(name, outdir, threads, extra_args=(), extra_env=None, timeout=1800):
+    """Generates the inputs of golden `name` with the C++ generator (checked against the manifest's checksums), runs the `hypo`
+    binary on them.  Returns (manifest, CompletedProcess, seconds of the run, peak RSS of the child in MB)."""
+    import resource
+    import time
+    man = json.load(open(os.path.join(GOLD, name + ".manifest.json")))
+    a = man["args"]
+    gen = build_fast_generator()
+    rep = json.loads(subprocess.check_output([gen, str(outdir), str(a["seed"]), str(a["contigs"]), str(a["contig_len"]), str(a["k"]),
+                                              str(a["coverage"]), str(a["read_len"]), str(a["read_sub_ppm"])], text=True))
+    assert rep == man["generator_report"], f"{name}: the generator's output changed: {rep}"
+    argv = [BIN] + man["command"].split()[1:]
+    argv[argv.index("-t") + 1] = str(threads)
+    argv += list(extra_args)
+    env = dict(os.environ)
+    env.update(extra_env or {})
+    before = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
+    t0 = time.perf_counter()
+    p = subprocess.run(argv, cwd=str(outdir), env=env, capture_output=True, text=True, timeout=timeout)
+    dt = time.perf_counter() - t0
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "oracle_device_shim" not in p.stderr, "wrong device library behind the C-ABI"
+    rss = max(resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss, before) / 1024.0
+    return man, p, dt, rss
+
+
+def fasta_md5(outdir):
+    h = hashlib.md5()
+    with open(os.path.join(str(outdir), "hypo_draft.fasta"), "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 24), b""):
+            h.update(chunk)
+    return h.hexdigest()
