@@ -10,7 +10,9 @@
 // regions), one lane per region for the gather.  The gather is window-centric on purpose: the arms of a window must appear in
 // alignment (file) order, because the POA result depends on it; a window therefore looks up, in order, the alignments whose
 // reference span overlaps it (binary search on the sorted start positions) and finds each one's candidate arm by direct
-// indexing — no atomics, no sort, deterministic.  Long-read arms (find_long_arms, Filter::is_good) stay on the host.
+// indexing — no atomics, no sort, deterministic.  Long reads (round 3): the same kernels over the pseudo regions of
+// Contig::prepare_long_windows with ArmsIn::long_mode set — find_long_arms' plain cuts, Filter::initialise per LONG window
+// (arms_draftmin_kernel) and Filter::is_good per arm (arm_is_good, inside the walk).
 #include <hip/hip_runtime.h>
 #include "arms_kernel.hpp"
 
@@ -21,7 +23,7 @@ constexpr int T = 256;
 enum : uint8_t { R_SWS, R_SW, R_WS, R_MWM, R_MW, R_WM, R_SWM, R_MWS, R_OTHER, R_LONG, R_SR, R_MSR };   // host/Settings.hpp RegionType
 enum : uint32_t { A_NONE = 0, A_INTERNAL = 1, A_PREFIX = 2, A_SUFFIX = 3, A_EMPTY = 4 };
 // Arms_settings / Minimizer_settings (include/globalDefs.hpp:110-156)
-constexpr uint32_t kMinShortNum = 3, kMinInternal1 = 20, kMinInternal2 = 5, kMinContrib = 10, kShortArmCoef = 10, kMinimizerK = 10;
+constexpr uint32_t kMinShortNum = 3, kMinInternal1 = 20, kMinInternal2 = 5, kMinInternal3 = 10, kMinContrib = 10, kShortArmCoef = 10, kMinimizerK = 10;
 constexpr double kMinInternalContrib = 0.4;
 
 __device__ __forceinline__ bool is_sr(uint8_t t) { return t == R_SR || t == R_MSR; }
@@ -97,7 +99,84 @@ __device__ uint2 prepare_short_arm(const ArmsIn& I, const uint8_t* rd, uint32_t 
     if (valid && q_beg < q_end) return make_uint2(q_beg, q_end | (kind << 28));
     return make_uint2(0, A_NONE);
 }
+
+// ---- Filter (include/Filter.hpp:33-102, include/MinimizerDeque.hpp): canonical (k = 10, w = 10) window minimizers -------------
+// The reference keeps a monotone deque: a new k-mer pops larger keys off the back, entries older than w positions leave at the
+// front, and the front is the window's minimizer.  Equal keys stay, so the front is the EARLIEST of the smallest keys among the
+// k-mers pushed at positions i - w + 1 .. i: a register file of the last w keys (0xffffffff where nothing was pushed: an N, or
+// fewer than k bases since one) gives the same (key, position) without a queue.  A k-mer of 10 bases fits 20 bits.
+constexpr uint32_t kFilterK = 10, kFilterW = 10, kFilterBpPerMinimizer = 50, kNoKey = 0xffffffffu;
+struct MinimizerScan {
+    uint32_t key[kFilterW];
+    uint32_t fwd = 0, rev = 0, run = 0, processed = 0;
+    __device__ MinimizerScan() { for (uint32_t j = 0; j < kFilterW; ++j) key[j] = kNoKey; }
+    // next base (c < 4) or an N (c >= 4) at position i; true: the window has a minimizer, (*mkey, *mpos)
+    __device__ bool step(uint32_t c, uint32_t i, uint32_t* mkey, uint32_t* mpos) {
+#pragma unroll
+        for (int j = kFilterW - 1; j >= 1; --j) key[j] = key[j - 1];
+        key[0] = kNoKey;
+        if (c >= 4) { run = 0; return false; }            // (the rolling k-mers and `processed` are NOT reset: Filter.hpp:48-65)
+        ++run;
+        fwd = ((fwd << 2) | c) & ((1u << (2 * kFilterK)) - 1u);
+        rev = (rev >> 2) | ((3u ^ c) << (2 * (kFilterK - 1)));
+        if (run < kFilterK) return false;
+        key[0] = fwd < rev ? fwd : rev;
+        if (++processed < kFilterW) return false;
+        uint32_t best = key[0], at = 0;
+#pragma unroll
+        for (uint32_t j = 1; j < kFilterW; ++j) if (key[j] <= best) { best = key[j]; at = j; }      // <=: the earliest of equal keys
+        *mkey = best; *mpos = i - at;
+        return true;
+    }
+};
+// Filter::is_good for the arm read[qb, qe) against the sorted minimizers of a window's draft
+__device__ bool arm_is_good(const uint8_t* rd, uint32_t qb, uint32_t qe, const uint32_t* dmin, uint32_t n_dmin) {
+    const uint32_t len = qe - qb;
+    if (len == 0) return true;                               // 0 * 50 >= 0
+    MinimizerScan ms;
+    uint32_t hits = 0, last_pos = 0xffffffffu;
+    for (uint32_t i = 0; i < len; ++i) {
+        uint32_t k, p;
+        if (!ms.step(base2(rd, qb + i), i, &k, &p) || p == last_pos) continue;      // found_minimizers: one entry per minimizer position
+        last_pos = p;
+        uint32_t lo = 0, hi = n_dmin;
+        while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (dmin[m] < k) lo = m + 1; else hi = m; }
+        hits += (lo < n_dmin && dmin[lo] == k) ? 1u : 0u;
+    }
+    return (uint64_t)hits * kFilterBpPerMinimizer >= len;
+}
 }  // namespace
+
+// ---- long mode: Filter::initialise per LONG window ------------------------------------------------------------------------
+__global__ void __launch_bounds__(T) arms_minlen_kernel(ArmsIn I, ArmsOut O) {
+    const uint32_t w = blockIdx.x * T + threadIdx.x;
+    if (w >= I.n_regions) return;
+    O.reg_min_len[w] = I.reg_type[w] == R_LONG ? I.reg_start[w + 1] - I.reg_start[w] : 0u;
+}
+__global__ void __launch_bounds__(T) arms_draftmin_kernel(ArmsIn I, ArmsOut O) {
+    const uint32_t w = blockIdx.x * T + threadIdx.x;
+    if (w >= I.n_regions) return;
+    if (I.reg_type[w] != R_LONG) { O.reg_min_cnt[w] = 0; return; }
+    const uint32_t ws = I.reg_start[w], len = I.reg_start[w + 1] - ws;
+    uint32_t* out = O.draft_min + O.reg_min_off[w];
+    MinimizerScan ms;
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < len; ++i) {
+        const uint32_t p = ws + i;
+        uint32_t c = (I.contig4[p >> 1] >> (4 - 4 * (p & 1))) & 15u;      // PackedSeq<4>: A C G T = 0..3, anything else reads as N
+        uint32_t k, pos;
+        if (ms.step(c, i, &k, &pos) && (n == 0 || out[n - 1] != k)) out[n++] = k;     // (the set takes a key once; neighbours repeat)
+    }
+    for (uint32_t a = 1; a < n; ++a) {                        // sort (about len / 5 keys)
+        const uint32_t v = out[a];
+        uint32_t b = a;
+        while (b > 0 && out[b - 1] > v) { out[b] = out[b - 1]; --b; }
+        out[b] = v;
+    }
+    uint32_t m = 0;
+    for (uint32_t a = 0; a < n; ++a) if (m == 0 || out[m - 1] != out[a]) out[m++] = out[a];
+    O.reg_min_cnt[w] = m;
+}
 
 // ---- 1. regions an alignment touches (Alignment.cpp:222-227: rank on the region bit vector = binary search on the starts) ----
 __global__ void __launch_bounds__(T) arms_span_kernel(ArmsIn I, uint32_t* __restrict__ b_ind, uint32_t* __restrict__ ntouch, uint32_t* __restrict__ bad) {
@@ -130,7 +209,7 @@ __global__ void __launch_bounds__(T) arms_span_kernel(ArmsIn I, uint32_t* __rest
 
 // ---- 2. CIGAR walk + candidate arms, one lane per alignment ----------------------------------------------------------
 __global__ void __launch_bounds__(T) arms_walk_kernel(ArmsIn I, const uint32_t* __restrict__ b_ind, const uint32_t* __restrict__ ntouch,
-                                                      const uint64_t* __restrict__ touch_off, uint32_t* __restrict__ bp, uint2* __restrict__ cand) {
+                                                      const uint64_t* __restrict__ touch_off, uint32_t* __restrict__ bp, uint2* __restrict__ cand, ArmsOut O) {
     const uint32_t a = blockIdx.x * T + threadIdx.x;
     if (a >= I.n_alignments) return;
     const uint32_t nt = ntouch[a];
@@ -174,9 +253,29 @@ __global__ void __launch_bounds__(T) arms_walk_kernel(ArmsIn I, const uint32_t* 
         }
         for (; n < nt - 1; ++n) mybp[n] = qae;              // (a CIGAR shorter than its span: never on consistent input)
     }
-    // Alignment::find_short_arms (Alignment.cpp:228-258)
     const uint8_t* rd = I.reads2 + I.seq_off[a];
     uint2* mc = cand + t0;
+    if (I.long_mode) {
+        // Alignment::find_long_arms (Alignment.cpp:262-299): the read cut at the borders of the pseudo regions, nothing re-anchored;
+        // Window::add_* keeps an arm of a LONG window only if Filter::is_good says so (include/Window.hpp:66-101).  A first /
+        // last arm of zero length is still an arm (is_good("") holds); between two equal break points the window gets an
+        // EMPTY arm, which no filter sees.
+        auto long_arm = [&](uint32_t ind, uint32_t qb, uint32_t qe, uint32_t kind) -> uint2 {
+            if (I.reg_type[ind] != R_LONG) return make_uint2(0, A_NONE);
+            if (!arm_is_good(rd, qb, qe, O.draft_min + O.reg_min_off[ind], O.reg_min_cnt[ind])) return make_uint2(0, A_NONE);
+            return make_uint2(qb, qe | (kind << 28));
+        };
+        mc[0] = long_arm(beg, 0, mybp[0], I.reg_start[beg] == rb ? A_INTERNAL : A_SUFFIX);
+        for (uint32_t i = 1; i + 1 < nt; ++i) {
+            const uint32_t ind = beg + i;
+            if (I.reg_type[ind] != R_LONG) mc[i] = make_uint2(0, A_NONE);
+            else if (mybp[i] == mybp[i - 1]) mc[i] = make_uint2(0, A_EMPTY << 28);
+            else mc[i] = long_arm(ind, mybp[i - 1], mybp[i], A_INTERNAL);
+        }
+        mc[nt - 1] = long_arm(end - 1, mybp[nt - 2], qae, I.reg_start[end] == re ? A_INTERNAL : A_PREFIX);
+        return;
+    }
+    // Alignment::find_short_arms (Alignment.cpp:228-258)
     {
         const uint32_t kind = I.reg_start[beg] == rb ? A_INTERNAL : A_SUFFIX;
         mc[0] = is_sr(I.reg_type[beg]) ? make_uint2(0, A_NONE) : prepare_short_arm(I, rd, qae, beg, 0, mybp[0], kind);
@@ -199,7 +298,7 @@ __global__ void __launch_bounds__(T) arms_window_kernel(ArmsIn I, const uint32_t
                                                         const uint64_t* __restrict__ touch_off, const uint2* __restrict__ cand, ArmsOut O) {
     const uint32_t w = blockIdx.x * T + threadIdx.x;
     if (w >= I.n_regions) return;
-    if (is_sr(I.reg_type[w])) { if (!WRITE) { O.reg_flags[w] = 0; O.reg_valid[w] = 0; O.reg_arms[w] = 0; O.reg_bytes[w] = 0; O.reg_draft_bytes[w] = 0; O.reg_slot[w] = 0; } return; }
+    if (is_sr(I.reg_type[w]) || (I.long_mode && I.reg_type[w] != R_LONG)) { if (!WRITE) { O.reg_flags[w] = 0; O.reg_valid[w] = 0; O.reg_arms[w] = 0; O.reg_bytes[w] = 0; O.reg_draft_bytes[w] = 0; O.reg_slot[w] = 0; } return; }
     if (WRITE && !(O.reg_flags[w] & 1)) return;
     const uint32_t ws = I.reg_start[w], we = I.reg_start[w + 1];
     // alignments that can overlap [ws, we): start position in [ws - max_span, we)   (the starts are sorted: file order)
@@ -255,6 +354,25 @@ __global__ void __launch_bounds__(T) arms_window_kernel(ArmsIn I, const uint32_t
         // thrown away where enough internal arms exist.  get_num_internal() counts empty arms too (include/Window.hpp:107).
         const uint32_t internal = n_int + n_empty;
         bool valid = true;
+        if (I.long_mode) {
+            // Contig::fill_long_windows (include/Contig.hpp:91-113): every LONG window stays; above min_internal_num3 internal arms
+            // (empty ones count) the prefix / suffix arms go
+            const bool clear_ps = internal > kMinInternal3;
+            const uint32_t np = clear_ps ? 0 : n_pre, ns = clear_ps ? 0 : n_suf;
+            O.reg_flags[w] = 1u | (clear_ps ? 0u : 2u);
+            O.reg_counts[w] = make_uint4(n_int, np, ns, n_empty);
+            O.reg_arms[w] = n_int + np + ns;
+            O.reg_bytes_int[w] = bytes_int;
+            O.reg_bytes_pre[w] = clear_ps ? 0 : bytes_pre;
+            O.reg_bytes[w] = bytes_int + (clear_ps ? 0 : bytes_pre + bytes_ps);
+            O.reg_draft_bytes[w] = (we - ws + 1) / 2;
+            uint32_t longest = we - ws;
+            longest = max_int > longest ? max_int : longest;
+            if (!clear_ps) { longest = max_pre > longest ? max_pre : longest; longest = max_suf > longest ? max_suf : longest; }
+            O.reg_slot[w] = (longest + longest / 2 + 24 + 7) / 8 * 8;
+            O.reg_valid[w] = 1u;
+            return;
+        }
         if (internal < kMinShortNum) {
             const bool covered = max_pre + max_suf >= we - ws;
             const bool enough = n_pre >= kMinShortNum && n_suf >= kMinShortNum;
@@ -292,7 +410,7 @@ __global__ void __launch_bounds__(T) arms_describe_kernel(ArmsIn I, ArmsOut O) {
     const uint32_t ws = I.reg_start[w], we = I.reg_start[w + 1], len = we - ws;
     const uint4 c = O.reg_counts[w];
     HypoWindow hw;
-    hw.type = HYPO_WIN_SHORT; hw.reserved[0] = hw.reserved[1] = hw.reserved[2] = 0;
+    hw.type = I.long_mode ? HYPO_WIN_LONG : HYPO_WIN_SHORT; hw.reserved[0] = hw.reserved[1] = hw.reserved[2] = 0;
     hw.draft_len = len; hw.draft_off = O.reg_draft_off[w];
     hw.first_arm = (uint32_t)O.reg_arm_off[w];
     hw.n_internal = c.x; hw.n_prefix = c.y; hw.n_suffix = c.z; hw.n_empty = c.w; hw.reserved2 = 0;
@@ -384,8 +502,16 @@ hipError_t arms_phase1(const ArmsIn& I, uint32_t* b_ind, uint32_t* ntouch, uint3
 }
 hipError_t arms_phase2(const ArmsIn& I, const uint32_t* b_ind, const uint32_t* ntouch, const uint64_t* touch_off, uint32_t* bp, uint2* cand,
                        const ArmsOut& O, hipStream_t st) {
-    if (I.n_alignments) hipLaunchKernelGGL(arms_walk_kernel, dim3((I.n_alignments + T - 1) / T), dim3(T), 0, st, I, b_ind, ntouch, touch_off, bp, cand);
+    if (I.n_alignments) hipLaunchKernelGGL(arms_walk_kernel, dim3((I.n_alignments + T - 1) / T), dim3(T), 0, st, I, b_ind, ntouch, touch_off, bp, cand, O);
     hipLaunchKernelGGL(arms_window_kernel<false>, dim3((I.n_regions + T - 1) / T), dim3(T), 0, st, I, b_ind, ntouch, touch_off, cand, O);
+    return hipGetLastError();
+}
+hipError_t arms_long_minlen(const ArmsIn& I, const ArmsOut& O, hipStream_t st) {
+    hipLaunchKernelGGL(arms_minlen_kernel, dim3((I.n_regions + T - 1) / T), dim3(T), 0, st, I, O);
+    return hipGetLastError();
+}
+hipError_t arms_long_draftmin(const ArmsIn& I, const ArmsOut& O, hipStream_t st) {
+    hipLaunchKernelGGL(arms_draftmin_kernel, dim3((I.n_regions + T - 1) / T), dim3(T), 0, st, I, O);
     return hipGetLastError();
 }
 hipError_t arms_phase3(const ArmsIn& I, const uint32_t* b_ind, const uint32_t* ntouch, const uint64_t* touch_off, const uint2* cand,

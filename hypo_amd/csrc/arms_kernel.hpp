@@ -26,6 +26,7 @@ struct ArmsIn {
     const uint32_t* cigar_off;      // [n_alignments + 1]
     const uint32_t* cigar;          // BAM encoding: len << 4 | op
     uint32_t max_span;              // max(re - rb)
+    uint32_t long_mode;             // 1: long reads over pseudo regions -> LONG windows (no anchors; Filter::is_good decides what stays)
 };
 
 struct ArmsOut {
@@ -52,6 +53,11 @@ struct ArmsOut {
     uint8_t* arms2;
     uint8_t* draft4;
     uint64_t* out_off;              // [n_windows] (the host appends the total)
+    // long mode: the window minimizers of every LONG window's draft (Filter::initialise), sorted, at reg_min_off[w] .. + reg_min_cnt[w]
+    uint32_t* reg_min_len;          // per region: slots it needs (its length for a LONG window, else 0); scan input
+    const uint64_t* reg_min_off;
+    uint32_t* reg_min_cnt;
+    uint32_t* draft_min;
 };
 
 hipError_t scan32(const uint32_t* in, uint64_t n, uint64_t* out, uint64_t* bsum, uint64_t* total, hipStream_t st);
@@ -59,6 +65,9 @@ size_t scan32_scratch_bytes(uint64_t n);
 hipError_t arms_phase1(const ArmsIn& I, uint32_t* b_ind, uint32_t* ntouch, uint32_t* bad, hipStream_t st);
 hipError_t arms_phase2(const ArmsIn& I, const uint32_t* b_ind, const uint32_t* ntouch, const uint64_t* touch_off, uint32_t* bp, uint2* cand,
                        const ArmsOut& O, hipStream_t st);
+// long mode, between phase 1's scan and phase 2: per-region minimizer slots (a), then the drafts' minimizers (b)
+hipError_t arms_long_minlen(const ArmsIn& I, const ArmsOut& O, hipStream_t st);
+hipError_t arms_long_draftmin(const ArmsIn& I, const ArmsOut& O, hipStream_t st);
 hipError_t arms_phase3(const ArmsIn& I, const uint32_t* b_ind, const uint32_t* ntouch, const uint64_t* touch_off, const uint2* cand,
                        const ArmsOut& O, const uint64_t* win_off, hipStream_t st);
 

@@ -62,7 +62,9 @@ struct Ctx {
     } slots[2];
     DevBuf scan_arena[7];
     // resident window batch of hypo_gpu_arms_build (inputs, work arrays, the batch, consensus slots, POA workspace)
-    DevBuf arms_arena[5]; HypoArmsSummary arms_sum{}; bool arms_ready = false; hypo::ArmsOut arms_out{};
+    // resident window batches built by the arm kernels: [0] SHORT windows (hypo_gpu_arms_build), [1] LONG windows (hypo_gpu_arms_build_long)
+    struct ArmsSet { DevBuf arena[5]; HypoArmsSummary sum{}; bool ready = false; hypo::ArmsOut out{}; };
+    ArmsSet arms[2];
     DevBuf solid_set; uint32_t solid_k = 0;            // hypo_gpu_solid_set_upload
     int poa_flags = 0;                                 // hypo_gpu_set_option
     std::vector<HypoWindow> sh_win; std::vector<uint64_t> sh_aoff, sh_off;   // rebased descriptors of this device's share (hypo_gpu_poa_batch_sharded)
@@ -217,8 +219,7 @@ static void release_ctx(Ctx& c) {
         if (c.slots[1].stream) (void)hipStreamDestroy(c.slots[1].stream);
         c.slots[0].stream = c.slots[1].stream = nullptr;
         for (auto& a : c.scan_arena) a.release();
-        for (auto& a : c.arms_arena) a.release();
-        c.arms_ready = false;
+        for (auto& as : c.arms) { for (auto& a : as.arena) a.release(); as.ready = false; }
         c.solid_set.release(); c.solid_k = 0;
         if (c.stream) (void)hipStreamDestroy(c.stream);
     }
@@ -733,15 +734,18 @@ int hypo_gpu_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k, co
 
 // ---- arm selection on the device (kernels in arms_kernel.hip) ------------------------------------------
 
-int hypo_gpu_arms_build(const HypoArmsRegions* R, const HypoArmsReads* A, uint8_t* region_valid, HypoArmsSummary* sum) {
+// which = 0: short reads -> SHORT windows; 1: long reads over the pseudo regions of Contig::prepare_long_windows -> LONG windows
+static int arms_build_impl(int which, const HypoArmsRegions* R, const HypoArmsReads* A, uint8_t* region_valid, HypoArmsSummary* sum) {
     HYPO_LOCKED();
     HYPO_ON_DEVICE();
+    auto& AS = g_ctx.arms[which];
+    const bool long_mode = which == 1;
     if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
     if (!R || !A || !region_valid || !sum) return fail(HYPO_E_INVALID, "NULL argument");
-    if (!R->n_regions || !R->start || !R->type || !R->info || !R->contig4 || (R->n_anchor_kmers && !R->anchor_kmers)) return fail(HYPO_E_INVALID, "NULL buffer in regions");
+    if (!R->n_regions || !R->start || !R->type || (!long_mode && !R->info) || !R->contig4 || (R->n_anchor_kmers && !R->anchor_kmers)) return fail(HYPO_E_INVALID, "NULL buffer in regions");
     if (A->n_alignments && (!A->rb || !A->re || !A->qae || !A->seq_off || !A->reads2 || !A->cigar_off || !A->cigar)) return fail(HYPO_E_INVALID, "NULL buffer in reads");
     if (R->k < 2 || R->k > 31) return fail(HYPO_E_INVALID, "k=%u out of range 2..31", R->k);
-    g_ctx.arms_ready = false;
+    AS.ready = false;
     const uint32_t nr = R->n_regions, na = A->n_alignments;
     const uint64_t total_len = R->start[nr];
     uint32_t max_span = 0;
@@ -764,7 +768,7 @@ int hypo_gpu_arms_build(const HypoArmsRegions* R, const HypoArmsReads* A, uint8_
                     max_span, (unsigned long long)(sum_span / na));
     const uint64_t n_cig = na ? A->cigar_off[na] : 0;
     hipStream_t st = g_ctx.stream;
-    DevBuf &dIn = g_ctx.arms_arena[0], &dWork = g_ctx.arms_arena[1], &dBatch = g_ctx.arms_arena[2];
+    DevBuf &dIn = AS.arena[0], &dWork = AS.arena[1], &dBatch = AS.arena[2];
     // inputs
     Carver ci;
     const size_t o_start = ci.take((size_t)(nr + 1) * 4), o_type = ci.take(nr + 1), o_info = ci.take((size_t)(nr + 1) * 4),
@@ -774,7 +778,7 @@ int hypo_gpu_arms_build(const HypoArmsRegions* R, const HypoArmsReads* A, uint8_
     HIP_TRY(dIn.alloc(ci.at));
     char* in = (char*)dIn.p;
 #define UP(off, src, bytes) do { if (bytes) HIP_TRY(hipMemcpyAsync(in + (off), (src), (bytes), hipMemcpyHostToDevice, st)); } while (0)
-    UP(o_start, R->start, (size_t)(nr + 1) * 4); UP(o_type, R->type, (size_t)nr + 1); UP(o_info, R->info, (size_t)(nr + 1) * 4);
+    UP(o_start, R->start, (size_t)(nr + 1) * 4); UP(o_type, R->type, (size_t)nr + 1); if (R->info) UP(o_info, R->info, (size_t)(nr + 1) * 4);
     UP(o_anchor, R->anchor_kmers, R->n_anchor_kmers * 8); UP(o_contig, R->contig4, (total_len + 1) / 2);
     UP(o_rb, A->rb, (size_t)na * 4); UP(o_re, A->re, (size_t)na * 4); UP(o_qae, A->qae, (size_t)na * 4); UP(o_soff, A->seq_off, (size_t)na * 8);
     UP(o_reads, A->reads2, A->reads2_bytes); if (na) UP(o_coff, A->cigar_off, (size_t)(na + 1) * 4); UP(o_cig, A->cigar, n_cig * 4);
@@ -784,7 +788,7 @@ int hypo_gpu_arms_build(const HypoArmsRegions* R, const HypoArmsReads* A, uint8_
     I.anchor_kmers = (const uint64_t*)(in + o_anchor); I.k = R->k; I.contig4 = (const uint8_t*)(in + o_contig);
     I.n_alignments = na; I.rb = (const uint32_t*)(in + o_rb); I.re = (const uint32_t*)(in + o_re); I.qae = (const uint32_t*)(in + o_qae);
     I.seq_off = (const uint64_t*)(in + o_soff); I.reads2 = (const uint8_t*)(in + o_reads); I.cigar_off = (const uint32_t*)(in + o_coff);
-    I.cigar = (const uint32_t*)(in + o_cig); I.max_span = max_span;
+    I.cigar = (const uint32_t*)(in + o_cig); I.max_span = max_span; I.long_mode = long_mode ? 1u : 0u;
     // work arrays that do not depend on the number of touched regions
     Carver cw;
     const size_t scan_n = nr > na ? nr : na;
@@ -792,7 +796,8 @@ int hypo_gpu_arms_build(const HypoArmsRegions* R, const HypoArmsReads* A, uint8_
                  w_tot = cw.take(64), w_flags = cw.take((size_t)nr * 4), w_valid = cw.take((size_t)nr * 4), w_counts = cw.take((size_t)nr * 16),
                  w_arms = cw.take((size_t)nr * 4), w_bytes = cw.take((size_t)nr * 4), w_bint = cw.take((size_t)nr * 4), w_bpre = cw.take((size_t)nr * 4),
                  w_dbytes = cw.take((size_t)nr * 4), w_slot = cw.take((size_t)nr * 4), w_winoff = cw.take((size_t)nr * 8), w_armoff = cw.take((size_t)nr * 8),
-                 w_byteoff = cw.take((size_t)nr * 8), w_droff = cw.take((size_t)nr * 8), w_slotoff = cw.take((size_t)nr * 8), w_widx = cw.take((size_t)nr * 4);
+                 w_byteoff = cw.take((size_t)nr * 8), w_droff = cw.take((size_t)nr * 8), w_slotoff = cw.take((size_t)nr * 8), w_widx = cw.take((size_t)nr * 4),
+                 w_minlen = cw.take(long_mode ? (size_t)nr * 4 : 0), w_minoff = cw.take(long_mode ? (size_t)nr * 8 : 0), w_mincnt = cw.take(long_mode ? (size_t)nr * 4 : 0);
     const size_t fixed_work = cw.at;
     // the candidate arrays follow: a read of span s touches at most s / (shortest region) + 2 regions; sized after phase 1
     HIP_TRY(dWork.alloc(fixed_work));
@@ -801,18 +806,24 @@ int hypo_gpu_arms_build(const HypoArmsRegions* R, const HypoArmsReads* A, uint8_
     HIP_TRY(hipMemsetAsync(tot, 0, 64, st));
     HIP_TRY(hypo::arms_phase1(I, (uint32_t*)(wk + w_bind), (uint32_t*)(wk + w_nt), (uint32_t*)(tot + 6), st));
     HIP_TRY(hypo::scan32((const uint32_t*)(wk + w_nt), na, (uint64_t*)(wk + w_toff), (uint64_t*)(wk + w_bsum), tot + 0, st));
+    hypo::ArmsOut O{};
+    if (long_mode) {      // slots for the minimizers of every LONG window's draft (Filter::initialise): one per base at most
+        O.reg_min_len = (uint32_t*)(wk + w_minlen); O.reg_min_off = (const uint64_t*)(wk + w_minoff); O.reg_min_cnt = (uint32_t*)(wk + w_mincnt);
+        HIP_TRY(hypo::arms_long_minlen(I, O, st));
+        HIP_TRY(hypo::scan32(O.reg_min_len, nr, (uint64_t*)(wk + w_minoff), (uint64_t*)(wk + w_bsum), tot + 7, st));
+    }
     uint64_t h_tot[8] = {0};
     HIP_TRY(hipMemcpyAsync(h_tot, tot, 64, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (h_tot[6]) return fail(HYPO_E_INVALID, "%llu alignment record(s) whose CIGAR disagrees with their span / aligned length", (unsigned long long)h_tot[6]);
     const uint64_t n_touch = h_tot[0];
     // candidates (in a buffer of their own: growing dWork would move the arrays phase 1 filled)
-    DevBuf& dCand = g_ctx.arms_arena[3];
+    DevBuf& dCand = AS.arena[3];
     Carver cc;
-    const size_t c_bp = cc.take(n_touch * 4), c_cand = cc.take(n_touch * 8);
+    const size_t c_bp = cc.take(n_touch * 4), c_cand = cc.take(n_touch * 8), c_dmin = cc.take(long_mode ? h_tot[7] * 4 + 16 : 0);
     HIP_TRY(dCand.alloc(cc.at));
     char* cd = (char*)dCand.p;
-    hypo::ArmsOut O{};
+    if (long_mode) { O.draft_min = (uint32_t*)(cd + c_dmin); HIP_TRY(hypo::arms_long_draftmin(I, O, st)); }
     O.reg_flags = (uint32_t*)(wk + w_flags); O.reg_valid = (uint32_t*)(wk + w_valid); O.reg_counts = (uint4*)(wk + w_counts); O.reg_arms = (uint32_t*)(wk + w_arms);
     O.reg_bytes = (uint32_t*)(wk + w_bytes); O.reg_bytes_int = (uint32_t*)(wk + w_bint); O.reg_bytes_pre = (uint32_t*)(wk + w_bpre);
     O.reg_draft_bytes = (uint32_t*)(wk + w_dbytes); O.reg_slot = (uint32_t*)(wk + w_slot);
@@ -847,16 +858,19 @@ int hypo_gpu_arms_build(const HypoArmsRegions* R, const HypoArmsReads* A, uint8_
         HIP_TRY(hipMemcpyAsync(O.out_off + n_win, tot + 5, 8, hipMemcpyDeviceToDevice, st));
     }
     sum->n_windows = (uint32_t)n_win; sum->n_arms = (uint32_t)n_arms; sum->arms2_bytes = arm_bytes; sum->draft4_bytes = draft_bytes; sum->out_bytes = slot_bytes;
-    g_ctx.arms_sum = *sum; g_ctx.arms_out = O; g_ctx.arms_ready = true;
+    AS.sum = *sum; AS.out = O; AS.ready = true;
     return HYPO_OK;
 }
+int hypo_gpu_arms_build(const HypoArmsRegions* R, const HypoArmsReads* A, uint8_t* region_valid, HypoArmsSummary* sum) { return arms_build_impl(0, R, A, region_valid, sum); }
+int hypo_gpu_arms_build_long(const HypoArmsRegions* R, const HypoArmsReads* A, uint8_t* region_valid, HypoArmsSummary* sum) { return arms_build_impl(1, R, A, region_valid, sum); }
 
-int hypo_gpu_arms_download(HypoWindow* windows, uint32_t* win_region, uint32_t* arm_len, uint64_t* arm_off, uint8_t* arms2, uint8_t* draft4) {
+static int arms_download_impl(int which, HypoWindow* windows, uint32_t* win_region, uint32_t* arm_len, uint64_t* arm_off, uint8_t* arms2, uint8_t* draft4) {
     HYPO_LOCKED();
     HYPO_ON_DEVICE();
     if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
-    if (!g_ctx.arms_ready) return fail(HYPO_E_INVALID, "no resident batch: call hypo_gpu_arms_build first");
-    const HypoArmsSummary& S = g_ctx.arms_sum; const hypo::ArmsOut& O = g_ctx.arms_out;
+    auto& AS = g_ctx.arms[which];
+    if (!AS.ready) return fail(HYPO_E_INVALID, "no resident batch: call hypo_gpu_arms_build%s first", which ? "_long" : "");
+    const HypoArmsSummary& S = AS.sum; const hypo::ArmsOut& O = AS.out;
     hipStream_t st = g_ctx.stream;
     if (windows && S.n_windows) HIP_TRY(hipMemcpyAsync(windows, O.windows, (size_t)S.n_windows * sizeof(HypoWindow), hipMemcpyDeviceToHost, st));
     if (win_region && S.n_windows) HIP_TRY(hipMemcpyAsync(win_region, O.win_region, (size_t)S.n_windows * 4, hipMemcpyDeviceToHost, st));
@@ -868,23 +882,32 @@ int hypo_gpu_arms_download(HypoWindow* windows, uint32_t* win_region, uint32_t* 
     return HYPO_OK;
 }
 
-int hypo_gpu_arms_poa(const HypoScoreParams* scores, char* bases, uint64_t* off, uint32_t* len, uint8_t* status) {
+int hypo_gpu_arms_download(HypoWindow* windows, uint32_t* win_region, uint32_t* arm_len, uint64_t* arm_off, uint8_t* arms2, uint8_t* draft4) {
+    return arms_download_impl(0, windows, win_region, arm_len, arm_off, arms2, draft4);
+}
+int hypo_gpu_arms_download_long(HypoWindow* windows, uint32_t* win_region, uint32_t* arm_len, uint64_t* arm_off, uint8_t* arms2, uint8_t* draft4) {
+    return arms_download_impl(1, windows, win_region, arm_len, arm_off, arms2, draft4);
+}
+
+static int arms_poa_impl(int which, const HypoScoreParams* scores, char* bases, uint64_t* off, uint32_t* len, uint8_t* status) {
     HYPO_LOCKED();
     HYPO_ON_DEVICE();
     if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
     int rc = check_scores(scores);
     if (rc) return rc;
-    if (!g_ctx.arms_ready) return fail(HYPO_E_INVALID, "no resident batch: call hypo_gpu_arms_build first");
-    const HypoArmsSummary& S = g_ctx.arms_sum; const hypo::ArmsOut& O = g_ctx.arms_out;
+    auto& AS = g_ctx.arms[which];
+    if (!AS.ready) return fail(HYPO_E_INVALID, "no resident batch: call hypo_gpu_arms_build%s first", which ? "_long" : "");
+    const HypoArmsSummary& S = AS.sum; const hypo::ArmsOut& O = AS.out;
     memset(&tl_stats, 0, sizeof(tl_stats));
     const uint32_t n = S.n_windows;
     if (!n) return HYPO_OK;
     if (!bases || !off || !len || !status) return fail(HYPO_E_INVALID, "NULL buffer");
     hipStream_t st = g_ctx.stream;
-    DevBuf& dOut = g_ctx.arms_arena[4];
+    DevBuf& dOut = AS.arena[4];
     Carver co;
-    // SHORT windows only: the HBM-scratch classes see the odd escalated window, their smallest scratch (16 resident groups) will do
-    const size_t wsb = hypo::poa_workspace_bytes(n, hypo::kMinGlobalGroups, 0);
+    // SHORT windows only: the HBM-scratch classes see the odd escalated window, their smallest scratch (16 resident groups) will do;
+    // LONG windows: one resident group per window up to what the device holds
+    const size_t wsb = hypo::poa_workspace_bytes(n, which ? (int)(n + 64 < 2048u ? n + 64 : 2048u) : hypo::kMinGlobalGroups, 0);
     const size_t o_bases = co.take(S.out_bytes + 16), o_len = co.take((size_t)n * 4), o_st = co.take(n), o_ws = co.take(wsb);
     const bool timing = getenv("HYPO_HOST_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
@@ -914,5 +937,7 @@ int hypo_gpu_arms_poa(const HypoScoreParams* scores, char* bases, uint64_t* off,
     tl_stats.n_windows = n;
     return HYPO_OK;
 }
+int hypo_gpu_arms_poa(const HypoScoreParams* scores, char* bases, uint64_t* off, uint32_t* len, uint8_t* status) { return arms_poa_impl(0, scores, bases, off, len, status); }
+int hypo_gpu_arms_poa_long(const HypoScoreParams* scores, char* bases, uint64_t* off, uint32_t* len, uint8_t* status) { return arms_poa_impl(1, scores, bases, off, len, status); }
 
 }  // extern "C"

@@ -141,15 +141,108 @@ bool DeviceArms::build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c
     return true;
 }
 
-void DeviceArms::adopt_arms(const std::vector<uint32_t>& which, const std::vector<HypoWindow>& hw, const std::vector<uint32_t>& win_region) {
-    std::vector<uint32_t> arm_len(_sum.n_arms);
-    std::vector<uint64_t> arm_off(_sum.n_arms);
-    std::vector<uint8_t> arms2(_sum.arms2_bytes ? _sum.arms2_bytes : 1);
-    if (hypo_gpu_arms_download(nullptr, nullptr, arm_len.data(), arm_off.data(), arms2.data(), nullptr) != HYPO_OK) {
+bool DeviceArms::build_long(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1,
+                            std::vector<std::vector<std::unique_ptr<Alignment>>>& store) {
+    _active_long = false;
+    if (hypo_gpu_use_device(_slot) != HYPO_OK) return false;
+    // the coordinate space of build(): contigs back to back, each starting on an even position (a 1-base filler region of type SR
+    // behind an odd-length contig); its regions are the PSEUDO regions of Contig::prepare_long_windows
+    uint64_t total = 0, n_reg = 0, n_aln = 0;
+    std::vector<uint64_t> aln_base(c1 - c0 + 1, 0);
+    for (uint32_t c = c0; c < c1; ++c) {
+        const Contig& ctg = *contigs[c];
+        if (ctg._pseudo_reg_type.empty()) return false;
+        total += ctg._len + (ctg._len & 1);
+        n_reg += ctg._pseudo_reg_type.size() - 1 + (ctg._len & 1);
+        aln_base[c - c0] = n_aln;
+        n_aln += store[c].size();
+    }
+    if (total >= 0xfffffff0ull || n_reg >= 0xfffffff0ull || n_aln >= 0xfffffff0ull || n_reg == 0) return false;
+    std::vector<uint64_t> seq_off(n_aln + 1);
+    std::vector<uint32_t> cigar_off(n_aln + 1);
+    bool sorted = true;
+    for (uint32_t c = c0; c < c1; ++c) {
+        const auto& alns = store[c];
+        const uint64_t a0 = aln_base[c - c0];
+        for (size_t t = 0; t < alns.size(); ++t) {
+            seq_off[a0 + t + 1] = alns[t]->_apseq.byte_size();
+            cigar_off[a0 + t + 1] = (uint32_t)alns[t]->_cigar.size();
+            if (t && alns[t - 1]->_rb > alns[t]->_rb) sorted = false;
+        }
+    }
+    if (!sorted) { std::fprintf(stdout, "[Hypo::Hypo] Info: long-read alignments are not sorted by position: long arms are computed on the host\n"); return false; }
+    seq_off[0] = 0; cigar_off[0] = 0;
+    uint64_t n_cig = 0;
+    for (uint64_t g = 0; g < n_aln; ++g) { n_cig += cigar_off[g + 1]; if (n_cig >= 0xfffffff0ull) return false; seq_off[g + 1] += seq_off[g]; cigar_off[g + 1] += cigar_off[g]; }
+    const uint64_t read_bytes = seq_off[n_aln];
+    std::vector<uint32_t> start(n_reg + 1);
+    std::vector<uint8_t> type(n_reg + 1, (uint8_t)RegionType::SR);
+    std::vector<uint8_t> contig4((total + 1) / 2, 0);
+    std::vector<uint32_t> rb(n_aln), re(n_aln), qae(n_aln);
+    std::unique_ptr<uint32_t[]> cigar(new uint32_t[n_cig ? n_cig : 1]);
+    std::unique_ptr<uint8_t[]> reads2(new uint8_t[read_bytes ? read_bytes : 1]);
+    _preg_window.assign(n_reg, nullptr);
+    uint64_t base = 0, r = 0;
+    for (uint32_t c = c0; c < c1; ++c) {
+        Contig& ctg = *contigs[c];
+        const size_t np = ctg._pseudo_reg_type.size() - 1;       // the last pseudo region is the end marker at the contig's length
+        for (size_t i = 0; i < np; ++i, ++r) {
+            start[r] = (uint32_t)(base + ctg._pseudo_reg_pos.select((uint64_t)i + 1));
+            const bool lw = ctg._pseudo_reg_type[i] == RegionType::LONG;
+            type[r] = (uint8_t)(lw ? RegionType::LONG : RegionType::SR);
+            if (lw) { _preg_window[r] = ctg._pwindows[ctg._true_reg_id[i]].get(); if (!_preg_window[r]) return false; }
+        }
+        std::memcpy(contig4.data() + base / 2, ctg._pseq.data(), ctg._pseq.byte_size());
+        if (ctg._len & 1) { start[r] = (uint32_t)(base + ctg._len); type[r] = (uint8_t)RegionType::SR; ++r; }
+        const uint64_t a0 = aln_base[c - c0];
+        auto& alns = store[c];
+#pragma omp parallel for schedule(static)
+        for (int64_t t = 0; t < (int64_t)alns.size(); ++t) {
+            const Alignment& a = *alns[(size_t)t];
+            const uint64_t g = a0 + (uint64_t)t;
+            rb[g] = (uint32_t)(base + a._rb); re[g] = (uint32_t)(base + a._re); qae[g] = a._qae;
+            std::memcpy(reads2.get() + seq_off[g], a._apseq.data(), a._apseq.byte_size());
+            std::memcpy(cigar.get() + cigar_off[g], a._cigar.data(), a._cigar.size() * 4);
+        }
+        base += ctg._len + (ctg._len & 1);
+    }
+    start[r] = (uint32_t)total;
+    HypoArmsRegions R;
+    R.n_regions = (uint32_t)n_reg; R.start = start.data(); R.type = type.data(); R.info = nullptr;
+    R.n_anchor_kmers = 0; R.anchor_kmers = nullptr; R.k = 10; R.contig4 = contig4.data();
+    HypoArmsReads A;
+    A.n_alignments = (uint32_t)n_aln; A.rb = rb.data(); A.re = re.data(); A.qae = qae.data(); A.seq_off = seq_off.data();
+    A.reads2 = reads2.get(); A.reads2_bytes = read_bytes; A.cigar_off = cigar_off.data(); A.cigar = cigar.get();
+    std::vector<uint8_t> valid(n_reg, 0);
+    const int rc = hypo_gpu_arms_build_long(&R, &A, valid.data(), &_sum_long);
+    if (rc != HYPO_OK) {
+        if (rc != HYPO_E_UNSUPPORTED) std::fprintf(stdout, "[Hypo::Hypo] Info: long arms are computed on the host (%s)\n", hypo_gpu_last_error());
+        return false;
+    }
+    // what Contig::fill_long_windows leaves behind (include/Contig.hpp:91-113): the alignments are spent, the pseudo tables gone
+    for (uint32_t c = c0; c < c1; ++c) {
+        Contig& ctg = *contigs[c];
+        store[c].clear();
+        ctg._pseudo_reg_pos.clear();
+        std::vector<RegionType>().swap(ctg._pseudo_reg_type);
+        std::vector<uint32_t>().swap(ctg._true_reg_id);
+    }
+    std::fprintf(stdout, "[Hypo::Hypo] Info: long arms cut on the device: %u windows, %u arms\n", _sum_long.n_windows, _sum_long.n_arms);
+    _active_long = true;
+    return true;
+}
+
+void DeviceArms::adopt_arms(const std::vector<uint32_t>& which, const std::vector<HypoWindow>& hw, const std::vector<uint32_t>& win_region, bool lng) {
+    const HypoArmsSummary& sum = lng ? _sum_long : _sum;
+    const std::vector<Window*>& rw = lng ? _preg_window : _reg_window;
+    std::vector<uint32_t> arm_len(sum.n_arms);
+    std::vector<uint64_t> arm_off(sum.n_arms);
+    std::vector<uint8_t> arms2(sum.arms2_bytes ? sum.arms2_bytes : 1);
+    if ((lng ? hypo_gpu_arms_download_long : hypo_gpu_arms_download)(nullptr, nullptr, arm_len.data(), arm_off.data(), arms2.data(), nullptr) != HYPO_OK) {
         std::fprintf(stderr, "[Hypo::Window] Error: %s\n", hypo_gpu_last_error()); std::exit(1);
     }
     for (uint32_t wi : which) {
-        Window& w = *_reg_window[win_region[wi]];
+        Window& w = *rw[win_region[wi]];
         const HypoWindow& d = hw[wi];
         uint32_t a = d.first_arm;
         auto take = [&](uint32_t arm) { return PackedSeq<2>(arms2.data() + arm_off[arm], arm_len[arm]); };
@@ -163,7 +256,17 @@ void DeviceArms::adopt_arms(const std::vector<uint32_t>& which, const std::vecto
 int DeviceArms::polish(const ScoreParams& sp, bool keep_arms, std::vector<Window*>* retry) {
     if (!_active) return HYPO_OK;
     _active = false;
+    return polish_impl(false, sp, keep_arms, retry);
+}
+int DeviceArms::polish_long(const ScoreParams& sp, bool keep_arms, std::vector<Window*>* retry) {
+    if (!_active_long) return HYPO_OK;
+    _active_long = false;
+    return polish_impl(true, sp, keep_arms, retry);
+}
+int DeviceArms::polish_impl(bool lng, const ScoreParams& sp, bool keep_arms, std::vector<Window*>* retry) {
     if (hypo_gpu_use_device(_slot) != HYPO_OK) return HYPO_E_INVALID;
+    const HypoArmsSummary& _sum = lng ? _sum_long : this->_sum;
+    const std::vector<Window*>& _reg_window = lng ? _preg_window : this->_reg_window;
     const uint32_t n = _sum.n_windows;
     if (!n) return HYPO_OK;
     const auto tp = std::chrono::steady_clock::now();
@@ -176,19 +279,19 @@ int DeviceArms::polish(const ScoreParams& sp, bool keep_arms, std::vector<Window
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     const auto t0 = now();
-    int rc = hypo_gpu_arms_poa(&sp, bases.data(), off.data(), len.data(), st.data());
+    int rc = (lng ? hypo_gpu_arms_poa_long : hypo_gpu_arms_poa)(&sp, bases.data(), off.data(), len.data(), st.data());
     if (rc != HYPO_OK) return rc;
     const auto t1 = now();
-    rc = hypo_gpu_arms_download(hw.data(), win_region.data(), nullptr, nullptr, nullptr, nullptr);
+    rc = (lng ? hypo_gpu_arms_download_long : hypo_gpu_arms_download)(hw.data(), win_region.data(), nullptr, nullptr, nullptr, nullptr);
     if (rc != HYPO_OK) return rc;
-    if (timing) std::fprintf(stderr, "[timing] device arms: buffers %.3f s, hypo_gpu_arms_poa %.3f s, descriptors %.3f s\n", secs(tp, t0), secs(t0, t1), secs(t1, now()));
+    if (timing) std::fprintf(stderr, "[timing] device arms: buffers %.3f s, hypo_gpu_arms_poa%s %.3f s, descriptors %.3f s\n", secs(tp, t0), lng ? "_long" : "", secs(t0, t1), secs(t1, now()));
     std::vector<uint32_t> again, all;
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < (int64_t)n; ++i)
         if (st[(size_t)i] == HYPO_ST_OK) _reg_window[win_region[(size_t)i]]->_consensus.assign(bases.data() + off[(size_t)i], len[(size_t)i]);
     for (uint32_t i = 0; i < n; ++i) { if (st[i] != HYPO_ST_OK) again.push_back(i); if (keep_arms) all.push_back(i); }
-    if (keep_arms) adopt_arms(all, hw, win_region);
-    else if (!again.empty()) adopt_arms(again, hw, win_region);
+    if (keep_arms) adopt_arms(all, hw, win_region, lng);
+    else if (!again.empty()) adopt_arms(again, hw, win_region, lng);
     if (!again.empty()) {          // a consensus longer than its slot, a window beyond the size classes: the host's retry / degraded path
         std::vector<Window*> ws;
         for (uint32_t i : again) ws.push_back(_reg_window[win_region[i]]);

@@ -32,6 +32,15 @@ public:
     // contexts); retry == nullptr: done here.  May be called from a thread of its own per context.
     int polish(const ScoreParams& sp, bool keep_arms, std::vector<Window*>* retry = nullptr);
     uint64_t num_windows() const { return _sum.n_windows; }
+    // The same for the long reads of the contigs [c0, c1) after Contig::prepare_long_windows: the device cuts them at the pseudo
+    // regions' borders (Alignment::find_long_arms), filters the arms (Filter::is_good against each LONG window's draft) and keeps
+    // the LONG windows as a second resident batch.  true: `store` is consumed and the pseudo-region tables of the contigs are
+    // released (what Contig::fill_long_windows does at its end); false: nothing changed, the host loops must run.
+    bool build_long(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1,
+                    std::vector<std::vector<std::unique_ptr<Alignment>>>& store);
+    bool active_long() const { return _active_long; }
+    int polish_long(const ScoreParams& sp, bool keep_arms, std::vector<Window*>* retry = nullptr);
+    uint64_t num_long_windows() const { return _sum_long.n_windows; }
 
 private:
     int _slot = 0;
@@ -40,7 +49,11 @@ private:
     std::vector<std::vector<std::unique_ptr<Alignment>>> _spent;   // the alignments of the batch, on their way out
     std::thread _releaser;
     std::vector<Window*> _reg_window;        // region of the coordinate space -> its window (nullptr: SR, filler, pruned)
-    void adopt_arms(const std::vector<uint32_t>& which, const std::vector<HypoWindow>& hw, const std::vector<uint32_t>& win_region);
+    void adopt_arms(const std::vector<uint32_t>& which, const std::vector<HypoWindow>& hw, const std::vector<uint32_t>& win_region, bool lng);
+    int polish_impl(bool lng, const ScoreParams& sp, bool keep_arms, std::vector<Window*>* retry);
+    bool _active_long = false;
+    HypoArmsSummary _sum_long{};
+    std::vector<Window*> _preg_window;       // pseudo region of the coordinate space -> its LONG window (nullptr: pseudo SR, filler)
 };
 
 }  // namespace hypo

@@ -132,6 +132,7 @@ void Hypo::polish() {
         // its contigs and polishes its own resident windows, no window travels between devices.
         for (auto& da : device_arms) da->wait_released();      // (the previous batch's alignments, still on their way out)
         std::vector<char> on_dev(final_cid - initial_cid, 0);  // per contig of the batch: its short arms were cut on a device
+        std::vector<char> long_dev(final_cid - initial_cid, 0);  // ... and its long arms (LONG windows resident on the device)
         std::vector<uint32_t> ctx_cut((size_t)n_ctx + 1, final_cid);
         ctx_cut[0] = initial_cid;
         if (!_cFlags.host_arms) {
@@ -177,13 +178,30 @@ void Hypo::polish() {
             start();
 #pragma omp parallel for schedule(static, 1)
             for (int64_t i = initial_cid; i < (int64_t)final_cid; ++i) _contigs[(size_t)i]->prepare_long_windows();
+            // the long reads are cut into arms, filtered (Filter::is_good) and kept as a second resident batch by the context that
+            // holds the contig's short arms; --host-arms, an unsorted file or a device error take the reference's host loops
+            std::vector<char> long_on_dev(final_cid - initial_cid, 0);
+            if (!_cFlags.host_arms) {
+                for (int d = 0; d < n_ctx; ++d) {
+                    const uint32_t c0 = ctx_cut[(size_t)d], c1 = ctx_cut[(size_t)d + 1];
+                    if (c0 >= c1) continue;
+                    if (device_arms[(size_t)d]->build_long(_contigs, c0, c1, _alignment_store))
+                        for (uint32_t c = c0; c < c1; ++c) long_on_dev[c - initial_cid] = 1;
+                }
+                hypo_gpu_use_device(0);
+            }
             for (uint32_t cid = initial_cid; cid < final_cid; ++cid) {
+                if (long_on_dev[cid - initial_cid]) continue;
                 auto& alns = _alignment_store[cid];
 #pragma omp parallel for
                 for (int64_t t = 0; t < (int64_t)alns.size(); ++t) alns[(size_t)t]->find_long_arms(*_contigs[cid]);
             }
 #pragma omp parallel for schedule(static, 1) if (over_contigs)
-            for (int64_t i = initial_cid; i < (int64_t)final_cid; ++i) { _contigs[(size_t)i]->fill_long_windows(_alignment_store[(size_t)i]); _alignment_store[(size_t)i].clear(); }
+            for (int64_t i = initial_cid; i < (int64_t)final_cid; ++i) {
+                if (long_on_dev[(size_t)i - initial_cid]) continue;
+                _contigs[(size_t)i]->fill_long_windows(_alignment_store[(size_t)i]); _alignment_store[(size_t)i].clear();
+            }
+            for (uint32_t c = initial_cid; c < final_cid; ++c) long_dev[c - initial_cid] = long_on_dev[c - initial_cid];
             stop("[Hypo:Hypo]: Long arms filling. ");
         } else {
             Contig::set_no_long_reads();
@@ -195,7 +213,10 @@ void Hypo::polish() {
         std::vector<Window*> wins;
         for (uint32_t i = initial_cid; i < final_cid; ++i)
             for (uint64_t w = 0; w < _contigs[i]->get_num_regions(); ++w)
-                if (_contigs[i]->is_valid_window((uint32_t)w) && !(on_dev[i - initial_cid] && !_contigs[i]->window((uint32_t)w)->is_long())) wins.push_back(_contigs[i]->window((uint32_t)w));
+                if (_contigs[i]->is_valid_window((uint32_t)w)) {
+                    const bool lw = _contigs[i]->window((uint32_t)w)->is_long();
+                    if (!(lw ? long_dev[i - initial_cid] : on_dev[i - initial_cid])) wins.push_back(_contigs[i]->window((uint32_t)w));
+                }
         uint64_t n_resident = 0;
         {   // the resident batches: every context polishes its own, side by side; what needs the host's retry path joins `wins`
             std::vector<std::vector<Window*>> retry((size_t)n_ctx);
@@ -203,10 +224,13 @@ void Hypo::polish() {
             std::vector<std::string> perr((size_t)n_ctx);
             std::vector<std::thread> th;
             for (int d = 0; d < n_ctx; ++d) {
-                if (!device_arms[(size_t)d]->active()) continue;
-                n_resident += device_arms[(size_t)d]->num_windows();
+                DeviceArms& da = *device_arms[(size_t)d];
+                if (!da.active() && !da.active_long()) continue;
+                n_resident += (da.active() ? da.num_windows() : 0) + (da.active_long() ? da.num_long_windows() : 0);
                 auto work = [&, d] {
-                    prc[(size_t)d] = device_arms[(size_t)d]->polish(_cFlags.score_params, dump.is_open(), &retry[(size_t)d]);
+                    DeviceArms& me = *device_arms[(size_t)d];
+                    prc[(size_t)d] = me.polish(_cFlags.score_params, dump.is_open(), &retry[(size_t)d]);
+                    if (prc[(size_t)d] == HYPO_OK) prc[(size_t)d] = me.polish_long(_cFlags.score_params, dump.is_open(), &retry[(size_t)d]);
                     if (prc[(size_t)d] != HYPO_OK) perr[(size_t)d] = hypo_gpu_last_error();
                 };
                 if (n_ctx == 1) work(); else th.emplace_back(work);

@@ -282,6 +282,21 @@ int hypo_gpu_arms_download(HypoWindow* windows, uint32_t* win_region, uint32_t* 
 /* bases [out_bytes], off [n_windows + 1] (OUT), len / status [n_windows]; stats through hypo_gpu_poa_last_stats. */
 int hypo_gpu_arms_poa(const HypoScoreParams* scores, char* bases, uint64_t* off, uint32_t* len, uint8_t* status);
 
+/* The same for LONG windows (ABI 6): replaces
+ *   Alignment::find_long_arms            src/Alignment.cpp:262-299   (the read cut at the borders of the pseudo regions)
+ *   Window::add_prefix / add_suffix / add_internal for LONG windows, i.e. Filter::initialise + Filter::is_good
+ *                                        include/Window.hpp:66-101, include/Filter.hpp:33-102   (an arm is kept if it shares one
+ *                                        canonical (k = 10, w = 10) window minimizer per 50 bases with the window's draft)
+ *   Contig::fill_long_windows            include/Contig.hpp:91-113   (prefix / suffix arms dropped above 10 internal arms)
+ * `regions` are the PSEUDO regions of Contig::prepare_long_windows (src/Contig.cpp:292-343: start = a set bit of
+ * _pseudo_reg_pos, type = SR or LONG, info and the anchor k-mers are not used and may be NULL / 0), `reads` the long-read
+ * alignments of the contig batch in file order.  Every LONG pseudo region becomes a window of type HYPO_WIN_LONG
+ * (region_valid = 1 there), with or without arms.  The resident LONG batch lives beside the SHORT one of hypo_gpu_arms_build:
+ * neither call disturbs the other's batch. */
+int hypo_gpu_arms_build_long(const HypoArmsRegions* pseudo_regions, const HypoArmsReads* long_reads, uint8_t* region_valid, HypoArmsSummary* summary);
+int hypo_gpu_arms_download_long(HypoWindow* windows, uint32_t* win_region, uint32_t* arm_len, uint64_t* arm_off, uint8_t* arms2, uint8_t* draft4);
+int hypo_gpu_arms_poa_long(const HypoScoreParams* scores, char* bases, uint64_t* off, uint32_t* len, uint8_t* status);
+
 /* Kernel timing with HIP events on the stream the kernels run on ----------------------------------
  * hypo_gpu_profile_begin(max_calls) arms the next max_calls (<= 256) *_device calls: each records
  * events around its kernels.  hypo_gpu_profile_read(call, ms, n) synchronises that call's last event

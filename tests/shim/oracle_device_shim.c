@@ -49,6 +49,9 @@ const char* hypo_gpu_build_id(void) { return "oracle_device_shim"; }
 int hypo_gpu_arms_build(const HypoArmsRegions* r, const HypoArmsReads* a, uint8_t* v, HypoArmsSummary* s) { (void)r; (void)a; (void)v; (void)s; return HYPO_E_UNSUPPORTED; }
 int hypo_gpu_arms_download(HypoWindow* w, uint32_t* r, uint32_t* l, uint64_t* o, uint8_t* a, uint8_t* d) { (void)w; (void)r; (void)l; (void)o; (void)a; (void)d; return HYPO_E_UNSUPPORTED; }
 int hypo_gpu_arms_poa(const HypoScoreParams* sc, char* b, uint64_t* o, uint32_t* l, uint8_t* st) { (void)sc; (void)b; (void)o; (void)l; (void)st; return HYPO_E_UNSUPPORTED; }
+int hypo_gpu_arms_build_long(const HypoArmsRegions* r, const HypoArmsReads* a, uint8_t* v, HypoArmsSummary* s) { (void)r; (void)a; (void)v; (void)s; return HYPO_E_UNSUPPORTED; }
+int hypo_gpu_arms_download_long(HypoWindow* w, uint32_t* r, uint32_t* l, uint64_t* o, uint8_t* a, uint8_t* d) { (void)w; (void)r; (void)l; (void)o; (void)a; (void)d; return HYPO_E_UNSUPPORTED; }
+int hypo_gpu_arms_poa_long(const HypoScoreParams* sc, char* b, uint64_t* o, uint32_t* l, uint8_t* st) { (void)sc; (void)b; (void)o; (void)l; (void)st; return HYPO_E_UNSUPPORTED; }
 
 int hypo_gpu_poa_slot_layout(const HypoWindowBatch* in, uint64_t* off) {
     uint64_t acc = 0;
