@@ -109,9 +109,9 @@ int Window::generate_consensus_batch(const std::vector<Window*>& windows) {
             size_t j = 0;
             for (size_t i = 0; i < part.size(); ++i) if (st[i] == HYPO_ST_CONS_OVERFLOW) st[i] = st2[j++];
         }
-        // Degraded path (documented in DESIGN.md): a window beyond the largest device size class (more than 1 023
-        // sequences, a graph of more than 4 000 nodes or 16 in-edges, an arm longer than 1 021 bases), or one whose
-        // alignment is undefined in the reference itself, keeps its draft; the run goes on.
+        // Degraded path (documented in DESIGN.md): a window beyond the largest device size class (more than 16 382
+        // sequences, a graph of more than 32 767 nodes or 58 in-edges per node, an arm longer than 1 021 bases), or one
+        // whose alignment is undefined in the reference itself, keeps its draft; the run goes on.
         // Anything else is a defect of the flattening / sharding above, not a property of the window (HYPO_ST_INVALID: a descriptor
         // that points outside the batch; a slot overflow that survived the retry): fatal, as every non-OK status was before the
         // degraded path existed.

@@ -8,7 +8,7 @@
 //                                                                                                                     above 2 x 100 bp, src/Contig.cpp:526-711) and small windows with large graphs
 //   4     64 (1)                      10        639     2400  12       1536000 (8)    491520     16384 256  int16  u16  HBM scratch 3.3 MB / resident group: the LONG windows (<= 500 bp, arms ~ window length,
 //                                                                                                                     graphs ~1.3 k nodes; src/Window.cpp:156-236), up to 2048 groups resident
-//   5     64 (1)                      16        1023    4000  16       4194304 (8)    2097152    16384 1024 int32  u16  HBM scratch 13.5 MB / resident group: whatever overflows everything else (64 groups)
+//   5     64 (1)                      16        1023    32767 58       33554432 (8)   2097152    16384 16383 int32 u16  HBM scratch 61 MB / resident group: whatever overflows everything else (up to 32 groups)
 // The kernel is VALU-issue bound (profiles/): a wavefront therefore carries 4 / 2 small windows side by side
 // (16- / 32-lane groups with group-uniform control flow), so one instruction stream advances several windows.
 // A window that does not fit class c (too many nodes / in-edges / cells, a predecessor row that already left
@@ -35,7 +35,11 @@ typedef PoaCfg<HYPO_C2_GW, HYPO_C2_CPL, 127, 126, 6, 13440, 1024, 1024, 127, int
 // class 3 keeps its direction codes (up to 254 x 256 cells) in HBM scratch (Cfg::DIRG): 16 KB of LDS per window instead of 40
 typedef PoaCfg<64, 4, 255, 254, 7, 65536, 2048, 1024, 192, int16_t, uint8_t, 0, false, true> PoaClass3;
 typedef PoaCfg<64, 10, 639, 2400, 12, 1536000, 491520, 16384, 256, int16_t, uint16_t, 1 << 18, true> PoaClass4;          // + 256 K path ids: runs LONG windows
-typedef PoaCfg<64, 16, 1023, 4000, 16, 1 << 22, 1 << 21, 16384, 1024, int32_t, uint16_t, 1 << 18> PoaClass5;    // last resort, also runs LONG windows
+// Last resort, also runs LONG windows.  The reference has no size limit (spoa's graph is a vector of heap nodes, external/spoa/
+// src/graph.cpp:99-128); a window of a deep repeat (mito / rDNA: thousands of reads) must not "keep its draft", so this class is
+// sized for what one window can plausibly be and then some: 16 382 sequences of up to 1 021 bases, 32 767 nodes, 58 in-edges per
+// node (61 MB of HBM scratch per resident group, few groups: it is slow and rare).
+typedef PoaCfg<64, 16, 1023, 32767, 58, 1 << 25, 1 << 21, 16384, 16383, int32_t, uint16_t, 1 << 22> PoaClass5;
 constexpr int kNumPoaClasses = 6;
 }  // namespace hypo
 

@@ -506,8 +506,10 @@ struct Poa {
     HD static int meta_back1(uint32_t meta) { return (int)(((meta >> 12) & 0xfu) | ((meta >> 2) & 0x10u)); }
     HD static uint32_t meta_backs(int b0, int b1) { return ((uint32_t)b0 << 27) | (((uint32_t)b1 & 0xfu) << 12) | (((uint32_t)b1 & 0x10u) << 2); }
     HD static bool meta_sink(uint32_t meta) { return (meta & META_SINK) != 0; }
-    HD static int meta_p0(uint32_t meta) { return (int)((meta >> 19) & (PK ? 0xffu : 0xfffu)); }
-    static_assert(NMAX <= (PK ? 255 : 4095) && (!PK || KIN <= 15), "field widths of rowmeta");
+    // (the packed classes keep the node code a second time in bits 16-18; the others use those bits for the row: 15 bits)
+    static constexpr int P0_SHIFT = PK ? 19 : 16;
+    HD static int meta_p0(uint32_t meta) { return (int)((meta >> P0_SHIFT) & (PK ? 0xffu : 0x7fffu)); }
+    static_assert(NMAX <= (PK ? 255 : 32767) && (!PK || KIN <= 15), "field widths of rowmeta");
     HD void build_rowmeta() {
         int md = 0;
         for (int r = g.lane; r < n_nodes; r += GW) {
@@ -525,9 +527,9 @@ struct Poa {
             const bool slow = !(k == 1 && p0 == r) || sink;
             const uint32_t c = code[u];
 #ifdef HYPO_DBG_SAVEALL
-            rowmeta[r] = c | META_SLOW | META_SAVE | (sink ? META_SINK : 0u) | ((uint32_t)k << 8) | (c << 16) | ((uint32_t)p0 << 19);
+            rowmeta[r] = c | META_SLOW | META_SAVE | (sink ? META_SINK : 0u) | ((uint32_t)k << 8) | (PK ? (c << 16) : 0u) | ((uint32_t)p0 << P0_SHIFT);
 #else
-            rowmeta[r] = c | (slow ? META_SLOW : 0u) | (sink ? META_SINK : 0u) | ((uint32_t)k << 8) | (c << 16) | ((uint32_t)p0 << 19);
+            rowmeta[r] = c | (slow ? META_SLOW : 0u) | (sink ? META_SINK : 0u) | ((uint32_t)k << 8) | (PK ? (c << 16) : 0u) | ((uint32_t)p0 << P0_SHIFT);
 #endif
         }
         meta_dirty = false;

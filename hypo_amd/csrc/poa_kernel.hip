@@ -499,8 +499,8 @@ size_t poa_workspace_bytes(uint32_t n_windows, int long_groups, uint64_t compute
     size_t big = 0;                                         // the HBM-scratch classes run one after the other and share the region
     int g4 = long_groups > 0 ? long_groups : max_global_groups(4, n_windows);
     g4 = g4 < kMinGlobalGroups ? kMinGlobalGroups : (g4 > kMaxGlobalGroups4 ? kMaxGlobalGroups4 : g4);
-    int g5 = long_groups == kMinGlobalGroups ? kMinGlobalGroups : max_global_groups(5, n_windows);   // the minimum applies to both classes
-    g5 = g5 < kMinGlobalGroups ? kMinGlobalGroups : g5;
+    int g5 = long_groups == kMinGlobalGroups ? kMinGlobalGroups5 : max_global_groups(5, n_windows);   // the minimum applies to both classes
+    g5 = g5 < kMinGlobalGroups5 ? kMinGlobalGroups5 : g5;
     const size_t x4 = (size_t)g4 * PoaLayout<PoaClass4>::BYTES, x5 = (size_t)g5 * PoaLayout<PoaClass5>::BYTES;
     big = x4 > x5 ? x4 : x5;
     return poa_workspace_prefix(n_windows) + big + arm_off_region_bytes(computed_arm_offsets);

@@ -14,13 +14,15 @@ constexpr int kRequeueClass = 3;         // where a SHORT window goes that outgr
 #define HYPO_C4_GROUPS 2048
 #endif
 constexpr int kMaxGlobalGroups4 = HYPO_C4_GROUPS;
-constexpr int kMaxGlobalGroups5 = 64;
+constexpr int kMaxGlobalGroups5 = 32;
 inline int max_global_groups(int cls, uint32_t n_windows) {
     const int cap = cls == 4 ? kMaxGlobalGroups4 : kMaxGlobalGroups5;
-    const int want = n_windows < 16u ? 16 : (n_windows > (uint32_t)cap ? cap : (int)n_windows);   // no batch needs more groups than windows
+    const uint32_t lo = cls == 4 ? 16u : 4u;
+    const int want = n_windows < lo ? (int)lo : (n_windows > (uint32_t)cap ? cap : (int)n_windows);   // no batch needs more groups than windows
     return want < cap ? want : cap;
 }
-constexpr int kMinGlobalGroups = 16;     // the smallest scratch poa_run accepts holds this many groups of either HBM-scratch class
+constexpr int kMinGlobalGroups = 16;     // the smallest scratch poa_run accepts holds this many groups of the LONG class ...
+constexpr int kMinGlobalGroups5 = 4;     // ... and this many of the last one (61 MB each)
 constexpr size_t kPoaHeaderBytes = 8192; // count[8] | head[8] @64 | HypoPoaStats @128 | phase cycles @512 | hist @2048 | start @4096 | cursor @6144 | planned @7680 | head2 @7744 | done[8] @7808 | spill_used @7872
 // resident groups of class 3 (direction codes in HBM scratch, PoaLayout::DIRG_BYTES each): what 256 CUs hold at 10 waves per CU
 constexpr int kMaxGroups3 = 2560;

@@ -252,3 +252,44 @@ def test_c4_mixed_short_and_long_batch_vs_oracle(gpu, oracle_lib):
     assert not bad, f"{len(bad)} windows differ, first {bad[0]} (type {int(b.windows['type'][bad[0]])})"
     is_long = b.windows["type"] == abi.WIN_LONG
     assert int(is_long.sum()) == 4000 and (ln[is_long] > 60).all()
+
+
+def _deep_windows():
+    """Windows beyond what round 2's largest class held (1 023 sequences, 4 000 nodes, 16 in-edges): a SHORT window of a deep
+    repeat (1 300 arms of ~90 bp at 3 % error), one with 2 200 noisy arms (~6 000 nodes), and LONG windows whose graphs pass
+    what the LONG class holds (500 bp, 300-420 arms at 8 % errors incl. indels: more than the 255 sequences of the LONG class; noisier arms would be dropped by
+    Filter::is_good inside the real Window class, which the reference harness goes through)."""
+    from hypo_amd.batch import TextWindow, build_batch
+    from test_gpu_fuzz import _mutate
+    rng = np.random.default_rng(2026)
+    A = "ACGT"
+    wins = []
+    for n_arms, L, err in ((1300, 90, 0.03), (2200, 100, 0.10)):
+        truth = "".join(A[i] for i in rng.integers(0, 4, size=L))
+        wins.append(TextWindow(_mutate(rng, truth, 0.01), [_mutate(rng, truth, err) for _ in range(n_arms)], [], [], n_empty=0, is_long=False))
+    for n_arms in (300, 420):
+        truth = "".join(A[i] for i in rng.integers(0, 4, size=500))
+        wins.append(TextWindow(_mutate(rng, truth, 0.02), [_mutate(rng, truth, 0.08) for _ in range(n_arms)], [], [], n_empty=0, is_long=True))
+    return build_batch(wins)
+
+
+def test_last_resort_class_vs_oracle_and_reference(gpu, oracle_lib):
+    """No window 'keeps its draft' because it is big: the last class holds 16 382 sequences / 32 767 nodes / 58 in-edges per
+    window (the reference has no limit, external/spoa/src/graph.cpp:99-128).  Deep SHORT windows and LONG windows with graphs of
+    more than 4 000 nodes against the oracle and, where the prebuilt real reference classes are there, against those."""
+    import oracle
+    b = _deep_windows()
+    off = b.slot_layout()
+    bases, _, ln, st = gpu.poa_batch(b, off=off)
+    s = gpu.last_stats()
+    assert (st == 0).all() and s["n_failed"] == 0
+    assert s["n_class"][5] == b.n_windows, s["n_class"]        # they really ran in the last class
+    ob, _, oln, ost, _, _ = oracle_lib.poa_batch_raw(b, off=off)
+    assert (ost == 0).all() and (ln == oln).all()
+    assert _cons_list(bases, off, ln) == _cons_list(ob, off, oln)
+    if oracle.Ref.available():
+        ref = oracle.Ref()
+        if hasattr(ref.lib, "hyporef_batch"):
+            rb, _, rln, rst, _ = ref.poa_batch_raw(b, off=off)
+            assert (rst == 0).all() and (rln == ln).all()
+            assert _cons_list(bases, off, ln) == _cons_list(rb, off, rln)
