@@ -267,7 +267,7 @@ struct Poa {
     struct alignas(pow2_of(NIB ? CPL / 2 : CPL)) DPack { uint8_t v[NIB ? CPL / 2 : CPL]; };
     // sequence table entry: bits 0-13 src (LDS offset of the staged bytes, or arm index), 14 "an earlier sequence of the window
     // has the same bytes, length, markers and mode" (a hint, from a hash: such a sequence spells a path of the graph), 15 "byte-identical to
-    // the previous entry" (set for staged arms only), 16-25 length, 26 head marker J, 27 tail marker O,
+    // the previous entry", 16-25 length, 26 head marker J, 27 tail marker O,
     // 28-29 mode (0 NW, 1 LOV, 2 ROV), 30-31 where (0 staged in LDS, 1 arms2 in HBM, 2 draft4 in HBM: 4-bit packed)
     HD static uint32_t seq_ent(uint32_t src, uint32_t len, bool head, bool tail, int mode, bool /*four*/, int where) {
         const uint32_t mc = mode == MODE_NW ? 0u : (mode == MODE_LOV ? 1u : 2u);
@@ -384,23 +384,42 @@ struct Poa {
         if (g.any(over)) return RES_OVERFLOW;
         any_len = g.any(any_len);
         g.sync();
+        // Arms that repeat their predecessor byte for byte (same length, markers, mode) are flagged first, on the packed bytes
+        // where they lie in HBM (one lane per arm; neighbours in consumption order are neighbours in memory): four arms in five
+        // of a 30x short-read window are such copies, they are never aligned (Poa::same_as_previous) and need no LDS of their own.
+        for (int t = g.lane + 1; t < narm; t += GW) {
+            const uint32_t a = seqtab[base + t], b = seqtab[base + t - 1];
+            const int nb = (int)(((a >> 16) & 0x3ff) + 3) >> 2;
+            if (((a ^ b) & 0x3fff0000u) == 0 && nb > 0) {
+                const uint8_t* pa = P->arms2 + P->arm_off[a0 + (a & 0x3fff)];
+                const uint8_t* pb = P->arms2 + P->arm_off[a0 + (b & 0x3fff)];
+                bool same = true;
+                for (int k = 0; k < nb; ++k) same &= pa[k] == pb[k];
+                if (same) seqtab[base + t] = a | 0x8000u;           // (the neighbour's compare looks at bits 0-13 and 16-29 only)
+            }
+        }
+        g.sync();
         if (g.lane == 0) {                                  // LDS offsets of the staged arms (serial prefix, <= SEQMAX small adds)
-            int used = 0;
+            int used = 0, prev_off = -1;                    // prev_off: where the predecessor's bytes were staged (-1: they were not)
             for (int t = 0; t < narm; ++t) {
                 const uint32_t e = seqtab[base + t];
                 const int nb = (int)(((e >> 16) & 0x3ff) + 3) >> 2;
-                if (used + nb <= Cfg::ARMBYTES) {
+                if (e & 0x8000u) {                          // a copy shares its predecessor's staged bytes
+                    if (prev_off >= 0) seqtab[base + t] = (e & 0x3fff8000u) | (uint32_t)prev_off;     // where = 0
+                    else prev_off = -1;
+                } else if (used + nb <= Cfg::ARMBYTES) {
                     // keep the arm index in posnode-free scratch: staged entries remember it via `stack`
                     stack[t] = (id_t)(e & 0x3fff);
                     seqtab[base + t] = (e & 0x3fff0000u) | (uint32_t)used;        // where = 0 (bits 30-31 cleared)
+                    prev_off = used;
                     used += nb;
-                }
+                } else prev_off = -1;
             }
         }
         g.sync();
         for (int t = g.lane; t < narm; t += GW) {           // one lane copies one arm: the loads of a lane pipeline
             const uint32_t e = seqtab[base + t];
-            if ((e >> 30) == 0) {
+            if ((e >> 30) == 0 && !(e & 0x8000u)) {
                 const int nb = (int)(((e >> 16) & 0x3ff) + 3) >> 2;
                 const uint8_t* src = P->arms2 + P->arm_off[a0 + (uint32_t)stack[t]];
                 uint8_t* dst = armbuf + (e & 0x3fff);
@@ -408,21 +427,8 @@ struct Poa {
             }
         }
         g.sync();
-        // flag arms that repeat their predecessor byte for byte (same length, markers, mode): one lane per arm
-        for (int t = g.lane + 1; t < narm; t += GW) {
-            const uint32_t a = seqtab[base + t], b = seqtab[base + t - 1];
-            if (((a ^ b) & 0xffff0000u) == 0 && (a >> 30) == 0) {
-                const int nb = (int)(((a >> 16) & 0x3ff) + 3) >> 2;
-                const uint8_t* pa = armbuf + (a & 0x3fff);
-                const uint8_t* pb = armbuf + (b & 0x3fff);
-                bool same = true;
-                for (int k = 0; k < nb; ++k) same &= pa[k] == pb[k];
-                if (same) seqtab[base + t] = a | 0x8000u;
-            }
-        }
-        g.sync();
         if constexpr (PK) {
-            // ... and arms that repeat ANY earlier arm of the window (not only their neighbour): a hash per staged arm, parked in
+            // ... and arms that repeat ANY earlier arm of the window (not only their neighbour): a hash per arm, parked in
             // the ring (idle until the first alignment), every lane looks its arm up among the earlier ones.  Such an arm spells
             // the path the earlier copy was threaded along or created, so threading it cannot fail (Poa::align attempts it whatever
             // the hit rate of the window's other arms is); a hash collision only costs a wasted attempt.
@@ -431,9 +437,9 @@ struct Poa {
             for (int t = g.lane; t < narm; t += GW) {
                 const uint32_t e = seqtab[base + t];
                 uint32_t h = 0;
-                if ((e >> 30) == 0 && ((e >> 16) & 0x3ff) != 0) {
+                if (((e >> 16) & 0x3ff) != 0) {
                     const int nb = (int)(((e >> 16) & 0x3ff) + 3) >> 2;
-                    const uint8_t* pa = armbuf + (e & 0x3fff);
+                    const uint8_t* pa = (e >> 30) == 0 ? armbuf + (e & 0x3fff) : P->arms2 + P->arm_off[a0 + (e & 0x3fff)];
                     h = 2166136261u ^ (e & 0x3fff0000u);
                     HYPO_NOUNROLL
                     for (int k = 0; k < nb; ++k) h = (h ^ pa[k]) * 16777619u;
