@@ -29,6 +29,7 @@ EXPORTS = [
     "hypo_gpu_poa_batch_sharded", "hypo_gpu_poa_batch_begin", "hypo_gpu_poa_batch_end", "hypo_gpu_set_option",
     "hypo_gpu_arms_build", "hypo_gpu_arms_download", "hypo_gpu_arms_poa",
     "hypo_gpu_arms_build_long", "hypo_gpu_arms_download_long", "hypo_gpu_arms_poa_long",
+    "hypo_gpu_reads_upload", "hypo_gpu_support_kmers", "hypo_gpu_support_minimizers",
 ]
 
 

@@ -13,6 +13,7 @@
 #include "../../include/hypo_gpu.h"
 #include "poa_kernel.hpp"
 #include "arms_kernel.hpp"
+#include "support_kernel.hpp"
 #include "scan_kernel.hpp"
 
 namespace {
@@ -65,6 +66,14 @@ struct Ctx {
     // resident window batches built by the arm kernels: [0] SHORT windows (hypo_gpu_arms_build), [1] LONG windows (hypo_gpu_arms_build_long)
     struct ArmsSet { DevBuf arena[5]; HypoArmsSummary sum{}; bool ready = false; hypo::ArmsOut out{}; };
     ArmsSet arms[2];
+    // the short reads of the contig batch in hand (hypo_gpu_reads_upload): the support kernels vote with them, hypo_gpu_arms_build
+    // (reads == NULL) cuts them into arms
+    struct ResidentReads {
+        DevBuf data, work; bool ready = false;
+        uint32_t n = 0; uint64_t n_cig = 0, reads2_bytes = 0; uint32_t max_span = 0; uint64_t sum_span = 0;
+        const uint32_t *rb = nullptr, *re = nullptr, *qae = nullptr, *cigar_off = nullptr, *cigar = nullptr, *read_contig = nullptr;
+        const uint64_t* seq_off = nullptr; const uint8_t* reads2 = nullptr;
+    } rr;
     DevBuf solid_set; uint32_t solid_k = 0;            // hypo_gpu_solid_set_upload
     int poa_flags = 0;                                 // hypo_gpu_set_option
     std::vector<HypoWindow> sh_win; std::vector<uint64_t> sh_aoff, sh_off;   // rebased descriptors of this device's share (hypo_gpu_poa_batch_sharded)
@@ -220,6 +229,7 @@ static void release_ctx(Ctx& c) {
         c.slots[0].stream = c.slots[1].stream = nullptr;
         for (auto& a : c.scan_arena) a.release();
         for (auto& as : c.arms) { for (auto& a : as.arena) a.release(); as.ready = false; }
+        c.rr.data.release(); c.rr.work.release(); c.rr.ready = false;
         c.solid_set.release(); c.solid_k = 0;
         if (c.stream) (void)hipStreamDestroy(c.stream);
     }
@@ -732,6 +742,115 @@ int hypo_gpu_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k, co
     return HYPO_OK;
 }
 
+// ---- support votes on the device (kernels in support_kernel.hip) -----------------------------------------
+
+int hypo_gpu_reads_upload(const HypoArmsReads* A, const uint32_t* read_contig, uint64_t total_len) {
+    HYPO_LOCKED();
+    HYPO_ON_DEVICE();
+    if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
+    auto& rr = g_ctx.rr;
+    rr.ready = false;
+    if (!A || !read_contig) return fail(HYPO_E_INVALID, "NULL argument");
+    const uint32_t na = A->n_alignments;
+    if (na && (!A->rb || !A->re || !A->qae || !A->seq_off || !A->reads2 || !A->cigar_off || !A->cigar)) return fail(HYPO_E_INVALID, "NULL buffer in reads");
+    uint32_t max_span = 0; uint64_t sum_span = 0;
+    for (uint32_t a = 0; a < na; ++a) {
+        if (A->re[a] <= A->rb[a] || A->re[a] > total_len) return fail(HYPO_E_INVALID, "alignment %u: span [%u, %u) outside the %llu bases", a, A->rb[a], A->re[a], (unsigned long long)total_len);
+        if (a && A->rb[a - 1] > A->rb[a]) return fail(HYPO_E_INVALID, "alignments are not sorted by reference start (alignment %u)", a);
+        if (A->seq_off[a] + ((uint64_t)A->qae[a] + 3) / 4 > A->reads2_bytes) return fail(HYPO_E_INVALID, "alignment %u: read outside reads2", a);
+        if (A->cigar_off[a] > A->cigar_off[a + 1]) return fail(HYPO_E_INVALID, "alignment %u: cigar_off decreases", a);
+        const uint32_t span = A->re[a] - A->rb[a];
+        max_span = span > max_span ? span : max_span;
+        sum_span += span;
+    }
+    const uint64_t n_cig = na ? A->cigar_off[na] : 0;
+    Carver c;
+    const size_t o_rb = c.take((size_t)na * 4), o_re = c.take((size_t)na * 4), o_qae = c.take((size_t)na * 4), o_soff = c.take((size_t)na * 8),
+                 o_reads = c.take(A->reads2_bytes), o_coff = c.take((size_t)(na + 1) * 4), o_cig = c.take(n_cig * 4), o_ctg = c.take((size_t)na * 4);
+    HIP_TRY(rr.data.alloc(c.at ? c.at : 256));
+    char* d = (char*)rr.data.p;
+    hipStream_t st = g_ctx.stream;
+#define UP(off, src, bytes) do { if (bytes) HIP_TRY(hipMemcpyAsync(d + (off), (src), (bytes), hipMemcpyHostToDevice, st)); } while (0)
+    UP(o_rb, A->rb, (size_t)na * 4); UP(o_re, A->re, (size_t)na * 4); UP(o_qae, A->qae, (size_t)na * 4); UP(o_soff, A->seq_off, (size_t)na * 8);
+    UP(o_reads, A->reads2, A->reads2_bytes); if (na) UP(o_coff, A->cigar_off, (size_t)(na + 1) * 4); UP(o_cig, A->cigar, n_cig * 4); UP(o_ctg, read_contig, (size_t)na * 4);
+#undef UP
+    HIP_TRY(hipStreamSynchronize(st));                          // the caller may release its arrays
+    rr.n = na; rr.n_cig = n_cig; rr.reads2_bytes = A->reads2_bytes; rr.max_span = max_span; rr.sum_span = sum_span;
+    rr.rb = (const uint32_t*)(d + o_rb); rr.re = (const uint32_t*)(d + o_re); rr.qae = (const uint32_t*)(d + o_qae); rr.seq_off = (const uint64_t*)(d + o_soff);
+    rr.reads2 = (const uint8_t*)(d + o_reads); rr.cigar_off = (const uint32_t*)(d + o_coff); rr.cigar = (const uint32_t*)(d + o_cig); rr.read_contig = (const uint32_t*)(d + o_ctg);
+    rr.ready = true;
+    return HYPO_OK;
+}
+
+static hypo::SupportReads support_reads_of(const Ctx& c) {
+    hypo::SupportReads R;
+    R.n_alignments = c.rr.n; R.rb = c.rr.rb; R.re = c.rr.re; R.qae = c.rr.qae; R.seq_off = c.rr.seq_off; R.reads2 = c.rr.reads2; R.read_contig = c.rr.read_contig;
+    return R;
+}
+
+int hypo_gpu_support_kmers(uint32_t k, uint64_t n_solid, const uint32_t* spos, const uint64_t* kids, uint32_t* coverage, uint32_t* support) {
+    HYPO_LOCKED();
+    HYPO_ON_DEVICE();
+    if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
+    if (!g_ctx.rr.ready) return fail(HYPO_E_INVALID, "no resident reads: call hypo_gpu_reads_upload first");
+    if (k < 2 || k > 31) return fail(HYPO_E_INVALID, "k=%u out of range 2..31", k);
+    if (n_solid >= 0xfffffff0ull) return fail(HYPO_E_CAPACITY, "%llu solid k-mers exceed the 32-bit counters of the boundary", (unsigned long long)n_solid);
+    if (n_solid && (!spos || !kids || !coverage || !support)) return fail(HYPO_E_INVALID, "NULL buffer");
+    if (!n_solid) return HYPO_OK;
+    for (uint64_t i = 1; i < n_solid; ++i) if (spos[i - 1] >= spos[i]) return fail(HYPO_E_INVALID, "solid positions are not increasing (entry %llu)", (unsigned long long)i);
+    Carver c;
+    const size_t o_sp = c.take(n_solid * 4), o_kd = c.take(n_solid * 8), o_cov = c.take(n_solid * 4), o_sup = c.take(n_solid * 4);
+    auto& wk = g_ctx.rr.work;
+    HIP_TRY(wk.alloc(c.at));
+    char* d = (char*)wk.p;
+    hipStream_t st = g_ctx.stream;
+    HIP_TRY(hipMemcpyAsync(d + o_sp, spos, n_solid * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d + o_kd, kids, n_solid * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d + o_cov, 0, c.at - o_cov, st));
+    HIP_TRY(hypo::support_kmers(support_reads_of(g_ctx), k, (uint32_t)n_solid, (const uint32_t*)(d + o_sp), (const uint64_t*)(d + o_kd), (uint32_t*)(d + o_cov), (uint32_t*)(d + o_sup), st));
+    HIP_TRY(hipMemcpyAsync(coverage, d + o_cov, n_solid * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(support, d + o_sup, n_solid * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return HYPO_OK;
+}
+
+int hypo_gpu_support_minimizers(const HypoMegaWindows* W, uint32_t* coverage, uint32_t* support) {
+    HYPO_LOCKED();
+    HYPO_ON_DEVICE();
+    if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
+    if (!g_ctx.rr.ready) return fail(HYPO_E_INVALID, "no resident reads: call hypo_gpu_reads_upload first");
+    if (!W || !W->n_contigs || !W->contig_base || !W->reg_base || !W->win_even || !W->info_base || !W->start || !W->mw_off) return fail(HYPO_E_INVALID, "NULL argument");
+    const uint32_t nc = W->n_contigs;
+    const uint64_t n_start = W->reg_base[nc], n_ent = W->mw_off[W->n_info];
+    if (n_ent && (!W->rel_pos || !W->minimisers || !coverage || !support)) return fail(HYPO_E_INVALID, "NULL buffer");
+    if (!n_ent) return HYPO_OK;
+    for (uint32_t c = 0; c < nc; ++c) {
+        if (W->reg_base[c] > W->reg_base[c + 1]) return fail(HYPO_E_INVALID, "contig %u: reg_base decreases", c);
+        for (uint64_t i = W->reg_base[c] + 1; i < W->reg_base[c + 1]; ++i) if (W->start[i - 1] >= W->start[i]) return fail(HYPO_E_INVALID, "contig %u: region starts are not increasing", c);
+    }
+    for (uint32_t x = 0; x < W->n_info; ++x) if (W->mw_off[x] > W->mw_off[x + 1]) return fail(HYPO_E_INVALID, "mw_off decreases at %u", x);
+    Carver c;
+    const size_t o_cb = c.take((size_t)nc * 4), o_rbase = c.take((size_t)(nc + 1) * 4), o_even = c.take(nc), o_ib = c.take((size_t)nc * 4), o_start = c.take(n_start * 4),
+                 o_off = c.take((size_t)(W->n_info + 1) * 4), o_rel = c.take(n_ent * 4), o_min = c.take(n_ent * 4), o_cov = c.take(n_ent * 4), o_sup = c.take(n_ent * 4);
+    auto& wk = g_ctx.rr.work;
+    HIP_TRY(wk.alloc(c.at));
+    char* d = (char*)wk.p;
+    hipStream_t st = g_ctx.stream;
+#define UP(off, src, bytes) do { if (bytes) HIP_TRY(hipMemcpyAsync(d + (off), (src), (bytes), hipMemcpyHostToDevice, st)); } while (0)
+    UP(o_cb, W->contig_base, (size_t)nc * 4); UP(o_rbase, W->reg_base, (size_t)(nc + 1) * 4); UP(o_even, W->win_even, nc); UP(o_ib, W->info_base, (size_t)nc * 4);
+    UP(o_start, W->start, n_start * 4); UP(o_off, W->mw_off, (size_t)(W->n_info + 1) * 4); UP(o_rel, W->rel_pos, n_ent * 4); UP(o_min, W->minimisers, n_ent * 4);
+#undef UP
+    HIP_TRY(hipMemsetAsync(d + o_cov, 0, c.at - o_cov, st));
+    hypo::MegaWindows M;
+    M.contig_base = (const uint32_t*)(d + o_cb); M.reg_base = (const uint32_t*)(d + o_rbase); M.win_even = (const uint8_t*)(d + o_even); M.info_base = (const uint32_t*)(d + o_ib);
+    M.start = (const uint32_t*)(d + o_start); M.mw_off = (const uint32_t*)(d + o_off); M.rel_pos = (const uint32_t*)(d + o_rel); M.minimisers = (const uint32_t*)(d + o_min);
+    HIP_TRY(hypo::support_minimizers(support_reads_of(g_ctx), M, (uint32_t*)(d + o_cov), (uint32_t*)(d + o_sup), st));
+    HIP_TRY(hipMemcpyAsync(coverage, d + o_cov, n_ent * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(support, d + o_sup, n_ent * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return HYPO_OK;
+}
+
 // ---- arm selection on the device (kernels in arms_kernel.hip) ------------------------------------------
 
 // which = 0: short reads -> SHORT windows; 1: long reads over the pseudo regions of Contig::prepare_long_windows -> LONG windows
@@ -741,9 +860,14 @@ static int arms_build_impl(int which, const HypoArmsRegions* R, const HypoArmsRe
     auto& AS = g_ctx.arms[which];
     const bool long_mode = which == 1;
     if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
-    if (!R || !A || !region_valid || !sum) return fail(HYPO_E_INVALID, "NULL argument");
+    if (!R || !region_valid || !sum) return fail(HYPO_E_INVALID, "NULL argument");
+    // reads == NULL: the reads hypo_gpu_reads_upload left on the device (already checked there)
+    const bool resident = A == nullptr;
+    if (resident && (long_mode || !g_ctx.rr.ready)) return fail(HYPO_E_INVALID, "reads == NULL but no resident reads (hypo_gpu_reads_upload)");
+    HypoArmsReads Ares{};
+    if (resident) { Ares.n_alignments = g_ctx.rr.n; Ares.reads2_bytes = g_ctx.rr.reads2_bytes; A = &Ares; }
     if (!R->n_regions || !R->start || !R->type || (!long_mode && !R->info) || !R->contig4 || (R->n_anchor_kmers && !R->anchor_kmers)) return fail(HYPO_E_INVALID, "NULL buffer in regions");
-    if (A->n_alignments && (!A->rb || !A->re || !A->qae || !A->seq_off || !A->reads2 || !A->cigar_off || !A->cigar)) return fail(HYPO_E_INVALID, "NULL buffer in reads");
+    if (!resident && A->n_alignments && (!A->rb || !A->re || !A->qae || !A->seq_off || !A->reads2 || !A->cigar_off || !A->cigar)) return fail(HYPO_E_INVALID, "NULL buffer in reads");
     if (R->k < 2 || R->k > 31) return fail(HYPO_E_INVALID, "k=%u out of range 2..31", R->k);
     AS.ready = false;
     const uint32_t nr = R->n_regions, na = A->n_alignments;
@@ -751,7 +875,8 @@ static int arms_build_impl(int which, const HypoArmsRegions* R, const HypoArmsRe
     uint32_t max_span = 0;
     uint64_t sum_span = 0;
     for (uint32_t i = 0; i < nr; ++i) if (R->start[i] >= R->start[i + 1]) return fail(HYPO_E_INVALID, "region %u is empty or the starts are not increasing", i);
-    for (uint32_t a = 0; a < na; ++a) {
+    if (resident) { max_span = g_ctx.rr.max_span; sum_span = g_ctx.rr.sum_span; }
+    for (uint32_t a = 0; a < (resident ? 0u : na); ++a) {
         if (A->re[a] <= A->rb[a] || A->re[a] > total_len) return fail(HYPO_E_INVALID, "alignment %u: span [%u, %u) outside the %llu bases", a, A->rb[a], A->re[a], (unsigned long long)total_len);
         if (a && A->rb[a - 1] > A->rb[a]) return fail(HYPO_E_INVALID, "alignments are not sorted by reference start (alignment %u)", a);
         if (A->seq_off[a] + ((uint64_t)A->qae[a] + 3) / 4 > A->reads2_bytes) return fail(HYPO_E_INVALID, "alignment %u: read outside reads2", a);
@@ -766,22 +891,24 @@ static int arms_build_impl(int which, const HypoArmsRegions* R, const HypoArmsRe
     if (na && max_span > 16384u && (uint64_t)max_span * na > 64ull * sum_span)
         return fail(HYPO_E_CAPACITY, "an alignment spans %u reference bases, more than 64 x the mean span (%llu): arm selection stays on the host",
                     max_span, (unsigned long long)(sum_span / na));
-    const uint64_t n_cig = na ? A->cigar_off[na] : 0;
+    const uint64_t n_cig = resident ? g_ctx.rr.n_cig : (na ? A->cigar_off[na] : 0);
     hipStream_t st = g_ctx.stream;
     DevBuf &dIn = AS.arena[0], &dWork = AS.arena[1], &dBatch = AS.arena[2];
     // inputs
     Carver ci;
     const size_t o_start = ci.take((size_t)(nr + 1) * 4), o_type = ci.take(nr + 1), o_info = ci.take((size_t)(nr + 1) * 4),
-                 o_anchor = ci.take(R->n_anchor_kmers * 8), o_contig = ci.take((total_len + 1) / 2), o_rb = ci.take((size_t)na * 4), o_re = ci.take((size_t)na * 4),
-                 o_qae = ci.take((size_t)na * 4), o_soff = ci.take((size_t)na * 8), o_reads = ci.take(A->reads2_bytes), o_coff = ci.take((size_t)(na + 1) * 4),
-                 o_cig = ci.take(n_cig * 4);
+                 o_anchor = ci.take(R->n_anchor_kmers * 8), o_contig = ci.take((total_len + 1) / 2), o_rb = ci.take(resident ? 0 : (size_t)na * 4), o_re = ci.take(resident ? 0 : (size_t)na * 4),
+                 o_qae = ci.take(resident ? 0 : (size_t)na * 4), o_soff = ci.take(resident ? 0 : (size_t)na * 8), o_reads = ci.take(resident ? 0 : A->reads2_bytes), o_coff = ci.take(resident ? 0 : (size_t)(na + 1) * 4),
+                 o_cig = ci.take(resident ? 0 : n_cig * 4);
     HIP_TRY(dIn.alloc(ci.at));
     char* in = (char*)dIn.p;
 #define UP(off, src, bytes) do { if (bytes) HIP_TRY(hipMemcpyAsync(in + (off), (src), (bytes), hipMemcpyHostToDevice, st)); } while (0)
     UP(o_start, R->start, (size_t)(nr + 1) * 4); UP(o_type, R->type, (size_t)nr + 1); if (R->info) UP(o_info, R->info, (size_t)(nr + 1) * 4);
     UP(o_anchor, R->anchor_kmers, R->n_anchor_kmers * 8); UP(o_contig, R->contig4, (total_len + 1) / 2);
-    UP(o_rb, A->rb, (size_t)na * 4); UP(o_re, A->re, (size_t)na * 4); UP(o_qae, A->qae, (size_t)na * 4); UP(o_soff, A->seq_off, (size_t)na * 8);
-    UP(o_reads, A->reads2, A->reads2_bytes); if (na) UP(o_coff, A->cigar_off, (size_t)(na + 1) * 4); UP(o_cig, A->cigar, n_cig * 4);
+    if (!resident) {
+        UP(o_rb, A->rb, (size_t)na * 4); UP(o_re, A->re, (size_t)na * 4); UP(o_qae, A->qae, (size_t)na * 4); UP(o_soff, A->seq_off, (size_t)na * 8);
+        UP(o_reads, A->reads2, A->reads2_bytes); if (na) UP(o_coff, A->cigar_off, (size_t)(na + 1) * 4); UP(o_cig, A->cigar, n_cig * 4);
+    }
 #undef UP
     hypo::ArmsIn I;
     I.n_regions = nr; I.reg_start = (const uint32_t*)(in + o_start); I.reg_type = (const uint8_t*)(in + o_type); I.reg_info = (const uint32_t*)(in + o_info);
@@ -789,6 +916,10 @@ static int arms_build_impl(int which, const HypoArmsRegions* R, const HypoArmsRe
     I.n_alignments = na; I.rb = (const uint32_t*)(in + o_rb); I.re = (const uint32_t*)(in + o_re); I.qae = (const uint32_t*)(in + o_qae);
     I.seq_off = (const uint64_t*)(in + o_soff); I.reads2 = (const uint8_t*)(in + o_reads); I.cigar_off = (const uint32_t*)(in + o_coff);
     I.cigar = (const uint32_t*)(in + o_cig); I.max_span = max_span; I.long_mode = long_mode ? 1u : 0u;
+    if (resident) {
+        const auto& rr = g_ctx.rr;
+        I.rb = rr.rb; I.re = rr.re; I.qae = rr.qae; I.seq_off = rr.seq_off; I.reads2 = rr.reads2; I.cigar_off = rr.cigar_off; I.cigar = rr.cigar;
+    }
     // work arrays that do not depend on the number of touched regions
     Carver cw;
     const size_t scan_n = nr > na ? nr : na;

@@ -9,28 +9,21 @@
 
 namespace hypo {
 
-bool DeviceArms::build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1,
-                       std::vector<std::vector<std::unique_ptr<Alignment>>>& store, unsigned k) {
-    _active = false;
+// The short-read alignments of contigs [c0, c1) as flat arrays in one coordinate space (every contig starts on an even position:
+// its PackedSeq<4> bytes are copied as they are; an odd-length contig is followed by one filler base), on the device.
+bool DeviceArms::upload_reads(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1,
+                              std::vector<std::vector<std::unique_ptr<Alignment>>>& store) {
+    _reads_resident = false;
     wait_released();
     if (hypo_gpu_use_device(_slot) != HYPO_OK) return false;
-    const bool timing = std::getenv("HYPO_HOST_TIMING") != nullptr;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-    const auto t0 = now();
-    // one coordinate space for the whole contig batch: every contig starts on an even position (its PackedSeq<4> bytes are
-    // copied as they are); an odd-length contig is followed by a 1-base filler region of type SR
-    uint64_t total = 0, n_reg = 0, n_anchor = 0, n_aln = 0, n_cig = 0, read_bytes = 0;
+    uint64_t total = 0, n_aln = 0, n_cig = 0;
     std::vector<uint64_t> aln_base(c1 - c0 + 1, 0);
     for (uint32_t c = c0; c < c1; ++c) {
-        const Contig& ctg = *contigs[c];
-        total += ctg._len + (ctg._len & 1);
-        n_reg += ctg.get_num_regions() + (ctg._len & 1);
-        n_anchor += ctg._anchor_kmers.size();
+        total += contigs[c]->_len + (contigs[c]->_len & 1);
         aln_base[c - c0] = n_aln;
         n_aln += store[c].size();
     }
-    if (n_aln >= 0xfffffff0ull) return false;
+    if (n_aln >= 0xfffffff0ull || total >= 0xfffffff0ull) return false;
     // per alignment: bytes of its read, CIGAR operations (exclusive prefix sums below), and the sort check
     std::vector<uint64_t> seq_off(n_aln + 1);
     std::vector<uint32_t> cigar_off(n_aln + 1);
@@ -46,18 +39,150 @@ bool DeviceArms::build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c
             if (t && alns[(size_t)t - 1]->_rb > a._rb) sorted = false;
         }
     }
-    if (!sorted) { std::fprintf(stdout, "[Hypo::Hypo] Info: alignments are not sorted by position: short arms are computed on the host\n"); return false; }
+    if (!sorted) { std::fprintf(stdout, "[Hypo::Hypo] Info: alignments are not sorted by position: support votes and short arms are computed on the host\n"); return false; }
     seq_off[0] = 0; cigar_off[0] = 0;
     for (uint64_t g = 0; g < n_aln; ++g) { n_cig += cigar_off[g + 1]; if (n_cig >= 0xfffffff0ull) return false; seq_off[g + 1] += seq_off[g]; cigar_off[g + 1] += cigar_off[g]; }
-    read_bytes = seq_off[n_aln];
-    if (total >= 0xfffffff0ull || n_reg >= 0xfffffff0ull || n_aln >= 0xfffffff0ull || n_cig >= 0xfffffff0ull || n_reg == 0) return false;
+    const uint64_t read_bytes = seq_off[n_aln];
+    std::vector<uint32_t> rb(n_aln), re(n_aln), qae(n_aln), ctg_of(n_aln);
+    std::unique_ptr<uint32_t[]> cigar(new uint32_t[n_cig ? n_cig : 1]);             // (not zero-filled: every element is written below)
+    std::unique_ptr<uint8_t[]> reads2(new uint8_t[read_bytes ? read_bytes : 1]);
+    {   // the copies, on all threads
+        uint64_t cbase = 0;
+        for (uint32_t c = c0; c < c1; ++c) {
+            auto& alns = store[c];
+            const uint64_t a0 = aln_base[c - c0];
+#pragma omp parallel for schedule(static)
+            for (int64_t t = 0; t < (int64_t)alns.size(); ++t) {
+                const Alignment& a = *alns[(size_t)t];
+                const uint64_t g = a0 + (uint64_t)t;
+                rb[g] = (uint32_t)(cbase + a._rb); re[g] = (uint32_t)(cbase + a._re); qae[g] = a._qae; ctg_of[g] = c - c0;
+                std::memcpy(reads2.get() + seq_off[g], a._apseq.data(), a._apseq.byte_size());
+                std::memcpy(cigar.get() + cigar_off[g], a._cigar.data(), a._cigar.size() * 4);
+            }
+            cbase += contigs[c]->_len + (contigs[c]->_len & 1);
+        }
+    }
+    HypoArmsReads A;
+    A.n_alignments = (uint32_t)n_aln; A.rb = rb.data(); A.re = re.data(); A.qae = qae.data(); A.seq_off = seq_off.data();
+    A.reads2 = reads2.get(); A.reads2_bytes = read_bytes; A.cigar_off = cigar_off.data(); A.cigar = cigar.get();
+    const int rc = hypo_gpu_reads_upload(&A, ctg_of.data(), total);
+    if (rc != HYPO_OK) {
+        if (rc != HYPO_E_UNSUPPORTED) std::fprintf(stdout, "[Hypo::Hypo] Info: support votes and short arms are computed on the host (%s)\n", hypo_gpu_last_error());
+        return false;
+    }
+    _reads_resident = true; _reads_c0 = c0; _reads_c1 = c1;
+    return true;
+}
+
+// Alignment::update_solidkmers_support for every resident read at once (support_kernel.hip): the solid k-mers of the contigs go
+// over as positions + k-mers, KmerInfo::coverage / support come back.
+bool DeviceArms::support_kmers(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1, unsigned k) {
+    if (!_reads_resident || c0 != _reads_c0 || c1 != _reads_c1 || hypo_gpu_use_device(_slot) != HYPO_OK) return false;
+    uint64_t ns = 0;
+    std::vector<uint64_t> kbase(c1 - c0 + 1, 0);
+    for (uint32_t c = c0; c < c1; ++c) { kbase[c - c0] = ns; ns += contigs[c]->_kids.size(); }
+    kbase[c1 - c0] = ns;
+    if (ns == 0) return true;
+    if (ns >= 0xfffffff0ull) return false;
+    std::vector<uint32_t> spos(ns), cov(ns), sup(ns);
+    std::vector<uint64_t> kids(ns);
+    uint64_t cbase = 0;
+    for (uint32_t c = c0; c < c1; ++c) {
+        const Contig& ctg = *contigs[c];
+        const uint64_t b = kbase[c - c0], n = ctg._kids.size();
+        std::memcpy(kids.data() + b, ctg._kids.data(), n * 8);
+#pragma omp parallel for schedule(static, 4096)
+        for (int64_t i = 0; i < (int64_t)n; ++i) spos[b + (uint64_t)i] = (uint32_t)(cbase + ctg._solid_pos.select((uint64_t)i + 1));
+        cbase += ctg._len + (ctg._len & 1);
+    }
+    const int rc = hypo_gpu_support_kmers(k, ns, spos.data(), kids.data(), cov.data(), sup.data());
+    if (rc != HYPO_OK) {
+        if (rc != HYPO_E_UNSUPPORTED) std::fprintf(stdout, "[Hypo::Hypo] Info: k-mer support is counted on the host (%s)\n", hypo_gpu_last_error());
+        return false;
+    }
+    for (uint32_t c = c0; c < c1; ++c) {
+        Contig& ctg = *contigs[c];
+        const uint64_t b = kbase[c - c0], n = ctg._kids.size();
+        std::memcpy(ctg._kcov.data(), cov.data() + b, n * 4);
+        std::memcpy(ctg._ksup.data(), sup.data() + b, n * 4);
+    }
+    std::fprintf(stdout, "[Hypo::Hypo] Info: k-mer support counted on the device: %llu solid k-mers\n", (unsigned long long)ns);
+    return true;
+}
+
+// Alignment::update_minimisers_support likewise: region borders and the minimizers of the mega-windows go over, MWMinimiserInfo::
+// coverage / support come back.
+bool DeviceArms::support_minimizers(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1) {
+    if (!_reads_resident || c0 != _reads_c0 || c1 != _reads_c1 || hypo_gpu_use_device(_slot) != HYPO_OK) return false;
+    const uint32_t nc = c1 - c0;
+    std::vector<uint32_t> contig_base(nc), reg_base(nc + 1, 0), info_base(nc), start, mw_off(1, 0), rel_pos, minimisers;
+    std::vector<uint8_t> even(nc);
+    uint64_t cbase = 0, n_info = 0;
+    for (uint32_t c = c0; c < c1; ++c) {
+        const Contig& ctg = *contigs[c];
+        contig_base[c - c0] = (uint32_t)cbase;
+        even[c - c0] = ctg._is_win_even ? 1 : 0;
+        info_base[c - c0] = (uint32_t)n_info;
+        const uint64_t nb = ctg._reg_pos.count();               // set bits: 0, SR starts and ends, the length
+        const size_t s0 = start.size();
+        start.resize(s0 + nb);
+#pragma omp parallel for schedule(static, 4096)
+        for (int64_t i = 0; i < (int64_t)nb; ++i) start[s0 + (size_t)i] = (uint32_t)ctg._reg_pos.select((uint64_t)i + 1);
+        reg_base[c - c0 + 1] = (uint32_t)start.size();
+        for (const MWMinimiserInfo& mi : ctg._minimserinfo) {
+            rel_pos.insert(rel_pos.end(), mi.rel_pos.begin(), mi.rel_pos.end());
+            minimisers.insert(minimisers.end(), mi.minimisers.begin(), mi.minimisers.end());
+            mw_off.push_back((uint32_t)rel_pos.size());
+        }
+        n_info += ctg._minimserinfo.size();
+        cbase += ctg._len + (ctg._len & 1);
+    }
+    if (rel_pos.empty()) return true;
+    if (start.size() >= 0xfffffff0ull || rel_pos.size() >= 0xfffffff0ull) return false;
+    std::vector<uint32_t> cov(rel_pos.size()), sup(rel_pos.size());
+    HypoMegaWindows W;
+    W.n_contigs = nc; W.contig_base = contig_base.data(); W.reg_base = reg_base.data(); W.win_even = even.data(); W.info_base = info_base.data();
+    W.start = start.data(); W.n_info = (uint32_t)n_info; W.mw_off = mw_off.data(); W.rel_pos = rel_pos.data(); W.minimisers = minimisers.data();
+    const int rc = hypo_gpu_support_minimizers(&W, cov.data(), sup.data());
+    if (rc != HYPO_OK) {
+        if (rc != HYPO_E_UNSUPPORTED) std::fprintf(stdout, "[Hypo::Hypo] Info: minimizer support is counted on the host (%s)\n", hypo_gpu_last_error());
+        return false;
+    }
+    size_t x = 0;
+    for (uint32_t c = c0; c < c1; ++c)
+        for (MWMinimiserInfo& mi : contigs[c]->_minimserinfo) {
+            const size_t e0 = mw_off[x], n = mi.rel_pos.size();
+            for (size_t m = 0; m < n; ++m) { mi.coverage[m] = cov[e0 + m]; mi.support[m] = sup[e0 + m]; }
+            ++x;
+        }
+    std::fprintf(stdout, "[Hypo::Hypo] Info: minimizer support counted on the device: %llu minimizers\n", (unsigned long long)rel_pos.size());
+    return true;
+}
+
+bool DeviceArms::build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1,
+                       std::vector<std::vector<std::unique_ptr<Alignment>>>& store, unsigned k) {
+    _active = false;
+    wait_released();
+    if (hypo_gpu_use_device(_slot) != HYPO_OK) return false;
+    const bool timing = std::getenv("HYPO_HOST_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const auto t0 = now();
+    // the reads: resident since the support votes, or put there now
+    if (!(_reads_resident && c0 == _reads_c0 && c1 == _reads_c1) && !upload_reads(contigs, c0, c1, store)) return false;
+    _reads_resident = false;                                   // (this build consumes them: the next batch uploads its own)
+    uint64_t total = 0, n_reg = 0, n_anchor = 0;
+    for (uint32_t c = c0; c < c1; ++c) {
+        const Contig& ctg = *contigs[c];
+        total += ctg._len + (ctg._len & 1);
+        n_reg += ctg.get_num_regions() + (ctg._len & 1);
+        n_anchor += ctg._anchor_kmers.size();
+    }
+    if (total >= 0xfffffff0ull || n_reg >= 0xfffffff0ull || n_reg == 0) return false;
     std::vector<uint32_t> start(n_reg + 1), info(n_reg + 1, 0);
     std::vector<uint8_t> type(n_reg + 1, (uint8_t)RegionType::SR);
     std::vector<uint64_t> anchors; anchors.reserve(n_anchor);
     std::vector<uint8_t> contig4((total + 1) / 2, 0);
-    std::vector<uint32_t> rb(n_aln), re(n_aln), qae(n_aln);
-    std::unique_ptr<uint32_t[]> cigar(new uint32_t[n_cig ? n_cig : 1]);             // (not zero-filled: every element is written below)
-    std::unique_ptr<uint8_t[]> reads2(new uint8_t[read_bytes ? read_bytes : 1]);
     _reg_window.assign(n_reg, nullptr);
     uint64_t base = 0, r = 0;
     for (uint32_t c = c0; c < c1; ++c) {
@@ -80,31 +205,12 @@ bool DeviceArms::build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c
         base += ctg._len + (ctg._len & 1);
     }
     start[r] = (uint32_t)total;
-    {   // the copies, on all threads; an alignment is released as soon as it is copied (its arms will never be cut on the host)
-        uint64_t cbase = 0;
-        for (uint32_t c = c0; c < c1; ++c) {
-            auto& alns = store[c];
-            const uint64_t a0 = aln_base[c - c0];
-#pragma omp parallel for schedule(static)
-            for (int64_t t = 0; t < (int64_t)alns.size(); ++t) {
-                const Alignment& a = *alns[(size_t)t];
-                const uint64_t g = a0 + (uint64_t)t;
-                rb[g] = (uint32_t)(cbase + a._rb); re[g] = (uint32_t)(cbase + a._re); qae[g] = a._qae;
-                std::memcpy(reads2.get() + seq_off[g], a._apseq.data(), a._apseq.byte_size());
-                std::memcpy(cigar.get() + cigar_off[g], a._cigar.data(), a._cigar.size() * 4);
-            }
-            cbase += contigs[c]->_len + (contigs[c]->_len & 1);
-        }
-    }
     HypoArmsRegions R;
     R.n_regions = (uint32_t)n_reg; R.start = start.data(); R.type = type.data(); R.info = info.data();
     R.n_anchor_kmers = anchors.size(); R.anchor_kmers = anchors.data(); R.k = k; R.contig4 = contig4.data();
-    HypoArmsReads A;
-    A.n_alignments = (uint32_t)n_aln; A.rb = rb.data(); A.re = re.data(); A.qae = qae.data(); A.seq_off = seq_off.data();
-    A.reads2 = reads2.get(); A.reads2_bytes = read_bytes; A.cigar_off = cigar_off.data(); A.cigar = cigar.get();
     std::vector<uint8_t> valid(n_reg, 0);
     const auto t1 = now();
-    const int rc = hypo_gpu_arms_build(&R, &A, valid.data(), &_sum);
+    const int rc = hypo_gpu_arms_build(&R, nullptr, valid.data(), &_sum);       // the resident reads
     const auto t2 = now();
     if (rc != HYPO_OK) {
         if (rc != HYPO_E_UNSUPPORTED) std::fprintf(stdout, "[Hypo::Hypo] Info: short arms are computed on the host (%s)\n", hypo_gpu_last_error());

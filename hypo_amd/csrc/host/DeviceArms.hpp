@@ -26,6 +26,13 @@ public:
     bool build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1,
                std::vector<std::vector<std::unique_ptr<Alignment>>>& store, unsigned k);
     bool active() const { return _active; }
+    // N1: the short reads of contigs [c0, c1) go to the device once, right after they were loaded; the support votes
+    // (Alignment::update_solidkmers_support / update_minimisers_support, src/Alignment.cpp:65-220) are counted there and come back
+    // into the contigs' counters, and build() later cuts the same resident copy into arms.  false: nothing changed, host loops.
+    bool upload_reads(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1,
+                      std::vector<std::vector<std::unique_ptr<Alignment>>>& store);
+    bool support_kmers(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1, unsigned k);
+    bool support_minimizers(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1);
     // consensus of every SHORT window of the resident batch; `keep_arms`: also copy the arms into the Window objects.  Windows
     // whose status asks for the host's retry / degraded path (a consensus longer than its slot, a window beyond the size classes)
     // get their arms and are appended to `retry` (the caller runs Window::generate_consensus_batch on them: one call for all
@@ -44,6 +51,7 @@ public:
 
 private:
     int _slot = 0;
+    bool _reads_resident = false; uint32_t _reads_c0 = 0, _reads_c1 = 0;
     bool _active = false;
     HypoArmsSummary _sum{};
     std::vector<std::vector<std::unique_ptr<Alignment>>> _spent;   // the alignments of the batch, on their way out

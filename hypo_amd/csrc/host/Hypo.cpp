@@ -95,12 +95,43 @@ void Hypo::polish() {
         create_alignments(true, batch_id);
         stop("[Hypo:Hypo]: Loaded alignments. ");
 
-        start();
-        for (uint32_t cid = initial_cid; cid < final_cid; ++cid) {
-            auto& alns = _alignment_store[cid];
-#pragma omp parallel for
-            for (int64_t t = 0; t < (int64_t)alns.size(); ++t) alns[(size_t)t]->update_solidkmers_support(_cFlags.k, *_contigs[cid]);
+        // With several devices the contigs of the batch are dealt out to the contexts in contiguous ranges of about equal
+        // numbers of alignments (a batch with fewer contigs than devices stays on the first one): every context keeps the reads of
+        // its contigs, counts their support votes, cuts their arms and polishes its own resident windows; no window travels.
+        for (auto& da : device_arms) da->wait_released();      // (the previous batch's alignments, still on their way out)
+        std::vector<uint32_t> ctx_cut((size_t)n_ctx + 1, final_cid);
+        ctx_cut[0] = initial_cid;
+        if ((uint32_t)n_ctx > 1 && final_cid - initial_cid >= (uint32_t)n_ctx) {
+            uint64_t total = 0, acc = 0;
+            for (uint32_t c = initial_cid; c < final_cid; ++c) total += _alignment_store[c].size() + 1;
+            int d = 1;
+            for (uint32_t c = initial_cid; c < final_cid && d < n_ctx; ++c) {
+                acc += _alignment_store[c].size() + 1;
+                // the cut behind contig c belongs to context d when the first d shares are full (every context gets >= 1 contig)
+                while (d < n_ctx && acc * (uint64_t)n_ctx >= total * (uint64_t)d && final_cid - (c + 1) >= (uint32_t)(n_ctx - d)) ctx_cut[(size_t)d++] = c + 1;
+            }
+            for (; d < n_ctx; ++d) ctx_cut[(size_t)d] = std::max(ctx_cut[(size_t)d - 1] + 1, final_cid - (uint32_t)(n_ctx - d));
         }
+        // N1: the reads go to the device once, now; the support votes are counted there (support_kernel.hip) and the arm kernels
+        // use the same copy later.  --host-arms, an unsorted file or a device error: the reference's host loops, per contig range.
+        start();
+        std::vector<char> votes_dev((size_t)n_ctx, 0);         // per context: its reads are resident
+        if (!_cFlags.host_arms && !std::getenv("HYPO_HOST_SUPPORT"))
+            for (int d = 0; d < n_ctx; ++d) {
+                const uint32_t c0 = ctx_cut[(size_t)d], c1 = ctx_cut[(size_t)d + 1];
+                if (c0 < c1) votes_dev[(size_t)d] = device_arms[(size_t)d]->upload_reads(_contigs, c0, c1, _alignment_store) ? 1 : 0;
+            }
+        for (int d = 0; d < n_ctx; ++d) {
+            const uint32_t c0 = ctx_cut[(size_t)d], c1 = ctx_cut[(size_t)d + 1];
+            if (c0 >= c1) continue;
+            if (votes_dev[(size_t)d] && device_arms[(size_t)d]->support_kmers(_contigs, c0, c1, _cFlags.k)) continue;
+            for (uint32_t cid = c0; cid < c1; ++cid) {
+                auto& alns = _alignment_store[cid];
+#pragma omp parallel for
+                for (int64_t t = 0; t < (int64_t)alns.size(); ++t) alns[(size_t)t]->update_solidkmers_support(_cFlags.k, *_contigs[cid]);
+            }
+        }
+        hypo_gpu_use_device(0);
         stop("[Hypo:Hypo]: Solid kmers support update. ");
 
         start();
@@ -112,11 +143,17 @@ void Hypo::polish() {
         stop("[Hypo:Hypo]: Finding SR (and preparing for division). ");
 
         start();
-        for (uint32_t cid = initial_cid; cid < final_cid; ++cid) {
-            auto& alns = _alignment_store[cid];
+        for (int d = 0; d < n_ctx; ++d) {
+            const uint32_t c0 = ctx_cut[(size_t)d], c1 = ctx_cut[(size_t)d + 1];
+            if (c0 >= c1) continue;
+            if (votes_dev[(size_t)d] && device_arms[(size_t)d]->support_minimizers(_contigs, c0, c1)) continue;
+            for (uint32_t cid = c0; cid < c1; ++cid) {
+                auto& alns = _alignment_store[cid];
 #pragma omp parallel for
-            for (int64_t t = 0; t < (int64_t)alns.size(); ++t) alns[(size_t)t]->update_minimisers_support(*_contigs[cid]);
+                for (int64_t t = 0; t < (int64_t)alns.size(); ++t) alns[(size_t)t]->update_minimisers_support(*_contigs[cid]);
+            }
         }
+        hypo_gpu_use_device(0);
         stop("[Hypo:Hypo]: Minimisers support update. ");
 
         start();
@@ -127,26 +164,9 @@ void Hypo::polish() {
         start();
         // The device cuts the reads into arms, prunes the windows and keeps the window batch in its memory (DeviceArms.hpp);
         // --host-arms, several devices or an unsorted alignment file take the host loops of the reference instead.
-        // With several devices the contigs of the batch are dealt out to the contexts in contiguous ranges of about equal
-        // numbers of alignments (a batch with fewer contigs than devices stays on the first one): every context cuts the arms of
-        // its contigs and polishes its own resident windows, no window travels between devices.
-        for (auto& da : device_arms) da->wait_released();      // (the previous batch's alignments, still on their way out)
         std::vector<char> on_dev(final_cid - initial_cid, 0);  // per contig of the batch: its short arms were cut on a device
         std::vector<char> long_dev(final_cid - initial_cid, 0);  // ... and its long arms (LONG windows resident on the device)
-        std::vector<uint32_t> ctx_cut((size_t)n_ctx + 1, final_cid);
-        ctx_cut[0] = initial_cid;
         if (!_cFlags.host_arms) {
-            if ((uint32_t)n_ctx > 1 && final_cid - initial_cid >= (uint32_t)n_ctx) {
-                uint64_t total = 0, acc = 0;
-                for (uint32_t c = initial_cid; c < final_cid; ++c) total += _alignment_store[c].size() + 1;
-                int d = 1;
-                for (uint32_t c = initial_cid; c < final_cid && d < n_ctx; ++c) {
-                    acc += _alignment_store[c].size() + 1;
-                    // the cut behind contig c belongs to context d when the first d shares are full (every context gets >= 1 contig)
-                    while (d < n_ctx && acc * (uint64_t)n_ctx >= total * (uint64_t)d && final_cid - (c + 1) >= (uint32_t)(n_ctx - d)) ctx_cut[(size_t)d++] = c + 1;
-                }
-                for (; d < n_ctx; ++d) ctx_cut[(size_t)d] = std::max(ctx_cut[(size_t)d - 1] + 1, final_cid - (uint32_t)(n_ctx - d));
-            }
             for (int d = 0; d < n_ctx; ++d) {
                 const uint32_t c0 = ctx_cut[(size_t)d], c1 = ctx_cut[(size_t)d + 1];
                 if (c0 >= c1) continue;

@@ -275,7 +275,7 @@ typedef struct HypoArmsSummary {
 } HypoArmsSummary;
 /* region_valid: [n_regions] out, 1 where the region keeps a SHORT window.  HYPO_E_CAPACITY: the batch exceeds the 32-bit
  * counters of the boundary (use the host path or smaller contig batches). */
-int hypo_gpu_arms_build(const HypoArmsRegions* regions, const HypoArmsReads* reads, uint8_t* region_valid, HypoArmsSummary* summary);
+int hypo_gpu_arms_build(const HypoArmsRegions* regions, const HypoArmsReads* reads /* NULL: the reads of hypo_gpu_reads_upload */, uint8_t* region_valid, HypoArmsSummary* summary);
 /* Any pointer may be NULL.  windows [n_windows], win_region [n_windows] (region of every window), arm_len / arm_off [n_arms],
  * arms2 [arms2_bytes], draft4 [draft4_bytes]. */
 int hypo_gpu_arms_download(HypoWindow* windows, uint32_t* win_region, uint32_t* arm_len, uint64_t* arm_off, uint8_t* arms2, uint8_t* draft4);
@@ -296,6 +296,34 @@ int hypo_gpu_arms_poa(const HypoScoreParams* scores, char* bases, uint64_t* off,
 int hypo_gpu_arms_build_long(const HypoArmsRegions* pseudo_regions, const HypoArmsReads* long_reads, uint8_t* region_valid, HypoArmsSummary* summary);
 int hypo_gpu_arms_download_long(HypoWindow* windows, uint32_t* win_region, uint32_t* arm_len, uint64_t* arm_off, uint8_t* arms2, uint8_t* draft4);
 int hypo_gpu_arms_poa_long(const HypoScoreParams* scores, char* bases, uint64_t* off, uint32_t* len, uint8_t* status);
+
+/* ---- Support votes on the device (ABI 6) --------------------------------------------------------------------
+ * Replaces the two per-alignment loops that count, for every solid k-mer and every mega-window minimizer of the draft, the
+ * reads that cover it and the reads that support it:
+ *   Alignment::update_solidkmers_support   src/Alignment.cpp:65-132    (mutex per k-mer, include/Contig.hpp:207-214)
+ *   Alignment::update_minimisers_support   src/Alignment.cpp:134-220
+ * hypo_gpu_reads_upload puts the short-read alignments of a contig batch on the device once (same arrays and coordinate space
+ * as hypo_gpu_arms_build; read_contig[a] = index of the read's contig in the batch; total_len = size of the coordinate space);
+ * the two support calls vote with that copy, and hypo_gpu_arms_build(regions, NULL, ...) later cuts the same copy into arms.
+ * Counters are 32-bit on the device; the reference's are 16-bit and wrap (the host reads them through & 0xffff). */
+int hypo_gpu_reads_upload(const HypoArmsReads* reads, const uint32_t* read_contig, uint64_t total_len);
+/* spos [n_solid]: positions of the solid k-mers of the coordinate space, ascending (Contig::_solid_pos); kids [n_solid]: their
+ * k-mers (KmerInfo::kid).  OUT coverage / support [n_solid] (KmerInfo::coverage / support). */
+int hypo_gpu_support_kmers(uint32_t k, uint64_t n_solid, const uint32_t* spos, const uint64_t* kids, uint32_t* coverage, uint32_t* support);
+typedef struct HypoMegaWindows {     /* Contig::_reg_pos / _is_win_even / _minimserinfo after prepare_for_division */
+    uint32_t        n_contigs;
+    const uint32_t* contig_base;     /* [n_contigs] start of the contig in the coordinate space */
+    const uint32_t* reg_base;        /* [n_contigs + 1] first entry of the contig in `start` */
+    const uint8_t*  win_even;        /* [n_contigs] Contig::_is_win_even */
+    const uint32_t* info_base;       /* [n_contigs] index of the contig's first MWMinimiserInfo */
+    const uint32_t* start;           /* contig-local region borders (set bits of _reg_pos: 0, SR starts and ends, the length) */
+    uint32_t        n_info;
+    const uint32_t* mw_off;          /* [n_info + 1] entries of every MWMinimiserInfo */
+    const uint32_t* rel_pos;         /* per entry: MWMinimiserInfo::rel_pos */
+    const uint32_t* minimisers;      /* per entry: MWMinimiserInfo::minimisers */
+} HypoMegaWindows;
+/* OUT coverage / support [mw_off[n_info]] (MWMinimiserInfo::coverage / support). */
+int hypo_gpu_support_minimizers(const HypoMegaWindows* windows, uint32_t* coverage, uint32_t* support);
 
 /* Kernel timing with HIP events on the stream the kernels run on ----------------------------------
  * hypo_gpu_profile_begin(max_calls) arms the next max_calls (<= 256) *_device calls: each records
