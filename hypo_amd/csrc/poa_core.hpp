@@ -129,6 +129,12 @@ struct PoaCfg {
     // the packed row loop: int16 rows, 4-bit direction codes, an even number of columns per lane, state in LDS
     static constexpr bool PACKED = HYPO_PACKED && sizeof(ScoreT) == 2 && CPL_ % 2 == 0 && CPL_ <= 8 && !HYBRID_ && (KIN_ <= 7);
     static constexpr bool HYBRID = HYBRID_;     // state in HBM scratch except the arrays the graph walks hammer (PoaLayout::FAST_BYTES of LDS)
+    // ... and the hybrid class runs its int16 rows on packed pairs as well (Poa::rows_pk_hyb: the dense ring, byte codes, any
+    // in-degree); HYPO_PACKED_HYB=0 keeps the one-column-per-register loop there
+#ifndef HYPO_PACKED_HYB
+#define HYPO_PACKED_HYB 1
+#endif
+    static constexpr bool PACKED_HYB = HYPO_PACKED_HYB && HYBRID_ && sizeof(ScoreT) == 2 && CPL_ % 2 == 0 && PATHCAP_ > 0;
     static constexpr int PATHCAP = PATHCAP_;    // node ids of the sequences' paths (LONG windows only; 0 = class cannot run them)
     static constexpr int GW = GW_;              // lanes per window
     static constexpr int CPL = CPL_;            // matrix columns per lane
@@ -1260,6 +1266,198 @@ struct Poa {
         return (int)first;                                   // group-uniform; -1: no perfect candidate
     }
 
+    // ---- the hybrid class's score rows on packed pairs of int16 columns ------------------------------------------------------
+    // Same recurrence, tie rules and byte codes as the one-column-per-register loop in align() (which classes without int16 rows
+    // keep), in the arithmetic of rows_pk: two columns per register, every select a multiply-add on t = min_u16(a - b, 1).  The
+    // hybrid class's own furniture stays: the dense ring (row i in slot i mod R of the HBM ring when a far row reads it, the
+    // RING1 most recent rows in LDS), row metadata and the second predecessor's row refilled 64 rows at a time, 8-bit codes
+    // (any in-degree), the list of rows tied for the end row that the lazy rank order needs (*ntie_out, newslot[]).
+    // Returns the end row as lane `L / CPL` sees it (the caller broadcasts), like the loop it replaces.
+    HD int rows_pk_hyb(int mode, int m, int n, int gp, int S, int R, int* ntie_out) {
+        constexpr int NP = CPL / 2;
+        constexpr int TIECAP = 48;
+        const int j0 = CPL * g.lane;
+        int amax = m < 0 ? -m : m; { const int b = n < 0 ? -n : n, c2 = gp < 0 ? -gp : gp; amax = amax > b ? amax : b; amax = amax > c2 ? amax : c2; }
+        const int NEG16 = -32768 + amax;
+        P2 SQ[NP], JG[NP], LAST[NP];
+        HYPO_UNROLL
+        for (int q = 0; q < NP; ++q) {
+            const int j = j0 + 2 * q;
+            const int s0 = (j >= 1 && j <= L) ? (int)seq[j - 1] : (int)C_NONE;
+            const int s1 = (j + 1 <= L) ? (int)seq[j] : (int)C_NONE;
+            SQ[q] = pk_make(s0, s1);
+            JG[q] = pk_make(j * gp, (j + 1) * gp);           // row 0: H[0][j] = j*g
+            LAST[q] = JG[q];
+        }
+        int vM = pk_bits(pk_splat(m)), vMN = pk_bits(pk_splat(n - m)), vGP = pk_bits(pk_splat(gp)), vONE = pk_bits(pk_splat(1));
+        HYPO_IN_VGPR(vM); HYPO_IN_VGPR(vMN); HYPO_IN_VGPR(vGP); HYPO_IN_VGPR(vONE);
+        const P2 M = pk_from_bits(vM), MN = pk_from_bits(vMN), GP = pk_from_bits(vGP), ONE = pk_from_bits(vONE);
+        const int negfill = pk_bits(pk_splat(NEG16));
+        const int keep0 = (g.lane == 0 && mode == MODE_ROV) ? (int)0xffff0000u : -1;      // kROV: first column is 0
+        const int le = L / CPL, ce = L % CPL;
+        const int ce_shift = 16 * (ce & 1);
+        int best = NEG, best_i = -1, ntie = 0;
+        const bool native_lov = mode == MODE_LOV && (P->flags & POA_NATIVE_KLOV) != 0;
+        auto end_value = [&](const P2 (&v)[NP]) -> int {
+            if (native_lov) {
+                int mx = NEG;
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) {
+                    const int c0 = j0 + 2 * q;
+                    if (c0 >= 1 && c0 <= L) { const int x = pk_lo(v[q]); mx = x > mx ? x : mx; }
+                    if (c0 + 1 >= 1 && c0 + 1 <= L) { const int x = pk_hi(v[q]); mx = x > mx ? x : mx; }
+                }
+                return g.reduce_max(mx);
+            }
+            int w = pk_bits(v[0]);
+            HYPO_UNROLL
+            for (int q = 1; q < NP; ++q) if (ce / 2 == q) w = pk_bits(v[q]);
+            return (int)(int16_t)(uint16_t)((uint32_t)w >> ce_shift);     // column L: meaningful in lane `le` only
+        };
+        int slot = 0, slotS = 0, rowS = 0;
+        const int RS = R * S;
+        constexpr int R1 = Cfg::RING1;
+        int slot1S = 0;
+        const int R1S = R1 * S;
+        int nbreg = negfill, exreg = (int)0x80000000;
+        uint32_t mchunk = 0u;
+        int p1chunk = 0;
+        auto load_pk = [&](const score_t* base, int off, P2 (&out)[NP]) {
+            if (j0 < S) {
+                const PackP pk = *(const PackP*)(base + off + j0);
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) out[q] = pk.v[q];
+            } else {
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) out[q] = pk_from_bits(negfill);
+            }
+        };
+        auto load_row = [&](int i, int pr, P2 (&out)[NP]) {          // matrix row pr as row i sees it
+            if (R1 > 0 && i - pr <= R1) { int ps = slot1S - (i - pr) * S; ps = ps < 0 ? ps + R1S : ps; load_pk(ring1, ps, out); }
+            else { int ps = slotS - (i - pr) * S; ps = ps < 0 ? ps + RS : ps; load_pk(ring, ps, out); }
+        };
+        auto hscan = [&](P2 (&v)[NP]) {
+            P2 x[NP];
+            x[0] = pk_fold_hi(pk_sub(v[0], JG[0]));
+            HYPO_UNROLL
+            for (int q = 1; q < NP; ++q) x[q] = pk_fold_hi(pk_max(pk_sub(v[q], JG[q]), pk_hi_splat(x[q - 1])));
+            exreg = g.scan_max_excl_c(pk_bits(x[NP - 1]), exreg);
+            const P2 EX = pk_hi_splat(pk_from_bits(exreg));
+            HYPO_UNROLL
+            for (int q = 0; q < NP; ++q) v[q] = pk_add(pk_max(x[q], EX), JG[q]);
+        };
+        for (int r = 0; r < n_nodes; ++r) {
+            const int i = r + 1;
+            if ((r & 63) == 0) {
+                mchunk = r + g.lane < n_nodes ? rowmeta[r + g.lane] : 0u;
+                if (KIN >= 2) { p1chunk = r + g.lane < n_nodes ? (int)predrows[(r + g.lane) * KIN + 1] : 0; HYPO_ARRIVED(p1chunk); }
+                HYPO_ARRIVED(mchunk);
+            }
+            const uint32_t meta = (uint32_t)g.shfl((int)mchunk, r & 63);
+            const int cd = meta_code(meta), k = meta_k(meta);
+            const bool sink = meta_sink(meta);
+            const int p0 = meta_p0(meta);                    // 0 when k == 0 (virtual source row)
+            const bool fastrow = p0 == i - 1;
+            const int fastcode = fastrow ? (int)DIR_FAST : dir_diag(0);
+            P2 MV[NP];
+            {
+                const P2 CD = pk_splat(cd);
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) MV[q] = pk_mad(pk_minu(pk_xor(SQ[q], CD), ONE), MN, M);
+            }
+            P2 D[NP], U[NP], cD[NP], cU[NP];
+            {
+                P2 hp[NP];
+                if (fastrow) { HYPO_UNROLL for (int q = 0; q < NP; ++q) hp[q] = LAST[q]; }
+                else if (p0 == 0) { HYPO_UNROLL for (int q = 0; q < NP; ++q) hp[q] = JG[q]; }
+                else load_row(i, p0, hp);
+                const int nb = nbreg = g.shfl_up1(pk_bits(hp[NP - 1]), nbreg);
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) {
+                    D[q] = pk_add(pk_shift_in(q ? hp[q - 1] : pk_from_bits(nb), hp[q]), MV[q]);
+                    U[q] = pk_add(hp[q], GP);
+                }
+            }
+            if (k > 1) {                                     // several predecessors: remember which one reaches each maximum first
+                P2 pD[NP], pU[NP];
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) { pD[q] = pk_splat(0); pU[q] = pk_splat(0); }
+                for (int p = 1; p < k; ++p) {
+                    P2 hp[NP];
+                    const int pr = (KIN >= 2 && p == 1) ? g.shfl(p1chunk, r & 63) : g.uniform(pred_row(r, p));
+                    load_row(i, pr, hp);
+                    const int nb = nbreg = g.shfl_up1(pk_bits(hp[NP - 1]), nbreg);
+                    const P2 PP = pk_splat(p);
+                    HYPO_UNROLL
+                    for (int q = 0; q < NP; ++q) {
+                        const P2 d = pk_add(pk_shift_in(q ? hp[q - 1] : pk_from_bits(nb), hp[q]), MV[q]);
+                        const P2 u = pk_add(hp[q], GP);
+                        const P2 nd = pk_max(D[q], d), nu = pk_max(U[q], u);
+                        pD[q] = pk_mad(pk_minu(pk_sub(nd, D[q]), ONE), pk_sub(PP, pD[q]), pD[q]);      // strict: the first pred reaching the maximum wins
+                        pU[q] = pk_mad(pk_minu(pk_sub(nu, U[q]), ONE), pk_sub(PP, pU[q]), pU[q]);
+                        D[q] = nd; U[q] = nu;
+                    }
+                }
+                const P2 FC = pk_splat(fastcode);
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) {               // byte codes: dir_diag(p) = 2 p, dir_vert(p) = 2 p + 1
+                    cD[q] = pk_mad(pk_sub(ONE, pk_minu(pD[q], ONE)), FC, pk_add(pD[q], pD[q]));
+                    cU[q] = pk_add(pk_add(pU[q], pU[q]), ONE);
+                }
+            } else {
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) { cD[q] = pk_splat(fastcode); cU[q] = pk_splat(dir_vert(0)); }
+            }
+            P2 v[NP];
+            HYPO_UNROLL
+            for (int q = 0; q < NP; ++q) v[q] = pk_max(D[q], U[q]);
+            v[0] = pk_from_bits(pk_bits(v[0]) & keep0);
+            hscan(v);
+            if (j0 < S) {
+                const P2 HZ = pk_splat(DIR_HORIZ);
+                DPack dk;
+                PackP pk;
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) {
+                    const P2 tD = pk_minu(pk_sub(v[q], D[q]), ONE), tU = pk_minu(pk_sub(v[q], U[q]), ONE);
+                    const uint32_t b = (uint32_t)pk_bits(pk_mad(tD, pk_mad(tU, pk_sub(HZ, cU[q]), pk_sub(cU[q], cD[q])), cD[q]));
+                    dk.v[2 * q] = (uint8_t)b; dk.v[2 * q + 1] = (uint8_t)(b >> 16);
+                    pk.v[q] = v[q];
+                }
+                *(DPack*)(dir + rowS + j0) = dk;
+                if (R1 > 0) {
+                    *(PackP*)(ring1 + slot1S + j0) = pk;
+                    if (meta & META_DEEP) *(PackP*)(ring + slotS + j0) = pk;      // read again from further back than the LDS ring reaches
+                } else {
+                    *(PackP*)(ring + slotS + j0) = pk;
+                }
+            }
+            slot = slot + 1 == R ? 0 : slot + 1;
+            slotS = slot == 0 ? 0 : slotS + S;
+            if (R1 > 0) slot1S = slot1S + S == R1S ? 0 : slot1S + S;
+            rowS += S;
+            HYPO_UNROLL
+            for (int q = 0; q < NP; ++q) LAST[q] = v[q];
+            if (mode == MODE_LOV || sink) {                  // end cell: first strictly greater in rank order (sisd..cpp:279-288,332-339)
+                HYPO_NO_IFCVT();
+                const int val = end_value(v);
+                if (native_lov) { if (val > best) { best = val; best_i = i; } }
+                else if (g.lane == le) {
+                    if constexpr (Cfg::LAZY) {               // lazy rank order: rows that tie for the end row are remembered
+                        if (lazy_on) {
+                            if (val > best) { ntie = 1; newslot[0] = (int16_t)i; }
+                            else if (val == best) { if (ntie < TIECAP) newslot[ntie] = (int16_t)i; ++ntie; }
+                        }
+                    }
+                    if (val > best) { best = val; best_i = i; }
+                }
+            }
+            g.sync();
+        }
+        *ntie_out = ntie;
+        return g.shfl(best_i, le);
+    }
+
     // [tb_fv, L) and tb_steps (number of traceback steps; 0 = "empty alignment").
     HD int align(int mode, int m, int n, int gp) {
         tb_steps = 0; tb_fv = L;
@@ -1275,7 +1473,7 @@ struct Poa {
             int a = m < 0 ? -m : m, b = n < 0 ? -n : n, c2 = gp < 0 ? -gp : gp;
             a = a > b ? a : b; a = a > c2 ? a : c2;
             if (a * (n_nodes + L + 1) >= 32767) return RES_OVERFLOW;
-            if (PK && a * (n_nodes + 2 * L + CPL + 8) >= 32767) return RES_OVERFLOW;   // rows_pk: H - j*g and NEG16 + score in 16 bits
+            if ((PK || Cfg::PACKED_HYB) && a * (n_nodes + 2 * L + CPL + 8) >= 32767) return RES_OVERFLOW;   // rows_pk: H - j*g and NEG16 + score in 16 bits
         }
         if (meta_dirty) { build_rowmeta(); HYPO_TICK(PH_META); }
         const int R = g.uniform(Cfg::RINGCELLS / S);        // ring rows; row i can still see rows i-R .. i-1
@@ -1310,6 +1508,13 @@ struct Poa {
             if (best_i <= 0) { best_i = rows_pk(mode, m, n, gp, S, R); stat_add(ST_CSCORED, (uint32_t)((n_nodes + 1) * W)); HYPO_DIAG(rows_scored_n += (uint32_t)n_nodes); }
         } else {
         stat_add(ST_CSCORED, (uint32_t)((n_nodes + 1) * W));
+        int ntie = 0;                                        // lazy rank order: rows tied for the end row (in newslot[], dead until add_alignment)
+        constexpr int TIECAP = 48;
+        static_assert(TIECAP <= 64 && TIECAP <= GW, "one lane per tied row, its index in 6 bits");
+        const int le = L / CPL;                              // owner of the last column
+        if constexpr (Cfg::PACKED_HYB) {
+            best_i = rows_pk_hyb(mode, m, n, gp, S, R, &ntie);
+        } else {
         HYPO_IN_VGPR(m); HYPO_IN_VGPR(n); HYPO_IN_VGPR(gp);
         const int j0 = CPL * g.lane;
         int sq[CPL];                                        // sq[c] = code of seq[j-1] for column j = j0+c
@@ -1320,11 +1525,8 @@ struct Poa {
         HYPO_UNROLL
         for (int c = 0; c < CPL; ++c) { jg[c] = (j0 + c) * gp; last[c] = jg[c]; }   // row 0: H[0][j] = j*g (sisd..cpp:197-199,230-232)
 
-        const int le = L / CPL, ce = L % CPL;               // owner of the last column
+        const int ce = L % CPL;
         int best = NEG;
-        int ntie = 0;                                        // lazy rank order: rows tied for the end row (in newslot[], dead until add_alignment)
-        constexpr int TIECAP = 48;
-        static_assert(TIECAP <= 64 && TIECAP <= GW, "one lane per tied row, its index in 6 bits");
 
         int slot = 0;                                        // ring slot of row i (no integer division in the loop)
         int slotS = 0, rowS = 0;                             // slot * S and r * S, advanced by addition (group-uniform)
@@ -1507,6 +1709,7 @@ struct Poa {
             g.sync();
         }
         best_i = g.shfl(best_i, le);
+        }   // !PACKED_HYB
         if constexpr (Cfg::LAZY) {
             if (lazy_on) {
                 ntie = g.shfl(ntie, le);
