@@ -75,15 +75,18 @@ def test_contig_scan_rank_select(mirror, device, oracle_lib):
 
 @pytest.mark.gpu
 def test_window_beyond_device_capacity_keeps_its_draft(mirror, device, capfd):
-    """A window deeper than the largest size class (1 100 arms > 1 023 sequences) must not stop the run: it keeps its
-    draft with a warning (the documented degraded path), its neighbours are polished as usual."""
+    """A window beyond the largest size class must not stop the run: it keeps its draft with a warning (the documented degraded
+    path), its neighbours are polished as usual.  Since round 3 depth alone no longer gets there (1 100 arms are polished: the last
+    class holds 16 382 sequences); an arm longer than 1 021 bases still does."""
     import random
     rng = random.Random(5)
     truth = "".join(rng.choice("ACGT") for _ in range(40))
     draft = truth[:10] + "A" + truth[11:]
     deep = TextWindow(draft, [truth] * 1100)
+    long_arm = TextWindow(draft, [truth] * 4 + ["".join(rng.choice("ACGT") for _ in range(1100))])
     normal = TextWindow(draft, [truth] * 8)
-    cons, _ = mirror.windows([normal, deep, normal], batched=True)
-    assert cons[0] == truth and cons[2] == truth
-    assert cons[1] == draft
+    cons, _ = mirror.windows([normal, deep, long_arm, normal], batched=True)
+    assert cons[0] == truth and cons[3] == truth
+    assert cons[1] == truth                                   # deep, but polished
+    assert cons[2] == draft
     assert "kept unpolished" in capfd.readouterr().err
