@@ -1,6 +1,7 @@
 // main.cpp — command line of the MI355X build: the reference's flags and defaults (src/main.cpp:46-67,100-113,
 // 124-358) plus the opt-in flags --device / --gpus / --devices.  usage() keeps the reference's layout, the wording is this build's own.
 #include <getopt.h>
+#include <unistd.h>
 #include <malloc.h>
 #include <sys/stat.h>
 #include <chrono>
@@ -102,6 +103,15 @@ int main(int argc, char** argv) {
     // the device library runs up to seven HIP streams; a ROCm process gets four hardware queues unless told otherwise before the
     // runtime initialises (two streams sharing a queue serialise: DESIGN.md 3.1)
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    // The OpenMP workers must sleep between parallel regions: the run alternates short parallel phases with serial stretches,
+    // device calls and helper threads (record reader, releasers, the HIP runtime's own), and libgomp's default lets idle workers
+    // spin — measured on the 100 x 1 Mbp set, -t 64: 8.98 s spinning, 4.77 s sleeping (profiles/diag/r03_c3_threads.sh).  libgomp
+    // reads the policy when it is loaded, i.e. before main(): set it and start over once.
+    if (!getenv("OMP_WAIT_POLICY") && !getenv("HYPO_NO_REEXEC")) {
+        setenv("OMP_WAIT_POLICY", "passive", 1);
+        setenv("HYPO_NO_REEXEC", "1", 1);
+        execv("/proc/self/exe", argv);                          // (if this fails the run goes on with the default policy)
+    }
     mallopt(M_TOP_PAD, 64 << 20);
     mallopt(M_TRIM_THRESHOLD, 1 << 30);
     hypo::InputFlags flags;
