@@ -1266,6 +1266,121 @@ struct Poa {
         return (int)first;                                   // group-uniform; -1: no perfect candidate
     }
 
+    // ---- the hybrid class's traceback through a tile in LDS -----------------------------------------------------------------------
+    // Every step of the plain traceback is a chain of dependent HBM reads in this class (code -> node of the row -> row metadata
+    // -> pred row: 60 alignments x ~200 steps x ~2 000 cycles were a fifth of a LONG window).  The walk moves up and to the left
+    // a step at a time, so a block of direction codes around the cell in hand, with the node and the metadata of its rows, is
+    // fetched in one go (two rows per lane, 16-byte loads) into the LDS the recent score rows occupy
+    // during the row loop (idle here), and the steps read LDS until the walk leaves the block.  Same moves, same result.
+#ifndef HYPO_TB_TILE
+#define HYPO_TB_TILE 1
+#endif
+    HD int traceback_tiled(int mode, int best_i, int S) {
+        // 128 rows x 48 columns: a LONG window's graph has ~2.6 rows per column (1 300 nodes for 500 bases), so the walk leaves a
+        // block of that shape through its top and its left edge at about the same time (~5 blocks per alignment)
+        constexpr int TR = 128, TC = 48;
+        static_assert(GW == 64 && TR == 2 * GW, "two tile rows per lane");
+        uint8_t* const tdir = (uint8_t*)ring1;                       // [TR][TC] codes
+        uint16_t* const tr2n = (uint16_t*)(tdir + TR * TC);          // [TR] node of the row
+        uint32_t* const tmeta = (uint32_t*)(tr2n + TR);              // [TR] row metadata (with the row of pred 0)
+        uint16_t* const tp1 = (uint16_t*)(tmeta + TR);               // [TR] row of pred 1 (a merge node has two in-edges as a rule; preds 2.. are read in place)
+        static_assert(!(Cfg::HYBRID && Cfg::PATHCAP > 0) || TR * TC + TR * 2 + TR * 4 + TR * 2 <= Cfg::RING1 * Lay::SMAX * (int)sizeof(score_t), "the tile fits the LDS row ring");
+        int i = best_i > 0 ? best_i : 0, j = best_i > 0 ? L : 0;
+        int steps = 0, guard = 0;
+        int ti0 = -1, tj0 = 0;                                       // the tile holds matrix rows ti0 - 127 .. ti0, columns tj0 .. tj0 + 47
+        while (mode == MODE_ROV ? (i != 0 && j != 0) : (i != 0 || j != 0)) {
+            if (++guard > n_nodes + L + 4) return RES_UNDEFINED;      // cannot loop; protects the GPU from a hang
+            if (i == 0) {                                   // only row 0 left: horizontal moves (insertions)
+                for (int t = g.lane; t < j; t += GW) posnode[t] = -1;
+                steps += j; j = 0;
+                break;
+            }
+            if (i > ti0 || i < ti0 - (TR - 17) || j < tj0 || j >= tj0 + TC || (tj0 > 0 && j - tj0 < 8)) {
+                g.sync();
+                ti0 = i; tj0 = j > 31 ? ((j - 31) & ~15) : 0;
+                HYPO_UNROLL
+                for (int h = 0; h < 2; ++h) {
+                    const int t = g.lane + h * GW, row = ti0 - t;
+                    if (row >= 1) {
+                        const uint8_t* src = dir + (size_t)(row - 1) * (size_t)S + tj0;
+                        uint4v* dst = (uint4v*)(tdir + t * TC);
+                        HYPO_UNROLL
+                        for (int c = 0; c < TC / 16; ++c) if (tj0 + 16 * c < S) dst[c] = *(const uint4v*)(src + 16 * c);
+                        tr2n[t] = (uint16_t)r2n[row - 1]; tmeta[t] = rowmeta[row - 1];
+                        if (KIN >= 2) tp1[t] = (uint16_t)predrows[(row - 1) * KIN + 1];      // (garbage for rows with fewer than two in-edges: never used)
+                    }
+                }
+                g.sync();
+            }
+            // run of FAST cells along the diagonal: lane t looks at (i-t, j-t), as far as the tile reaches
+            const int ii = i - g.lane, jj = j - g.lane;
+            const int tr = ti0 - ii;
+            const bool inside = ii >= 1 && jj >= 1 && tr < TR && jj >= tj0;
+            int dv = -1, nodev = 0;
+            if (inside) { dv = tdir[tr * TC + (jj - tj0)]; nodev = (int)tr2n[tr]; }
+            else if (g.lane == 0) dv = tdir[(ti0 - i) * TC + (j - tj0)];       // (i >= 1 here; j == 0: the code of column 0)
+            const bool fast = inside && dv == DIR_FAST;
+            const uint64_t stop = g.ballot(!fast);
+            const int run = stop ? ctz64(stop) : GW;
+            if (run >= 6) {
+                if (g.lane < run) posnode[jj - 1] = (int16_t)nodev;
+                i -= run; j -= run; steps += run;
+                continue;
+            }
+            // No run worth a wave's iteration: a noisy read moves one cell at a time (its rows' first predecessor is rarely the row before: bubbles interleave
+            // in rank order), and a full-wave iteration per move costs ~500 cycles.  Lane 0 walks on alone through the tile — code,
+            // metadata and node of a cell are three LDS reads — until it leaves the tile, needs a predecessor beyond the second (its
+            // row is read from HBM by everybody below) or has made 96 moves (the wave then looks for a long run of FAST cells again).
+            int wi = i, wj = j, ws = 0, wstop = 0;                 // wstop: 1 = j ran out (undefined), 2 = needs pred p >= 1
+            if (g.lane == 0) {
+                for (int it = 0; it < 96; ++it) {
+                    if (wi < 1 || wi > ti0 || wi <= ti0 - TR || wj < tj0 || wj >= tj0 + TC) break;
+                    if (mode == MODE_ROV ? (wi == 0 || wj == 0) : (wi == 0 && wj == 0)) break;
+                    const int d = tdir[(ti0 - wi) * TC + (wj - tj0)];
+                    if (d == DIR_FAST) {                          // diagonal to the row before
+                        if (wj == 0) { wstop = 1; break; }
+                        posnode[wj - 1] = (int16_t)tr2n[ti0 - wi]; --wj; --wi; ++ws;
+                        continue;
+                    }
+                    if (d == DIR_HORIZ) {
+                        if (wj == 0) { wstop = 1; break; }
+                        posnode[wj - 1] = -1; --wj; ++ws;
+                        continue;
+                    }
+                    const int p = dir_pred(d);
+                    const uint32_t mt = tmeta[ti0 - wi];
+                    if (meta_k(mt) && p > 1) { wstop = 2; break; }
+                    const int pi = meta_k(mt) ? (p == 0 ? meta_p0(mt) : (int)tp1[ti0 - wi]) : 0;
+                    if (!is_vert(d)) {
+                        if (wj == 0) { wstop = 1; break; }
+                        posnode[wj - 1] = (int16_t)tr2n[ti0 - wi]; --wj;
+                    }
+                    wi = pi; ++ws;
+                }
+            }
+            wi = g.shfl(wi, 0); wj = g.shfl(wj, 0); ws = g.shfl(ws, 0); wstop = g.shfl(wstop, 0);
+            g.sync();
+            if (wstop == 1) return RES_UNDEFINED;
+            i = wi; j = wj; steps += ws;
+            if (wstop == 2) {                                     // a move through pred p >= 2: its row from the table in HBM
+                const int d = g.shfl((int)tdir[(ti0 - i) * TC + (j - tj0)], 0);
+                const int p = dir_pred(d);
+                const int pi = pred_row(i - 1, p);
+                if (!is_vert(d)) {
+                    if (j == 0) return RES_UNDEFINED;
+                    if (g.lane == 0) posnode[j - 1] = (int16_t)tr2n[ti0 - i];
+                    --j;
+                }
+                i = pi;
+                ++steps;
+            } else if (ws == 0) return RES_UNDEFINED;              // (cannot happen: the cell in hand is inside the tile and not a run)
+            guard += ws;
+        }
+        tb_steps = g.uniform(steps); tb_fv = g.uniform(j);
+        g.sync();
+        return RES_OK;
+    }
+
     // ---- the hybrid class's score rows on packed pairs of int16 columns ------------------------------------------------------
     // Same recurrence, tie rules and byte codes as the one-column-per-register loop in align() (which classes without int16 rows
     // keep), in the arithmetic of rows_pk: two columns per register, every select a multiply-add on t = min_u16(a - b, 1).  The
@@ -1467,7 +1582,11 @@ struct Poa {
         const bool seen_before = (mode & MODE_SEEN) != 0;
         mode &= 0xff;
         const int W = g.uniform(L) + 1;
-        const int S = (W + CPL - 1) / CPL * CPL;           // row stride (even when NIB)
+        // row stride (even when NIB); the hybrid class rounds to a multiple of 16 as well, so that the traceback's tile loads of
+        // direction codes (traceback_tiled) are 16-byte aligned
+        constexpr int SQ = (Cfg::HYBRID && Cfg::PATHCAP > 0) ? (CPL % 16 == 0 ? CPL : (CPL % 8 == 0 ? 2 * CPL : (CPL % 4 == 0 ? 4 * CPL : (CPL % 2 == 0 ? 8 * CPL : 16 * CPL)))) : CPL;
+        static_assert(Lay::SMAX % SQ == 0 || !(Cfg::HYBRID && Cfg::PATHCAP > 0), "largest row stride is a multiple of the stride quantum");
+        const int S = (W + SQ - 1) / SQ * SQ;
         if (n_nodes * S > Cfg::DIRCELLS) return RES_OVERFLOW;
         if (sizeof(score_t) < 4) {                          // int16 rows are exact only below this bound
             int a = m < 0 ? -m : m, b = n < 0 ? -n : n, c2 = gp < 0 ? -gp : gp;
@@ -1765,6 +1884,11 @@ struct Poa {
         HYPO_TICK(PH_DP);
 
         // ---- traceback over direction codes ----
+        if constexpr (Cfg::HYBRID && Cfg::PATHCAP > 0 && HYPO_TB_TILE) {
+            const int rc = traceback_tiled(mode, best_i, S);
+            HYPO_TICK(PH_TRACE);
+            return rc;
+        }
         int i = best_i > 0 ? best_i : 0, j = best_i > 0 ? L : 0;
         int steps = 0, guard = 0;
         while (mode == MODE_ROV ? (i != 0 && j != 0) : (i != 0 || j != 0)) {
