@@ -204,6 +204,7 @@ class Ref:
 
 
 REF_SCAN_SO = os.path.join(HERE, "_ref", "libhyporef_scan.so")
+REF_ARMS_SO = os.path.join(HERE, "_ref", "libhyporef_arms.so")
 
 
 class RefScan:
@@ -241,3 +242,53 @@ class RefScan:
         if rc != 0:
             raise RuntimeError(f"hyporef_solid_scan rc={rc}")
         return words[:nw], kids[:int(ns.value)], rank, int(ns.value)
+
+
+_CIG = {c: i for i, c in enumerate("MIDNSHP=X")}
+
+
+class RefArms:
+    """The real short-read stage between "alignments loaded" and "windows filled" (src/Hypo.cpp:126-199) with the reference's own
+    per-region dump as its output (oracle/ref_arms_harness.cpp)."""
+
+    def __init__(self, path: str = REF_ARMS_SO):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path + " (build it with `make -C oracle ref` where /root/reference exists)")
+        self.lib = C.CDLL(path)
+        self.lib.hyporef_arms.restype = C.c_long
+
+    @staticmethod
+    def available() -> bool:
+        return os.path.exists(REF_ARMS_SO)
+
+    @staticmethod
+    def sam_records(sam_path: str, contig: str, min_mapq: int = 2):
+        """The records of `contig` the reference would turn into Alignment objects (flag and mapping-quality filter of
+        src/Hypo.cpp:299-301), flattened: pos, cigar_off, cigar, seq_off, seq."""
+        import re
+        pos, coff, cig, soff, seq = [], [0], [], [0], []
+        for line in open(sam_path):
+            if line.startswith("@"):
+                continue
+            f = line.rstrip("\n").split("\t")
+            if f[2] != contig or int(f[1]) & (4 | 256 | 512 | 1024) or int(f[4]) < min_mapq:
+                continue
+            pos.append(int(f[3]) - 1)
+            for n, op in re.findall(r"(\d+)([MIDNSHP=X])", f[5]):
+                cig.append(int(n) << 4 | _CIG[op])
+            coff.append(len(cig))
+            seq.append(f[9])
+            soff.append(soff[-1] + len(f[9]))
+        return (np.array(pos, dtype=np.uint32), np.array(coff, dtype=np.uint32), np.array(cig or [0], dtype=np.uint32),
+                np.array(soff, dtype=np.uint64), "".join(seq).encode())
+
+    def regions_dump(self, contig_seq: bytes, k: int, bvsd_path: str, records, work_dir: str) -> str:
+        """Runs the stage and returns the path of the reference's dump (aux/inspect_c.txt under work_dir)."""
+        pos, coff, cig, soff, seq = records
+        inv = C.c_uint64(0)
+        rc = self.lib.hyporef_arms(contig_seq, C.c_uint64(len(contig_seq)), C.c_uint32(k), bvsd_path.encode(),
+                                   C.c_uint32(len(pos)), _ptr(pos), _ptr(coff), _ptr(cig), _ptr(soff), seq,
+                                   work_dir.encode(), C.byref(inv))
+        if rc < 0:
+            raise RuntimeError(f"hyporef_arms rc={rc}")
+        return os.path.join(work_dir, "aux", "inspect_c.txt")

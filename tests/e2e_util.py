@@ -170,3 +170,68 @@ def fasta_md5(outdir):
         for chunk in iter(lambda: f.read(1 << 24), b""):
             h.update(chunk)
     return h.hexdigest()
+
+
+# ---- fresh inputs against the reference's own stage compiled in place (oracle/_ref/libhyporef_arms.so) --------------------------
+def _gen():
+    spec = importlib.util.spec_from_file_location("gen_e2e", os.path.join(GOLD, "gen_e2e.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    return gen
+
+
+def _reference_dump_regions(path):
+    spec = importlib.util.spec_from_file_location("make_e2e_golden", os.path.join(GOLD, "make_e2e_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.regions(path)
+
+
+def run_vs_reference_stage(outdir, seed, device, messy, threads=4):
+    """One single-contig short-read set made NOW (no committed golden behind it): this repo's `hypo` (region dump) against the
+    real Alignment / Contig / Window code of the reference run on the same records (oracle.RefArms): region borders and types
+    (A14, through the support votes N1), arm counts and crc32 of the arms of every window (A13 / N2).  Returns the number of
+    windows compared, or None when the seed's messy set has several contigs or long reads (the harness is short-read only)."""
+    import oracle
+    os.makedirs(str(outdir), exist_ok=True)
+    gen = _gen()
+    if messy:
+        args, nc, with_long = gen.generate_messy(str(outdir), seed)
+        if nc != 1 or with_long:
+            return None
+    else:
+        k = [7, 9, 11][seed % 3]
+        gen.generate(str(outdir), seed, [8000, 20000, 40000][seed % 3], False, k)
+        args = ["-d", "draft.fa", "-r", "reads.fa", "-s", {7: "10k", 9: "100k", 11: "1m"}[k], "-c", "30", "-b", "sr.sam", "-t", "1", "-i"]
+    k = {"10k": 7, "100k": 9, "1m": 11}[args[args.index("-s") + 1]]
+    mq = int(args[args.index("-q") + 1]) if "-q" in args else 2
+    argv = [BIN] + args
+    argv[argv.index("-t") + 1] = str(threads)
+    env = dict(os.environ)
+    env["HYPO_REGION_DUMP"] = os.path.join(str(outdir), "regions.tsv")
+    if device == "shim":
+        env["LD_LIBRARY_PATH"] = SHIM_DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    p = subprocess.run(argv, cwd=str(outdir), env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert ("oracle_device_shim" in p.stderr) == (device == "shim"), "wrong device library behind the C-ABI"
+    if device != "shim":
+        assert "short arms cut on the device" in p.stdout or "not sorted" in p.stdout     # unsorted records: the host loops
+    fa = open(os.path.join(str(outdir), "draft.fa")).read().split("\n")
+    name, draft = fa[0][1:].split()[0], "".join(fa[1:])
+    ref = oracle.RefArms()
+    recs = ref.sam_records(os.path.join(str(outdir), "sr.sam"), name, mq)
+    work = os.path.join(str(outdir), "refstage")
+    os.makedirs(work, exist_ok=True)
+    dump = ref.regions_dump(draft.encode(), k, os.path.join(str(outdir), "aux", "solid_kmers.bvsd"), recs, work)
+    regions = _reference_dump_regions(dump)
+    rows = [l.rstrip("\n").split("\t") for l in open(os.path.join(str(outdir), "regions.tsv"))]
+    assert len(rows) == len(regions), f"seed {seed}: {len(rows)} regions, reference stage has {len(regions)}"
+    n = 0
+    for r, g in zip(rows, regions):
+        beg, end, typ = int(r[1]), int(r[2]) - 1, r[3]
+        assert [beg, end, typ] == g[:3], f"seed {seed}: region {r[:4]} vs reference {g[:3]}"
+        if typ not in ("SR", "MSR"):
+            assert [int(x) for x in r[4:8]] == g[3:7], f"seed {seed}: arms of window {beg}-{end}: {r[4:8]} vs reference {g[3:7]}"
+            assert int(r[8]) == g[7], f"seed {seed}: arm bytes of window {beg}-{end} differ"
+            n += 1
+    return n

@@ -82,3 +82,26 @@ def test_scan_vs_real_contig_find_solid_pos(oracle_lib):
         rw, rk, rr, rn = ref.solid_scan(text, k, bits)
         ow, ok, orank, on = oracle_lib.solid_scan(p4, n, k, bits)
         assert rn == on and (rw == ow).all() and (rk == ok).all() and (rr == orank).all(), (n, k)
+
+
+def test_host_stage_vs_real_alignment_and_contig_code(tmp_path):
+    """Support votes, division into regions and short-arm selection of this repo's host (over the CPU shim) against the
+    reference's own Alignment.cpp / Contig.cpp / Window.cpp compiled in place (oracle/_ref/libhyporef_arms.so) on sets
+    generated now: 3 clean seeds (k = 7 / 9 / 11) and the single-contig short-read ones of 40 messy seeds."""
+    import pytest
+    import oracle
+    import e2e_util
+    if not oracle.RefArms.available():
+        pytest.skip("oracle/_ref/libhyporef_arms.so not built (the real reference only exists in the build container)")
+    e2e_util.build_binary()
+    e2e_util.build_shim()
+    total = 0
+    for seed in (301, 302, 303):
+        total += e2e_util.run_vs_reference_stage(tmp_path / f"c{seed}", seed, "shim", messy=False)
+    done = 0
+    for seed in range(400, 440):
+        n = e2e_util.run_vs_reference_stage(tmp_path / f"m{seed}", seed, "shim", messy=True)
+        if n is not None:
+            total += n
+            done += 1
+    assert done >= 4 and total > 500, (done, total)
