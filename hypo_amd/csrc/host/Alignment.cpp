@@ -63,13 +63,7 @@ void Alignment::initialise_pos(const SamRecord& rec) {
 void Alignment::copy_data(const SamRecord& rec) {
     const uint32_t qlen = _qae - _qab;
     if ((size_t)_qab + qlen > rec.seq.size()) { is_valid = false; return; }
-    bool ok = true;
-    for (uint32_t i = 0; i < qlen && ok; ++i) {
-        const char ch = rec.seq[_qab + i];
-        ok = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' || ch == 'a' || ch == 'c' || ch == 'g' || ch == 't';
-    }
-    if (!ok) { is_valid = false; return; }
-    _apseq = PackedSeq<2>(rec.seq.substr(_qab, qlen));
+    if (!_apseq.assign_acgt(rec.seq.data() + _qab, qlen)) { is_valid = false; return; }
     _qae -= _qab;
     _qab = 0;
     _cigar = rec.cigar;

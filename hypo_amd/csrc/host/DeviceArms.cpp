@@ -14,7 +14,10 @@ namespace hypo {
 bool DeviceArms::upload_reads(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1,
                               std::vector<std::vector<std::unique_ptr<Alignment>>>& store) {
     _reads_resident = false;
+    const bool timing = std::getenv("HYPO_HOST_TIMING") != nullptr;
+    const auto tu0 = std::chrono::steady_clock::now();
     wait_released();
+    const auto tu1 = std::chrono::steady_clock::now();
     if (hypo_gpu_use_device(_slot) != HYPO_OK) return false;
     uint64_t total = 0, n_aln = 0, n_cig = 0;
     std::vector<uint64_t> aln_base(c1 - c0 + 1, 0);
@@ -25,8 +28,9 @@ bool DeviceArms::upload_reads(std::vector<std::unique_ptr<Contig>>& contigs, uin
     }
     if (n_aln >= 0xfffffff0ull || total >= 0xfffffff0ull) return false;
     // per alignment: bytes of its read, CIGAR operations (exclusive prefix sums below), and the sort check
-    std::vector<uint64_t> seq_off(n_aln + 1);
-    std::vector<uint32_t> cigar_off(n_aln + 1);
+    // (plain arrays: nothing here is read before it is written, and zero-filling 28 bytes per record on one thread was 0.15 s of the C3 run)
+    std::unique_ptr<uint64_t[]> seq_off(new uint64_t[n_aln + 1]);
+    std::unique_ptr<uint32_t[]> cigar_off(new uint32_t[n_aln + 1]);
     bool sorted = true;
     for (uint32_t c = c0; c < c1; ++c) {
         const auto& alns = store[c];
@@ -43,7 +47,7 @@ bool DeviceArms::upload_reads(std::vector<std::unique_ptr<Contig>>& contigs, uin
     seq_off[0] = 0; cigar_off[0] = 0;
     for (uint64_t g = 0; g < n_aln; ++g) { n_cig += cigar_off[g + 1]; if (n_cig >= 0xfffffff0ull) return false; seq_off[g + 1] += seq_off[g]; cigar_off[g + 1] += cigar_off[g]; }
     const uint64_t read_bytes = seq_off[n_aln];
-    std::vector<uint32_t> rb(n_aln), re(n_aln), qae(n_aln), ctg_of(n_aln);
+    std::unique_ptr<uint32_t[]> rb(new uint32_t[n_aln + 1]), re(new uint32_t[n_aln + 1]), qae(new uint32_t[n_aln + 1]), ctg_of(new uint32_t[n_aln + 1]);
     std::unique_ptr<uint32_t[]> cigar(new uint32_t[n_cig ? n_cig : 1]);             // (not zero-filled: every element is written below)
     std::unique_ptr<uint8_t[]> reads2(new uint8_t[read_bytes ? read_bytes : 1]);
     {   // the copies, on all threads
@@ -63,9 +67,15 @@ bool DeviceArms::upload_reads(std::vector<std::unique_ptr<Contig>>& contigs, uin
         }
     }
     HypoArmsReads A;
-    A.n_alignments = (uint32_t)n_aln; A.rb = rb.data(); A.re = re.data(); A.qae = qae.data(); A.seq_off = seq_off.data();
-    A.reads2 = reads2.get(); A.reads2_bytes = read_bytes; A.cigar_off = cigar_off.data(); A.cigar = cigar.get();
-    const int rc = hypo_gpu_reads_upload(&A, ctg_of.data(), total);
+    A.n_alignments = (uint32_t)n_aln; A.rb = rb.get(); A.re = re.get(); A.qae = qae.get(); A.seq_off = seq_off.get();
+    A.reads2 = reads2.get(); A.reads2_bytes = read_bytes; A.cigar_off = cigar_off.get(); A.cigar = cigar.get();
+    const auto tu2 = std::chrono::steady_clock::now();
+    const int rc = hypo_gpu_reads_upload(&A, ctg_of.get(), total);
+    if (timing) {
+        auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+        std::fprintf(stderr, "[timing] upload_reads: wait for the last batch's release %.3f s, flatten %.3f s, hypo_gpu_reads_upload %.3f s (%.0f MB)\n",
+                     sec(tu0, tu1), sec(tu1, tu2), sec(tu2, std::chrono::steady_clock::now()), (read_bytes + 4.0 * n_cig + 28.0 * n_aln) / 1e6);
+    }
     if (rc != HYPO_OK) {
         if (rc != HYPO_E_UNSUPPORTED) std::fprintf(stdout, "[Hypo::Hypo] Info: support votes and short arms are computed on the host (%s)\n", hypo_gpu_last_error());
         return false;
@@ -79,6 +89,7 @@ bool DeviceArms::upload_reads(std::vector<std::unique_ptr<Contig>>& contigs, uin
 bool DeviceArms::support_kmers(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1, unsigned k) {
     if (!_reads_resident || c0 != _reads_c0 || c1 != _reads_c1 || hypo_gpu_use_device(_slot) != HYPO_OK) return false;
     uint64_t ns = 0;
+    const auto ts0 = std::chrono::steady_clock::now();
     std::vector<uint64_t> kbase(c1 - c0 + 1, 0);
     for (uint32_t c = c0; c < c1; ++c) { kbase[c - c0] = ns; ns += contigs[c]->_kids.size(); }
     kbase[c1 - c0] = ns;
@@ -95,7 +106,11 @@ bool DeviceArms::support_kmers(std::vector<std::unique_ptr<Contig>>& contigs, ui
         for (int64_t i = 0; i < (int64_t)n; ++i) spos[b + (uint64_t)i] = (uint32_t)(cbase + ctg._solid_pos.select((uint64_t)i + 1));
         cbase += ctg._len + (ctg._len & 1);
     }
+    const auto ts1 = std::chrono::steady_clock::now();
     const int rc = hypo_gpu_support_kmers(k, ns, spos.data(), kids.data(), cov.data(), sup.data());
+    if (std::getenv("HYPO_HOST_TIMING"))
+        std::fprintf(stderr, "[timing] support_kmers: positions of %llu solid k-mers %.3f s, hypo_gpu_support_kmers %.3f s\n", (unsigned long long)ns,
+                     std::chrono::duration<double>(ts1 - ts0).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - ts1).count());
     if (rc != HYPO_OK) {
         if (rc != HYPO_E_UNSUPPORTED) std::fprintf(stdout, "[Hypo::Hypo] Info: k-mer support is counted on the host (%s)\n", hypo_gpu_last_error());
         return false;

@@ -179,6 +179,8 @@ struct SamRecord {
     std::vector<uint32_t> cigar;               // op | len << 4
     bool has_nm = false;
     int64_t nm = 0;
+    std::string rname_seen;                    // SamReader::parse: the last reference name this object saw and its tid (records of a
+    int32_t tid_seen = -1;                     // sorted file repeat it millions of times: no string, no hash per record)
 };
 
 class SamReader {
@@ -265,8 +267,12 @@ public:
         auto flen = [&](int k) { return (k < nf ? f[k + 1] - 1 : n) - f[k]; };
         r.qname.assign(fbeg(0), flen(0));
         r.flag = (uint32_t)std::strtoul(fbeg(1), nullptr, 10);
-        auto it = _tid.find(std::string(fbeg(2), flen(2)));
-        r.tid = it == _tid.end() ? -1 : it->second;
+        if (!r.rname_seen.empty() && r.rname_seen.size() == flen(2) && std::memcmp(r.rname_seen.data(), fbeg(2), flen(2)) == 0) r.tid = r.tid_seen;
+        else {
+            r.rname_seen.assign(fbeg(2), flen(2));
+            auto it = _tid.find(r.rname_seen);
+            r.tid = r.tid_seen = it == _tid.end() ? -1 : it->second;
+        }
         r.pos = (uint32_t)(std::strtoul(fbeg(3), nullptr, 10) - 1);
         r.mapq = (uint32_t)std::strtoul(fbeg(4), nullptr, 10);
         r.cigar.clear();

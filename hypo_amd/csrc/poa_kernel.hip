@@ -634,8 +634,12 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     // {3,4,5} 3.64 / 3.55, {4,3,5} 3.60 / 3.71, {4,4,4} 3.64 / 3.94, {5,5,5} 3.61 / 3.78, {5,4,4} 3.58 / 4.13.  Class 0 is set below.
     int caps[kNumPoaClasses] = {4, 4, 5, 0, 0, 0};
     if (const char* cs = getenv("HYPO_POA_CAPS")) sscanf(cs, "%d,%d,%d,%d,%d", &caps[0], &caps[1], &caps[2], &caps[3], &caps[4]);
+    // One kernel after the other instead: when the last call left more than a tenth of its windows to class 3 (read error of
+    // several per cent) every kernel is long and fills the chip alone, and fixed LDS shares only leave the share of whichever
+    // kernel ends first idle: 5 % read error 47 -> 40 ms, 3 % 30 -> 29 ms; below that the concurrent schedule wins (2 %: 20 against
+    // 21.6 ms, C2: 3.7 against 4.2 ms; profiles/diag/r03_seq.sh, r03_backfill.sh).  HYPO_POA_SEQUENTIAL=0|1 forces.
     const char* seq_env = getenv("HYPO_POA_SEQUENTIAL");
-    const bool sequential = seq_env && atoi(seq_env) > 0;
+    const bool sequential = seq_env ? atoi(seq_env) > 0 : (A->history_valid && (uint64_t)last_count[3] * kSequentialDivisor > n_windows);
     auto rec = [&](int idx, hipStream_t st) { if (prof) (void)hipEventRecord(prof->ev[idx], st); };
     if (sequential) {
 #define HYPO_LAUNCH(ID, CFG)                                                                              \

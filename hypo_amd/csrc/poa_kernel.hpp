@@ -26,6 +26,7 @@ constexpr int kMinGlobalGroups5 = 4;     // ... and this many of the last one (6
 constexpr size_t kPoaHeaderBytes = 8192; // count[8] | head[8] @64 | HypoPoaStats @128 | phase cycles @512 | hist @2048 | start @4096 | cursor @6144 | planned @7680 | head2 @7744 | done[8] @7808 | spill_used @7872
 // resident groups of class 3 (direction codes in HBM scratch, PoaLayout::DIRG_BYTES each): what 256 CUs hold at 10 waves per CU
 constexpr int kMaxGroups3 = 2560;
+constexpr uint32_t kSequentialDivisor = 10;           // class kernels one after the other when the last call left more than 1/10 of its windows to class 3
 constexpr uint32_t kQueueUnpublished = 0xffffffffu;   // queue slot of a polled class that no producer has filled yet
 
 constexpr int kPlanBuckets = 64;         // cost buckets per class of the plan's counting sort
