@@ -92,14 +92,35 @@ void Hypo::polish() {
     const int n_ctx = std::max(1, hypo_gpu_num_devices());
     std::vector<std::unique_ptr<DeviceArms>> device_arms;
     for (int d = 0; d < n_ctx; ++d) device_arms.emplace_back(new DeviceArms(d));
+    std::thread prefetch;
+    AlignmentStore staged;                                 // the next batch's short-read alignments while the helper collects them
+    const bool prefetch_on = !(std::getenv("HYPO_PREFETCH") && std::atoi(std::getenv("HYPO_PREFETCH")) == 0);
     for (uint32_t batch_id = 0; batch_id < num_batches; ++batch_id) {
         std::fprintf(stdout, "********** [Hypo::Hypo] Info: BATCH-ID: %u\n", batch_id);
         const uint32_t initial_cid = batch_id * _contig_batch_size;
         const uint32_t final_cid = std::min<uint32_t>((uint32_t)_contigs.size(), initial_cid + _contig_batch_size);
         const bool over_contigs = (final_cid - initial_cid) >= _cFlags.threads;
+        // The short-read records of the NEXT batch are parsed on a helper thread while this batch is with the device (support
+        // votes, arms and POA leave the host's cores idle most of the time); it fills a store of its own,
+        // the reader state belongs to create_alignments alone.  HYPO_PREFETCH=0: one batch after the other.
         start();
-        create_alignments(true, batch_id);
+        if (prefetch.joinable()) {
+            prefetch.join();
+            // what the helper collected goes behind what the store already holds for a contig (the first long read of this batch,
+            // consumed with the previous one as in the reference, stays in front of the short reads)
+            for (size_t c = 0; c < staged.size(); ++c) {
+                if (staged[c].empty()) continue;
+                if (_alignment_store[c].empty()) _alignment_store[c].swap(staged[c]);
+                else { for (auto& a : staged[c]) _alignment_store[c].emplace_back(std::move(a)); staged[c].clear(); }
+            }
+        } else {
+            create_alignments(true, batch_id);
+        }
         stop("[Hypo:Hypo]: Loaded alignments. ");
+        if (prefetch_on && batch_id + 1 < num_batches) {
+            staged.resize(_contigs.size());
+            prefetch = std::thread([this, batch_id, &staged] { omp_set_num_threads((int)_cFlags.threads); create_alignments(true, batch_id + 1, &staged); });
+        }
 
         // With several devices the contigs of the batch are dealt out to the contexts in contiguous ranges of about equal
         // numbers of alignments (a batch with fewer contigs than devices stays on the first one): every context keeps the reads of
@@ -312,6 +333,9 @@ void Hypo::polish() {
     for (auto& da : device_arms) da->wait_released();      // inside the Overall timer, like the reference's own clear() of its alignment store
     _times.overall = std::chrono::duration<double>(std::chrono::steady_clock::now() - _tstart).count();
     std::fprintf(stdout, "RESOURCES ([Hypo:Hypo]: Overall. ): TIME= %g sec.\n", _times.overall);
+    // (1.5 M windows with their arms and consensus strings: freed contig by contig on all threads, 0.37 s of the C3 run's wall otherwise)
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t i = 0; i < (int64_t)_contigs.size(); ++i) _contigs[(size_t)i].reset();
     _contigs.clear();
 }
 
@@ -319,7 +343,8 @@ void Hypo::polish() {
 // A reader thread inflates the file and cuts it into blocks of raw records (SeqIO.hpp); while it fetches the next block,
 // record parsing and the Alignment constructors (CIGAR walk, 2-bit packing) of the current block run on all threads; a serial
 // pass then files the alignments in record order, so every contig's store is in file order exactly as the reference builds it.
-void Hypo::create_alignments(bool is_sr, uint32_t batch_id) {
+void Hypo::create_alignments(bool is_sr, uint32_t batch_id, AlignmentStore* into) {
+    AlignmentStore& store = into ? *into : _alignment_store;
     const uint32_t mq = _cFlags.map_qual_th;
     SamReader& sf = is_sr ? *_sf_short : *_sf_long;
     RecordStream& rs = is_sr ? _rs_short : _rs_long;
@@ -410,7 +435,7 @@ void Hypo::create_alignments(bool is_sr, uint32_t batch_id) {
             {
                 for (auto& rr : runs)
                     for (Run& r : rr) {
-                        auto& v = _alignment_store[(size_t)r.cid];
+                        auto& v = store[(size_t)r.cid];
                         r.at = v.size();
                         v.resize(v.size() + r.n);
                         num_alns += r.n;
@@ -425,7 +450,7 @@ void Hypo::create_alignments(bool is_sr, uint32_t batch_id) {
                     Slot& sl = slots[i];
                     if (sl.skip || !sl.aln->is_valid) continue;
                     if (ri < 0 || my[(size_t)ri].cid != sl.cid) { ++ri; at = my[(size_t)ri].at; }
-                    _alignment_store[(size_t)sl.cid][at++] = std::move(sl.aln);
+                    store[(size_t)sl.cid][at++] = std::move(sl.aln);
                 }
             }
         }

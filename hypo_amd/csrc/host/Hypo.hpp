@@ -29,7 +29,8 @@ private:
     const InputFlags _cFlags;
     std::vector<std::unique_ptr<Contig>> _contigs;
     std::unordered_map<std::string, uint32_t> _cname_to_id;
-    std::vector<std::vector<std::unique_ptr<Alignment>>> _alignment_store;
+    using AlignmentStore = std::vector<std::vector<std::unique_ptr<Alignment>>>;
+    AlignmentStore _alignment_store;
     uint32_t _contig_batch_size = 0;
     std::unique_ptr<SamReader> _sf_short, _sf_long;
     // per alignment file: the block of raw records being consumed (a contig batch may end in the middle of it), the block a
@@ -42,7 +43,7 @@ private:
 
     void start() { _t0 = std::chrono::steady_clock::now(); }
     void stop(const char* label);
-    void create_alignments(bool is_sr, uint32_t batch_id);
+    void create_alignments(bool is_sr, uint32_t batch_id, AlignmentStore* into = nullptr);   // into: the helper thread's own store (Hypo::polish)
 };
 
 }  // namespace hypo
