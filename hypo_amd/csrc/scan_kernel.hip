@@ -1,18 +1,20 @@
 // scan_kernel.hip — solid-kmer scan of a 4-bit packed contig (replaces Contig::find_solid_pos,
 // src/Contig.cpp:40-74, and suk::SolidKmers::is_solid, external/suk/include/suk/SolidKmers.hpp:119).
 //
-// MI355X mapping: HBM/L2-bound integer work, no MFMA.
-//   pass 1  scan_mark_kernel   one lane owns 64 consecutive k-mer start positions (= one output word).
-//           A 256-lane workgroup stages its 8 KiB of packed bases (+ k+1 bases of halo) into LDS with
-//           coalesced 16-byte loads, every lane then rolls the 2-bit k-mer over its 64+k-1 bases out of
-//           LDS and probes the 4^k-bit solid set (random 1-bit gathers: L2-resident for k<=13 = 8 MiB,
-//           Infinity-Cache-resident for k=15 = 128 MiB, HBM sectors for k=17 = 2 GiB).  The reference's
-//           two homopolymer-edge tests are applied, the lane writes its 64 mark bits as one coalesced
-//           8-byte store and its popcount.
-//   pass 2  scan_rank_*        exclusive prefix sum of the per-word popcounts = the rank directory
-//           behind the reference's sdsl rank/select support (Contig.cpp:72-73).
-//   pass 3  scan_kids_kernel   every marked position re-reads its k bases and writes the k-mer id at
-//           rank order (Contig::_kmerinfo order, Contig.cpp:67-68).
+// MI355X mapping: HBM/L2-bound integer work, no MFMA.  ONE kernel (scan_fused_kernel) behind one small memset:
+//   * a 256-lane workgroup takes the next tile of 4 096 positions (tiles = workgroups in launch order), stages its 2 KiB of packed
+//     bases (+ 1 byte before, 16 after) into LDS with coalesced 16-byte loads; every lane rolls the 2-bit k-mer over its 16
+//     positions (+ k - 1 bases) out of LDS and probes the 4^k-bit solid set for each (random 1-bit gathers, all in flight:
+//     L2-resident for k <= 13 = 8 MiB, Infinity-Cache-resident for k = 15 = 128 MiB, HBM sectors for k = 17 = 2 GiB), with the
+//     reference's two homopolymer-edge tests; four lanes put their 16 mark bits together into one output word;
+//   * the rank directory behind the reference's sdsl rank/select support (Contig.cpp:72-73) is an exclusive prefix sum of the
+//     words' popcounts: inside the tile by one wave; across tiles through a status word per tile (agent-scope atomics) — a contig
+//     of up to 16.8 Mbp (4 096 tiles, all resident at once) has every tile add up the aggregates of the tiles before it in one
+//     round trip, a longer one chains inclusive prefixes by a decoupled look-back, where tiles outnumber the resident ones;
+//   * every marked position then re-reads its k bases from the tile's LDS copy and writes the k-mer id at its rank
+//     (Contig::_kmerinfo order, Contig.cpp:67-68).
+// Round 2 had five launches here (mark, three for the prefix sum, k-mer ids): 94 us for the 5 Mbp contig of the C2 batch, most of
+// it the gaps between launches and a mark kernel with 1.2 workgroups per CU.
 // The 4^k-bit set is NOT staged through LDS for the survey's configurations: k=11 needs 512 KiB,
 // more than the 160 KiB of a CU, while it fits every XCD's 4 MiB L2.
 #include <hip/hip_runtime.h>
@@ -21,14 +23,17 @@
 namespace hypo {
 
 constexpr int SCAN_THREADS = 256;
-constexpr int SCAN_POS_PER_BLOCK = SCAN_THREADS * 64;             // 16384 positions
-constexpr int SCAN_BYTES_PER_BLOCK = SCAN_POS_PER_BLOCK / 2;      // 8192 bytes
-constexpr int SCAN_LDS_BYTES = SCAN_BYTES_PER_BLOCK + 32;         // + 1 byte before, k+1 bases after
+constexpr int SCAN_POS_PER_LANE = 16;
+constexpr int SCAN_POS_PER_BLOCK = SCAN_THREADS * SCAN_POS_PER_LANE;   // 4096 positions
+constexpr int SCAN_BYTES_PER_BLOCK = SCAN_POS_PER_BLOCK / 2;            // 2048 bytes
+constexpr int SCAN_WORDS_PER_BLOCK = SCAN_POS_PER_BLOCK / 64;           // 64 output words
+constexpr int SCAN_LDS_BYTES = SCAN_BYTES_PER_BLOCK + 32;               // + 1 byte before, k+1 bases after
+constexpr uint64_t SCAN_DIRECT_TILES = 4096;                               // up to 16.8 Mbp: every tile sums its predecessors' aggregates itself
+constexpr uint32_t kScanSpinLimit = 1u << 20;                               // polls of a status word (about a microsecond each) before a tile gives up
+constexpr uint64_t ST_AGGREGATE = 1ull << 62, ST_INCLUSIVE = 2ull << 62, ST_VALUE = (1ull << 62) - 1ull;   // status word of a tile
 
-__device__ __forceinline__ unsigned nib(const uint8_t* p, long i) { return (p[i >> 1] >> (4 - 4 * (i & 1))) & 15; }
-
-// Stages the workgroup's 8 KiB of packed bases (+ one byte before, 16 after) into LDS: sb[16 + x] = packed4[blk_byte0 + x] for
-// x in [-1, 8192 + 16); out of range -> 0x44 ("NN").
+// Stages the workgroup's 2 KiB of packed bases (+ one byte before, 16 after) into LDS: sb[16 + x] = packed4[blk_byte0 + x] for
+// x in [-1, 2048 + 16); out of range -> 0x44 ("NN").
 __device__ __forceinline__ void stage_block(const uint8_t* __restrict__ packed4, uint64_t n_bytes, uint64_t blk_byte0, uint8_t* sb) {
     const int t = threadIdx.x;
     for (int c = t; c < SCAN_BYTES_PER_BLOCK / 16 + 1; c += SCAN_THREADS) {
@@ -46,21 +51,21 @@ __device__ __forceinline__ void stage_block(const uint8_t* __restrict__ packed4,
     if (t == 0) sb[15] = blk_byte0 > 0 ? packed4[blk_byte0 - 1] : (uint8_t)0x44;
 }
 
-// The k-mers that START at the lane's 64 positions (local nibble indices l0 .. l0 + 63 of the staged block), in position order:
-// emit(p, kmer, ok) with p = 0..63, ok = the k-mer has no N, lies inside the contig and passes the reference's two
+// The k-mers that START at the lane's P positions (local nibble indices l0 .. l0 + P - 1 of the staged block), in position
+// order: emit(p, kmer, ok) with p = 0..P-1, ok = the k-mer has no N, lies inside the contig and passes the reference's two
 // homopolymer-edge tests (next base != last base, Contig.cpp:59; previous base != first base, Contig.cpp:63).  Bases come
 // out of LDS 8 at a time (one 32-bit read); the 2-bit k-mer, the run length since the last N and a history of "equals its
 // predecessor" bits roll in registers.  Fillers beyond the contig are N, so k-mers that would run over the end are never ok,
 // and a filler never equals a real base; `n_left` = bases of the contig from the lane's first position on (the pad nibble of an
 // odd-length contig is not a base).
-template <class Emit>
-__device__ __forceinline__ void roll64(const uint8_t* base, long l0, uint32_t k, int64_t n_left, Emit&& emit) {
+template <int P, class Emit>
+__device__ __forceinline__ void roll(const uint8_t* base, long l0, uint32_t k, int64_t n_left, Emit&& emit) {
     const uint64_t kmask = (1ull << (2 * k)) - 1ull;     // k <= 31
     uint64_t kmer = 0;
     uint32_t klen = 0, eh = 0;
     unsigned pb = (base[(l0 - 1) >> 1] >> (4 - 4 * ((l0 - 1) & 1))) & 15u;        // base before the first position
     const uint8_t* src = base + (l0 >> 1);               // l0 is even: the lane's bases start on a byte
-    const int last = 63 + (int)k;                        // step t looks at base t: the k-mer ending at t - 1 starts at t - k
+    const int last = P - 1 + (int)k;                     // step t looks at base t: the k-mer ending at t - 1 starts at t - k
     for (int w = 0; w * 8 <= last; ++w) {
         const uint32_t word = __builtin_bswap32(*(const uint32_t*)(src + 4 * w));
 #pragma unroll
@@ -69,7 +74,7 @@ __device__ __forceinline__ void roll64(const uint8_t* base, long l0, uint32_t k,
             const unsigned b = t < n_left ? (word >> (28 - 4 * j)) & 15u : 4u;
             eh = (eh << 1) | (b == pb ? 1u : 0u);        // bit i: base t - i equals base t - i - 1
             const int p = t - (int)k;
-            if (p >= 0 && p < 64) {
+            if (p >= 0 && p < P) {
                 // reject: base t == base t - 1 (the k-mer's last), or base p == base p - 1 (bit t - p = k of the history)
                 const bool ok = klen >= k && ((eh | (eh >> k)) & 1u) == 0;
                 emit(p, kmer, ok);
@@ -81,96 +86,6 @@ __device__ __forceinline__ void roll64(const uint8_t* base, long l0, uint32_t k,
     }
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS)
-scan_mark_kernel(const uint8_t* __restrict__ packed4, uint64_t n_bases, uint32_t k,
-                 const uint64_t* __restrict__ bits, uint64_t* __restrict__ words,
-                 uint32_t* __restrict__ wcount, uint64_t n_words) {
-    __shared__ __attribute__((aligned(16))) uint8_t sb[SCAN_LDS_BYTES + 16];
-    stage_block(packed4, (n_bases + 1) / 2, (uint64_t)blockIdx.x * SCAN_BYTES_PER_BLOCK, sb);
-    __syncthreads();
-    const uint64_t word = (uint64_t)blockIdx.x * SCAN_THREADS + threadIdx.x;
-    if (word >= n_words) return;
-    uint64_t out = 0;
-    // the probe is issued for every position (word 0 of the set where the k-mer is not a candidate): no branch between the
-    // loads, so many of them are in flight per lane
-    roll64(sb + 16, (long)threadIdx.x * 64, k, (int64_t)n_bases - (int64_t)(word * 64), [&](int p, uint64_t kmer, bool ok) {
-        const uint64_t wd = bits[ok ? (kmer >> 6) : 0];
-        out |= (uint64_t)(ok && ((wd >> (kmer & 63)) & 1ull)) << p;
-    });
-    words[word] = out;
-    wcount[word] = (uint32_t)__popcll(out);
-}
-
-// ---- exclusive scan of per-word popcounts (three small kernels) ---------------------------------
-constexpr int RANK_THREADS = 256;
-constexpr int RANK_ITEMS = 1024;     // words per block
-
-__global__ void __launch_bounds__(RANK_THREADS)
-scan_rank_partial(const uint32_t* __restrict__ wcount, uint64_t n_words, uint64_t* __restrict__ bsum) {
-    __shared__ uint32_t red[RANK_THREADS / 64];
-    const uint64_t b0 = (uint64_t)blockIdx.x * RANK_ITEMS;
-    uint32_t s = 0;
-    for (int i = threadIdx.x; i < RANK_ITEMS; i += RANK_THREADS) {
-        const uint64_t w = b0 + i;
-        if (w < n_words) s += wcount[w];
-    }
-    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) { uint64_t t = 0; for (int i = 0; i < RANK_THREADS / 64; ++i) t += red[i]; bsum[blockIdx.x] = t; }
-}
-
-__global__ void __launch_bounds__(1024)
-scan_rank_blocksums(uint64_t* __restrict__ bsum, uint64_t n_blocks, uint64_t* __restrict__ total) {
-    // single workgroup: sequential chunks of 1024 block sums
-    __shared__ uint64_t sh[1024];
-    __shared__ uint64_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint64_t c0 = 0; c0 < n_blocks; c0 += 1024) {
-        const uint64_t i = c0 + threadIdx.x;
-        const uint64_t v = i < n_blocks ? bsum[i] : 0;
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {
-            uint64_t add = threadIdx.x >= (unsigned)d ? sh[threadIdx.x - d] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += add;
-            __syncthreads();
-        }
-        const uint64_t incl = sh[threadIdx.x];
-        if (i < n_blocks) bsum[i] = carry + incl - v;      // exclusive
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && total) *total = carry;
-}
-
-__global__ void __launch_bounds__(RANK_THREADS)
-scan_rank_final(const uint32_t* __restrict__ wcount, uint64_t n_words, const uint64_t* __restrict__ bsum,
-                uint64_t* __restrict__ word_rank, const uint64_t* __restrict__ total) {
-    // each lane owns 4 consecutive words of the block's 1024
-    __shared__ uint32_t wsum[RANK_THREADS / 64];
-    const uint64_t b0 = (uint64_t)blockIdx.x * RANK_ITEMS;
-    const uint64_t w0 = b0 + (uint64_t)threadIdx.x * 4;
-    uint32_t c[4];
-    uint32_t mine = 0;
-    for (int i = 0; i < 4; ++i) { c[i] = (w0 + i < n_words) ? wcount[w0 + i] : 0; mine += c[i]; }
-    // wave-inclusive scan
-    uint32_t inc = mine;
-    const int lane = threadIdx.x & 63;
-    for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
-    if (lane == 63) wsum[threadIdx.x >> 6] = inc;
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int i = 0; i < (int)(threadIdx.x >> 6); ++i) woff += wsum[i];
-    uint64_t run = bsum[blockIdx.x] + woff + (inc - mine);
-    for (int i = 0; i < 4; ++i) { if (w0 + i < n_words) word_rank[w0 + i] = run; run += c[i]; }
-    if (blockIdx.x == 0 && threadIdx.x == 0) word_rank[n_words] = *total;
-}
-
-// ---- k-mer ids of the marked positions, in position order --------------------------------------
 // 16 bases (one big-endian 64-bit word of nibbles) -> 32 bits, first base on top.  The nibbles of a marked k-mer are 0..3; the
 // ones after it in the word may be N and are cut down to two bits so that they cannot spill into their neighbour.
 __device__ __forceinline__ uint32_t squeeze16(uint64_t x) {
@@ -182,45 +97,133 @@ __device__ __forceinline__ uint32_t squeeze16(uint64_t x) {
     return (uint32_t)x;
 }
 
-// One lane per output word.  A marked position reads the two or three aligned 8-byte words that hold its k bases (neighbouring
-// marks share them in L2), lines the nibbles up with two funnel shifts and squeezes them to 2 bits each.  The words are
-// aligned in memory: a contig that does not start on an 8-byte boundary is read from the boundary before it (same 8-byte
-// word, so same page), the bytes after the last whole word one by one.
-__device__ __forceinline__ uint64_t be_qword(const uint64_t* q8, uint64_t q, uint64_t n_full, uint64_t n_total_bytes) {
-    if (q < n_full) return __builtin_bswap64(q8[q]);
-    uint64_t v = 0;
-    const uint8_t* p = (const uint8_t*)q8;
-    for (int i = 0; i < 8; ++i) { const uint64_t at = q * 8 + (uint64_t)i; v = (v << 8) | (at < n_total_bytes ? p[at] : 0u); }
-    return v;
-}
-__global__ void __launch_bounds__(256)
-scan_kids_kernel(const uint8_t* __restrict__ packed4, uint64_t n_bytes, uint32_t k, const uint64_t* __restrict__ words,
-                 const uint64_t* __restrict__ word_rank, uint64_t n_words,
-                 uint64_t* __restrict__ kids, uint64_t kids_cap) {
-    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_words) return;
-    uint64_t m = words[w];
-    uint64_t r = word_rank[w];
-    const uint64_t mis = (uint64_t)((uintptr_t)packed4 & 7);
-    const uint64_t* q8 = (const uint64_t*)(packed4 - mis);
-    const uint64_t n_total = mis + n_bytes, n_full = n_total / 8;
+
+__device__ __forceinline__ uint64_t st_load(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_store(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// hdr[0] = number of marked positions (out), hdr[2] = 1 when a wait was abandoned; status[tile]; both zeroed before the launch.
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_fused_kernel(const uint8_t* __restrict__ packed4, uint64_t n_bases, uint32_t k, const uint64_t* __restrict__ bits,
+                  uint64_t* __restrict__ words, uint64_t* __restrict__ word_rank, uint64_t* __restrict__ kids, uint64_t kids_cap,
+                  uint64_t n_words, uint64_t n_tiles, uint64_t* __restrict__ hdr, uint64_t* __restrict__ status, uint64_t* __restrict__ n_solid) {
+    __shared__ __attribute__((aligned(16))) uint8_t sb[SCAN_LDS_BYTES + 16];
+    __shared__ uint32_t wex[SCAN_WORDS_PER_BLOCK];
+    __shared__ uint32_t wc[SCAN_WORDS_PER_BLOCK];
+    __shared__ uint64_t s_prefix;
+    __shared__ uint32_t s_total;
+    __shared__ uint64_t s_part[SCAN_THREADS / 64];
+    const bool direct = n_tiles <= SCAN_DIRECT_TILES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // Tiles are workgroups in launch order.  A tile waits for tiles with smaller indices only, and workgroups are dispatched in
+    // index order, so what it waits for is resident or done.  (A ticket from one atomic counter would make that order explicit, as
+    // rocPRIM's look-back scan does: 1 221 tiles of a 5 Mbp contig queueing on one address cost 25 us of a 44-us kernel.)  The waits
+    // are bounded all the same: a tile that sees no progress for kScanSpinLimit polls gives up and raises hdr[2].
+    const uint64_t tile = blockIdx.x;
+    stage_block(packed4, (n_bases + 1) / 2, tile * SCAN_BYTES_PER_BLOCK, sb);
+    __syncthreads();
+    // ---- marks: 16 positions per lane, every probe issued without a branch in between (word 0 of the set where the k-mer is
+    // not a candidate), so all of a lane's loads are in flight together
+    const uint64_t pos0 = tile * SCAN_POS_PER_BLOCK + (uint64_t)tid * SCAN_POS_PER_LANE;
+    uint32_t m = 0;
+    if (pos0 < n_bases)
+        roll<SCAN_POS_PER_LANE>(sb + 16, (long)tid * SCAN_POS_PER_LANE, k, (int64_t)(n_bases - pos0), [&](int p, uint64_t kmer, bool ok) {
+            const uint64_t wd = bits[ok ? (kmer >> 6) : 0];
+            m |= (uint32_t)(ok && ((wd >> (kmer & 63)) & 1ull)) << p;
+        });
+    // ---- four lanes -> one word
+    const uint32_t m1 = __shfl_down(m, 1, 64), m2 = __shfl_down(m, 2, 64), m3 = __shfl_down(m, 3, 64);
+    const int wl = tid >> 2;                                       // word of the tile
+    const uint64_t wg = tile * SCAN_WORDS_PER_BLOCK + (uint64_t)wl;
+    if ((tid & 3) == 0) {
+        const uint64_t word = (uint64_t)m | ((uint64_t)m1 << 16) | ((uint64_t)m2 << 32) | ((uint64_t)m3 << 48);
+        if (wg < n_words) words[wg] = word;
+        wc[wl] = (uint32_t)__popcll(word);
+    }
+    __syncthreads();
+    // ---- ranks: inside the tile (wave 0), then the tile's exclusive prefix by look-back over the tiles before it
+    if (tid < 64) {
+        const uint32_t c = wc[tid];
+        uint32_t inc = c;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+        wex[tid] = inc - c;
+        const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
+        uint64_t prefix = 0;
+        if (direct) {
+            if (lane == 0) st_store(status + tile, ST_AGGREGATE | (uint64_t)total);       // (summed by the tiles behind it, below)
+        } else if (tile == 0) {
+            if (lane == 0) st_store(status, ST_INCLUSIVE | (uint64_t)total);
+        } else {
+            if (lane == 0) st_store(status + tile, ST_AGGREGATE | (uint64_t)total);
+            int64_t j = (int64_t)tile - 1;                        // lane l looks at tile j - l
+            uint32_t spins = 0;
+            for (;;) {
+                const int64_t idx = j - lane;
+                const uint64_t s = idx >= 0 ? st_load(status + idx) : ST_INCLUSIVE;       // (before tile 0: an inclusive prefix of 0)
+                const uint64_t inc_mask = __ballot((s >> 62) == 2), pend_mask = __ballot((s >> 62) == 0);
+                const int f = inc_mask ? __ffsll((unsigned long long)inc_mask) - 1 : 63;   // nearest tile with an inclusive prefix
+                const uint64_t need = f == 63 ? ~0ull : ((2ull << f) - 1ull);
+                if (pend_mask & need) {                                                  // a tile in between has not published yet
+                    if (++spins > kScanSpinLimit) { if (lane == 0) hdr[2] = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                uint64_t v = lane <= f ? (s & ST_VALUE) : 0ull;
+                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+                prefix += v;
+                if (inc_mask) break;
+                j -= 64;
+            }
+            if (lane == 0) st_store(status + tile, ST_INCLUSIVE | (prefix + (uint64_t)total));
+        }
+        if (lane == 0) { s_prefix = prefix; s_total = total; }
+    }
+    __syncthreads();
+    if (direct) {
+        // few tiles (all of them resident at once, so a chain of inclusive prefixes would be pure latency: 20 - 35 us at 5 Mbp): every
+        // tile adds up the aggregates of ALL tiles before it, each of its lanes a few independent loads — one round trip.  A tile's
+        // aggregate depends on nothing but its own marks, and tiles start in ticket order, so the wait below always ends.
+        uint64_t v = 0;
+        for (uint64_t idx = (uint64_t)tid; idx < tile; idx += SCAN_THREADS) {
+            uint64_t st;
+            uint32_t spins = 0;
+            while (((st = st_load(status + idx)) >> 62) == 0) {
+                if (++spins > kScanSpinLimit) { hdr[2] = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            v += st & ST_VALUE;
+        }
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (lane == 0) s_part[tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) s_prefix = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        __syncthreads();
+    }
+    const uint64_t prefix = s_prefix;
+    if ((tid & 3) == 0 && wg < n_words) word_rank[wg] = prefix + wex[wl];
+    if (tile + 1 == n_tiles && tid == 0) {
+        const uint64_t tot = prefix + s_total;
+        word_rank[n_words] = tot;
+        hdr[0] = tot;
+        if (n_solid) *n_solid = tot;
+    }
+    // ---- k-mer ids of the lane's marked positions at their ranks, bases from the tile's LDS copy
+    const uint32_t pc = (uint32_t)__popc(m);
+    const uint32_t q1 = __shfl_up(pc, 1, 64), q2 = __shfl_up(pc, 2, 64), q3 = __shfl_up(pc, 3, 64);
+    if (!kids || !kids_cap || m == 0) return;
+    const int sub = tid & 3;
+    uint64_t r = prefix + wex[wl] + (sub >= 1 ? q1 : 0u) + (sub >= 2 ? q2 : 0u) + (sub >= 3 ? q3 : 0u);
     while (m) {
-        const int b = __ffsll((unsigned long long)m) - 1;
+        const int b = __ffs((int)m) - 1;
         m &= m - 1;
         if (r < kids_cap) {
-            const uint64_t beg = w * 64 + (uint64_t)b + 2 * mis;          // nibble index of the first base, from the aligned boundary
-            const uint64_t q = beg >> 4;                                 // 16 nibbles per 8-byte word
-            const int sh = 4 * (int)(beg & 15);
-            const uint64_t w0 = be_qword(q8, q, n_full, n_total);
-            const uint64_t w1 = be_qword(q8, q + 1, n_full, n_total);
-            const uint64_t hi = sh ? (w0 << sh) | (w1 >> (64 - sh)) : w0;                 // bases 0..15
+            const int l = tid * SCAN_POS_PER_LANE + b;                          // nibble of the tile
+            const uint8_t* q = sb + 16 + (l >> 1);
+            uint64_t hi = 0, lo = 0;
+            for (int i = 0; i < 8; ++i) { hi = (hi << 8) | q[i]; lo = (lo << 8) | q[8 + i]; }
+            if (l & 1) { hi = (hi << 4) | (lo >> 60); lo = (lo << 4) | (uint64_t)(q[16] >> 4); }
             uint64_t kmer;
             if (k <= 16) kmer = (uint64_t)squeeze16(hi) >> (2 * (16 - k));
-            else {
-                const uint64_t w2 = be_qword(q8, q + 2, n_full, n_total);
-                const uint64_t lo = sh ? (w1 << sh) | (w2 >> (64 - sh)) : w1;             // bases 16..31
-                kmer = (((uint64_t)squeeze16(hi) << 32) | squeeze16(lo)) >> (2 * (32 - k));
-            }
+            else kmer = (((uint64_t)squeeze16(hi) << 32) | squeeze16(lo)) >> (2 * (32 - k));
             kids[r] = kmer;
         }
         ++r;
@@ -228,12 +231,14 @@ scan_kids_kernel(const uint8_t* __restrict__ packed4, uint64_t n_bytes, uint32_t
 }
 
 size_t scan_workspace_bytes(uint64_t n_bases) {
+    // (sized as in round 2, when the per-word counts and block sums of three prefix-sum kernels lived here: a caller's allocation
+    // stays valid; the fused kernel needs 256 + 8 bytes per tile of 4 096 positions + the rank directory if the caller passes none)
     const uint64_t n_words = (n_bases + 63) / 64;
-    const uint64_t n_blocks = (n_words + RANK_ITEMS - 1) / RANK_ITEMS;
-    size_t b = 256;                                        // total
-    b += (n_words * 4 + 255) / 256 * 256;                  // wcount
-    b += (n_blocks * 8 + 255) / 256 * 256;                 // block sums
-    b += (n_words + 1) * 8 + 256;                          // internal rank directory if the caller passes none
+    const uint64_t n_blocks = (n_words + 1023) / 1024;
+    size_t b = 256;
+    b += (n_words * 4 + 255) / 256 * 256;
+    b += (n_blocks * 8 + 255) / 256 * 256;
+    b += (n_words + 1) * 8 + 256;
     return b;
 }
 
@@ -243,36 +248,26 @@ hipError_t scan_run(const uint8_t* packed4, uint64_t n_bases, uint32_t k, const 
                     hipEvent_t* prof_ev) {
     if (workspace_bytes < scan_workspace_bytes(n_bases)) return hipErrorInvalidValue;
     const uint64_t n_words = (n_bases + 63) / 64;
+    const uint64_t n_tiles = (n_words + SCAN_WORDS_PER_BLOCK - 1) / SCAN_WORDS_PER_BLOCK;
     char* ws = (char*)workspace;
-    uint64_t* total = (uint64_t*)ws;
-    uint32_t* wcount = (uint32_t*)(ws + 256);
-    const uint64_t n_rblocks = (n_words + RANK_ITEMS - 1) / RANK_ITEMS;
-    uint64_t* bsum = (uint64_t*)(ws + 256 + (n_words * 4 + 255) / 256 * 256);
-    uint64_t* own_rank = (uint64_t*)((char*)bsum + (n_rblocks * 8 + 255) / 256 * 256);
+    uint64_t* hdr = (uint64_t*)ws;
+    uint64_t* status = (uint64_t*)(ws + 256);
+    const size_t status_bytes = (n_tiles * 8 + 255) / 256 * 256;           // <= n_words * 4 rounded up: inside round 2's wcount area
+    uint64_t* own_rank = (uint64_t*)(ws + 256 + (n_words * 4 + 255) / 256 * 256 + ((n_words + 1023) / 1024 * 8 + 255) / 256 * 256);
     if (!word_rank) word_rank = own_rank;
     hipError_t e;
     if (n_words == 0) {
-        if ((e = hipMemsetAsync(total, 0, 8, stream)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(hdr, 0, 8, stream)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(word_rank, 0, 8, stream)) != hipSuccess) return e;
         if (n_solid) return hipMemsetAsync(n_solid, 0, 8, stream);
         return hipSuccess;
     }
-    const unsigned mark_blocks = (unsigned)((n_words + SCAN_THREADS - 1) / SCAN_THREADS);
     if (prof_ev) (void)hipEventRecord(prof_ev[0], stream);
-    hipLaunchKernelGGL(scan_mark_kernel, dim3(mark_blocks), dim3(SCAN_THREADS), 0, stream,
-                       packed4, n_bases, k, bits, words, wcount, n_words);
-    if (prof_ev) (void)hipEventRecord(prof_ev[1], stream);
-    hipLaunchKernelGGL(scan_rank_partial, dim3((unsigned)n_rblocks), dim3(RANK_THREADS), 0, stream, wcount, n_words, bsum);
-    hipLaunchKernelGGL(scan_rank_blocksums, dim3(1), dim3(1024), 0, stream, bsum, n_rblocks, total);
-    hipLaunchKernelGGL(scan_rank_final, dim3((unsigned)n_rblocks), dim3(RANK_THREADS), 0, stream, wcount, n_words, bsum, word_rank, total);
-    if (prof_ev) (void)hipEventRecord(prof_ev[2], stream);
-    if (kids && kids_cap)
-        hipLaunchKernelGGL(scan_kids_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, stream,
-                           packed4, (n_bases + 1) / 2, k, words, word_rank, n_words, kids, kids_cap);
-    if (prof_ev) (void)hipEventRecord(prof_ev[3], stream);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    if (n_solid) return hipMemcpyAsync(n_solid, total, 8, hipMemcpyDeviceToDevice, stream);
-    return hipSuccess;
+    if ((e = hipMemsetAsync(ws, 0, 256 + status_bytes, stream)) != hipSuccess) return e;
+    hipLaunchKernelGGL(scan_fused_kernel, dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, stream,
+                       packed4, n_bases, k, bits, words, word_rank, (kids && kids_cap) ? kids : nullptr, kids_cap, n_words, n_tiles, hdr, status, n_solid);
+    if (prof_ev) { (void)hipEventRecord(prof_ev[1], stream); (void)hipEventRecord(prof_ev[2], stream); (void)hipEventRecord(prof_ev[3], stream); }
+    return hipGetLastError();
 }
 
 }  // namespace hypo
