@@ -34,7 +34,10 @@ typedef PoaCfg<32, 4, 79, 84, 4, 6720, 640, 736, 64, int16_t, uint8_t> PoaClass1
 #ifndef HYPO_C2_ARMBYTES
 #define HYPO_C2_ARMBYTES 1024
 #endif
-typedef PoaCfg<HYPO_C2_GW, HYPO_C2_CPL, 127, 126, 6, 13440, 1024, HYPO_C2_ARMBYTES, 127, int16_t, uint8_t> PoaClass2;
+#ifndef HYPO_C2_DIRG
+#define HYPO_C2_DIRG 0
+#endif
+typedef PoaCfg<HYPO_C2_GW, HYPO_C2_CPL, 127, 126, 6, 13440, 1024, HYPO_C2_ARMBYTES, 127, int16_t, uint8_t, 0, false, (HYPO_C2_DIRG != 0)> PoaClass2;
 // class 3 keeps its direction codes (up to 254 x 256 cells) in HBM scratch (Cfg::DIRG): 16 KB of LDS per window instead of 40
 typedef PoaCfg<64, 4, 255, 254, 7, 65536, 2048, 1024, 192, int16_t, uint8_t, 0, false, true> PoaClass3;
 typedef PoaCfg<64, 10, 639, 2400, 12, 1536000, 491520, 16384, 256, int16_t, uint16_t, 1 << 18, true> PoaClass4;          // + 256 K path ids: runs LONG windows

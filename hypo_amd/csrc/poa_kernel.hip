@@ -107,7 +107,16 @@ poa_plan_count_kernel(PoaParams P, PoaQueues Q, uint32_t n_windows) {
                 const uint64_t o = P.arm_off[W.first_arm + a];
                 const uint32_t nb = (l + 3) / 4;
                 const uint8_t* p = (o <= P.arms2_bytes && nb <= P.arms2_bytes - o) ? P.arms2 + o : nullptr;
-                if (p && q && l == pl) for (uint32_t b = 0; b < nb; ++b) changes += p[b] != q[b];
+                if (p && q && l == pl) {                       // eight bytes per (unaligned) load, the rest one by one
+                    typedef uint64_t __attribute__((aligned(1))) u64u;
+                    uint32_t b = 0;
+                    for (; b + 8 <= nb; b += 8) {
+                        uint64_t x = *(const u64u*)(p + b) ^ *(const u64u*)(q + b);
+                        x |= x >> 4; x |= x >> 2; x |= x >> 1;
+                        changes += (uint32_t)__popcll(x & 0x0101010101010101ull);
+                    }
+                    for (; b < nb; ++b) changes += p[b] != q[b];
+                }
                 q = p; pl = l;
             }
         }
@@ -492,6 +501,7 @@ static size_t poa_workspace_prefix(uint32_t n_windows) {       // header, class 
     b += ((size_t)n_windows * 4 + 255) / 256 * 256;
     b += poa_spill_bytes(n_windows);
     b += (size_t)groups3_for(n_windows) * PoaLayout<PoaClass3>::DIRG_BYTES;
+    b += (size_t)groups3_for(n_windows) * PoaLayout<PoaClass2>::DIRG_BYTES;      // (0 unless HYPO_C2_DIRG)
     return b;
 }
 
@@ -552,6 +562,8 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     Q.done = (uint32_t*)(ws + 7808);
     const ClassScratch scr3{ws + off, groups3_for(n_windows)};
     off += (size_t)scr3.groups * PoaLayout<PoaClass3>::DIRG_BYTES;
+    const ClassScratch scr2{PoaClass2::DIRG ? ws + off : nullptr, PoaClass2::DIRG ? groups3_for(n_windows) : 0};
+    off += (size_t)scr2.groups * PoaLayout<PoaClass2>::DIRG_BYTES;
     char* scratch = ws + off;
     const ClassScratch scr4{scratch, groups4}, scr5{scratch, groups5}, scr_lds{nullptr, 0};
     hipError_t e = hipMemsetAsync(ws, 0, kPoaHeaderBytes, stream);
@@ -645,7 +657,7 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
 #define HYPO_LAUNCH(ID, CFG)                                                                              \
         rec(2 + 2 * ID, stream);                                                                          \
         if ((e = launch_class<CFG, (ID < kFirstGlobalClass)>(P, Q, ID, ID >= 3 ? rare_grid_hint(ID) : n_windows,                   \
-                                                             (ID == 3 ? scr3 : (ID == 4 ? scr4 : (ID == 5 ? scr5 : scr_lds))), num_cus, stream)) != hipSuccess) return e; \
+                                                             (ID == 3 ? scr3 : (ID == 4 ? scr4 : (ID == 5 ? scr5 : (ID == 2 ? scr2 : scr_lds)))), num_cus, stream)) != hipSuccess) return e; \
         rec(3 + 2 * ID, stream);
         HYPO_FOR_EACH_CLASS(HYPO_LAUNCH)
 #undef HYPO_LAUNCH
@@ -670,7 +682,7 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
         uint32_t producers = 0;                              // lane groups of every launch of classes 0 - 2 (what class 3's polling pass waits for)
         auto first2 = [&]() -> hipError_t {
             rec(2 + 2 * 2, stream);
-            hipError_t r = launch_class<PoaClass2, true>(P, Q, 2, n_windows, scr_lds, num_cus, stream, caps[2], false, &producers);
+            hipError_t r = launch_class<PoaClass2, true>(P, Q, 2, n_windows, scr2, num_cus, stream, caps[2], false, &producers);
             rec(3 + 2 * 2, stream);
             return r;
         };
