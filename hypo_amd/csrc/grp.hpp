@@ -100,6 +100,14 @@ struct Grp {
     }
     // same with the identity handed in as a loop-carried value (device: lane 0 of the final shift keeps what it had)
     HD int scan_max_excl_c(int v, int carry) const { const int r = scan_max_excl(v, (int)0x80000000); return lane ? r : carry; }
+    // inclusive prefix sum over the group's lanes
+    HD int scan_add_incl(int v) const {
+        eg->box[lane] = v; sync();
+        int r = 0;
+        for (int i = 0; i <= lane; ++i) r += (int)eg->box[i];
+        sync();
+        return r;
+    }
     HD int uniform(int v) const { return v; }
 };
 HD int popc64(uint64_t x) { return __builtin_popcountll(x); }
@@ -177,6 +185,12 @@ struct Grp {
         if (GW >= 32) { t = dpp_mov<0x142, 0xa>(ID, x); x = t > x ? t : x; }
         if (GW == 64) { t = dpp_mov<0x143, 0xc>(ID, x); x = t > x ? t : x; }
         return shfl_up1(x, carry);
+    }
+    // inclusive prefix sum over the group's lanes (cold code: window staging)
+    HD int scan_add_incl(int v) const {
+        HYPO_UNROLL
+        for (int d = 1; d < GW; d <<= 1) { const int t = __shfl_up(v, d, GW); if (lane >= d) v += t; }
+        return v;
     }
     // hint: value is identical in every lane of the WAVE (only true for GW == 64)
     HD int uniform(int v) const { return GW == 64 ? __builtin_amdgcn_readfirstlane(v) : v; }

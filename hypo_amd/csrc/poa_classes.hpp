@@ -26,7 +26,7 @@ typedef PoaCfg<16, 4, 47, 48, 4, 2208, 384, 384, 64, int16_t, uint8_t> PoaClass0
 // two per call: four groups when the batch is tiny windows almost only (dense short reads: 56 vs 46 M windows/s), two groups
 // otherwise (C2: 3.89 vs 4.08 ms).
 typedef PoaCfg<32, 2, 47, 48, 4, 2208, 384, 384, 64, int16_t, uint8_t> PoaClass0W;
-typedef PoaCfg<32, 4, 79, 84, 4, 6720, 640, 736, 64, int16_t, uint8_t> PoaClass1;     // (736 staged arm bytes: two groups + their stat blocks fill 32 LDS granules of 512 B exactly; copies of a neighbour take none)
+typedef PoaCfg<32, 4, 79, 84, 4, 6720, 640, 640, 64, int16_t, uint8_t> PoaClass1;     // (640 staged arm bytes: two groups + their stat blocks fill 32 LDS granules of 512 B exactly; copies of a neighbour take none)
 #ifndef HYPO_C2_GW
 #define HYPO_C2_GW 64
 #define HYPO_C2_CPL 2

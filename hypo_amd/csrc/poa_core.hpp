@@ -230,7 +230,7 @@ struct PoaLayout {   // byte offsets inside a group's memory slice
     // rarely touched group-uniform scalars (Poa::stat): per-window counters, what a re-queued window takes along, and the
     // per-wave totals of the kernel.  In registers they were live across the whole window — a vector register each in the
     // sub-wave classes, spilled scalars in the others; here they cost an LDS access where they change.
-    static constexpr int STAT_BYTES = 112;
+    static constexpr int STAT_BYTES = 208;
     static constexpr int oStat = oNewSlot + align_up<16>(LAZYL * 2);
     static constexpr int BYTES = oStat + STAT_BYTES;
     // Hybrid classes (Cfg::HYBRID) keep everything above in HBM scratch except what the topological sort and the graph update
@@ -248,7 +248,13 @@ struct PoaLayout {   // byte offsets inside a group's memory slice
                                                                              // waves cost more than the shorter row loop gains)
 };
 
-template <class Cfg>
+// What the persistent kernel hangs on a Poa object (poa_kernel.hip: PoaPrefetch): where the queue of the launch is, so that a
+// group can fetch its next window's descriptor, output range and carry word into its LDS block in one go (Poa::fetch_next) and
+// a window opens without touching HBM for them.  The emulator and the HBM-scratch classes use PoaNoHook: one window per run()
+// call, descriptor and output range read where they are needed.
+struct PoaNoHook { static constexpr bool enabled = false; };
+
+template <class Cfg, class Hook = PoaNoHook>
 struct Poa {
     typedef typename Cfg::score_t score_t;
     typedef typename Cfg::id_t id_t;
@@ -308,11 +314,19 @@ struct Poa {
     //                          fit (the next class sorts first); ST_CPASS: nothing newer to spill, but the spill the window came
     //                          with is still valid and travels on
     //   ACC_*                  per-wave totals of poa_class_kernel (LDS classes)
-    enum { ST_CELLS = 0, ST_ALIGNS, ST_REUSED, ST_XHITS, ST_CSCORED, ST_CEXACT, ST_XT, ST_XH, ST_NEED, ST_CKIND, ST_CS, ST_CCHAIN0, ST_CPASS, ST_N,
+    //   ST_ARMB, ST_OLEN       packed bytes of the window's arms (build_seqtab) and the length it answered with (finish): the
+    //                          algorithmic bytes of SURVEY.md 8(d) without reading the descriptor and the arm lengths again
+    //   NX_*                   Hook::enabled: the NEXT window of this group (window index, the descriptor's ten words,
+    //                          out_off[w], out_off[w + 1], carry word; Poa::fetch_next); CUR_OFF / CUR_STATIC: the output range of
+    //                          the window in hand and the part of its algorithmic bytes the descriptor gives
+    enum { ST_CELLS = 0, ST_ALIGNS, ST_REUSED, ST_XHITS, ST_CSCORED, ST_CEXACT, ST_XT, ST_XH, ST_NEED, ST_CKIND, ST_CS, ST_CCHAIN0, ST_CPASS, ST_ARMB, ST_OLEN, ST_N,
            ST_LASTX = ST_CPASS,   // while a window runs: did its latest alignment thread?  (ST_CPASS is written after the window's last step only)
            ST_MAXD = ST_N, ST_LSRC,   // of the rank order in hand (Poa::build_rowmeta): ring rows the furthest predecessor needs; last rank without in-edges
-           ACC_CELLS, ACC_ALIGNS, ACC_ABYTES, ACC_REUSED, ACC_THR, ACC_CSCORED, ACC_CTHR, ACC_NOK, ACC_NESC, ACC_NFAIL, ACC_NCARRIED, ACC_END };
-    static_assert(ACC_END <= Lay::STAT_BYTES / 4 && ST_N <= GW, "stat block");
+           ACC_CELLS, ACC_ALIGNS, ACC_ABYTES, ACC_REUSED, ACC_THR, ACC_CSCORED, ACC_CTHR, ACC_NOK, ACC_NESC, ACC_NFAIL, ACC_NCARRIED, ACC_END,
+           NX_W0 = ACC_END, NX_OFF = NX_W0 + 10, NX_WIDX = NX_OFF + 4, NX_CARRY, CUR_STATIC, CUR_OFF, NX_END = CUR_OFF + 4 };
+    static constexpr uint32_t NX_NONE = 0xffffffffu;         // NX_WIDX: the queue is drained
+    static_assert(sizeof(HypoWindow) == 40, "the prefetch moves the descriptor as ten words");
+    static_assert(NX_END <= Lay::STAT_BYTES / 4 && ST_N <= GW && GW >= 16, "stat block");
     enum { CARRY_NONE = 0, CARRY_BEFORE = 1, CARRY_UNSORTED = 2 };
     static constexpr int RES_OVERFLOW_CLEAN = 64;            // add_alignment: RES_OVERFLOW before anything was changed (internal)
     uint32_t* stat;
@@ -360,6 +374,42 @@ struct Poa {
         HYPO_TICK_RESET();
     }
 
+    // ---- the next window of this group (Hook::enabled) ----------------------------------------------------------------------
+    // Behind every window the group claims its next queue slot (one atomic by lane 0), reads the slot's window index, then — side
+    // by side, a word per lane — the descriptor (lanes 0-9), the output range out_off[w], out_off[w + 1] (lanes 10-13) and the
+    // carry word (lane 15), and leaves all of it in the stat block (NX_*): three dependent round trips where a window used to
+    // open with five (a look at the cursor, the atomic, the slot, the descriptor, later the output range) and to close with
+    // three more for its statistics.
+    // (Measured and dropped: claiming the next slot while the window in hand is still being staged, the three round trips riding
+    // on those of build_seqtab — C2 call 3.45 ms against 2.94 ms with the claim behind the window, class 2 alone 2.4-2.8 ms
+    // against 2.07: a claimed window waits for its group while others run dry.  profiles/diag/r03_prefetch_ab.sh)
+    Hook hk;
+    HD void fetch_next() const {
+        if constexpr (Hook::enabled) {
+            g.sync();
+            uint32_t a = 0;
+            if (g.lane == 0) a = hk.claim();
+            const uint32_t count = hk.count();                  // (read beside the atomic: no round trip of its own)
+            const uint32_t idx = (uint32_t)g.shfl((int)a, 0);
+            const uint32_t wn = idx < count ? hk.item(idx) : NX_NONE;
+            a = wn;                                            // (lane 14 keeps the window index: NX_WIDX)
+            if (wn != NX_NONE) {
+                if (g.lane < 10) a = ((const uint32_t*)(P->windows + wn))[g.lane];
+                else if (g.lane < 14) a = ((const uint32_t*)(P->out_off + wn))[g.lane - 10];
+                else if (g.lane == 15) a = idx >= hk.planned() ? hk.carry(wn) : 0u;      // slots from `planned` on hold re-queued windows
+            }
+            if (g.lane < 16) stat[NX_W0 + g.lane] = a;
+            g.sync();
+        }
+    }
+    // output range of window w (the hook keeps the one of the window in hand in LDS)
+    HD void out_range(uint32_t w, uint64_t* o, uint64_t* cap) const {
+        if constexpr (Hook::enabled) {
+            const uint64_t o0 = (uint64_t)stat[CUR_OFF] | ((uint64_t)stat[CUR_OFF + 1] << 32), o1 = (uint64_t)stat[CUR_OFF + 2] | ((uint64_t)stat[CUR_OFF + 3] << 32);
+            *o = o0; *cap = o1 - o0;
+        } else { *o = P->out_off[w]; *cap = P->out_off[w + 1] - *o; }
+    }
+
     // ---- sequence table: the window's sequences in the reference's consumption order -----------------
     // (Window.cpp:87-130: [draft if no internal arm] internal.. | prefix arms reversed | suffix arms;
     // zero-length arms are skipped).  Packed arm bytes are staged once into `armbuf` (one exposed HBM
@@ -374,6 +424,10 @@ struct Poa {
         g.sync();
         if (base && g.lane == 0) seqtab[0] = seq_ent(0, W.draft_len, !is_long, !is_long, MODE_NW, true, 2);
         bool over = false, any_len = false, bad = false;
+        uint32_t armb = 0;
+        if constexpr (STAGE_FUSED) {
+            if (!is_long) return build_seqtab_fused(W, base, narm, n_seq_out, added_out);
+        }
         for (int t = g.lane; t < narm; t += GW) {
             int a, mode; bool head, tail;                  // consumption slot t -> arm index
             if (is_long) { a = t; mode = MODE_NW; head = false; tail = false; }   // all kNW, insertion order, no markers (Window.cpp:179-206)
@@ -384,11 +438,13 @@ struct Poa {
             { const uint64_t ao = P->arm_off[a0 + a], ab = P->arms2_bytes; if (ao > ab || ((uint64_t)len + 3) / 4 > ab - ao) { bad = true; continue; } }
             if (len + (is_long ? 0u : 2u) > (uint32_t)Cfg::LMAX) { over = true; continue; }
             if (len) any_len = true;
+            armb += (len + 3) >> 2;
             seqtab[base + t] = seq_ent((uint32_t)a, len, head, tail, mode, false, 1);
         }
         if (g.any(bad)) return RES_INVALID;
         if (g.any(over)) return RES_OVERFLOW;
         any_len = g.any(any_len);
+        if constexpr (Hook::enabled) { armb = (uint32_t)g.reduce_add((int)armb); stat_set(ST_ARMB, armb); }
         g.sync();
         // Arms that repeat their predecessor byte for byte (same length, markers, mode) are flagged first, on the packed bytes
         // where they lie in HBM (one lane per arm; neighbours in consumption order are neighbours in memory): four arms in five
@@ -463,6 +519,130 @@ struct Poa {
             }
             g.sync();
         }
+        *n_seq_out = narm + base;
+        *added_out = any_len;
+        return RES_OK;
+    }
+
+    // The same table in one pass over the arms (SHORT windows of the classes whose arms fit a few registers): a lane reads its
+    // arm's length and offset, then the arm's packed bytes ONCE, as whole words into registers — two dependent round trips to HBM
+    // for the whole window, where the passes above make five (lengths and offsets, the two byte ranges of every neighbour
+    // compare, offsets and bytes again for staging) and read the bytes one by one.  Everything else happens on the registers:
+    // the neighbour compare against the lane below (the last lane of the previous round for lane 0), the arm's hash, its place in
+    // `armbuf` from a prefix sum over the lanes (copies take none; slots are word-aligned so that the words go to LDS as they
+    // are), the stores.  What differs from the passes above is invisible to the alignment: once an arm does not fit `armbuf` no
+    // later arm is staged either (the serial pass skipped it and went on), and the hash is a different function.
+    static constexpr int STAGE_NB = (Cfg::LMAX + 3) / 4, STAGE_NDW = (STAGE_NB + 3) / 4;
+#ifndef HYPO_STAGE_FUSED
+#define HYPO_STAGE_FUSED 1
+#endif
+    static constexpr bool STAGE_FUSED = HYPO_STAGE_FUSED && PK && STAGE_NDW <= 8;
+    HD static uint32_t load_u32(const uint8_t* p) {
+#ifdef HYPO_EMU
+        uint32_t v; __builtin_memcpy(&v, p, 4); return v;
+#else
+        typedef uint32_t __attribute__((aligned(1))) u32u;
+        return *(const u32u*)p;
+#endif
+    }
+    HD int build_seqtab_fused(const HypoWindow& W, int base, int narm, int* n_seq_out, bool* added_out) {
+        constexpr int NDW = STAGE_NDW;
+        const uint32_t a0 = W.first_arm;
+        const int ni = (int)W.n_internal, np = (int)W.n_prefix;
+        bool over = false, any_len = false, bad = false;
+        uint32_t armb = 0;
+        uint32_t* const hs = (uint32_t*)ring;                  // arm hashes, parked in the ring (idle until the first alignment)
+        static_assert((int)sizeof(score_t) * Cfg::RINGCELLS >= 4 * Cfg::SEQMAX, "arm hashes fit the ring");
+        uint32_t prev_e = 0, prev_d[NDW];                      // the arm before this round's first (group-uniform)
+        HYPO_UNROLL
+        for (int i = 0; i < NDW; ++i) prev_d[i] = 0;
+        int run = 0;                                           // bytes of armbuf taken so far (group-uniform)
+        for (int t0 = 0; t0 < narm; t0 += GW) {
+            const int t = t0 + g.lane;
+            const bool on = t < narm;
+            uint32_t e0 = 0, d[NDW];
+            HYPO_UNROLL
+            for (int i = 0; i < NDW; ++i) d[i] = 0;
+            int nb = 0;
+            if (on) {
+                int a, mode; bool head, tail;                  // consumption slot t -> arm index (Window.cpp:87-130)
+                if (t < ni) { a = t; mode = MODE_NW; head = true; tail = true; }
+                else if (t < ni + np) { a = ni + (np - 1 - (t - ni)); mode = MODE_LOV; head = true; tail = false; }
+                else { a = t; mode = MODE_ROV; head = false; tail = true; }
+                uint32_t len = P->arm_len[a0 + a];
+                const uint64_t ao = P->arm_off[a0 + a], ab = P->arms2_bytes;
+                if (ao > ab || ((uint64_t)len + 3) / 4 > ab - ao) { bad = true; len = 0; }
+                else if (len + 2u > (uint32_t)Cfg::LMAX) { over = true; len = 0; }
+                if (len) any_len = true;
+                nb = (int)((len + 3) >> 2);
+                armb += (uint32_t)nb;
+                e0 = seq_ent((uint32_t)a, len, head, tail, mode, false, 1);
+                if (nb) {
+                    const uint8_t* p = P->arms2 + ao;
+                    const int ndw = (nb + 3) >> 2;
+                    if ((uint64_t)ndw * 4 <= ab - ao) {        // whole words (the last one may reach past the arm, never past the buffer)
+                        HYPO_UNROLL
+                        for (int i = 0; i < NDW; ++i) if (i < ndw) d[i] = load_u32(p + 4 * i);
+                    } else {
+                        HYPO_UNROLL
+                        for (int i = 0; i < NDW; ++i) {
+                            HYPO_UNROLL
+                            for (int j = 0; j < 4; ++j) if (4 * i + j < nb) d[i] |= (uint32_t)p[4 * i + j] << (8 * j);
+                        }
+                    }
+                    if (nb & 3) {                              // bytes behind the arm do not count
+                        const uint32_t keep = (1u << (8 * (nb & 3))) - 1u;
+                        HYPO_UNROLL
+                        for (int i = 0; i < NDW; ++i) if (i == ndw - 1) d[i] &= keep;
+                    }
+                }
+            }
+            // copy of the arm before it: same length, markers and mode, same bytes
+            const uint32_t pe = g.shfl_up1(e0, prev_e);
+            bool same = on && t > 0 && nb > 0 && ((e0 ^ pe) & 0x3fff0000u) == 0;
+            uint32_t h = 2166136261u ^ (e0 & 0x3fff0000u);
+            HYPO_UNROLL
+            for (int i = 0; i < NDW; ++i) {
+                const uint32_t pd = g.shfl_up1(d[i], prev_d[i]);
+                same &= pd == d[i];
+                h = (h ^ d[i]) * 16777619u; h ^= h >> 15;
+            }
+            // place in armbuf: copies take none, the others a word-aligned slot while the arms so far fit
+            const int slot = (nb + 3) & ~3;
+            const int incl = run + g.scan_add_incl(on && !same ? slot : 0);
+            const bool staged = on && incl <= Cfg::ARMBYTES;
+            const int off = incl - slot;
+            if (on) {
+                seqtab[base + t] = staged ? ((e0 & 0x3fff0000u) | (uint32_t)off | (same ? 0x8000u : 0u)) : (e0 | (same ? 0x8000u : 0u));
+                hs[t] = nb ? (h | 1u) : 0u;
+                if (staged && !same && nb) {
+                    uint32_t* const dst = (uint32_t*)(armbuf + off);
+                    const int ndw = (nb + 3) >> 2;
+                    HYPO_UNROLL
+                    for (int i = 0; i < NDW; ++i) if (i < ndw) dst[i] = d[i];
+                }
+            }
+            if (t0 + GW < narm) {                              // what the next round's first lane compares with
+                prev_e = (uint32_t)g.shfl((int)e0, GW - 1);
+                HYPO_UNROLL
+                for (int i = 0; i < NDW; ++i) prev_d[i] = (uint32_t)g.shfl((int)d[i], GW - 1);
+                run = g.shfl(incl, GW - 1);
+            }
+        }
+        if (g.any(bad)) return RES_INVALID;
+        if (g.any(over)) return RES_OVERFLOW;
+        any_len = g.any(any_len);
+        if constexpr (Hook::enabled) { armb = (uint32_t)g.reduce_add((int)armb); stat_set(ST_ARMB, armb); }
+        g.sync();
+        // arms that repeat ANY earlier arm of the window spell a path of the graph when their turn comes (see build_seqtab)
+        for (int t = g.lane; t < narm; t += GW) {
+            const uint32_t h = hs[t];
+            bool seen = false;
+            HYPO_NOUNROLL
+            for (int u = 0; u < t; ++u) seen |= hs[u] == h;
+            if (seen && h) seqtab[base + t] |= 0x4000u;
+        }
+        g.sync();
         *n_seq_out = narm + base;
         *added_out = any_len;
         return RES_OK;
@@ -2691,7 +2871,7 @@ struct Poa {
             g.sync();
             HYPO_TICK(PH_CONS);
         }
-        const uint64_t oo = P->out_off[w], cap = P->out_off[w + 1] - oo;
+        uint64_t oo, cap; out_range(w, &oo, &cap);
         if ((uint64_t)conslen > cap) { finish(w, HYPO_ST_CONS_OVERFLOW, (uint32_t)conslen); return RES_OK; }
         for (int t = g.lane; t < conslen; t += GW) P->out_bases[oo + t] = "ACGTNJO"[consbuf[t]];
         finish(w, HYPO_ST_OK, (uint32_t)conslen);
@@ -2700,10 +2880,10 @@ struct Poa {
 
     // ---- outputs -----------------------------------------------------------------------------------
     HD void finish(uint32_t w, int status, uint32_t len) const {
-        if (g.lane == 0) { P->out_len[w] = len; P->out_status[w] = (uint8_t)status; }
+        if (g.lane == 0) { P->out_len[w] = len; P->out_status[w] = (uint8_t)status; if constexpr (Hook::enabled) stat[ST_OLEN] = len; }
     }
     HD int emit_draft(uint32_t w, const uint8_t* d4, int dlen) const {
-        const uint64_t o = P->out_off[w], cap = P->out_off[w + 1] - o;
+        uint64_t o, cap; out_range(w, &o, &cap);
         if ((uint64_t)dlen > cap) { finish(w, HYPO_ST_CONS_OVERFLOW, (uint32_t)dlen); return RES_OK; }
         for (int t = g.lane; t < dlen; t += GW) {
             int c = (d4[t >> 1] >> (4 - 4 * (t & 1))) & 15;
@@ -2782,7 +2962,7 @@ struct Poa {
         HYPO_TICK(PH_CONS);
         if (len < 2) return RES_UNDEFINED;                  // Window.hpp:144 strips two markers
         const int olen = len - 2;
-        const uint64_t o = P->out_off[w], cap = P->out_off[w + 1] - o;
+        uint64_t o, cap; out_range(w, &o, &cap);
         if ((uint64_t)olen > cap) { finish(w, HYPO_ST_CONS_OVERFLOW, (uint32_t)olen); return RES_OK; }
         for (int t = g.lane; t < olen; t += GW) P->out_bases[o + t] = "ACGTNJO"[code[path[len - 2 - t]]];
         finish(w, HYPO_ST_OK, (uint32_t)olen);
@@ -2792,6 +2972,11 @@ struct Poa {
 
     // Window::generate_consensus (src/Window.cpp:44-61)
     HD int run(uint32_t w, const uint8_t* carry_in = nullptr) {
+        const HypoWindow W = P->windows[w];
+        return run_window(w, W, carry_in);
+    }
+    // ... with the descriptor in hand (the persistent kernel's prefetch has it in LDS when the window starts)
+    HD int run_window(uint32_t w, const HypoWindow& W, const uint8_t* carry_in) {
         // the object outlives the window (one per persistent group): per-window counters and flags start over here
         last_changed = true;
         g.sync();
@@ -2802,11 +2987,19 @@ struct Poa {
         lazy_on = false; n_new = 0;
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
         HYPO_TICK_RESET();
-        const HypoWindow W = P->windows[w];
         const uint32_t ne = W.n_internal + W.n_prefix + W.n_suffix;
         // a descriptor that points outside the batch's buffers is answered with HYPO_ST_INVALID, never followed
         if ((uint64_t)W.n_internal + W.n_prefix + W.n_suffix > P->n_arms || (uint64_t)W.first_arm + ne > P->n_arms ||
             W.draft_off > P->draft4_bytes || ((uint64_t)W.draft_len + 1) / 2 > P->draft4_bytes - W.draft_off) return RES_INVALID;
+        if constexpr (Hook::enabled) {
+            // (windows answered without staging their arms: the packed arm bytes of the statistics are summed here, rare)
+            if ((W.n_empty > ne || ne < 2) && g.lane == 0) {
+                uint32_t a = 0;
+                HYPO_NOUNROLL
+                for (uint32_t t = 0; t < ne; ++t) a += (P->arm_len[W.first_arm + t] + 3) >> 2;
+                stat[ST_ARMB] = a;
+            }
+        }
         if (W.n_empty > ne) { finish(w, HYPO_ST_OK, 0); return RES_OK; }
         if (ne < 2) return emit_draft(w, P->draft4 + W.draft_off, (int)W.draft_len);
         if (W.type != HYPO_WIN_SHORT) {

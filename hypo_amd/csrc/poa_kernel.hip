@@ -84,6 +84,9 @@ poa_plan_count_kernel(PoaParams P, PoaQueues Q, uint32_t n_windows) {
     if (w < n_windows) {
         W = P.windows[w];
         narm = W.n_internal + W.n_prefix + W.n_suffix;
+        // a descriptor whose arms run past the arm table is answered HYPO_ST_INVALID by whichever class gets it (Poa::run_window);
+        // the plan must not walk its "arms" either (a wrapped count made one lane read 4 G arm lengths: 20 s for one window)
+        if ((uint64_t)W.n_internal + W.n_prefix + W.n_suffix + (uint64_t)W.first_arm > P.n_arms) { narm = 0; W.n_internal = W.n_prefix = W.n_suffix = 0; }
         if (narm) { atomicMin(&amin, W.first_arm); atomicMax(&amax, W.first_arm + narm); }
     }
     __syncthreads();
@@ -185,6 +188,23 @@ struct PoaKArgs {
 typedef const PoaKArgs __attribute__((address_space(4)))* PoaKArgPtr;
 __device__ __forceinline__ PoaKArgPtr fresh(PoaKArgPtr p) { asm volatile("" : "+s"(p)); return p; }
 
+// The kernel's side of Poa::fetch_next (poa_core.hpp): where the queue of this launch is.  The pointers are read from the
+// kernel-argument segment at the point of use (nothing lives in registers between windows but the two bounds the loop had before).
+struct PoaPrefetch {
+    static constexpr bool enabled = true;
+    // queue slots of this launch (what *bound holds does not change while a launch of an LDS class outside a polling launch runs:
+    // first passes end at `planned`, everything else starts when its producers are done) and where the re-queued windows begin
+    __device__ __forceinline__ static uint32_t count() { return *ka()->bound; }
+    __device__ __forceinline__ static uint32_t planned() { const PoaKArgPtr k = ka(); return k->Q.planned[k->cls]; }
+    __device__ __forceinline__ static PoaKArgPtr ka() { return fresh((PoaKArgPtr)__builtin_amdgcn_kernarg_segment_ptr()); }
+    __device__ __forceinline__ uint32_t claim() const { return atomicAdd(ka()->head, 1u); }
+    __device__ __forceinline__ uint32_t item(uint32_t idx) const { const PoaKArgPtr k = ka(); return k->Q.items[(size_t)k->cls * k->Q.stride + idx]; }
+    __device__ __forceinline__ uint32_t carry(uint32_t w) const { return ka()->Q.carry[w]; }
+};
+#ifndef HYPO_PREFETCH_NEXT
+#define HYPO_PREFETCH_NEXT 1
+#endif
+
 #ifndef HYPO_C4_WAVES
 #define HYPO_C4_WAVES 2
 #endif
@@ -216,7 +236,9 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
     // The LDS classes keep the totals in the group's stat block in LDS (Poa::ACC_*, 32 bits: a wave of those sees at most a few
     // thousand windows of < 1 M cells); in registers they were live across every window — a vector register each in the sub-wave
     // classes.  The HBM-scratch classes (two waves per SIMD anyway) keep 64-bit registers.
-    typedef Poa<Cfg> PoaT;
+    // the LDS classes outside a polling launch fetch a group's next window into its LDS block (PoaPrefetch, Poa::fetch_next)
+    constexpr bool PF = HYPO_PREFETCH_NEXT && USE_LDS && !POLL;
+    typedef typename std::conditional<PF, Poa<Cfg, PoaPrefetch>, Poa<Cfg>>::type PoaT;
     uint64_t cells = 0, aligns = 0, abytes = 0, n_reused = 0, n_thr = 0, c_scored = 0, c_thr = 0;
     uint32_t n_ok = 0, n_esc = 0, n_fail = 0, n_carried = 0;
     uint32_t carry_in = 0;                                      // Q.carry value of the window in hand
@@ -226,7 +248,7 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
     const uint64_t tstart = (uint64_t)clock64();
 #endif
     // what happens to a window once Poa::run / step has returned something other than RES_CONTINUE
-    auto account = [&](Poa<Cfg>& poa, uint32_t w, int rc) {
+    auto account = [&](PoaT& poa, uint32_t w, int rc) {
         uint32_t* const stt = poa.stat;
         if constexpr (USE_LDS) {
             if (g.lane == 0) {
@@ -246,12 +268,17 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
 #endif
         if (rc == RES_OK) {
             if (g.lane == 0) {                                  // algorithmic bytes, SURVEY.md 8(d)
-                const HypoWindow W = P->windows[w];
-                const uint32_t narm = W.n_internal + W.n_prefix + W.n_suffix;
-                uint32_t a = (uint32_t)((W.draft_len + 1) / 2 + 16 + 8 * (1 + narm) + P->out_len[w]);
-                const uint32_t* alen = P->arm_len;
-                for (uint32_t t = 0; t < narm; ++t) a += (alen[W.first_arm + t] + 3) / 4;
-                if constexpr (USE_LDS) { stt[PoaT::ACC_ABYTES] += a; stt[PoaT::ACC_NOK] += 1; } else abytes += a;
+                if constexpr (PF) {                              // (the window left its arm bytes and its answer's length in the stat block)
+                    stt[PoaT::ACC_ABYTES] += stt[PoaT::CUR_STATIC] + stt[PoaT::ST_OLEN] + stt[PoaT::ST_ARMB];
+                    stt[PoaT::ACC_NOK] += 1;
+                } else {
+                    const HypoWindow W = P->windows[w];
+                    const uint32_t narm = W.n_internal + W.n_prefix + W.n_suffix;
+                    uint32_t a = (uint32_t)((W.draft_len + 1) / 2 + 16 + 8 * (1 + narm) + P->out_len[w]);
+                    const uint32_t* alen = P->arm_len;
+                    for (uint32_t t = 0; t < narm; ++t) a += (alen[W.first_arm + t] + 3) / 4;
+                    if constexpr (USE_LDS) { stt[PoaT::ACC_ABYTES] += a; stt[PoaT::ACC_NOK] += 1; } else abytes += a;
+                }
             }
             if constexpr (!USE_LDS) ++n_ok;
         } else if ((rc == RES_OVERFLOW || rc == RES_UNSUPPORTED) && cls + 1 < kNumPoaClasses) {
@@ -339,12 +366,34 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
         carry_in = idx >= planned ? fresh(ka)->Q.carry[*w] : 0u;
         return true;
     };
-    Poa<Cfg> poa(g, P, mem, fast, dirg);
+    PoaT poa(g, P, mem, fast, dirg);
     // The groups of a wavefront (GPW > 1) take windows in lock step: all dequeue, all run, all write their consensus.
     // (Letting a finished group open its next window while its neighbours are still aligning was measured and is
     // slower: the dequeue + descriptor + arm staging round trips of one group then stall the other three, 4x as often.)
-    uint32_t w;
-    while (dequeue(&w)) account(poa, w, poa.run(w, carry_in ? (const uint8_t*)fresh(ka)->Q.spill + (size_t)(carry_in - 1) * 16 : nullptr));
+    if constexpr (PF) {
+        // A window arrives through Poa::fetch_next: queue slot, descriptor, output range and carry word are in the group's LDS
+        // block when it starts, and its statistics need no HBM read when it ends.
+        uint32_t* const stt = poa.stat;
+        poa.fetch_next();
+        for (;;) {
+            // (group-uniform values read from LDS: Grp::uniform makes them scalars again in the 64-lane classes)
+            const uint32_t w = (uint32_t)g.uniform((int)stt[PoaT::NX_WIDX]);
+            if (w == PoaT::NX_NONE) break;
+            HypoWindow W;
+            { uint32_t* const wd = (uint32_t*)&W; HYPO_UNROLL for (int i = 0; i < 10; ++i) wd[i] = (uint32_t)g.uniform((int)stt[PoaT::NX_W0 + i]); }
+            carry_in = (uint32_t)g.uniform((int)stt[PoaT::NX_CARRY]);
+            const uint32_t oc = g.lane < 4 ? stt[PoaT::NX_OFF + g.lane] : 0u;
+            g.sync();
+            if (g.lane < 4) stt[PoaT::CUR_OFF + g.lane] = oc;
+            if (g.lane == 4) stt[PoaT::CUR_STATIC] = (uint32_t)((W.draft_len + 1) / 2 + 16 + 8 * (1 + W.n_internal + W.n_prefix + W.n_suffix));
+            const int rc = poa.run_window(w, W, carry_in ? (const uint8_t*)fresh(ka)->Q.spill + (size_t)(carry_in - 1) * 16 : nullptr);
+            account(poa, w, rc);
+            poa.fetch_next();
+        }
+    } else {
+        uint32_t w;
+        while (dequeue(&w)) account(poa, w, poa.run(w, carry_in ? (const uint8_t*)fresh(ka)->Q.spill + (size_t)(carry_in - 1) * 16 : nullptr));
+    }
     if (g.lane == 0) {
         HypoPoaStats* st = fresh(ka)->Q.stats;
         if constexpr (USE_LDS) {
