@@ -2,15 +2,15 @@
 //
 //   class lanes/window (windows/wave) cols/lane max seq nodes in-edges dir cells(bits) ring cells arm B seqs scores ids  memory / window
 //   0     16 (4)                      4         47      48    4        2208 (4)       384        384   64   int16  u8   LDS  3.8 KB
-//   1     32 (2)                      4         79      84    4        6720 (4)       640        768   64   int16  u8   LDS  7.9 KB
+//   1     64 (1)                      2         79      84    4        6720 (4)       640        640   64   int16  u8   LDS  8.0 KB
 //   2     64 (1)                      2         127     126   6        13440 (4)      1024       1024  127  int16  u8   LDS  14.1 KB
 //   3     64 (1)                      4         255     254   7        49152 (4)      2048       1024  192  int16  u8   LDS  40 KB (4 waves per CU): the wide SHORT windows (the reference cuts a weak region only
 //                                                                                                                     above 2 x 100 bp, src/Contig.cpp:526-711) and small windows with large graphs
 //   4     64 (1)                      10        639     2400  12       1536000 (8)    491520     16384 256  int16  u16  HBM scratch 3.3 MB / resident group: the LONG windows (<= 500 bp, arms ~ window length,
 //                                                                                                                     graphs ~1.3 k nodes; src/Window.cpp:156-236), up to 2048 groups resident
 //   5     64 (1)                      16        1023    32767 58       33554432 (8)   2097152    16384 16383 int32 u16  HBM scratch 61 MB / resident group: whatever overflows everything else (up to 32 groups)
-// The kernel is VALU-issue bound (profiles/): a wavefront therefore carries 4 / 2 small windows side by side
-// (16- / 32-lane groups with group-uniform control flow), so one instruction stream advances several windows.
+// Class 0 carries 4 or 2 tiny windows per wavefront (16- / 32-lane groups with group-uniform control flow, one instruction
+// stream advancing several windows); from class 1 on a window has the wave to itself.
 // A window that does not fit class c (too many nodes / in-edges / cells, a predecessor row that already left
 // the ring, sequence too long, or scores whose magnitude could overflow int16) is re-queued to class c+1 by
 // the kernel itself.  int16 is exact iff max(|m|,|n|,|g|) * (nodes + len + 1) < 32767 (the guard spoa's SIMD
@@ -25,8 +25,20 @@ typedef PoaCfg<16, 4, 47, 48, 4, 2208, 384, 384, 64, int16_t, uint8_t> PoaClass0
 // the windows per wave but half the partners a group waits for when the windows of a wave differ.  poa_run picks one of the
 // two per call: four groups when the batch is tiny windows almost only (dense short reads: 56 vs 46 M windows/s), two groups
 // otherwise (C2: 3.89 vs 4.08 ms).
-typedef PoaCfg<32, 2, 47, 48, 4, 2208, 384, 384, 64, int16_t, uint8_t> PoaClass0W;
-typedef PoaCfg<32, 4, 79, 84, 4, 6720, 640, 640, 64, int16_t, uint8_t> PoaClass1;     // (640 staged arm bytes: two groups + their stat blocks fill 32 LDS granules of 512 B exactly; copies of a neighbour take none)
+#ifndef HYPO_C0W_GW
+#define HYPO_C0W_GW 32
+#endif
+// Class 1 runs ONE window per wave (64 lanes x 2 columns) since round 3: with two 32-lane groups per wave (x 4 columns, the
+// geometry of rounds 1-2: -DHYPO_C1_GW=32 -DHYPO_C1_CPL=4) a window cost 345 k wave-cycles against 472 k for a class-2 window with
+// four times the rows — the two windows of a wave wait for each other at every step and their group-uniform values are vector
+// registers.  A window of its own per wave: class 1 alone 1.73 -> 1.33 ms on the C2 batch in 3/4 of the LDS, C2 call 2.90 -> 2.56
+// ms, 1 % read error 11.3 -> 10.2 ms, dense short reads 59.6 -> 76 M windows/s (profiles/diag/r03_wave_wide_*.sh).
+#ifndef HYPO_C1_GW
+#define HYPO_C1_GW 64
+#define HYPO_C1_CPL 2
+#endif
+typedef PoaCfg<HYPO_C0W_GW, 2, 47, 48, 4, 2208, 384, 384, 64, int16_t, uint8_t> PoaClass0W;
+typedef PoaCfg<HYPO_C1_GW, HYPO_C1_CPL, 79, 84, 4, 6720, 640, 640, 64, int16_t, uint8_t> PoaClass1;     // (640 staged arm bytes: two groups + their stat blocks fill 32 LDS granules of 512 B exactly; copies of a neighbour take none)
 #ifndef HYPO_C2_GW
 #define HYPO_C2_GW 64
 #define HYPO_C2_CPL 2

@@ -693,7 +693,9 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     // another finished, and which one that was depended on the stream -> hardware queue mapping of the process (C2 call 3.5 - 4.2 ms
     // for the same code).  Swept on C2 under two mappings (profiles/diag/caps_fit_sweep.sh, ms per call): {4,4,5} 3.48 / 3.48,
     // {3,4,5} 3.64 / 3.55, {4,3,5} 3.60 / 3.71, {4,4,4} 3.64 / 3.94, {5,5,5} 3.61 / 3.78, {5,4,4} 3.58 / 4.13.  Class 0 is set below.
-    int caps[kNumPoaClasses] = {4, 4, 5, 0, 0, 0};
+    // After Poa::fetch_next and with class 1 at one window per wave (8 KB per wave): {5,5,6} (profiles/diag/r03_wave_wide_sweep2.sh:
+    // C2 2.56 ms, 0.5 % read error 4.76, 1 % 10.2; {4,5,6} 2.56 / 4.72 / 11.1, {4,6,6} 2.65 / 4.96 / 11.3, {4,4,5} 2.94 / - / 9.8-11).
+    int caps[kNumPoaClasses] = {5, 5, 6, 0, 0, 0};
     if (const char* cs = getenv("HYPO_POA_CAPS")) sscanf(cs, "%d,%d,%d,%d,%d", &caps[0], &caps[1], &caps[2], &caps[3], &caps[4]);
     // One kernel after the other instead: when the last call left more than a tenth of its windows to class 3 (read error of
     // several per cent) every kernel is long and fills the chip alone, and fixed LDS shares only leave the share of whichever
@@ -723,7 +725,7 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
         const uint64_t lds_windows = (uint64_t)planned_host[0] + planned_host[1] + planned_host[2];
         bool four_groups = (uint64_t)planned_host[0] * 100 > lds_windows * 85;
         if (const char* g0 = getenv("HYPO_POA_CLASS0")) four_groups = atoi(g0) == 16;      // 16 | 32: lanes per group (tests)
-        if (!getenv("HYPO_POA_CAPS")) caps[0] = four_groups ? 7 : 4;      // (dense shape: {7,4,5} 53.8 M windows/s, {6,5,5} 50.8 M)
+        if (!getenv("HYPO_POA_CAPS") && four_groups) { caps[0] = 7; caps[1] = 6; caps[2] = 5; }      // (dense shape: {7,6,5} 76.0 M windows/s, {8,5,4} 74.8, {7,4,5} 73.4)
         (void)hipEventRecord(fork_ev, stream);
         (void)hipStreamWaitEvent(aux[0], fork_ev, 0);
         (void)hipStreamWaitEvent(aux[1], fork_ev, 0);
