@@ -1,7 +1,7 @@
 // poa_kernel.hip — gfx950 kernels and launch logic of the batched window POA.
 //
 // Execution model (MI355X: 256 CUs, 64-lane waves, 160 KiB LDS per CU):
-//   * one lane group (16, 32 or 64 lanes of a wavefront, by size class) owns one window from its first sequence
+//   * one lane group (the whole wavefront from class 1 on; 16 or 32 lanes in class 0) owns one window from its first sequence
 //     to its consensus; the window's state stays in that group's LDS slice (HBM scratch for the two largest
 //     classes), the only algorithmic HBM traffic is the packed input (read once) and the consensus (written once);
 //   * workgroups are single waves and persistent: each pulls window indices from a per-class queue
@@ -44,7 +44,10 @@ __device__ __forceinline__ uint32_t plan_key_from(const HypoWindow& W, uint32_t 
     // arms of equal length, about two per new node).  The kernel re-queues a window that outgrows its class all the same.
     uint32_t maxlen = (W.n_internal == 0 || W.type != HYPO_WIN_SHORT) ? W.draft_len + 2 : 0;
     if (narm) maxlen = maxarm + 2 > maxlen ? maxarm + 2 : maxlen;
-    const uint32_t slack = maxlen / 16 + 3, grow = changes / 2 + 3;
+#ifndef HYPO_PLAN_GROW_Q
+#define HYPO_PLAN_GROW_Q 2            // expected new nodes per differing byte, in quarters
+#endif
+    const uint32_t slack = maxlen / 16 + 3, grow = changes * HYPO_PLAN_GROW_Q / 4 + 3;
     const uint32_t est_nodes = maxlen + (grow > slack ? grow : slack);
     const ClassLimits lim[kNumPoaClasses] = {
 #define HYPO_LIM(ID, CFG) limits_of<CFG>(),
@@ -687,8 +690,8 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     hipStream_t* const aux = A->aux;
     hipEvent_t* const join_ev = A->join_ev;
     hipEvent_t& fork_ev = A->fork_ev;
-    // waves per CU of the three concurrent kernels (they share the CU's 160 KB of LDS, which is what bounds residency: 7.6 / 15.8 /
-    // 14.1 KB per wave of classes 0 / 1 / 2).  Caps whose footprints add up to about one CU's LDS make the split independent of
+    // waves per CU of the three concurrent kernels (they share the CU's 160 KB of LDS, which is what bounds residency: 8 / 8 /
+    // 14.5 KB per wave of classes 0 / 1 / 2 since class 1 runs one window per wave; 7.6 / 15.8 / 14.1 KB when the sweep below was made).  Caps whose footprints add up to about one CU's LDS make the split independent of
     // which kernel the dispatcher happens to serve first — with {5,5,5} (187 KB) the last one to arrive got what was left until
     // another finished, and which one that was depended on the stream -> hardware queue mapping of the process (C2 call 3.5 - 4.2 ms
     // for the same code).  Swept on C2 under two mappings (profiles/diag/caps_fit_sweep.sh, ms per call): {4,4,5} 3.48 / 3.48,

@@ -10,8 +10,8 @@ import json
 import os
 import sys
 
-# class 0 runs as 32;2;47 (two groups per wave) or 16;4;47 (four), whichever poa_run picked for the profiled batch
-CLASS_CFG = {0: ("32;2;47", "16;4;47"), 1: ("32;4;79",), 2: ("64;2;127;126",), 3: ("64;4;255",), 4: ("64;10;639",), 5: ("64;16;1023",)}
+# class 0 runs as 32;2;47 (two groups per wave) or 16;4;47 (four), whichever poa_run picked for the profiled batch; class 1 is 64;2;79 since round 3 (32;4;79 before)
+CLASS_CFG = {0: ("32;2;47", "16;4;47"), 1: ("64;2;79", "32;4;79"), 2: ("64;2;127;126",), 3: ("64;4;255",), 4: ("64;10;639",), 5: ("64;16;1023",)}
 
 
 def entry(path, cls, n_windows):
