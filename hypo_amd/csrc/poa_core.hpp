@@ -1516,10 +1516,16 @@ struct Poa {
                 for (int it = 0; it < 96; ++it) {
                     if (wi < 1 || wi > ti0 || wi <= ti0 - TR || wj < tj0 || wj >= tj0 + TC) break;
                     if (mode == MODE_ROV ? (wi == 0 || wj == 0) : (wi == 0 && wj == 0)) break;
-                    const int d = tdir[(ti0 - wi) * TC + (wj - tj0)];
+                    // everything a move can need of its row is asked for together with the cell's code: one LDS round trip per
+                    // move instead of a chain of two or three (code -> metadata -> second predecessor)
+                    const int trow = ti0 - wi;
+                    const int d = tdir[trow * TC + (wj - tj0)];
+                    int nd = (int)tr2n[trow], p1r = KIN >= 2 ? (int)tp1[trow] : 0;
+                    uint32_t mt = tmeta[trow];
+                    HYPO_ARRIVED(d); HYPO_ARRIVED(nd); HYPO_ARRIVED(p1r); HYPO_ARRIVED(mt);
                     if (d == DIR_FAST) {                          // diagonal to the row before
                         if (wj == 0) { wstop = 1; break; }
-                        posnode[wj - 1] = (int16_t)tr2n[ti0 - wi]; --wj; --wi; ++ws;
+                        posnode[wj - 1] = (int16_t)nd; --wj; --wi; ++ws;
                         continue;
                     }
                     if (d == DIR_HORIZ) {
@@ -1528,12 +1534,11 @@ struct Poa {
                         continue;
                     }
                     const int p = dir_pred(d);
-                    const uint32_t mt = tmeta[ti0 - wi];
                     if (meta_k(mt) && p > 1) { wstop = 2; break; }
-                    const int pi = meta_k(mt) ? (p == 0 ? meta_p0(mt) : (int)tp1[ti0 - wi]) : 0;
+                    const int pi = meta_k(mt) ? (p == 0 ? meta_p0(mt) : p1r) : 0;
                     if (!is_vert(d)) {
                         if (wj == 0) { wstop = 1; break; }
-                        posnode[wj - 1] = (int16_t)tr2n[ti0 - wi]; --wj;
+                        posnode[wj - 1] = (int16_t)nd; --wj;
                     }
                     wi = pi; ++ws;
                 }
@@ -1568,8 +1573,15 @@ struct Poa {
     // RING1 most recent rows in LDS), row metadata and the second predecessor's row refilled 64 rows at a time, 8-bit codes
     // (any in-degree), the list of rows tied for the end row that the lazy rank order needs (*ntie_out, newslot[]).
     // Returns the end row as lane `L / CPL` sees it (the caller broadcasts), like the loop it replaces.
-    HD int rows_pk_hyb(int mode, int m, int n, int gp, int S, int R, int* ntie_out) {
-        constexpr int NP = CPL / 2;
+    template <int NP>
+    struct alignas(pow2_of(NP * 4)) PackPX { P2 v[NP]; };
+    template <int NP>
+    struct alignas(pow2_of(NP * 2)) DPackX { uint8_t v[2 * NP]; };
+    template <int NP>
+    HD int rows_pk_hyb_w(int mode, int m, int n, int gp, int S, int R, int* ntie_out) {
+        constexpr int CPL = 2 * NP;                          // columns per lane of THIS alignment (shadows the class's)
+        typedef PackPX<NP> PackP;
+        typedef DPackX<NP> DPack;
         constexpr int TIECAP = 48;
         const int j0 = CPL * g.lane;
         int amax = m < 0 ? -m : m; { const int b = n < 0 ? -n : n, c2 = gp < 0 ? -gp : gp; amax = amax > b ? amax : b; amax = amax > c2 ? amax : c2; }
@@ -1753,6 +1765,28 @@ struct Poa {
         return g.shfl(best_i, le);
     }
 
+    // Columns per lane follow the sequence in hand: the row loop is VALU bound (two waves per SIMD, both in it most of the time) and
+    // its cost grows with the register pairs a lane carries whether the columns exist or not.  A LONG window's arms are 120-550
+    // bases, the class is built for 639: rows_pk_hyb_w<2..5> = 4 / 6 / 8 / 10 columns per lane for up to 256 / 384 / 512 / 640
+    // columns (Poa::hyb_pairs; the row stride is a multiple of the lane's columns, Poa::align).  Scores, codes and their places
+    // in memory do not depend on the split.
+    static constexpr int HYB_NP_MAX = Cfg::CPL / 2;
+#ifndef HYPO_HYB_ADAPT
+#define HYPO_HYB_ADAPT 1
+#endif
+    HD static constexpr int hyb_pairs(int W) {             // register pairs per lane for rows of W columns
+        return !HYPO_HYB_ADAPT ? HYB_NP_MAX : (W <= 2 * GW * 2 && HYB_NP_MAX >= 2 ? 2 : (W <= 3 * GW * 2 && HYB_NP_MAX >= 3 ? 3 : (W <= 4 * GW * 2 && HYB_NP_MAX >= 4 ? 4 : HYB_NP_MAX)));
+    }
+    HD int rows_pk_hyb(int mode, int m, int n, int gp, int S, int R, int* ntie_out) {
+        if constexpr (HYB_NP_MAX > 4) {
+            const int np = g.uniform(hyb_pairs(L + 1));
+            if (np == 2) return rows_pk_hyb_w<2>(mode, m, n, gp, S, R, ntie_out);
+            if (np == 3) return rows_pk_hyb_w<3>(mode, m, n, gp, S, R, ntie_out);
+            if (np == 4) return rows_pk_hyb_w<4>(mode, m, n, gp, S, R, ntie_out);
+        }
+        return rows_pk_hyb_w<HYB_NP_MAX>(mode, m, n, gp, S, R, ntie_out);
+    }
+
     // [tb_fv, L) and tb_steps (number of traceback steps; 0 = "empty alignment").
     HD int align(int mode, int m, int n, int gp) {
         tb_steps = 0; tb_fv = L;
@@ -1766,7 +1800,12 @@ struct Poa {
         // direction codes (traceback_tiled) are 16-byte aligned
         constexpr int SQ = (Cfg::HYBRID && Cfg::PATHCAP > 0) ? (CPL % 16 == 0 ? CPL : (CPL % 8 == 0 ? 2 * CPL : (CPL % 4 == 0 ? 4 * CPL : (CPL % 2 == 0 ? 8 * CPL : 16 * CPL)))) : CPL;
         static_assert(Lay::SMAX % SQ == 0 || !(Cfg::HYBRID && Cfg::PATHCAP > 0), "largest row stride is a multiple of the stride quantum");
-        const int S = (W + SQ - 1) / SQ * SQ;
+        int sq = SQ;
+        if constexpr (Cfg::PACKED_HYB && CPL / 2 > 4) {     // columns per lane follow the sequence (Poa::rows_pk_hyb): stride = a multiple of them and of 16
+            const int np = hyb_pairs(W);
+            sq = np == 3 ? 48 : (np == CPL / 2 ? SQ : 16);
+        }
+        const int S = (W + sq - 1) / sq * sq;
         if (n_nodes * S > Cfg::DIRCELLS) return RES_OVERFLOW;
         if (sizeof(score_t) < 4) {                          // int16 rows are exact only below this bound
             int a = m < 0 ? -m : m, b = n < 0 ? -n : n, c2 = gp < 0 ? -gp : gp;

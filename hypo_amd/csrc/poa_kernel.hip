@@ -231,6 +231,9 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
     char* fast = smem + (size_t)grp * PoaLayout<Cfg>::FAST_BYTES;     // hybrid classes only
     char* dirg = Cfg::DIRG ? fresh(ka)->dirg + ((size_t)blockIdx.x * GPW + grp) * PoaLayout<Cfg>::DIRG_BYTES : nullptr;
     const int cls = fresh(ka)->cls;
+    // wave-time this launch takes (what poa_run's wave shares of the NEXT call are made from): -start now, +end at exit, so
+    // that nothing lives in a register in between (a polling launch mostly waits: not counted)
+    if (!POLL && USE_LDS && wl == 0) atomicAdd((unsigned long long*)(fresh(ka)->Q.work + cls), 0ull - (unsigned long long)wall_clock64());
     const uint32_t count = POLL ? 0u : *fresh(ka)->bound;   // queue slots [.., *bound) are final when this launch starts (POLL: the queue grows)
     const uint32_t planned = fresh(ka)->Q.planned[cls];      // slots from here on hold re-queued windows (they may come with a spill)
     const PoaParamRef P{&ka->P};
@@ -427,6 +430,7 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
         __threadfence();
         atomicAdd(fresh(ka)->Q.done + cls, 1u);
     }
+    if (!POLL && USE_LDS && wl == 0) atomicAdd((unsigned long long*)(fresh(ka)->Q.work + cls), (unsigned long long)wall_clock64());
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -557,6 +561,60 @@ static size_t poa_workspace_prefix(uint32_t n_windows) {       // header, class 
     return b;
 }
 
+// ------------------------------------------------------------------------------------------------
+// wave shares of the three concurrent LDS-class kernels from the work of the last call
+// ------------------------------------------------------------------------------------------------
+// What a wave of a class takes of a CU: LDS bytes (granules of 512) and vector registers (granules of 8, 2 048 per CU).  The
+// shares {w0, w1, w2} minimise max_c work[c] / w[c] under both budgets; the LDS budget is a CU's 160 KB plus the 5 % by which the
+// measured-best fixed shares {5,5,6} overbook it (167 KB: the kernel submitted last grows into what the first one to run dry
+// leaves), less what the polling class-3 waves hold.  Among shares within 3 % of the best the one with most waves wins (latency).
+struct WaveFootprint { size_t lds; int vgprs; int max_waves; };
+template <class Cfg> static WaveFootprint footprint_of() {
+    auto kern = poa_class_kernel<Cfg, true, false>;
+    constexpr int GPW = 64 / Cfg::GW;
+    WaveFootprint f;
+    f.lds = ((size_t)GPW * PoaLayout<Cfg>::BYTES + 511) / 512 * 512;
+    hipFuncAttributes at;
+    f.vgprs = 128;
+    if (hipFuncGetAttributes(&at, (const void*)kern) == hipSuccess && at.numRegs >= 8 && at.numRegs <= 512) f.vgprs = (at.numRegs + 7) / 8 * 8;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 64, (size_t)GPW * PoaLayout<Cfg>::BYTES) != hipSuccess || per_cu < 1) per_cu = 4;
+    f.max_waves = per_cu;
+    // (the occupancy query knows the register file: a footprint it contradicts is not trusted)
+    if (f.max_waves * f.vgprs > 2048) f.vgprs = 2048 / f.max_waves / 8 * 8;
+    return f;
+}
+static void pick_wave_shares(const uint64_t work[3], bool four_groups, int poll_waves_per_cu, int caps[]) {
+    static const WaveFootprint fp0 = footprint_of<PoaClass0>(), fp0w = footprint_of<PoaClass0W>(), fp1 = footprint_of<PoaClass1>(),
+                               fp2 = footprint_of<PoaClass2>(), fp3 = footprint_of<PoaClass3>();
+    const WaveFootprint fp[3] = {four_groups ? fp0 : fp0w, fp1, fp2};
+    const double total = (double)work[0] + (double)work[1] + (double)work[2];
+    // nothing measured (first call, or a torn / implausible read: a wave lives < 10 s = 1e9 ticks, a launch has < 1e5 waves)
+    if (total <= 0.0) return;
+    for (int c = 0; c < 3; ++c) if (work[c] > (uint64_t)1e14) return;
+    double lds_budget = 160.0 * 1024.0 * 1.05 - (double)poll_waves_per_cu * (double)fp3.lds;
+    double vgpr_budget = 2048.0 - (double)poll_waves_per_cu * (double)fp3.vgprs * 0.5;      // (a polling wave sleeps most of the time, but it holds its registers)
+    double best_t = 1e300; int best[3] = {caps[0], caps[1], caps[2]}, best_sum = 0;
+    for (int pass = 0; pass < 2; ++pass) {                 // pass 0: the best time; pass 1: most waves within 3 % of it
+        for (int w0 = 1; w0 <= fp[0].max_waves; ++w0)
+            for (int w1 = 1; w1 <= fp[1].max_waves; ++w1)
+                for (int w2 = 1; w2 <= fp[2].max_waves; ++w2) {
+                    const double lds = (double)w0 * fp[0].lds + (double)w1 * fp[1].lds + (double)w2 * fp[2].lds;
+                    const double vg = (double)w0 * fp[0].vgprs + (double)w1 * fp[1].vgprs + (double)w2 * fp[2].vgprs;
+                    if (lds > lds_budget || vg > vgpr_budget) continue;
+                    double t = (double)work[0] / w0;
+                    if ((double)work[1] / w1 > t) t = (double)work[1] / w1;
+                    if ((double)work[2] / w2 > t) t = (double)work[2] / w2;
+                    if (pass == 0) { if (t < best_t) best_t = t; }
+                    else if (t <= best_t * 1.03 && w0 + w1 + w2 > best_sum) { best_sum = w0 + w1 + w2; best[0] = w0; best[1] = w1; best[2] = w2; }
+                }
+        if (best_t >= 1e300) return;                       // nothing fits (cannot happen: {1,1,1} does)
+    }
+    caps[0] = best[0]; caps[1] = best[1]; caps[2] = best[2];
+    if (getenv("HYPO_POA_ADAPT_LOG")) fprintf(stderr, "[hypo_gpu] wave shares {%d,%d,%d} from wave-time {%.2f, %.2f, %.2f} ms (x 1 wave), poll %d\n",
+                                               caps[0], caps[1], caps[2], work[0] * 1e-5, work[1] * 1e-5, work[2] * 1e-5, poll_waves_per_cu);
+}
+
 size_t poa_workspace_bytes(uint32_t n_windows, int long_groups, uint64_t computed_arm_offsets) {
     size_t big = 0;                                         // the HBM-scratch classes run one after the other and share the region
     int g4 = long_groups > 0 ? long_groups : max_global_groups(4, n_windows);
@@ -612,6 +670,7 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     off += poa_spill_bytes(n_windows);
     Q.spill_used = (uint32_t*)(ws + 7872);
     Q.done = (uint32_t*)(ws + 7808);
+    Q.work = (uint64_t*)(ws + 7936);
     const ClassScratch scr3{ws + off, groups3_for(n_windows)};
     off += (size_t)scr3.groups * PoaLayout<PoaClass3>::DIRG_BYTES;
     const ClassScratch scr2{PoaClass2::DIRG ? ws + off : nullptr, PoaClass2::DIRG ? groups3_for(n_windows) : 0};
@@ -634,8 +693,8 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     // dispatch even if every wave leaves at once, and these classes are empty in most batches (a few escalated windows still
     // find a small grid waiting).
     if (!A->planned_host) {
-        if ((e = hipHostMalloc((void**)&A->planned_host, 24 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return e;
-        memset(A->planned_host, 0, 24 * sizeof(uint32_t));
+        if ((e = hipHostMalloc((void**)&A->planned_host, 40 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return e;
+        memset(A->planned_host, 0, 40 * sizeof(uint32_t));
         if ((e = hipEventCreateWithFlags(&A->planned_ev, hipEventDisableTiming)) != hipSuccess) return e;
     }
     // The FIRST call of a context waits for its own plan (nothing to go by yet).  Every later call is queued without a host wait:
@@ -700,6 +759,9 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     // C2 2.56 ms, 0.5 % read error 4.76, 1 % 10.2; {4,5,6} 2.56 / 4.72 / 11.1, {4,6,6} 2.65 / 4.96 / 11.3, {4,4,5} 2.94 / - / 9.8-11).
     int caps[kNumPoaClasses] = {5, 5, 6, 0, 0, 0};
     if (const char* cs = getenv("HYPO_POA_CAPS")) sscanf(cs, "%d,%d,%d,%d,%d", &caps[0], &caps[1], &caps[2], &caps[3], &caps[4]);
+    // wave-time per class of the last finished call (PoaQueues::work; read like the counts above: whatever call finished last)
+    uint64_t last_work[3];
+    for (int c = 0; c < 3; ++c) last_work[c] = wait_for_plan && !A->history_valid ? 0ull : ((const volatile uint64_t*)(pinned + 24))[c];
     // One kernel after the other instead: when the last call left more than a tenth of its windows to class 3 (read error of
     // several per cent) every kernel is long and fills the chip alone, and fixed LDS shares only leave the share of whichever
     // kernel ends first idle: 5 % read error 47 -> 40 ms, 3 % 30 -> 29 ms; below that the concurrent schedule wins (2 %: 20 against
@@ -729,6 +791,22 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
         bool four_groups = (uint64_t)planned_host[0] * 100 > lds_windows * 85;
         if (const char* g0 = getenv("HYPO_POA_CLASS0")) four_groups = atoi(g0) == 16;      // 16 | 32: lanes per group (tests)
         if (!getenv("HYPO_POA_CAPS") && four_groups) { caps[0] = 7; caps[1] = 6; caps[2] = 5; }      // (dense shape: {7,6,5} 76.0 M windows/s, {8,5,4} 74.8, {7,4,5} 73.4)
+        // ... and from the second call on, batches of tiny windows get their shares from the WORK of the last finished call
+        // (pick_wave_shares: wave-time per class as the kernels measured it, shares that let the three end together within the
+        // CU's LDS and registers): the mix of classes differs from genome to genome there (dense short reads: 91 % / 8 % / 1 % of
+        // the windows -> {7,5,1}, 69.6 -> 76.9-77.5 M windows/s; HiFi-like 56.3 -> 59.3-59.8 M).  Mixed batches keep the fixed
+        // shares: on the C2 batch the model's pick lost (0.2 % read error {4,4,7}: 2.57 -> 3.03 ms — class 2 issues VALU work back
+        // to back and gains little from a seventh wave, class 0 ends with single long windows, not with a shortage of waves), and
+        // from 1 % read error on the chip is full whatever the shares are: nine fixed splits, each run twice, all landed within
+        // 10.0-11.1 ms at 1 % and 17.4-19.9 ms at 2 % while the three kernels' own times swapped places from run to run
+        // (profiles/diag/r03_adapt_ab.sh, r03_caps_err_sweep.sh + .txt).  HYPO_POA_ADAPT=1 forces the model everywhere, 0 turns it off.
+        const char* adapt_env = getenv("HYPO_POA_ADAPT");
+        const bool adapt = adapt_env ? atoi(adapt_env) != 0 : four_groups;
+        if (!getenv("HYPO_POA_CAPS") && adapt && A->history_valid) {
+            const uint32_t seen3_now = last_count[3] > planned_host[3] ? last_count[3] : planned_host[3];
+            const int poll_waves_per_cu = seen3_now == 0 ? 0 : ((seen3_now + seen3_now / 4) > 512u ? 2 : 1);
+            pick_wave_shares(last_work, four_groups, poll_waves_per_cu, caps);
+        }
         (void)hipEventRecord(fork_ev, stream);
         (void)hipStreamWaitEvent(aux[0], fork_ev, 0);
         (void)hipStreamWaitEvent(aux[1], fork_ev, 0);
@@ -831,6 +909,7 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     }
     // this call's final and planned counts for the next call's grid sizes (no wait: whoever reads them gets the last finished call)
     (void)hipMemcpyAsync(pinned + 8, Q.count, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    (void)hipMemcpyAsync(pinned + 24, Q.work, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream);
     for (int c = 0; c < 8; ++c) A->last_planned[c] = hist[c];
     A->history_valid = true;
     A->history_windows = n_windows;

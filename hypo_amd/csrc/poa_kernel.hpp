@@ -23,7 +23,7 @@ inline int max_global_groups(int cls, uint32_t n_windows) {
 }
 constexpr int kMinGlobalGroups = 16;     // the smallest scratch poa_run accepts holds this many groups of the LONG class ...
 constexpr int kMinGlobalGroups5 = 4;     // ... and this many of the last one (61 MB each)
-constexpr size_t kPoaHeaderBytes = 8192; // count[8] | head[8] @64 | HypoPoaStats @128 | phase cycles @512 | hist @2048 | start @4096 | cursor @6144 | planned @7680 | head2 @7744 | done[8] @7808 | spill_used @7872
+constexpr size_t kPoaHeaderBytes = 8192; // count[8] | head[8] @64 | HypoPoaStats @128 | phase cycles @512 | hist @2048 | start @4096 | cursor @6144 | planned @7680 | head2 @7744 | done[8] @7808 | spill_used @7872 | work[8] (u64) @7936
 // resident groups of class 3 (direction codes in HBM scratch, PoaLayout::DIRG_BYTES each): what 256 CUs hold at 10 waves per CU
 constexpr int kMaxGroups3 = 2560;
 constexpr uint32_t kSequentialDivisor = 10;           // class kernels one after the other when the last call left more than 1/10 of its windows to class 3
@@ -50,6 +50,7 @@ struct PoaQueues {
     uint32_t spill_cap16;   // pool size in 16-byte units
     uint32_t* spill_used;
     uint32_t* done;         // [classes] lane groups of class c's kernels that have exited (what a polling kernel waits for)
+    uint64_t* work;         // [classes] summed lifetimes of the waves of class c's (non-polling) launches, 100 MHz ticks
 };
 
 // optional event recorder: ev[0]/ev[1] around the plan kernels, ev[2+2c]/ev[3+2c] around size-class kernel c
@@ -61,7 +62,8 @@ struct KernelEvents { hipEvent_t ev[16]; int n; };
 struct PoaAux {
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork_ev = nullptr, join_ev[4] = {nullptr, nullptr, nullptr, nullptr}, planned_ev = nullptr;
-    uint32_t* planned_host = nullptr;     // pinned: [0..7] planned counts of the call in flight, [8..15] final counts of the last finished call
+    uint32_t* planned_host = nullptr;     // pinned: [0..7] planned counts of the call in flight, [8..15] final counts of the last finished call,
+                                          // [24..39] = 8 x u64 wave-time per class of the last finished call (PoaQueues::work)
     uint32_t last_planned[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // planned counts the previous call worked with
     bool history_valid = false;           // a call has been queued on this context before
     uint32_t history_windows = 0;         // its batch size

@@ -70,3 +70,21 @@ def test_build_id_matches_sources(lib):
     for f in files:
         h.update(open(f, "rb").read())
     assert lib.hypo_gpu_build_id().decode() == h.hexdigest()[:16]
+
+
+def test_library_asks_for_hardware_queues_when_loaded():
+    """the host does not have to set GPU_MAX_HW_QUEUES; a value it does set is kept."""
+    import subprocess
+    import sys
+    if not os.path.exists(capi.LIB_PATH):
+        capi.build_library()
+    code = ("import ctypes, os, sys\n"
+            "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
+            "before = libc.getenv(b'GPU_MAX_HW_QUEUES')\n"
+            "ctypes.CDLL(sys.argv[1])\n"
+            "print(before, libc.getenv(b'GPU_MAX_HW_QUEUES'))\n")
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.run([sys.executable, "-c", code, capi.LIB_PATH], env=env, capture_output=True, text=True, check=True).stdout
+    assert out.strip() == "None b'8'", out
+    out = subprocess.run([sys.executable, "-c", code, capi.LIB_PATH], env=dict(env, GPU_MAX_HW_QUEUES="2"), capture_output=True, text=True, check=True).stdout
+    assert out.strip() == "b'2' b'2'", out
