@@ -1711,9 +1711,6 @@ struct Poa {
                     cD[q] = pk_mad(pk_sub(ONE, pk_minu(pD[q], ONE)), FC, pk_add(pD[q], pD[q]));
                     cU[q] = pk_add(pk_add(pU[q], pU[q]), ONE);
                 }
-            } else {
-                HYPO_UNROLL
-                for (int q = 0; q < NP; ++q) { cD[q] = pk_splat(fastcode); cU[q] = pk_splat(dir_vert(0)); }
             }
             P2 v[NP];
             HYPO_UNROLL
@@ -1724,12 +1721,27 @@ struct Poa {
                 const P2 HZ = pk_splat(DIR_HORIZ);
                 DPack dk;
                 PackP pk;
-                HYPO_UNROLL
-                for (int q = 0; q < NP; ++q) {
-                    const P2 tD = pk_minu(pk_sub(v[q], D[q]), ONE), tU = pk_minu(pk_sub(v[q], U[q]), ONE);
-                    const uint32_t b = (uint32_t)pk_bits(pk_mad(tD, pk_mad(tU, pk_sub(HZ, cU[q]), pk_sub(cU[q], cD[q])), cD[q]));
-                    dk.v[2 * q] = (uint8_t)b; dk.v[2 * q + 1] = (uint8_t)(b >> 16);
-                    pk.v[q] = v[q];
+                // code = cD, unless the vertical term wins (cU), unless the horizontal one does (DIR_HORIZ): cD + tD ((cU - cD) + tU (HZ - cU))
+                if (k > 1) {
+                    HYPO_UNROLL
+                    for (int q = 0; q < NP; ++q) {
+                        const P2 tD = pk_minu(pk_sub(v[q], D[q]), ONE), tU = pk_minu(pk_sub(v[q], U[q]), ONE);
+                        const uint32_t b = (uint32_t)pk_bits(pk_mad(tD, pk_mad(tU, pk_sub(HZ, cU[q]), pk_sub(cU[q], cD[q])), cD[q]));
+                        dk.v[2 * q] = (uint8_t)b; dk.v[2 * q + 1] = (uint8_t)(b >> 16);
+                        pk.v[q] = v[q];
+                    }
+                } else {                                     // one predecessor (most rows): the two codes are the same in every column
+                    HYPO_NO_IFCVT();
+                    int vCD = pk_bits(pk_splat(fastcode)), vY = pk_bits(pk_splat(dir_vert(0) - fastcode));
+                    HYPO_IN_VGPR(vCD); HYPO_IN_VGPR(vY);
+                    const P2 CDU = pk_from_bits(vCD), Y = pk_from_bits(vY), X = pk_splat(DIR_HORIZ - dir_vert(0));
+                    HYPO_UNROLL
+                    for (int q = 0; q < NP; ++q) {
+                        const P2 tD = pk_minu(pk_sub(v[q], D[q]), ONE), tU = pk_minu(pk_sub(v[q], U[q]), ONE);
+                        const uint32_t b = (uint32_t)pk_bits(pk_mad(tD, pk_mad(tU, X, Y), CDU));
+                        dk.v[2 * q] = (uint8_t)b; dk.v[2 * q + 1] = (uint8_t)(b >> 16);
+                        pk.v[q] = v[q];
+                    }
                 }
                 *(DPack*)(dir + rowS + j0) = dk;
                 if (R1 > 0) {
@@ -1761,7 +1773,7 @@ struct Poa {
             }
             g.sync();
         }
-        *ntie_out = ntie;
+        *ntie_out = g.shfl(ntie, le);                        // (group-uniform, like the end row: the caller does not know this alignment's split)
         return g.shfl(best_i, le);
     }
 

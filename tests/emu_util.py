@@ -22,6 +22,7 @@ class Emu:
     def __init__(self, asan=False, exact=True):
         build()
         name = "libhypo_emu_asan.so" if asan else ("libhypo_emu.so" if exact else "libhypo_emu_noexact.so")
+        name = os.environ.get("HYPO_EMU_LIB", name)          # (a differently built emulator, for A/B runs)
         self.lib = C.CDLL(os.path.join(BUILD, name))
         self.lib.emu_poa_batch.restype = C.c_int
         self.lib.emu_class_bytes.restype = C.c_int
