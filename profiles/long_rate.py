@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Rate of LONG windows (size class 4, state in HBM scratch): the 163 real LONG windows of tests/golden replicated.
-usage: long_rate.py [replicas]"""
+usage: long_rate.py [replicas]            (163 x replicas real LONG windows)
+       long_rate.py <n> c4                 (n noisy LONG windows of the C4 mix, sim.c4_batch: 120-500 bp, 12-45 arms, 10 % errors)"""
 import os
 import sys
 import time
@@ -19,6 +20,10 @@ def main():
     recs = [r for r in gu.load_jsonl("windows_real_long.jsonl.gz") if r["long"]]
     wins = [gu.to_window(r) for r in recs] * rep
     b = build_batch(wins)
+    if len(sys.argv) > 2 and sys.argv[2] == "c4":
+        from hypo_amd import sim
+        b = sim.c4_batch(0, rep, seed=404)
+        wins = [None] * rep
     lib = os.environ.get("HYPO_GPU_LIB")
     gpu = capi.HypoGpu(0, path=lib) if lib else capi.HypoGpu(0)
     db = gpu.device_batch(b)
@@ -47,6 +52,8 @@ def main():
               f" toposort {ph[c, 4] / max(ph[c, D + 3], 1) / 1e3:.1f} kcycles each, {ph[c, D + 10] / max(ph[c, D + 3], 1):.0f} DFS steps + {ph[c, D + 11] / max(ph[c, D + 3], 1):.0f} run steps")
     import oracle
     orc = oracle.Oracle()
+    if wins[0] is None:
+        return
     sub = build_batch(wins[:len(recs) * min(rep, 2)])
     t0 = time.perf_counter(); orc.poa_batch_raw(sub); dt2 = time.perf_counter() - t0
     print(f"CPU oracle ({orc.num_threads()} threads): {sub.n_windows} windows in {dt2 * 1e3:.0f} ms = {sub.n_windows / dt2:.0f} windows/s")
