@@ -124,6 +124,36 @@ def test_class4_long_windows_lazy_rank_order_vs_oracle():
     assert n >= 100
 
 
+def test_class4_rows_as_wide_as_the_sequence_short_windows_vs_oracle():
+    """The hybrid class's row loop carries 2-5 register pairs per lane, whichever holds the sequence in hand (Poa::rows_pk_hyb_w):
+    SHORT fuzz windows pushed straight into class 4 (prefix / suffix arms of 20-190 bases: every split within one window, kLOV /
+    kROV end rows and their ties), three score sets, against the oracle.  The first case is the window of
+    tests/sweep_parity_gpu.py's round 424242 that differed on the GPU while the tie count of an alignment was read from the lane
+    that owns the last column under the class's ten columns per lane (round 3)."""
+    import numpy as np
+    import oracle
+    from test_gpu_fuzz import _window
+    orc = oracle.Oracle()
+    e = emu_util.Emu()
+    rng = np.random.default_rng(7000 + 424242)
+    skipped = [_window(rng, False) for _ in range(6000)] + [_window(rng, True) for _ in range(150)]
+    the_one = [_window(rng, False) for _ in range(2318)][2317:]
+    del skipped
+    rng = np.random.default_rng(4242)
+    cases = [(build_batch(the_one), (3, -6, -5, 3, -5, -4))]
+    for scores in ((5, -4, -8, 3, -5, -4), (3, -6, -5, 3, -5, -4), (1, -1, -1, 1, -1, -1)):
+        cases.append((build_batch([_window(rng, False) for _ in range(120)]), scores))
+    n = 0
+    for b, scores in cases:
+        cons, st, res, _, _ = e.poa_batch(b, 4, scores)
+        want = orc.poa_batch(b, scores=scores)[0]
+        for i in range(b.n_windows):
+            if res[i] == emu_util.RES_OK:
+                assert cons[i] == want[i], (scores, i)
+                n += 1
+    assert n >= 300
+
+
 def _requeue_cases(small):
     from hypo_amd import sim
     n = 40 if small else 200
