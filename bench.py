@@ -425,8 +425,9 @@ def main():
         wl = rng.choice([3, 5, 8, 12, 16, 24, 32, 48, 64, 99], size=nd, p=[.15, .15, .15, .13, .13, .1, .1, .05, .03, .01])
         shapes = np.stack([wl, rng.integers(3, 45, size=nd), np.zeros(nd, np.int64), np.zeros(nd, np.int64), np.zeros(nd, np.int64)], axis=1)
         ddb = gpu.device_batch(sim.window_batch(nd, seed=9, shapes=shapes, read_sub=0.002))
-        for _ in range(2):
+        for _ in range(3):          # one at a time: a call sizes its launches from the last FINISHED call of the context, as in a hypo run
             ddb.run()
+            torch.cuda.synchronize(dev)
         t4 = timed(ddb.run, 4, lambda: torch.cuda.synchronize(dev))
         extra["value_dense"] = {"value": round(nd / t4, 1), "unit": "windows/s", "ms_per_call": round(t4 * 1e3, 3), "failed": ddb.stats()["n_failed"],
                                 "workload": "dense short-read shape of C4/C5 (1 M tiny windows, 45 % <= 8 bp, 3-44 arms), POA call only"}

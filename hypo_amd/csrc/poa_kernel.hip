@@ -234,6 +234,7 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
     // wave-time this launch takes (what poa_run's wave shares of the NEXT call are made from): -start now, +end at exit, so
     // that nothing lives in a register in between (a polling launch mostly waits: not counted)
     if (!POLL && USE_LDS && wl == 0) atomicAdd((unsigned long long*)(fresh(ka)->Q.work + cls), 0ull - (unsigned long long)wall_clock64());
+    if (!POLL && USE_LDS && cls == 0 && blockIdx.x == 0 && wl == 0) fresh(ka)->Q.work[6] = (uint64_t)GW;      // class 0's geometry in the call these times come from
     const uint32_t count = POLL ? 0u : *fresh(ka)->bound;   // queue slots [.., *bound) are final when this launch starts (POLL: the queue grows)
     const uint32_t planned = fresh(ka)->Q.planned[cls];      // slots from here on hold re-queued windows (they may come with a spill)
     const PoaParamRef P{&ka->P};
@@ -802,7 +803,12 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
         // (profiles/diag/r03_adapt_ab.sh, r03_caps_err_sweep.sh + .txt).  HYPO_POA_ADAPT=1 forces the model everywhere, 0 turns it off.
         const char* adapt_env = getenv("HYPO_POA_ADAPT");
         const bool adapt = adapt_env ? atoi(adapt_env) != 0 : four_groups;
-        if (!getenv("HYPO_POA_CAPS") && adapt && A->history_valid) {
+        // (the measurement must come from a call that ran class 0 in the geometry this call picks: the calls of a run are
+        // queued without waiting for each other, so the last FINISHED call may be a batch of another kind, and a class-0 wave
+        // of four groups takes twice the time of one of two)
+        const uint64_t measured_gw = ((const volatile uint64_t*)(pinned + 24))[6];
+        const bool same_kind = measured_gw == (four_groups ? (uint64_t)PoaClass0::GW : (uint64_t)PoaClass0W::GW);
+        if (!getenv("HYPO_POA_CAPS") && adapt && A->history_valid && same_kind) {
             const uint32_t seen3_now = last_count[3] > planned_host[3] ? last_count[3] : planned_host[3];
             const int poll_waves_per_cu = seen3_now == 0 ? 0 : ((seen3_now + seen3_now / 4) > 512u ? 2 : 1);
             pick_wave_shares(last_work, four_groups, poll_waves_per_cu, caps);
