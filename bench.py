@@ -111,7 +111,7 @@ def end_to_end_c3_leg():
         gen = os.path.join(ROOT, "tests", "_build", "gen_e2e_fast")
         if not os.path.exists(gen) or os.path.getmtime(gen) < os.path.getmtime(src):
             os.makedirs(os.path.dirname(gen), exist_ok=True)
-            subprocess.check_call(["g++", "-O2", "-fopenmp", "-o", gen, src])
+            subprocess.check_call(["g++", "-O2", "-fopenmp", "-o", gen, src, "-lz"])
         a = man["args"]
         tg = time.perf_counter()
         rep = json.loads(subprocess.check_output([gen, d, str(a["seed"]), str(a["contigs"]), str(a["contig_len"]), str(a["k"]),
@@ -438,6 +438,33 @@ def main():
         extra["value_c4mix"] = {"value": round(408000 / t5, 1), "unit": "windows/s", "ms_per_call": round(t5 * 1e3, 3), "failed": cdb.stats()["n_failed"],
                                 "workload": "C4 window mix: 400 000 C1-shaped SHORT + 8 000 LONG windows (120-500 bp, 12-45 noisy long-read arms) in one batch, POA call only"}
         del cdb
+        # the N > 1 workload on ONE GPU: the like-for-like base of the scaling curve (BASELINE configs[2]: the same 1.94 M windows,
+        # the same 100 scans of 1 Mbp at k = 13, the same resident-input protocol; only the all-gather has nobody to talk to)
+        if os.environ.get("HYPO_BENCH_VALUE_C3", "1") == "1":
+            n_total = int(os.environ.get("HYPO_BENCH_C3_WINDOWS", C3_REPLICAS * N_WINDOWS))
+            whole = sim.window_batch(n_total, seed=3000)
+            c3db = gpu.device_batch(whole, off=whole.slot_layout())
+            rb3 = np.random.default_rng(7)
+            bits3 = rb3.integers(0, 1 << 63, size=(1 << (2 * C3_K)) // 64, dtype=np.int64).view(np.uint64) & \
+                rb3.integers(0, 1 << 63, size=(1 << (2 * C3_K)) // 64, dtype=np.int64).view(np.uint64)
+            scans3 = []
+            for c in range(C3_CONTIGS):
+                _, p4 = sim.random_contig(C3_CONTIG_BASES, seed=2000 + c, n_frac=0.0)
+                scans3.append(gpu.device_scan(p4, C3_CONTIG_BASES, C3_K, bits3, kids_cap=C3_CONTIG_BASES // 2))
+            for s3 in scans3[1:]:
+                s3.bits = scans3[0].bits
+            def c3_step():
+                for s3 in scans3:
+                    s3.run()
+                c3db.run()
+            c3_step()
+            torch.cuda.synchronize(dev)
+            t6 = timed(c3_step, 3, lambda: torch.cuda.synchronize(dev))
+            c3st = c3db.stats()
+            extra["value_c3"] = {"value": round(n_total / t6, 1), "unit": "windows/s", "ms_per_step": round(t6 * 1e3, 3), "steps": 3, "failed": c3st["n_failed"],
+                                 "workload": f"C3 on one GPU, exactly the step `--gpus N` runs for N > 1 (strong scaling): ONE batch of {n_total} C1-shaped windows "
+                                             f"+ the solid-kmer scan of {C3_CONTIGS} x 1 Mbp (k = 13), inputs resident; divide the N-GPU `value` by this for the speed-up"}
+            del c3db, scans3, whole
         hoff = batch.slot_layout()
         for _ in range(2):
             gpu.poa_batch(batch, off=hoff)

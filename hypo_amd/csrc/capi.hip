@@ -71,6 +71,8 @@ struct Ctx {
     struct ResidentReads {
         DevBuf data, work; bool ready = false;
         uint32_t n = 0; uint64_t n_cig = 0, reads2_bytes = 0; uint32_t max_span = 0; uint64_t sum_span = 0;
+        uint64_t total_len = 0;                            // the coordinate space the reads were checked against
+        std::vector<uint32_t> ctg_min_rb, ctg_max_re;      // per contig index of read_contig: what its reads span (later calls check their tables against it)
         const uint32_t *rb = nullptr, *re = nullptr, *qae = nullptr, *cigar_off = nullptr, *cigar = nullptr, *read_contig = nullptr;
         const uint64_t* seq_off = nullptr; const uint8_t* reads2 = nullptr;
     } rr;
@@ -761,6 +763,7 @@ int hypo_gpu_reads_upload(const HypoArmsReads* A, const uint32_t* read_contig, u
     const uint32_t na = A->n_alignments;
     if (na && (!A->rb || !A->re || !A->qae || !A->seq_off || !A->reads2 || !A->cigar_off || !A->cigar)) return fail(HYPO_E_INVALID, "NULL buffer in reads");
     uint32_t max_span = 0; uint64_t sum_span = 0;
+    rr.ctg_min_rb.clear(); rr.ctg_max_re.clear();
     for (uint32_t a = 0; a < na; ++a) {
         if (A->re[a] <= A->rb[a] || A->re[a] > total_len) return fail(HYPO_E_INVALID, "alignment %u: span [%u, %u) outside the %llu bases", a, A->rb[a], A->re[a], (unsigned long long)total_len);
         if (a && A->rb[a - 1] > A->rb[a]) return fail(HYPO_E_INVALID, "alignments are not sorted by reference start (alignment %u)", a);
@@ -769,7 +772,13 @@ int hypo_gpu_reads_upload(const HypoArmsReads* A, const uint32_t* read_contig, u
         const uint32_t span = A->re[a] - A->rb[a];
         max_span = span > max_span ? span : max_span;
         sum_span += span;
+        const uint32_t rc = read_contig[a];
+        if (rc >= 0x01000000u) return fail(HYPO_E_INVALID, "alignment %u: contig index %u out of range", a, rc);
+        if (rc >= rr.ctg_min_rb.size()) { rr.ctg_min_rb.resize((size_t)rc + 1, 0xffffffffu); rr.ctg_max_re.resize((size_t)rc + 1, 0u); }
+        if (A->rb[a] < rr.ctg_min_rb[rc]) rr.ctg_min_rb[rc] = A->rb[a];
+        if (A->re[a] > rr.ctg_max_re[rc]) rr.ctg_max_re[rc] = A->re[a];
     }
+    rr.total_len = total_len;
     const uint64_t n_cig = na ? A->cigar_off[na] : 0;
     Carver c;
     const size_t o_rb = c.take((size_t)na * 4), o_re = c.take((size_t)na * 4), o_qae = c.take((size_t)na * 4), o_soff = c.take((size_t)na * 8),
@@ -836,9 +845,29 @@ int hypo_gpu_support_minimizers(const HypoMegaWindows* W, uint32_t* coverage, ui
         for (uint64_t i = W->reg_base[c] + 1; i < W->reg_base[c + 1]; ++i) if (W->start[i - 1] >= W->start[i]) return fail(HYPO_E_INVALID, "contig %u: region starts are not increasing", c);
     }
     for (uint32_t x = 0; x < W->n_info; ++x) if (W->mw_off[x] > W->mw_off[x + 1]) return fail(HYPO_E_INVALID, "mw_off decreases at %u", x);
+    // the tables against the resident reads (another caller than DeviceArms may pass tables of other contigs): every read's contig
+    // exists, its span lies inside that contig, and the MWMinimiserInfo entries its mega-windows index exist (a read that ends in
+    // the last region looks at entry info_base + (borders - 1) / 2, one past the contig's last: mw_off is padded by one on the device)
+    {
+        const auto& rr = g_ctx.rr;
+        if (rr.ctg_min_rb.size() > nc) return fail(HYPO_E_INVALID, "the resident reads name contig %zu, the tables hold %u contigs", rr.ctg_min_rb.size() - 1, nc);
+        for (uint32_t c = 0; c < nc; ++c) {
+            const uint32_t nb = W->reg_base[c + 1] - W->reg_base[c];
+            const bool has_reads = c < rr.ctg_min_rb.size() && rr.ctg_max_re[c] > 0;
+            if (!has_reads) continue;
+            if (nb < 2) return fail(HYPO_E_INVALID, "contig %u has reads but fewer than two region borders", c);
+            const uint64_t len = W->start[W->reg_base[c + 1] - 1];
+            if (rr.ctg_min_rb[c] < W->contig_base[c] || (uint64_t)rr.ctg_max_re[c] > (uint64_t)W->contig_base[c] + len)
+                return fail(HYPO_E_INVALID, "contig %u: its resident reads span [%u, %u), the tables place it at [%u, %llu)", c, rr.ctg_min_rb[c], rr.ctg_max_re[c],
+                            W->contig_base[c], (unsigned long long)((uint64_t)W->contig_base[c] + len));
+            if ((uint64_t)W->info_base[c] + (nb - 1) / 2 > (uint64_t)W->n_info)
+                return fail(HYPO_E_INVALID, "contig %u: %u region borders need MWMinimiserInfo entries up to %llu, the tables hold %u", c, nb,
+                            (unsigned long long)((uint64_t)W->info_base[c] + (nb - 1) / 2), W->n_info);
+        }
+    }
     Carver c;
     const size_t o_cb = c.take((size_t)nc * 4), o_rbase = c.take((size_t)(nc + 1) * 4), o_even = c.take(nc), o_ib = c.take((size_t)nc * 4), o_start = c.take(n_start * 4),
-                 o_off = c.take((size_t)(W->n_info + 1) * 4), o_rel = c.take(n_ent * 4), o_min = c.take(n_ent * 4), o_cov = c.take(n_ent * 4), o_sup = c.take(n_ent * 4);
+                 o_off = c.take((size_t)(W->n_info + 2) * 4), o_rel = c.take(n_ent * 4), o_min = c.take(n_ent * 4), o_cov = c.take(n_ent * 4), o_sup = c.take(n_ent * 4);
     auto& wk = g_ctx.rr.work;
     HIP_TRY(wk.alloc(c.at));
     char* d = (char*)wk.p;
@@ -846,6 +875,7 @@ int hypo_gpu_support_minimizers(const HypoMegaWindows* W, uint32_t* coverage, ui
 #define UP(off, src, bytes) do { if (bytes) HIP_TRY(hipMemcpyAsync(d + (off), (src), (bytes), hipMemcpyHostToDevice, st)); } while (0)
     UP(o_cb, W->contig_base, (size_t)nc * 4); UP(o_rbase, W->reg_base, (size_t)(nc + 1) * 4); UP(o_even, W->win_even, nc); UP(o_ib, W->info_base, (size_t)nc * 4);
     UP(o_start, W->start, n_start * 4); UP(o_off, W->mw_off, (size_t)(W->n_info + 1) * 4); UP(o_rel, W->rel_pos, n_ent * 4); UP(o_min, W->minimisers, n_ent * 4);
+    UP(o_off + (size_t)(W->n_info + 1) * 4, W->mw_off + W->n_info, 4);          // the pad entry: an empty range behind the last info
 #undef UP
     HIP_TRY(hipMemsetAsync(d + o_cov, 0, c.at - o_cov, st));
     hypo::MegaWindows M;
@@ -882,7 +912,11 @@ static int arms_build_impl(int which, const HypoArmsRegions* R, const HypoArmsRe
     uint32_t max_span = 0;
     uint64_t sum_span = 0;
     for (uint32_t i = 0; i < nr; ++i) if (R->start[i] >= R->start[i + 1]) return fail(HYPO_E_INVALID, "region %u is empty or the starts are not increasing", i);
-    if (resident) { max_span = g_ctx.rr.max_span; sum_span = g_ctx.rr.sum_span; }
+    if (resident) {
+        if (total_len != g_ctx.rr.total_len)
+            return fail(HYPO_E_INVALID, "the regions cover %llu bases, the resident reads were checked against %llu (hypo_gpu_reads_upload)", (unsigned long long)total_len, (unsigned long long)g_ctx.rr.total_len);
+        max_span = g_ctx.rr.max_span; sum_span = g_ctx.rr.sum_span;
+    }
     for (uint32_t a = 0; a < (resident ? 0u : na); ++a) {
         if (A->re[a] <= A->rb[a] || A->re[a] > total_len) return fail(HYPO_E_INVALID, "alignment %u: span [%u, %u) outside the %llu bases", a, A->rb[a], A->re[a], (unsigned long long)total_len);
         if (a && A->rb[a - 1] > A->rb[a]) return fail(HYPO_E_INVALID, "alignments are not sorted by reference start (alignment %u)", a);

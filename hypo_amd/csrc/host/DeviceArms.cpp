@@ -406,6 +406,12 @@ int DeviceArms::polish_impl(bool lng, const ScoreParams& sp, bool keep_arms, std
     rc = (lng ? hypo_gpu_arms_download_long : hypo_gpu_arms_download)(hw.data(), win_region.data(), nullptr, nullptr, nullptr, nullptr);
     if (rc != HYPO_OK) return rc;
     if (timing) std::fprintf(stderr, "[timing] device arms: buffers %.3f s, hypo_gpu_arms_poa%s %.3f s, descriptors %.3f s\n", secs(tp, t0), lng ? "_long" : "", secs(t0, t1), secs(t1, now()));
+    // (every status byte starts as HYPO_ST_UNWRITTEN on the device: a window no kernel answered is an internal error, not a retry)
+    for (uint32_t i = 0; i < n; ++i)
+        if (st[i] == HYPO_ST_UNWRITTEN) {
+            std::fprintf(stderr, "[Hypo::Window] Error: resident window %u of %u came back unanswered by the device (status 0xff)\n", i, n);
+            return HYPO_E_INVALID;
+        }
     std::vector<uint32_t> again, all;
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < (int64_t)n; ++i)

@@ -302,10 +302,20 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
             uint32_t cv = 0;
             if (HYPO_CARRY_SPILL && rc == RES_OVERFLOW && stt[PoaT::ST_CKIND] != PoaT::CARRY_NONE) {
                 const uint32_t sz16 = poa.spill_size() >> 4;
-                uint32_t off = 0;
-                if (g.lane == 0) off = atomicAdd(fresh(ka)->Q.spill_used, sz16);
+                // (the cursor saturates: a request that does not fit leaves it where it is, so that it cannot wrap around after 2^32
+                // units of failed requests and hand out memory that still holds another window's spill)
+                const uint32_t cap16 = fresh(ka)->Q.spill_cap16;
+                uint32_t off = 0xffffffffu;
+                if (g.lane == 0) {
+                    uint32_t cur = __hip_atomic_load(fresh(ka)->Q.spill_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    while ((uint64_t)cur + sz16 <= (uint64_t)cap16) {
+                        const uint32_t seen = atomicCAS(fresh(ka)->Q.spill_used, cur, cur + sz16);
+                        if (seen == cur) { off = cur; break; }
+                        cur = seen;
+                    }
+                }
                 off = (uint32_t)g.shfl((int)off, 0);
-                if ((uint64_t)off + sz16 <= (uint64_t)fresh(ka)->Q.spill_cap16) {
+                if (off != 0xffffffffu) {
                     poa.spill((uint8_t*)fresh(ka)->Q.spill + (size_t)off * 16);
                     cv = off + 1;
                     if constexpr (USE_LDS) { if (g.lane == 0) stt[PoaT::ACC_NCARRIED] += 1; } else ++n_carried;
@@ -342,17 +352,23 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
             for (;;) {
                 // once the classes that feed this one are done, what is left is the regular launch's (full width, no polling)
                 if (producers_done()) return false;
-                if (aload(fresh(ka)->head) < aload(cnt)) {
-                    if (g.lane == 0) idx = atomicAdd(fresh(ka)->head, 1u);
-                    idx = (uint32_t)g.shfl((int)idx, 0);
-                    // the slot is this group's now; its entry may still be on its way (the producer bumps the count first)
+                const uint32_t h = aload(fresh(ka)->head);
+                if (h < aload(cnt)) {
+                    // Claimed with a compare-and-swap on the value just seen to be below the count: a claimed slot is always one a
+                    // producer has already counted (its entry is at most a few instructions away).  An unconditional atomicAdd let
+                    // several idle pollers that saw the same new entry claim slots BEHIND the count; one that then timed out left a
+                    // slot claimed for good, and the window later published into it was never run.
+                    uint32_t got = kQueueUnpublished;
+                    if (g.lane == 0 && atomicCAS(fresh(ka)->head, h, h + 1u) == h) got = h;
+                    got = (uint32_t)g.shfl((int)got, 0);
+                    if (got == kQueueUnpublished) continue;                           // another group took it: look again
+                    idx = got;
+                    // the slot is this group's now; its entry may still be on its way (the producer bumps the count first).  It is
+                    // never abandoned: the producer that counted it is a running wave of a launch submitted before this one.
                     const uint32_t* const slot = fresh(ka)->Q.items + (size_t)cls * fresh(ka)->Q.stride + idx;
-                    t0 = wall_clock64();
                     for (;;) {
                         const uint32_t v = aload(slot);
                         if (v != kQueueUnpublished) { *w = v; break; }
-                        if (producers_done() && aload(cnt) <= idx) return false;      // claimed a slot behind the last entry
-                        if (wall_clock64() - t0 > kPollLimitTicks) return false;       // (a producer that died between count and entry)
                         __builtin_amdgcn_s_sleep(8);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // carry[w] and the spill were written before the entry
@@ -680,6 +696,10 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     const ClassScratch scr4{scratch, groups4}, scr5{scratch, groups5}, scr_lds{nullptr, 0};
     hipError_t e = hipMemsetAsync(ws, 0, kPoaHeaderBytes, stream);
     if (e != hipSuccess) return e;
+    // every window's status starts as "not written" (HYPO_ST_UNWRITTEN) and its length as 0: a window no kernel answered cannot come
+    // back looking like HYPO_ST_OK with whatever the result buffers held before (the host mirror treats the sentinel as fatal)
+    if ((e = hipMemsetAsync(P.out_status, 0xff, n_windows, stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(P.out_len, 0, (size_t)n_windows * sizeof(uint32_t), stream)) != hipSuccess) return e;
     // class 3 is polled (poa_class_kernel<.., POLL>): its queue slots read "unpublished" until the plan or a re-queue fills them
     if ((e = hipMemsetAsync(Q.items + (size_t)3 * n_windows, 0xff, (size_t)n_windows * sizeof(uint32_t), stream)) != hipSuccess) return e;
     int pe = 0;

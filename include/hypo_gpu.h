@@ -53,6 +53,8 @@ extern "C" {
                                     (graph.cpp:184-200: alignment without any sequence position) */
 #define HYPO_ST_INVALID       4  /* the window's descriptor points outside the batch's buffers (first_arm + arms > n_arms,
                                     draft_off / arm_off + bytes beyond draft4_bytes / arms2_bytes); nothing was read there */
+#define HYPO_ST_UNWRITTEN  0xff  /* what every status byte holds when the kernels start (len = 0): a window that comes back with it
+                                    was answered by no kernel - an internal error of the library, never a property of the window */
 
 /* Reference: ScoreParams, include/globalDefs.hpp:58-66 (same field order, INT8 each). */
 typedef struct HypoScoreParams {

@@ -23,7 +23,7 @@ if free_gb < 20:
 print(f"free disk {free_gb:.0f} GB -> {n} contigs of 1 Mbp; {os.cpu_count()} host threads", flush=True)
 gen = os.path.join(ROOT, "tests", "_build", "gen_e2e_fast")
 os.makedirs(os.path.dirname(gen), exist_ok=True)
-subprocess.check_call(["g++", "-O2", "-fopenmp", "-o", gen, os.path.join(ROOT, "tests", "golden", "gen_e2e_fast.cpp")])
+subprocess.check_call(["g++", "-O2", "-fopenmp", "-o", gen, os.path.join(ROOT, "tests", "golden", "gen_e2e_fast.cpp"), "-lz"])
 t0 = time.time()
 rep = subprocess.check_output([gen, D, "77", str(n), "1000000", "15", "30", "150", "2000"], text=True)
 print(f"inputs generated in {time.time() - t0:.1f} s: {rep.strip()}; sr.sam {os.path.getsize(os.path.join(D, 'sr.sam')) / 2**30:.1f} GiB", flush=True)

@@ -134,7 +134,7 @@ FAST_GEN_BIN = os.path.join(HERE, "_build", "gen_e2e_fast")
 def build_fast_generator():
     if not os.path.exists(FAST_GEN_BIN) or os.path.getmtime(FAST_GEN_BIN) < os.path.getmtime(FAST_GEN_SRC):
         os.makedirs(os.path.dirname(FAST_GEN_BIN), exist_ok=True)
-        subprocess.check_call(["g++", "-O2", "-fopenmp", "-o", FAST_GEN_BIN, FAST_GEN_SRC])
+        subprocess.check_call(["g++", "-O2", "-fopenmp", "-o", FAST_GEN_BIN, FAST_GEN_SRC, "-lz"])
     return FAST_GEN_BIN
 
 

@@ -1,21 +1,35 @@
-// gen_e2e_fast.cpp — deterministic end-to-end inputs at the size of BASELINE's configs C3 / T1 (100 x 1 Mbp and larger), fast.
+// gen_e2e_fast.cpp — deterministic end-to-end inputs at the size of BASELINE's configs C3 / C4 / T1 (100 x 1 Mbp ... 3 Gbp), fast.
 //
 // Same model as tests/golden/gen_e2e.py (which is Python and takes 20 s per 5 Mbp): per contig a random truth, a draft with
 // 0.4 % substitutions / insertions / deletions each, 30x reads of 150 bp with 0.2 % substitutions whose CIGARs are the
-// composition of the truth -> draft edit script, as coordinate-sorted SAM text; the solid k-mers (canonical k-mers that occur
+// composition of the truth -> draft edit script, coordinate-sorted; the solid k-mers (canonical k-mers that occur
 // exactly once in all truths together, no homopolymer at either end, both strands set: external/suk/src/SolidKmers.cpp:166-189)
 // as aux/solid_kmers.bvsd + aux/stage.txt, which `hypo -i` loads instead of running KMC.  NOT byte-compatible with gen_e2e.py:
-// its own generator (splitmix64 per contig, integer arithmetic only), so that a 100-contig set is written in seconds on all
-// cores.  The golden of such a set is the md5 of what the REAL reference binary (tests/golden/build_reference_binary.sh) makes
-// of these files, kept in tests/golden/<name>.manifest.json together with the checksums this program prints.
+// its own generator (splitmix64 per contig, integer arithmetic only).  The golden of such a set is the md5 of what the REAL
+// reference binary (tests/golden/build_reference_binary.sh) makes of these files, kept in tests/golden/<name>.manifest.json
+// together with the checksums this program prints.
+//
+// Round 4: every contig's draft length comes from a first pass over the edit script alone (the @SQ lines / BAM reference table
+// need them before the first record), so the records stream straight to their file — no second copy of a 116 GB body —; contigs
+// are generated on all cores (`--threads`), a writer thread files chunk i while chunk i + 1 is made; k up to 17 (atomic saturating
+// k-mer counters, the 4^k sweep on all cores); `--bam` writes the same records as BAM (BGZF, deflate level 1, compressed per
+// contig on the generating thread) into sr.bam instead of sr.sam; `--fast-hash` replaces the serial FNV-1a over the whole
+// files (1 GB/s: two minutes for a 3 Gbp set) by FNV-1a over the per-contig FNV-1a values.  Without the two flags the files
+// and the printed checksums are byte for byte what the round-3 program produced (the committed manifests depend on that).
 //
 // usage: gen_e2e_fast <outdir> <seed> <n_contigs> <contig_len> <k> [coverage=30] [read_len=150] [read_sub_ppm=2000]
-// build: g++ -O2 -fopenmp -o gen_e2e_fast gen_e2e_fast.cpp        (test infrastructure: tests/ and bench.py's e2e_c3 leg only)
+//                     [--bam] [--fast-hash] [--threads N]
+// build: g++ -O2 -fopenmp -o gen_e2e_fast gen_e2e_fast.cpp -lz      (test infrastructure: tests/ and bench.py's e2e legs only)
+#include <zlib.h>
+#include <omp.h>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include <sys/stat.h>
 
@@ -30,27 +44,80 @@ struct Rng {                                     // splitmix64
 };
 
 const char kA[] = "ACGT";
+constexpr uint64_t kFnv0 = 1469598103934665603ull;
 
-uint64_t fnv(const std::string& s, uint64_t h = 1469598103934665603ull) {
-    for (unsigned char c : s) h = (h ^ c) * 1099511628211ull;
+uint64_t fnv(const char* p, size_t n, uint64_t h = kFnv0) {
+    for (size_t i = 0; i < n; ++i) h = (h ^ (unsigned char)p[i]) * 1099511628211ull;
     return h;
 }
+uint64_t fnv(const std::string& s, uint64_t h = kFnv0) { return fnv(s.data(), s.size(), h); }
 
 void append_uint(std::string& o, uint64_t v) { char b[24]; int n = snprintf(b, sizeof b, "%llu", (unsigned long long)v); o.append(b, (size_t)n); }
 
 struct Contig {
-    std::string truth, draft, sam;
-    uint64_t n_reads = 0;
+    std::string truth, draft, recs;              // recs: SAM text, or BGZF blocks of BAM records
+    uint64_t n_reads = 0, h_draft = 0, h_recs = 0;
 };
 
-// ops: 0 = M (truth base == draft base), 1 = X (substituted), 2 = D (draft lacks the truth base), 3 = I (draft has an extra base)
-void make_contig(Contig& c, uint64_t seed, int idx, uint32_t G, uint32_t cov, uint32_t rl, uint32_t sub_ppm) {
+Rng contig_rng(uint64_t seed, int idx) {
     // (the start state is itself a splitmix output of (seed, contig): states that differ by a multiple of the generator's
     // increment would give shifted copies of one stream)
     Rng seeder(seed * 0x100000001b3ull + 12345);
     uint64_t s0 = seeder.next() ^ (0xd1b54a32d192ed03ull * (uint64_t)(idx + 1));
     s0 = (s0 ^ (s0 >> 29)) * 0xbf58476d1ce4e5b9ull; s0 ^= s0 >> 32;
-    Rng r(s0);
+    return Rng(s0);
+}
+
+// BGZF (SAM spec 4.1): gzip members with a BC extra field, at most 64 KiB of payload each
+struct Bgzf {
+    std::string* out;
+    std::string buf;
+    explicit Bgzf(std::string* o) : out(o) { buf.reserve(0xff00); }
+    void put(const void* p, size_t n) {
+        const char* c = (const char*)p;
+        while (n) {
+            const size_t take = n < 0xff00 - buf.size() ? n : 0xff00 - buf.size();
+            buf.append(c, take); c += take; n -= take;
+            if (buf.size() == 0xff00) flush();
+        }
+    }
+    void flush() {
+        if (buf.empty()) return;
+        unsigned char z[0x10000 + 64];
+        z_stream zs; memset(&zs, 0, sizeof zs);
+        deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+        zs.next_in = (Bytef*)buf.data(); zs.avail_in = (uInt)buf.size();
+        zs.next_out = z + 18; zs.avail_out = sizeof z - 18 - 8;
+        const int rc = deflate(&zs, Z_FINISH);
+        if (rc != Z_STREAM_END) { fprintf(stderr, "gen_e2e_fast: deflate failed\n"); exit(1); }
+        const size_t clen = zs.total_out;
+        deflateEnd(&zs);
+        static const unsigned char hd[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+        memcpy(z, hd, 16);
+        const uint32_t bsize = (uint32_t)(clen + 18 + 8 - 1);
+        z[16] = (unsigned char)(bsize & 0xff); z[17] = (unsigned char)(bsize >> 8);
+        const uint32_t crc = (uint32_t)crc32(crc32(0, nullptr, 0), (const Bytef*)buf.data(), (uInt)buf.size()), isz = (uint32_t)buf.size();
+        memcpy(z + 18 + clen, &crc, 4); memcpy(z + 18 + clen + 4, &isz, 4);
+        out->append((const char*)z, clen + 26);
+        buf.clear();
+    }
+};
+const unsigned char kBgzfEof[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+int reg2bin(int64_t beg, int64_t end) {            // SAM spec 5.3
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+// ops: 0 = M (truth base == draft base), 1 = X (substituted), 2 = D (draft lacks the truth base), 3 = I (draft has an extra base)
+// cnt: saturating (at 2) counters of the canonical k-mers of all truths, shared by the generating threads
+void make_contig(Contig& c, uint64_t seed, int idx, uint32_t G, uint32_t cov, uint32_t rl, uint32_t sub_ppm, bool bam, int K, uint8_t* cnt) {
+    Rng r = contig_rng(seed, idx);
     c.truth.resize(G);
     for (uint32_t i = 0; i < G; ++i) c.truth[i] = kA[r.below(4)];
     std::vector<uint8_t> op; std::vector<char> tb, db;       // per op: kind, truth base (0 = none), draft base (0 = none)
@@ -65,6 +132,7 @@ void make_contig(Contig& c, uint64_t seed, int idx, uint32_t G, uint32_t cov, ui
     }
     const size_t n_ops = op.size();
     std::vector<uint32_t> tpos(G), dprefix(n_ops + 1);
+    c.draft.clear();
     { uint32_t t = 0, d = 0; for (size_t i = 0; i < n_ops; ++i) { dprefix[i] = d; if (tb[i]) tpos[t++] = (uint32_t)i; if (db[i]) { c.draft.push_back(db[i]); ++d; } } dprefix[n_ops] = d; }
     // reads in order of their truth start (=> non-decreasing draft start): k reads start at a position with the Poisson(cov / rl)
     // probabilities of k = 0, 1, 2 (more than two at one position: 0.1 % of the positions at 30x / 150 bp, folded into two)
@@ -72,9 +140,12 @@ void make_contig(Contig& c, uint64_t seed, int idx, uint32_t G, uint32_t cov, ui
     double e = 1.0; { double term = 1.0, sum = 1.0; for (int i = 1; i < 30; ++i) { term *= lam / i; sum += term; } e = 1.0 / sum; }   // exp(-lam)
     const uint32_t p0 = (uint32_t)(e * 1e6), p1 = (uint32_t)((e + e * lam) * 1e6);
     char name[32]; const int nl = snprintf(name, sizeof name, "ctg%d", idx + 1);
-    std::string& o = c.sam;
-    o.reserve((size_t)((double)G * lam * (rl + 48)));
-    std::string seq, cig;
+    std::string& o = c.recs;
+    o.clear();
+    o.reserve((size_t)((double)G * lam * (bam ? (rl / 2 + 48) : (rl + 48))));
+    Bgzf bz(&o);
+    std::string seq, cig, rec;
+    std::vector<uint32_t> cigops;
     uint64_t rid = 0;
     for (uint32_t s = 0; s + rl < G; ++s) {
         const uint32_t x = r.below(1000000u);
@@ -83,115 +154,199 @@ void make_contig(Contig& c, uint64_t seed, int idx, uint32_t G, uint32_t cov, ui
             size_t i0 = tpos[s], i1 = (size_t)tpos[s + rl - 1] + 1;
             while (op[i0] > 1) ++i0;                       // a read starts and ends on a base both sequences have
             while (op[i1 - 1] > 1) --i1;
-            seq.clear(); cig.clear();
-            char last = 0; uint32_t run = 0;
-            auto push = [&](char ch) { if (ch == last) ++run; else { if (last) { append_uint(cig, run); cig.push_back(last); } last = ch; run = 1; } };
+            seq.clear(); cig.clear(); cigops.clear();
+            char last = 0; uint32_t run = 0, rspan = 0;
+            auto emit = [&]() { if (!last) return; if (bam) cigops.push_back((run << 4) | (last == 'M' ? 0u : (last == 'I' ? 1u : 2u))); else { append_uint(cig, run); cig.push_back(last); } };
+            auto push = [&](char ch) { if (ch == last) ++run; else { emit(); last = ch; run = 1; } };
             for (size_t i = i0; i < i1; ++i) {
-                if (op[i] <= 1) { char b = tb[i]; if (r.ppm(sub_ppm)) b = kA[r.below(4)]; seq.push_back(b); push('M'); }
+                if (op[i] <= 1) { char b = tb[i]; if (r.ppm(sub_ppm)) b = kA[r.below(4)]; seq.push_back(b); push('M'); ++rspan; }
                 else if (op[i] == 2) { seq.push_back(tb[i]); push('I'); }
-                else push('D');
+                else { push('D'); ++rspan; }
             }
-            append_uint(cig, run); cig.push_back(last);
-            o.push_back('r'); append_uint(o, rid++); o.append("\t0\t"); o.append(name, (size_t)nl); o.push_back('\t');
-            append_uint(o, (uint64_t)dprefix[i0] + 1); o.append("\t60\t"); o += cig; o.append("\t*\t0\t0\t"); o += seq; o.append("\t*\n");
+            emit();
+            if (!bam) {
+                o.push_back('r'); append_uint(o, rid++); o.append("\t0\t"); o.append(name, (size_t)nl); o.push_back('\t');
+                append_uint(o, (uint64_t)dprefix[i0] + 1); o.append("\t60\t"); o += cig; o.append("\t*\t0\t0\t"); o += seq; o.append("\t*\n");
+            } else {
+                char qn[24]; const int ql = snprintf(qn, sizeof qn, "r%llu", (unsigned long long)rid++) + 1;
+                const int32_t pos = (int32_t)dprefix[i0], lseq = (int32_t)seq.size();
+                const uint32_t ncig = (uint32_t)cigops.size();
+                const int32_t bs = 32 + ql + 4 * (int32_t)ncig + (lseq + 1) / 2 + lseq;
+                rec.resize((size_t)bs + 4);
+                char* p = &rec[0];
+                auto w32 = [&](int32_t v) { memcpy(p, &v, 4); p += 4; };
+                auto w16 = [&](uint16_t v) { memcpy(p, &v, 2); p += 2; };
+                w32(bs); w32(idx); w32(pos); *p++ = (char)ql; *p++ = 60; w16((uint16_t)reg2bin(pos, pos + (int64_t)rspan)); w16((uint16_t)ncig); w16(0); w32(lseq); w32(-1); w32(-1); w32(0);
+                memcpy(p, qn, (size_t)ql); p += ql;
+                memcpy(p, cigops.data(), 4 * (size_t)ncig); p += 4 * (size_t)ncig;
+                for (int32_t i = 0; i < lseq; i += 2) {
+                    auto code = [](char ch) { return ch == 'A' ? 1 : (ch == 'C' ? 2 : (ch == 'G' ? 4 : 8)); };
+                    *p++ = (char)((code(seq[(size_t)i]) << 4) | (i + 1 < lseq ? code(seq[(size_t)i + 1]) : 0));
+                }
+                memset(p, 0xff, (size_t)lseq);
+                bz.put(rec.data(), rec.size());
+            }
         }
     }
+    if (bam) bz.flush();
     c.n_reads = rid;
+    c.h_draft = fnv(c.draft);
+    c.h_recs = fnv(c.recs);
+    // canonical k-mers of the truth into the shared counters (saturating at 2: the result does not depend on the order)
+    uint64_t fw = 0, rv = 0; const uint64_t mask = (1ull << (2 * K)) - 1;
+    for (uint32_t i = 0; i < G; ++i) {
+        const uint64_t b = (uint64_t)(strchr(kA, c.truth[i]) - kA);
+        fw = ((fw << 2) | b) & mask;
+        rv = (rv >> 2) | ((3 - b) << (2 * (K - 1)));
+        if (i + 1 >= (uint32_t)K) {
+            const uint64_t cn = fw < rv ? fw : rv;
+            uint8_t v = __atomic_load_n(&cnt[cn], __ATOMIC_RELAXED);
+            while (v < 2 && !__atomic_compare_exchange_n(&cnt[cn], &v, (uint8_t)(v + 1), true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+        }
+    }
+    std::string().swap(c.truth);
+}
+
+// first pass: the draft's length only — the same draws as make_contig's truth and edit script (a substituted base is drawn until
+// it differs from the truth base, so the truth bases are kept for the length of this call: 1 byte per base)
+uint32_t draft_length_exact(uint64_t seed, int idx, uint32_t G) {
+    Rng r = contig_rng(seed, idx);
+    std::vector<char> truth(G);
+    for (uint32_t i = 0; i < G; ++i) truth[i] = kA[r.below(4)];
+    uint32_t d = 0;
+    for (uint32_t i = 0; i < G; ++i) {
+        const char t = truth[i];
+        const uint32_t x = r.below(1000000u);
+        if (x < 4000) {}
+        else if (x < 8000) { char b; do b = kA[r.below(4)]; while (b == t); ++d; }
+        else ++d;
+        if (r.ppm(4000)) { (void)r.below(4); ++d; }
+    }
+    return d;
 }
 
 }  // namespace
 
 int main(int argc, char** argv) {
-    if (argc < 6) { fprintf(stderr, "usage: gen_e2e_fast <outdir> <seed> <n_contigs> <contig_len> <k> [coverage=30] [read_len=150] [read_sub_ppm=2000]\n"); return 2; }
-    const std::string out = argv[1];
-    const uint64_t seed = strtoull(argv[2], nullptr, 10);
-    const int nc = atoi(argv[3]);
-    const uint32_t G = (uint32_t)strtoul(argv[4], nullptr, 10);
-    const int K = atoi(argv[5]);
-    const uint32_t cov = argc > 6 ? (uint32_t)atoi(argv[6]) : 30, rl = argc > 7 ? (uint32_t)atoi(argv[7]) : 150, sub = argc > 8 ? (uint32_t)atoi(argv[8]) : 2000;
-    if (nc < 1 || G < 4 * rl || K < 5 || K > 15) { fprintf(stderr, "gen_e2e_fast: bad arguments\n"); return 2; }
+    std::vector<const char*> pos;
+    bool bam = false, fast_hash = false;
+    int threads = omp_get_max_threads();
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--bam")) bam = true;
+        else if (!strcmp(argv[i], "--fast-hash")) fast_hash = true;
+        else if (!strcmp(argv[i], "--threads") && i + 1 < argc) threads = atoi(argv[++i]);
+        else pos.push_back(argv[i]);
+    }
+    if (pos.size() < 5) { fprintf(stderr, "usage: gen_e2e_fast <outdir> <seed> <n_contigs> <contig_len> <k> [coverage=30] [read_len=150] [read_sub_ppm=2000] [--bam] [--fast-hash] [--threads N]\n"); return 2; }
+    const std::string out = pos[0];
+    const uint64_t seed = strtoull(pos[1], nullptr, 10);
+    const int nc = atoi(pos[2]);
+    const uint32_t G = (uint32_t)strtoul(pos[3], nullptr, 10);
+    const int K = atoi(pos[4]);
+    const uint32_t cov = pos.size() > 5 ? (uint32_t)atoi(pos[5]) : 30, rl = pos.size() > 6 ? (uint32_t)atoi(pos[6]) : 150, sub = pos.size() > 7 ? (uint32_t)atoi(pos[7]) : 2000;
+    if (nc < 1 || G < 4 * rl || K < 5 || K > 17 || threads < 1) { fprintf(stderr, "gen_e2e_fast: bad arguments\n"); return 2; }
+    omp_set_num_threads(threads);
     mkdir(out.c_str(), 0777); mkdir((out + "/aux").c_str(), 0777);
     FILE* fd = fopen((out + "/draft.fa").c_str(), "wb");
-    FILE* fs = fopen((out + "/sr.sam").c_str(), "wb");
+    FILE* fs = fopen((out + (bam ? "/sr.bam" : "/sr.sam")).c_str(), "wb");
     if (!fd || !fs) { perror("gen_e2e_fast"); return 1; }
+    setvbuf(fd, nullptr, _IOFBF, 1 << 22); setvbuf(fs, nullptr, _IOFBF, 1 << 22);
+    // ---- first pass: draft lengths (the header names them) ----
+    std::vector<uint32_t> dlen((size_t)nc);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int c = 0; c < nc; ++c) dlen[(size_t)c] = draft_length_exact(seed, c, G);
     {   // header
         std::string h = "@HD\tVN:1.6\tSO:coordinate\n";
-        fwrite(h.data(), 1, h.size(), fs);
+        for (int c = 0; c < nc; ++c) { char q[96]; const int m = snprintf(q, sizeof q, "@SQ\tSN:ctg%d\tLN:%u\n", c + 1, dlen[(size_t)c]); h.append(q, (size_t)m); }
+        if (!bam) fwrite(h.data(), 1, h.size(), fs);
+        else {
+            std::string hb, blk;
+            hb.append("BAM\1", 4);
+            const int32_t lt = (int32_t)h.size(), nr = nc;
+            hb.append((const char*)&lt, 4); hb += h; hb.append((const char*)&nr, 4);
+            for (int c = 0; c < nc; ++c) {
+                char nm[32]; const int32_t ln = snprintf(nm, sizeof nm, "ctg%d", c + 1) + 1, lr = (int32_t)dlen[(size_t)c];
+                hb.append((const char*)&ln, 4); hb.append(nm, (size_t)ln); hb.append((const char*)&lr, 4);
+            }
+            Bgzf bz(&blk); bz.put(hb.data(), hb.size()); bz.flush();
+            fwrite(blk.data(), 1, blk.size(), fs);
+        }
     }
     // k-mer counts over all truths (canonical, saturating at 2)
     const uint64_t nk = 1ull << (2 * K);
-    std::vector<uint8_t> cnt(nk, 0);
-    std::vector<Contig> cs((size_t)nc);
-    uint64_t h_draft = 1469598103934665603ull, h_sam = 1469598103934665603ull, n_reads = 0, draft_bases = 0;
-    std::vector<std::string> sq((size_t)nc);
-    // contigs are generated in chunks of `par` in parallel and written in order; the @SQ lines need every draft length first, so
-    // the records are kept per chunk and the header is completed by a first pass that only builds the drafts' lengths — cheaper:
-    // generate everything chunk by chunk into a body file and prepend the header at the end.
-    FILE* fb = fopen((out + "/sr.body.tmp").c_str(), "wb");
-    if (!fb) { perror("gen_e2e_fast"); return 1; }
-    const int par = 16;
-    for (int c0 = 0; c0 < nc; c0 += par) {
-        const int c1 = c0 + par < nc ? c0 + par : nc;
-#pragma omp parallel for schedule(dynamic, 1)
-        for (int c = c0; c < c1; ++c) make_contig(cs[(size_t)c], seed, c, G, cov, rl, sub);
+    uint8_t* cnt = (uint8_t*)calloc(nk, 1);
+    if (!cnt) { fprintf(stderr, "gen_e2e_fast: no memory for %llu k-mer counters\n", (unsigned long long)nk); return 1; }
+    uint64_t h_draft = kFnv0, h_sam = kFnv0, n_reads = 0, draft_bases = 0;
+    // chunks of `par` contigs: made on all threads, filed in order by a writer thread while the next chunk is made
+    const int par = threads < 16 ? 16 : threads;
+    std::vector<Contig> bufs[2]; bufs[0].resize((size_t)par); bufs[1].resize((size_t)par);
+    std::thread writer;
+    auto file_chunk = [&](std::vector<Contig>* cs, int c0, int c1) {
         for (int c = c0; c < c1; ++c) {
-            Contig& C = cs[(size_t)c];
+            Contig& C = (*cs)[(size_t)(c - c0)];
+            if (C.draft.size() != dlen[(size_t)c]) { fprintf(stderr, "gen_e2e_fast: internal error: draft length of contig %d\n", c + 1); exit(1); }
             char hd[64]; const int n = snprintf(hd, sizeof hd, ">ctg%d\n", c + 1);
             fwrite(hd, 1, (size_t)n, fd); fwrite(C.draft.data(), 1, C.draft.size(), fd); fputc('\n', fd);
-            h_draft = fnv(C.draft, h_draft);
-            char q[96]; const int m = snprintf(q, sizeof q, "@SQ\tSN:ctg%d\tLN:%zu\n", c + 1, C.draft.size());
-            sq[(size_t)c].assign(q, (size_t)m);
-            fwrite(C.sam.data(), 1, C.sam.size(), fb);
-            h_sam = fnv(C.sam, h_sam);
+            fwrite(C.recs.data(), 1, C.recs.size(), fs);
+            if (fast_hash) { h_draft = fnv((const char*)&C.h_draft, 8, h_draft); h_sam = fnv((const char*)&C.h_recs, 8, h_sam); }
+            else { h_draft = fnv(C.draft, h_draft); h_sam = fnv(C.recs, h_sam); }
             n_reads += C.n_reads; draft_bases += C.draft.size();
-            // canonical k-mers of the truth
-            uint64_t fw = 0, rv = 0; const uint64_t mask = nk - 1;
-            for (uint32_t i = 0; i < G; ++i) {
-                const uint64_t b = (uint64_t)(strchr(kA, C.truth[i]) - kA);
-                fw = ((fw << 2) | b) & mask;
-                rv = (rv >> 2) | ((3 - b) << (2 * (K - 1)));
-                if (i + 1 >= (uint32_t)K) { const uint64_t cn = fw < rv ? fw : rv; if (cnt[cn] < 2) ++cnt[cn]; }
-            }
-            std::string().swap(C.sam); std::string().swap(C.draft);
+            std::string().swap(C.recs); std::string().swap(C.draft);
         }
+    };
+    int flip = 0;
+    for (int c0 = 0; c0 < nc; c0 += par, flip ^= 1) {
+        const int c1 = c0 + par < nc ? c0 + par : nc;
+        std::vector<Contig>& cs = bufs[flip];
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int c = c0; c < c1; ++c) make_contig(cs[(size_t)(c - c0)], seed, c, G, cov, rl, sub, bam, K, cnt);
+        if (writer.joinable()) writer.join();
+        writer = std::thread(file_chunk, &cs, c0, c1);
     }
-    fclose(fb); fclose(fd);
-    for (int c = 0; c < nc; ++c) fwrite(sq[(size_t)c].data(), 1, sq[(size_t)c].size(), fs);
-    {   // body behind the header
-        FILE* fi = fopen((out + "/sr.body.tmp").c_str(), "rb");
-        std::vector<char> buf(1 << 24);
-        size_t n;
-        while ((n = fread(buf.data(), 1, buf.size(), fi)) > 0) fwrite(buf.data(), 1, n, fs);
-        fclose(fi); remove((out + "/sr.body.tmp").c_str());
-    }
-    fclose(fs);
+    if (writer.joinable()) writer.join();
+    if (bam) fwrite(kBgzfEof, 1, sizeof kBgzfEof, fs);
+    fclose(fd); fclose(fs);
     if (getenv("GEN_DEBUG")) { uint64_t hst[3] = {0, 0, 0}; for (uint64_t v = 0; v < nk; ++v) hst[cnt[v]]++; fprintf(stderr, "counts 0/1/2+: %llu %llu %llu\n", (unsigned long long)hst[0], (unsigned long long)hst[1], (unsigned long long)hst[2]); }
     // solid set: count == 1 and no homopolymer at either end; both strands
     std::vector<uint64_t> words(nk / 64, 0);
     uint64_t n_solid = 0;
-    auto base_at = [&](uint64_t v, int pos) { return (int)((v >> (2 * (K - 1 - pos))) & 3); };      // pos 0 = first base
-    for (uint64_t v = 0; v < nk; ++v) {
-        if (cnt[v] != 1) continue;
-        // v is canonical (the smaller of the two strands' codes, which is how gen_e2e.py's min() of the strings orders them too)
-        if (base_at(v, 0) == base_at(v, 1) || base_at(v, K - 1) == base_at(v, K - 2)) continue;
-        uint64_t rcv = 0;
-        for (int p = 0; p < K; ++p) rcv |= (uint64_t)(3 - base_at(v, p)) << (2 * p);
-        words[v >> 6] |= 1ull << (v & 63);
-        words[rcv >> 6] |= 1ull << (rcv & 63);
-        ++n_solid;
+#pragma omp parallel for schedule(static) reduction(+ : n_solid)
+    for (int64_t wv = 0; wv < (int64_t)(nk / 64); ++wv) {
+        for (uint64_t v = (uint64_t)wv * 64; v < (uint64_t)wv * 64 + 64; ++v) {
+            if (cnt[v] != 1) continue;
+            auto base_at = [&](uint64_t x, int p) { return (int)((x >> (2 * (K - 1 - p))) & 3); };      // p 0 = first base
+            // v is canonical (the smaller of the two strands' codes, which is how gen_e2e.py's min() of the strings orders them too)
+            if (base_at(v, 0) == base_at(v, 1) || base_at(v, K - 1) == base_at(v, K - 2)) continue;
+            uint64_t rcv = 0;
+            for (int p = 0; p < K; ++p) rcv |= (uint64_t)(3 - base_at(v, p)) << (2 * p);
+            __atomic_fetch_or(&words[v >> 6], 1ull << (v & 63), __ATOMIC_RELAXED);
+            __atomic_fetch_or(&words[rcv >> 6], 1ull << (rcv & 63), __ATOMIC_RELAXED);
+            ++n_solid;
+        }
     }
-    uint64_t h_bv = 1469598103934665603ull;
+    free(cnt);
+    uint64_t h_bv = kFnv0;
     {
         FILE* f = fopen((out + "/aux/solid_kmers.bvsd").c_str(), "wb");
         fwrite(&nk, 8, 1, f); fwrite(words.data(), 8, words.size(), f); fclose(f);
-        for (uint64_t w : words) for (int b = 0; b < 8; ++b) h_bv = (h_bv ^ ((w >> (8 * b)) & 0xff)) * 1099511628211ull;
+        if (fast_hash) {                                         // FNV-1a over the FNV-1a of 1 MiB pieces
+            const size_t piece = (size_t)1 << 17, np = (words.size() + piece - 1) / piece;      // words per piece
+            std::vector<uint64_t> hp(np);
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < (int64_t)np; ++i) {
+                const size_t a = (size_t)i * piece, b = a + piece < words.size() ? a + piece : words.size();
+                hp[(size_t)i] = fnv((const char*)(words.data() + a), (b - a) * 8);
+            }
+            h_bv = fnv((const char*)hp.data(), hp.size() * 8);
+        } else h_bv = fnv((const char*)words.data(), words.size() * 8);
         f = fopen((out + "/aux/stage.txt").c_str(), "wb");
         fputs("Stage:SolidKmers [2026-09-28 12:00:00]\t1\n", f); fclose(f);
         f = fopen((out + "/reads.fa").c_str(), "wb");          // named on the command line, not read when -i finds the aux files
         fputs(">unused\nACGT\n", f); fclose(f);
     }
-    printf("{\"contigs\": %d, \"draft_bases\": %llu, \"reads\": %llu, \"solid_kmers\": %llu, \"fnv_draft\": \"%016llx\", \"fnv_sam_records\": \"%016llx\", \"fnv_bitvector\": \"%016llx\"}\n",
+    printf("{\"contigs\": %d, \"draft_bases\": %llu, \"reads\": %llu, \"solid_kmers\": %llu, \"fnv_draft\": \"%016llx\", \"%s\": \"%016llx\", \"fnv_bitvector\": \"%016llx\"%s}\n",
            nc, (unsigned long long)draft_bases, (unsigned long long)n_reads, (unsigned long long)n_solid,
-           (unsigned long long)h_draft, (unsigned long long)h_sam, (unsigned long long)h_bv);
+           (unsigned long long)h_draft, bam ? "fnv_bam_blocks" : "fnv_sam_records", (unsigned long long)h_sam, (unsigned long long)h_bv,
+           fast_hash ? ", \"hash\": \"fnv of per-contig fnv\"" : "");
     return 0;
 }
