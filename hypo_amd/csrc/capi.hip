@@ -77,6 +77,10 @@ struct Ctx {
         const uint64_t* seq_off = nullptr; const uint8_t* reads2 = nullptr;
     } rr;
     DevBuf solid_set; uint32_t solid_k = 0;            // hypo_gpu_solid_set_upload
+    // hypo_gpu_solid_scan_keep: the marked positions (contig-local) and their k-mers stay on the device, one pair of exact-size
+    // buffers per handle (the caller's contig number); hypo_gpu_support_kmers_kept votes against them
+    struct KeptScan { void* kids = nullptr; uint32_t* spos = nullptr; uint64_t n = 0, n_bases = 0; uint32_t k = 0; bool used = false; };
+    std::vector<KeptScan> kept;
     int poa_flags = 0;                                 // hypo_gpu_set_option
     std::vector<HypoWindow> sh_win; std::vector<uint64_t> sh_aoff, sh_off;   // rebased descriptors of this device's share (hypo_gpu_poa_batch_sharded)
     Prof prof;
@@ -240,6 +244,8 @@ static void release_ctx(Ctx& c) {
         for (auto& as : c.arms) { for (auto& a : as.arena) a.release(); as.ready = false; }
         c.rr.data.release(); c.rr.work.release(); c.rr.ready = false;
         c.solid_set.release(); c.solid_k = 0;
+        for (auto& ks : c.kept) { if (ks.kids) (void)hipFree(ks.kids); if (ks.spos) (void)hipFree(ks.spos); }
+        c.kept.clear();
         if (c.stream) (void)hipStreamDestroy(c.stream);
     }
     c.ready = false; c.device = -1; c.num_cus = 0; c.stream = nullptr;
@@ -751,6 +757,81 @@ int hypo_gpu_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k, co
     return HYPO_OK;
 }
 
+// ---- a scan whose k-mer ids and positions stay on the device (round 4) -------------------------------------------------------
+// The host of a run needs the mark bits and their rank directory (Contig::_solid_pos); the k-mer ids and the positions are read
+// by the support votes only, on the device: 8 bytes per marked position went to pageable host vectors here and came back, 12 per
+// position with the positions, for hypo_gpu_support_kmers (2 x 2 GB at 250 Mbp / k = 15, where nearly every position is marked).
+int hypo_gpu_solid_scan_keep(uint32_t handle, const uint8_t* packed4, uint64_t n_bases, uint32_t k,
+                             uint64_t* solid_pos_words, uint64_t* word_rank, uint64_t* n_solid) {
+    HYPO_LOCKED();
+    HYPO_ON_DEVICE();
+    if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
+    if (k < 2 || k > 31) return fail(HYPO_E_INVALID, "k=%u out of range 2..31", k);
+    if ((n_bases && !packed4) || (n_bases && !solid_pos_words)) return fail(HYPO_E_INVALID, "NULL buffer");
+    if (g_ctx.solid_k != k) return fail(HYPO_E_INVALID, "no %u-mer set was uploaded (hypo_gpu_solid_set_upload)", k);
+    if (handle >= (1u << 24) || n_bases >= 0xfffffff0ull) return fail(HYPO_E_INVALID, "handle or contig length out of range");
+    const uint64_t nw = (n_bases + 63) / 64, nbytes = (n_bases + 1) / 2, cap = n_bases ? n_bases : 1;
+    const bool narrow = k <= 16;
+    DevBuf* const sa = g_ctx.scan_arena;
+    DevBuf &dP = sa[0], &dWords = sa[2], &dKids = sa[3], &dRank = sa[4], &dN = sa[5], &dWS = sa[6];
+    const size_t wsb = hypo::scan_workspace_bytes(n_bases);
+    const size_t kid_bytes = narrow ? 4 : 8;
+    HIP_TRY(dP.alloc(nbytes)); HIP_TRY(dWords.alloc(nw * 8)); HIP_TRY(dKids.alloc(cap * (kid_bytes + 4) + 256));
+    HIP_TRY(dRank.alloc((nw + 1) * 8)); HIP_TRY(dN.alloc(8)); HIP_TRY(dWS.alloc(wsb));
+    hipStream_t st = g_ctx.stream;
+    char* const kid_arena = (char*)dKids.p;
+    uint32_t* const spos_arena = (uint32_t*)(kid_arena + (cap * kid_bytes + 255) / 256 * 256);
+    if (nbytes) HIP_TRY(hipMemcpyAsync(dP.p, packed4, nbytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hypo::scan_run((const uint8_t*)dP.p, n_bases, k, (const uint64_t*)g_ctx.solid_set.p, (uint64_t*)dWords.p,
+                           narrow ? nullptr : (uint64_t*)kid_arena, cap, (uint64_t*)dRank.p, (uint64_t*)dN.p, dWS.p, wsb, st, nullptr,
+                           narrow ? (uint32_t*)kid_arena : nullptr, spos_arena));
+    uint64_t ns = 0;
+    HIP_TRY(hipMemcpyAsync(&ns, dN.p, 8, hipMemcpyDeviceToHost, st));
+    if (nw) HIP_TRY(hipMemcpyAsync(solid_pos_words, dWords.p, nw * 8, hipMemcpyDeviceToHost, st));
+    if (word_rank) HIP_TRY(hipMemcpyAsync(word_rank, dRank.p, (nw + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (handle >= g_ctx.kept.size()) g_ctx.kept.resize((size_t)handle + 1);
+    Ctx::KeptScan& ks = g_ctx.kept[handle];
+    if (ks.kids) { (void)hipFree(ks.kids); ks.kids = nullptr; }
+    if (ks.spos) { (void)hipFree(ks.spos); ks.spos = nullptr; }
+    ks.used = false;
+    if (ns) {
+        HIP_TRY(hipMalloc(&ks.kids, ns * kid_bytes));
+        HIP_TRY(hipMalloc((void**)&ks.spos, ns * 4));
+        HIP_TRY(hipMemcpyAsync(ks.kids, kid_arena, ns * kid_bytes, hipMemcpyDeviceToDevice, st));      // (stream order keeps the arena
+        HIP_TRY(hipMemcpyAsync(ks.spos, spos_arena, ns * 4, hipMemcpyDeviceToDevice, st));             //  intact until these ran)
+    }
+    ks.n = ns; ks.n_bases = n_bases; ks.k = k; ks.used = true;
+    if (n_solid) *n_solid = ns;
+    return HYPO_OK;
+}
+
+int hypo_gpu_solid_release(uint32_t handle) {
+    HYPO_LOCKED();
+    HYPO_ON_DEVICE();
+    if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
+    auto drop = [](Ctx::KeptScan& ks) { if (ks.kids) (void)hipFree(ks.kids); if (ks.spos) (void)hipFree(ks.spos); ks = Ctx::KeptScan(); };
+    if (handle == 0xffffffffu) { HIP_TRY(hipStreamSynchronize(g_ctx.stream)); for (auto& ks : g_ctx.kept) drop(ks); return HYPO_OK; }
+    if (handle >= g_ctx.kept.size() || !g_ctx.kept[handle].used) return fail(HYPO_E_INVALID, "handle %u holds no scan on this context", handle);
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    drop(g_ctx.kept[handle]);
+    return HYPO_OK;
+}
+
+int hypo_gpu_host_alloc(size_t bytes, void** out) {
+    if (!out) return fail(HYPO_E_INVALID, "NULL");
+    *out = nullptr;
+    HYPO_ON_DEVICE();
+    if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
+    HIP_TRY(hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault));
+    return HYPO_OK;
+}
+int hypo_gpu_host_free(void* p) {
+    if (!p) return HYPO_OK;
+    HIP_TRY(hipHostFree(p));
+    return HYPO_OK;
+}
+
 // ---- support votes on the device (kernels in support_kernel.hip) -----------------------------------------
 
 int hypo_gpu_reads_upload(const HypoArmsReads* A, const uint32_t* read_contig, uint64_t total_len) {
@@ -826,6 +907,52 @@ int hypo_gpu_support_kmers(uint32_t k, uint64_t n_solid, const uint32_t* spos, c
     HIP_TRY(hypo::support_kmers(support_reads_of(g_ctx), k, (uint32_t)n_solid, (const uint32_t*)(d + o_sp), (const uint64_t*)(d + o_kd), (uint32_t*)(d + o_cov), (uint32_t*)(d + o_sup), st));
     HIP_TRY(hipMemcpyAsync(coverage, d + o_cov, n_solid * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(support, d + o_sup, n_solid * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return HYPO_OK;
+}
+
+int hypo_gpu_support_kmers_kept(uint32_t k, uint32_t n_contigs, const uint32_t* handles, const uint32_t* contig_base,
+                                uint32_t* coverage, uint32_t* support, uint64_t* n_solid_total) {
+    HYPO_LOCKED();
+    HYPO_ON_DEVICE();
+    if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
+    if (!g_ctx.rr.ready) return fail(HYPO_E_INVALID, "no resident reads: call hypo_gpu_reads_upload first");
+    if (k < 2 || k > 31) return fail(HYPO_E_INVALID, "k=%u out of range 2..31", k);
+    if (n_contigs && (!handles || !contig_base)) return fail(HYPO_E_INVALID, "NULL argument");
+    uint64_t ns = 0;
+    for (uint32_t c = 0; c < n_contigs; ++c) {
+        if (handles[c] >= g_ctx.kept.size() || !g_ctx.kept[handles[c]].used) return fail(HYPO_E_INVALID, "contig %u: handle %u holds no scan on this context", c, handles[c]);
+        const Ctx::KeptScan& ks = g_ctx.kept[handles[c]];
+        if (ks.k != k) return fail(HYPO_E_INVALID, "contig %u was scanned with k = %u", c, ks.k);
+        if ((uint64_t)contig_base[c] + ks.n_bases > g_ctx.rr.total_len) return fail(HYPO_E_INVALID, "contig %u ends behind the %llu bases of the resident reads", c, (unsigned long long)g_ctx.rr.total_len);
+        if (c && (uint64_t)contig_base[c] < (uint64_t)contig_base[c - 1] + g_ctx.kept[handles[c - 1]].n_bases) return fail(HYPO_E_INVALID, "contig %u overlaps the one before it", c);
+        ns += ks.n;
+    }
+    if (n_solid_total) *n_solid_total = ns;
+    if (ns >= 0xfffffff0ull) return fail(HYPO_E_CAPACITY, "%llu solid k-mers exceed the 32-bit counters of the boundary", (unsigned long long)ns);
+    if (!ns) return HYPO_OK;
+    if (!coverage || !support) return fail(HYPO_E_INVALID, "NULL buffer");
+    const bool narrow = k <= 16;
+    const size_t kid_bytes = narrow ? 4 : 8;
+    Carver c;
+    const size_t o_sp = c.take(ns * 4), o_kd = c.take(ns * kid_bytes), o_cov = c.take(ns * 4), o_sup = c.take(ns * 4);
+    auto& wk = g_ctx.rr.work;
+    HIP_TRY(wk.alloc(c.at));
+    char* d = (char*)wk.p;
+    hipStream_t st = g_ctx.stream;
+    uint64_t at = 0;
+    for (uint32_t ci = 0; ci < n_contigs; ++ci) {
+        const Ctx::KeptScan& ks = g_ctx.kept[handles[ci]];
+        if (!ks.n) continue;
+        HIP_TRY(hypo::add_base(ks.spos, (uint32_t*)(d + o_sp) + at, ks.n, contig_base[ci], st));
+        HIP_TRY(hipMemcpyAsync(d + o_kd + at * kid_bytes, ks.kids, ks.n * kid_bytes, hipMemcpyDeviceToDevice, st));
+        at += ks.n;
+    }
+    HIP_TRY(hipMemsetAsync(d + o_cov, 0, c.at - o_cov, st));
+    if (narrow) HIP_TRY(hypo::support_kmers32(support_reads_of(g_ctx), k, (uint32_t)ns, (const uint32_t*)(d + o_sp), (const uint32_t*)(d + o_kd), (uint32_t*)(d + o_cov), (uint32_t*)(d + o_sup), st));
+    else HIP_TRY(hypo::support_kmers(support_reads_of(g_ctx), k, (uint32_t)ns, (const uint32_t*)(d + o_sp), (const uint64_t*)(d + o_kd), (uint32_t*)(d + o_cov), (uint32_t*)(d + o_sup), st));
+    HIP_TRY(hipMemcpyAsync(coverage, d + o_cov, ns * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(support, d + o_sup, ns * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return HYPO_OK;
 }

@@ -58,6 +58,26 @@ void Alignment::initialise_pos(const SamRecord& rec) {
     _re = rp;
 }
 
+void Alignment::span_of(const Contig& contig, const SamRecord& rec, uint32_t& rb, uint32_t& re, uint32_t& qab, uint32_t& qae) {
+    rb = rec.pos; qab = 0;
+    uint32_t qp = 0, rp = rb, clip_end = 0;
+    bool clip_before = true;
+    for (uint32_t c : rec.cigar) {
+        const uint32_t op = cigar_op(c), len = cigar_len(c);
+        if (clip_before) {
+            if (op == CIG_S) qab += len;
+            else if (op != CIG_H) clip_before = false;
+        }
+        const uint32_t t = cigar_type(op);
+        if ((t & 3) == 3) { rp += len; qp += len; }
+        else if (t & 2) rp += len;
+        else if (t & 1) { if (!clip_before && op == CIG_S) clip_end += len; qp += len; }
+    }
+    qae = qp - clip_end;
+    re = rp;
+    check_bounds(contig, rec, rb, re);
+}
+
 // Alignment.cpp:551-571: the aligned part 2-bit packed; a read with a non-ACGT base there is dropped
 // (htslib's 4-bit codes: only A, C, G, T in either case map to 1, 2, 4, 8)
 void Alignment::copy_data(const SamRecord& rec) {

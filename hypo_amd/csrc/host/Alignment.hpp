@@ -28,6 +28,12 @@ class Alignment {
 public:
     Alignment(Contig& contig, const SamRecord& rec);                          // short read
     Alignment(Contig& contig, uint64_t norm_edit_th, const SamRecord& rec);  // long read (normalised edit distance filter)
+    // from the flat record a ReadBatch holds (ReadBatch::materialize): span, aligned query length, packed bases, CIGAR
+    Alignment(uint32_t rb, uint32_t re, uint32_t qae, const uint8_t* seq2, const uint32_t* cigar, size_t n_cigar)
+        : _rb(rb), _re(re), _qab(0), _qae(qae), _apseq(seq2, qae), _cigar(cigar, cigar + n_cigar) {}
+    // What the two constructors above compute before they copy anything (Alignment.cpp:514-549 + the bounds check of :31-36, fatal):
+    // reference span and the aligned part [qab, qae) of the query.  Used by the flat parser of Hypo::create_alignments_flat.
+    static void span_of(const Contig& contig, const SamRecord& rec, uint32_t& rb, uint32_t& re, uint32_t& qab, uint32_t& qae);
     Alignment(const Alignment&) = delete;
     Alignment& operator=(const Alignment&) = delete;
 
@@ -49,6 +55,7 @@ public:
 
 private:
     friend class DeviceArms;
+    friend class ReadBatch;
     uint32_t _rb = 0, _re = 0, _qab = 0, _qae = 0;
     PackedSeq<2> _apseq;
     std::vector<uint32_t> _cigar;

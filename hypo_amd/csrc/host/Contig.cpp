@@ -50,6 +50,28 @@ Contig::Contig(uint32_t id, const std::string& name, const std::string& seq)
 int Contig::find_solid_pos(const SolidKmers& sk, bool set_on_device) {
     const uint64_t nw = ((uint64_t)_len + 63) / 64;
     std::vector<uint64_t> words(nw ? nw : 1), rank(nw + 1);
+    _scan_k = sk.get_k();
+    // Round 4: the k-mer ids and positions stay on the device for the support votes (hypo_gpu_solid_scan_keep); the host takes the
+    // mark bits and their rank directory only.  HYPO_SCAN_KEEP=0, a library without the entry point (the CPU test shim) or several
+    // device contexts (a kept scan lives on the context that made it): the ids come back as before.
+    if (set_on_device && hypo_gpu_num_devices() == 1 && !(std::getenv("HYPO_SCAN_KEEP") && std::atoi(std::getenv("HYPO_SCAN_KEEP")) == 0)) {
+        uint64_t ns = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = hypo_gpu_solid_scan_keep(_id, _pseq.data(), _len, sk.get_k(), words.data(), rank.data(), &ns);
+        if (rc == HYPO_OK) {
+            _solid_pos = BitVec(_len);
+            std::memcpy(_solid_pos.data(), words.data(), nw * 8);
+            _solid_pos.adopt_rank(std::move(rank));
+            _kids.clear(); _n_solid = ns; _scan_kept = true;
+            _kcov.assign(ns, 0); _ksup.assign(ns, 0);
+            if (std::getenv("HYPO_HOST_TIMING"))
+                std::fprintf(stderr, "[timing] find_solid_pos: hypo_gpu_solid_scan_keep %.3f s (%llu marked positions stay on the device)\n",
+                             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), (unsigned long long)ns);
+            return HYPO_OK;
+        }
+        if (rc != HYPO_E_UNSUPPORTED) return rc;
+        rank.assign(nw + 1, 0);
+    }
     const uint64_t cap = _len ? _len : 1;                             // at most one k-mer id per position; only n of them are written
     std::unique_ptr<uint64_t[]> kids(new uint64_t[cap]);              // (not zero-filled: 8 bytes per base)
     uint64_t n = 0;
@@ -70,8 +92,16 @@ void Contig::adopt_solid_scan(const uint64_t* words, const uint64_t* rank, const
     for (uint64_t w = 0; w < nw; ++w) _solid_pos.data()[w] = words[w];
     if (rank) _solid_pos.adopt_rank(std::vector<uint64_t>(rank, rank + nw + 1)); else _solid_pos.init_support();
     _kids.assign(kids, kids + n_solid);
+    _n_solid = n_solid; _scan_kept = false;
     _kcov.assign(n_solid, 0);
     _ksup.assign(n_solid, 0);
+}
+
+void Contig::ensure_kids() {
+    if (!_kids.empty() || !_n_solid) return;
+    _kids.resize(_n_solid);
+#pragma omp parallel for schedule(static, 4096)
+    for (int64_t i = 0; i < (int64_t)_n_solid; ++i) _kids[(size_t)i] = kmer_at(_solid_pos.select((uint64_t)i + 1), _scan_k);
 }
 
 // ---- Contig::prepare_for_division (src/Contig.cpp:75-185) -----------------------------------------------------------
@@ -82,6 +112,8 @@ void Contig::prepare_for_division(unsigned k) {
     uint32_t last_kind = 0, first_kind = 0;
     uint64_t last_sr_pos = 0, first_sr_pos = 0;
     bool in_sr = false, pvs_80 = true;
+    const bool have_kids = !_kids.empty();
+    (void)first_kind; (void)last_kind;
     uint32_t i = 0;
     for (uint32_t pos = 0; pos < _len; ++pos) {
         if (_solid_pos[pos]) {
@@ -101,13 +133,17 @@ void Contig::prepare_for_division(unsigned k) {
         }
         if (in_sr && pos == last_sr_pos) {
             sr_pos.push_back((uint32_t)first_sr_pos); sr_len.push_back((uint32_t)(last_sr_pos - first_sr_pos));
-            _anchor_kmers.push_back(_kids[first_kind]); _anchor_kmers.push_back(_kids[last_kind]);
+            // (the k-mer ids of a resident scan are on the device: the id of a marked position is the k bases that start there;
+            // the last valid k-mer of the SR starts at last_sr_pos - k)
+            _anchor_kmers.push_back(have_kids ? _kids[first_kind] : kmer_at(first_sr_pos, k));
+            _anchor_kmers.push_back(have_kids ? _kids[last_kind] : kmer_at(last_sr_pos - k, k));
             in_sr = false; pvs_80 = true;
         }
     }
     if (in_sr) {
         sr_pos.push_back((uint32_t)first_sr_pos); sr_len.push_back((uint32_t)(last_sr_pos - first_sr_pos));
-        _anchor_kmers.push_back(_kids[first_kind]); _anchor_kmers.push_back(_kids[last_kind]);
+        _anchor_kmers.push_back(have_kids ? _kids[first_kind] : kmer_at(first_sr_pos, k));
+        _anchor_kmers.push_back(have_kids ? _kids[last_kind] : kmer_at(last_sr_pos - k, k));
     }
     std::vector<uint64_t>().swap(_kids); std::vector<uint32_t>().swap(_kcov); std::vector<uint32_t>().swap(_ksup);
     _solid_pos.clear();
@@ -391,6 +427,15 @@ void Contig::fill_long_windows(std::vector<std::unique_ptr<Alignment>>& alignmen
     _pseudo_reg_pos.clear();
     std::vector<RegionType>().swap(_pseudo_reg_type);
     std::vector<uint32_t>().swap(_true_reg_id);
+}
+
+void Contig::release_after_output() {
+    std::vector<std::unique_ptr<Window>>().swap(_pwindows);
+    std::vector<RegionType>(1, RegionType::SR).swap(_reg_type);      // (get_num_regions() stays defined: 0)
+    std::vector<uint32_t>().swap(_reg_info);
+    std::vector<MWMinimiserInfo>().swap(_minimserinfo);
+    _reg_pos = BitVec(1);
+    _pseq = PackedSeq<4>();
 }
 
 // ---- operator<< (src/Contig.cpp:345-366): one-line FASTA record -------------------------------------------------------

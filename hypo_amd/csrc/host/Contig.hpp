@@ -57,14 +57,23 @@ public:
     void generate_consensus(uint64_t ind, uint32_t th) { _pwindows[ind]->generate_consensus(th); }
     Window* window(uint32_t ind) const { return _pwindows[ind].get(); }
     static void set_no_long_reads() { _no_long_reads = true; }
+    // the polished record has been written: windows, region tables and the packed draft go; name and length stay (the record parser
+    // checks later alignments against them)
+    void release_after_output();
     friend std::ostream& operator<<(std::ostream&, const Contig&);
     friend class Alignment;
     friend class DeviceArms;
 
     // scan results (Contig::_solid_pos / _kmerinfo[i]->kid)
-    uint64_t get_num_solid() const { return _kids.size(); }
+    uint64_t get_num_solid() const { return _n_solid; }
     bool is_solid_pos(uint64_t p) const { return _solid_pos[p]; }
-    uint64_t kid_at(uint64_t i) const { return _kids[i]; }
+    uint64_t kid_at(uint64_t i) const { return _kids.empty() ? kmer_at((uint64_t)_solid_pos.select(i + 1), _scan_k) : _kids[i]; }
+    // the k-mer that starts at position p (what the scan stored as Contig::_kmerinfo[i]->kid for a marked p: no N among its bases)
+    uint64_t kmer_at(uint64_t p, unsigned k) const { uint64_t v = 0; for (unsigned i = 0; i < k; ++i) v = (v << 2) | (_pseq.enc_base_at(p + i) & 3u); return v; }
+    // the k-mer ids of the marked positions as a host array (a resident scan, hypo_gpu_solid_scan_keep, leaves them on the device:
+    // the host loops of the reference that read them — Alignment::update_solidkmers_support — ask for them here first)
+    void ensure_kids();
+    bool scan_kept() const { return _scan_kept; }
     uint64_t rank(uint64_t p) const { return _solid_pos.rank(p); }
     uint64_t select(uint64_t i) const { return _solid_pos.select(i); }
     const std::string& get_name() const { return _name; }
@@ -79,7 +88,8 @@ private:
     uint32_t _len;
     PackedSeq<4> _pseq;
     BitVec _solid_pos;
-    std::vector<uint64_t> _kids;
+    std::vector<uint64_t> _kids;                 // empty after a resident scan (ensure_kids() fills it)
+    uint64_t _n_solid = 0; unsigned _scan_k = 0; bool _scan_kept = false;
     std::vector<uint32_t> _kcov, _ksup;          // KmerInfo::coverage / support (UINT16 in the reference)
     std::vector<uint64_t> _anchor_kmers;
     BitVec _reg_pos;

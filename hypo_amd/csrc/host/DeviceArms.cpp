@@ -9,72 +9,39 @@
 
 namespace hypo {
 
-// The short-read alignments of contigs [c0, c1) as flat arrays in one coordinate space (every contig starts on an even position:
-// its PackedSeq<4> bytes are copied as they are; an odd-length contig is followed by one filler base), on the device.
-bool DeviceArms::upload_reads(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1,
-                              std::vector<std::vector<std::unique_ptr<Alignment>>>& store) {
+// The short-read alignments of contigs [c0, c1) in one coordinate space (every contig starts on an even position: its PackedSeq<4>
+// bytes are copied as they are; an odd-length contig is followed by one filler base), on the device.  Round 4: the records come
+// as the flat slices the parser threads wrote (ReadBatch); flatten() lays them out in this context's page-locked staging arrays,
+// which hypo_gpu_reads_upload copies at the link's rate — no per-record objects to walk, no fresh pages per batch, nothing to
+// release afterwards.
+bool DeviceArms::upload_reads(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1, const ReadBatch& reads) {
     _reads_resident = false;
     const bool timing = std::getenv("HYPO_HOST_TIMING") != nullptr;
-    const auto tu0 = std::chrono::steady_clock::now();
-    wait_released();
     const auto tu1 = std::chrono::steady_clock::now();
     if (hypo_gpu_use_device(_slot) != HYPO_OK) return false;
-    uint64_t total = 0, n_aln = 0, n_cig = 0;
-    std::vector<uint64_t> aln_base(c1 - c0 + 1, 0);
+    uint64_t total = 0, n_aln = 0;
+    std::vector<uint64_t> base(c1 - c0, 0);
     for (uint32_t c = c0; c < c1; ++c) {
+        base[c - c0] = total;
         total += contigs[c]->_len + (contigs[c]->_len & 1);
-        aln_base[c - c0] = n_aln;
-        n_aln += store[c].size();
+        n_aln += reads.count(c);
     }
     if (n_aln >= 0xfffffff0ull || total >= 0xfffffff0ull) return false;
-    // per alignment: bytes of its read, CIGAR operations (exclusive prefix sums below), and the sort check
-    // (plain arrays: nothing here is read before it is written, and zero-filling 28 bytes per record on one thread was 0.15 s of the C3 run)
-    std::unique_ptr<uint64_t[]> seq_off(new uint64_t[n_aln + 1]);
-    std::unique_ptr<uint32_t[]> cigar_off(new uint32_t[n_aln + 1]);
     bool sorted = true;
-    for (uint32_t c = c0; c < c1; ++c) {
-        const auto& alns = store[c];
-        const uint64_t a0 = aln_base[c - c0];
-#pragma omp parallel for schedule(static) reduction(&& : sorted)
-        for (int64_t t = 0; t < (int64_t)alns.size(); ++t) {
-            const Alignment& a = *alns[(size_t)t];
-            seq_off[a0 + (uint64_t)t + 1] = a._apseq.byte_size();
-            cigar_off[a0 + (uint64_t)t + 1] = (uint32_t)a._cigar.size();
-            if (t && alns[(size_t)t - 1]->_rb > a._rb) sorted = false;
-        }
+    if (!reads.flatten(c0, c1, base, _stage, sorted)) {
+        std::fprintf(stdout, "[Hypo::Hypo] Info: no page-locked staging memory for %llu alignments: support votes and short arms are computed on the host\n", (unsigned long long)n_aln);
+        return false;
     }
     if (!sorted) { std::fprintf(stdout, "[Hypo::Hypo] Info: alignments are not sorted by position: support votes and short arms are computed on the host\n"); return false; }
-    seq_off[0] = 0; cigar_off[0] = 0;
-    for (uint64_t g = 0; g < n_aln; ++g) { n_cig += cigar_off[g + 1]; if (n_cig >= 0xfffffff0ull) return false; seq_off[g + 1] += seq_off[g]; cigar_off[g + 1] += cigar_off[g]; }
-    const uint64_t read_bytes = seq_off[n_aln];
-    std::unique_ptr<uint32_t[]> rb(new uint32_t[n_aln + 1]), re(new uint32_t[n_aln + 1]), qae(new uint32_t[n_aln + 1]), ctg_of(new uint32_t[n_aln + 1]);
-    std::unique_ptr<uint32_t[]> cigar(new uint32_t[n_cig ? n_cig : 1]);             // (not zero-filled: every element is written below)
-    std::unique_ptr<uint8_t[]> reads2(new uint8_t[read_bytes ? read_bytes : 1]);
-    {   // the copies, on all threads
-        uint64_t cbase = 0;
-        for (uint32_t c = c0; c < c1; ++c) {
-            auto& alns = store[c];
-            const uint64_t a0 = aln_base[c - c0];
-#pragma omp parallel for schedule(static)
-            for (int64_t t = 0; t < (int64_t)alns.size(); ++t) {
-                const Alignment& a = *alns[(size_t)t];
-                const uint64_t g = a0 + (uint64_t)t;
-                rb[g] = (uint32_t)(cbase + a._rb); re[g] = (uint32_t)(cbase + a._re); qae[g] = a._qae; ctg_of[g] = c - c0;
-                std::memcpy(reads2.get() + seq_off[g], a._apseq.data(), a._apseq.byte_size());
-                std::memcpy(cigar.get() + cigar_off[g], a._cigar.data(), a._cigar.size() * 4);
-            }
-            cbase += contigs[c]->_len + (contigs[c]->_len & 1);
-        }
-    }
     HypoArmsReads A;
-    A.n_alignments = (uint32_t)n_aln; A.rb = rb.get(); A.re = re.get(); A.qae = qae.get(); A.seq_off = seq_off.get();
-    A.reads2 = reads2.get(); A.reads2_bytes = read_bytes; A.cigar_off = cigar_off.get(); A.cigar = cigar.get();
+    A.n_alignments = (uint32_t)_stage.n_reads; A.rb = _stage.rb; A.re = _stage.re; A.qae = _stage.qae; A.seq_off = _stage.seq_off;
+    A.reads2 = _stage.reads2; A.reads2_bytes = _stage.n_bytes; A.cigar_off = _stage.cigar_off; A.cigar = _stage.cigar;
     const auto tu2 = std::chrono::steady_clock::now();
-    const int rc = hypo_gpu_reads_upload(&A, ctg_of.get(), total);
+    const int rc = hypo_gpu_reads_upload(&A, _stage.ctg, total);
     if (timing) {
         auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-        std::fprintf(stderr, "[timing] upload_reads: wait for the last batch's release %.3f s, flatten %.3f s, hypo_gpu_reads_upload %.3f s (%.0f MB)\n",
-                     sec(tu0, tu1), sec(tu1, tu2), sec(tu2, std::chrono::steady_clock::now()), (read_bytes + 4.0 * n_cig + 28.0 * n_aln) / 1e6);
+        std::fprintf(stderr, "[timing] upload_reads: flatten into the staging arrays %.3f s, hypo_gpu_reads_upload %.3f s (%.0f MB)\n",
+                     sec(tu1, tu2), sec(tu2, std::chrono::steady_clock::now()), (_stage.n_bytes + 4.0 * _stage.n_cigar + 28.0 * n_aln) / 1e6);
     }
     if (rc != HYPO_OK) {
         if (rc != HYPO_E_UNSUPPORTED) std::fprintf(stdout, "[Hypo::Hypo] Info: support votes and short arms are computed on the host (%s)\n", hypo_gpu_last_error());
@@ -84,42 +51,67 @@ bool DeviceArms::upload_reads(std::vector<std::unique_ptr<Contig>>& contigs, uin
     return true;
 }
 
-// Alignment::update_solidkmers_support for every resident read at once (support_kernel.hip): the solid k-mers of the contigs go
-// over as positions + k-mers, KmerInfo::coverage / support come back.
+// Alignment::update_solidkmers_support for every resident read at once (support_kernel.hip).  Contigs whose scan stayed on the
+// device (Contig::scan_kept) vote against that copy: nothing goes over, KmerInfo::coverage / support come back into page-locked
+// memory; otherwise the solid k-mers of the contigs go over as positions + k-mers.
 bool DeviceArms::support_kmers(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1, unsigned k) {
     if (!_reads_resident || c0 != _reads_c0 || c1 != _reads_c1 || hypo_gpu_use_device(_slot) != HYPO_OK) return false;
     uint64_t ns = 0;
     const auto ts0 = std::chrono::steady_clock::now();
     std::vector<uint64_t> kbase(c1 - c0 + 1, 0);
-    for (uint32_t c = c0; c < c1; ++c) { kbase[c - c0] = ns; ns += contigs[c]->_kids.size(); }
+    bool all_kept = true;
+    for (uint32_t c = c0; c < c1; ++c) { kbase[c - c0] = ns; ns += contigs[c]->_n_solid; all_kept = all_kept && contigs[c]->_scan_kept; }
     kbase[c1 - c0] = ns;
     if (ns == 0) return true;
     if (ns >= 0xfffffff0ull) return false;
-    std::vector<uint32_t> spos(ns), cov(ns), sup(ns);
-    std::vector<uint64_t> kids(ns);
-    uint64_t cbase = 0;
-    for (uint32_t c = c0; c < c1; ++c) {
-        const Contig& ctg = *contigs[c];
-        const uint64_t b = kbase[c - c0], n = ctg._kids.size();
-        std::memcpy(kids.data() + b, ctg._kids.data(), n * 8);
-#pragma omp parallel for schedule(static, 4096)
-        for (int64_t i = 0; i < (int64_t)n; ++i) spos[b + (uint64_t)i] = (uint32_t)(cbase + ctg._solid_pos.select((uint64_t)i + 1));
-        cbase += ctg._len + (ctg._len & 1);
+    // results: page-locked, grow-only
+    if (ns > _votes_cap) {
+        if (_votes) (void)hypo_gpu_host_free(_votes);
+        _votes = nullptr; _votes_cap = 0;
+        void* p = nullptr;
+        if (hypo_gpu_host_alloc((ns + ns / 8 + 1024) * 8, &p) != HYPO_OK || !p) return false;
+        _votes = (uint32_t*)p; _votes_cap = ns + ns / 8 + 1024;
     }
-    const auto ts1 = std::chrono::steady_clock::now();
-    const int rc = hypo_gpu_support_kmers(k, ns, spos.data(), kids.data(), cov.data(), sup.data());
+    uint32_t* const cov = _votes; uint32_t* const sup = _votes + _votes_cap;
+    int rc = HYPO_E_INVALID;
+    double t_pos = 0;
+    if (all_kept) {
+        std::vector<uint32_t> handles(c1 - c0), bases(c1 - c0);
+        uint64_t cbase = 0;
+        for (uint32_t c = c0; c < c1; ++c) { handles[c - c0] = contigs[c]->_id; bases[c - c0] = (uint32_t)cbase; cbase += contigs[c]->_len + (contigs[c]->_len & 1); }
+        uint64_t got = 0;
+        rc = hypo_gpu_support_kmers_kept(k, c1 - c0, handles.data(), bases.data(), cov, sup, &got);
+        if (rc == HYPO_OK && got != ns) { std::fprintf(stderr, "[Hypo::Hypo] Error: the device kept %llu solid k-mers, the host counts %llu\n", (unsigned long long)got, (unsigned long long)ns); std::exit(1); }
+        if (rc == HYPO_OK) for (uint32_t c = c0; c < c1; ++c) { (void)hypo_gpu_solid_release(contigs[c]->_id); contigs[c]->_scan_kept = false; }
+    }
+    if (rc != HYPO_OK) {
+        std::vector<uint32_t> spos(ns);
+        std::vector<uint64_t> kids(ns);
+        uint64_t cbase = 0;
+        for (uint32_t c = c0; c < c1; ++c) {
+            Contig& ctg = *contigs[c];
+            ctg.ensure_kids();
+            const uint64_t b = kbase[c - c0], n = ctg._n_solid;
+            std::memcpy(kids.data() + b, ctg._kids.data(), n * 8);
+#pragma omp parallel for schedule(static, 4096)
+            for (int64_t i = 0; i < (int64_t)n; ++i) spos[b + (uint64_t)i] = (uint32_t)(cbase + ctg._solid_pos.select((uint64_t)i + 1));
+            cbase += ctg._len + (ctg._len & 1);
+        }
+        t_pos = std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count();
+        rc = hypo_gpu_support_kmers(k, ns, spos.data(), kids.data(), cov, sup);
+    }
     if (std::getenv("HYPO_HOST_TIMING"))
-        std::fprintf(stderr, "[timing] support_kmers: positions of %llu solid k-mers %.3f s, hypo_gpu_support_kmers %.3f s\n", (unsigned long long)ns,
-                     std::chrono::duration<double>(ts1 - ts0).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - ts1).count());
+        std::fprintf(stderr, "[timing] support_kmers: %llu solid k-mers (%s), positions + k-mers on the host %.3f s, whole call %.3f s\n", (unsigned long long)ns,
+                     all_kept ? "kept on the device" : "sent over", t_pos, std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count());
     if (rc != HYPO_OK) {
         if (rc != HYPO_E_UNSUPPORTED) std::fprintf(stdout, "[Hypo::Hypo] Info: k-mer support is counted on the host (%s)\n", hypo_gpu_last_error());
         return false;
     }
     for (uint32_t c = c0; c < c1; ++c) {
         Contig& ctg = *contigs[c];
-        const uint64_t b = kbase[c - c0], n = ctg._kids.size();
-        std::memcpy(ctg._kcov.data(), cov.data() + b, n * 4);
-        std::memcpy(ctg._ksup.data(), sup.data() + b, n * 4);
+        const uint64_t b = kbase[c - c0], n = ctg._n_solid;
+        std::memcpy(ctg._kcov.data(), cov + b, n * 4);
+        std::memcpy(ctg._ksup.data(), sup + b, n * 4);
     }
     std::fprintf(stdout, "[Hypo::Hypo] Info: k-mer support counted on the device: %llu solid k-mers\n", (unsigned long long)ns);
     return true;
@@ -129,100 +121,134 @@ bool DeviceArms::support_kmers(std::vector<std::unique_ptr<Contig>>& contigs, ui
 // coverage / support come back.
 bool DeviceArms::support_minimizers(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1) {
     if (!_reads_resident || c0 != _reads_c0 || c1 != _reads_c1 || hypo_gpu_use_device(_slot) != HYPO_OK) return false;
+    const auto tm0 = std::chrono::steady_clock::now();
     const uint32_t nc = c1 - c0;
-    std::vector<uint32_t> contig_base(nc), reg_base(nc + 1, 0), info_base(nc), start, mw_off(1, 0), rel_pos, minimisers;
+    // sizes first, then every contig (its borders) and every mega-window (its minimizers) copies into its own slice on all threads
+    std::vector<uint32_t> contig_base(nc), reg_base(nc + 1, 0), info_base(nc + 1, 0);
     std::vector<uint8_t> even(nc);
-    uint64_t cbase = 0, n_info = 0;
+    uint64_t cbase = 0;
     for (uint32_t c = c0; c < c1; ++c) {
         const Contig& ctg = *contigs[c];
         contig_base[c - c0] = (uint32_t)cbase;
         even[c - c0] = ctg._is_win_even ? 1 : 0;
-        info_base[c - c0] = (uint32_t)n_info;
-        const uint64_t nb = ctg._reg_pos.count();               // set bits: 0, SR starts and ends, the length
-        const size_t s0 = start.size();
-        start.resize(s0 + nb);
-#pragma omp parallel for schedule(static, 4096)
-        for (int64_t i = 0; i < (int64_t)nb; ++i) start[s0 + (size_t)i] = (uint32_t)ctg._reg_pos.select((uint64_t)i + 1);
-        reg_base[c - c0 + 1] = (uint32_t)start.size();
-        for (const MWMinimiserInfo& mi : ctg._minimserinfo) {
-            rel_pos.insert(rel_pos.end(), mi.rel_pos.begin(), mi.rel_pos.end());
-            minimisers.insert(minimisers.end(), mi.minimisers.begin(), mi.minimisers.end());
-            mw_off.push_back((uint32_t)rel_pos.size());
-        }
-        n_info += ctg._minimserinfo.size();
+        reg_base[c - c0 + 1] = reg_base[c - c0] + (uint32_t)ctg._reg_pos.count();      // set bits: 0, SR starts and ends, the length
+        info_base[c - c0 + 1] = info_base[c - c0] + (uint32_t)ctg._minimserinfo.size();
         cbase += ctg._len + (ctg._len & 1);
     }
-    if (rel_pos.empty()) return true;
-    if (start.size() >= 0xfffffff0ull || rel_pos.size() >= 0xfffffff0ull) return false;
-    std::vector<uint32_t> cov(rel_pos.size()), sup(rel_pos.size());
+    const uint64_t n_start = reg_base[nc], n_info = info_base[nc];
+    std::vector<MWMinimiserInfo*> infos(n_info);
+    uint32_t* const mw_off = _pb[0].get<uint32_t>(n_info + 2);
+    if (!mw_off) return false;
+    {
+        uint64_t x = 0, e = 0;
+        for (uint32_t c = c0; c < c1; ++c)
+            for (MWMinimiserInfo& mi : contigs[c]->_minimserinfo) { infos[x] = &mi; mw_off[x] = (uint32_t)e; e += mi.rel_pos.size(); ++x; if (e >= 0xfffffff0ull) return false; }
+        mw_off[n_info] = (uint32_t)e;
+    }
+    const uint64_t n_ent = mw_off[n_info];
+    if (!n_ent) return true;
+    if (n_start >= 0xfffffff0ull) return false;
+    uint32_t* const start = _pb[1].get<uint32_t>(n_start);
+    uint32_t* const rel_pos = _pb[2].get<uint32_t>(n_ent);
+    uint32_t* const minimisers = _pb[3].get<uint32_t>(n_ent);
+    uint32_t* const cov = _pb[4].get<uint32_t>(n_ent);
+    uint32_t* const sup = _pb[5].get<uint32_t>(n_ent);
+    if (!start || !rel_pos || !minimisers || !cov || !sup) return false;
+    for (uint32_t c = c0; c < c1; ++c) {
+        const Contig& ctg = *contigs[c];
+        const uint64_t s0 = reg_base[c - c0], nb = reg_base[c - c0 + 1] - s0;
+#pragma omp parallel for schedule(static, 4096)
+        for (int64_t i = 0; i < (int64_t)nb; ++i) start[s0 + (uint64_t)i] = (uint32_t)ctg._reg_pos.select((uint64_t)i + 1);
+    }
+#pragma omp parallel for schedule(static, 256)
+    for (int64_t x = 0; x < (int64_t)n_info; ++x) {
+        const MWMinimiserInfo& mi = *infos[(size_t)x];
+        if (mi.rel_pos.empty()) continue;
+        std::memcpy(rel_pos + mw_off[x], mi.rel_pos.data(), mi.rel_pos.size() * 4);
+        std::memcpy(minimisers + mw_off[x], mi.minimisers.data(), mi.minimisers.size() * 4);
+    }
+    const auto tm1 = std::chrono::steady_clock::now();
     HypoMegaWindows W;
     W.n_contigs = nc; W.contig_base = contig_base.data(); W.reg_base = reg_base.data(); W.win_even = even.data(); W.info_base = info_base.data();
-    W.start = start.data(); W.n_info = (uint32_t)n_info; W.mw_off = mw_off.data(); W.rel_pos = rel_pos.data(); W.minimisers = minimisers.data();
-    const int rc = hypo_gpu_support_minimizers(&W, cov.data(), sup.data());
+    W.start = start; W.n_info = (uint32_t)n_info; W.mw_off = mw_off; W.rel_pos = rel_pos; W.minimisers = minimisers;
+    const int rc = hypo_gpu_support_minimizers(&W, cov, sup);
+    const auto tm2 = std::chrono::steady_clock::now();
     if (rc != HYPO_OK) {
         if (rc != HYPO_E_UNSUPPORTED) std::fprintf(stdout, "[Hypo::Hypo] Info: minimizer support is counted on the host (%s)\n", hypo_gpu_last_error());
         return false;
     }
-    size_t x = 0;
-    for (uint32_t c = c0; c < c1; ++c)
-        for (MWMinimiserInfo& mi : contigs[c]->_minimserinfo) {
-            const size_t e0 = mw_off[x], n = mi.rel_pos.size();
-            for (size_t m = 0; m < n; ++m) { mi.coverage[m] = cov[e0 + m]; mi.support[m] = sup[e0 + m]; }
-            ++x;
-        }
-    std::fprintf(stdout, "[Hypo::Hypo] Info: minimizer support counted on the device: %llu minimizers\n", (unsigned long long)rel_pos.size());
+#pragma omp parallel for schedule(static, 256)
+    for (int64_t x = 0; x < (int64_t)n_info; ++x) {
+        MWMinimiserInfo& mi = *infos[(size_t)x];
+        const size_t n = mi.rel_pos.size();
+        if (!n) continue;
+        std::memcpy(mi.coverage.data(), cov + mw_off[x], n * 4);
+        std::memcpy(mi.support.data(), sup + mw_off[x], n * 4);
+    }
+    if (std::getenv("HYPO_HOST_TIMING")) {
+        auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+        std::fprintf(stderr, "[timing] support_minimizers: tables %.3f s, hypo_gpu_support_minimizers %.3f s, counters back %.3f s\n", sec(tm0, tm1), sec(tm1, tm2), sec(tm2, std::chrono::steady_clock::now()));
+    }
+    std::fprintf(stdout, "[Hypo::Hypo] Info: minimizer support counted on the device: %llu minimizers\n", (unsigned long long)n_ent);
     return true;
 }
 
-bool DeviceArms::build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1,
-                       std::vector<std::vector<std::unique_ptr<Alignment>>>& store, unsigned k) {
+bool DeviceArms::build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1, const ReadBatch& reads, unsigned k) {
     _active = false;
-    wait_released();
     if (hypo_gpu_use_device(_slot) != HYPO_OK) return false;
     const bool timing = std::getenv("HYPO_HOST_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     const auto t0 = now();
     // the reads: resident since the support votes, or put there now
-    if (!(_reads_resident && c0 == _reads_c0 && c1 == _reads_c1) && !upload_reads(contigs, c0, c1, store)) return false;
+    if (!(_reads_resident && c0 == _reads_c0 && c1 == _reads_c1) && !upload_reads(contigs, c0, c1, reads)) return false;
     _reads_resident = false;                                   // (this build consumes them: the next batch uploads its own)
-    uint64_t total = 0, n_reg = 0, n_anchor = 0;
+    // the coordinate space and its region tables: sizes per contig first, then every contig fills its own slices (page-locked,
+    // reused by every batch) on a thread of its own
+    const uint32_t nc = c1 - c0;
+    std::vector<uint64_t> cbase(nc + 1, 0), rbase(nc + 1, 0), abase(nc + 1, 0);
     for (uint32_t c = c0; c < c1; ++c) {
         const Contig& ctg = *contigs[c];
-        total += ctg._len + (ctg._len & 1);
-        n_reg += ctg.get_num_regions() + (ctg._len & 1);
-        n_anchor += ctg._anchor_kmers.size();
-    }
-    if (total >= 0xfffffff0ull || n_reg >= 0xfffffff0ull || n_reg == 0) return false;
-    std::vector<uint32_t> start(n_reg + 1), info(n_reg + 1, 0);
-    std::vector<uint8_t> type(n_reg + 1, (uint8_t)RegionType::SR);
-    std::vector<uint64_t> anchors; anchors.reserve(n_anchor);
-    std::vector<uint8_t> contig4((total + 1) / 2, 0);
-    _reg_window.assign(n_reg, nullptr);
-    uint64_t base = 0, r = 0;
-    for (uint32_t c = c0; c < c1; ++c) {
-        Contig& ctg = *contigs[c];
-        const uint32_t nr = (uint32_t)ctg.get_num_regions();
+        cbase[c - c0 + 1] = cbase[c - c0] + ctg._len + (ctg._len & 1);
+        rbase[c - c0 + 1] = rbase[c - c0] + ctg.get_num_regions() + (ctg._len & 1);
         // Contig::_anchor_kmers is [dummy, first k-mer of SR 1, last k-mer of SR 1, first of SR 2, ...] and the SR ranks start at 1:
         // one dummy for the whole coordinate space, the ranks of later contigs shifted by the SRs before them
-        if (anchors.empty()) anchors.push_back(0);
-        const uint32_t sr_before = (uint32_t)((anchors.size() - 1) / 2);
+        abase[c - c0 + 1] = abase[c - c0] + (ctg._anchor_kmers.size() > 1 ? ctg._anchor_kmers.size() - 1 : 0);
+    }
+    const uint64_t total = cbase[nc], n_reg = rbase[nc], n_anchor = abase[nc] + 1;
+    if (total >= 0xfffffff0ull || n_reg >= 0xfffffff0ull || n_reg == 0) return false;
+    uint32_t* const start = _pb[6].get<uint32_t>(n_reg + 1);
+    uint32_t* const info = _pb[7].get<uint32_t>(n_reg + 1);
+    uint8_t* const type = _pb[8].get<uint8_t>(n_reg + 1);
+    uint64_t* const anchors = _pb[9].get<uint64_t>(n_anchor);
+    uint8_t* const contig4 = _pb[10].get<uint8_t>((total + 1) / 2 + 16);
+    if (!start || !info || !type || !anchors || !contig4) return false;
+    _reg_window.assign(n_reg, nullptr);
+    anchors[0] = 0;
+    bool bad = false;
+#pragma omp parallel for schedule(dynamic, 1) reduction(|| : bad)
+    for (int64_t ci = 0; ci < (int64_t)nc; ++ci) {
+        Contig& ctg = *contigs[c0 + (uint32_t)ci];
+        const uint32_t nr = (uint32_t)ctg.get_num_regions();
+        const uint64_t base = cbase[(size_t)ci];
+        uint64_t r = rbase[(size_t)ci];
+        const uint32_t sr_before = (uint32_t)(abase[(size_t)ci] / 2);
         for (uint32_t i = 0; i < nr; ++i, ++r) {
             start[r] = (uint32_t)(base + ctg._reg_pos.select((uint64_t)i + 1));
             type[r] = (uint8_t)ctg._reg_type[i];
             info[r] = ctg._reg_info[i] + (ctg._reg_type[i] == RegionType::SR ? sr_before : 0u);
             _reg_window[r] = ctg._pwindows[i].get();
-            if (type[r] != (uint8_t)RegionType::SR && type[r] != (uint8_t)RegionType::MSR && !_reg_window[r]) return false;   // (never: every non-SR region has a window here)
+            if (type[r] != (uint8_t)RegionType::SR && type[r] != (uint8_t)RegionType::MSR && !_reg_window[r]) bad = true;   // (never: every non-SR region has a window here)
         }
-        if (ctg._anchor_kmers.size() > 1) anchors.insert(anchors.end(), ctg._anchor_kmers.begin() + 1, ctg._anchor_kmers.end());
-        std::memcpy(contig4.data() + base / 2, ctg._pseq.data(), ctg._pseq.byte_size());
+        if (ctg._anchor_kmers.size() > 1) std::memcpy(anchors + 1 + abase[(size_t)ci], ctg._anchor_kmers.data() + 1, (ctg._anchor_kmers.size() - 1) * 8);
+        std::memcpy(contig4 + base / 2, ctg._pseq.data(), ctg._pseq.byte_size());
         if (ctg._len & 1) { start[r] = (uint32_t)(base + ctg._len); type[r] = (uint8_t)RegionType::SR; info[r] = 0; ++r; }
-        base += ctg._len + (ctg._len & 1);
     }
-    start[r] = (uint32_t)total;
+    if (bad) return false;
+    start[n_reg] = (uint32_t)total; type[n_reg] = (uint8_t)RegionType::SR; info[n_reg] = 0;
     HypoArmsRegions R;
-    R.n_regions = (uint32_t)n_reg; R.start = start.data(); R.type = type.data(); R.info = info.data();
-    R.n_anchor_kmers = anchors.size(); R.anchor_kmers = anchors.data(); R.k = k; R.contig4 = contig4.data();
+    R.n_regions = (uint32_t)n_reg; R.start = start; R.type = type; R.info = info;
+    R.n_anchor_kmers = n_anchor; R.anchor_kmers = anchors; R.k = k; R.contig4 = contig4;
     std::vector<uint8_t> valid(n_reg, 0);
     const auto t1 = now();
     const int rc = hypo_gpu_arms_build(&R, nullptr, valid.data(), &_sum);       // the resident reads
@@ -232,30 +258,16 @@ bool DeviceArms::build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c
         return false;
     }
     // what Contig::fill_short_windows leaves behind (src/Contig.cpp:249-289): pruned windows are gone, the anchors are freed
-    r = 0;
-    for (uint32_t c = c0; c < c1; ++c) {
-        Contig& ctg = *contigs[c];
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t ci = 0; ci < (int64_t)nc; ++ci) {
+        Contig& ctg = *contigs[c0 + (uint32_t)ci];
         const uint32_t nr = (uint32_t)ctg.get_num_regions();
+        uint64_t r = rbase[(size_t)ci];
         for (uint32_t i = 0; i < nr; ++i, ++r)
             if (ctg._pwindows[i] && !valid[r]) { ctg._pwindows[i].reset(); _reg_window[r] = nullptr; }
-        if (ctg._len & 1) ++r;
         std::vector<uint64_t>().swap(ctg._anchor_kmers);
         std::vector<uint32_t>().swap(ctg._reg_info);
-        _spent.emplace_back(std::move(store[c]));
-        store[c].clear();
     }
-    // a million small objects: they are released behind the next phases of the run (joined in the destructor)
-    _releaser = std::thread([this] {
-        constexpr size_t kHelpers = 24;
-        for (auto& alns : _spent) {
-            std::vector<std::thread> helpers;
-            const size_t n = alns.size(), per = (n + kHelpers - 1) / kHelpers;
-            for (size_t h = 0; h < kHelpers; ++h)
-                helpers.emplace_back([&alns, h, per, n] { for (size_t t = h * per; t < n && t < (h + 1) * per; ++t) alns[t].reset(); });
-            for (auto& th : helpers) th.join();
-        }
-        std::vector<std::vector<std::unique_ptr<Alignment>>>().swap(_spent);
-    });
     if (timing) std::fprintf(stderr, "[timing] device arms: flatten %.3f s, hypo_gpu_arms_build %.3f s, prune + release %.3f s\n", secs(t0, t1), secs(t1, t2), secs(t2, now()));
     std::fprintf(stdout, "[Hypo::Hypo] Info: short arms cut on the device: %u windows, %u arms\n", _sum.n_windows, _sum.n_arms);
     _active = true;
@@ -391,19 +403,23 @@ int DeviceArms::polish_impl(bool lng, const ScoreParams& sp, bool keep_arms, std
     const uint32_t n = _sum.n_windows;
     if (!n) return HYPO_OK;
     const auto tp = std::chrono::steady_clock::now();
-    std::vector<char> bases(_sum.out_bytes ? _sum.out_bytes : 1);
-    std::vector<uint64_t> off((size_t)n + 1);
-    std::vector<uint32_t> len(n), win_region(n);
-    std::vector<uint8_t> st(n);
-    std::vector<HypoWindow> hw(n);
+    // results: page-locked, reused by every batch (fresh pageable vectors cost their page faults and a staged copy per batch)
+    PinnedBuf* const pb = lng ? _pbl : _pbr;
+    char* const bases = pb[0].get<char>(_sum.out_bytes + 16);
+    uint64_t* const off = pb[1].get<uint64_t>((size_t)n + 1);
+    uint32_t* const len = pb[2].get<uint32_t>(n);
+    uint32_t* const win_region = pb[3].get<uint32_t>(n);
+    uint8_t* const st = pb[4].get<uint8_t>(n);
+    if (!bases || !off || !len || !win_region || !st) return HYPO_E_HIP;
+    std::vector<HypoWindow> hw;                                  // (descriptors: only when arms are adopted)
     const bool timing = std::getenv("HYPO_HOST_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     const auto t0 = now();
-    int rc = (lng ? hypo_gpu_arms_poa_long : hypo_gpu_arms_poa)(&sp, bases.data(), off.data(), len.data(), st.data());
+    int rc = (lng ? hypo_gpu_arms_poa_long : hypo_gpu_arms_poa)(&sp, bases, off, len, st);
     if (rc != HYPO_OK) return rc;
     const auto t1 = now();
-    rc = (lng ? hypo_gpu_arms_download_long : hypo_gpu_arms_download)(hw.data(), win_region.data(), nullptr, nullptr, nullptr, nullptr);
+    rc = (lng ? hypo_gpu_arms_download_long : hypo_gpu_arms_download)(nullptr, win_region, nullptr, nullptr, nullptr, nullptr);
     if (rc != HYPO_OK) return rc;
     if (timing) std::fprintf(stderr, "[timing] device arms: buffers %.3f s, hypo_gpu_arms_poa%s %.3f s, descriptors %.3f s\n", secs(tp, t0), lng ? "_long" : "", secs(t0, t1), secs(t1, now()));
     // (every status byte starts as HYPO_ST_UNWRITTEN on the device: a window no kernel answered is an internal error, not a retry)
@@ -415,10 +431,17 @@ int DeviceArms::polish_impl(bool lng, const ScoreParams& sp, bool keep_arms, std
     std::vector<uint32_t> again, all;
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < (int64_t)n; ++i)
-        if (st[(size_t)i] == HYPO_ST_OK) _reg_window[win_region[(size_t)i]]->_consensus.assign(bases.data() + off[(size_t)i], len[(size_t)i]);
+        if (st[(size_t)i] == HYPO_ST_OK) _reg_window[win_region[(size_t)i]]->_consensus.assign(bases + off[(size_t)i], len[(size_t)i]);
     for (uint32_t i = 0; i < n; ++i) { if (st[i] != HYPO_ST_OK) again.push_back(i); if (keep_arms) all.push_back(i); }
-    if (keep_arms) adopt_arms(all, hw, win_region, lng);
-    else if (!again.empty()) adopt_arms(again, hw, win_region, lng);
+    if (keep_arms || !again.empty()) {
+        hw.resize(n);
+        rc = (lng ? hypo_gpu_arms_download_long : hypo_gpu_arms_download)(hw.data(), nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (rc != HYPO_OK) return rc;
+    }
+    if (keep_arms || !again.empty()) {
+        const std::vector<uint32_t> wr(win_region, win_region + n);
+        adopt_arms(keep_arms ? all : again, hw, wr, lng);
+    }
     if (!again.empty()) {          // a consensus longer than its slot, a window beyond the size classes: the host's retry / degraded path
         std::vector<Window*> ws;
         for (uint32_t i : again) ws.push_back(_reg_window[win_region[i]]);

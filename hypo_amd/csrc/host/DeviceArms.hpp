@@ -5,12 +5,34 @@
 // objects.  The windows never see their arms unless somebody asks (region dump, a window that needs the host's retry path).
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <memory>
 #include <thread>
 #include <vector>
 #include "Contig.hpp"
+#include "ReadBatch.hpp"
 
 namespace hypo {
+
+// a page-locked, grow-only buffer (hypo_gpu_host_alloc; plain memory when the library has none to give)
+struct PinnedBuf {
+    void* p = nullptr; size_t cap = 0; bool pinned = false;
+    template <class T> T* get(size_t n) {
+        const size_t bytes = n * sizeof(T) + 64;
+        if (bytes > cap) {
+            release();
+            const size_t want = bytes + bytes / 4;
+            if (hypo_gpu_host_alloc(want, &p) == HYPO_OK && p) pinned = true; else { p = std::malloc(want); pinned = false; }
+            cap = p ? want : 0;
+        }
+        return (T*)p;
+    }
+    void release() { if (p) { if (pinned) (void)hypo_gpu_host_free(p); else std::free(p); } p = nullptr; cap = 0; }
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf() { release(); }
+};
 
 class DeviceArms {
 public:
@@ -19,18 +41,15 @@ public:
     explicit DeviceArms(int slot = 0) : _slot(slot) {}
     DeviceArms(const DeviceArms&) = delete;
     DeviceArms& operator=(const DeviceArms&) = delete;
-    ~DeviceArms() { wait_released(); }
-    void wait_released() { if (_releaser.joinable()) _releaser.join(); }
+    ~DeviceArms() { if (_votes) (void)hypo_gpu_host_free(_votes); }
     // true: the windows of contigs [c0, c1) are pruned, their arms lie on the device and `store` is consumed; false: nothing
     // was changed and the host path must run (several devices, an unsorted alignment file, a batch beyond 32-bit coordinates)
-    bool build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1,
-               std::vector<std::vector<std::unique_ptr<Alignment>>>& store, unsigned k);
+    bool build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1, const ReadBatch& reads, unsigned k);
     bool active() const { return _active; }
     // N1: the short reads of contigs [c0, c1) go to the device once, right after they were loaded; the support votes
     // (Alignment::update_solidkmers_support / update_minimisers_support, src/Alignment.cpp:65-220) are counted there and come back
     // into the contigs' counters, and build() later cuts the same resident copy into arms.  false: nothing changed, host loops.
-    bool upload_reads(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1,
-                      std::vector<std::vector<std::unique_ptr<Alignment>>>& store);
+    bool upload_reads(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1, const ReadBatch& reads);
     bool support_kmers(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1, unsigned k);
     bool support_minimizers(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1);
     // consensus of every SHORT window of the resident batch; `keep_arms`: also copy the arms into the Window objects.  Windows
@@ -54,8 +73,10 @@ private:
     bool _reads_resident = false; uint32_t _reads_c0 = 0, _reads_c1 = 0;
     bool _active = false;
     HypoArmsSummary _sum{};
-    std::vector<std::vector<std::unique_ptr<Alignment>>> _spent;   // the alignments of the batch, on their way out
-    std::thread _releaser;
+    ReadStaging _stage;                      // page-locked staging arrays of this context's reads (grow-only, reused by every batch)
+    uint32_t* _votes = nullptr; uint64_t _votes_cap = 0;       // page-locked: coverage [_votes_cap] then support [_votes_cap] of the k-mer votes
+    PinnedBuf _pb[12];                       // staging of the minimizer tables and the region tables
+    PinnedBuf _pbr[5], _pbl[5];              // POA results of the SHORT / LONG resident batch (polish and polish_long may run side by side)
     std::vector<Window*> _reg_window;        // region of the coordinate space -> its window (nullptr: SR, filler, pruned)
     void adopt_arms(const std::vector<uint32_t>& which, const std::vector<HypoWindow>& hw, const std::vector<uint32_t>& win_region, bool lng);
     int polish_impl(bool lng, const ScoreParams& sp, bool keep_arms, std::vector<Window*>* retry);

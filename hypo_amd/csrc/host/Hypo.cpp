@@ -66,6 +66,22 @@ void Hypo::polish() {
     stop("[Hypo:Hypo]: Loaded Contigs. ");
     _alignment_store.resize(_contigs.size());
 
+    _contig_batch_size = _cFlags.processing_batch_size == 0 ? (uint32_t)_contigs.size() : _cFlags.processing_batch_size;
+    uint32_t num_batches = _contig_batch_size ? (uint32_t)_contigs.size() / _contig_batch_size : 0;
+    if (_contig_batch_size && _contigs.size() % _contig_batch_size != 0) ++num_batches;
+    _sf_short.reset(new SamReader(_cFlags.sr_bam_filename));
+    if (!_sf_short->ok()) { std::fprintf(stderr, "[Hypo::Hypo] Error: File open error: %s\n", _cFlags.sr_bam_filename.c_str()); std::exit(1); }
+    _sf_short->set_inflate_threads(std::max(1, std::min((int)_cFlags.threads, 32)));
+    // the short reads of the first batch are parsed while the contigs are scanned (the parser needs the contigs' names and lengths only)
+    std::thread prefetch;
+    ReadBatch staged;                                      // the next batch's short reads while the helper parses them
+    const bool prefetch_on = !(std::getenv("HYPO_PREFETCH") && std::atoi(std::getenv("HYPO_PREFETCH")) == 0);
+    const int helper_threads = (2 * (int)_cFlags.threads <= (int)std::thread::hardware_concurrency()) ? (int)_cFlags.threads : std::max(1, (int)_cFlags.threads / 2);
+    if (prefetch_on && num_batches > 0) {
+        staged.reset(_contigs.size());
+        prefetch = std::thread([this, &staged, helper_threads] { omp_set_num_threads(helper_threads); create_alignments_flat(0, staged); });
+    }
+
     // ---- solid positions: device scan (the C-ABI call is serialised on the context's stream) ------
     // the 4^k-bit set goes to the device once (2 GiB at the default k = 17), not once per contig
     start();
@@ -82,12 +98,7 @@ void Hypo::polish() {
     }
     stop("[Hypo:Hypo]: Found Solid pos in contigs. ");
 
-    _contig_batch_size = _cFlags.processing_batch_size == 0 ? (uint32_t)_contigs.size() : _cFlags.processing_batch_size;
-    uint32_t num_batches = _contig_batch_size ? (uint32_t)_contigs.size() / _contig_batch_size : 0;
-    if (_contig_batch_size && _contigs.size() % _contig_batch_size != 0) ++num_batches;
     std::fprintf(stdout, "[Hypo::Hypo] Info: Number.of contigs: %lu; Number of batches: %u\n", (unsigned long)_contigs.size(), num_batches);
-    _sf_short.reset(new SamReader(_cFlags.sr_bam_filename));
-    if (!_sf_short->ok()) { std::fprintf(stderr, "[Hypo::Hypo] Error: File open error: %s\n", _cFlags.sr_bam_filename.c_str()); std::exit(1); }
     if (!_cFlags.lr_bam_filename.empty()) {
         _sf_long.reset(new SamReader(_cFlags.lr_bam_filename));
         if (!_sf_long->ok()) { std::fprintf(stderr, "[Hypo::Hypo] Error: File open error: %s\n", _cFlags.lr_bam_filename.c_str()); std::exit(1); }
@@ -99,9 +110,16 @@ void Hypo::polish() {
     const int n_ctx = std::max(1, hypo_gpu_num_devices());
     std::vector<std::unique_ptr<DeviceArms>> device_arms;
     for (int d = 0; d < n_ctx; ++d) device_arms.emplace_back(new DeviceArms(d));
-    std::thread prefetch;
-    AlignmentStore staged;                                 // the next batch's short-read alignments while the helper collects them
-    const bool prefetch_on = !(std::getenv("HYPO_PREFETCH") && std::atoi(std::getenv("HYPO_PREFETCH")) == 0);
+    _reads.reset(_contigs.size());
+    // The polished contigs of a batch are filed by a writer thread while the next batch is processed (the reference writes
+    // everything at the end, src/Hypo.cpp:256-268: the same bytes in the same order); what a written contig no longer needs is
+    // released there.
+    std::ofstream ofile(_cFlags.output_filename);
+    if (!ofile.is_open()) {
+        std::fprintf(stderr, "[Hypo::Hypo] Error: File open error: Output File (%s) could not be opened!\n", _cFlags.output_filename.c_str());
+        std::exit(1);
+    }
+    std::thread writer;
     for (uint32_t batch_id = 0; batch_id < num_batches; ++batch_id) {
         std::fprintf(stdout, "********** [Hypo::Hypo] Info: BATCH-ID: %u\n", batch_id);
         const uint32_t initial_cid = batch_id * _contig_batch_size;
@@ -111,36 +129,40 @@ void Hypo::polish() {
         // votes, arms and POA leave the host's cores idle most of the time); it fills a store of its own,
         // the reader state belongs to create_alignments alone.  HYPO_PREFETCH=0: one batch after the other.
         start();
+        // (records of contigs behind the previous batch that it had consumed — _reads holds them — come first, then what the helper
+        // or this thread parses now)
         if (prefetch.joinable()) {
             prefetch.join();
-            // what the helper collected goes behind what the store already holds for a contig (the first long read of this batch,
-            // consumed with the previous one as in the reference, stays in front of the short reads)
-            for (size_t c = 0; c < staged.size(); ++c) {
-                if (staged[c].empty()) continue;
-                if (_alignment_store[c].empty()) _alignment_store[c].swap(staged[c]);
-                else { for (auto& a : staged[c]) _alignment_store[c].emplace_back(std::move(a)); staged[c].clear(); }
-            }
+            _reads.append(staged);
         } else {
-            create_alignments(true, batch_id);
+            create_alignments_flat(batch_id, _reads);
         }
         stop("[Hypo:Hypo]: Loaded alignments. ");
         if (prefetch_on && batch_id + 1 < num_batches) {
-            staged.resize(_contigs.size());
-            prefetch = std::thread([this, batch_id, &staged] { omp_set_num_threads((int)_cFlags.threads); create_alignments(true, batch_id + 1, &staged); });
+            staged.reset(_contigs.size());
+            // (the helper's team: all of -t while the machine has threads to spare, half of it otherwise — the main thread's own
+            // parallel phases run next to it)
+            prefetch = std::thread([this, batch_id, &staged, helper_threads] { omp_set_num_threads(helper_threads); create_alignments_flat(batch_id + 1, staged); });
         }
+        std::vector<char> materialized(final_cid - initial_cid, 0);        // per contig of the batch: its Alignment objects exist (host loops)
+        _mat_base = initial_cid;
+        // The first long read of a contig may have been consumed while the previous batch's long reads were loaded; the reference
+        // files it in this contig's store entry, where the short-read phases of THIS batch find it in front of the short reads and
+        // treat it as one of them (src/Hypo.cpp:314-325, :126-199).  Same here: it moves to the front of the flat batch.
+        for (uint32_t c = initial_cid; c < final_cid; ++c)
+            if (!_alignment_store[c].empty()) { _reads.prepend(c, _alignment_store[c]); _alignment_store[c].clear(); }
 
         // With several devices the contigs of the batch are dealt out to the contexts in contiguous ranges of about equal
         // numbers of alignments (a batch with fewer contigs than devices stays on the first one): every context keeps the reads of
         // its contigs, counts their support votes, cuts their arms and polishes its own resident windows; no window travels.
-        for (auto& da : device_arms) da->wait_released();      // (the previous batch's alignments, still on their way out)
         std::vector<uint32_t> ctx_cut((size_t)n_ctx + 1, final_cid);
         ctx_cut[0] = initial_cid;
         if ((uint32_t)n_ctx > 1 && final_cid - initial_cid >= (uint32_t)n_ctx) {
             uint64_t total = 0, acc = 0;
-            for (uint32_t c = initial_cid; c < final_cid; ++c) total += _alignment_store[c].size() + 1;
+            for (uint32_t c = initial_cid; c < final_cid; ++c) total += _reads.count(c) + 1;
             int d = 1;
             for (uint32_t c = initial_cid; c < final_cid && d < n_ctx; ++c) {
-                acc += _alignment_store[c].size() + 1;
+                acc += _reads.count(c) + 1;
                 // the cut behind contig c belongs to context d when the first d shares are full (every context gets >= 1 contig)
                 while (d < n_ctx && acc * (uint64_t)n_ctx >= total * (uint64_t)d && final_cid - (c + 1) >= (uint32_t)(n_ctx - d)) ctx_cut[(size_t)d++] = c + 1;
             }
@@ -153,13 +175,15 @@ void Hypo::polish() {
         if (!_cFlags.host_arms && !std::getenv("HYPO_HOST_SUPPORT"))
             for (int d = 0; d < n_ctx; ++d) {
                 const uint32_t c0 = ctx_cut[(size_t)d], c1 = ctx_cut[(size_t)d + 1];
-                if (c0 < c1) votes_dev[(size_t)d] = device_arms[(size_t)d]->upload_reads(_contigs, c0, c1, _alignment_store) ? 1 : 0;
+                if (c0 < c1) votes_dev[(size_t)d] = device_arms[(size_t)d]->upload_reads(_contigs, c0, c1, _reads) ? 1 : 0;
             }
         for (int d = 0; d < n_ctx; ++d) {
             const uint32_t c0 = ctx_cut[(size_t)d], c1 = ctx_cut[(size_t)d + 1];
             if (c0 >= c1) continue;
             if (votes_dev[(size_t)d] && device_arms[(size_t)d]->support_kmers(_contigs, c0, c1, _cFlags.k)) continue;
+            materialize_alignments(c0, c1, materialized);
             for (uint32_t cid = c0; cid < c1; ++cid) {
+                _contigs[cid]->ensure_kids();
                 auto& alns = _alignment_store[cid];
 #pragma omp parallel for
                 for (int64_t t = 0; t < (int64_t)alns.size(); ++t) alns[(size_t)t]->update_solidkmers_support(_cFlags.k, *_contigs[cid]);
@@ -192,6 +216,7 @@ void Hypo::polish() {
             const uint32_t c0 = ctx_cut[(size_t)d], c1 = ctx_cut[(size_t)d + 1];
             if (c0 >= c1) continue;
             if (votes_dev[(size_t)d] && device_arms[(size_t)d]->support_minimizers(_contigs, c0, c1)) continue;
+            materialize_alignments(c0, c1, materialized);
             for (uint32_t cid = c0; cid < c1; ++cid) {
                 auto& alns = _alignment_store[cid];
 #pragma omp parallel for
@@ -215,13 +240,14 @@ void Hypo::polish() {
             for (int d = 0; d < n_ctx; ++d) {
                 const uint32_t c0 = ctx_cut[(size_t)d], c1 = ctx_cut[(size_t)d + 1];
                 if (c0 >= c1) continue;
-                if (device_arms[(size_t)d]->build(_contigs, c0, c1, _alignment_store, _cFlags.k))
+                if (device_arms[(size_t)d]->build(_contigs, c0, c1, _reads, _cFlags.k))
                     for (uint32_t c = c0; c < c1; ++c) on_dev[c - initial_cid] = 1;
             }
             hypo_gpu_use_device(0);
         }
         for (uint32_t cid = initial_cid; cid < final_cid; ++cid) {
-            if (on_dev[cid - initial_cid]) continue;
+            if (on_dev[cid - initial_cid]) { _alignment_store[cid].clear(); continue; }       // (objects a host vote loop had asked for)
+            materialize_alignments(cid, cid + 1, materialized);
             auto& alns = _alignment_store[cid];
 #pragma omp parallel for
             for (int64_t t = 0; t < (int64_t)alns.size(); ++t) alns[(size_t)t]->find_short_arms(_cFlags.k, *_contigs[cid]);
@@ -233,6 +259,14 @@ void Hypo::polish() {
         for (int64_t i = initial_cid; i < (int64_t)final_cid; ++i) {
             if (on_dev[(size_t)i - initial_cid]) continue;
             _contigs[(size_t)i]->fill_short_windows(_alignment_store[(size_t)i]); _alignment_store[(size_t)i].clear();
+        }
+        {   // the batch's short reads are spent; what it consumed for contigs of later batches stays for them (src/Hypo.cpp:314-325)
+            ReadBatch later;
+            later.reset(_contigs.size());
+            _reads.carry_beyond(final_cid, later);
+            _reads.clear(&_block_pool, &_pool_mu);
+            _reads.reset(_contigs.size());
+            _reads.append(later);
         }
         stop("[Hypo:Hypo]: Short arms filling. ");
 
@@ -325,19 +359,19 @@ void Hypo::polish() {
                     else if (t != RegionType::SR && t != RegionType::MSR) dump << "\t0\t0\t0\t0\t0\t" << _contigs[i]->draft_segment(b, e);   // no arms: draft kept
                     dump << '\n';
                 }
+        if (writer.joinable()) writer.join();
+        writer = std::thread([this, &ofile, initial_cid, final_cid] {
+            omp_set_num_threads(std::max(1, std::min((int)_cFlags.threads, 8)));
+            for (uint32_t c = initial_cid; c < final_cid; ++c) { ofile << *_contigs[c]; _contigs[c]->release_after_output(); }
+        });
     }
     _alignment_store.clear();
 
     start();
-    std::ofstream ofile(_cFlags.output_filename);
-    if (!ofile.is_open()) {
-        std::fprintf(stderr, "[Hypo::Hypo] Error: File open error: Output File (%s) could not be opened!\n", _cFlags.output_filename.c_str());
-        std::exit(1);
-    }
-    for (auto& c : _contigs) ofile << *c;
+    if (writer.joinable()) writer.join();
     ofile.close();
+    if (!ofile) { std::fprintf(stderr, "[Hypo::Hypo] Error: writing the output file (%s) failed!\n", _cFlags.output_filename.c_str()); std::exit(1); }
     stop("[Hypo:Hypo]: Writing results. ");
-    for (auto& da : device_arms) da->wait_released();      // inside the Overall timer, like the reference's own clear() of its alignment store
     _times.overall = std::chrono::duration<double>(std::chrono::steady_clock::now() - _tstart).count();
     std::fprintf(stdout, "RESOURCES ([Hypo:Hypo]: Overall. ): TIME= %g sec.\n", _times.overall);
     // (1.5 M windows with their arms and consensus strings: freed contig by contig on all threads, 0.37 s of the C3 run's wall otherwise)
@@ -468,6 +502,132 @@ void Hypo::create_alignments(bool is_sr, uint32_t batch_id, AlignmentStore* into
         t_wait += now() - t3;
     }
     if (std::getenv("HYPO_HOST_TIMING")) std::fprintf(stderr, "[timing] create_alignments: waiting for records %.3f s, parse + construct %.3f s, into the store %.3f s\n", t_wait, t_par, t_col);
+    std::fprintf(stdout, "[Hypo::Hypo] Info: Number of alignments (Batch %u): loaded (%lu) invalid (%lu)\n", batch_id,
+                 (unsigned long)num_alns, (unsigned long)num_invalid);
+}
+
+// ---- the flat path of the short reads (ReadBatch.hpp) -------------------------------------------------------------------------
+void Hypo::materialize_alignments(uint32_t c0, uint32_t c1, std::vector<char>& done) {
+    // `done` belongs to the batch in hand: entry i = contig (_mat_base + i), _mat_base = the batch's first contig
+    for (uint32_t c = c0; c < c1; ++c) {
+        char& d = done[c - _mat_base];
+        if (d) continue;
+        d = 1;
+        _reads.materialize(c, _alignment_store[c]);
+    }
+}
+
+void Hypo::parse_block(const SamReader& sf, const SamReader::RecordBlock& raw, ParsedBlock& blk) {
+    const uint32_t mq = _cFlags.map_qual_th;
+    const size_t count = raw.n();
+    blk.n = count;
+    blk.status.assign(count, ParsedBlock::ST_SKIPPED);
+    blk.cid.assign(count, -1);
+    blk.bad_ref_name.clear();
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)omp_get_max_threads(), count / 512 + 1));
+    blk.chunks.resize((size_t)T);
+#pragma omp parallel num_threads(T)
+    {
+        SamRecord rec;                                   // one per thread: its strings and CIGAR vector are reused
+        int32_t tid_seen = -2; int64_t cid_seen = -1;
+        for (int c = omp_get_thread_num(); c < T; c += omp_get_num_threads()) {
+            ReadChunk& ch = blk.chunks[(size_t)c];
+            ch.clear();
+            const size_t a = count * (size_t)c / (size_t)T, b = count * ((size_t)c + 1) / (size_t)T;
+            for (size_t i = a; i < b; ++i) {
+                sf.parse(raw.rec(i), raw.len(i), rec);
+                if ((rec.flag & (SAM_FUNMAP | SAM_FSECONDARY | SAM_FQCFAIL | SAM_FDUP)) || rec.mapq < mq) continue;
+                if (rec.tid != tid_seen) {                 // (one look-up per run of records of a contig)
+                    auto it = rec.tid < 0 ? _cname_to_id.end() : _cname_to_id.find(sf.tid2name(rec.tid));
+                    tid_seen = rec.tid;
+                    cid_seen = it == _cname_to_id.end() ? -1 : (int64_t)it->second;
+                }
+                if (cid_seen < 0) { blk.status[i] = ParsedBlock::ST_BADREF; continue; }
+                blk.cid[i] = (int32_t)cid_seen;
+                uint32_t rb, re, qab, qae;
+                Alignment::span_of(*_contigs[(size_t)cid_seen], rec, rb, re, qab, qae);
+                const uint32_t qlen = qae - qab;
+                // Alignment.cpp:551-571: the aligned part 2-bit packed; a read with a non-ACGT base there is dropped
+                bool ok = (size_t)qab + qlen <= rec.seq.size();
+                const size_t at = ch.seq.size();
+                if (ok) {
+                    ch.seq.resize(at + (qlen + 3) / 4);
+                    ok = pack2_acgt(rec.seq.data() + qab, qlen, ch.seq.data() + at);
+                    if (!ok) ch.seq.resize(at);
+                }
+                if (!ok) { blk.status[i] = ParsedBlock::ST_INVALID; continue; }
+                blk.status[i] = ParsedBlock::ST_KEPT;
+                ch.raw.push_back((uint32_t)i); ch.cid.push_back((int32_t)cid_seen); ch.rb.push_back(rb); ch.re.push_back(re); ch.qae.push_back(qlen);
+                ch.cig.insert(ch.cig.end(), rec.cigar.begin(), rec.cigar.end());
+                ch.seq_at.push_back((uint32_t)ch.seq.size()); ch.cig_at.push_back((uint32_t)ch.cig.size());
+            }
+        }
+    }
+    for (size_t i = 0; i < count; ++i)
+        if (blk.status[i] == ParsedBlock::ST_BADREF) { blk.bad_ref_name = sf.record_name(raw.rec(i), raw.len(i)); break; }
+}
+
+// src/Hypo.cpp:278-329 for the short reads: stream the (coordinate-sorted) file, stop when a record of the next batch shows up.
+// A reader thread inflates the file and cuts the next block of raw records while this block is parsed on all threads, every
+// thread writing the records of its stretch into a chunk of flat arrays; the batch takes the kept records as slices of the block.
+void Hypo::create_alignments_flat(uint32_t batch_id, ReadBatch& into) {
+    SamReader& sf = *_sf_short;
+    RecordStream& rs = _rs_short;
+    const uint32_t final_cid = batch_id * _contig_batch_size + _contig_batch_size;
+    uint64_t num_invalid = 0, num_alns = 0;
+    constexpr size_t kBlock = 1 << 17;
+    if (rs.carry_blk) { into.add(rs.carry_blk, rs.carry_r0, rs.carry_r1); rs.carry_blk.reset(); }
+    bool stop = false, more_ahead = true;
+    double t_wait = 0, t_par = 0, t_col = 0; auto now = []{ return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    while (!stop) {
+        std::thread reader;
+        const double t0 = now();
+        if (!rs.parsed || rs.ppos >= rs.parsed->n) {
+            if (rs.have_ahead) { std::swap(rs.cur, rs.ahead); rs.have_ahead = false; }
+            else if (rs.more) rs.more = sf.read_block(rs.cur, kBlock);
+            else break;
+            if (rs.cur.n() == 0) { if (!rs.more) break; continue; }
+            if (rs.more && !rs.have_ahead) reader = std::thread([&] { more_ahead = sf.read_block(rs.ahead, kBlock); });
+            std::shared_ptr<ParsedBlock> blk;
+            {
+                std::lock_guard<std::mutex> lk(_pool_mu);
+                if (rs.parsed && rs.parsed.use_count() == 1 && _block_pool.size() < 8) _block_pool.push_back(std::move(rs.parsed));
+                rs.parsed.reset();
+                if (!_block_pool.empty()) { blk = std::move(_block_pool.back()); _block_pool.pop_back(); }
+            }
+            if (!blk) blk = std::make_shared<ParsedBlock>();
+            const double t1 = now(); t_wait += t1 - t0;
+            parse_block(sf, rs.cur, *blk);
+            t_par += now() - t1;
+            rs.parsed = blk; rs.ppos = 0;
+        }
+        const double t2 = now();
+        const ParsedBlock& B = *rs.parsed;
+        // where the batch ends: the first record that is not skipped and belongs to a contig of a later batch is consumed as well,
+        // as in the reference; a record with an unknown reference before that is fatal
+        size_t s_first = B.n;
+        for (size_t i = rs.ppos; i < B.n; ++i) {
+            const uint8_t st = B.status[i];
+            if (st == ParsedBlock::ST_SKIPPED) continue;
+            if (st == ParsedBlock::ST_BADREF) {
+                std::fprintf(stderr, "[Hypo::Hypo] Error: Alignment File error: Contig-reference of record %s does not exist in the draft!\n", B.bad_ref_name.c_str());
+                std::exit(1);
+            }
+            if (st == ParsedBlock::ST_KEPT) ++num_alns; else ++num_invalid;
+            if ((uint32_t)B.cid[i] >= final_cid) { s_first = i; break; }
+        }
+        into.add(rs.parsed, rs.ppos, s_first);
+        if (s_first < B.n) {
+            if (B.status[s_first] == ParsedBlock::ST_KEPT) { rs.carry_blk = rs.parsed; rs.carry_r0 = s_first; rs.carry_r1 = s_first + 1; }
+            rs.ppos = s_first + 1;
+            stop = true;
+        } else rs.ppos = B.n;
+        const double t3 = now();
+        t_col += t3 - t2;
+        if (reader.joinable()) { reader.join(); rs.more = more_ahead; rs.have_ahead = rs.ahead.n() > 0; }
+        t_wait += now() - t3;
+    }
+    if (std::getenv("HYPO_HOST_TIMING")) std::fprintf(stderr, "[timing] create_alignments_flat: waiting for records %.3f s, parse %.3f s, into the batch %.3f s\n", t_wait, t_par, t_col);
     std::fprintf(stdout, "[Hypo::Hypo] Info: Number of alignments (Batch %u): loaded (%lu) invalid (%lu)\n", batch_id,
                  (unsigned long)num_alns, (unsigned long)num_invalid);
 }

@@ -10,6 +10,7 @@
 #include <vector>
 #include "Alignment.hpp"
 #include "Contig.hpp"
+#include "ReadBatch.hpp"
 #include "SeqIO.hpp"
 #include "Settings.hpp"
 
@@ -35,7 +36,13 @@ private:
     std::unique_ptr<SamReader> _sf_short, _sf_long;
     // per alignment file: the block of raw records being consumed (a contig batch may end in the middle of it), the block a
     // reader thread fetched meanwhile, and whether the file has more
-    struct RecordStream { SamReader::RecordBlock cur, ahead; size_t pos = 0; bool have_ahead = false, more = true; };
+    struct RecordStream {
+        SamReader::RecordBlock cur, ahead; size_t pos = 0; bool have_ahead = false, more = true;
+        // flat path (short reads): the parsed form of `cur`, how far it has been consumed, and the one record a call consumed for
+        // a contig of a later batch (the reference files it in that contig's store entry, src/Hypo.cpp:314-325)
+        std::shared_ptr<ParsedBlock> parsed; size_t ppos = 0;
+        std::shared_ptr<ParsedBlock> carry_blk; size_t carry_r0 = 0, carry_r1 = 0;
+    };
     RecordStream _rs_short, _rs_long;
     PhaseTimes _times;
     std::string _region_dump;
@@ -44,6 +51,14 @@ private:
     void start() { _t0 = std::chrono::steady_clock::now(); }
     void stop(const char* label);
     void create_alignments(bool is_sr, uint32_t batch_id, AlignmentStore* into = nullptr);   // into: the helper thread's own store (Hypo::polish)
+    // Round 4: the short reads of a contig batch as flat slices (ReadBatch.hpp) instead of one Alignment object per record
+    ReadBatch _reads;
+    std::vector<std::shared_ptr<ParsedBlock>> _block_pool; std::mutex _pool_mu;
+    void create_alignments_flat(uint32_t batch_id, ReadBatch& into);
+    void parse_block(const SamReader& sf, const SamReader::RecordBlock& raw, ParsedBlock& blk);
+    // Alignment objects of contigs [c0, c1) from _reads into _alignment_store (the host loops of the reference read those)
+    void materialize_alignments(uint32_t c0, uint32_t c1, std::vector<char>& done);
+    uint32_t _mat_base = 0;
 };
 
 }  // namespace hypo

@@ -22,6 +22,28 @@ inline uint8_t nt4(unsigned char c) {
     }
 }
 
+// n characters of A, C, G, T (either case) -> PackedSeq<2> bytes at dst ((n + 3) / 4 of them, the last one zero padded);
+// false when another character is among them (dst is then garbage)
+inline bool pack2_acgt(const char* s, size_t n, uint8_t* dst) {
+    struct Lut { uint8_t v[256]; Lut() { for (int i = 0; i < 256; ++i) v[i] = 0x80; v['A'] = v['a'] = 0; v['C'] = v['c'] = 1; v['G'] = v['g'] = 2; v['T'] = v['t'] = 3; } };
+    static const Lut lut;
+    const unsigned char* u = (const unsigned char*)s;
+    uint8_t* d = dst;
+    unsigned bad = 0;
+    size_t i = 0;
+    for (; i + 4 <= n; i += 4) {
+        const unsigned a = lut.v[u[i]], b = lut.v[u[i + 1]], c = lut.v[u[i + 2]], e = lut.v[u[i + 3]];
+        bad |= a | b | c | e;
+        *d++ = (uint8_t)((a << 6) | (b << 4) | (c << 2) | e);
+    }
+    if (i < n) {
+        unsigned byte = 0;
+        for (int sh = 6; i < n; ++i, sh -= 2) { const unsigned a = lut.v[u[i]]; bad |= a; byte |= (a & 3u) << sh; }
+        *d = (uint8_t)byte;
+    }
+    return !(bad & 0x80u);
+}
+
 template <int NB>
 class PackedSeq {
     static_assert(NB == 2 || NB == 4, "2 or 4 bits per base");

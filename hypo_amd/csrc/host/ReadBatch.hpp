@@ -1,0 +1,82 @@
+// ReadBatch.hpp — the short-read alignments of a contig batch as flat arrays (round 4).
+//
+// The reference keeps one heap object per mapped read (std::unique_ptr<Alignment> in Hypo::_alignment_store, src/Hypo.cpp:314-318)
+// and so did rounds 1-3 here: 20 M objects on the 100 Mbp set, each with a PackedSeq and a CIGAR vector of its own, built by the
+// parser threads, walked once to be flattened for hypo_gpu_reads_upload, and released again (a helper thread per batch, which the
+// next batch had to wait for).  What the device path reads of a record is five numbers, its packed bases and its CIGAR: the parser
+// threads now write exactly that, back to back, into per-thread chunks of the block of records in hand (ReadChunk / ParsedBlock);
+// a contig batch is a list of slices of such blocks (ReadBatch), and flatten() lays them out — per contig, in file order — in the
+// caller's page-locked staging arrays, which go to the device as they are.  Alignment objects are made from the same slices only
+// when a host loop of the reference has to run (materialize(): --host-arms, an unsorted file, a device error, the CPU test shim).
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "Alignment.hpp"
+
+namespace hypo {
+
+class Contig;
+
+struct ReadChunk {                           // the KEPT records of one stretch of a block, in file order (filled by one thread)
+    std::vector<uint32_t> raw;               // index of the record within its block
+    std::vector<int32_t> cid;                // contig id
+    std::vector<uint32_t> rb, re, qae;       // contig-local reference span, aligned query length (Alignment::_rb / _re / _qae)
+    std::vector<uint32_t> seq_at, cig_at;    // where the record's packed bases / CIGAR start in seq / cig (n + 1 entries)
+    std::vector<uint8_t> seq;                // PackedSeq<2> bytes of the aligned part, each record on a byte boundary
+    std::vector<uint32_t> cig;               // op | len << 4
+    size_t n() const { return raw.size(); }
+    void clear() { raw.clear(); cid.clear(); rb.clear(); re.clear(); qae.clear(); seq_at.assign(1, 0); cig_at.assign(1, 0); seq.clear(); cig.clear(); }
+};
+
+struct ParsedBlock {
+    std::vector<ReadChunk> chunks;           // in file order
+    std::vector<uint8_t> status;             // per raw record: ST_*
+    std::vector<int32_t> cid;                // per raw record (-1: skipped or unknown reference)
+    std::string bad_ref_name;                // read name of the first record with an unknown reference
+    size_t n = 0;
+    enum : uint8_t { ST_KEPT = 0, ST_SKIPPED = 1, ST_BADREF = 2, ST_INVALID = 3 };
+};
+
+// Page-locked staging arrays of one device context (hypo_gpu_host_alloc; grow-only, reused by every batch): what
+// hypo_gpu_reads_upload takes.
+struct ReadStaging {
+    uint32_t *rb = nullptr, *re = nullptr, *qae = nullptr, *ctg = nullptr, *cigar_off = nullptr, *cigar = nullptr;
+    uint64_t* seq_off = nullptr; uint8_t* reads2 = nullptr;
+    size_t cap_reads = 0, cap_cigar = 0, cap_bytes = 0;
+    uint64_t n_reads = 0, n_cigar = 0, n_bytes = 0;
+    bool reserve(size_t reads, size_t cig, size_t bytes);          // false: no memory
+    void release();
+    ~ReadStaging() { release(); }
+};
+
+class ReadBatch {
+public:
+    struct Slice { std::shared_ptr<ParsedBlock> blk; uint32_t chunk, k0, k1; };
+    void reset(size_t n_contigs) { _slices.clear(); _per_contig.assign(n_contigs, 0); _n = 0; }
+    // the kept records among raw records [r0, r1) of blk
+    void add(const std::shared_ptr<ParsedBlock>& blk, size_t r0, size_t r1);
+    void append(ReadBatch& other);                                  // other's slices behind this one's (other is left empty)
+    // Alignment objects of contig cid (in their order) in FRONT of everything the batch holds
+    void prepend(uint32_t cid, const std::vector<std::unique_ptr<Alignment>>& objs);
+    uint64_t size() const { return _n; }
+    uint64_t count(uint32_t cid) const { return cid < _per_contig.size() ? _per_contig[cid] : 0; }
+    bool empty() const { return _slices.empty(); }
+    // The records of contigs [c0, c1) in `out`: contig after contig (contig c starts at base[c - c0] of the coordinate space), each
+    // contig's records in file order.  `sorted` = every contig's records come with non-decreasing rb.  false: no memory.
+    bool flatten(uint32_t c0, uint32_t c1, const std::vector<uint64_t>& base, ReadStaging& out, bool& sorted) const;
+    // Alignment objects for contig cid (the reference's store entry), appended to `into`
+    void materialize(uint32_t cid, std::vector<std::unique_ptr<Alignment>>& into) const;
+    // the records of contigs >= first_cid as a batch of their own (copied into a block of its own): what a later batch inherits
+    void carry_beyond(uint32_t first_cid, ReadBatch& into) const;
+    void clear(std::vector<std::shared_ptr<ParsedBlock>>* pool = nullptr, std::mutex* pool_mu = nullptr);
+private:
+    std::vector<Slice> _slices;
+    std::vector<uint64_t> _per_contig;
+    uint64_t _n = 0;
+};
+
+}  // namespace hypo

@@ -105,7 +105,8 @@ __device__ __forceinline__ void st_store(uint64_t* p, uint64_t v) { __hip_atomic
 __global__ void __launch_bounds__(SCAN_THREADS)
 scan_fused_kernel(const uint8_t* __restrict__ packed4, uint64_t n_bases, uint32_t k, const uint64_t* __restrict__ bits,
                   uint64_t* __restrict__ words, uint64_t* __restrict__ word_rank, uint64_t* __restrict__ kids, uint64_t kids_cap,
-                  uint64_t n_words, uint64_t n_tiles, uint64_t* __restrict__ hdr, uint64_t* __restrict__ status, uint64_t* __restrict__ n_solid) {
+                  uint64_t n_words, uint64_t n_tiles, uint64_t* __restrict__ hdr, uint64_t* __restrict__ status, uint64_t* __restrict__ n_solid,
+                  uint32_t* __restrict__ kids32, uint32_t* __restrict__ spos) {
     __shared__ __attribute__((aligned(16))) uint8_t sb[SCAN_LDS_BYTES + 16];
     __shared__ uint32_t wex[SCAN_WORDS_PER_BLOCK];
     __shared__ uint32_t wc[SCAN_WORDS_PER_BLOCK];
@@ -209,7 +210,7 @@ scan_fused_kernel(const uint8_t* __restrict__ packed4, uint64_t n_bases, uint32_
     // ---- k-mer ids of the lane's marked positions at their ranks, bases from the tile's LDS copy
     const uint32_t pc = (uint32_t)__popc(m);
     const uint32_t q1 = __shfl_up(pc, 1, 64), q2 = __shfl_up(pc, 2, 64), q3 = __shfl_up(pc, 3, 64);
-    if (!kids || !kids_cap || m == 0) return;
+    if ((!kids && !kids32) || !kids_cap || m == 0) return;
     const int sub = tid & 3;
     uint64_t r = prefix + wex[wl] + (sub >= 1 ? q1 : 0u) + (sub >= 2 ? q2 : 0u) + (sub >= 3 ? q3 : 0u);
     while (m) {
@@ -224,7 +225,9 @@ scan_fused_kernel(const uint8_t* __restrict__ packed4, uint64_t n_bases, uint32_
             uint64_t kmer;
             if (k <= 16) kmer = (uint64_t)squeeze16(hi) >> (2 * (16 - k));
             else kmer = (((uint64_t)squeeze16(hi) << 32) | squeeze16(lo)) >> (2 * (32 - k));
-            kids[r] = kmer;
+            // (a resident scan, hypo_gpu_solid_scan_keep: k-mers of k <= 16 as 32-bit words, and the position next to each)
+            if (kids32) kids32[r] = (uint32_t)kmer; else kids[r] = kmer;
+            if (spos) spos[r] = (uint32_t)(tile * SCAN_POS_PER_BLOCK + (uint64_t)l);
         }
         ++r;
     }
@@ -245,7 +248,8 @@ size_t scan_workspace_bytes(uint64_t n_bases) {
 hipError_t scan_run(const uint8_t* packed4, uint64_t n_bases, uint32_t k, const uint64_t* bits,
                     uint64_t* words, uint64_t* kids, uint64_t kids_cap, uint64_t* word_rank,
                     uint64_t* n_solid, void* workspace, size_t workspace_bytes, hipStream_t stream,
-                    hipEvent_t* prof_ev) {
+                    hipEvent_t* prof_ev, uint32_t* kids32, uint32_t* spos) {
+    if (kids32 && k > 16) return hipErrorInvalidValue;
     if (workspace_bytes < scan_workspace_bytes(n_bases)) return hipErrorInvalidValue;
     const uint64_t n_words = (n_bases + 63) / 64;
     const uint64_t n_tiles = (n_words + SCAN_WORDS_PER_BLOCK - 1) / SCAN_WORDS_PER_BLOCK;
@@ -265,7 +269,8 @@ hipError_t scan_run(const uint8_t* packed4, uint64_t n_bases, uint32_t k, const 
     if (prof_ev) (void)hipEventRecord(prof_ev[0], stream);
     if ((e = hipMemsetAsync(ws, 0, 256 + status_bytes, stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(scan_fused_kernel, dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, stream,
-                       packed4, n_bases, k, bits, words, word_rank, (kids && kids_cap) ? kids : nullptr, kids_cap, n_words, n_tiles, hdr, status, n_solid);
+                       packed4, n_bases, k, bits, words, word_rank, (kids && kids_cap) ? kids : nullptr, kids_cap, n_words, n_tiles, hdr, status, n_solid,
+                       kids_cap ? kids32 : nullptr, kids_cap ? spos : nullptr);
     if (prof_ev) { (void)hipEventRecord(prof_ev[1], stream); (void)hipEventRecord(prof_ev[2], stream); (void)hipEventRecord(prof_ev[3], stream); }
     return hipGetLastError();
 }

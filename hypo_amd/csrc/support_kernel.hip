@@ -35,8 +35,9 @@ __device__ __forceinline__ uint32_t count_less_equal(const uint32_t* a, uint32_t
 // kid).  The reference looks every k-mer of the read up in an unordered_multimap of the span's solid k-mers and walks equal_range
 // in reverse insertion order; the matches that can vote lie within k bases of the read k-mer's offset, so a window over the
 // position-sorted solid k-mers that slides along with the read gives the same visits in the same order (host/Alignment.cpp).
+template <typename KidT>
 __global__ void __launch_bounds__(T) support_kmers_kernel(SupportReads R, uint32_t k, uint32_t n_solid, const uint32_t* __restrict__ spos,
-                                                          const uint64_t* __restrict__ kids, uint32_t* __restrict__ cov, uint32_t* __restrict__ sup) {
+                                                          const KidT* __restrict__ kids, uint32_t* __restrict__ cov, uint32_t* __restrict__ sup) {
     const uint32_t a = blockIdx.x * T + threadIdx.x;
     if (a >= R.n_alignments) return;
     const uint32_t rb = R.rb[a], re = R.re[a];
@@ -48,7 +49,7 @@ __global__ void __launch_bounds__(T) support_kmers_kernel(SupportReads R, uint32
     const uint32_t n = last - first;
     for (uint32_t t = 0; t < n; ++t) atomicAdd(&cov[first + t], 1u);
     const uint32_t* sp = spos + first;
-    const uint64_t* kd = kids + first;
+    const KidT* kd = kids + first;
     const uint8_t* rd = R.reads2 + R.seq_off[a];
     const uint32_t nq = R.qae[a];
     const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
@@ -64,7 +65,7 @@ __global__ void __launch_bounds__(T) support_kmers_kernel(SupportReads R, uint32
         while (hi < n && (int64_t)sp[hi] - (int64_t)rb <= (int64_t)r_bind + (int64_t)k) ++hi;
         while (lo < hi && (int64_t)sp[lo] - (int64_t)rb + (int64_t)k < (int64_t)r_bind) ++lo;
         for (uint32_t c = hi; c-- > lo;) {
-            if (kd[c] != kmer) continue;
+            if ((uint64_t)kd[c] != kmer) continue;
             const int64_t c_dist = (int64_t)sp[c] - (int64_t)rb;
             const uint32_t left = c_dist > (int64_t)k ? (uint32_t)(c_dist - k) : 0u;
             const int64_t rr = c_dist + (int64_t)k;
@@ -178,7 +179,22 @@ __global__ void __launch_bounds__(T) support_minimizers_kernel(SupportReads R, M
 
 hipError_t support_kmers(const SupportReads& R, uint32_t k, uint32_t n_solid, const uint32_t* spos, const uint64_t* kids, uint32_t* cov, uint32_t* sup, hipStream_t st) {
     if (!R.n_alignments || !n_solid) return hipSuccess;
-    hipLaunchKernelGGL(support_kmers_kernel, dim3((R.n_alignments + T - 1) / T), dim3(T), 0, st, R, k, n_solid, spos, kids, cov, sup);
+    hipLaunchKernelGGL(support_kmers_kernel<uint64_t>, dim3((R.n_alignments + T - 1) / T), dim3(T), 0, st, R, k, n_solid, spos, kids, cov, sup);
+    return hipGetLastError();
+}
+hipError_t support_kmers32(const SupportReads& R, uint32_t k, uint32_t n_solid, const uint32_t* spos, const uint32_t* kids32, uint32_t* cov, uint32_t* sup, hipStream_t st) {
+    if (!R.n_alignments || !n_solid) return hipSuccess;
+    hipLaunchKernelGGL(support_kmers_kernel<uint32_t>, dim3((R.n_alignments + T - 1) / T), dim3(T), 0, st, R, k, n_solid, spos, kids32, cov, sup);
+    return hipGetLastError();
+}
+// out[i] = in[i] + base: the contig-local positions a resident scan kept, moved into the batch's coordinate space
+__global__ void __launch_bounds__(T) add_base_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n, uint32_t base) {
+    const uint64_t i = (uint64_t)blockIdx.x * T + threadIdx.x;
+    if (i < n) out[i] = in[i] + base;
+}
+hipError_t add_base(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t base, hipStream_t st) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(add_base_kernel, dim3((unsigned)((n + T - 1) / T)), dim3(T), 0, st, in, out, n, base);
     return hipGetLastError();
 }
 hipError_t support_minimizers(const SupportReads& R, const MegaWindows& M, uint32_t* cov, uint32_t* sup, hipStream_t st) {

@@ -27,6 +27,8 @@ struct MegaWindows {                 // Contig::_reg_pos / _is_win_even / _minim
 };
 
 hipError_t support_kmers(const SupportReads& R, uint32_t k, uint32_t n_solid, const uint32_t* spos, const uint64_t* kids, uint32_t* cov, uint32_t* sup, hipStream_t st);
+hipError_t support_kmers32(const SupportReads& R, uint32_t k, uint32_t n_solid, const uint32_t* spos, const uint32_t* kids32, uint32_t* cov, uint32_t* sup, hipStream_t st);   // k <= 16
+hipError_t add_base(const uint32_t* in, uint32_t* out, uint64_t n, uint32_t base, hipStream_t st);
 hipError_t support_minimizers(const SupportReads& R, const MegaWindows& M, uint32_t* cov, uint32_t* sup, hipStream_t st);
 
 }  // namespace hypo

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HYPO_GPU_ABI_VERSION 6
+#define HYPO_GPU_ABI_VERSION 7
 #define HYPO_MAX_DEVICES 16      /* contexts one process can hold (an MI355X node has 8 GPUs) */
 
 /* error codes */
@@ -326,6 +326,28 @@ typedef struct HypoMegaWindows {     /* Contig::_reg_pos / _is_win_even / _minim
 } HypoMegaWindows;
 /* OUT coverage / support [mw_off[n_info]] (MWMinimiserInfo::coverage / support). */
 int hypo_gpu_support_minimizers(const HypoMegaWindows* windows, uint32_t* coverage, uint32_t* support);
+
+/* Round 4 (ABI 7): what only the device reads stays on the device ------------------------------------------------------------------
+ * hypo_gpu_solid_scan_keep: hypo_gpu_solid_scan (the 4^k-bit set must have been uploaded with hypo_gpu_solid_set_upload) whose
+ * k-mer ids (Contig::_kmerinfo[i]->kid, src/Contig.cpp:68) and marked positions are NOT returned: they stay in device memory under
+ * `handle` (the caller's contig number, < 2^24) until hypo_gpu_solid_release(handle) (0xffffffff: every handle of the context) or
+ * hypo_gpu_shutdown.  The host gets the mark bits, their rank directory and the count — what Contig::_solid_pos needs; a k-mer id it
+ * wants later (the anchors of Contig::prepare_for_division, src/Contig.cpp:117-118,126-127) is the k bases at that position of
+ * the contig it already holds.
+ * hypo_gpu_support_kmers_kept: hypo_gpu_support_kmers for the kept scans of `n_contigs` contigs laid back to back in the
+ * coordinate space of the resident reads at contig_base[c] (ascending): OUT coverage / support, Contig::_kmerinfo counters of
+ * contig 0, then contig 1, ... (n_solid_total entries; pass buffers of sum(n_solid) entries).  A handle that holds no scan ON
+ * THE CALLING THREAD'S CONTEXT -> HYPO_E_INVALID (the caller then sends positions and k-mers with hypo_gpu_support_kmers). */
+int hypo_gpu_solid_scan_keep(uint32_t handle, const uint8_t* packed4, uint64_t n_bases, uint32_t k,
+                             uint64_t* solid_pos_words_out, uint64_t* word_rank_out, uint64_t* n_solid_out);
+int hypo_gpu_solid_release(uint32_t handle);
+int hypo_gpu_support_kmers_kept(uint32_t k, uint32_t n_contigs, const uint32_t* handles, const uint32_t* contig_base,
+                                uint32_t* coverage, uint32_t* support, uint64_t* n_solid_total);
+/* Page-locked host memory for the caller's staging buffers (reads, result buffers): copies from / into it run at the link's rate
+ * and truly asynchronously; pageable memory is staged through the runtime's own bounce buffers.  Any buffer of this header may
+ * live in it; none has to. */
+int hypo_gpu_host_alloc(size_t bytes, void** out);
+int hypo_gpu_host_free(void* p);
 
 /* Kernel timing with HIP events on the stream the kernels run on ----------------------------------
  * hypo_gpu_profile_begin(max_calls) arms the next max_calls (<= 256) *_device calls: each records
