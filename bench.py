@@ -92,80 +92,200 @@ def end_to_end_leg():
         shutil.rmtree(d, ignore_errors=True)
 
 
-def end_to_end_c3_leg():
-    """BASELINE config C3 end to end: the `hypo` binary on 100 contigs of 1 Mbp with 30x short reads (tests/golden/gen_e2e_fast.cpp
-    writes the 3.9 GB of SAM text), ten contig batches; the FASTA must have the md5 the REAL reference produced for these inputs."""
+def _scratch_dir(prefix, need_bytes):
+    """Memory-backed scratch when /dev/shm has the room (the GPU boxes: 1.5 TB), else the default temp directory."""
+    import shutil
+    import tempfile
+    try:
+        if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > need_bytes * 2:
+            return tempfile.mkdtemp(prefix=prefix, dir="/dev/shm")
+    except OSError:
+        pass
+    return tempfile.mkdtemp(prefix=prefix)
+
+
+def _gpu_busy_sampler():
+    """(start, stop) of a 20 Hz sampler of the first GPU's busy percentage (amdgpu sysfs); stop() returns the mean or None."""
+    import glob
+    import threading
+    paths = sorted(glob.glob("/sys/class/drm/card*/device/gpu_busy_percent"))
+    vals, flag = [], [True]
+    def run():
+        while flag[0] and paths:
+            try:
+                vals.append(float(open(paths[0]).read().strip()))
+            except (OSError, ValueError):
+                pass
+            time.sleep(0.05)
+    th = threading.Thread(target=run, daemon=True)
+    def stop():
+        flag[0] = False
+        th.join(timeout=1)
+        return round(sum(vals) / len(vals), 2) if vals else None
+    return th.start, stop
+
+
+def _run_hypo(argv, cwd, timeout=3000):
+    """Runs the binary; returns (returncode, stdout, stderr, wall seconds, peak RSS in MB from /proc VmHWM, mean GPU busy %)."""
+    import subprocess
+    import threading
+    peak = [0]
+    start_busy, stop_busy = _gpu_busy_sampler()
+    tw = time.perf_counter()
+    proc = subprocess.Popen(argv, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    start_busy()
+    def watch():
+        # (VmHWM belongs to the new address space; getrusage's ru_maxrss, which the binary prints, starts from this python process's own high-water mark)
+        while proc.poll() is None:
+            try:
+                for line in open(f"/proc/{proc.pid}/status"):
+                    if line.startswith("VmHWM:"):
+                        peak[0] = max(peak[0], int(line.split()[1]))
+            except OSError:
+                pass
+            time.sleep(0.05)
+    th = threading.Thread(target=watch, daemon=True)
+    th.start()
+    out, err = proc.communicate(timeout=timeout)
+    th.join(timeout=1)
+    busy = stop_busy()
+    return proc.returncode, out, err, time.perf_counter() - tw, (round(peak[0] / 1024.0, 1) if peak[0] else None), busy
+
+
+def _fasta_md5(path):
     import hashlib
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 24), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
+def _build_generator():
+    import subprocess
+    src = os.path.join(ROOT, "tests", "golden", "gen_e2e_fast.cpp")
+    gen = os.path.join(ROOT, "tests", "_build", "gen_e2e_fast")
+    if not os.path.exists(gen) or os.path.getmtime(gen) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(gen), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-fopenmp", "-o", gen, src, "-lz"])
+    return gen
+
+
+def end_to_end_fast_leg(name, bam, what):
+    """The `hypo` binary on a set of the C++ generator (tests/golden/gen_e2e_fast.cpp) whose golden manifest holds the md5 of the FASTA
+    the REAL reference produced for it: BASELINE config C3 (100 x 1 Mbp, SAM text) and the 250 Mbp / k = 15 set (BAM)."""
     import re
     import shutil
     import subprocess
-    import tempfile
     binp = os.path.join(ROOT, "hypo_amd", "_build", "hypo")
-    manp = os.path.join(ROOT, "tests", "golden", "e2e_c3_100m_s31.manifest.json")
-    src = os.path.join(ROOT, "tests", "golden", "gen_e2e_fast.cpp")
-    if not (os.path.exists(binp) and os.path.exists(manp) and os.path.exists(src)):
-        return {"error": "hypo binary, generator or golden manifest missing"}
+    manp = os.path.join(ROOT, "tests", "golden", name + ".manifest.json")
+    if not (os.path.exists(binp) and os.path.exists(manp)):
+        return {"error": "hypo binary or golden manifest missing"}
     man = json.load(open(manp))
-    d = tempfile.mkdtemp(prefix="hypo_bench_c3_")
+    a = man["args"]
+    d = _scratch_dir("hypo_bench_e2e_", a["contigs"] * a["contig_len"] * (8 if bam else 45))
     try:
-        gen = os.path.join(ROOT, "tests", "_build", "gen_e2e_fast")
-        if not os.path.exists(gen) or os.path.getmtime(gen) < os.path.getmtime(src):
-            os.makedirs(os.path.dirname(gen), exist_ok=True)
-            subprocess.check_call(["g++", "-O2", "-fopenmp", "-o", gen, src, "-lz"])
-        a = man["args"]
+        gen = _build_generator()
         tg = time.perf_counter()
         rep = json.loads(subprocess.check_output([gen, d, str(a["seed"]), str(a["contigs"]), str(a["contig_len"]), str(a["k"]),
-                                                  str(a["coverage"]), str(a["read_len"]), str(a["read_sub_ppm"])], text=True))
+                                                  str(a["coverage"]), str(a["read_len"]), str(a["read_sub_ppm"])] + (["--bam"] if bam else []), text=True))
         tg = time.perf_counter() - tg
-        if rep != man["generator_report"]:
+        want = man["generator_report"]
+        keys = ("contigs", "draft_bases", "reads", "solid_kmers", "fnv_draft", "fnv_bitvector") if bam else tuple(want.keys())
+        if any(rep.get(k) != want[k] for k in keys):
             return {"error": "the generator's output differs from the golden's inputs"}
         threads = min(64, os.cpu_count() or 1)
         argv = [binp] + man["command"].split()[1:]
         argv[argv.index("-t") + 1] = str(threads)
-        tw = time.perf_counter()
-        # peak resident set of the child from /proc (VmHWM belongs to the new address space; getrusage's ru_maxrss, which the
-        # binary prints, starts from this python process's own high-water mark on Linux)
-        import threading
-        peak = [0]
-        proc = subprocess.Popen(argv, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-        def watch():
-            while proc.poll() is None:
-                try:
-                    for line in open(f"/proc/{proc.pid}/status"):
-                        if line.startswith("VmHWM:"):
-                            peak[0] = max(peak[0], int(line.split()[1]))
-                except OSError:
-                    pass
-                time.sleep(0.05)
-        th = threading.Thread(target=watch, daemon=True)
-        th.start()
-        out, err = proc.communicate(timeout=1500)
-        th.join(timeout=1)
-        wall = time.perf_counter() - tw
-        class _P:
-            pass
-        p = _P()
-        p.stdout, p.stderr, p.returncode = out, err, proc.returncode
-        if p.returncode != 0:
-            return {"error": (p.stdout + p.stderr)[-300:]}
-        m = re.search(r"Overall\. \): TIME= ([0-9.eE+-]+) sec", p.stdout)
+        if bam:
+            argv[argv.index("-b") + 1] = "sr.bam"
+        rc, out, err, wall, rss, busy = _run_hypo(argv, d)
+        if rc != 0:
+            return {"error": (out + err)[-300:]}
+        m = re.search(r"Overall\. \): TIME= ([0-9.eE+-]+) sec", out)
         overall = float(m.group(1)) if m else wall
-        h = hashlib.md5()
-        with open(os.path.join(d, "hypo_draft.fasta"), "rb") as f:
-            for chunk in iter(lambda: f.read(1 << 24), b""):
-                h.update(chunk)
-        if h.hexdigest() != man["expected_fasta_md5"]:
-            raise SystemExit("bench: C3 end-to-end FASTA differs from the real reference's — refusing to report a number")
-        poa = [float(x) for x in re.findall(r"POA of windows\. \): TIME= ([0-9.eE+-]+) sec", p.stdout)]
+        if _fasta_md5(os.path.join(d, "hypo_draft.fasta")) != man["expected_fasta_md5"]:
+            raise SystemExit(f"bench: {name}: end-to-end FASTA differs from the real reference's — refusing to report a number")
+        poa = [float(x) for x in re.findall(r"POA of windows\. \): TIME= ([0-9.eE+-]+) sec", out)]
+        nwin = sum(int(x) for x in re.findall(r"polished windows \(Batch \d+\): (\d+)", out))
         G = rep["draft_bases"]
         return {"mbp_per_s": round(G / 1e6 / overall, 2), "seconds": round(overall, 3), "process_wall_seconds": round(wall, 3),
-                "peak_rss_mb": round(peak[0] / 1024.0, 1) if peak[0] else None, "host_threads": threads,
-                "windows": man["reference_stat"]["windows"], "poa_seconds_total": round(sum(poa), 3), "contig_batches": len(poa),
-                "input_generation_seconds": round(tg, 1),
+                "peak_rss_mb": rss, "gpu_busy_percent_mean": busy, "host_threads": threads,
+                "windows": nwin, "poa_seconds_total": round(sum(poa), 3), "contig_batches": len(poa),
+                "input_generation_seconds": round(tg, 1), "alignment_file": "BAM (BGZF, inflated in parallel)" if bam else "SAM text",
                 "reference": {"seconds": man["reference_run"]["overall_seconds"], "threads": man["reference_run"]["threads"],
-                              "peak_rss_mb": man["reference_run"]["peak_rss_mb"], "where": man["reference_run"]["host"]},
-                "workload": "C3 end to end: 100 x 1 Mbp draft, 30x 150-bp reads (19.9 M records, 3.9 GB of SAM text), k = 13, -p 10, hypo binary = host pipeline + device, one run",
+                              "peak_rss_mb": man["reference_run"]["peak_rss_mb"], "where": man["reference_run"]["host"] + " (not this box)"},
+                "workload": what,
                 "fasta": "md5 identical to the real reference's output for these inputs"}
+    except (subprocess.SubprocessError, OSError, ValueError) as ex:
+        return {"error": str(ex)[:300]}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def end_to_end_c3_leg():
+    return end_to_end_fast_leg("e2e_c3_100m_s31", False,
+                               "C3 end to end: 100 x 1 Mbp draft, 30x 150-bp reads (19.9 M records, 3.9 GB of SAM text), k = 13, -p 10, hypo binary = host pipeline + device, one run")
+
+
+def end_to_end_k15_leg():
+    return end_to_end_fast_leg("e2e_k15_250m_s77", True,
+                               "250 Mbp at the k of C4 end to end: 250 x 1 Mbp draft, 30x 150-bp reads (49.7 M records as BAM), -s 250m -> k = 15 (128 MiB solid set, dense tiny-window shape), -p 10, one run")
+
+
+def end_to_end_t1_leg(n_contigs, contig_len=1_000_000, batchings=(10, 50)):
+    """Row T1 (north_star: 3 Gbp / 30x short reads on one GPU): `n_contigs` x 1 Mbp from the C++ generator as BAM, `-s <size>` picks k as the
+    reference does (1g -> 15, 3g -> 17), the run is made once per contig-batch size in `batchings` and the FASTA of all of them must be
+    identical (`-p` invariance); no reference md5 at this size (the real reference needs hours and > 100 GB for it), the same binary
+    reproduces the reference's FASTA on every smaller golden."""
+    import re
+    import shutil
+    import subprocess
+    binp = os.path.join(ROOT, "hypo_amd", "_build", "hypo")
+    if not os.path.exists(binp):
+        return {"error": "hypo binary missing"}
+    total = n_contigs * contig_len
+    size_flag = f"{total // 1_000_000_000}g" if total % 1_000_000_000 == 0 else f"{total // 1_000_000}m"
+    import math
+    d = _scratch_dir("hypo_bench_t1_", total * 8)
+    try:
+        gen = _build_generator()
+        # k as src/main.cpp:490-528 derives it from the size flag
+        val, unit = (total // 1_000_000_000, 30) if size_flag.endswith("g") else (total // 1_000_000, 20)
+        kk = (unit + int(math.ceil(math.log2(val)))) // 2
+        kk = kk + 1 if kk % 2 == 0 else kk
+        tg = time.perf_counter()
+        rep = json.loads(subprocess.check_output([gen, d, "97", str(n_contigs), str(contig_len), str(kk), "30", "150", "2000", "--bam", "--fast-hash"], text=True))
+        tg = time.perf_counter() - tg
+        threads = min(64, os.cpu_count() or 1)
+        runs, md5s = [], []
+        for pb in batchings:
+            outp = f"out_p{pb}.fa"
+            argv = [binp, "-d", "draft.fa", "-r", "reads.fa", "-s", size_flag, "-c", "30", "-b", "sr.bam", "-t", str(threads), "-i", "-p", str(pb), "-o", outp]
+            rc, out, err, wall, rss, busy = _run_hypo(argv, d, timeout=5000)
+            if rc != 0:
+                return {"error": (out + err)[-300:]}
+            if f"chosen for the given genome size ({size_flag}): {kk}" not in out:
+                return {"error": f"k mismatch: expected {kk}: " + out[:200]}
+            m = re.search(r"Overall\. \): TIME= ([0-9.eE+-]+) sec", out)
+            overall = float(m.group(1)) if m else wall
+            md5s.append(_fasta_md5(os.path.join(d, outp)))
+            os.remove(os.path.join(d, outp))
+            poa = [float(x) for x in re.findall(r"POA of windows\. \): TIME= ([0-9.eE+-]+) sec", out)]
+            nwin = sum(int(x) for x in re.findall(r"polished windows \(Batch \d+\): (\d+)", out))
+            phases = {}
+            for lab, sec in re.findall(r"RESOURCES \(\[Hypo:Hypo\]: (.*?)\. \): TIME= ([0-9.eE+-]+)", out):
+                phases[lab] = round(phases.get(lab, 0.0) + float(sec), 3)
+            runs.append({"p": pb, "seconds": round(overall, 2), "mbp_per_s": round(rep["draft_bases"] / 1e6 / overall, 2), "process_wall_seconds": round(wall, 2),
+                         "peak_rss_mb": rss, "gpu_busy_percent_mean": busy, "windows": nwin, "poa_seconds_total": round(sum(poa), 2), "contig_batches": len(poa), "phases": phases})
+        best = min(runs, key=lambda r: r["seconds"])
+        return {"mbp_per_s": best["mbp_per_s"], "seconds": best["seconds"], "draft_bases": rep["draft_bases"], "reads": rep["reads"], "k": kk, "size_flag": size_flag,
+                "solid_kmers": rep["solid_kmers"], "peak_rss_mb": best["peak_rss_mb"], "gpu_busy_percent_mean": best["gpu_busy_percent_mean"], "windows": best["windows"],
+                "runs": runs, "fasta_identical_across_batchings": len(set(md5s)) == 1, "fasta_md5": md5s[0], "host_threads": threads,
+                "input_generation_seconds": round(tg, 1), "bam_bytes": os.path.getsize(os.path.join(d, "sr.bam")),
+                "workload": f"T1: {n_contigs} x {contig_len // 1000} kbp draft, 30x 150-bp short reads as BAM, -s {size_flag} -> k = {kk}, hypo binary = host pipeline + device on ONE MI355X, "
+                            f"-p {' and -p '.join(str(x) for x in batchings)}; seconds = the binary's Overall timer of the faster run",
+                "fasta": "identical across contig-batch sizes; no reference md5 at this size (the same binary matches the real reference's md5 at 5 / 17 / 100 / 250 Mbp)"}
     except (subprocess.SubprocessError, OSError, ValueError) as ex:
         return {"error": str(ex)[:300]}
     finally:
@@ -197,6 +317,9 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-e2e-c3", action="store_true", help="skip the 100 Mbp end-to-end run (about a minute and 4 GB of scratch files)")
+    ap.add_argument("--no-e2e-k15", action="store_true", help="skip the 250 Mbp / k = 15 end-to-end run (BAM input, about half a minute)")
+    ap.add_argument("--t1-contigs", type=int, default=int(os.environ.get("HYPO_BENCH_T1_CONTIGS", "0")),
+                    help="also run row T1 end to end on this many 1 Mbp contigs (3000 = the north star's 3 Gbp; needs ~20 GB of /dev/shm and a few minutes)")
     ap.add_argument("--no-extras", action="store_true", help="skip value_at_0p5pct / value_at_1pct / value_dense / value_c4mix and host_api")
     args = ap.parse_args()
 
@@ -555,10 +678,16 @@ def main():
     # reference produced for these inputs (tests/golden/e2e_5m_s11.manifest.json).  Wall time = the run's own "Overall" timer, like the reference's.
     e2e = None
     e2e_c3 = None
+    e2e_k15 = None
+    e2e_t1 = None
     if rank == 0 and world == 1 and not args.no_e2e and not strong:
         e2e = end_to_end_leg()
         if not args.no_e2e_c3:
             e2e_c3 = end_to_end_c3_leg()
+        if not args.no_e2e_k15:
+            e2e_k15 = end_to_end_k15_leg()
+        if args.t1_contigs > 0:
+            e2e_t1 = end_to_end_t1_leg(args.t1_contigs)
 
     if strong and world > 1:                               # per-rank imbalance of the measured step
         tt = torch.tensor([my_dt], dtype=torch.float64, device=dev)
@@ -592,7 +721,7 @@ def main():
                        "contig_bases": total_bases, "k": k,
                        "parallelism": f"window sharding x{world}" + (" + RCCL all-gather of consensus" if world > 1 else "")},
             "mbp_per_s": round(total_bases * args.steps / dt / 1e6, 2),
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "e2e": e2e, "e2e_c3": e2e_c3,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "e2e": e2e, "e2e_c3": e2e_c3, "e2e_k15_250m": e2e_k15, "e2e_t1": e2e_t1,
         }
         if imbalance:
             out["imbalance"] = imbalance

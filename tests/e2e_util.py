@@ -138,18 +138,28 @@ def build_fast_generator():
     return FAST_GEN_BIN
 
 
-def run_fast_case(name, outdir, threads, extra_args=(), extra_env=None, timeout=1800):
+def run_fast_case(name, outdir, threads, extra_args=(), extra_env=None, timeout=1800, bam=False):
     """Generates the inputs of golden `name` with the C++ generator (checked against the manifest's checksums), runs the `hypo`
-    binary on them.  Returns (manifest, CompletedProcess, seconds of the run, peak RSS of the child in MB)."""
+    binary on them.  Returns (manifest, CompletedProcess, seconds of the run, peak RSS of the child in MB).  bam: the same records
+    as BAM (BGZF) instead of SAM text (the generator's --bam; the draft, the solid set and the number of records are checked against
+    the manifest, the records themselves through the FASTA they lead to)."""
     import resource
     import time
     man = json.load(open(os.path.join(GOLD, name + ".manifest.json")))
     a = man["args"]
     gen = build_fast_generator()
     rep = json.loads(subprocess.check_output([gen, str(outdir), str(a["seed"]), str(a["contigs"]), str(a["contig_len"]), str(a["k"]),
-                                              str(a["coverage"]), str(a["read_len"]), str(a["read_sub_ppm"])], text=True))
-    assert rep == man["generator_report"], f"{name}: the generator's output changed: {rep}"
+                                              str(a["coverage"]), str(a["read_len"]), str(a["read_sub_ppm"])] + (["--bam"] if bam else []), text=True))
+    want = man["generator_report"]
+    if bam:
+        assert "fnv_bam_blocks" in rep
+        for key in ("contigs", "draft_bases", "reads", "solid_kmers", "fnv_draft", "fnv_bitvector"):
+            assert rep[key] == want[key], f"{name}: the generator's output changed: {key} = {rep[key]}"
+    else:
+        assert rep == want, f"{name}: the generator's output changed: {rep}"
     argv = [BIN] + man["command"].split()[1:]
+    if bam:
+        argv[argv.index("-b") + 1] = "sr.bam"
     argv[argv.index("-t") + 1] = str(threads)
     argv += list(extra_args)
     env = dict(os.environ)
