@@ -534,9 +534,20 @@ void Hypo::parse_block(const SamReader& sf, const SamReader::RecordBlock& raw, P
             ReadChunk& ch = blk.chunks[(size_t)c];
             ch.clear();
             const size_t a = count * (size_t)c / (size_t)T, b = count * ((size_t)c + 1) / (size_t)T;
+            const bool bam = sf.is_bam();
             for (size_t i = a; i < b; ++i) {
-                sf.parse(raw.rec(i), raw.len(i), rec);
-                if ((rec.flag & (SAM_FUNMAP | SAM_FSECONDARY | SAM_FQCFAIL | SAM_FDUP)) || rec.mapq < mq) continue;
+                SamReader::BamCore bc;
+                const bool direct = bam && sf.bam_core(raw.rec(i), raw.len(i), bc);       // BAM: fixed fields in place, bases straight from 4 to 2 bits
+                if (direct) {
+                    if ((bc.flag & (SAM_FUNMAP | SAM_FSECONDARY | SAM_FQCFAIL | SAM_FDUP)) || bc.mapq < mq) continue;
+                    rec.tid = bc.tid; rec.pos = bc.pos; rec.flag = bc.flag; rec.mapq = bc.mapq;
+                    rec.cigar.resize(bc.n_cigar);
+                    if (bc.n_cigar) std::memcpy(rec.cigar.data(), bc.cigar, 4ull * bc.n_cigar);
+                    rec.qname.assign(bc.qname);
+                } else {
+                    sf.parse(raw.rec(i), raw.len(i), rec);
+                    if ((rec.flag & (SAM_FUNMAP | SAM_FSECONDARY | SAM_FQCFAIL | SAM_FDUP)) || rec.mapq < mq) continue;
+                }
                 if (rec.tid != tid_seen) {                 // (one look-up per run of records of a contig)
                     auto it = rec.tid < 0 ? _cname_to_id.end() : _cname_to_id.find(sf.tid2name(rec.tid));
                     tid_seen = rec.tid;
@@ -548,11 +559,11 @@ void Hypo::parse_block(const SamReader& sf, const SamReader::RecordBlock& raw, P
                 Alignment::span_of(*_contigs[(size_t)cid_seen], rec, rb, re, qab, qae);
                 const uint32_t qlen = qae - qab;
                 // Alignment.cpp:551-571: the aligned part 2-bit packed; a read with a non-ACGT base there is dropped
-                bool ok = (size_t)qab + qlen <= rec.seq.size();
+                bool ok = (size_t)qab + qlen <= (direct ? (size_t)bc.l_seq : rec.seq.size());
                 const size_t at = ch.seq.size();
                 if (ok) {
                     ch.seq.resize(at + (qlen + 3) / 4);
-                    ok = pack2_acgt(rec.seq.data() + qab, qlen, ch.seq.data() + at);
+                    ok = direct ? pack2_from_bam4(bc.seq4, qab, qlen, ch.seq.data() + at) : pack2_acgt(rec.seq.data() + qab, qlen, ch.seq.data() + at);
                     if (!ok) ch.seq.resize(at);
                 }
                 if (!ok) { blk.status[i] = ParsedBlock::ST_INVALID; continue; }

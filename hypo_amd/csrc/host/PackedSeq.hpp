@@ -44,6 +44,39 @@ inline bool pack2_acgt(const char* s, size_t n, uint8_t* dst) {
     return !(bad & 0x80u);
 }
 
+// the same from BAM's 4-bit codes (=ACMGRSVTWYHKDBN: A 1, C 2, G 4, T 8; two per byte, first base in the high nibble): bases
+// [first, first + n) of seq4 -> PackedSeq<2> bytes at dst; false when a code other than A, C, G, T is among them
+inline bool pack2_from_bam4(const uint8_t* seq4, size_t first, size_t n, uint8_t* dst) {
+    struct Lut { uint16_t v[256]; Lut() {
+        auto nib = [](unsigned c) -> unsigned { return c == 1 ? 0u : c == 2 ? 1u : c == 4 ? 2u : c == 8 ? 3u : 0x100u; };
+        for (unsigned b = 0; b < 256; ++b) { const unsigned h = nib(b >> 4), l = nib(b & 15); v[b] = (uint16_t)((((h & 3u) << 2) | (l & 3u)) | ((h | l) & 0x100u)); } } };
+    static const Lut lut;
+    auto code = [&](size_t i) -> unsigned { const unsigned c = (seq4[i >> 1] >> ((~i & 1) << 2)) & 15u; return c == 1 ? 0u : c == 2 ? 1u : c == 4 ? 2u : c == 8 ? 3u : 0x100u; };
+    unsigned bad = 0;
+    size_t i = 0;
+    uint8_t* d = dst;
+    if ((first & 1) == 0) {
+        const uint8_t* s = seq4 + (first >> 1);
+        for (; i + 4 <= n; i += 4, s += 2) {
+            const unsigned a = lut.v[s[0]], b = lut.v[s[1]];
+            bad |= a | b;
+            *d++ = (uint8_t)(((a & 15u) << 4) | (b & 15u));
+        }
+    } else {
+        for (; i + 4 <= n; i += 4) {
+            const unsigned a = code(first + i), b = code(first + i + 1), c = code(first + i + 2), e = code(first + i + 3);
+            bad |= a | b | c | e;
+            *d++ = (uint8_t)(((a & 3u) << 6) | ((b & 3u) << 4) | ((c & 3u) << 2) | (e & 3u));
+        }
+    }
+    if (i < n) {
+        unsigned byte = 0;
+        for (int sh = 6; i < n; ++i, sh -= 2) { const unsigned a = code(first + i); bad |= a; byte |= (a & 3u) << sh; }
+        *d = (uint8_t)byte;
+    }
+    return !(bad & 0x100u);
+}
+
 template <int NB>
 class PackedSeq {
     static_assert(NB == 2 || NB == 4, "2 or 4 bits per base");

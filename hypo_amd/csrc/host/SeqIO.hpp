@@ -131,6 +131,10 @@ public:
     size_t buffered_bytes() const { return _end - _pos; }
     void skip(size_t n) { _pos += n; }
     bool more() { return _pos < _end || (!_eof && refill()); }
+    // a mapped BGZF file: more inflated bytes BEHIND the unread ones (which move to the front of the other buffer); false at the
+    // end of the file.  Pointers into the buffer that was current before the call stay valid until the call after the next.
+    bool bgzf() const { return _cmap != nullptr; }
+    bool extend() { return _cmap && !_eof && fill_bgzf(); }
 private:
     // the next stretch of the (inflated) stream into _buf; false at the end of the file
     bool refill() {
@@ -167,8 +171,15 @@ private:
             total += isize;
             _cpos += bsize;
         }
-        if (blks.empty()) { _eof = true; _pos = _end = 0; return false; }
-        if (_buf.size() < total) _buf.resize(total);
+        if (blks.empty()) { _eof = true; return false; }          // (what is unread stays where it is)
+        // Two buffers take turns: the records a caller cut out of the previous one in place (SamReader::read_block, BAM) are
+        // still being parsed while this one fills; the unread tail of the previous buffer (a record that straddles the two
+        // runs of blocks) moves to the front of this one.
+        const size_t keep = _end - _pos;
+        std::vector<char>& nb = _bz[_bz_cur ^ 1];
+        if (nb.size() < keep + total) nb.resize(keep + total);
+        if (keep) std::memcpy(nb.data(), _src + _pos, keep);
+        char* const dst = nb.data() + keep;
         int bad = 0;
         const int nt = (int)std::min<size_t>((size_t)_inflate_threads, blks.size());
 #pragma omp parallel for schedule(dynamic, 4) num_threads(nt) reduction(| : bad)
@@ -177,13 +188,13 @@ private:
             z_stream zs; std::memset(&zs, 0, sizeof zs);
             if (inflateInit2(&zs, -15) != Z_OK) { bad |= 1; continue; }
             zs.next_in = (Bytef*)(_cmap + b.data); zs.avail_in = (uInt)b.clen;
-            zs.next_out = (Bytef*)(_buf.data() + b.out); zs.avail_out = b.isize;
+            zs.next_out = (Bytef*)(dst + b.out); zs.avail_out = b.isize;
             const int rc = inflate(&zs, Z_FINISH);
             if (rc != Z_STREAM_END || zs.total_out != b.isize) bad |= 1;
             inflateEnd(&zs);
             const unsigned char* t = _cmap + b.at + (b.data - b.at) + b.clen;
             const uint32_t want = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
-            if ((uint32_t)crc32(crc32(0L, nullptr, 0), (const Bytef*)(_buf.data() + b.out), b.isize) != want) bad |= 2;
+            if ((uint32_t)crc32(crc32(0L, nullptr, 0), (const Bytef*)(dst + b.out), b.isize) != want) bad |= 2;
         }
         if (bad) bgzf_fail(bad & 2 ? "CRC mismatch in a BGZF block" : "a BGZF block does not inflate");
         // compressed pages behind the read position are handed back (see consume())
@@ -193,7 +204,8 @@ private:
             (void)::madvise((void*)(_cmap + _creleased), upto - _creleased, MADV_DONTNEED);
             _creleased = upto;
         }
-        _src = _buf.data(); _pos = 0; _end = total;
+        _bz_cur ^= 1;
+        _src = nb.data(); _pos = 0; _end = keep + total;
         return true;
     }
     [[noreturn]] static void bgzf_fail(const char* what) { std::fprintf(stderr, "[Hypo::SeqIO] Error: %s\n", what); std::exit(1); }
@@ -202,6 +214,7 @@ private:
     int _inflate_threads = 8;
     gzFile _fp = nullptr;
     std::vector<char> _buf;
+    std::vector<char> _bz[2]; int _bz_cur = 0;          // BGZF: the inflated run of blocks in hand and the one before it
     const char* _map = nullptr; size_t _map_len = 0, _released = 0;
     const char* _src = nullptr;                        // the bytes being consumed: _buf or the mapping
     size_t _pos = 0, _end = 0;
@@ -281,11 +294,12 @@ public:
     struct RecordBlock {
         std::vector<char> buf;
         std::vector<uint64_t> off;
+        std::vector<uint32_t> lens;                  // BAM records cut out of the inflated buffer in place: their lengths (else from off)
         const char* base = nullptr;
         size_t n() const { return off.empty() ? 0 : off.size() - 1; }
         const char* rec(size_t i) const { return (base ? base : buf.data()) + off[i]; }
-        size_t len(size_t i) const { return (size_t)(off[i + 1] - off[i] - 1); }
-        void clear() { buf.clear(); off.clear(); base = nullptr; }
+        size_t len(size_t i) const { return lens.empty() ? (size_t)(off[i + 1] - off[i] - 1) : (size_t)lens[i]; }
+        void clear() { buf.clear(); off.clear(); lens.clear(); base = nullptr; }
     };
     // fills b with up to max_records records (or ~max_bytes); false once the end of the file has been reached
     bool read_block(RecordBlock& b, size_t max_records, size_t max_bytes = 32u << 20) {
@@ -307,6 +321,34 @@ public:
             }
             _lr.consume(at < avail ? at : avail);
             return at < avail;
+        }
+        if (_bam && _lr.bgzf()) {
+            // BAM out of a mapped BGZF file: the records stay where the blocks were inflated to (LineReader keeps the buffer alive
+            // while the next one fills); only their borders are located here — one hop over block_size per record, no copy (copying
+            // 280 bytes per record on this one thread was what bound the 3 Gbp run: 57 of its 75 s).  A block of records ends where the
+            // inflated buffer does; the record that straddles the end is completed by the next call.
+            if (!_bam_ok) return false;
+            for (;;) {
+                const char* const p0 = _lr.buffered();
+                const size_t avail = _lr.buffered_bytes();
+                size_t at = 0;
+                b.base = p0;
+                while (b.n() < max_records && at + 4 <= avail) {
+                    int32_t bs; std::memcpy(&bs, p0 + at, 4);
+                    if (bs < 32) { std::fprintf(stderr, "[Hypo::SamReader] Error: malformed BAM record\n"); std::exit(1); }
+                    if (at + 4 + (size_t)bs > avail) break;
+                    b.off.back() = at + 4;
+                    b.lens.push_back((uint32_t)bs);
+                    b.off.push_back(at + 4 + (size_t)bs);
+                    at += 4 + (size_t)bs;
+                }
+                _lr.skip(at);
+                if (b.n() > 0) return true;                          // (more may follow: the next call finds out)
+                if (!_lr.extend()) {
+                    if (_lr.buffered_bytes()) { std::fprintf(stderr, "[Hypo::SamReader] Error: truncated BAM record\n"); std::exit(1); }
+                    return false;
+                }
+            }
         }
         while (b.n() < max_records && b.buf.size() < max_bytes) {
             const size_t start = b.buf.size();
@@ -365,6 +407,27 @@ public:
             const char* p = (const char*)memmem(line + f[10] - 1, n - (f[10] - 1), "\tNM:i:", 6);
             if (p) { r.has_nm = true; r.nm = std::strtoll(p + 6, nullptr, 10); }
         }
+    }
+    // BAM only: the fixed fields of a raw record and where its CIGAR and 4-bit bases lie (Hypo::parse_block packs the bases straight
+    // into 2 bits: no SamRecord, no ASCII detour).  false: a long-CIGAR placeholder (the real operations are in the CG tag) — the
+    // caller takes parse() for that record.
+    bool is_bam() const { return _bam; }
+    struct BamCore { int32_t tid; uint32_t pos, mapq, flag, n_cigar, l_seq; const char* qname; const char* cigar; const uint8_t* seq4; };
+    bool bam_core(const char* p, size_t n, BamCore& c) const {
+        const int32_t ref = le32(p), l_seq = le32(p + 16);
+        const unsigned l_name = (unsigned char)p[8];
+        c.mapq = (unsigned char)p[9]; c.n_cigar = le16(p + 12); c.flag = le16(p + 14);
+        if (l_seq < 0 || 32 + (size_t)l_name + 4ull * c.n_cigar + ((size_t)l_seq + 1) / 2 + (size_t)l_seq > n) {
+            std::fprintf(stderr, "[Hypo::SamReader] Error: malformed BAM record\n"); std::exit(1);
+        }
+        c.tid = (ref >= 0 && (size_t)ref < _names.size()) ? ref : -1;
+        c.pos = (uint32_t)le32(p + 4); c.l_seq = (uint32_t)l_seq;
+        c.qname = p + 32; c.cigar = p + 32 + l_name; c.seq4 = (const uint8_t*)(c.cigar + 4ull * c.n_cigar);
+        if (c.n_cigar == 2) {
+            const uint32_t c0 = (uint32_t)le32(c.cigar), c1 = (uint32_t)le32(c.cigar + 4);
+            if ((c0 & 0xf) == 4 && (c0 >> 4) == c.l_seq && (c1 & 0xf) == 3) return false;
+        }
+        return true;
     }
     // read name of a raw record (for messages)
     std::string record_name(const char* line, size_t n) const {

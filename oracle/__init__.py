@@ -282,10 +282,22 @@ class RefArms:
         return (np.array(pos, dtype=np.uint32), np.array(coff, dtype=np.uint32), np.array(cig or [0], dtype=np.uint32),
                 np.array(soff, dtype=np.uint64), "".join(seq).encode())
 
-    def regions_dump(self, contig_seq: bytes, k: int, bvsd_path: str, records, work_dir: str) -> str:
-        """Runs the stage and returns the path of the reference's dump (aux/inspect_c.txt under work_dir)."""
+    def regions_dump(self, contig_seq: bytes, k: int, bvsd_path: str, records, work_dir: str, long_records=None) -> str:
+        """Runs the stage and returns the path of the reference's dump (aux/inspect_c.txt under work_dir).  long_records: the
+        long reads of a `-B` run (same layout): the LONG-read stage follows (prepare_long_windows, find_long_arms, fill_long_windows
+        with the real Filter); the caller guarantees none of them fails the reference's NM filter."""
         pos, coff, cig, soff, seq = records
         inv = C.c_uint64(0)
+        if long_records is not None:
+            self.lib.hyporef_arms_long.restype = C.c_long
+            lpos, lcoff, lcig, lsoff, lseq = long_records
+            rc = self.lib.hyporef_arms_long(contig_seq, C.c_uint64(len(contig_seq)), C.c_uint32(k), bvsd_path.encode(),
+                                            C.c_uint32(len(pos)), _ptr(pos), _ptr(coff), _ptr(cig), _ptr(soff), seq,
+                                            C.c_uint32(len(lpos)), _ptr(lpos), _ptr(lcoff), _ptr(lcig), _ptr(lsoff), lseq,
+                                            work_dir.encode(), C.byref(inv))
+            if rc < 0:
+                raise RuntimeError(f"hyporef_arms_long rc={rc}")
+            return os.path.join(work_dir, "aux", "inspect_c.txt")
         rc = self.lib.hyporef_arms(contig_seq, C.c_uint64(len(contig_seq)), C.c_uint32(k), bvsd_path.encode(),
                                    C.c_uint32(len(pos)), _ptr(pos), _ptr(coff), _ptr(cig), _ptr(soff), seq,
                                    work_dir.encode(), C.byref(inv))

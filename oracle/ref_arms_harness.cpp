@@ -43,6 +43,92 @@ uint8_t nt16(char c) {
 }
 }  // namespace
 
+namespace {
+// the records of one file as Alignment objects through the SHORT-read constructor (src/Alignment.cpp:39-46; the long-read one,
+// :48-63, differs by the NM-based filter only and needs htslib's bam_aux_get: the caller passes long reads that would all pass it)
+void make_alignments(hypo::Contig& c, uint32_t n_reads, const uint32_t* pos, const uint32_t* cigar_off, const uint32_t* cigar,
+                     const uint64_t* seq_off, const char* seq, std::vector<std::unique_ptr<hypo::Alignment>>& als, uint64_t& invalid) {
+    als.reserve(n_reads);
+    std::vector<uint8_t> data;
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        const uint32_t nc = cigar_off[r + 1] - cigar_off[r];
+        const uint32_t lq = (uint32_t)(seq_off[r + 1] - seq_off[r]);
+        const char* s = seq + seq_off[r];
+        bam1_t b;
+        std::memset(&b, 0, sizeof b);
+        b.core.pos = pos[r];
+        b.core.tid = 0;
+        b.core.qual = 60;
+        b.core.l_qname = 4;     // "r\0\0\0": sam.h pads the name to a multiple of four
+        b.core.l_extranul = 2;
+        b.core.n_cigar = nc;
+        b.core.l_qseq = (int32_t)lq;
+        b.core.mtid = -1;
+        b.core.mpos = -1;
+        data.assign(4 + 4ull * nc + (lq + 1) / 2 + lq, 0);
+        data[0] = 'r';
+        std::memcpy(data.data() + 4, cigar + cigar_off[r], 4ull * nc);
+        uint8_t* q = data.data() + 4 + 4ull * nc;
+        for (uint32_t i = 0; i < lq; ++i) q[i >> 1] |= (uint8_t)(nt16(s[i]) << ((~i & 1) << 2));
+        std::memset(q + (lq + 1) / 2, 30, lq);
+        b.data = data.data();
+        b.l_data = (int)data.size();
+        b.m_data = (uint32_t)data.size();
+        als.emplace_back(std::make_unique<hypo::Alignment>(c, &b));       // src/Hypo.cpp:309
+        if (!als.back()->is_valid) { als.pop_back(); ++invalid; }         // src/Hypo.cpp:314-318
+    }
+}
+}  // namespace
+
+extern "C" __attribute__((visibility("default")))
+// The same stage followed by the LONG-read stage of a `-B` run (src/Hypo.cpp:203-229): Contig::prepare_long_windows,
+// Alignment::find_long_arms (src/Alignment.cpp:262-299), Contig::fill_long_windows (include/Contig.hpp:91-113) with the real
+// Window::add_* and their Filter (include/Window.hpp:66-103, include/Filter.hpp).  Long reads as the short ones (l*): the records
+// the reference would keep (flag / mapping-quality filter AND its NM filter, which the caller guarantees nothing fails).
+long hyporef_arms_long(const char* contig, uint64_t n, uint32_t k, const char* bvsd_path, uint32_t n_reads, const uint32_t* pos,
+                       const uint32_t* cigar_off, const uint32_t* cigar, const uint64_t* seq_off, const char* seq,
+                       uint32_t ln_reads, const uint32_t* lpos, const uint32_t* lcigar_off, const uint32_t* lcigar, const uint64_t* lseq_off, const char* lseq,
+                       const char* work_dir, uint64_t* n_invalid) {
+    auto sk = std::make_unique<suk::SolidKmers>(k);
+    if (!sk->load(std::string(bvsd_path))) return -1;
+    hypo::Contig c(0, "c", std::string(contig, (size_t)n));
+    c.find_solid_pos(sk);
+    uint64_t invalid = 0;
+    {
+        std::vector<std::unique_ptr<hypo::Alignment>> als;
+        make_alignments(c, n_reads, pos, cigar_off, cigar, seq_off, seq, als, invalid);
+        #pragma omp parallel for
+        for (uint64_t t = 0; t < als.size(); ++t) als[t]->update_solidkmers_support(k, c);
+        c.prepare_for_division(k);
+        #pragma omp parallel for
+        for (uint64_t t = 0; t < als.size(); ++t) als[t]->update_minimisers_support(c);
+        c.divide_into_regions();
+        #pragma omp parallel for
+        for (uint64_t t = 0; t < als.size(); ++t) als[t]->find_short_arms(k, c);
+        c.fill_short_windows(als);
+    }
+    {
+        std::vector<std::unique_ptr<hypo::Alignment>> lals;
+        make_alignments(c, ln_reads, lpos, lcigar_off, lcigar, lseq_off, lseq, lals, invalid);
+        c.prepare_long_windows();                                          // src/Hypo.cpp:212
+        #pragma omp parallel for
+        for (uint64_t t = 0; t < lals.size(); ++t) lals[t]->find_long_arms(c);   // :217
+        c.fill_long_windows(lals);                                         // :222
+    }
+    if (n_invalid) *n_invalid = invalid;
+    char cwd[4096];
+    if (!getcwd(cwd, sizeof cwd) || chdir(work_dir) != 0) return -2;
+    mkdir("aux", 0777);
+    long rc = (long)c.get_num_regions();
+    {
+        std::ofstream bed(BEDFILE);
+        if (!bed.is_open()) rc = -2;
+        else c.generate_inspect_file(bed);
+    }
+    if (chdir(cwd) != 0) return -2;
+    return rc;
+}
+
 extern "C" __attribute__((visibility("default")))
 // contig: n ASCII bases.  bvsd_path: the solid k-mer bit vector (as hyporef_solid_scan).  Reads: the primary mapped records
 // of one contig in file order — pos (0-based leftmost reference position), BAM-encoded CIGAR operations cigar[cigar_off[r] ..

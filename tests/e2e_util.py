@@ -197,7 +197,24 @@ def _reference_dump_regions(path):
     return m.regions(path)
 
 
-def run_vs_reference_stage(outdir, seed, device, messy, threads=4):
+def long_reads_pass_nm_filter(sam_path, ned_th=20):
+    """True when no record of the long-read file would be dropped by the reference's NM filter (src/Alignment.cpp:51-58: NM * 100 /
+    reference span > -n): the in-place harness builds long reads through the short-read constructor, which has no such filter."""
+    import re
+    for line in open(sam_path):
+        if line.startswith("@"):
+            continue
+        f = line.rstrip("\n").split("\t")
+        if int(f[1]) & (4 | 256 | 512 | 1024):
+            continue
+        span = sum(int(n) for n, op in re.findall(r"(\d+)([MIDNSHP=X])", f[5]) if op in "MDN=X")
+        m = re.search(r"\tNM:i:(-?\d+)", line)
+        if m and span and int(m.group(1)) * 100 // span > ned_th:
+            return False
+    return True
+
+
+def run_vs_reference_stage(outdir, seed, device, messy, threads=4, long_reads=False):
     """One single-contig short-read set made NOW (no committed golden behind it): this repo's `hypo` (region dump) against the
     real Alignment / Contig / Window code of the reference run on the same records (oracle.RefArms): region borders and types
     (A14, through the support votes N1), arm counts and crc32 of the arms of every window (A13 / N2).  Returns the number of
@@ -205,14 +222,20 @@ def run_vs_reference_stage(outdir, seed, device, messy, threads=4):
     import oracle
     os.makedirs(str(outdir), exist_ok=True)
     gen = _gen()
+    with_long = False
     if messy:
         args, nc, with_long = gen.generate_messy(str(outdir), seed)
-        if nc != 1 or with_long:
+        if nc != 1 or with_long != long_reads:
             return None
     else:
         k = [7, 9, 11][seed % 3]
-        gen.generate(str(outdir), seed, [8000, 20000, 40000][seed % 3], False, k)
-        args = ["-d", "draft.fa", "-r", "reads.fa", "-s", {7: "10k", 9: "100k", 11: "1m"}[k], "-c", "30", "-b", "sr.sam", "-t", "1", "-i"]
+        gen.generate(str(outdir), seed, [8000, 20000, 40000][seed % 3], long_reads, k)
+        with_long = long_reads
+        args = ["-d", "draft.fa", "-r", "reads.fa", "-s", {7: "10k", 9: "100k", 11: "1m"}[k], "-c", "30", "-b", "sr.sam"] + (["-B", "lr.sam"] if long_reads else []) + ["-t", "1", "-i"]
+    if with_long:
+        ned = int(args[args.index("-n") + 1]) if "-n" in args else 20
+        if not long_reads_pass_nm_filter(os.path.join(str(outdir), "lr.sam"), ned):
+            return None
     k = {"10k": 7, "100k": 9, "1m": 11}[args[args.index("-s") + 1]]
     mq = int(args[args.index("-q") + 1]) if "-q" in args else 2
     argv = [BIN] + args
@@ -226,17 +249,22 @@ def run_vs_reference_stage(outdir, seed, device, messy, threads=4):
     assert ("oracle_device_shim" in p.stderr) == (device == "shim"), "wrong device library behind the C-ABI"
     if device != "shim":
         assert "short arms cut on the device" in p.stdout or "not sorted" in p.stdout     # unsorted records: the host loops
+        if with_long:
+            assert "long arms cut on the device" in p.stdout or "not sorted" in p.stdout
     fa = open(os.path.join(str(outdir), "draft.fa")).read().split("\n")
     name, draft = fa[0][1:].split()[0], "".join(fa[1:])
     ref = oracle.RefArms()
     recs = ref.sam_records(os.path.join(str(outdir), "sr.sam"), name, mq)
     work = os.path.join(str(outdir), "refstage")
     os.makedirs(work, exist_ok=True)
-    dump = ref.regions_dump(draft.encode(), k, os.path.join(str(outdir), "aux", "solid_kmers.bvsd"), recs, work)
+    lrecs = ref.sam_records(os.path.join(str(outdir), "lr.sam"), name, mq) if with_long else None
+    dump = ref.regions_dump(draft.encode(), k, os.path.join(str(outdir), "aux", "solid_kmers.bvsd"), recs, work, long_records=lrecs)
     regions = _reference_dump_regions(dump)
     rows = [l.rstrip("\n").split("\t") for l in open(os.path.join(str(outdir), "regions.tsv"))]
     assert len(rows) == len(regions), f"seed {seed}: {len(rows)} regions, reference stage has {len(regions)}"
     n = 0
+    global LAST_LONG_WINDOWS
+    LAST_LONG_WINDOWS = 0
     for r, g in zip(rows, regions):
         beg, end, typ = int(r[1]), int(r[2]) - 1, r[3]
         assert [beg, end, typ] == g[:3], f"seed {seed}: region {r[:4]} vs reference {g[:3]}"
@@ -244,4 +272,8 @@ def run_vs_reference_stage(outdir, seed, device, messy, threads=4):
             assert [int(x) for x in r[4:8]] == g[3:7], f"seed {seed}: arms of window {beg}-{end}: {r[4:8]} vs reference {g[3:7]}"
             assert int(r[8]) == g[7], f"seed {seed}: arm bytes of window {beg}-{end} differ"
             n += 1
+            LAST_LONG_WINDOWS += typ == "LNG"
     return n
+
+
+LAST_LONG_WINDOWS = 0          # LONG windows among those the last run_vs_reference_stage call compared

@@ -105,3 +105,32 @@ def test_host_stage_vs_real_alignment_and_contig_code(tmp_path):
             total += n
             done += 1
     assert done >= 4 and total > 500, (done, total)
+
+
+def test_host_long_read_stage_vs_real_filter_and_alignment_code(tmp_path):
+    """`-B` sets generated now: long-read arm selection (Alignment::find_long_arms, src/Alignment.cpp:262-299) and the minimizer
+    filter of LONG windows (include/Filter.hpp through the real Window::add_*) of this repo's host mirror (over the CPU shim)
+    against the reference's own code compiled in place (hyporef_arms_long in oracle/_ref/libhyporef_arms.so): region borders and
+    types incl. the LONG windows, arm counts and crc32(arms) of every window.  The in-place build has no htslib, so its long reads
+    go through the short-read constructor: only sets none of whose long reads fails the reference's NM filter take part."""
+    import pytest
+    import oracle
+    import e2e_util
+    if not oracle.RefArms.available():
+        pytest.skip("oracle/_ref/libhyporef_arms.so not built (the real reference only exists in the build container)")
+    e2e_util.build_binary()
+    e2e_util.build_shim()
+    total, done, n_long = 0, 0, 0
+    for seed in (311, 312, 313):
+        n = e2e_util.run_vs_reference_stage(tmp_path / f"c{seed}", seed, "shim", messy=False, long_reads=True)
+        assert n is not None
+        total += n
+        n_long += e2e_util.LAST_LONG_WINDOWS
+        done += 1
+    for seed in range(400, 440):
+        n = e2e_util.run_vs_reference_stage(tmp_path / f"m{seed}", seed, "shim", messy=True, long_reads=True)
+        if n is not None:
+            total += n
+            n_long += e2e_util.LAST_LONG_WINDOWS
+            done += 1
+    assert done >= 4 and total > 300 and n_long >= 10, (done, total, n_long)
