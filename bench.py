@@ -257,7 +257,7 @@ def end_to_end_t1_leg(n_contigs, contig_len=1_000_000, batchings=(10, 50)):
         tg = time.perf_counter()
         rep = json.loads(subprocess.check_output([gen, d, "97", str(n_contigs), str(contig_len), str(kk), "30", "150", "2000", "--bam", "--fast-hash"], text=True))
         tg = time.perf_counter() - tg
-        threads = min(64, os.cpu_count() or 1)
+        threads = min(128, max(1, (os.cpu_count() or 2) // 2))
         runs, md5s = [], []
         for pb in batchings:
             outp = f"out_p{pb}.fa"

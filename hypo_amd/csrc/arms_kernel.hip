@@ -336,6 +336,23 @@ __global__ void __launch_bounds__(T) arms_window_kernel(ArmsIn I, const uint32_t
             if (kind != A_INTERNAL && !keep_ps) continue;
             uint64_t& ai = kind == A_INTERNAL ? arm_i : (kind == A_PREFIX ? arm_p : arm_s);
             uint64_t& bo = kind == A_INTERNAL ? byte_i : (kind == A_PREFIX ? byte_p : byte_s);
+            if (I.file_rank) {
+                // records of an unsorted file, sorted by position on ingest: the arm's place in its group is the number of the
+                // window's arms of that kind that come EARLIER IN THE FILE (a few dozen candidates per window: counted, not sorted)
+                const uint32_t my = I.file_rank[a];
+                uint64_t before = 0, bytes_before = 0;
+                for (uint32_t a2 = a_lo; a2 < a_hi; ++a2) {
+                    const uint32_t nt2 = ntouch[a2], b2 = b_ind[a2];
+                    if (a2 == a || nt2 == 0 || w < b2 || w >= b2 + nt2 || I.file_rank[a2] >= my) continue;
+                    const uint2 c2 = cand[touch_off[a2] + (w - b2)];
+                    if ((c2.y >> 28) != kind) continue;
+                    ++before; bytes_before += (((c2.y & 0x0fffffffu) - c2.x) + 3) >> 2;
+                }
+                const HypoWindow* hw = O.windows + O.win_index[w];
+                const uint64_t g0 = kind == A_INTERNAL ? hw->first_arm : (kind == A_PREFIX ? (uint64_t)hw->first_arm + hw->n_internal : (uint64_t)hw->first_arm + hw->n_internal + hw->n_prefix);
+                const uint64_t y0 = kind == A_INTERNAL ? O.reg_byte_off[w] : (kind == A_PREFIX ? O.reg_byte_off[w] + O.reg_bytes_int[w] : O.reg_byte_off[w] + O.reg_bytes_int[w] + O.reg_bytes_pre[w]);
+                ai = g0 + before; bo = y0 + bytes_before;
+            }
             O.arm_len[ai] = len;
             O.arm_off[ai] = bo;
             // PackedSeq<2>(ps, left, right): bases qb.. repacked from bit 7 of a fresh byte (src/PackedSeq.cpp:91-139)

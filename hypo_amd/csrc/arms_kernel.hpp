@@ -25,6 +25,7 @@ struct ArmsIn {
     const uint8_t* reads2;
     const uint32_t* cigar_off;      // [n_alignments + 1]
     const uint32_t* cigar;          // BAM encoding: len << 4 | op
+    const uint32_t* file_rank;      // NULL, or the alignments' positions in the file when that is not the order they are given in
     uint32_t max_span;              // max(re - rb)
     uint32_t long_mode;             // 1: long reads over pseudo regions -> LONG windows (no anchors; Filter::is_good decides what stays)
 };

@@ -73,7 +73,7 @@ struct Ctx {
         uint32_t n = 0; uint64_t n_cig = 0, reads2_bytes = 0; uint32_t max_span = 0; uint64_t sum_span = 0;
         uint64_t total_len = 0;                            // the coordinate space the reads were checked against
         std::vector<uint32_t> ctg_min_rb, ctg_max_re;      // per contig index of read_contig: what its reads span (later calls check their tables against it)
-        const uint32_t *rb = nullptr, *re = nullptr, *qae = nullptr, *cigar_off = nullptr, *cigar = nullptr, *read_contig = nullptr;
+        const uint32_t *rb = nullptr, *re = nullptr, *qae = nullptr, *cigar_off = nullptr, *cigar = nullptr, *read_contig = nullptr, *file_rank = nullptr;
         const uint64_t* seq_off = nullptr; const uint8_t* reads2 = nullptr;
     } rr;
     DevBuf solid_set; uint32_t solid_k = 0;            // hypo_gpu_solid_set_upload
@@ -863,15 +863,18 @@ int hypo_gpu_reads_upload(const HypoArmsReads* A, const uint32_t* read_contig, u
     const uint64_t n_cig = na ? A->cigar_off[na] : 0;
     Carver c;
     const size_t o_rb = c.take((size_t)na * 4), o_re = c.take((size_t)na * 4), o_qae = c.take((size_t)na * 4), o_soff = c.take((size_t)na * 8),
-                 o_reads = c.take(A->reads2_bytes), o_coff = c.take((size_t)(na + 1) * 4), o_cig = c.take(n_cig * 4), o_ctg = c.take((size_t)na * 4);
+                 o_reads = c.take(A->reads2_bytes), o_coff = c.take((size_t)(na + 1) * 4), o_cig = c.take(n_cig * 4), o_ctg = c.take((size_t)na * 4),
+                 o_rank = c.take(A->file_rank ? (size_t)na * 4 : 0);
     HIP_TRY(rr.data.alloc(c.at ? c.at : 256));
     char* d = (char*)rr.data.p;
     hipStream_t st = g_ctx.stream;
 #define UP(off, src, bytes) do { if (bytes) HIP_TRY(hipMemcpyAsync(d + (off), (src), (bytes), hipMemcpyHostToDevice, st)); } while (0)
     UP(o_rb, A->rb, (size_t)na * 4); UP(o_re, A->re, (size_t)na * 4); UP(o_qae, A->qae, (size_t)na * 4); UP(o_soff, A->seq_off, (size_t)na * 8);
     UP(o_reads, A->reads2, A->reads2_bytes); if (na) UP(o_coff, A->cigar_off, (size_t)(na + 1) * 4); UP(o_cig, A->cigar, n_cig * 4); UP(o_ctg, read_contig, (size_t)na * 4);
+    if (A->file_rank) UP(o_rank, A->file_rank, (size_t)na * 4);
 #undef UP
     HIP_TRY(hipStreamSynchronize(st));                          // the caller may release its arrays
+    rr.file_rank = A->file_rank ? (const uint32_t*)(d + o_rank) : nullptr;
     rr.n = na; rr.n_cig = n_cig; rr.reads2_bytes = A->reads2_bytes; rr.max_span = max_span; rr.sum_span = sum_span;
     rr.rb = (const uint32_t*)(d + o_rb); rr.re = (const uint32_t*)(d + o_re); rr.qae = (const uint32_t*)(d + o_qae); rr.seq_off = (const uint64_t*)(d + o_soff);
     rr.reads2 = (const uint8_t*)(d + o_reads); rr.cigar_off = (const uint32_t*)(d + o_coff); rr.cigar = (const uint32_t*)(d + o_cig); rr.read_contig = (const uint32_t*)(d + o_ctg);
@@ -1067,7 +1070,7 @@ static int arms_build_impl(int which, const HypoArmsRegions* R, const HypoArmsRe
     const size_t o_start = ci.take((size_t)(nr + 1) * 4), o_type = ci.take(nr + 1), o_info = ci.take((size_t)(nr + 1) * 4),
                  o_anchor = ci.take(R->n_anchor_kmers * 8), o_contig = ci.take((total_len + 1) / 2), o_rb = ci.take(resident ? 0 : (size_t)na * 4), o_re = ci.take(resident ? 0 : (size_t)na * 4),
                  o_qae = ci.take(resident ? 0 : (size_t)na * 4), o_soff = ci.take(resident ? 0 : (size_t)na * 8), o_reads = ci.take(resident ? 0 : A->reads2_bytes), o_coff = ci.take(resident ? 0 : (size_t)(na + 1) * 4),
-                 o_cig = ci.take(resident ? 0 : n_cig * 4);
+                 o_cig = ci.take(resident ? 0 : n_cig * 4), o_frank = ci.take((resident || !A->file_rank) ? 0 : (size_t)na * 4);
     HIP_TRY(dIn.alloc(ci.at));
     char* in = (char*)dIn.p;
 #define UP(off, src, bytes) do { if (bytes) HIP_TRY(hipMemcpyAsync(in + (off), (src), (bytes), hipMemcpyHostToDevice, st)); } while (0)
@@ -1076,6 +1079,7 @@ static int arms_build_impl(int which, const HypoArmsRegions* R, const HypoArmsRe
     if (!resident) {
         UP(o_rb, A->rb, (size_t)na * 4); UP(o_re, A->re, (size_t)na * 4); UP(o_qae, A->qae, (size_t)na * 4); UP(o_soff, A->seq_off, (size_t)na * 8);
         UP(o_reads, A->reads2, A->reads2_bytes); if (na) UP(o_coff, A->cigar_off, (size_t)(na + 1) * 4); UP(o_cig, A->cigar, n_cig * 4);
+        if (A->file_rank) UP(o_frank, A->file_rank, (size_t)na * 4);
     }
 #undef UP
     hypo::ArmsIn I;
@@ -1084,8 +1088,10 @@ static int arms_build_impl(int which, const HypoArmsRegions* R, const HypoArmsRe
     I.n_alignments = na; I.rb = (const uint32_t*)(in + o_rb); I.re = (const uint32_t*)(in + o_re); I.qae = (const uint32_t*)(in + o_qae);
     I.seq_off = (const uint64_t*)(in + o_soff); I.reads2 = (const uint8_t*)(in + o_reads); I.cigar_off = (const uint32_t*)(in + o_coff);
     I.cigar = (const uint32_t*)(in + o_cig); I.max_span = max_span; I.long_mode = long_mode ? 1u : 0u;
+    I.file_rank = (!resident && A->file_rank) ? (const uint32_t*)(in + o_frank) : nullptr;
     if (resident) {
         const auto& rr = g_ctx.rr;
+        I.file_rank = rr.file_rank;
         I.rb = rr.rb; I.re = rr.re; I.qae = rr.qae; I.seq_off = rr.seq_off; I.reads2 = rr.reads2; I.cigar_off = rr.cigar_off; I.cigar = rr.cigar;
     }
     // work arrays that do not depend on the number of touched regions

@@ -32,8 +32,9 @@ bool DeviceArms::upload_reads(std::vector<std::unique_ptr<Contig>>& contigs, uin
         std::fprintf(stdout, "[Hypo::Hypo] Info: no page-locked staging memory for %llu alignments: support votes and short arms are computed on the host\n", (unsigned long long)n_aln);
         return false;
     }
-    if (!sorted) { std::fprintf(stdout, "[Hypo::Hypo] Info: alignments are not sorted by position: support votes and short arms are computed on the host\n"); return false; }
+    if (!sorted) std::fprintf(stdout, "[Hypo::Hypo] Info: alignments are not sorted by position: sorted on ingest, the arms of a window keep their file order\n");
     HypoArmsReads A;
+    A.file_rank = _stage.ranked ? _stage.file_rank : nullptr;
     A.n_alignments = (uint32_t)_stage.n_reads; A.rb = _stage.rb; A.re = _stage.re; A.qae = _stage.qae; A.seq_off = _stage.seq_off;
     A.reads2 = _stage.reads2; A.reads2_bytes = _stage.n_bytes; A.cigar_off = _stage.cigar_off; A.cigar = _stage.cigar;
     const auto tu2 = std::chrono::steady_clock::now();
@@ -344,6 +345,7 @@ bool DeviceArms::build_long(std::vector<std::unique_ptr<Contig>>& contigs, uint3
     R.n_regions = (uint32_t)n_reg; R.start = start.data(); R.type = type.data(); R.info = nullptr;
     R.n_anchor_kmers = 0; R.anchor_kmers = nullptr; R.k = 10; R.contig4 = contig4.data();
     HypoArmsReads A;
+    A.file_rank = nullptr;
     A.n_alignments = (uint32_t)n_aln; A.rb = rb.data(); A.re = re.data(); A.qae = qae.data(); A.seq_off = seq_off.data();
     A.reads2 = reads2.get(); A.reads2_bytes = read_bytes; A.cigar_off = cigar_off.data(); A.cigar = cigar.get();
     std::vector<uint8_t> valid(n_reg, 0);

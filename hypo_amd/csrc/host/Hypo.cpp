@@ -71,7 +71,7 @@ void Hypo::polish() {
     if (_contig_batch_size && _contigs.size() % _contig_batch_size != 0) ++num_batches;
     _sf_short.reset(new SamReader(_cFlags.sr_bam_filename));
     if (!_sf_short->ok()) { std::fprintf(stderr, "[Hypo::Hypo] Error: File open error: %s\n", _cFlags.sr_bam_filename.c_str()); std::exit(1); }
-    _sf_short->set_inflate_threads(std::max(1, std::min((int)_cFlags.threads, 32)));
+    _sf_short->set_inflate_threads(std::max(1, (int)_cFlags.threads));      // (BGZF: inflate is what bounds a BAM run — 280 bytes per 150-bp record)
     // the short reads of the first batch are parsed while the contigs are scanned (the parser needs the contigs' names and lengths only)
     std::thread prefetch;
     ReadBatch staged;                                      // the next batch's short reads while the helper parses them
@@ -586,7 +586,7 @@ void Hypo::create_alignments_flat(uint32_t batch_id, ReadBatch& into) {
     RecordStream& rs = _rs_short;
     const uint32_t final_cid = batch_id * _contig_batch_size + _contig_batch_size;
     uint64_t num_invalid = 0, num_alns = 0;
-    constexpr size_t kBlock = 1 << 17;
+    constexpr size_t kBlock = 1 << 19, kBlockBytes = (size_t)128 << 20;     // (a block of records = about one run of inflated BGZF blocks, SeqIO.hpp)
     if (rs.carry_blk) { into.add(rs.carry_blk, rs.carry_r0, rs.carry_r1); rs.carry_blk.reset(); }
     bool stop = false, more_ahead = true;
     double t_wait = 0, t_par = 0, t_col = 0; auto now = []{ return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -595,10 +595,10 @@ void Hypo::create_alignments_flat(uint32_t batch_id, ReadBatch& into) {
         const double t0 = now();
         if (!rs.parsed || rs.ppos >= rs.parsed->n) {
             if (rs.have_ahead) { std::swap(rs.cur, rs.ahead); rs.have_ahead = false; }
-            else if (rs.more) rs.more = sf.read_block(rs.cur, kBlock);
+            else if (rs.more) rs.more = sf.read_block(rs.cur, kBlock, kBlockBytes);
             else break;
             if (rs.cur.n() == 0) { if (!rs.more) break; continue; }
-            if (rs.more && !rs.have_ahead) reader = std::thread([&] { more_ahead = sf.read_block(rs.ahead, kBlock); });
+            if (rs.more && !rs.have_ahead) reader = std::thread([&] { more_ahead = sf.read_block(rs.ahead, kBlock, kBlockBytes); });
             std::shared_ptr<ParsedBlock> blk;
             {
                 std::lock_guard<std::mutex> lk(_pool_mu);

@@ -29,7 +29,7 @@ bool ReadStaging::reserve(size_t reads, size_t cig, size_t bytes) {
         const size_t want = reads + reads / 8 + 1024;
         size_t dummy = 0;
         if (!grow(rb, dummy, want, 1) || !grow(re, dummy, want, 1) || !grow(qae, dummy, want, 1) || !grow(ctg, dummy, want, 1) ||
-            !grow(cigar_off, dummy, want, 2) || !grow(seq_off, dummy, want, 2)) return false;
+            !grow(cigar_off, dummy, want, 2) || !grow(seq_off, dummy, want, 2) || !grow(file_rank, dummy, want, 1)) return false;
         cap_reads = want;
     }
     if (cig > cap_cigar || !cigar) { const size_t want = cig + cig / 8 + 1024; size_t d = 0; if (!grow(cigar, d, want, 1)) return false; cap_cigar = want; }
@@ -37,8 +37,8 @@ bool ReadStaging::reserve(size_t reads, size_t cig, size_t bytes) {
     return true;
 }
 void ReadStaging::release() {
-    for (void* p : {(void*)rb, (void*)re, (void*)qae, (void*)ctg, (void*)cigar_off, (void*)cigar, (void*)seq_off, (void*)reads2}) if (p) (void)hypo_gpu_host_free(p);
-    rb = re = qae = ctg = cigar_off = cigar = nullptr; seq_off = nullptr; reads2 = nullptr;
+    for (void* p : {(void*)rb, (void*)re, (void*)qae, (void*)ctg, (void*)cigar_off, (void*)cigar, (void*)seq_off, (void*)reads2, (void*)file_rank}) if (p) (void)hypo_gpu_host_free(p);
+    rb = re = qae = ctg = cigar_off = cigar = file_rank = nullptr; seq_off = nullptr; reads2 = nullptr;
     cap_reads = cap_cigar = cap_bytes = 0;
 }
 
@@ -158,6 +158,32 @@ bool ReadBatch::flatten(uint32_t c0, uint32_t c1, const std::vector<uint64_t>& b
     for (int64_t g = 1; g < (int64_t)n; ++g)
         if (out.ctg[g] == out.ctg[g - 1] && out.rb[g - 1] > out.rb[g]) ok = false;
     sorted = ok;
+    out.ranked = false;
+    if (!ok) {
+        // An unsorted file (the reference takes any order, src/Hypo.cpp:278-329): the device's kernels find a window's reads by
+        // binary search over the start positions, so the records are sorted here — stably, by position in the coordinate space —
+        // and carry their places in the file along: the arms of a window are laid out in FILE order (arms_window_kernel).
+        std::vector<uint32_t> perm(n);
+        for (uint64_t g = 0; g < n; ++g) perm[g] = (uint32_t)g;
+        std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return out.rb[a] < out.rb[b]; });
+        std::vector<uint32_t> t_rb(n), t_re(n), t_qae(n), t_ctg(n), t_coff(n + 1), t_cig(ncg ? ncg : 1);
+        std::vector<uint64_t> t_soff(n);
+        uint32_t acc = 0;
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint32_t g = perm[i];
+            t_rb[i] = out.rb[g]; t_re[i] = out.re[g]; t_qae[i] = out.qae[g]; t_ctg[i] = out.ctg[g]; t_soff[i] = out.seq_off[g];
+            const uint32_t c0g = out.cigar_off[g], c1g = out.cigar_off[g + 1];
+            t_coff[i] = acc;
+            std::memcpy(t_cig.data() + acc, out.cigar + c0g, (size_t)(c1g - c0g) * 4);
+            acc += c1g - c0g;
+        }
+        t_coff[n] = acc;
+        std::memcpy(out.rb, t_rb.data(), n * 4); std::memcpy(out.re, t_re.data(), n * 4); std::memcpy(out.qae, t_qae.data(), n * 4);
+        std::memcpy(out.ctg, t_ctg.data(), n * 4); std::memcpy(out.seq_off, t_soff.data(), n * 8);
+        std::memcpy(out.cigar_off, t_coff.data(), (n + 1) * 4); std::memcpy(out.cigar, t_cig.data(), (size_t)acc * 4);
+        std::memcpy(out.file_rank, perm.data(), n * 4);
+        out.ranked = true;
+    }
     return true;
 }
 

@@ -46,6 +46,7 @@ struct ParsedBlock {
 struct ReadStaging {
     uint32_t *rb = nullptr, *re = nullptr, *qae = nullptr, *ctg = nullptr, *cigar_off = nullptr, *cigar = nullptr;
     uint64_t* seq_off = nullptr; uint8_t* reads2 = nullptr;
+    uint32_t* file_rank = nullptr; bool ranked = false;      // ranked: the records were NOT sorted in the file; they are here, and file_rank says where each one was
     size_t cap_reads = 0, cap_cigar = 0, cap_bytes = 0;
     uint64_t n_reads = 0, n_cigar = 0, n_bytes = 0;
     bool reserve(size_t reads, size_t cig, size_t bytes);          // false: no memory
@@ -66,7 +67,8 @@ public:
     uint64_t count(uint32_t cid) const { return cid < _per_contig.size() ? _per_contig[cid] : 0; }
     bool empty() const { return _slices.empty(); }
     // The records of contigs [c0, c1) in `out`: contig after contig (contig c starts at base[c - c0] of the coordinate space), each
-    // contig's records in file order.  `sorted` = every contig's records come with non-decreasing rb.  false: no memory.
+    // contig's records in file order.  `sorted` = every contig's records came with non-decreasing rb; when they did not they are
+    // sorted by rb here (stably) and out.file_rank holds their places in the file (out.ranked).  false: no memory.
     bool flatten(uint32_t c0, uint32_t c1, const std::vector<uint64_t>& base, ReadStaging& out, bool& sorted) const;
     // Alignment objects for contig cid (the reference's store entry), appended to `into`
     void materialize(uint32_t cid, std::vector<std::unique_ptr<Alignment>>& into) const;

@@ -46,7 +46,7 @@ public:
     }
     ~LineReader() { if (_fp) gzclose(_fp); if (_map) ::munmap((void*)_map, _map_len); if (_cmap) ::munmap((void*)_cmap, _cmap_len); }
     // threads that inflate BGZF blocks side by side (a reader thread calls the read functions; its team is its own)
-    void set_inflate_threads(int n) { _inflate_threads = n < 1 ? 1 : n; }
+    void set_inflate_threads(int n) { _inflate_threads = n < 1 ? 1 : n; _bgzf_run = std::max<size_t>((size_t)32 << 20, (size_t)_inflate_threads << 21); }
     LineReader(const LineReader&) = delete;
     LineReader& operator=(const LineReader&) = delete;
     bool ok() const { return _fp != nullptr || _map != nullptr || _cmap != nullptr; }
@@ -153,7 +153,7 @@ private:
         struct Blk { size_t at, data, clen, out; uint32_t isize; };
         std::vector<Blk> blks;
         size_t total = 0;
-        while (_cpos + 28 <= _cmap_len && total < ((size_t)32 << 20)) {
+        while (_cpos + 28 <= _cmap_len && total < _bgzf_run) {
             const unsigned char* h = _cmap + _cpos;
             if (!(h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4))) bgzf_fail("not a BGZF block header");
             const size_t xlen = h[10] | ((size_t)h[11] << 8);
@@ -212,6 +212,7 @@ private:
     static constexpr size_t kBuf = 4u << 20;
     const unsigned char* _cmap = nullptr; size_t _cmap_len = 0, _cpos = 0, _creleased = 0;     // a mapped BGZF file and the next block
     int _inflate_threads = 8;
+    size_t _bgzf_run = (size_t)32 << 20;               // inflated bytes per fill_bgzf call: a few blocks per inflating thread
     gzFile _fp = nullptr;
     std::vector<char> _buf;
     std::vector<char> _bz[2]; int _bz_cur = 0;          // BGZF: the inflated run of blocks in hand and the one before it

@@ -268,6 +268,11 @@ typedef struct HypoArmsReads {
     uint64_t        reads2_bytes;
     const uint32_t* cigar_off;     /* [n_alignments + 1] */
     const uint32_t* cigar;         /* BAM encoding: len << 4 | op */
+    const uint32_t* file_rank;     /* NULL: the alignments are given in file order (a coordinate-sorted file).  Else [n_alignments]:
+                                      the position of every alignment in the FILE; the alignments themselves must still come sorted
+                                      by rb (the caller sorts an unsorted file's records on ingest), and the arms of a window are
+                                      laid out by file_rank — the reference takes them in file order whatever the positions are
+                                      (src/Hypo.cpp:314-318, src/Alignment.cpp:301-318), and the POA result depends on that order */
 } HypoArmsReads;
 typedef struct HypoArmsSummary {
     uint32_t n_windows;            /* windows that survived Contig::fill_short_windows' pruning */

@@ -17,8 +17,14 @@
 // files (1 GB/s: two minutes for a 3 Gbp set) by FNV-1a over the per-contig FNV-1a values.  Without the two flags the files
 // and the printed checksums are byte for byte what the round-3 program produced (the committed manifests depend on that).
 //
+// Config C4 (one chr1-sized contig, short reads + noisy long reads, `-B`): `--join` files all pieces as ONE contig "ctg1" (the pieces
+// are generated independently, so reads never cross a junction: a coverage dip every <contig_len> bases); `--long <cov> <len>` adds
+// long reads (lr.sam / lr.bam: 3 % deletions, 3 % substitutions, 2 % insertions against the truth, CIGAR against the draft by
+// composing the two edit scripts, NM tag) and `--gaps <every> <len>` leaves the short reads out of <len> bases every <every> bases,
+// which is where the reference builds LONG windows from the long reads (src/Contig.cpp:292-343).
+//
 // usage: gen_e2e_fast <outdir> <seed> <n_contigs> <contig_len> <k> [coverage=30] [read_len=150] [read_sub_ppm=2000]
-//                     [--bam] [--fast-hash] [--threads N]
+//                     [--bam] [--fast-hash] [--threads N] [--join] [--long <cov> <len>] [--gaps <every> <len>]
 // build: g++ -O2 -fopenmp -o gen_e2e_fast gen_e2e_fast.cpp -lz      (test infrastructure: tests/ and bench.py's e2e legs only)
 #include <zlib.h>
 #include <omp.h>
@@ -55,8 +61,13 @@ uint64_t fnv(const std::string& s, uint64_t h = kFnv0) { return fnv(s.data(), s.
 void append_uint(std::string& o, uint64_t v) { char b[24]; int n = snprintf(b, sizeof b, "%llu", (unsigned long long)v); o.append(b, (size_t)n); }
 
 struct Contig {
-    std::string truth, draft, recs;              // recs: SAM text, or BGZF blocks of BAM records
-    uint64_t n_reads = 0, h_draft = 0, h_recs = 0;
+    std::string truth, draft, recs, lrecs;       // recs / lrecs: SAM text, or BGZF blocks of BAM records (short / long reads)
+    uint64_t n_reads = 0, n_long = 0, h_draft = 0, h_recs = 0, h_lrecs = 0;
+};
+struct Extra {                                   // config C4 options
+    bool join = false; uint64_t pos_off = 0;     // join: all pieces are one contig; this piece starts at pos_off of it
+    uint32_t long_cov = 0, long_len = 0;         // long reads (0 = none)
+    uint32_t gap_every = 0, gap_len = 0;         // short reads leave [x * gap_every + gap_every / 2, ... + gap_len) of the truth alone
 };
 
 Rng contig_rng(uint64_t seed, int idx) {
@@ -116,7 +127,7 @@ int reg2bin(int64_t beg, int64_t end) {            // SAM spec 5.3
 
 // ops: 0 = M (truth base == draft base), 1 = X (substituted), 2 = D (draft lacks the truth base), 3 = I (draft has an extra base)
 // cnt: saturating (at 2) counters of the canonical k-mers of all truths, shared by the generating threads
-void make_contig(Contig& c, uint64_t seed, int idx, uint32_t G, uint32_t cov, uint32_t rl, uint32_t sub_ppm, bool bam, int K, uint8_t* cnt) {
+void make_contig(Contig& c, uint64_t seed, int idx, uint32_t G, uint32_t cov, uint32_t rl, uint32_t sub_ppm, bool bam, int K, uint8_t* cnt, const Extra& ex = Extra()) {
     Rng r = contig_rng(seed, idx);
     c.truth.resize(G);
     for (uint32_t i = 0; i < G; ++i) c.truth[i] = kA[r.below(4)];
@@ -139,7 +150,8 @@ void make_contig(Contig& c, uint64_t seed, int idx, uint32_t G, uint32_t cov, ui
     const double lam = (double)cov / rl;
     double e = 1.0; { double term = 1.0, sum = 1.0; for (int i = 1; i < 30; ++i) { term *= lam / i; sum += term; } e = 1.0 / sum; }   // exp(-lam)
     const uint32_t p0 = (uint32_t)(e * 1e6), p1 = (uint32_t)((e + e * lam) * 1e6);
-    char name[32]; const int nl = snprintf(name, sizeof name, "ctg%d", idx + 1);
+    char name[32]; const int nl = snprintf(name, sizeof name, "ctg%d", ex.join ? 1 : idx + 1);
+    const int ref_id = ex.join ? 0 : idx;
     std::string& o = c.recs;
     o.clear();
     o.reserve((size_t)((double)G * lam * (bam ? (rl / 2 + 48) : (rl + 48))));
@@ -149,7 +161,13 @@ void make_contig(Contig& c, uint64_t seed, int idx, uint32_t G, uint32_t cov, ui
     uint64_t rid = 0;
     for (uint32_t s = 0; s + rl < G; ++s) {
         const uint32_t x = r.below(1000000u);
-        const int k = x < p0 ? 0 : (x < p1 ? 1 : 2);
+        int k = x < p0 ? 0 : (x < p1 ? 1 : 2);
+        if (ex.gap_every && k) {                             // (the draws stay what they are: a gap only drops reads)
+            const uint32_t g0 = s / ex.gap_every * ex.gap_every + ex.gap_every / 2, g1 = g0 + ex.gap_len;
+            if (s + rl > g0 && s < g1) k = -k;
+        }
+        const bool dropped = k < 0;
+        if (dropped) k = -k;
         for (int q = 0; q < k; ++q) {
             size_t i0 = tpos[s], i1 = (size_t)tpos[s + rl - 1] + 1;
             while (op[i0] > 1) ++i0;                       // a read starts and ends on a base both sequences have
@@ -164,19 +182,20 @@ void make_contig(Contig& c, uint64_t seed, int idx, uint32_t G, uint32_t cov, ui
                 else { push('D'); ++rspan; }
             }
             emit();
+            if (dropped) continue;                           // (every random draw of the read was made: the stream behind it is unchanged)
             if (!bam) {
                 o.push_back('r'); append_uint(o, rid++); o.append("\t0\t"); o.append(name, (size_t)nl); o.push_back('\t');
-                append_uint(o, (uint64_t)dprefix[i0] + 1); o.append("\t60\t"); o += cig; o.append("\t*\t0\t0\t"); o += seq; o.append("\t*\n");
+                append_uint(o, ex.pos_off + (uint64_t)dprefix[i0] + 1); o.append("\t60\t"); o += cig; o.append("\t*\t0\t0\t"); o += seq; o.append("\t*\n");
             } else {
                 char qn[24]; const int ql = snprintf(qn, sizeof qn, "r%llu", (unsigned long long)rid++) + 1;
-                const int32_t pos = (int32_t)dprefix[i0], lseq = (int32_t)seq.size();
+                const int32_t pos = (int32_t)(ex.pos_off + dprefix[i0]), lseq = (int32_t)seq.size();
                 const uint32_t ncig = (uint32_t)cigops.size();
                 const int32_t bs = 32 + ql + 4 * (int32_t)ncig + (lseq + 1) / 2 + lseq;
                 rec.resize((size_t)bs + 4);
                 char* p = &rec[0];
                 auto w32 = [&](int32_t v) { memcpy(p, &v, 4); p += 4; };
                 auto w16 = [&](uint16_t v) { memcpy(p, &v, 2); p += 2; };
-                w32(bs); w32(idx); w32(pos); *p++ = (char)ql; *p++ = 60; w16((uint16_t)reg2bin(pos, pos + (int64_t)rspan)); w16((uint16_t)ncig); w16(0); w32(lseq); w32(-1); w32(-1); w32(0);
+                w32(bs); w32(ref_id); w32(pos); *p++ = (char)ql; *p++ = 60; w16((uint16_t)reg2bin(pos, pos + (int64_t)rspan)); w16((uint16_t)ncig); w16(0); w32(lseq); w32(-1); w32(-1); w32(0);
                 memcpy(p, qn, (size_t)ql); p += ql;
                 memcpy(p, cigops.data(), 4 * (size_t)ncig); p += 4 * (size_t)ncig;
                 for (int32_t i = 0; i < lseq; i += 2) {
@@ -190,8 +209,83 @@ void make_contig(Contig& c, uint64_t seed, int idx, uint32_t G, uint32_t cov, ui
     }
     if (bam) bz.flush();
     c.n_reads = rid;
+    c.lrecs.clear(); c.n_long = 0;
+    if (ex.long_cov && ex.long_len && G > 2 * ex.long_len) {
+        // long reads: a generator of their own (the short reads' stream is what it was without them); a read is the truth over
+        // [s, s + len) with 3 % deletions, 3 % substitutions, 2 % insertions; its CIGAR against the DRAFT composes both edit scripts
+        Rng lr(r.next() ^ 0x5bd1e9955bd1e995ull);
+        Bgzf lbz(&c.lrecs);
+        const uint32_t ll = ex.long_len;
+        const uint32_t pstart = (uint32_t)((double)ex.long_cov / ll * 1e9);      // starts per 1e9 positions
+        uint64_t lid = 0;
+        std::string lseq_s, lcig, lrec;
+        std::vector<uint32_t> lops;
+        for (uint32_t s = 0; s + ll < G; ++s) {
+            if (lr.below(1000000000u) >= pstart) continue;
+            size_t i0 = tpos[s], i1 = (size_t)tpos[s + ll - 1] + 1;
+            lseq_s.clear(); lcig.clear(); lops.clear();
+            char last = 0; uint32_t run = 0, rspan = 0, nm = 0; size_t first_m = (size_t)-1; uint32_t span_at_first = 0;
+            // ops are collected first (kind per step), then trimmed to start and end on an M
+            std::vector<char> kinds; std::vector<char> bases;
+            kinds.reserve(ll + ll / 8); bases.reserve(ll + ll / 8);
+            for (size_t i = i0; i < i1; ++i) {
+                const uint32_t e = lr.below(1000u);
+                const bool del = e < 30, sub = e >= 30 && e < 60;
+                if (op[i] <= 1) {                              // truth and draft both have a base here
+                    if (del) { kinds.push_back('D'); bases.push_back(0); }
+                    else { char b = tb[i]; if (sub) b = kA[lr.below(4)]; kinds.push_back(b == db[i] ? 'M' : 'X'); bases.push_back(b); }
+                } else if (op[i] == 2) {                       // the draft lacks this truth base
+                    if (!del) { char b = tb[i]; if (sub) b = kA[lr.below(4)]; kinds.push_back('I'); bases.push_back(b); }
+                } else { kinds.push_back('D'); bases.push_back(0); }        // a base only the draft has
+                if (op[i] != 3 && lr.below(1000u) < 20) { kinds.push_back('I'); bases.push_back(kA[lr.below(4)]); }
+            }
+            size_t a = 0, b = kinds.size();
+            uint32_t lead_ref = 0;
+            while (a < b && kinds[a] != 'M' && kinds[a] != 'X') { if (kinds[a] == 'D') ++lead_ref; ++a; }
+            while (b > a && kinds[b - 1] != 'M' && kinds[b - 1] != 'X') --b;
+            if (b - a < ll / 2) continue;
+            (void)first_m; (void)span_at_first;
+            auto emit = [&]() { if (!last) return; if (bam) lops.push_back((run << 4) | (last == 'M' ? 0u : (last == 'I' ? 1u : 2u))); else { append_uint(lcig, run); lcig.push_back(last); } };
+            auto push = [&](char ch) { if (ch == last) ++run; else { emit(); last = ch; run = 1; } };
+            for (size_t t = a; t < b; ++t) {
+                const char kd = kinds[t];
+                if (kd == 'M' || kd == 'X') { push('M'); lseq_s.push_back(bases[t]); ++rspan; nm += kd == 'X'; }
+                else if (kd == 'I') { push('I'); lseq_s.push_back(bases[t]); ++nm; }
+                else { push('D'); ++rspan; ++nm; }
+            }
+            emit();
+            const uint64_t pos0 = ex.pos_off + dprefix[i0] + lead_ref;      // 0-based position of the first M in the (joined) draft
+            if (!bam) {
+                std::string& lo = c.lrecs;
+                lo.push_back('l'); append_uint(lo, lid++); lo.append("\t0\t"); lo.append(name, (size_t)nl); lo.push_back('\t');
+                append_uint(lo, pos0 + 1); lo.append("\t60\t"); lo += lcig; lo.append("\t*\t0\t0\t"); lo += lseq_s; lo.append("\t*\tNM:i:"); append_uint(lo, nm); lo.push_back('\n');
+            } else {
+                char qn[24]; const int ql = snprintf(qn, sizeof qn, "l%llu", (unsigned long long)lid++) + 1;
+                const int32_t pos = (int32_t)pos0, lseq = (int32_t)lseq_s.size();
+                const uint32_t ncig = (uint32_t)lops.size();
+                const int32_t bs = 32 + ql + 4 * (int32_t)ncig + (lseq + 1) / 2 + lseq + 7;      // + NM:I tag
+                lrec.resize((size_t)bs + 4);
+                char* p = &lrec[0];
+                auto w32 = [&](int32_t v) { memcpy(p, &v, 4); p += 4; };
+                auto w16 = [&](uint16_t v) { memcpy(p, &v, 2); p += 2; };
+                w32(bs); w32(ref_id); w32(pos); *p++ = (char)ql; *p++ = 60; w16((uint16_t)reg2bin(pos, pos + (int64_t)rspan)); w16((uint16_t)ncig); w16(0); w32(lseq); w32(-1); w32(-1); w32(0);
+                memcpy(p, qn, (size_t)ql); p += ql;
+                memcpy(p, lops.data(), 4 * (size_t)ncig); p += 4 * (size_t)ncig;
+                for (int32_t i = 0; i < lseq; i += 2) {
+                    auto code = [](char ch) { return ch == 'A' ? 1 : (ch == 'C' ? 2 : (ch == 'G' ? 4 : 8)); };
+                    *p++ = (char)((code(lseq_s[(size_t)i]) << 4) | (i + 1 < lseq ? code(lseq_s[(size_t)i + 1]) : 0));
+                }
+                memset(p, 0xff, (size_t)lseq); p += lseq;
+                *p++ = 'N'; *p++ = 'M'; *p++ = 'I'; memcpy(p, &nm, 4);
+                lbz.put(lrec.data(), lrec.size());
+            }
+        }
+        if (bam) lbz.flush();
+        c.n_long = lid;
+    }
     c.h_draft = fnv(c.draft);
     c.h_recs = fnv(c.recs);
+    c.h_lrecs = fnv(c.lrecs);
     // canonical k-mers of the truth into the shared counters (saturating at 2: the result does not depend on the order)
     uint64_t fw = 0, rv = 0; const uint64_t mask = (1ull << (2 * K)) - 1;
     for (uint32_t i = 0; i < G; ++i) {
@@ -230,11 +324,15 @@ uint32_t draft_length_exact(uint64_t seed, int idx, uint32_t G) {
 int main(int argc, char** argv) {
     std::vector<const char*> pos;
     bool bam = false, fast_hash = false;
+    Extra ex0;
     int threads = omp_get_max_threads();
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--bam")) bam = true;
         else if (!strcmp(argv[i], "--fast-hash")) fast_hash = true;
         else if (!strcmp(argv[i], "--threads") && i + 1 < argc) threads = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--join")) ex0.join = true;
+        else if (!strcmp(argv[i], "--long") && i + 2 < argc) { ex0.long_cov = (uint32_t)atoi(argv[++i]); ex0.long_len = (uint32_t)atoi(argv[++i]); }
+        else if (!strcmp(argv[i], "--gaps") && i + 2 < argc) { ex0.gap_every = (uint32_t)atoi(argv[++i]); ex0.gap_len = (uint32_t)atoi(argv[++i]); }
         else pos.push_back(argv[i]);
     }
     if (pos.size() < 5) { fprintf(stderr, "usage: gen_e2e_fast <outdir> <seed> <n_contigs> <contig_len> <k> [coverage=30] [read_len=150] [read_sub_ppm=2000] [--bam] [--fast-hash] [--threads N]\n"); return 2; }
@@ -255,28 +353,38 @@ int main(int argc, char** argv) {
     std::vector<uint32_t> dlen((size_t)nc);
 #pragma omp parallel for schedule(dynamic, 1)
     for (int c = 0; c < nc; ++c) dlen[(size_t)c] = draft_length_exact(seed, c, G);
-    {   // header
+    std::vector<uint64_t> pos_off((size_t)nc + 1, 0);
+    for (int c = 0; c < nc; ++c) pos_off[(size_t)c + 1] = pos_off[(size_t)c] + dlen[(size_t)c];
+    if (ex0.join && pos_off[(size_t)nc] >= 0x7fffffffull) { fprintf(stderr, "gen_e2e_fast: a joined contig of %llu bases exceeds BAM's 2^31\n", (unsigned long long)pos_off[(size_t)nc]); return 2; }
+    FILE* fl = nullptr;
+    if (ex0.long_cov) { fl = fopen((out + (bam ? "/lr.bam" : "/lr.sam")).c_str(), "wb"); if (!fl) { perror("gen_e2e_fast"); return 1; } setvbuf(fl, nullptr, _IOFBF, 1 << 22); }
+    {   // header(s)
         std::string h = "@HD\tVN:1.6\tSO:coordinate\n";
-        for (int c = 0; c < nc; ++c) { char q[96]; const int m = snprintf(q, sizeof q, "@SQ\tSN:ctg%d\tLN:%u\n", c + 1, dlen[(size_t)c]); h.append(q, (size_t)m); }
-        if (!bam) fwrite(h.data(), 1, h.size(), fs);
-        else {
-            std::string hb, blk;
+        const int n_ref = ex0.join ? 1 : nc;
+        auto ref_len = [&](int c) -> uint64_t { return ex0.join ? pos_off[(size_t)nc] : dlen[(size_t)c]; };
+        for (int c = 0; c < n_ref; ++c) { char q[96]; const int m = snprintf(q, sizeof q, "@SQ\tSN:ctg%d\tLN:%llu\n", c + 1, (unsigned long long)ref_len(c)); h.append(q, (size_t)m); }
+        std::string blk;
+        if (bam) {
+            std::string hb;
             hb.append("BAM\1", 4);
-            const int32_t lt = (int32_t)h.size(), nr = nc;
+            const int32_t lt = (int32_t)h.size(), nr = n_ref;
             hb.append((const char*)&lt, 4); hb += h; hb.append((const char*)&nr, 4);
-            for (int c = 0; c < nc; ++c) {
-                char nm[32]; const int32_t ln = snprintf(nm, sizeof nm, "ctg%d", c + 1) + 1, lr = (int32_t)dlen[(size_t)c];
+            for (int c = 0; c < n_ref; ++c) {
+                char nm[32]; const int32_t ln = snprintf(nm, sizeof nm, "ctg%d", c + 1) + 1, lr = (int32_t)ref_len(c);
                 hb.append((const char*)&ln, 4); hb.append(nm, (size_t)ln); hb.append((const char*)&lr, 4);
             }
             Bgzf bz(&blk); bz.put(hb.data(), hb.size()); bz.flush();
-            fwrite(blk.data(), 1, blk.size(), fs);
         }
+        const std::string& hd = bam ? blk : h;
+        fwrite(hd.data(), 1, hd.size(), fs);
+        if (fl) fwrite(hd.data(), 1, hd.size(), fl);
     }
     // k-mer counts over all truths (canonical, saturating at 2)
     const uint64_t nk = 1ull << (2 * K);
     uint8_t* cnt = (uint8_t*)calloc(nk, 1);
     if (!cnt) { fprintf(stderr, "gen_e2e_fast: no memory for %llu k-mer counters\n", (unsigned long long)nk); return 1; }
-    uint64_t h_draft = kFnv0, h_sam = kFnv0, n_reads = 0, draft_bases = 0;
+    uint64_t h_draft = kFnv0, h_sam = kFnv0, h_long = kFnv0, n_reads = 0, n_long = 0, draft_bases = 0;
+    if (ex0.join) fputs(">ctg1\n", fd);
     // chunks of `par` contigs: made on all threads, filed in order by a writer thread while the next chunk is made
     const int par = threads < 16 ? 16 : threads;
     std::vector<Contig> bufs[2]; bufs[0].resize((size_t)par); bufs[1].resize((size_t)par);
@@ -285,13 +393,15 @@ int main(int argc, char** argv) {
         for (int c = c0; c < c1; ++c) {
             Contig& C = (*cs)[(size_t)(c - c0)];
             if (C.draft.size() != dlen[(size_t)c]) { fprintf(stderr, "gen_e2e_fast: internal error: draft length of contig %d\n", c + 1); exit(1); }
-            char hd[64]; const int n = snprintf(hd, sizeof hd, ">ctg%d\n", c + 1);
-            fwrite(hd, 1, (size_t)n, fd); fwrite(C.draft.data(), 1, C.draft.size(), fd); fputc('\n', fd);
+            if (!ex0.join) { char hd[64]; const int n = snprintf(hd, sizeof hd, ">ctg%d\n", c + 1); fwrite(hd, 1, (size_t)n, fd); }
+            fwrite(C.draft.data(), 1, C.draft.size(), fd);
+            if (!ex0.join) fputc('\n', fd);
             fwrite(C.recs.data(), 1, C.recs.size(), fs);
-            if (fast_hash) { h_draft = fnv((const char*)&C.h_draft, 8, h_draft); h_sam = fnv((const char*)&C.h_recs, 8, h_sam); }
-            else { h_draft = fnv(C.draft, h_draft); h_sam = fnv(C.recs, h_sam); }
-            n_reads += C.n_reads; draft_bases += C.draft.size();
-            std::string().swap(C.recs); std::string().swap(C.draft);
+            if (fl) fwrite(C.lrecs.data(), 1, C.lrecs.size(), fl);
+            if (fast_hash) { h_draft = fnv((const char*)&C.h_draft, 8, h_draft); h_sam = fnv((const char*)&C.h_recs, 8, h_sam); h_long = fnv((const char*)&C.h_lrecs, 8, h_long); }
+            else { h_draft = fnv(C.draft, h_draft); h_sam = fnv(C.recs, h_sam); h_long = fnv(C.lrecs, h_long); }
+            n_reads += C.n_reads; n_long += C.n_long; draft_bases += C.draft.size();
+            std::string().swap(C.recs); std::string().swap(C.lrecs); std::string().swap(C.draft);
         }
     };
     int flip = 0;
@@ -299,13 +409,14 @@ int main(int argc, char** argv) {
         const int c1 = c0 + par < nc ? c0 + par : nc;
         std::vector<Contig>& cs = bufs[flip];
 #pragma omp parallel for schedule(dynamic, 1)
-        for (int c = c0; c < c1; ++c) make_contig(cs[(size_t)(c - c0)], seed, c, G, cov, rl, sub, bam, K, cnt);
+        for (int c = c0; c < c1; ++c) { Extra ex = ex0; ex.pos_off = ex0.join ? pos_off[(size_t)c] : 0; make_contig(cs[(size_t)(c - c0)], seed, c, G, cov, rl, sub, bam, K, cnt, ex); }
         if (writer.joinable()) writer.join();
         writer = std::thread(file_chunk, &cs, c0, c1);
     }
     if (writer.joinable()) writer.join();
-    if (bam) fwrite(kBgzfEof, 1, sizeof kBgzfEof, fs);
-    fclose(fd); fclose(fs);
+    if (bam) { fwrite(kBgzfEof, 1, sizeof kBgzfEof, fs); if (fl) fwrite(kBgzfEof, 1, sizeof kBgzfEof, fl); }
+    if (ex0.join) fputc('\n', fd);
+    fclose(fd); fclose(fs); if (fl) fclose(fl);
     if (getenv("GEN_DEBUG")) { uint64_t hst[3] = {0, 0, 0}; for (uint64_t v = 0; v < nk; ++v) hst[cnt[v]]++; fprintf(stderr, "counts 0/1/2+: %llu %llu %llu\n", (unsigned long long)hst[0], (unsigned long long)hst[1], (unsigned long long)hst[2]); }
     // solid set: count == 1 and no homopolymer at either end; both strands
     std::vector<uint64_t> words(nk / 64, 0);
@@ -344,9 +455,13 @@ int main(int argc, char** argv) {
         f = fopen((out + "/reads.fa").c_str(), "wb");          // named on the command line, not read when -i finds the aux files
         fputs(">unused\nACGT\n", f); fclose(f);
     }
-    printf("{\"contigs\": %d, \"draft_bases\": %llu, \"reads\": %llu, \"solid_kmers\": %llu, \"fnv_draft\": \"%016llx\", \"%s\": \"%016llx\", \"fnv_bitvector\": \"%016llx\"%s}\n",
+    char extra[256] = "";
+    if (ex0.long_cov || ex0.join || ex0.gap_every)
+        snprintf(extra, sizeof extra, ", \"joined\": %s, \"long_reads\": %llu, \"fnv_long_records\": \"%016llx\", \"gaps\": [%u, %u]", ex0.join ? "true" : "false",
+                 (unsigned long long)n_long, (unsigned long long)h_long, ex0.gap_every, ex0.gap_len);
+    printf("{\"contigs\": %d, \"draft_bases\": %llu, \"reads\": %llu, \"solid_kmers\": %llu, \"fnv_draft\": \"%016llx\", \"%s\": \"%016llx\", \"fnv_bitvector\": \"%016llx\"%s%s}\n",
            nc, (unsigned long long)draft_bases, (unsigned long long)n_reads, (unsigned long long)n_solid,
            (unsigned long long)h_draft, bam ? "fnv_bam_blocks" : "fnv_sam_records", (unsigned long long)h_sam, (unsigned long long)h_bv,
-           fast_hash ? ", \"hash\": \"fnv of per-contig fnv\"" : "");
+           fast_hash ? ", \"hash\": \"fnv of per-contig fnv\"" : "", extra);
     return 0;
 }
