@@ -188,17 +188,22 @@ def end_to_end_fast_leg(name, bam, what):
         gen = _build_generator()
         tg = time.perf_counter()
         rep = json.loads(subprocess.check_output([gen, d, str(a["seed"]), str(a["contigs"]), str(a["contig_len"]), str(a["k"]),
-                                                  str(a["coverage"]), str(a["read_len"]), str(a["read_sub_ppm"])] + (["--bam"] if bam else []), text=True))
+                                                  str(a["coverage"]), str(a["read_len"]), str(a["read_sub_ppm"])] +
+                                                 (list(a["flags"]) if "flags" in a else (["--bam"] if bam else [])), text=True))
         tg = time.perf_counter() - tg
         want = man["generator_report"]
-        keys = ("contigs", "draft_bases", "reads", "solid_kmers", "fnv_draft", "fnv_bitvector") if bam else tuple(want.keys())
+        if "flags" in a:
+            bam = "--bam" in a["flags"]
+        keys = ("contigs", "draft_bases", "reads", "solid_kmers", "fnv_draft", "fnv_bitvector") if (bam and "flags" not in a) else tuple(want.keys())
         if any(rep.get(k) != want[k] for k in keys):
             return {"error": "the generator's output differs from the golden's inputs"}
-        threads = min(64, os.cpu_count() or 1)
+        threads = min(128, max(1, (os.cpu_count() or 2) // 2)) if a["contigs"] * a["contig_len"] >= 500_000_000 else min(64, os.cpu_count() or 1)
         argv = [binp] + man["command"].split()[1:]
         argv[argv.index("-t") + 1] = str(threads)
         if bam:
             argv[argv.index("-b") + 1] = "sr.bam"
+            if "-B" in argv:
+                argv[argv.index("-B") + 1] = "lr.bam"
         rc, out, err, wall, rss, busy = _run_hypo(argv, d)
         if rc != 0:
             return {"error": (out + err)[-300:]}
@@ -231,6 +236,11 @@ def end_to_end_c3_leg():
 def end_to_end_k15_leg():
     return end_to_end_fast_leg("e2e_k15_250m_s77", True,
                                "250 Mbp at the k of C4 end to end: 250 x 1 Mbp draft, 30x 150-bp reads (49.7 M records as BAM), -s 250m -> k = 15 (128 MiB solid set, dense tiny-window shape), -p 10, one run")
+
+
+def end_to_end_1g_leg():
+    return end_to_end_fast_leg("e2e_1g_s91", True,
+                               "Row T1 at 1 Gbp end to end: 1000 x 1 Mbp draft, 30x 150-bp reads (198.8 M records as BAM), -s 1g -> k = 15, -p 10, hypo binary = host pipeline + device on ONE MI355X, one run")
 
 
 def end_to_end_t1_leg(n_contigs, contig_len=1_000_000, batchings=(10, 50)):
@@ -318,6 +328,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-e2e-c3", action="store_true", help="skip the 100 Mbp end-to-end run (about a minute and 4 GB of scratch files)")
     ap.add_argument("--no-e2e-k15", action="store_true", help="skip the 250 Mbp / k = 15 end-to-end run (BAM input, about half a minute)")
+    ap.add_argument("--no-e2e-1g", action="store_true", help="skip the 1 Gbp end-to-end run (BAM input, about a minute of input generation + half a minute)")
     ap.add_argument("--t1-contigs", type=int, default=int(os.environ.get("HYPO_BENCH_T1_CONTIGS", "0")),
                     help="also run row T1 end to end on this many 1 Mbp contigs (3000 = the north star's 3 Gbp; needs ~20 GB of /dev/shm and a few minutes)")
     ap.add_argument("--no-extras", action="store_true", help="skip value_at_0p5pct / value_at_1pct / value_dense / value_c4mix and host_api")
@@ -688,6 +699,8 @@ def main():
             e2e_k15 = end_to_end_k15_leg()
         if args.t1_contigs > 0:
             e2e_t1 = end_to_end_t1_leg(args.t1_contigs)
+        elif not args.no_e2e_1g:
+            e2e_t1 = end_to_end_1g_leg()                   # (the default: 1 Gbp with the real reference's md5; --t1-contigs 3000 = the 3 Gbp run)
 
     if strong and world > 1:                               # per-rank imbalance of the measured step
         tt = torch.tensor([my_dt], dtype=torch.float64, device=dev)

@@ -28,7 +28,8 @@ bool DeviceArms::upload_reads(std::vector<std::unique_ptr<Contig>>& contigs, uin
     }
     if (n_aln >= 0xfffffff0ull || total >= 0xfffffff0ull) return false;
     bool sorted = true;
-    if (!reads.flatten(c0, c1, base, _stage, sorted)) {
+    if (_piece && c1 - c0 != 1) return false;
+    if (!reads.flatten(c0, c1, base, _stage, sorted, _piece ? _span : nullptr)) {
         std::fprintf(stdout, "[Hypo::Hypo] Info: no page-locked staging memory for %llu alignments: support votes and short arms are computed on the host\n", (unsigned long long)n_aln);
         return false;
     }
@@ -60,7 +61,7 @@ bool DeviceArms::support_kmers(std::vector<std::unique_ptr<Contig>>& contigs, ui
     uint64_t ns = 0;
     const auto ts0 = std::chrono::steady_clock::now();
     std::vector<uint64_t> kbase(c1 - c0 + 1, 0);
-    bool all_kept = true;
+    bool all_kept = !_piece;
     for (uint32_t c = c0; c < c1; ++c) { kbase[c - c0] = ns; ns += contigs[c]->_n_solid; all_kept = all_kept && contigs[c]->_scan_kept; }
     kbase[c1 - c0] = ns;
     if (ns == 0) return true;
@@ -111,8 +112,12 @@ bool DeviceArms::support_kmers(std::vector<std::unique_ptr<Contig>>& contigs, ui
     for (uint32_t c = c0; c < c1; ++c) {
         Contig& ctg = *contigs[c];
         const uint64_t b = kbase[c - c0], n = ctg._n_solid;
-        std::memcpy(ctg._kcov.data(), cov + b, n * 4);
-        std::memcpy(ctg._ksup.data(), sup + b, n * 4);
+        // (piece mode: the counters of the solid k-mers this context owns; the others are another context's)
+        const uint64_t i0 = _piece ? ctg._solid_pos.rank(_own0) : 0, i1 = _piece ? ctg._solid_pos.rank(std::min<uint64_t>(_own1, ctg._len)) : n;
+        if (i1 > i0) {
+            std::memcpy(ctg._kcov.data() + i0, cov + b + i0, (i1 - i0) * 4);
+            std::memcpy(ctg._ksup.data() + i0, sup + b + i0, (i1 - i0) * 4);
+        }
     }
     std::fprintf(stdout, "[Hypo::Hypo] Info: k-mer support counted on the device: %llu solid k-mers\n", (unsigned long long)ns);
     return true;
@@ -178,13 +183,32 @@ bool DeviceArms::support_minimizers(std::vector<std::unique_ptr<Contig>>& contig
         if (rc != HYPO_E_UNSUPPORTED) std::fprintf(stdout, "[Hypo::Hypo] Info: minimizer support is counted on the host (%s)\n", hypo_gpu_last_error());
         return false;
     }
+    if (!_piece) {
 #pragma omp parallel for schedule(static, 256)
-    for (int64_t x = 0; x < (int64_t)n_info; ++x) {
-        MWMinimiserInfo& mi = *infos[(size_t)x];
-        const size_t n = mi.rel_pos.size();
-        if (!n) continue;
-        std::memcpy(mi.coverage.data(), cov + mw_off[x], n * 4);
-        std::memcpy(mi.support.data(), sup + mw_off[x], n * 4);
+        for (int64_t x = 0; x < (int64_t)n_info; ++x) {
+            MWMinimiserInfo& mi = *infos[(size_t)x];
+            const size_t n = mi.rel_pos.size();
+            if (!n) continue;
+            std::memcpy(mi.coverage.data(), cov + mw_off[x], n * 4);
+            std::memcpy(mi.support.data(), sup + mw_off[x], n * 4);
+        }
+    } else {
+        // piece mode (one contig): the counters of the minimizers that lie in the owned range.  Mega-window x of the contig is region
+        // 2 x (+ 1 when the contig starts with an SR) of the border table; a minimizer's position is the window's start plus the
+        // distances before it (support_kernel.hip: MwCursor)
+        const Contig& ctg = *contigs[c0];
+#pragma omp parallel for schedule(static, 256)
+        for (int64_t x = 0; x < (int64_t)n_info; ++x) {
+            MWMinimiserInfo& mi = *infos[(size_t)x];
+            const size_t n = mi.rel_pos.size();
+            if (!n) continue;
+            const uint64_t w = ctg._is_win_even ? 2 * (uint64_t)x : 2 * (uint64_t)x + 1;
+            uint64_t pos = start[w];
+            for (size_t m = 0; m < n; ++m) {
+                pos += mi.rel_pos[m];
+                if (pos >= _own0 && pos < _own1) { mi.coverage[m] = cov[mw_off[x] + m]; mi.support[m] = sup[mw_off[x] + m]; }
+            }
+        }
     }
     if (std::getenv("HYPO_HOST_TIMING")) {
         auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
@@ -264,10 +288,16 @@ bool DeviceArms::build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c
         Contig& ctg = *contigs[c0 + (uint32_t)ci];
         const uint32_t nr = (uint32_t)ctg.get_num_regions();
         uint64_t r = rbase[(size_t)ci];
-        for (uint32_t i = 0; i < nr; ++i, ++r)
+        for (uint32_t i = 0; i < nr; ++i, ++r) {
+            // (piece mode: a region belongs to the context that owns its start; the windows this context built in its halo are
+            // another context's to judge and to polish)
+            if (_piece && !owns((uint64_t)start[r] - cbase[(size_t)ci])) { _reg_window[r] = nullptr; continue; }
             if (ctg._pwindows[i] && !valid[r]) { ctg._pwindows[i].reset(); _reg_window[r] = nullptr; }
-        std::vector<uint64_t>().swap(ctg._anchor_kmers);
-        std::vector<uint32_t>().swap(ctg._reg_info);
+        }
+        if (!_piece) {                                     // (piece mode: the other contexts of the contig still read them; Hypo::polish frees them)
+            std::vector<uint64_t>().swap(ctg._anchor_kmers);
+            std::vector<uint32_t>().swap(ctg._reg_info);
+        }
     }
     if (timing) std::fprintf(stderr, "[timing] device arms: flatten %.3f s, hypo_gpu_arms_build %.3f s, prune + release %.3f s\n", secs(t0, t1), secs(t1, t2), secs(t2, now()));
     std::fprintf(stdout, "[Hypo::Hypo] Info: short arms cut on the device: %u windows, %u arms\n", _sum.n_windows, _sum.n_arms);
@@ -283,13 +313,19 @@ bool DeviceArms::build_long(std::vector<std::unique_ptr<Contig>>& contigs, uint3
     // behind an odd-length contig); its regions are the PSEUDO regions of Contig::prepare_long_windows
     uint64_t total = 0, n_reg = 0, n_aln = 0;
     std::vector<uint64_t> aln_base(c1 - c0 + 1, 0);
+    if (_piece && c1 - c0 != 1) return false;
+    // (piece mode: the long reads that overlap this context's span of the contig; `pick` = their indices in the contig's store entry)
+    std::vector<std::vector<uint32_t>> pick(c1 - c0);
     for (uint32_t c = c0; c < c1; ++c) {
         const Contig& ctg = *contigs[c];
         if (ctg._pseudo_reg_type.empty()) return false;
         total += ctg._len + (ctg._len & 1);
         n_reg += ctg._pseudo_reg_type.size() - 1 + (ctg._len & 1);
         aln_base[c - c0] = n_aln;
-        n_aln += store[c].size();
+        auto& pk = pick[c - c0];
+        for (size_t t = 0; t < store[c].size(); ++t)
+            if (!_piece || (store[c][t]->_rb < _span[1] && store[c][t]->_re > _span[0])) pk.push_back((uint32_t)t);
+        n_aln += pk.size();
     }
     if (total >= 0xfffffff0ull || n_reg >= 0xfffffff0ull || n_aln >= 0xfffffff0ull || n_reg == 0) return false;
     std::vector<uint64_t> seq_off(n_aln + 1);
@@ -297,11 +333,12 @@ bool DeviceArms::build_long(std::vector<std::unique_ptr<Contig>>& contigs, uint3
     bool sorted = true;
     for (uint32_t c = c0; c < c1; ++c) {
         const auto& alns = store[c];
+        const auto& pk = pick[c - c0];
         const uint64_t a0 = aln_base[c - c0];
-        for (size_t t = 0; t < alns.size(); ++t) {
-            seq_off[a0 + t + 1] = alns[t]->_apseq.byte_size();
-            cigar_off[a0 + t + 1] = (uint32_t)alns[t]->_cigar.size();
-            if (t && alns[t - 1]->_rb > alns[t]->_rb) sorted = false;
+        for (size_t t = 0; t < pk.size(); ++t) {
+            seq_off[a0 + t + 1] = alns[pk[t]]->_apseq.byte_size();
+            cigar_off[a0 + t + 1] = (uint32_t)alns[pk[t]]->_cigar.size();
+            if (t && alns[pk[t - 1]]->_rb > alns[pk[t]]->_rb) sorted = false;
         }
     }
     if (!sorted) { std::fprintf(stdout, "[Hypo::Hypo] Info: long-read alignments are not sorted by position: long arms are computed on the host\n"); return false; }
@@ -324,15 +361,20 @@ bool DeviceArms::build_long(std::vector<std::unique_ptr<Contig>>& contigs, uint3
             start[r] = (uint32_t)(base + ctg._pseudo_reg_pos.select((uint64_t)i + 1));
             const bool lw = ctg._pseudo_reg_type[i] == RegionType::LONG;
             type[r] = (uint8_t)(lw ? RegionType::LONG : RegionType::SR);
-            if (lw) { _preg_window[r] = ctg._pwindows[ctg._true_reg_id[i]].get(); if (!_preg_window[r]) return false; }
+            if (lw) {
+                _preg_window[r] = ctg._pwindows[ctg._true_reg_id[i]].get();
+                if (!_preg_window[r]) return false;
+                if (_piece && !owns((uint64_t)start[r] - base)) _preg_window[r] = nullptr;      // (a LONG window of the halo: another context's)
+            }
         }
         std::memcpy(contig4.data() + base / 2, ctg._pseq.data(), ctg._pseq.byte_size());
         if (ctg._len & 1) { start[r] = (uint32_t)(base + ctg._len); type[r] = (uint8_t)RegionType::SR; ++r; }
         const uint64_t a0 = aln_base[c - c0];
         auto& alns = store[c];
+        const auto& pk = pick[c - c0];
 #pragma omp parallel for schedule(static)
-        for (int64_t t = 0; t < (int64_t)alns.size(); ++t) {
-            const Alignment& a = *alns[(size_t)t];
+        for (int64_t t = 0; t < (int64_t)pk.size(); ++t) {
+            const Alignment& a = *alns[pk[(size_t)t]];
             const uint64_t g = a0 + (uint64_t)t;
             rb[g] = (uint32_t)(base + a._rb); re[g] = (uint32_t)(base + a._re); qae[g] = a._qae;
             std::memcpy(reads2.get() + seq_off[g], a._apseq.data(), a._apseq.byte_size());
@@ -355,6 +397,13 @@ bool DeviceArms::build_long(std::vector<std::unique_ptr<Contig>>& contigs, uint3
         return false;
     }
     // what Contig::fill_long_windows leaves behind (include/Contig.hpp:91-113): the alignments are spent, the pseudo tables gone
+    if (!_piece) finish_long(contigs, c0, c1, store);          // (piece mode: the other contexts of the contig still read them; Hypo::polish calls it)
+    std::fprintf(stdout, "[Hypo::Hypo] Info: long arms cut on the device: %u windows, %u arms\n", _sum_long.n_windows, _sum_long.n_arms);
+    _active_long = true;
+    return true;
+}
+
+void DeviceArms::finish_long(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1, std::vector<std::vector<std::unique_ptr<Alignment>>>& store) {
     for (uint32_t c = c0; c < c1; ++c) {
         Contig& ctg = *contigs[c];
         store[c].clear();
@@ -362,9 +411,12 @@ bool DeviceArms::build_long(std::vector<std::unique_ptr<Contig>>& contigs, uint3
         std::vector<RegionType>().swap(ctg._pseudo_reg_type);
         std::vector<uint32_t>().swap(ctg._true_reg_id);
     }
-    std::fprintf(stdout, "[Hypo::Hypo] Info: long arms cut on the device: %u windows, %u arms\n", _sum_long.n_windows, _sum_long.n_arms);
-    _active_long = true;
-    return true;
+}
+void DeviceArms::finish_short(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1) {
+    for (uint32_t c = c0; c < c1; ++c) {
+        std::vector<uint64_t>().swap(contigs[c]->_anchor_kmers);
+        std::vector<uint32_t>().swap(contigs[c]->_reg_info);
+    }
 }
 
 void DeviceArms::adopt_arms(const std::vector<uint32_t>& which, const std::vector<HypoWindow>& hw, const std::vector<uint32_t>& win_region, bool lng) {
@@ -389,11 +441,13 @@ void DeviceArms::adopt_arms(const std::vector<uint32_t>& which, const std::vecto
 }
 
 int DeviceArms::polish(const ScoreParams& sp, bool keep_arms, std::vector<Window*>* retry) {
+    _n_pol[0] = 0;
     if (!_active) return HYPO_OK;
     _active = false;
     return polish_impl(false, sp, keep_arms, retry);
 }
 int DeviceArms::polish_long(const ScoreParams& sp, bool keep_arms, std::vector<Window*>* retry) {
+    _n_pol[1] = 0;
     if (!_active_long) return HYPO_OK;
     _active_long = false;
     return polish_impl(true, sp, keep_arms, retry);
@@ -433,8 +487,15 @@ int DeviceArms::polish_impl(bool lng, const ScoreParams& sp, bool keep_arms, std
     std::vector<uint32_t> again, all;
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < (int64_t)n; ++i)
-        if (st[(size_t)i] == HYPO_ST_OK) _reg_window[win_region[(size_t)i]]->_consensus.assign(bases + off[(size_t)i], len[(size_t)i]);
-    for (uint32_t i = 0; i < n; ++i) { if (st[i] != HYPO_ST_OK) again.push_back(i); if (keep_arms) all.push_back(i); }
+        if (st[(size_t)i] == HYPO_ST_OK && _reg_window[win_region[(size_t)i]]) _reg_window[win_region[(size_t)i]]->_consensus.assign(bases + off[(size_t)i], len[(size_t)i]);
+    uint64_t owned = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!_reg_window[win_region[i]]) continue;           // (piece mode: a window of the halo, another context's)
+        ++owned;
+        if (st[i] != HYPO_ST_OK) again.push_back(i);
+        if (keep_arms) all.push_back(i);
+    }
+    _n_pol[lng ? 1 : 0] = owned;
     if (keep_arms || !again.empty()) {
         hw.resize(n);
         rc = (lng ? hypo_gpu_arms_download_long : hypo_gpu_arms_download)(hw.data(), nullptr, nullptr, nullptr, nullptr, nullptr);

@@ -39,6 +39,20 @@ public:
     // slot: the device context (index into the device list of hypo_gpu_init) this object's batches live on; with several
     // devices the contigs of a batch are dealt out to one DeviceArms per context (Hypo::polish)
     explicit DeviceArms(int slot = 0) : _slot(slot) {}
+    // Piece mode (round 4): this context owns [own0, own1) of ONE contig (a batch with fewer contigs than device contexts: BASELINE
+    // config C4 is a single 250 Mbp contig).  It is given the contig's whole tables — the coordinates stay the contig's — but only
+    // the reads that overlap [own0 - halo, own1 + halo); what it counts or builds is adopted where it owns the position: a solid
+    // k-mer / a minimizer by where it lies, a window by where its region starts.  Every read that can vote for an owned k-mer or
+    // give an arm to an owned window lies inside the halo (halo >= longest read span + longest window), and a read's walk over the
+    // k-mers / minimizers of its own span sees all of them, so the owned results are what a single context computes.
+    void set_piece(uint32_t own0, uint32_t own1, uint32_t halo, uint32_t contig_len) {
+        _piece = true; _own0 = own0; _own1 = own1;
+        _span[0] = own0 > halo ? own0 - halo : 0; _span[1] = (uint64_t)own1 + halo < contig_len ? own1 + halo : contig_len;
+    }
+    void clear_piece() { _piece = false; }
+    bool piece() const { return _piece; }
+    bool owns(uint64_t pos) const { return !_piece || (pos >= _own0 && pos < _own1); }
+    uint64_t polished_windows() const { return _n_pol[0] + _n_pol[1]; }       // owned windows the last polish() + polish_long() answered
     DeviceArms(const DeviceArms&) = delete;
     DeviceArms& operator=(const DeviceArms&) = delete;
     ~DeviceArms() { if (_votes) (void)hypo_gpu_host_free(_votes); }
@@ -65,11 +79,19 @@ public:
     bool build_long(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1,
                     std::vector<std::vector<std::unique_ptr<Alignment>>>& store);
     bool active_long() const { return _active_long; }
+    // what build() / build_long() leave behind in the contigs once ALL contexts that work on them are done (piece mode defers it)
+    static void finish_short(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1);
+    static void finish_long(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1, std::vector<std::vector<std::unique_ptr<Alignment>>>& store);
+    void reset_polished() { _n_pol[0] = _n_pol[1] = 0; }
+    void drop() { _active = false; _active_long = false; }      // forget the resident batches (another context of the same contig failed)
+    void drop_long() { _active_long = false; }
     int polish_long(const ScoreParams& sp, bool keep_arms, std::vector<Window*>* retry = nullptr);
     uint64_t num_long_windows() const { return _sum_long.n_windows; }
 
 private:
     int _slot = 0;
+    bool _piece = false; uint32_t _own0 = 0, _own1 = 0, _span[2] = {0, 0};
+    uint64_t _n_pol[2] = {0, 0};
     bool _reads_resident = false; uint32_t _reads_c0 = 0, _reads_c1 = 0;
     bool _active = false;
     HypoArmsSummary _sum{};

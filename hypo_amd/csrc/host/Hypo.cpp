@@ -153,11 +153,18 @@ void Hypo::polish() {
             if (!_alignment_store[c].empty()) { _reads.prepend(c, _alignment_store[c]); _alignment_store[c].clear(); }
 
         // With several devices the contigs of the batch are dealt out to the contexts in contiguous ranges of about equal
-        // numbers of alignments (a batch with fewer contigs than devices stays on the first one): every context keeps the reads of
-        // its contigs, counts their support votes, cuts their arms and polishes its own resident windows; no window travels.
-        std::vector<uint32_t> ctx_cut((size_t)n_ctx + 1, final_cid);
-        ctx_cut[0] = initial_cid;
-        if ((uint32_t)n_ctx > 1 && final_cid - initial_cid >= (uint32_t)n_ctx) {
+        // numbers of alignments: every context keeps the reads of its contigs, counts their support votes, cuts their arms and
+        // polishes its own resident windows; no window travels.  A batch with FEWER contigs than contexts (BASELINE config C4 is one
+        // 250 Mbp contig) shares its contigs out instead (round 4): a contig's contexts each own a coordinate range of it and work
+        // on the reads around that range (DeviceArms::set_piece) — the reference's loop is over the windows of ONE contig too
+        // (src/Hypo.cpp:236-248).
+        struct CtxWork { uint32_t c0 = 0, c1 = 0; bool piece = false; uint32_t own0 = 0, own1 = 0; };
+        std::vector<CtxWork> work((size_t)n_ctx);
+        const uint32_t n_batch_contigs = final_cid - initial_cid;
+        work[0].c0 = initial_cid; work[0].c1 = final_cid;
+        if ((uint32_t)n_ctx > 1 && !_cFlags.host_arms && n_batch_contigs >= (uint32_t)n_ctx) {
+            std::vector<uint32_t> ctx_cut((size_t)n_ctx + 1, final_cid);
+            ctx_cut[0] = initial_cid;
             uint64_t total = 0, acc = 0;
             for (uint32_t c = initial_cid; c < final_cid; ++c) total += _reads.count(c) + 1;
             int d = 1;
@@ -167,20 +174,59 @@ void Hypo::polish() {
                 while (d < n_ctx && acc * (uint64_t)n_ctx >= total * (uint64_t)d && final_cid - (c + 1) >= (uint32_t)(n_ctx - d)) ctx_cut[(size_t)d++] = c + 1;
             }
             for (; d < n_ctx; ++d) ctx_cut[(size_t)d] = std::max(ctx_cut[(size_t)d - 1] + 1, final_cid - (uint32_t)(n_ctx - d));
+            for (int x = 0; x < n_ctx; ++x) { work[(size_t)x].c0 = ctx_cut[(size_t)x]; work[(size_t)x].c1 = ctx_cut[(size_t)x + 1]; }
+        } else if ((uint32_t)n_ctx > 1 && !_cFlags.host_arms && !std::getenv("HYPO_NO_PIECES") && hypo_gpu_reads_upload(nullptr, nullptr, 0) != HYPO_E_UNSUPPORTED) {
+            // (the probe: a library without the resident-read entry points — the CPU test shim — answers HYPO_E_UNSUPPORTED, and the
+            // host loops, which know nothing of pieces, take the batch as before)
+            // contexts per contig: one each, the rest one at a time to the contig with most alignments per context it has
+            std::vector<uint32_t> share(n_batch_contigs, 1);
+            for (uint32_t extra = (uint32_t)n_ctx - n_batch_contigs; extra > 0; --extra) {
+                uint32_t best = 0; double best_load = -1;
+                for (uint32_t i = 0; i < n_batch_contigs; ++i) {
+                    const double load = (double)(_reads.count(initial_cid + i) + 1) / share[i];
+                    if (load > best_load) { best_load = load; best = i; }
+                }
+                ++share[best];
+            }
+            int d = 0;
+            for (uint32_t i = 0; i < n_batch_contigs; ++i) {
+                const uint32_t c = initial_cid + i, len = (uint32_t)_contigs[c]->get_len();
+                for (uint32_t j = 0; j < share[i]; ++j, ++d) {
+                    CtxWork& w = work[(size_t)d];
+                    w.c0 = c; w.c1 = c + 1; w.piece = share[i] > 1;
+                    w.own0 = (uint32_t)((uint64_t)len * j / share[i]); w.own1 = j + 1 == share[i] ? len : (uint32_t)((uint64_t)len * (j + 1) / share[i]);
+                }
+            }
         }
+        for (int d = 0; d < n_ctx; ++d) {
+            const CtxWork& w = work[(size_t)d];
+            if (w.piece) {
+                // halo: the longest read of the contig + the longest window a read at the edge can still reach into
+                const uint32_t halo = _reads.max_span(w.c0) + 2048;
+                device_arms[(size_t)d]->set_piece(w.own0, w.own1, halo, (uint32_t)_contigs[w.c0]->get_len());
+                std::fprintf(stdout, "[Hypo::Hypo] Info: context %d owns [%u, %u) of contig %s (halo %u)\n", d, w.own0, w.own1, _contigs[w.c0]->get_name().c_str(), halo);
+            } else device_arms[(size_t)d]->clear_piece();
+        }
+        auto piece_failed = [&](int d, const char* what) {
+            std::fprintf(stderr, "[Hypo::Hypo] Error: %s failed on context %d, which shares contig %s with other contexts (%s); run on one device or with --host-arms\n",
+                         what, d, _contigs[work[(size_t)d].c0]->get_name().c_str(), hypo_gpu_last_error());
+            std::exit(1);
+        };
         // N1: the reads go to the device once, now; the support votes are counted there (support_kernel.hip) and the arm kernels
         // use the same copy later.  --host-arms, an unsorted file or a device error: the reference's host loops, per contig range.
         start();
         std::vector<char> votes_dev((size_t)n_ctx, 0);         // per context: its reads are resident
         if (!_cFlags.host_arms && !std::getenv("HYPO_HOST_SUPPORT"))
             for (int d = 0; d < n_ctx; ++d) {
-                const uint32_t c0 = ctx_cut[(size_t)d], c1 = ctx_cut[(size_t)d + 1];
+                const uint32_t c0 = work[(size_t)d].c0, c1 = work[(size_t)d].c1;
                 if (c0 < c1) votes_dev[(size_t)d] = device_arms[(size_t)d]->upload_reads(_contigs, c0, c1, _reads) ? 1 : 0;
+                if (c0 < c1 && work[(size_t)d].piece && !votes_dev[(size_t)d]) piece_failed(d, "the upload of the reads");
             }
         for (int d = 0; d < n_ctx; ++d) {
-            const uint32_t c0 = ctx_cut[(size_t)d], c1 = ctx_cut[(size_t)d + 1];
+            const uint32_t c0 = work[(size_t)d].c0, c1 = work[(size_t)d].c1;
             if (c0 >= c1) continue;
             if (votes_dev[(size_t)d] && device_arms[(size_t)d]->support_kmers(_contigs, c0, c1, _cFlags.k)) continue;
+            if (work[(size_t)d].piece) piece_failed(d, "the k-mer support votes");
             materialize_alignments(c0, c1, materialized);
             for (uint32_t cid = c0; cid < c1; ++cid) {
                 _contigs[cid]->ensure_kids();
@@ -213,9 +259,10 @@ void Hypo::polish() {
 
         start();
         for (int d = 0; d < n_ctx; ++d) {
-            const uint32_t c0 = ctx_cut[(size_t)d], c1 = ctx_cut[(size_t)d + 1];
+            const uint32_t c0 = work[(size_t)d].c0, c1 = work[(size_t)d].c1;
             if (c0 >= c1) continue;
             if (votes_dev[(size_t)d] && device_arms[(size_t)d]->support_minimizers(_contigs, c0, c1)) continue;
+            if (work[(size_t)d].piece) piece_failed(d, "the minimizer support votes");
             materialize_alignments(c0, c1, materialized);
             for (uint32_t cid = c0; cid < c1; ++cid) {
                 auto& alns = _alignment_store[cid];
@@ -238,11 +285,13 @@ void Hypo::polish() {
         std::vector<char> long_dev(final_cid - initial_cid, 0);  // ... and its long arms (LONG windows resident on the device)
         if (!_cFlags.host_arms) {
             for (int d = 0; d < n_ctx; ++d) {
-                const uint32_t c0 = ctx_cut[(size_t)d], c1 = ctx_cut[(size_t)d + 1];
+                const uint32_t c0 = work[(size_t)d].c0, c1 = work[(size_t)d].c1;
                 if (c0 >= c1) continue;
                 if (device_arms[(size_t)d]->build(_contigs, c0, c1, _reads, _cFlags.k))
                     for (uint32_t c = c0; c < c1; ++c) on_dev[c - initial_cid] = 1;
+                else if (work[(size_t)d].piece) piece_failed(d, "short-arm selection");
             }
+            for (int d = 0; d < n_ctx; ++d) if (work[(size_t)d].piece) DeviceArms::finish_short(_contigs, work[(size_t)d].c0, work[(size_t)d].c1);
             hypo_gpu_use_device(0);
         }
         for (uint32_t cid = initial_cid; cid < final_cid; ++cid) {
@@ -282,10 +331,22 @@ void Hypo::polish() {
             std::vector<char> long_on_dev(final_cid - initial_cid, 0);
             if (!_cFlags.host_arms) {
                 for (int d = 0; d < n_ctx; ++d) {
-                    const uint32_t c0 = ctx_cut[(size_t)d], c1 = ctx_cut[(size_t)d + 1];
+                    const uint32_t c0 = work[(size_t)d].c0, c1 = work[(size_t)d].c1;
                     if (c0 >= c1) continue;
                     if (device_arms[(size_t)d]->build_long(_contigs, c0, c1, _alignment_store))
-                        for (uint32_t c = c0; c < c1; ++c) long_on_dev[c - initial_cid] = 1;
+                        for (uint32_t c = c0; c < c1; ++c) long_on_dev[c - initial_cid] |= 1;
+                    else if (work[(size_t)d].piece) long_on_dev[c0 - initial_cid] |= 2;      // (a shared contig: all of its contexts or none)
+                }
+                for (int d = 0; d < n_ctx; ++d) {
+                    if (!work[(size_t)d].piece) continue;
+                    const uint32_t c = work[(size_t)d].c0;
+                    if (long_on_dev[c - initial_cid] & 2) device_arms[(size_t)d]->drop_long();
+                }
+                for (uint32_t c = initial_cid; c < final_cid; ++c) {
+                    char& f = long_on_dev[c - initial_cid];
+                    const bool shared = f != 0 && n_batch_contigs < (uint32_t)n_ctx;
+                    if (f & 2) f = 0;
+                    else if (f == 1 && shared) DeviceArms::finish_long(_contigs, c, c + 1, _alignment_store);
                 }
                 hypo_gpu_use_device(0);
             }
@@ -324,17 +385,19 @@ void Hypo::polish() {
             std::vector<std::thread> th;
             for (int d = 0; d < n_ctx; ++d) {
                 DeviceArms& da = *device_arms[(size_t)d];
+                da.reset_polished();
                 if (!da.active() && !da.active_long()) continue;
-                n_resident += (da.active() ? da.num_windows() : 0) + (da.active_long() ? da.num_long_windows() : 0);
-                auto work = [&, d] {
+
+                auto job = [&, d] {
                     DeviceArms& me = *device_arms[(size_t)d];
                     prc[(size_t)d] = me.polish(_cFlags.score_params, dump.is_open(), &retry[(size_t)d]);
                     if (prc[(size_t)d] == HYPO_OK) prc[(size_t)d] = me.polish_long(_cFlags.score_params, dump.is_open(), &retry[(size_t)d]);
                     if (prc[(size_t)d] != HYPO_OK) perr[(size_t)d] = hypo_gpu_last_error();
                 };
-                if (n_ctx == 1) work(); else th.emplace_back(work);
+                if (n_ctx == 1) job(); else th.emplace_back(job);
             }
             for (auto& t : th) t.join();
+            for (int d = 0; d < n_ctx; ++d) n_resident += device_arms[(size_t)d]->polished_windows();      // (windows a context owns: its halo's are another's)
             hypo_gpu_use_device(0);
             for (int d = 0; d < n_ctx; ++d) {
                 if (prc[(size_t)d] != HYPO_OK) { std::fprintf(stderr, "[Hypo::Window] Error: %s\n", perr[(size_t)d].c_str()); std::exit(1); }
@@ -590,15 +653,16 @@ void Hypo::create_alignments_flat(uint32_t batch_id, ReadBatch& into) {
     if (rs.carry_blk) { into.add(rs.carry_blk, rs.carry_r0, rs.carry_r1); rs.carry_blk.reset(); }
     bool stop = false, more_ahead = true;
     double t_wait = 0, t_par = 0, t_col = 0; auto now = []{ return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    if (!rs.reader) { rs.reader.reset(new BlockReader()); rs.reader->start(&sf); }
     while (!stop) {
-        std::thread reader;
+        bool asked = false;
         const double t0 = now();
         if (!rs.parsed || rs.ppos >= rs.parsed->n) {
             if (rs.have_ahead) { std::swap(rs.cur, rs.ahead); rs.have_ahead = false; }
             else if (rs.more) rs.more = sf.read_block(rs.cur, kBlock, kBlockBytes);
             else break;
             if (rs.cur.n() == 0) { if (!rs.more) break; continue; }
-            if (rs.more && !rs.have_ahead) reader = std::thread([&] { more_ahead = sf.read_block(rs.ahead, kBlock, kBlockBytes); });
+            if (rs.more && !rs.have_ahead) { rs.reader->request(&rs.ahead, kBlock, kBlockBytes); asked = true; }
             std::shared_ptr<ParsedBlock> blk;
             {
                 std::lock_guard<std::mutex> lk(_pool_mu);
@@ -635,7 +699,7 @@ void Hypo::create_alignments_flat(uint32_t batch_id, ReadBatch& into) {
         } else rs.ppos = B.n;
         const double t3 = now();
         t_col += t3 - t2;
-        if (reader.joinable()) { reader.join(); rs.more = more_ahead; rs.have_ahead = rs.ahead.n() > 0; }
+        if (asked) { more_ahead = rs.reader->wait(); rs.more = more_ahead; rs.have_ahead = rs.ahead.n() > 0; }
         t_wait += now() - t3;
     }
     if (std::getenv("HYPO_HOST_TIMING")) std::fprintf(stderr, "[timing] create_alignments_flat: waiting for records %.3f s, parse %.3f s, into the batch %.3f s\n", t_wait, t_par, t_col);

@@ -4,7 +4,10 @@
 // (all valid windows of a contig batch in ONE Window::generate_consensus_batch call).
 #pragma once
 #include <chrono>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -36,7 +39,38 @@ private:
     std::unique_ptr<SamReader> _sf_short, _sf_long;
     // per alignment file: the block of raw records being consumed (a contig batch may end in the middle of it), the block a
     // reader thread fetched meanwhile, and whether the file has more
+    // One long-lived thread per alignment file that fetches the next block of raw records when asked (BGZF: inflates a run of blocks
+    // on its own team of threads, which lives as long as it does: a thread per block had to raise a new team of 64-128 threads 1 300
+    // times on the 3 Gbp set).
+    struct BlockReader {
+        std::thread th; std::mutex mu; std::condition_variable cv;
+        SamReader* sf = nullptr; SamReader::RecordBlock* dst = nullptr; size_t max_rec = 0, max_bytes = 0;
+        bool pending = false, done = false, quit = false, more = false;
+        void start(SamReader* s) {
+            sf = s;
+            th = std::thread([this] {
+                std::unique_lock<std::mutex> lk(mu);
+                for (;;) {
+                    cv.wait(lk, [this] { return pending || quit; });
+                    if (quit) return;
+                    lk.unlock();
+                    const bool m = sf->read_block(*dst, max_rec, max_bytes);
+                    lk.lock();
+                    more = m; pending = false; done = true;
+                    cv.notify_all();
+                }
+            });
+        }
+        void request(SamReader::RecordBlock* d, size_t n, size_t b) {
+            std::lock_guard<std::mutex> lk(mu);
+            dst = d; max_rec = n; max_bytes = b; pending = true; done = false;
+            cv.notify_all();
+        }
+        bool wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [this] { return done; }); done = false; return more; }
+        ~BlockReader() { { std::lock_guard<std::mutex> lk(mu); quit = true; cv.notify_all(); } if (th.joinable()) th.join(); }
+    };
     struct RecordStream {
+        std::unique_ptr<BlockReader> reader;
         SamReader::RecordBlock cur, ahead; size_t pos = 0; bool have_ahead = false, more = true;
         // flat path (short reads): the parsed form of `cur`, how far it has been consumed, and the one record a call consumed for
         // a contig of a later batch (the reference files it in that contig's store entry, src/Hypo.cpp:314-325)

@@ -65,6 +65,18 @@ void ReadBatch::add(const std::shared_ptr<ParsedBlock>& blk, size_t r0, size_t r
     }
 }
 
+uint32_t ReadBatch::max_span(uint32_t cid) const {
+    uint32_t best = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(max : best)
+    for (int64_t s = 0; s < (int64_t)_slices.size(); ++s) {
+        const Slice& sl = _slices[(size_t)s];
+        const ReadChunk& ch = sl.blk->chunks[sl.chunk];
+        for (uint32_t k = sl.k0; k < sl.k1; ++k)
+            if ((uint32_t)ch.cid[k] == cid && ch.re[k] - ch.rb[k] > best) best = ch.re[k] - ch.rb[k];
+    }
+    return best;
+}
+
 void ReadBatch::append(ReadBatch& other) {
     for (auto& s : other._slices) _slices.push_back(std::move(s));
     if (other._per_contig.size() > _per_contig.size()) _per_contig.resize(other._per_contig.size(), 0);
@@ -106,9 +118,10 @@ void ReadBatch::clear(std::vector<std::shared_ptr<ParsedBlock>>* pool, std::mute
     _n = 0;
 }
 
-bool ReadBatch::flatten(uint32_t c0, uint32_t c1, const std::vector<uint64_t>& base, ReadStaging& out, bool& sorted) const {
+bool ReadBatch::flatten(uint32_t c0, uint32_t c1, const std::vector<uint64_t>& base, ReadStaging& out, bool& sorted, const uint32_t* span) const {
     struct Run { uint32_t slice, k0, k1; int32_t cid; uint64_t at, bytes, cigs, byte_at, cig_at; };
     std::vector<Run> runs;
+    std::vector<uint64_t> taken(c1 - c0, 0);
     for (uint32_t s = 0; s < _slices.size(); ++s) {
         const Slice& sl = _slices[s];
         const ReadChunk& ch = sl.blk->chunks[sl.chunk];
@@ -117,14 +130,25 @@ bool ReadBatch::flatten(uint32_t c0, uint32_t c1, const std::vector<uint64_t>& b
             const int32_t id = ch.cid[k];
             uint32_t e = k + 1;
             while (e < sl.k1 && ch.cid[e] == id) ++e;
-            if ((uint32_t)id >= c0 && (uint32_t)id < c1)
-                runs.push_back(Run{s, k, e, id, 0, (uint64_t)ch.seq_at[e] - ch.seq_at[k], (uint64_t)ch.cig_at[e] - ch.cig_at[k], 0, 0});
+            if ((uint32_t)id >= c0 && (uint32_t)id < c1) {
+                if (!span) { runs.push_back(Run{s, k, e, id, 0, (uint64_t)ch.seq_at[e] - ch.seq_at[k], (uint64_t)ch.cig_at[e] - ch.cig_at[k], 0, 0}); taken[(uint32_t)id - c0] += e - k; }
+                else {                                   // stretches of records that overlap the span
+                    uint32_t a = k;
+                    while (a < e) {
+                        while (a < e && !(ch.rb[a] < span[1] && ch.re[a] > span[0])) ++a;
+                        uint32_t b = a;
+                        while (b < e && ch.rb[b] < span[1] && ch.re[b] > span[0]) ++b;
+                        if (b > a) { runs.push_back(Run{s, a, b, id, 0, (uint64_t)ch.seq_at[b] - ch.seq_at[a], (uint64_t)ch.cig_at[b] - ch.cig_at[a], 0, 0}); taken[(uint32_t)id - c0] += b - a; }
+                        a = b;
+                    }
+                }
+            }
             k = e;
         }
     }
     // where every run goes: contigs in order, a contig's runs in file order
     std::vector<uint64_t> first(c1 - c0 + 1, 0);
-    for (uint32_t c = c0; c < c1; ++c) first[c - c0 + 1] = first[c - c0] + count(c);
+    for (uint32_t c = c0; c < c1; ++c) first[c - c0 + 1] = first[c - c0] + taken[c - c0];
     std::vector<uint64_t> seen(c1 - c0, 0);
     for (Run& r : runs) { r.at = first[(uint32_t)r.cid - c0] + seen[(uint32_t)r.cid - c0]; seen[(uint32_t)r.cid - c0] += r.k1 - r.k0; }
     std::vector<uint32_t> order(runs.size());

@@ -66,10 +66,13 @@ public:
     uint64_t size() const { return _n; }
     uint64_t count(uint32_t cid) const { return cid < _per_contig.size() ? _per_contig[cid] : 0; }
     bool empty() const { return _slices.empty(); }
+    uint32_t max_span(uint32_t cid) const;                          // longest reference span among the records of contig cid
     // The records of contigs [c0, c1) in `out`: contig after contig (contig c starts at base[c - c0] of the coordinate space), each
     // contig's records in file order.  `sorted` = every contig's records came with non-decreasing rb; when they did not they are
     // sorted by rb here (stably) and out.file_rank holds their places in the file (out.ranked).  false: no memory.
-    bool flatten(uint32_t c0, uint32_t c1, const std::vector<uint64_t>& base, ReadStaging& out, bool& sorted) const;
+    // span != nullptr (one contig only): the records that overlap [span[0], span[1]) of the contig — a device context that owns a
+    // coordinate range of a large contig takes the reads its windows, k-mers and minimizers can see.
+    bool flatten(uint32_t c0, uint32_t c1, const std::vector<uint64_t>& base, ReadStaging& out, bool& sorted, const uint32_t* span = nullptr) const;
     // Alignment objects for contig cid (the reference's store entry), appended to `into`
     void materialize(uint32_t cid, std::vector<std::unique_ptr<Alignment>>& into) const;
     // the records of contigs >= first_cid as a batch of their own (copied into a block of its own): what a later batch inherits

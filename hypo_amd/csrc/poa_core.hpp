@@ -146,7 +146,10 @@ struct PoaCfg {
     static constexpr int ARMBYTES = ARMBYTES_;  // packed arm bytes staged per window
     static constexpr int SEQMAX = SEQMAX_;      // sequences (arms + backbone) per window
     static constexpr int AL = 6;                // aligned clique partners (alphabet ACGTNJO -> at most 6)
-    static constexpr int STK = HYBRID_ ? 1536 : 2 * NMAX_;   // DFS stack entries (hybrid: the LDS copy is smaller; deeper DFS -> next class)
+#ifndef HYPO_HYB_STK
+#define HYPO_HYB_STK 1536
+#endif
+    static constexpr int STK = HYBRID_ ? HYPO_HYB_STK : 2 * NMAX_;   // DFS stack entries (hybrid: the LDS copy is smaller; deeper DFS -> next class)
     #ifndef HYPO_RING1
 #define HYPO_RING1 6
 #endif

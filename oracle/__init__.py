@@ -289,9 +289,19 @@ class RefArms:
         pos, coff, cig, soff, seq = records
         inv = C.c_uint64(0)
         if long_records is not None:
-            self.lib.hyporef_arms_long.restype = C.c_long
+            # hypo::Contig::set_no_long_reads() (which the short-read entry point calls, as src/Hypo.cpp:230-232 does for a run without
+            # -B) sets a static flag for the rest of the process and the reference has nothing that clears it: the long-read stage
+            # runs in a second, private copy of the library (its own statics), whatever ran before in this process
+            if getattr(self, "_long_lib", None) is None:
+                import shutil
+                import tempfile
+                self._long_dir = tempfile.mkdtemp(prefix="hyporef_long_")
+                dst = os.path.join(self._long_dir, "libhyporef_arms_long.so")
+                shutil.copy(REF_ARMS_SO, dst)
+                self._long_lib = C.CDLL(dst)
+                self._long_lib.hyporef_arms_long.restype = C.c_long
             lpos, lcoff, lcig, lsoff, lseq = long_records
-            rc = self.lib.hyporef_arms_long(contig_seq, C.c_uint64(len(contig_seq)), C.c_uint32(k), bvsd_path.encode(),
+            rc = self._long_lib.hyporef_arms_long(contig_seq, C.c_uint64(len(contig_seq)), C.c_uint32(k), bvsd_path.encode(),
                                             C.c_uint32(len(pos)), _ptr(pos), _ptr(coff), _ptr(cig), _ptr(soff), seq,
                                             C.c_uint32(len(lpos)), _ptr(lpos), _ptr(lcoff), _ptr(lcig), _ptr(lsoff), lseq,
                                             work_dir.encode(), C.byref(inv))

@@ -149,9 +149,13 @@ def run_fast_case(name, outdir, threads, extra_args=(), extra_env=None, timeout=
     a = man["args"]
     gen = build_fast_generator()
     rep = json.loads(subprocess.check_output([gen, str(outdir), str(a["seed"]), str(a["contigs"]), str(a["contig_len"]), str(a["k"]),
-                                              str(a["coverage"]), str(a["read_len"]), str(a["read_sub_ppm"])] + (["--bam"] if bam else []), text=True))
+                                              str(a["coverage"]), str(a["read_len"]), str(a["read_sub_ppm"])] +
+                                             (list(a["flags"]) if "flags" in a else (["--bam"] if bam else [])), text=True))
     want = man["generator_report"]
-    if bam:
+    if "flags" in a:                                 # a golden made from the flagged output itself (BAM): everything must match
+        bam = "--bam" in a["flags"]
+        assert rep == want, f"{name}: the generator's output changed: {rep}"
+    elif bam:
         assert "fnv_bam_blocks" in rep
         for key in ("contigs", "draft_bases", "reads", "solid_kmers", "fnv_draft", "fnv_bitvector"):
             assert rep[key] == want[key], f"{name}: the generator's output changed: {key} = {rep[key]}"
@@ -160,6 +164,8 @@ def run_fast_case(name, outdir, threads, extra_args=(), extra_env=None, timeout=
     argv = [BIN] + man["command"].split()[1:]
     if bam:
         argv[argv.index("-b") + 1] = "sr.bam"
+    if "-B" in argv and bam:
+        argv[argv.index("-B") + 1] = "lr.bam"
     argv[argv.index("-t") + 1] = str(threads)
     argv += list(extra_args)
     env = dict(os.environ)

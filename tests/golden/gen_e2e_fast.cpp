@@ -34,6 +34,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <algorithm>
 #include <string>
 #include <thread>
 #include <vector>
@@ -218,6 +219,7 @@ void make_contig(Contig& c, uint64_t seed, int idx, uint32_t G, uint32_t cov, ui
         const uint32_t ll = ex.long_len;
         const uint32_t pstart = (uint32_t)((double)ex.long_cov / ll * 1e9);      // starts per 1e9 positions
         uint64_t lid = 0;
+        std::vector<std::pair<uint64_t, std::string>> sorted_recs;       // (position, record): trimming a read's leading non-M operations can move its start past its successor's
         std::string lseq_s, lcig, lrec;
         std::vector<uint32_t> lops;
         for (uint32_t s = 0; s + ll < G; ++s) {
@@ -256,7 +258,8 @@ void make_contig(Contig& c, uint64_t seed, int idx, uint32_t G, uint32_t cov, ui
             emit();
             const uint64_t pos0 = ex.pos_off + dprefix[i0] + lead_ref;      // 0-based position of the first M in the (joined) draft
             if (!bam) {
-                std::string& lo = c.lrecs;
+                sorted_recs.emplace_back(pos0, std::string());
+                std::string& lo = sorted_recs.back().second;
                 lo.push_back('l'); append_uint(lo, lid++); lo.append("\t0\t"); lo.append(name, (size_t)nl); lo.push_back('\t');
                 append_uint(lo, pos0 + 1); lo.append("\t60\t"); lo += lcig; lo.append("\t*\t0\t0\t"); lo += lseq_s; lo.append("\t*\tNM:i:"); append_uint(lo, nm); lo.push_back('\n');
             } else {
@@ -277,9 +280,11 @@ void make_contig(Contig& c, uint64_t seed, int idx, uint32_t G, uint32_t cov, ui
                 }
                 memset(p, 0xff, (size_t)lseq); p += lseq;
                 *p++ = 'N'; *p++ = 'M'; *p++ = 'I'; memcpy(p, &nm, 4);
-                lbz.put(lrec.data(), lrec.size());
+                sorted_recs.emplace_back(pos0, lrec);
             }
         }
+        std::stable_sort(sorted_recs.begin(), sorted_recs.end(), [](const std::pair<uint64_t, std::string>& a, const std::pair<uint64_t, std::string>& b) { return a.first < b.first; });
+        for (const auto& pr : sorted_recs) { if (bam) lbz.put(pr.second.data(), pr.second.size()); else c.lrecs += pr.second; }
         if (bam) lbz.flush();
         c.n_long = lid;
     }
