@@ -263,7 +263,9 @@ bool DeviceArms::build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c
             type[r] = (uint8_t)ctg._reg_type[i];
             info[r] = ctg._reg_info[i] + (ctg._reg_type[i] == RegionType::SR ? sr_before : 0u);
             _reg_window[r] = ctg._pwindows[i].get();
-            if (type[r] != (uint8_t)RegionType::SR && type[r] != (uint8_t)RegionType::MSR && !_reg_window[r]) bad = true;   // (never: every non-SR region has a window here)
+            // (never: every non-SR region has a window here — unless another context of a shared contig has already pruned a window
+            // it owns: not this context's business)
+            if (!_piece && type[r] != (uint8_t)RegionType::SR && type[r] != (uint8_t)RegionType::MSR && !_reg_window[r]) bad = true;
         }
         if (ctg._anchor_kmers.size() > 1) std::memcpy(anchors + 1 + abase[(size_t)ci], ctg._anchor_kmers.data() + 1, (ctg._anchor_kmers.size() - 1) * 8);
         std::memcpy(contig4 + base / 2, ctg._pseq.data(), ctg._pseq.byte_size());

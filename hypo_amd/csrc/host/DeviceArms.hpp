@@ -14,26 +14,6 @@
 
 namespace hypo {
 
-// a page-locked, grow-only buffer (hypo_gpu_host_alloc; plain memory when the library has none to give)
-struct PinnedBuf {
-    void* p = nullptr; size_t cap = 0; bool pinned = false;
-    template <class T> T* get(size_t n) {
-        const size_t bytes = n * sizeof(T) + 64;
-        if (bytes > cap) {
-            release();
-            const size_t want = bytes + bytes / 4;
-            if (hypo_gpu_host_alloc(want, &p) == HYPO_OK && p) pinned = true; else { p = std::malloc(want); pinned = false; }
-            cap = p ? want : 0;
-        }
-        return (T*)p;
-    }
-    void release() { if (p) { if (pinned) (void)hypo_gpu_host_free(p); else std::free(p); } p = nullptr; cap = 0; }
-    PinnedBuf() = default;
-    PinnedBuf(const PinnedBuf&) = delete;
-    PinnedBuf& operator=(const PinnedBuf&) = delete;
-    ~PinnedBuf() { release(); }
-};
-
 class DeviceArms {
 public:
     // slot: the device context (index into the device list of hypo_gpu_init) this object's batches live on; with several

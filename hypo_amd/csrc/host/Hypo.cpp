@@ -207,6 +207,7 @@ void Hypo::polish() {
                 std::fprintf(stdout, "[Hypo::Hypo] Info: context %d owns [%u, %u) of contig %s (halo %u)\n", d, w.own0, w.own1, _contigs[w.c0]->get_name().c_str(), halo);
             } else device_arms[(size_t)d]->clear_piece();
         }
+        (void)hypo_gpu_last_error();
         auto piece_failed = [&](int d, const char* what) {
             std::fprintf(stderr, "[Hypo::Hypo] Error: %s failed on context %d, which shares contig %s with other contexts (%s); run on one device or with --host-arms\n",
                          what, d, _contigs[work[(size_t)d].c0]->get_name().c_str(), hypo_gpu_last_error());
@@ -686,7 +687,10 @@ void Hypo::create_alignments_flat(uint32_t batch_id, ReadBatch& into) {
             if (st == ParsedBlock::ST_SKIPPED) continue;
             if (st == ParsedBlock::ST_BADREF) {
                 std::fprintf(stderr, "[Hypo::Hypo] Error: Alignment File error: Contig-reference of record %s does not exist in the draft!\n", B.bad_ref_name.c_str());
-                std::exit(1);
+                // (this may be the helper thread, with the main thread inside a device call: leave without running the static
+                // destructors under it)
+                std::fflush(nullptr);
+                std::_Exit(1);
             }
             if (st == ParsedBlock::ST_KEPT) ++num_alns; else ++num_invalid;
             if ((uint32_t)B.cid[i] >= final_cid) { s_first = i; break; }

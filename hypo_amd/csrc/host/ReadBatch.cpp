@@ -7,39 +7,11 @@
 
 namespace hypo {
 
-namespace {
-// page-locked when the device library provides it (the CPU test shim hands out plain memory)
-void* staging_alloc(size_t bytes) {
-    void* p = nullptr;
-    if (hypo_gpu_host_alloc(bytes, &p) == HYPO_OK && p) return p;
-    return nullptr;
-}
-template <class T> bool grow(T*& p, size_t& cap_holder, size_t want, size_t elems_extra) {
-    (void)cap_holder;
-    T* q = (T*)staging_alloc((want + elems_extra) * sizeof(T));
-    if (!q) return false;
-    if (p) (void)hypo_gpu_host_free(p);
-    p = q;
-    return true;
-}
-}  // namespace
-
 bool ReadStaging::reserve(size_t reads, size_t cig, size_t bytes) {
-    if (reads > cap_reads || !rb) {
-        const size_t want = reads + reads / 8 + 1024;
-        size_t dummy = 0;
-        if (!grow(rb, dummy, want, 1) || !grow(re, dummy, want, 1) || !grow(qae, dummy, want, 1) || !grow(ctg, dummy, want, 1) ||
-            !grow(cigar_off, dummy, want, 2) || !grow(seq_off, dummy, want, 2) || !grow(file_rank, dummy, want, 1)) return false;
-        cap_reads = want;
-    }
-    if (cig > cap_cigar || !cigar) { const size_t want = cig + cig / 8 + 1024; size_t d = 0; if (!grow(cigar, d, want, 1)) return false; cap_cigar = want; }
-    if (bytes > cap_bytes || !reads2) { const size_t want = bytes + bytes / 8 + 4096; size_t d = 0; if (!grow(reads2, d, want, 16)) return false; cap_bytes = want; }
-    return true;
-}
-void ReadStaging::release() {
-    for (void* p : {(void*)rb, (void*)re, (void*)qae, (void*)ctg, (void*)cigar_off, (void*)cigar, (void*)seq_off, (void*)reads2, (void*)file_rank}) if (p) (void)hypo_gpu_host_free(p);
-    rb = re = qae = ctg = cigar_off = cigar = file_rank = nullptr; seq_off = nullptr; reads2 = nullptr;
-    cap_reads = cap_cigar = cap_bytes = 0;
+    rb = _b[0].get<uint32_t>(reads + 1); re = _b[1].get<uint32_t>(reads + 1); qae = _b[2].get<uint32_t>(reads + 1); ctg = _b[3].get<uint32_t>(reads + 1);
+    cigar_off = _b[4].get<uint32_t>(reads + 2); seq_off = _b[5].get<uint64_t>(reads + 2); file_rank = _b[6].get<uint32_t>(reads + 1);
+    cigar = _b[7].get<uint32_t>(cig + 1); reads2 = _b[8].get<uint8_t>(bytes + 16);
+    return rb && re && qae && ctg && cigar_off && seq_off && file_rank && cigar && reads2;
 }
 
 void ReadBatch::add(const std::shared_ptr<ParsedBlock>& blk, size_t r0, size_t r1) {

@@ -10,11 +10,13 @@
 // when a host loop of the reference has to run (materialize(): --host-arms, an unsorted file, a device error, the CPU test shim).
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
+#include "../../../include/hypo_gpu.h"
 #include "Alignment.hpp"
 
 namespace hypo {
@@ -41,17 +43,40 @@ struct ParsedBlock {
     enum : uint8_t { ST_KEPT = 0, ST_SKIPPED = 1, ST_BADREF = 2, ST_INVALID = 3 };
 };
 
+// A grow-only buffer, page-locked (hypo_gpu_host_alloc) from 4 MB on: copies from / into it run at the link's rate.  Small ones
+// are plain memory — pinning has a per-call cost (a millisecond or more) that a 5 Mbp run, with two dozen staging arrays, would
+// pay for nothing — and so is everything when the library has no pinned memory to give (the CPU test shim).
+struct PinnedBuf {
+    void* p = nullptr; size_t cap = 0; bool pinned = false;
+    template <class T> T* get(size_t n) {
+        const size_t bytes = n * sizeof(T) + 64;
+        if (bytes > cap) {
+            release();
+            const size_t want = bytes + bytes / 4;
+            void* q = nullptr;
+            if (want >= ((size_t)4 << 20) && hypo_gpu_host_alloc(want, &q) == HYPO_OK && q) { p = q; pinned = true; }
+            else { p = std::malloc(want); pinned = false; }
+            cap = p ? want : 0;
+        }
+        return (T*)p;
+    }
+    void release() { if (p) { if (pinned) (void)hypo_gpu_host_free(p); else std::free(p); } p = nullptr; cap = 0; }
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf() { release(); }
+};
+
 // Page-locked staging arrays of one device context (hypo_gpu_host_alloc; grow-only, reused by every batch): what
 // hypo_gpu_reads_upload takes.
 struct ReadStaging {
     uint32_t *rb = nullptr, *re = nullptr, *qae = nullptr, *ctg = nullptr, *cigar_off = nullptr, *cigar = nullptr;
     uint64_t* seq_off = nullptr; uint8_t* reads2 = nullptr;
     uint32_t* file_rank = nullptr; bool ranked = false;      // ranked: the records were NOT sorted in the file; they are here, and file_rank says where each one was
-    size_t cap_reads = 0, cap_cigar = 0, cap_bytes = 0;
     uint64_t n_reads = 0, n_cigar = 0, n_bytes = 0;
     bool reserve(size_t reads, size_t cig, size_t bytes);          // false: no memory
-    void release();
-    ~ReadStaging() { release(); }
+private:
+    PinnedBuf _b[9];
 };
 
 class ReadBatch {

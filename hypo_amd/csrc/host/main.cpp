@@ -56,7 +56,7 @@ void usage() {
         {"-q, --qual-map-th <int>", "Reads mapped with a quality below this are ignored.", "2"},
         {"-i, --intermed", "Keep and reuse intermediate files (aux/solid_kmers.bvsd). Needed here: k-mer counting (KMC) is not part of this build.", nullptr},
         {"    --device <int>", "[MI355X build] HIP device to run on.", "0"},
-        {"    --gpus <int>", "[MI355X build] Use devices 0..N-1: the windows of a contig batch are sharded over them, results gathered with RCCL.", "1"},
+        {"    --gpus <int>", "[MI355X build] Use devices 0..N-1, one context each: the contigs of a batch are dealt out to them (a contig larger than its share is cut into coordinate ranges), every context votes, cuts arms and polishes its own resident windows; windows that exist as host objects are sharded with an RCCL gather.", "1"},
         {"    --devices <list>", "[MI355X build] Comma-separated HIP device ids instead of --device / --gpus.", nullptr},
         {"    --native-klov", "[MI355X build] Choose the end row of prefix arms like the AVX2 / SSE4.1 alignment engine of a -march=native build of the reference does (the default follows the scalar engine of the reference's default build; the two differ on noisy prefix arms).", "off"},
         {"    --ccs-windows", "[MI355X build] Cut windows with the sizes -k ccs was meant to select (ideal length 500, search threshold 400; the reference parses -k but never applies it).", "off"},
@@ -107,7 +107,15 @@ int main(int argc, char** argv) {
     // device calls and helper threads (record reader, releasers, the HIP runtime's own), and libgomp's default lets idle workers
     // spin — measured on the 100 x 1 Mbp set, -t 64: 8.98 s spinning, 4.77 s sleeping (profiles/diag/r03_c3_threads.sh).  libgomp
     // reads the policy when it is loaded, i.e. before main(): set it and start over once.
-    if (!getenv("OMP_WAIT_POLICY") && !getenv("HYPO_NO_REEXEC")) {
+    // HYPO_NO_REEXEC=1 (or an OMP_WAIT_POLICY of the caller's own) opts out; a traced process (debugger, strace, profilers that
+    // attach) is never re-executed either — it would lose its tracer's state.
+    auto traced = [] {
+        std::ifstream st("/proc/self/status");
+        std::string key; long v = 0;
+        while (st >> key) { if (key == "TracerPid:") { st >> v; return v != 0; } st.ignore(4096, '\n'); }
+        return false;
+    };
+    if (!getenv("OMP_WAIT_POLICY") && !getenv("HYPO_NO_REEXEC") && !traced()) {
         setenv("OMP_WAIT_POLICY", "passive", 1);
         setenv("HYPO_NO_REEXEC", "1", 1);
         execv("/proc/self/exe", argv);                          // (if this fails the run goes on with the default policy)

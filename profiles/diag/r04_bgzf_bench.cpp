@@ -1,0 +1,20 @@
+#include "../../hypo_amd/csrc/host/SeqIO.hpp"
+#include <chrono>
+#include <omp.h>
+int main(int argc, char** argv) {
+    hypo::SamReader sf(argv[1]);
+    const int nt = atoi(argv[2]);
+    sf.set_inflate_threads(nt);
+    hypo::SamReader::RecordBlock b;
+    size_t n = 0, bytes = 0; int blocks = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    double tcut = 0;
+    while (blocks < 100000) {
+        bool more = sf.read_block(b, 1 << 19, (size_t)128 << 20);
+        n += b.n(); for (size_t i = 0; i < b.n(); i += 1000) bytes += b.len(i);
+        ++blocks;
+        if (!more && b.n() == 0) break;
+    }
+    double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("%zu records in %.2f s = %.1f M rec/s (%d blocks) ~%.2f GB/s inflated\n", n, dt, n / dt / 1e6, blocks, n * 284.0 / dt / 1e9);
+}
