@@ -238,6 +238,11 @@ def end_to_end_k15_leg():
                                "250 Mbp at the k of C4 end to end: 250 x 1 Mbp draft, 30x 150-bp reads (49.7 M records as BAM), -s 250m -> k = 15 (128 MiB solid set, dense tiny-window shape), -p 10, one run")
 
 
+def end_to_end_c4_leg():
+    return end_to_end_fast_leg("e2e_c4_250m_s77", True,
+                               "C4 at size end to end: ONE 250 Mbp contig, 30x 150-bp reads with coverage gaps (48.9 M records, BAM) + 40x noisy 8 kbp long reads (1.24 M records, -B, BAM), k = 15, one batch (3.7 M SHORT + ~10 k LONG windows), one run")
+
+
 def end_to_end_1g_leg():
     return end_to_end_fast_leg("e2e_1g_s91", True,
                                "Row T1 at 1 Gbp end to end: 1000 x 1 Mbp draft, 30x 150-bp reads (198.8 M records as BAM), -s 1g -> k = 15, -p 10, hypo binary = host pipeline + device on ONE MI355X, one run")
@@ -328,6 +333,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-e2e-c3", action="store_true", help="skip the 100 Mbp end-to-end run (about a minute and 4 GB of scratch files)")
     ap.add_argument("--no-e2e-k15", action="store_true", help="skip the 250 Mbp / k = 15 end-to-end run (BAM input, about half a minute)")
+    ap.add_argument("--no-e2e-c4", action="store_true", help="skip the C4-at-size end-to-end run (one 250 Mbp contig, short + long reads, about a minute)")
     ap.add_argument("--no-e2e-1g", action="store_true", help="skip the 1 Gbp end-to-end run (BAM input, about a minute of input generation + half a minute)")
     ap.add_argument("--t1-contigs", type=int, default=int(os.environ.get("HYPO_BENCH_T1_CONTIGS", "0")),
                     help="also run row T1 end to end on this many 1 Mbp contigs (3000 = the north star's 3 Gbp; needs ~20 GB of /dev/shm and a few minutes)")
@@ -690,6 +696,7 @@ def main():
     e2e = None
     e2e_c3 = None
     e2e_k15 = None
+    e2e_c4 = None
     e2e_t1 = None
     if rank == 0 and world == 1 and not args.no_e2e and not strong:
         e2e = end_to_end_leg()
@@ -697,6 +704,8 @@ def main():
             e2e_c3 = end_to_end_c3_leg()
         if not args.no_e2e_k15:
             e2e_k15 = end_to_end_k15_leg()
+        if not args.no_e2e_c4:
+            e2e_c4 = end_to_end_c4_leg()
         if args.t1_contigs > 0:
             e2e_t1 = end_to_end_t1_leg(args.t1_contigs)
         elif not args.no_e2e_1g:
@@ -734,7 +743,7 @@ def main():
                        "contig_bases": total_bases, "k": k,
                        "parallelism": f"window sharding x{world}" + (" + RCCL all-gather of consensus" if world > 1 else "")},
             "mbp_per_s": round(total_bases * args.steps / dt / 1e6, 2),
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "e2e": e2e, "e2e_c3": e2e_c3, "e2e_k15_250m": e2e_k15, "e2e_t1": e2e_t1,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "e2e": e2e, "e2e_c3": e2e_c3, "e2e_k15_250m": e2e_k15, "e2e_c4_250m": e2e_c4, "e2e_t1": e2e_t1,
         }
         if imbalance:
             out["imbalance"] = imbalance
