@@ -197,9 +197,11 @@ def end_to_end_fast_leg(name, bam, what):
         keys = ("contigs", "draft_bases", "reads", "solid_kmers", "fnv_draft", "fnv_bitvector") if (bam and "flags" not in a) else tuple(want.keys())
         if any(rep.get(k) != want[k] for k in keys):
             return {"error": "the generator's output differs from the golden's inputs"}
-        threads = min(128, max(1, (os.cpu_count() or 2) // 2)) if a["contigs"] * a["contig_len"] >= 500_000_000 else min(64, os.cpu_count() or 1)
+        threads = min(64, os.cpu_count() or 1)        # (128 threads were measured slower on the 2 x 64-core box: 14.0 against 12.1 s on the 1 Gbp set)
         argv = [binp] + man["command"].split()[1:]
         argv[argv.index("-t") + 1] = str(threads)
+        if "our_p" in a and "-p" in argv:
+            argv[argv.index("-p") + 1] = str(a["our_p"])
         if bam:
             argv[argv.index("-b") + 1] = "sr.bam"
             if "-B" in argv:
@@ -272,7 +274,7 @@ def end_to_end_t1_leg(n_contigs, contig_len=1_000_000, batchings=(10, 50)):
         tg = time.perf_counter()
         rep = json.loads(subprocess.check_output([gen, d, "97", str(n_contigs), str(contig_len), str(kk), "30", "150", "2000", "--bam", "--fast-hash"], text=True))
         tg = time.perf_counter() - tg
-        threads = min(128, max(1, (os.cpu_count() or 2) // 2))
+        threads = min(64, os.cpu_count() or 1)
         runs, md5s = [], []
         for pb in batchings:
             outp = f"out_p{pb}.fa"

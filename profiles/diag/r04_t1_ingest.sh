@@ -1,0 +1,22 @@
+#!/bin/bash
+# Where the 1 Gbp run (row T1, BAM) spends its time at -t 64 / -t 128: phase sums + the reader's own split (waiting / parse / collect).
+set -e
+N=${1:-1000}
+D=/dev/shm/t1ing_$$; rm -rf $D; mkdir -p $D
+tests/_build/gen_e2e_fast $D 91 $N 1000000 15 30 150 2000 --bam --fast-hash > /dev/null
+cd $D
+export GPU_MAX_HW_QUEUES=8
+for T in 64 128; do
+  HYPO_HOST_TIMING=1 $GRAFT_REPO_ROOT/hypo_amd/_build/hypo -d draft.fa -r reads.fa -s 1g -c 30 -b sr.bam -t $T -i -p 10 -o out.fa > run.log 2> run.err
+  echo "== -t $T: $(grep Overall run.log | sed 's/.*TIME= //')  md5 $(md5sum out.fa | cut -c1-32)"
+  grep "RESOURCES" run.log | python3 -c "
+import sys,re,collections
+acc=collections.OrderedDict()
+for l in sys.stdin:
+    m=re.search(r'\(\[Hypo:Hypo\]: (.*?)\. \): TIME= ([0-9.e+-]+)',l)
+    if m: acc[m.group(1)]=acc.get(m.group(1),0)+float(m.group(2))
+print('  '.join(f'{k}: {v:.2f}' for k,v in acc.items()))"
+  grep "create_alignments_flat" run.err | awk '{w+=$6; p+=$10; c+=$15} END {printf "  reader: waiting for records %.2f s, parse %.2f s, into the batch %.2f s\n", w, p, c}'
+  grep "upload_reads" run.err | awk '{f+=$8; u+=$11} END {printf "  upload_reads: flatten %.2f s, upload %.2f s\n", f, u}'
+done
+rm -rf $D

@@ -166,6 +166,8 @@ def run_fast_case(name, outdir, threads, extra_args=(), extra_env=None, timeout=
         argv[argv.index("-b") + 1] = "sr.bam"
     if "-B" in argv and bam:
         argv[argv.index("-B") + 1] = "lr.bam"
+    if "our_p" in a and "-p" in argv:
+        argv[argv.index("-p") + 1] = str(a["our_p"])
     argv[argv.index("-t") + 1] = str(threads)
     argv += list(extra_args)
     env = dict(os.environ)
