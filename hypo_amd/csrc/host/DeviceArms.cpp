@@ -109,7 +109,9 @@ bool DeviceArms::support_kmers(std::vector<std::unique_ptr<Contig>>& contigs, ui
         if (rc != HYPO_E_UNSUPPORTED) std::fprintf(stdout, "[Hypo::Hypo] Info: k-mer support is counted on the host (%s)\n", hypo_gpu_last_error());
         return false;
     }
-    for (uint32_t c = c0; c < c1; ++c) {
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t cc = (int64_t)c0; cc < (int64_t)c1; ++cc) {
+        const uint32_t c = (uint32_t)cc;
         Contig& ctg = *contigs[c];
         const uint64_t b = kbase[c - c0], n = ctg._n_solid;
         // (piece mode: the counters of the solid k-mers this context owns; the others are another context's)

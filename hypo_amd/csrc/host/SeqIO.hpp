@@ -238,7 +238,8 @@ inline bool read_fastx(const std::string& path, std::vector<FastaRecord>& out) {
         const size_t e = line.find_first_of(" \t");
         r.name = line.substr(1, e == std::string::npos ? std::string::npos : e - 1);
         have = lr.next(line);
-        while (have && !(line.size() && (line[0] == '>' || (fq && line[0] == '+')))) { r.seq += line; have = lr.next(line); }
+        // (a sequence written on one line — the usual case for assemblies — changes hands without a copy)
+        while (have && !(line.size() && (line[0] == '>' || (fq && line[0] == '+')))) { if (r.seq.empty()) r.seq.swap(line); else r.seq += line; have = lr.next(line); }
         if (fq && have) {                                   // skip qualities: as many characters as bases
             size_t q = 0;
             have = lr.next(line);
