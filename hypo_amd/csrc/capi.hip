@@ -7,6 +7,7 @@
 #include <string.h>
 #include <dlfcn.h>
 #include <chrono>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -26,6 +27,65 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(HYPO_E_HIP, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
+
+// ---- host -> device copies of the host-pointer entry points ---------------------------------------------------------------
+// A caller of the C-ABI hands over ordinary (pageable) memory: the reference's objects know nothing of page-locked buffers, and
+// locking a few GB for one upload costs more than the upload (MI355X box, profiles/r04_pin_bench.txt: hipHostMalloc 0.18 s per GB
+// + 0.12 s per GB to free it; a copy out of page-locked memory 57 GB/s, out of pageable memory 15-25 GB/s).  Large copies out of
+// pageable memory are therefore staged here: a few threads copy the next 32 MB into one of two page-locked bounce buffers of the
+// context while the DMA engine drains the other.  Memory the caller did page-lock (hypo_gpu_host_alloc) is copied from directly.
+class CopyPool {                                   // a handful of threads that memcpy slices side by side (one pool per process)
+public:
+    void copy(char* d, const char* s, size_t n) {
+        constexpr size_t kSlice = (size_t)4 << 20;
+        if (n <= kSlice) { memcpy(d, s, n); return; }
+        std::unique_lock<std::mutex> lk(mu);
+        if (th.empty()) for (int i = 0; i < kWorkers; ++i) th.emplace_back([this] { work(); });
+        for (size_t at = 0; at < n; at += kSlice) jobs.push_back(Job{d + at, s + at, n - at < kSlice ? n - at : kSlice});
+        left += jobs.size() - next;
+        cv.notify_all();
+        while (next < jobs.size()) {                 // the caller takes slices too
+            const Job j = jobs[next++];
+            lk.unlock(); memcpy(j.d, j.s, j.n); lk.lock();
+            --left;
+        }
+        done.wait(lk, [this] { return left == 0; });
+        jobs.clear(); next = 0;
+    }
+    ~CopyPool() { { std::lock_guard<std::mutex> lk(mu); quit = true; } cv.notify_all(); for (auto& t : th) t.join(); }
+private:
+    static constexpr int kWorkers = 5;
+    struct Job { char* d; const char* s; size_t n; };
+    std::vector<std::thread> th; std::vector<Job> jobs; size_t next = 0, left = 0; bool quit = false;
+    std::mutex mu; std::condition_variable cv, done;
+    void work() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [this] { return quit || next < jobs.size(); });
+            if (quit) return;
+            const Job j = jobs[next++];
+            lk.unlock(); memcpy(j.d, j.s, j.n); lk.lock();
+            if (--left == 0) done.notify_all();
+        }
+    }
+};
+CopyPool g_copy_pool;
+std::mutex g_copy_mu;                              // one staged copy at a time uses the pool
+
+struct Bounce {
+    static constexpr size_t kChunk = (size_t)32 << 20;
+    void* buf[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; bool used[2] = {false, false}; int turn = 0;
+    hipError_t ensure() {
+        if (buf[0]) return hipSuccess;
+        for (int i = 0; i < 2; ++i) {
+            hipError_t e = hipHostMalloc(&buf[i], kChunk, hipHostMallocNonCoherent);
+            if (e != hipSuccess) return e;
+            if ((e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming)) != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    void release() { for (int i = 0; i < 2; ++i) { if (ev[i]) (void)hipEventDestroy(ev[i]); if (buf[i]) (void)hipHostFree(buf[i]); buf[i] = nullptr; ev[i] = nullptr; used[i] = false; } }
+};
 
 // Device buffers of the host-pointer entry points: grow-only arenas owned by the context (no allocation in the
 // steady-state path); released at shutdown.  Slot numbers are local to each entry point.
@@ -82,6 +142,7 @@ struct Ctx {
     struct KeptScan { void* kids = nullptr; uint32_t* spos = nullptr; uint64_t n = 0, n_bases = 0; uint32_t k = 0; bool used = false; };
     std::vector<KeptScan> kept;
     int poa_flags = 0;                                 // hypo_gpu_set_option
+    Bounce bounce;                                     // page-locked staging of large copies out of pageable memory (h2d below)
     std::vector<HypoWindow> sh_win; std::vector<uint64_t> sh_aoff, sh_off;   // rebased descriptors of this device's share (hypo_gpu_poa_batch_sharded)
     Prof prof;
     std::recursive_mutex mu;                           // recursive: the host-buffer variants call the device variants
@@ -97,6 +158,32 @@ Ctx& cur() { return g_ctxs[(tl_slot >= 0 && tl_slot < kMaxDevices) ? tl_slot : 0
 #define HYPO_LOCKED() std::lock_guard<std::recursive_mutex> hypo_lock_(cur().mu)
 // the device of the context is made current for the calling thread (hypo_gpu_init did that for its own thread only)
 #define HYPO_ON_DEVICE() do { if (g_ctx.ready) HIP_TRY(hipSetDevice(g_ctx.device)); } while (0)
+
+// Host memory -> device memory on `st`.  On return the host range may be reused (as with hipMemcpyAsync out of pageable
+// memory); when `src` is page-locked the copy is queued as it is and the caller's usual rule applies (leave it alone until the
+// stream has been synchronised — every entry point that takes page-locked memory does that before it returns or says so).
+hipError_t h2d(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    constexpr size_t kStagedFrom = (size_t)8 << 20;
+    if (bytes < kStagedFrom) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, src) == hipSuccess && at.type != hipMemoryTypeUnregistered) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+    (void)hipGetLastError();                           // (an ordinary pointer is "invalid" to that query)
+    Ctx& c = cur();
+    hipError_t e = c.bounce.ensure();
+    if (e != hipSuccess) { (void)hipGetLastError(); return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st); }
+    std::lock_guard<std::mutex> lk(g_copy_mu);
+    Bounce& b = c.bounce;
+    for (size_t at0 = 0; at0 < bytes; at0 += Bounce::kChunk) {
+        const size_t n = bytes - at0 < Bounce::kChunk ? bytes - at0 : Bounce::kChunk;
+        const int i = b.turn; b.turn ^= 1;
+        if (b.used[i] && (e = hipEventSynchronize(b.ev[i])) != hipSuccess) return e;      // the copy that last read this buffer has left it
+        g_copy_pool.copy((char*)b.buf[i], (const char*)src + at0, n);
+        if ((e = hipMemcpyAsync((char*)dst + at0, b.buf[i], n, hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+        if ((e = hipEventRecord(b.ev[i], st)) != hipSuccess) return e;
+        b.used[i] = true;
+    }
+    return hipSuccess;
+}
 
 ProfCall* prof_next(int kind) {
     if (g_prof.used >= (int)g_prof.calls.size()) return nullptr;
@@ -244,6 +331,7 @@ static void release_ctx(Ctx& c) {
         for (auto& as : c.arms) { for (auto& a : as.arena) a.release(); as.ready = false; }
         c.rr.data.release(); c.rr.work.release(); c.rr.ready = false;
         c.solid_set.release(); c.solid_k = 0;
+        c.bounce.release();
         for (auto& ks : c.kept) { if (ks.kids) (void)hipFree(ks.kids); if (ks.spos) (void)hipFree(ks.spos); }
         c.kept.clear();
         if (c.stream) (void)hipStreamDestroy(c.stream);
@@ -439,12 +527,12 @@ int hypo_gpu_poa_batch_begin(const HypoScoreParams* scores, const HypoWindowBatc
     if (!S.stream) HIP_TRY_S(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
     if (!S.stats_pinned) HIP_TRY_S(hipHostMalloc((void**)&S.stats_pinned, sizeof(HypoPoaStats), hipHostMallocDefault));
     hipStream_t st = S.stream;
-    HIP_TRY_S(hipMemcpyAsync(dW.p, in->windows, (size_t)n * sizeof(HypoWindow), hipMemcpyHostToDevice, st));
-    HIP_TRY_S(hipMemcpyAsync(dD.p, in->draft4, in->draft4_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY_S(h2d(dW.p, in->windows, (size_t)n * sizeof(HypoWindow), st));
+    HIP_TRY_S(h2d(dD.p, in->draft4, in->draft4_bytes, st));
     if (na) {
         if (in->arm_off) HIP_TRY_S(hipMemcpyAsync(dAO.p, in->arm_off, (size_t)na * 8, hipMemcpyHostToDevice, st));
         HIP_TRY_S(hipMemcpyAsync(dAL.p, in->arm_len, (size_t)na * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY_S(hipMemcpyAsync(dA.p, in->arms2, in->arms2_bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY_S(h2d(dA.p, in->arms2, in->arms2_bytes, st));
     }
     HIP_TRY_S(hipMemcpyAsync(dO.p, out->off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, st));
     HIP_TRY_S(hipMemsetAsync(dB.p, 0, out_bytes ? out_bytes : 16, st));   // slack bytes of a slot come back as 0
@@ -716,7 +804,7 @@ int hypo_gpu_solid_set_upload(const uint64_t* bits, uint32_t k) {
     const uint64_t bit_words = (1ull << (2 * k)) / 64 ? (1ull << (2 * k)) / 64 : 1;
     g_ctx.solid_k = 0;
     HIP_TRY(g_ctx.solid_set.alloc(bit_words * 8));
-    HIP_TRY(hipMemcpyAsync(g_ctx.solid_set.p, bits, bit_words * 8, hipMemcpyHostToDevice, g_ctx.stream));
+    HIP_TRY(h2d(g_ctx.solid_set.p, bits, bit_words * 8, g_ctx.stream));
     HIP_TRY(hipStreamSynchronize(g_ctx.stream));
     g_ctx.solid_k = k;
     return HYPO_OK;
@@ -738,8 +826,8 @@ int hypo_gpu_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k, co
     HIP_TRY(dP.alloc(nbytes)); if (bits) HIP_TRY(dBits.alloc(bit_words * 8)); HIP_TRY(dWords.alloc(nw * 8));
     HIP_TRY(dKids.alloc(kids_cap * 8)); HIP_TRY(dRank.alloc((nw + 1) * 8)); HIP_TRY(dN.alloc(8)); HIP_TRY(dWS.alloc(wsb));
     hipStream_t st = g_ctx.stream;
-    if (nbytes) HIP_TRY(hipMemcpyAsync(dP.p, packed4, nbytes, hipMemcpyHostToDevice, st));
-    if (bits) HIP_TRY(hipMemcpyAsync(dBits.p, bits, bit_words * 8, hipMemcpyHostToDevice, st));
+    if (nbytes) HIP_TRY(h2d(dP.p, packed4, nbytes, st));
+    if (bits) HIP_TRY(h2d(dBits.p, bits, bit_words * 8, st));
     int rc = hypo_gpu_solid_scan_device((const uint8_t*)dP.p, n_bases, k, (const uint64_t*)(bits ? dBits.p : g_ctx.solid_set.p), (uint64_t*)dWords.p,
                                         kids ? (uint64_t*)dKids.p : nullptr, kids ? kids_cap : 0, (uint64_t*)dRank.p,
                                         (uint64_t*)dN.p, dWS.p, wsb, st);
@@ -781,7 +869,7 @@ int hypo_gpu_solid_scan_keep(uint32_t handle, const uint8_t* packed4, uint64_t n
     hipStream_t st = g_ctx.stream;
     char* const kid_arena = (char*)dKids.p;
     uint32_t* const spos_arena = (uint32_t*)(kid_arena + (cap * kid_bytes + 255) / 256 * 256);
-    if (nbytes) HIP_TRY(hipMemcpyAsync(dP.p, packed4, nbytes, hipMemcpyHostToDevice, st));
+    if (nbytes) HIP_TRY(h2d(dP.p, packed4, nbytes, st));
     HIP_TRY(hypo::scan_run((const uint8_t*)dP.p, n_bases, k, (const uint64_t*)g_ctx.solid_set.p, (uint64_t*)dWords.p,
                            narrow ? nullptr : (uint64_t*)kid_arena, cap, (uint64_t*)dRank.p, (uint64_t*)dN.p, dWS.p, wsb, st, nullptr,
                            narrow ? (uint32_t*)kid_arena : nullptr, spos_arena));
@@ -868,7 +956,7 @@ int hypo_gpu_reads_upload(const HypoArmsReads* A, const uint32_t* read_contig, u
     HIP_TRY(rr.data.alloc(c.at ? c.at : 256));
     char* d = (char*)rr.data.p;
     hipStream_t st = g_ctx.stream;
-#define UP(off, src, bytes) do { if (bytes) HIP_TRY(hipMemcpyAsync(d + (off), (src), (bytes), hipMemcpyHostToDevice, st)); } while (0)
+#define UP(off, src, bytes) do { if (bytes) HIP_TRY(h2d(d + (off), (src), (bytes), st)); } while (0)
     UP(o_rb, A->rb, (size_t)na * 4); UP(o_re, A->re, (size_t)na * 4); UP(o_qae, A->qae, (size_t)na * 4); UP(o_soff, A->seq_off, (size_t)na * 8);
     UP(o_reads, A->reads2, A->reads2_bytes); if (na) UP(o_coff, A->cigar_off, (size_t)(na + 1) * 4); UP(o_cig, A->cigar, n_cig * 4); UP(o_ctg, read_contig, (size_t)na * 4);
     if (A->file_rank) UP(o_rank, A->file_rank, (size_t)na * 4);
@@ -904,8 +992,8 @@ int hypo_gpu_support_kmers(uint32_t k, uint64_t n_solid, const uint32_t* spos, c
     HIP_TRY(wk.alloc(c.at));
     char* d = (char*)wk.p;
     hipStream_t st = g_ctx.stream;
-    HIP_TRY(hipMemcpyAsync(d + o_sp, spos, n_solid * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d + o_kd, kids, n_solid * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(h2d(d + o_sp, spos, n_solid * 4, st));
+    HIP_TRY(h2d(d + o_kd, kids, n_solid * 8, st));
     HIP_TRY(hipMemsetAsync(d + o_cov, 0, c.at - o_cov, st));
     HIP_TRY(hypo::support_kmers(support_reads_of(g_ctx), k, (uint32_t)n_solid, (const uint32_t*)(d + o_sp), (const uint64_t*)(d + o_kd), (uint32_t*)(d + o_cov), (uint32_t*)(d + o_sup), st));
     HIP_TRY(hipMemcpyAsync(coverage, d + o_cov, n_solid * 4, hipMemcpyDeviceToHost, st));
@@ -1002,7 +1090,7 @@ int hypo_gpu_support_minimizers(const HypoMegaWindows* W, uint32_t* coverage, ui
     HIP_TRY(wk.alloc(c.at));
     char* d = (char*)wk.p;
     hipStream_t st = g_ctx.stream;
-#define UP(off, src, bytes) do { if (bytes) HIP_TRY(hipMemcpyAsync(d + (off), (src), (bytes), hipMemcpyHostToDevice, st)); } while (0)
+#define UP(off, src, bytes) do { if (bytes) HIP_TRY(h2d(d + (off), (src), (bytes), st)); } while (0)
     UP(o_cb, W->contig_base, (size_t)nc * 4); UP(o_rbase, W->reg_base, (size_t)(nc + 1) * 4); UP(o_even, W->win_even, nc); UP(o_ib, W->info_base, (size_t)nc * 4);
     UP(o_start, W->start, n_start * 4); UP(o_off, W->mw_off, (size_t)(W->n_info + 1) * 4); UP(o_rel, W->rel_pos, n_ent * 4); UP(o_min, W->minimisers, n_ent * 4);
     UP(o_off + (size_t)(W->n_info + 1) * 4, W->mw_off + W->n_info, 4);          // the pad entry: an empty range behind the last info
@@ -1073,7 +1161,7 @@ static int arms_build_impl(int which, const HypoArmsRegions* R, const HypoArmsRe
                  o_cig = ci.take(resident ? 0 : n_cig * 4), o_frank = ci.take((resident || !A->file_rank) ? 0 : (size_t)na * 4);
     HIP_TRY(dIn.alloc(ci.at));
     char* in = (char*)dIn.p;
-#define UP(off, src, bytes) do { if (bytes) HIP_TRY(hipMemcpyAsync(in + (off), (src), (bytes), hipMemcpyHostToDevice, st)); } while (0)
+#define UP(off, src, bytes) do { if (bytes) HIP_TRY(h2d(in + (off), (src), (bytes), st)); } while (0)
     UP(o_start, R->start, (size_t)(nr + 1) * 4); UP(o_type, R->type, (size_t)nr + 1); if (R->info) UP(o_info, R->info, (size_t)(nr + 1) * 4);
     UP(o_anchor, R->anchor_kmers, R->n_anchor_kmers * 8); UP(o_contig, R->contig4, (total_len + 1) / 2);
     if (!resident) {
@@ -1226,7 +1314,10 @@ static int arms_poa_impl(int which, const HypoScoreParams* scores, char* bases, 
     HypoConsensusBatch dout;
     dout.bases = ob + o_bases; dout.off = O.out_off; dout.len = (uint32_t*)(ob + o_len); dout.status = (uint8_t*)(ob + o_st);
     hypo::PoaParams P = make_params(scores, &din, &dout);
-    HIP_TRY(hypo::poa_run(P, n, ob + o_ws, wsb, g_ctx.num_cus, st, nullptr, &g_ctx.slots[0].aux));
+    g_ctx.slots[0].aux.next_kind = which;                      // (a LONG batch says nothing about the SHORT one behind it, and the other way round)
+    const hipError_t pr = hypo::poa_run(P, n, ob + o_ws, wsb, g_ctx.num_cus, st, nullptr, &g_ctx.slots[0].aux);
+    g_ctx.slots[0].aux.next_kind = 0;
+    HIP_TRY(pr);
     if (timing) HIP_TRY(hipStreamSynchronize(st));
     const auto t2 = std::chrono::steady_clock::now();
     HIP_TRY(hipMemcpyAsync(bases, ob + o_bases, S.out_bytes, hipMemcpyDeviceToHost, st));

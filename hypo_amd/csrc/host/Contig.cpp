@@ -137,8 +137,26 @@ void Contig::prepare_for_division(unsigned k) {
     const bool have_kids = !_kids.empty();
     (void)first_kind; (void)last_kind;
     uint32_t i = 0;
-    for (uint32_t pos = 0; pos < _len; ++pos) {
-        if (_solid_pos[pos]) {
+    auto close_sr = [&] {
+        sr_pos.push_back((uint32_t)first_sr_pos); sr_len.push_back((uint32_t)(last_sr_pos - first_sr_pos));
+        // (the k-mer ids of a resident scan are on the device: the id of a marked position is the k bases that start there;
+        // the last valid k-mer of the SR starts at last_sr_pos - k)
+        _anchor_kmers.push_back(have_kids ? _kids[first_kind] : kmer_at(first_sr_pos, k));
+        _anchor_kmers.push_back(have_kids ? _kids[last_kind] : kmer_at(last_sr_pos - k, k));
+        in_sr = false; pvs_80 = true;
+    };
+    // The reference walks every position (src/Contig.cpp:96-150); only marked ones change the state, and an SR ends at the first
+    // position == last_sr_pos that no valid k-mer has moved on: the marked positions are taken out of the words of the bit vector
+    // one by one (a 250 Mbp contig: 45 M of them), an open SR that ends before the next one is closed first.
+    const uint64_t* const words = _solid_pos.data();
+    const uint64_t n_words = _solid_pos.n_words();
+    for (uint64_t wi = 0; wi < n_words; ++wi) {
+        uint64_t word = words[wi];
+        while (word) {
+            const uint32_t pos = (uint32_t)(wi * 64 + (uint64_t)__builtin_ctzll(word));
+            word &= word - 1;
+            if (pos >= _len) break;
+            if (in_sr && last_sr_pos < pos) close_sr();
             bool is_valid = false;
             const uint32_t cov = _kcov[i] & 0xffffu, sup = _ksup[i] & 0xffffu;
             if (cov >= Sr_settings.cov_th) {
@@ -152,16 +170,10 @@ void Contig::prepare_for_division(unsigned k) {
                 last_sr_pos = (uint64_t)pos + k;
             }
             ++i;
-        }
-        if (in_sr && pos == last_sr_pos) {
-            sr_pos.push_back((uint32_t)first_sr_pos); sr_len.push_back((uint32_t)(last_sr_pos - first_sr_pos));
-            // (the k-mer ids of a resident scan are on the device: the id of a marked position is the k bases that start there;
-            // the last valid k-mer of the SR starts at last_sr_pos - k)
-            _anchor_kmers.push_back(have_kids ? _kids[first_kind] : kmer_at(first_sr_pos, k));
-            _anchor_kmers.push_back(have_kids ? _kids[last_kind] : kmer_at(last_sr_pos - k, k));
-            in_sr = false; pvs_80 = true;
+            if (in_sr && pos == last_sr_pos) close_sr();
         }
     }
+    if (in_sr && last_sr_pos < _len) close_sr();                 // (an SR that ends before the contig does, behind the last marked position)
     if (in_sr) {
         sr_pos.push_back((uint32_t)first_sr_pos); sr_len.push_back((uint32_t)(last_sr_pos - first_sr_pos));
         _anchor_kmers.push_back(have_kids ? _kids[first_kind] : kmer_at(first_sr_pos, k));
@@ -244,8 +256,16 @@ void Contig::initialise_minimserinfo(const std::string& draft_seq, uint32_t minf
 // ---- Contig::divide_into_regions (src/Contig.cpp:187-245) -----------------------------------------------------------
 void Contig::divide_into_regions() {
     uint32_t sr_rank = 1, reg_start = 0, reg_ind = 0;
-    for (uint64_t i = 1; i < (uint64_t)_len + 1; ++i) {
-        if (!_reg_pos[i]) continue;
+    // (the borders set so far, out of the words of the bit vector: divide() adds borders inside the region in hand only, which lie
+    // behind the walk — the reference tests all _len + 1 positions)
+    const uint64_t n_words = _reg_pos.n_words();
+    for (uint64_t wi = 0; wi < n_words; ++wi) {
+      uint64_t word = _reg_pos.data()[wi];
+      if (wi == 0) word &= ~1ULL;                                  // (position 0 opens the first region)
+      while (word) {
+        const uint64_t i = wi * 64 + (uint64_t)__builtin_ctzll(word);
+        word &= word - 1;
+        if (i > _len) break;
         const uint32_t reg_end = (uint32_t)i;
         if ((_is_win_even && reg_ind % 2 == 0) || (!_is_win_even && reg_ind % 2 == 1)) {
             const char pvs = reg_ind == 0 ? 'n' : 's';
@@ -257,16 +277,28 @@ void Contig::divide_into_regions() {
         }
         ++reg_ind;
         reg_start = reg_end;
+      }
     }
     _reg_type.push_back(RegionType::SR);                         // dummy
     std::vector<MWMinimiserInfo>().swap(_minimserinfo);
     _mreg_ready = false;
     _reg_pos.init_support();
+    // the windows: region i = [border i + 1, border i + 2) in rank terms; the borders are listed once and the Window objects (each
+    // with its own copy of the draft stretch) are made on all threads when the contig has the team to itself
+    const size_t n_reg = _reg_type.size();
+    std::vector<uint32_t> border;
+    border.reserve(n_reg + 1);
+    for (uint64_t wi = 0; wi < n_words; ++wi) {
+        uint64_t word = _reg_pos.data()[wi];
+        while (word) { border.push_back((uint32_t)(wi * 64 + (uint64_t)__builtin_ctzll(word))); word &= word - 1; }
+    }
     _pwindows.clear();
-    _pwindows.reserve(_reg_type.size());
-    for (size_t i = 0; i < _reg_type.size(); ++i) {
-        if (_reg_type[i] == RegionType::SR || _reg_type[i] == RegionType::MSR) _pwindows.emplace_back();
-        else _pwindows.emplace_back(new Window(_pseq, _reg_pos.select(i + 1), _reg_pos.select(i + 2), WindowType::SHORT));
+    _pwindows.resize(n_reg);
+#pragma omp parallel for schedule(static)
+    for (int64_t ii = 0; ii < (int64_t)n_reg; ++ii) {
+        const size_t i = (size_t)ii;
+        if (_reg_type[i] == RegionType::SR || _reg_type[i] == RegionType::MSR || i + 1 >= border.size()) continue;
+        _pwindows[i].reset(new Window(_pseq, border[i], border[i + 1], WindowType::SHORT));
     }
 }
 
@@ -418,15 +450,24 @@ void Contig::prepare_long_windows() {
     _pseudo_reg_type.clear(); _true_reg_id.clear();
     bool pvs_iswin = true;
     uint32_t cur_len = 0;
+    // (region i starts at the (i + 1)-th border: the borders are listed once instead of two select() calls per region — 7 M regions
+    // on a 250 Mbp contig)
+    std::vector<uint32_t> border;
+    border.reserve(num_reg + 1);
+    for (uint64_t wi = 0; wi < _reg_pos.n_words(); ++wi) {
+        uint64_t word = _reg_pos.data()[wi];
+        while (word) { border.push_back((uint32_t)(wi * 64 + (uint64_t)__builtin_ctzll(word))); word &= word - 1; }
+    }
+    border.push_back(_len);                                       // (never read for a well-formed table: the last region is the SR end marker)
     for (uint32_t i = 0; i < num_reg; ++i) {
-        const uint32_t pos = (uint32_t)_reg_pos.select(i + 1);
+        const uint32_t pos = border[i];
         if (_reg_type[i] == RegionType::SR || _reg_type[i] == RegionType::MSR || _pwindows[i]) {
             if (pvs_iswin || i == num_reg - 1) {
                 _pseudo_reg_pos.set(pos); _pseudo_reg_type.push_back(RegionType::SR); _true_reg_id.push_back(i); cur_len = 0;
             }
             pvs_iswin = false;
         } else {
-            const uint32_t winlen = (uint32_t)_reg_pos.select(i + 2) - pos;
+            const uint32_t winlen = border[i + 1] - pos;
             if (pos == 0 || cur_len + winlen > Window_settings.ideal_lwind_size || !pvs_iswin) {
                 _pseudo_reg_pos.set(pos); _pseudo_reg_type.push_back(RegionType::LONG); _true_reg_id.push_back(i);
                 _reg_type[i] = RegionType::LONG; cur_len = winlen;

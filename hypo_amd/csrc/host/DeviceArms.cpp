@@ -42,8 +42,8 @@ bool DeviceArms::upload_reads(std::vector<std::unique_ptr<Contig>>& contigs, uin
     const int rc = hypo_gpu_reads_upload(&A, _stage.ctg, total);
     if (timing) {
         auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-        std::fprintf(stderr, "[timing] upload_reads: flatten into the staging arrays %.3f s, hypo_gpu_reads_upload %.3f s (%.0f MB)\n",
-                     sec(tu1, tu2), sec(tu2, std::chrono::steady_clock::now()), (_stage.n_bytes + 4.0 * _stage.n_cigar + 28.0 * n_aln) / 1e6);
+        std::fprintf(stderr, "[timing] upload_reads: flatten into the staging arrays %.3f s (growing them, so far: %.3f s), hypo_gpu_reads_upload %.3f s (%.0f MB)\n",
+                     sec(tu1, tu2), _stage.reserve_seconds, sec(tu2, std::chrono::steady_clock::now()), (_stage.n_bytes + 4.0 * _stage.n_cigar + 28.0 * n_aln) / 1e6);
     }
     if (rc != HYPO_OK) {
         if (rc != HYPO_E_UNSUPPORTED) std::fprintf(stdout, "[Hypo::Hypo] Info: support votes and short arms are computed on the host (%s)\n", hypo_gpu_last_error());
@@ -309,82 +309,53 @@ bool DeviceArms::build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c
     return true;
 }
 
-bool DeviceArms::build_long(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1,
-                            std::vector<std::vector<std::unique_ptr<Alignment>>>& store) {
+bool DeviceArms::build_long(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1, const ReadBatch& reads) {
     _active_long = false;
     if (hypo_gpu_use_device(_slot) != HYPO_OK) return false;
+    const bool timing = std::getenv("HYPO_HOST_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    const auto t0 = now();
     // the coordinate space of build(): contigs back to back, each starting on an even position (a 1-base filler region of type SR
     // behind an odd-length contig); its regions are the PSEUDO regions of Contig::prepare_long_windows
     uint64_t total = 0, n_reg = 0, n_aln = 0;
-    std::vector<uint64_t> aln_base(c1 - c0 + 1, 0);
+    std::vector<uint64_t> base(c1 - c0, 0);
     if (_piece && c1 - c0 != 1) return false;
-    // (piece mode: the long reads that overlap this context's span of the contig; `pick` = their indices in the contig's store entry)
-    std::vector<std::vector<uint32_t>> pick(c1 - c0);
     for (uint32_t c = c0; c < c1; ++c) {
         const Contig& ctg = *contigs[c];
         if (ctg._pseudo_reg_type.empty()) return false;
+        base[c - c0] = total;
         total += ctg._len + (ctg._len & 1);
         n_reg += ctg._pseudo_reg_type.size() - 1 + (ctg._len & 1);
-        aln_base[c - c0] = n_aln;
-        auto& pk = pick[c - c0];
-        for (size_t t = 0; t < store[c].size(); ++t)
-            if (!_piece || (store[c][t]->_rb < _span[1] && store[c][t]->_re > _span[0])) pk.push_back((uint32_t)t);
-        n_aln += pk.size();
+        n_aln += reads.count(c);
     }
     if (total >= 0xfffffff0ull || n_reg >= 0xfffffff0ull || n_aln >= 0xfffffff0ull || n_reg == 0) return false;
-    std::vector<uint64_t> seq_off(n_aln + 1);
-    std::vector<uint32_t> cigar_off(n_aln + 1);
+    // the long reads of the contigs, flat (ReadBatch.hpp), laid out contig after contig in the staging arrays of this context (piece
+    // mode: the reads that overlap this context's span of the contig)
     bool sorted = true;
-    for (uint32_t c = c0; c < c1; ++c) {
-        const auto& alns = store[c];
-        const auto& pk = pick[c - c0];
-        const uint64_t a0 = aln_base[c - c0];
-        for (size_t t = 0; t < pk.size(); ++t) {
-            seq_off[a0 + t + 1] = alns[pk[t]]->_apseq.byte_size();
-            cigar_off[a0 + t + 1] = (uint32_t)alns[pk[t]]->_cigar.size();
-            if (t && alns[pk[t - 1]]->_rb > alns[pk[t]]->_rb) sorted = false;
-        }
-    }
+    if (!reads.flatten(c0, c1, base, _stage_long, sorted, _piece ? _span : nullptr)) return false;
     if (!sorted) { std::fprintf(stdout, "[Hypo::Hypo] Info: long-read alignments are not sorted by position: long arms are computed on the host\n"); return false; }
-    seq_off[0] = 0; cigar_off[0] = 0;
-    uint64_t n_cig = 0;
-    for (uint64_t g = 0; g < n_aln; ++g) { n_cig += cigar_off[g + 1]; if (n_cig >= 0xfffffff0ull) return false; seq_off[g + 1] += seq_off[g]; cigar_off[g + 1] += cigar_off[g]; }
-    const uint64_t read_bytes = seq_off[n_aln];
     std::vector<uint32_t> start(n_reg + 1);
     std::vector<uint8_t> type(n_reg + 1, (uint8_t)RegionType::SR);
     std::vector<uint8_t> contig4((total + 1) / 2, 0);
-    std::vector<uint32_t> rb(n_aln), re(n_aln), qae(n_aln);
-    std::unique_ptr<uint32_t[]> cigar(new uint32_t[n_cig ? n_cig : 1]);
-    std::unique_ptr<uint8_t[]> reads2(new uint8_t[read_bytes ? read_bytes : 1]);
     _preg_window.assign(n_reg, nullptr);
-    uint64_t base = 0, r = 0;
+    uint64_t r = 0;
     for (uint32_t c = c0; c < c1; ++c) {
         Contig& ctg = *contigs[c];
+        const uint64_t b0 = base[c - c0];
         const size_t np = ctg._pseudo_reg_type.size() - 1;       // the last pseudo region is the end marker at the contig's length
         for (size_t i = 0; i < np; ++i, ++r) {
-            start[r] = (uint32_t)(base + ctg._pseudo_reg_pos.select((uint64_t)i + 1));
+            start[r] = (uint32_t)(b0 + ctg._pseudo_reg_pos.select((uint64_t)i + 1));
             const bool lw = ctg._pseudo_reg_type[i] == RegionType::LONG;
             type[r] = (uint8_t)(lw ? RegionType::LONG : RegionType::SR);
             if (lw) {
                 _preg_window[r] = ctg._pwindows[ctg._true_reg_id[i]].get();
                 if (!_preg_window[r]) return false;
-                if (_piece && !owns((uint64_t)start[r] - base)) _preg_window[r] = nullptr;      // (a LONG window of the halo: another context's)
+                if (_piece && !owns((uint64_t)start[r] - b0)) _preg_window[r] = nullptr;      // (a LONG window of the halo: another context's)
             }
         }
-        std::memcpy(contig4.data() + base / 2, ctg._pseq.data(), ctg._pseq.byte_size());
-        if (ctg._len & 1) { start[r] = (uint32_t)(base + ctg._len); type[r] = (uint8_t)RegionType::SR; ++r; }
-        const uint64_t a0 = aln_base[c - c0];
-        auto& alns = store[c];
-        const auto& pk = pick[c - c0];
-#pragma omp parallel for schedule(static)
-        for (int64_t t = 0; t < (int64_t)pk.size(); ++t) {
-            const Alignment& a = *alns[pk[(size_t)t]];
-            const uint64_t g = a0 + (uint64_t)t;
-            rb[g] = (uint32_t)(base + a._rb); re[g] = (uint32_t)(base + a._re); qae[g] = a._qae;
-            std::memcpy(reads2.get() + seq_off[g], a._apseq.data(), a._apseq.byte_size());
-            std::memcpy(cigar.get() + cigar_off[g], a._cigar.data(), a._cigar.size() * 4);
-        }
-        base += ctg._len + (ctg._len & 1);
+        std::memcpy(contig4.data() + b0 / 2, ctg._pseq.data(), ctg._pseq.byte_size());
+        if (ctg._len & 1) { start[r] = (uint32_t)(b0 + ctg._len); type[r] = (uint8_t)RegionType::SR; ++r; }
     }
     start[r] = (uint32_t)total;
     HypoArmsRegions R;
@@ -392,25 +363,26 @@ bool DeviceArms::build_long(std::vector<std::unique_ptr<Contig>>& contigs, uint3
     R.n_anchor_kmers = 0; R.anchor_kmers = nullptr; R.k = 10; R.contig4 = contig4.data();
     HypoArmsReads A;
     A.file_rank = nullptr;
-    A.n_alignments = (uint32_t)n_aln; A.rb = rb.data(); A.re = re.data(); A.qae = qae.data(); A.seq_off = seq_off.data();
-    A.reads2 = reads2.get(); A.reads2_bytes = read_bytes; A.cigar_off = cigar_off.data(); A.cigar = cigar.get();
+    A.n_alignments = (uint32_t)_stage_long.n_reads; A.rb = _stage_long.rb; A.re = _stage_long.re; A.qae = _stage_long.qae; A.seq_off = _stage_long.seq_off;
+    A.reads2 = _stage_long.reads2; A.reads2_bytes = _stage_long.n_bytes; A.cigar_off = _stage_long.cigar_off; A.cigar = _stage_long.cigar;
     std::vector<uint8_t> valid(n_reg, 0);
+    const auto t1 = now();
     const int rc = hypo_gpu_arms_build_long(&R, &A, valid.data(), &_sum_long);
+    if (timing) std::fprintf(stderr, "[timing] device long arms: flatten %.3f s (%.0f MB of bases, %.0f MB of CIGAR), hypo_gpu_arms_build_long %.3f s\n", secs(t0, t1), _stage_long.n_bytes / 1e6, _stage_long.n_cigar * 4 / 1e6, secs(t1, now()));
     if (rc != HYPO_OK) {
         if (rc != HYPO_E_UNSUPPORTED) std::fprintf(stdout, "[Hypo::Hypo] Info: long arms are computed on the host (%s)\n", hypo_gpu_last_error());
         return false;
     }
-    // what Contig::fill_long_windows leaves behind (include/Contig.hpp:91-113): the alignments are spent, the pseudo tables gone
-    if (!_piece) finish_long(contigs, c0, c1, store);          // (piece mode: the other contexts of the contig still read them; Hypo::polish calls it)
+    // what Contig::fill_long_windows leaves behind (include/Contig.hpp:91-113): the pseudo tables are gone
+    if (!_piece) finish_long(contigs, c0, c1);                 // (piece mode: the other contexts of the contig still read them; Hypo::polish calls it)
     std::fprintf(stdout, "[Hypo::Hypo] Info: long arms cut on the device: %u windows, %u arms\n", _sum_long.n_windows, _sum_long.n_arms);
     _active_long = true;
     return true;
 }
 
-void DeviceArms::finish_long(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1, std::vector<std::vector<std::unique_ptr<Alignment>>>& store) {
+void DeviceArms::finish_long(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1) {
     for (uint32_t c = c0; c < c1; ++c) {
         Contig& ctg = *contigs[c];
-        store[c].clear();
         ctg._pseudo_reg_pos.clear();
         std::vector<RegionType>().swap(ctg._pseudo_reg_type);
         std::vector<uint32_t>().swap(ctg._true_reg_id);
@@ -481,7 +453,43 @@ int DeviceArms::polish_impl(bool lng, const ScoreParams& sp, bool keep_arms, std
     const auto t1 = now();
     rc = (lng ? hypo_gpu_arms_download_long : hypo_gpu_arms_download)(nullptr, win_region, nullptr, nullptr, nullptr, nullptr);
     if (rc != HYPO_OK) return rc;
-    if (timing) std::fprintf(stderr, "[timing] device arms: buffers %.3f s, hypo_gpu_arms_poa%s %.3f s, descriptors %.3f s\n", secs(tp, t0), lng ? "_long" : "", secs(t0, t1), secs(t1, now()));
+    if (timing) {
+        std::fprintf(stderr, "[timing] device arms: buffers %.3f s, hypo_gpu_arms_poa%s %.3f s, descriptors %.3f s\n", secs(tp, t0), lng ? "_long" : "", secs(t0, t1), secs(t1, now()));
+        HypoPoaStats ps;
+        if (hypo_gpu_poa_last_stats(&ps) == HYPO_OK)
+            std::fprintf(stderr, "[timing]   windows finished per class [%llu %llu %llu %llu %llu %llu], re-queued %llu (with their graph: %llu), alignments %llu (reused %llu, threaded %llu), cells scored %.2f G of %.2f G\n",
+                         (unsigned long long)ps.n_class[0], (unsigned long long)ps.n_class[1], (unsigned long long)ps.n_class[2], (unsigned long long)ps.n_class[3],
+                         (unsigned long long)ps.n_class[4], (unsigned long long)ps.n_class[5], (unsigned long long)ps.n_escalated, (unsigned long long)ps.n_carried,
+                         (unsigned long long)ps.n_alignments, (unsigned long long)ps.n_reused, (unsigned long long)ps.n_threaded, ps.cells_scored / 1e9, ps.dp_cells / 1e9);
+        if (const char* dp = lng && std::getenv("HYPO_DUMP_LONG") && *std::getenv("HYPO_DUMP_LONG") ? std::getenv("HYPO_DUMP_LONG") : nullptr) {      // the resident LONG batch as a file (profiles/diag/r04_long_replay.py runs it again)
+            std::vector<HypoWindow> dw(n);
+            std::vector<uint32_t> al(_sum.n_arms ? _sum.n_arms : 1);
+            std::vector<uint64_t> ao(_sum.n_arms ? _sum.n_arms : 1);
+            std::vector<uint8_t> a2(_sum.arms2_bytes ? _sum.arms2_bytes : 1), d4(_sum.draft4_bytes ? _sum.draft4_bytes : 1);
+            if (hypo_gpu_arms_download_long(dw.data(), nullptr, al.data(), ao.data(), a2.data(), d4.data()) == HYPO_OK) {
+                if (FILE* f = std::fopen(dp, "wb")) {
+                    const uint64_t hd[4] = {n, _sum.n_arms, _sum.arms2_bytes, _sum.draft4_bytes};
+                    std::fwrite(hd, 8, 4, f); std::fwrite(dw.data(), sizeof(HypoWindow), n, f); std::fwrite(al.data(), 4, _sum.n_arms, f);
+                    std::fwrite(ao.data(), 8, _sum.n_arms, f); std::fwrite(a2.data(), 1, _sum.arms2_bytes, f); std::fwrite(d4.data(), 1, _sum.draft4_bytes, f);
+                    std::fclose(f);
+                }
+            }
+        }
+        if (lng) {                                                  // the shapes of the LONG batch (what the rate files of profiles/ are to be compared with)
+            std::vector<HypoWindow> dw(n);
+            std::vector<uint32_t> al(_sum.n_arms ? _sum.n_arms : 1);
+            if (hypo_gpu_arms_download_long(dw.data(), nullptr, al.data(), nullptr, nullptr, nullptr) == HYPO_OK) {
+                uint64_t arms = 0, dsum = 0, lsum = 0, over384 = 0, over512 = 0; uint32_t amax = 0, dmax = 0, lmax = 0, wmax_arms = 0;
+                for (const HypoWindow& w : dw) {
+                    const uint32_t na = w.n_internal + w.n_prefix + w.n_suffix;
+                    arms += na; dsum += w.draft_len; dmax = std::max(dmax, w.draft_len); wmax_arms = std::max(wmax_arms, na);
+                    for (uint32_t a = 0; a < na; ++a) { const uint32_t l = al[w.first_arm + a]; lsum += l; lmax = std::max(lmax, l); over384 += l > 383; over512 += l > 511; amax = std::max(amax, l); }
+                }
+                std::fprintf(stderr, "[timing]   LONG batch: %u windows, draft %.0f bases on average (longest %u), %.1f arms per window (most %u), arms %.0f bases on average (longest %u; %llu over 383, %llu over 511)\n",
+                             n, (double)dsum / n, dmax, (double)arms / n, wmax_arms, arms ? (double)lsum / arms : 0.0, lmax, (unsigned long long)over384, (unsigned long long)over512);
+            }
+        }
+    }
     // (every status byte starts as HYPO_ST_UNWRITTEN on the device: a window no kernel answered is an internal error, not a retry)
     for (uint32_t i = 0; i < n; ++i)
         if (st[i] == HYPO_ST_UNWRITTEN) {

@@ -56,12 +56,11 @@ public:
     // regions' borders (Alignment::find_long_arms), filters the arms (Filter::is_good against each LONG window's draft) and keeps
     // the LONG windows as a second resident batch.  true: `store` is consumed and the pseudo-region tables of the contigs are
     // released (what Contig::fill_long_windows does at its end); false: nothing changed, the host loops must run.
-    bool build_long(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1,
-                    std::vector<std::vector<std::unique_ptr<Alignment>>>& store);
+    bool build_long(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1, const ReadBatch& long_reads);
     bool active_long() const { return _active_long; }
     // what build() / build_long() leave behind in the contigs once ALL contexts that work on them are done (piece mode defers it)
     static void finish_short(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1);
-    static void finish_long(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1, std::vector<std::vector<std::unique_ptr<Alignment>>>& store);
+    static void finish_long(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1);
     void reset_polished() { _n_pol[0] = _n_pol[1] = 0; }
     void drop() { _active = false; _active_long = false; }      // forget the resident batches (another context of the same contig failed)
     void drop_long() { _active_long = false; }
@@ -75,6 +74,7 @@ private:
     bool _reads_resident = false; uint32_t _reads_c0 = 0, _reads_c1 = 0;
     bool _active = false;
     HypoArmsSummary _sum{};
+    ReadStaging _stage_long;                 // ... and of its long reads
     ReadStaging _stage;                      // page-locked staging arrays of this context's reads (grow-only, reused by every batch)
     uint32_t* _votes = nullptr; uint64_t _votes_cap = 0;       // page-locked: coverage [_votes_cap] then support [_votes_cap] of the k-mer votes
     PinnedBuf _pb[12];                       // staging of the minimizer tables and the region tables

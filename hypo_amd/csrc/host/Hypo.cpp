@@ -55,8 +55,10 @@ void Hypo::polish() {
             std::exit(1);
         }
         // (the records are packed into Contig objects on all threads: 100 x 1 Mbp took 0.7 s one after the other)
+        // (a handful of large contigs: one after the other, each packed by all threads — PackedSeq::assign)
         _contigs.resize(recs.size());
-#pragma omp parallel for schedule(dynamic, 1)
+        const bool many = recs.size() >= (size_t)std::max(2u, _cFlags.threads / 2);
+#pragma omp parallel for schedule(dynamic, 1) if (many)
         for (int64_t i = 0; i < (int64_t)recs.size(); ++i) {
             _contigs[(size_t)i].reset(new Contig((uint32_t)i, recs[(size_t)i].name, recs[(size_t)i].seq));
             std::string().swap(recs[(size_t)i].seq);
@@ -102,6 +104,7 @@ void Hypo::polish() {
     if (!_cFlags.lr_bam_filename.empty()) {
         _sf_long.reset(new SamReader(_cFlags.lr_bam_filename));
         if (!_sf_long->ok()) { std::fprintf(stderr, "[Hypo::Hypo] Error: File open error: %s\n", _cFlags.lr_bam_filename.c_str()); std::exit(1); }
+        _sf_long->set_inflate_threads(std::max(1, (int)_cFlags.threads));
     }
     std::ofstream dump;
     if (!_region_dump.empty()) dump.open(_region_dump);
@@ -275,8 +278,17 @@ void Hypo::polish() {
         stop("[Hypo:Hypo]: Minimisers support update. ");
 
         start();
-#pragma omp parallel for schedule(static, 1)
-        for (int64_t i = initial_cid; i < (int64_t)final_cid; ++i) _contigs[(size_t)i]->divide_into_regions();
+        {   // (as above: fewer contigs than threads share the team, each contig builds its Window objects with its share)
+            const int nc = (int)(final_cid - initial_cid), T = (int)_cFlags.threads;
+            const int outer = std::max(1, std::min(nc, T)), inner = over_contigs ? 1 : std::max(1, T / outer);
+            if (inner > 1) omp_set_max_active_levels(2);
+#pragma omp parallel for schedule(static, 1) num_threads(outer)
+            for (int64_t i = initial_cid; i < (int64_t)final_cid; ++i) {
+                omp_set_num_threads(inner);
+                _contigs[(size_t)i]->divide_into_regions();
+            }
+            omp_set_max_active_levels(1);
+        }
         stop("[Hypo:Hypo]: Division into windows. ");
 
         start();
@@ -322,7 +334,19 @@ void Hypo::polish() {
 
         if (!_cFlags.lr_bam_filename.empty()) {
             start();
-            create_alignments(false, batch_id);
+            // the long reads of the batch, flat like the short ones (ReadBatch.hpp; round 4: 1.2 M objects of 8 kb each took 2.5 s to
+            // build on the 250 Mbp set).  The reader stops behind the first kept record of a later contig; the reference files that
+            // record in ITS contig's store entry (src/Hypo.cpp:314-325), where that batch's short-read phases find it: it becomes
+            // an object there (see the top of the batch loop).
+            _reads_long.reset(_contigs.size());
+            create_alignments_flat(batch_id, _reads_long, false);
+            if (_rs_long.carry_blk) {
+                ReadBatch one;
+                one.reset(_contigs.size());
+                one.add(_rs_long.carry_blk, _rs_long.carry_r0, _rs_long.carry_r1);
+                if (_rs_long.carry_cid >= 0) one.materialize((uint32_t)_rs_long.carry_cid, _alignment_store[(size_t)_rs_long.carry_cid]);
+                _rs_long.carry_blk.reset();
+            }
             stop("[Hypo:Hypo]: Loaded alignments of Long reads. ");
             start();
 #pragma omp parallel for schedule(static, 1)
@@ -334,7 +358,7 @@ void Hypo::polish() {
                 for (int d = 0; d < n_ctx; ++d) {
                     const uint32_t c0 = work[(size_t)d].c0, c1 = work[(size_t)d].c1;
                     if (c0 >= c1) continue;
-                    if (device_arms[(size_t)d]->build_long(_contigs, c0, c1, _alignment_store))
+                    if (device_arms[(size_t)d]->build_long(_contigs, c0, c1, _reads_long))
                         for (uint32_t c = c0; c < c1; ++c) long_on_dev[c - initial_cid] |= 1;
                     else if (work[(size_t)d].piece) long_on_dev[c0 - initial_cid] |= 2;      // (a shared contig: all of its contexts or none)
                 }
@@ -347,13 +371,14 @@ void Hypo::polish() {
                     char& f = long_on_dev[c - initial_cid];
                     const bool shared = f != 0 && n_batch_contigs < (uint32_t)n_ctx;
                     if (f & 2) f = 0;
-                    else if (f == 1 && shared) DeviceArms::finish_long(_contigs, c, c + 1, _alignment_store);
+                    else if (f == 1 && shared) DeviceArms::finish_long(_contigs, c, c + 1);
                 }
                 hypo_gpu_use_device(0);
             }
             for (uint32_t cid = initial_cid; cid < final_cid; ++cid) {
                 if (long_on_dev[cid - initial_cid]) continue;
-                auto& alns = _alignment_store[cid];
+                auto& alns = _alignment_store[cid];                     // (the host loops of the reference read objects)
+                _reads_long.materialize(cid, alns);
 #pragma omp parallel for
                 for (int64_t t = 0; t < (int64_t)alns.size(); ++t) alns[(size_t)t]->find_long_arms(*_contigs[cid]);
             }
@@ -363,6 +388,7 @@ void Hypo::polish() {
                 _contigs[(size_t)i]->fill_long_windows(_alignment_store[(size_t)i]); _alignment_store[(size_t)i].clear();
             }
             for (uint32_t c = initial_cid; c < final_cid; ++c) long_dev[c - initial_cid] = long_on_dev[c - initial_cid];
+            _reads_long.clear(&_block_pool, &_pool_mu);
             stop("[Hypo:Hypo]: Long arms filling. ");
         } else {
             Contig::set_no_long_reads();
@@ -444,132 +470,6 @@ void Hypo::polish() {
     _contigs.clear();
 }
 
-// src/Hypo.cpp:278-329: stream the (coordinate-sorted) file, stop when a record of the next batch shows up.
-// A reader thread inflates the file and cuts it into blocks of raw records (SeqIO.hpp); while it fetches the next block,
-// record parsing and the Alignment constructors (CIGAR walk, 2-bit packing) of the current block run on all threads; a serial
-// pass then files the alignments in record order, so every contig's store is in file order exactly as the reference builds it.
-void Hypo::create_alignments(bool is_sr, uint32_t batch_id, AlignmentStore* into) {
-    AlignmentStore& store = into ? *into : _alignment_store;
-    const uint32_t mq = _cFlags.map_qual_th;
-    SamReader& sf = is_sr ? *_sf_short : *_sf_long;
-    RecordStream& rs = is_sr ? _rs_short : _rs_long;
-    const uint32_t final_cid = batch_id * _contig_batch_size + _contig_batch_size;
-    uint64_t num_invalid = 0, num_alns = 0;
-    constexpr size_t kBlock = 1 << 17;
-    struct Slot { std::unique_ptr<Alignment> aln; int32_t cid; bool skip, bad_ref; };
-    std::vector<Slot> slots;
-    bool stop = false, more_ahead = true;
-    double t_wait = 0, t_par = 0, t_col = 0; auto now = []{ return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    while (!stop) {
-        const double t0 = now();
-        if (rs.pos >= rs.cur.n()) {                          // current block used up: take the prefetched one or read one
-            if (rs.have_ahead) { std::swap(rs.cur, rs.ahead); rs.have_ahead = false; }
-            else if (rs.more) rs.more = sf.read_block(rs.cur, kBlock);
-            else break;
-            rs.pos = 0;
-            if (rs.cur.n() == 0) { if (!rs.more) break; continue; }
-        }
-        std::thread reader;                                  // inflate + record splitting of the next block overlap the parsing of this one
-        if (rs.more && !rs.have_ahead) reader = std::thread([&] { more_ahead = sf.read_block(rs.ahead, kBlock); });
-        const size_t first = rs.pos, count = rs.cur.n() - first;
-        slots.clear(); slots.resize(count);
-        const double t1 = now(); t_wait += t1 - t0;
-#pragma omp parallel
-        {
-            SamRecord rec;                                   // one per thread: its strings and CIGAR vector are reused
-            int32_t tid_seen = -2; int64_t cid_seen = -1;
-#pragma omp for schedule(dynamic, 256)
-            for (int64_t i = 0; i < (int64_t)count; ++i) {
-                Slot& sl = slots[(size_t)i];
-                sl.skip = false; sl.bad_ref = false; sl.cid = -1;
-                sf.parse(rs.cur.rec(first + (size_t)i), rs.cur.len(first + (size_t)i), rec);
-                if ((rec.flag & (SAM_FUNMAP | SAM_FSECONDARY | SAM_FQCFAIL | SAM_FDUP)) || rec.mapq < mq) { sl.skip = true; continue; }
-                if (rec.tid != tid_seen) {                     // (one look-up per run of records of a contig)
-                    auto it = rec.tid < 0 ? _cname_to_id.end() : _cname_to_id.find(sf.tid2name(rec.tid));
-                    tid_seen = rec.tid;
-                    cid_seen = it == _cname_to_id.end() ? -1 : (int64_t)it->second;
-                }
-                if (cid_seen < 0) { sl.bad_ref = true; continue; }
-                sl.cid = (int32_t)cid_seen;
-                if (is_sr) sl.aln.reset(new Alignment(*_contigs[(size_t)cid_seen], rec));
-                else sl.aln.reset(new Alignment(*_contigs[(size_t)cid_seen], _cFlags.norm_edit_th, rec));
-            }
-        }
-        const double t2 = now();
-        t_par += t2 - t1;
-        rs.pos = rs.cur.n();
-        // Into the store, in file order (the reference appends record by record): where the batch ends — the first kept record of
-        // a later contig is consumed as well, as in the reference — and the first record with an unknown reference are found first;
-        // then every thread takes a contiguous share of the records, counts what each contig gets from it (runs of one contig),
-        // the shares are lined up, and the pointers are moved side by side (20 M records one after the other took 0.3 s).
-        int64_t s_first = (int64_t)count, b_first = (int64_t)count;
-#pragma omp parallel for schedule(static) reduction(min : s_first, b_first)
-        for (int64_t i = 0; i < (int64_t)count; ++i) {
-            const Slot& sl = slots[(size_t)i];
-            if (sl.skip) continue;
-            if (sl.bad_ref) { if (i < b_first) b_first = i; }
-            else if ((uint32_t)sl.cid >= final_cid && i < s_first) s_first = i;
-        }
-        const size_t end = s_first < (int64_t)count ? (size_t)s_first + 1 : count;
-        if ((size_t)b_first < end) {
-            std::fprintf(stderr, "[Hypo::Hypo] Error: Alignment File error: Contig-reference of record %s does not exist in the draft!\n",
-                         sf.record_name(rs.cur.rec(first + (size_t)b_first), rs.cur.len(first + (size_t)b_first)).c_str());
-            std::exit(1);
-        }
-        struct Run { int32_t cid; uint64_t n, at; };
-        const int nt = std::max(1, std::min<int>((int)_cFlags.threads, (int)(end / 4096) + 1));
-        std::vector<std::vector<Run>> runs((size_t)nt);
-        std::vector<uint64_t> bad((size_t)nt, 0);
-        auto share = [&](int t, size_t& a, size_t& b) { a = end * (size_t)t / (size_t)nt; b = end * ((size_t)t + 1) / (size_t)nt; };
-#pragma omp parallel num_threads(nt)
-        {
-            const int me = omp_get_thread_num(), step = omp_get_num_threads();
-            for (int t = me; t < nt; t += step) {
-                size_t a, b; share(t, a, b);
-                std::vector<Run>& my = runs[(size_t)t];
-                for (size_t i = a; i < b; ++i) {
-                    const Slot& sl = slots[i];
-                    if (sl.skip) continue;
-                    if (!sl.aln->is_valid) { ++bad[(size_t)t]; continue; }
-                    if (my.empty() || my.back().cid != sl.cid) my.push_back(Run{sl.cid, 0, 0});
-                    ++my.back().n;
-                }
-            }
-#pragma omp barrier
-#pragma omp single
-            {
-                for (auto& rr : runs)
-                    for (Run& r : rr) {
-                        auto& v = store[(size_t)r.cid];
-                        r.at = v.size();
-                        v.resize(v.size() + r.n);
-                        num_alns += r.n;
-                    }
-                for (uint64_t x : bad) num_invalid += x;
-            }   // (implicit barrier)
-            for (int t = me; t < nt; t += step) {
-                size_t a, b; share(t, a, b);
-                const std::vector<Run>& my = runs[(size_t)t];
-                int64_t ri = -1; uint64_t at = 0;
-                for (size_t i = a; i < b; ++i) {
-                    Slot& sl = slots[i];
-                    if (sl.skip || !sl.aln->is_valid) continue;
-                    if (ri < 0 || my[(size_t)ri].cid != sl.cid) { ++ri; at = my[(size_t)ri].at; }
-                    store[(size_t)sl.cid][at++] = std::move(sl.aln);
-                }
-            }
-        }
-        if (s_first < (int64_t)count) { rs.pos = first + end; stop = true; }
-        const double t3 = now();
-        t_col += t3 - t2;
-        if (reader.joinable()) { reader.join(); rs.more = more_ahead; rs.have_ahead = rs.ahead.n() > 0; }
-        t_wait += now() - t3;
-    }
-    if (std::getenv("HYPO_HOST_TIMING")) std::fprintf(stderr, "[timing] create_alignments: waiting for records %.3f s, parse + construct %.3f s, into the store %.3f s\n", t_wait, t_par, t_col);
-    std::fprintf(stdout, "[Hypo::Hypo] Info: Number of alignments (Batch %u): loaded (%lu) invalid (%lu)\n", batch_id,
-                 (unsigned long)num_alns, (unsigned long)num_invalid);
-}
-
 // ---- the flat path of the short reads (ReadBatch.hpp) -------------------------------------------------------------------------
 void Hypo::materialize_alignments(uint32_t c0, uint32_t c1, std::vector<char>& done) {
     // `done` belongs to the batch in hand: entry i = contig (_mat_base + i), _mat_base = the batch's first contig
@@ -581,14 +481,15 @@ void Hypo::materialize_alignments(uint32_t c0, uint32_t c1, std::vector<char>& d
     }
 }
 
-void Hypo::parse_block(const SamReader& sf, const SamReader::RecordBlock& raw, ParsedBlock& blk) {
+void Hypo::parse_block(const SamReader& sf, const SamReader::RecordBlock& raw, ParsedBlock& blk, bool long_reads) {
     const uint32_t mq = _cFlags.map_qual_th;
     const size_t count = raw.n();
     blk.n = count;
     blk.status.assign(count, ParsedBlock::ST_SKIPPED);
     blk.cid.assign(count, -1);
     blk.bad_ref_name.clear();
-    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)omp_get_max_threads(), count / 512 + 1));
+    // (a block of long reads is a few thousand records of 10+ kb: shares small enough for every thread to get some)
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)omp_get_max_threads(), count / (long_reads ? 8 : 512) + 1));
     blk.chunks.resize((size_t)T);
 #pragma omp parallel num_threads(T)
     {
@@ -608,6 +509,7 @@ void Hypo::parse_block(const SamReader& sf, const SamReader::RecordBlock& raw, P
                     rec.cigar.resize(bc.n_cigar);
                     if (bc.n_cigar) std::memcpy(rec.cigar.data(), bc.cigar, 4ull * bc.n_cigar);
                     rec.qname.assign(bc.qname);
+                    if (long_reads) rec.has_nm = sf.bam_nm(raw.rec(i), raw.len(i), bc, rec.nm);
                 } else {
                     sf.parse(raw.rec(i), raw.len(i), rec);
                     if ((rec.flag & (SAM_FUNMAP | SAM_FSECONDARY | SAM_FQCFAIL | SAM_FDUP)) || rec.mapq < mq) continue;
@@ -622,6 +524,9 @@ void Hypo::parse_block(const SamReader& sf, const SamReader::RecordBlock& raw, P
                 uint32_t rb, re, qab, qae;
                 Alignment::span_of(*_contigs[(size_t)cid_seen], rec, rb, re, qab, qae);
                 const uint32_t qlen = qae - qab;
+                // a long read is dropped when its NM-based normalised edit distance exceeds the threshold; the reference divides the
+                // integers first (edit_dist * 100 / rlen) and compares the quotient (Alignment.cpp:51-58)
+                if (long_reads && rec.has_nm && re > rb && (double)(rec.nm * 100 / (int64_t)(re - rb)) > (double)_cFlags.norm_edit_th) { blk.status[i] = ParsedBlock::ST_INVALID; continue; }
                 // Alignment.cpp:551-571: the aligned part 2-bit packed; a read with a non-ACGT base there is dropped
                 bool ok = (size_t)qab + qlen <= (direct ? (size_t)bc.l_seq : rec.seq.size());
                 const size_t at = ch.seq.size();
@@ -645,13 +550,16 @@ void Hypo::parse_block(const SamReader& sf, const SamReader::RecordBlock& raw, P
 // src/Hypo.cpp:278-329 for the short reads: stream the (coordinate-sorted) file, stop when a record of the next batch shows up.
 // A reader thread inflates the file and cuts the next block of raw records while this block is parsed on all threads, every
 // thread writing the records of its stretch into a chunk of flat arrays; the batch takes the kept records as slices of the block.
-void Hypo::create_alignments_flat(uint32_t batch_id, ReadBatch& into) {
-    SamReader& sf = *_sf_short;
-    RecordStream& rs = _rs_short;
+void Hypo::create_alignments_flat(uint32_t batch_id, ReadBatch& into, bool is_sr) {
+    SamReader& sf = is_sr ? *_sf_short : *_sf_long;
+    RecordStream& rs = is_sr ? _rs_short : _rs_long;
     const uint32_t final_cid = batch_id * _contig_batch_size + _contig_batch_size;
     uint64_t num_invalid = 0, num_alns = 0;
     constexpr size_t kBlock = 1 << 19, kBlockBytes = (size_t)128 << 20;     // (a block of records = about one run of inflated BGZF blocks, SeqIO.hpp)
-    if (rs.carry_blk) { into.add(rs.carry_blk, rs.carry_r0, rs.carry_r1); rs.carry_blk.reset(); }
+    // (the record a call consumed for a contig behind its batch: a short read opens that contig's batch; a LONG read has been filed
+    // as an object in that contig's store entry by Hypo::polish, where the reference's short-read phases find it)
+    if (rs.carry_blk && is_sr) into.add(rs.carry_blk, rs.carry_r0, rs.carry_r1);
+    rs.carry_blk.reset();
     bool stop = false, more_ahead = true;
     double t_wait = 0, t_par = 0, t_col = 0; auto now = []{ return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     if (!rs.reader) { rs.reader.reset(new BlockReader()); rs.reader->start(&sf); }
@@ -673,7 +581,7 @@ void Hypo::create_alignments_flat(uint32_t batch_id, ReadBatch& into) {
             }
             if (!blk) blk = std::make_shared<ParsedBlock>();
             const double t1 = now(); t_wait += t1 - t0;
-            parse_block(sf, rs.cur, *blk);
+            parse_block(sf, rs.cur, *blk, !is_sr);
             t_par += now() - t1;
             rs.parsed = blk; rs.ppos = 0;
         }
@@ -697,7 +605,7 @@ void Hypo::create_alignments_flat(uint32_t batch_id, ReadBatch& into) {
         }
         into.add(rs.parsed, rs.ppos, s_first);
         if (s_first < B.n) {
-            if (B.status[s_first] == ParsedBlock::ST_KEPT) { rs.carry_blk = rs.parsed; rs.carry_r0 = s_first; rs.carry_r1 = s_first + 1; }
+            if (B.status[s_first] == ParsedBlock::ST_KEPT) { rs.carry_blk = rs.parsed; rs.carry_r0 = s_first; rs.carry_r1 = s_first + 1; rs.carry_cid = B.cid[s_first]; }
             rs.ppos = s_first + 1;
             stop = true;
         } else rs.ppos = B.n;
@@ -706,7 +614,7 @@ void Hypo::create_alignments_flat(uint32_t batch_id, ReadBatch& into) {
         if (asked) { more_ahead = rs.reader->wait(); rs.more = more_ahead; rs.have_ahead = rs.ahead.n() > 0; }
         t_wait += now() - t3;
     }
-    if (std::getenv("HYPO_HOST_TIMING")) std::fprintf(stderr, "[timing] create_alignments_flat: waiting for records %.3f s, parse %.3f s, into the batch %.3f s\n", t_wait, t_par, t_col);
+    if (std::getenv("HYPO_HOST_TIMING")) std::fprintf(stderr, "[timing] create_alignments_flat: waiting for records %.3f s, parse %.3f s, into the batch %.3f s (BGZF blocks: %s)\n", t_wait, t_par, t_col, BlockInflater::name());
     std::fprintf(stdout, "[Hypo::Hypo] Info: Number of alignments (Batch %u): loaded (%lu) invalid (%lu)\n", batch_id,
                  (unsigned long)num_alns, (unsigned long)num_invalid);
 }

@@ -75,7 +75,7 @@ private:
         // flat path (short reads): the parsed form of `cur`, how far it has been consumed, and the one record a call consumed for
         // a contig of a later batch (the reference files it in that contig's store entry, src/Hypo.cpp:314-325)
         std::shared_ptr<ParsedBlock> parsed; size_t ppos = 0;
-        std::shared_ptr<ParsedBlock> carry_blk; size_t carry_r0 = 0, carry_r1 = 0;
+        std::shared_ptr<ParsedBlock> carry_blk; size_t carry_r0 = 0, carry_r1 = 0; int32_t carry_cid = -1;
     };
     RecordStream _rs_short, _rs_long;
     PhaseTimes _times;
@@ -84,12 +84,13 @@ private:
 
     void start() { _t0 = std::chrono::steady_clock::now(); }
     void stop(const char* label);
-    void create_alignments(bool is_sr, uint32_t batch_id, AlignmentStore* into = nullptr);   // into: the helper thread's own store (Hypo::polish)
     // Round 4: the short reads of a contig batch as flat slices (ReadBatch.hpp) instead of one Alignment object per record
     ReadBatch _reads;
+    ReadBatch _reads_long;                   // the long reads of the batch in hand (-B), flat as well
     std::vector<std::shared_ptr<ParsedBlock>> _block_pool; std::mutex _pool_mu;
-    void create_alignments_flat(uint32_t batch_id, ReadBatch& into);
-    void parse_block(const SamReader& sf, const SamReader::RecordBlock& raw, ParsedBlock& blk);
+    void create_alignments_flat(uint32_t batch_id, ReadBatch& into, bool is_sr = true);
+    // long_reads: the normalised-edit-distance filter of the long-read constructor applies (src/Alignment.cpp:51-58)
+    void parse_block(const SamReader& sf, const SamReader::RecordBlock& raw, ParsedBlock& blk, bool long_reads);
     // Alignment objects of contigs [c0, c1) from _reads into _alignment_store (the host loops of the reference read those)
     void materialize_alignments(uint32_t c0, uint32_t c1, std::vector<char>& done);
     uint32_t _mat_base = 0;

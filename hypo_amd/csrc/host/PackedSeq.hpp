@@ -13,13 +13,11 @@ namespace hypo {
 
 // cNt4Table (include/globalDefs.hpp:160-178): A/a 0, C/c 1, G/g 2, T/t/U/u 3, bytes 0..3 themselves, else 4
 inline uint8_t nt4(unsigned char c) {
-    switch (c) {
-        case 'A': case 'a': case 0: return 0;
-        case 'C': case 'c': case 1: return 1;
-        case 'G': case 'g': case 2: return 2;
-        case 'T': case 't': case 'U': case 'u': case 3: return 3;
-        default: return 4;
-    }
+    struct Lut { uint8_t v[256]; Lut() {
+        for (int i = 0; i < 256; ++i) v[i] = 4;
+        v['A'] = v['a'] = v[0] = 0; v['C'] = v['c'] = v[1] = 1; v['G'] = v['g'] = v[2] = 2; v['T'] = v['t'] = v['U'] = v['u'] = v[3] = 3; } };
+    static const Lut lut;                          // (a table, not a switch: a random genome mispredicts every other base of one)
+    return lut.v[c];
 }
 
 // n characters of A, C, G, T (either case) -> PackedSeq<2> bytes at dst ((n + 3) / 4 of them, the last one zero padded);

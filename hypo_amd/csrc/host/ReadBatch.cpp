@@ -1,5 +1,6 @@
 // ReadBatch.cpp — see ReadBatch.hpp.
 #include "ReadBatch.hpp"
+#include <chrono>
 #include <omp.h>
 #include <algorithm>
 #include <cstdlib>
@@ -8,6 +9,8 @@
 namespace hypo {
 
 bool ReadStaging::reserve(size_t reads, size_t cig, size_t bytes) {
+    const auto t0 = std::chrono::steady_clock::now();
+    struct Timer { std::chrono::steady_clock::time_point t0; double& acc; ~Timer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } timer{t0, reserve_seconds};
     rb = _b[0].get<uint32_t>(reads + 1); re = _b[1].get<uint32_t>(reads + 1); qae = _b[2].get<uint32_t>(reads + 1); ctg = _b[3].get<uint32_t>(reads + 1);
     cigar_off = _b[4].get<uint32_t>(reads + 2); seq_off = _b[5].get<uint64_t>(reads + 2); file_rank = _b[6].get<uint32_t>(reads + 1);
     cigar = _b[7].get<uint32_t>(cig + 1); reads2 = _b[8].get<uint8_t>(bytes + 16);

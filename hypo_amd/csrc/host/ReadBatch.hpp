@@ -9,6 +9,7 @@
 // caller's page-locked staging arrays, which go to the device as they are.  Alignment objects are made from the same slices only
 // when a host loop of the reference has to run (materialize(): --host-arms, an unsorted file, a device error, the CPU test shim).
 #pragma once
+#include <sys/mman.h>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -43,9 +44,12 @@ struct ParsedBlock {
     enum : uint8_t { ST_KEPT = 0, ST_SKIPPED = 1, ST_BADREF = 2, ST_INVALID = 3 };
 };
 
-// A grow-only buffer, page-locked (hypo_gpu_host_alloc) from 4 MB on: copies from / into it run at the link's rate.  Small ones
-// are plain memory — pinning has a per-call cost (a millisecond or more) that a 5 Mbp run, with two dozen staging arrays, would
-// pay for nothing — and so is everything when the library has no pinned memory to give (the CPU test shim).
+// A grow-only buffer, page-locked (hypo_gpu_host_alloc) between 4 and 64 MB: copies from / into it run at the link's rate.
+// Small ones are plain memory — pinning has a per-call cost (a millisecond or more) that a 5 Mbp run, with two dozen staging arrays,
+// would pay for nothing.  LARGE ones are plain memory as well: page-locking costs 0.18 s per GB and 0.12 s per GB to undo (MI355X
+// box, profiles/r04_pin_bench.txt) — the 3.9 GB of read staging of the 250 Mbp set took 0.84 s to lock for an upload of 0.17 s —
+// while the library stages a large copy out of ordinary memory through its own bounce buffers at the same rate (capi.hip, h2d).
+// Plain memory it is, too, when the library has no pinned memory to give (the CPU test shim).
 struct PinnedBuf {
     void* p = nullptr; size_t cap = 0; bool pinned = false;
     template <class T> T* get(size_t n) {
@@ -54,8 +58,12 @@ struct PinnedBuf {
             release();
             const size_t want = bytes + bytes / 4;
             void* q = nullptr;
-            if (want >= ((size_t)4 << 20) && hypo_gpu_host_alloc(want, &q) == HYPO_OK && q) { p = q; pinned = true; }
-            else { p = std::malloc(want); pinned = false; }
+            if (want >= ((size_t)4 << 20) && want <= ((size_t)64 << 20) && hypo_gpu_host_alloc(want, &q) == HYPO_OK && q) { p = q; pinned = true; }
+            else if (want > ((size_t)64 << 20)) {            // (2 MB pages where the system hands them out: a fresh GB is 512 page faults, not 262 144)
+                if (::posix_memalign(&q, (size_t)2 << 20, (want + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1)) != 0) q = nullptr;
+                if (q) (void)::madvise(q, want, MADV_HUGEPAGE);
+                p = q; pinned = false;
+            } else { p = std::malloc(want); pinned = false; }
             cap = p ? want : 0;
         }
         return (T*)p;
@@ -74,6 +82,7 @@ struct ReadStaging {
     uint64_t* seq_off = nullptr; uint8_t* reads2 = nullptr;
     uint32_t* file_rank = nullptr; bool ranked = false;      // ranked: the records were NOT sorted in the file; they are here, and file_rank says where each one was
     uint64_t n_reads = 0, n_cigar = 0, n_bytes = 0;
+    double reserve_seconds = 0;                                      // time spent growing the buffers, all calls
     bool reserve(size_t reads, size_t cig, size_t bytes);          // false: no memory
 private:
     PinnedBuf _b[9];

@@ -724,7 +724,8 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     // waves still drain the queue), and leaves its own counts behind for the next one.  HYPO_POA_SYNC_PLAN=1 waits every time.
     uint32_t* const pinned = A->planned_host;          // [0..7] this call's plan (async copy), [8..15] final counts of the last finished call
     const hipEvent_t planned_ev = A->planned_ev;
-    const bool wait_for_plan = !A->history_valid || getenv("HYPO_POA_SYNC_PLAN") != nullptr;
+    const bool have_history = A->history_valid && A->next_kind == A->last_kind;      // (PoaAux::next_kind)
+    const bool wait_for_plan = !have_history || getenv("HYPO_POA_SYNC_PLAN") != nullptr;
     uint32_t hist[24];
     if (!wait_for_plan) {
         // what the previous call left in the pinned buffer (complete unless that call is still running: then the one before it)
@@ -739,7 +740,7 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     (void)hipEventRecord(planned_ev, stream);
     if (wait_for_plan) {
         if ((e = hipEventSynchronize(planned_ev)) != hipSuccess) return e;
-        for (int c = 0; c < 8; ++c) { hist[c] = pinned[c]; hist[8 + c] = A->history_valid ? pinned[8 + c] : 0u; hist[16 + c] = A->history_valid ? A->last_planned[c] : 0u; }
+        for (int c = 0; c < 8; ++c) { hist[c] = pinned[c]; hist[8 + c] = have_history ? pinned[8 + c] : 0u; hist[16 + c] = have_history ? A->last_planned[c] : 0u; }
     }
     const uint32_t* const planned_host = hist;
     // Windows re-queued into a class are only known on the device.  The grids of the mop-up passes and of the rare classes
@@ -782,13 +783,13 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     if (const char* cs = getenv("HYPO_POA_CAPS")) sscanf(cs, "%d,%d,%d,%d,%d", &caps[0], &caps[1], &caps[2], &caps[3], &caps[4]);
     // wave-time per class of the last finished call (PoaQueues::work; read like the counts above: whatever call finished last)
     uint64_t last_work[3];
-    for (int c = 0; c < 3; ++c) last_work[c] = wait_for_plan && !A->history_valid ? 0ull : ((const volatile uint64_t*)(pinned + 24))[c];
+    for (int c = 0; c < 3; ++c) last_work[c] = wait_for_plan && !have_history ? 0ull : ((const volatile uint64_t*)(pinned + 24))[c];
     // One kernel after the other instead: when the last call left more than a tenth of its windows to class 3 (read error of
     // several per cent) every kernel is long and fills the chip alone, and fixed LDS shares only leave the share of whichever
     // kernel ends first idle: 5 % read error 47 -> 40 ms, 3 % 30 -> 29 ms; below that the concurrent schedule wins (2 %: 20 against
     // 21.6 ms, C2: 3.7 against 4.2 ms; profiles/diag/r03_seq.sh, r03_backfill.sh).  HYPO_POA_SEQUENTIAL=0|1 forces.
     const char* seq_env = getenv("HYPO_POA_SEQUENTIAL");
-    const bool sequential = seq_env ? atoi(seq_env) > 0 : (A->history_valid && (uint64_t)last_count[3] * kSequentialDivisor > n_windows);
+    const bool sequential = seq_env ? atoi(seq_env) > 0 : (have_history && (uint64_t)last_count[3] * kSequentialDivisor > n_windows);
     auto rec = [&](int idx, hipStream_t st) { if (prof) (void)hipEventRecord(prof->ev[idx], st); };
     if (sequential) {
 #define HYPO_LAUNCH(ID, CFG)                                                                              \
@@ -828,7 +829,7 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
         // of four groups takes twice the time of one of two)
         const uint64_t measured_gw = ((const volatile uint64_t*)(pinned + 24))[6];
         const bool same_kind = measured_gw == (four_groups ? (uint64_t)PoaClass0::GW : (uint64_t)PoaClass0W::GW);
-        if (!getenv("HYPO_POA_CAPS") && adapt && A->history_valid && same_kind) {
+        if (!getenv("HYPO_POA_CAPS") && adapt && have_history && same_kind) {
             const uint32_t seen3_now = last_count[3] > planned_host[3] ? last_count[3] : planned_host[3];
             const int poll_waves_per_cu = seen3_now == 0 ? 0 : ((seen3_now + seen3_now / 4) > 512u ? 2 : 1);
             pick_wave_shares(last_work, four_groups, poll_waves_per_cu, caps);
@@ -939,6 +940,7 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     for (int c = 0; c < 8; ++c) A->last_planned[c] = hist[c];
     A->history_valid = true;
     A->history_windows = n_windows;
+    A->last_kind = A->next_kind;
     rec(2 + 2 * kNumPoaClasses, stream);
     pe = 3 + 2 * kNumPoaClasses;
     if (prof) prof->n = pe;

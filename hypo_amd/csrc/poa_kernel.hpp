@@ -67,6 +67,11 @@ struct PoaAux {
     uint32_t last_planned[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // planned counts the previous call worked with
     bool history_valid = false;           // a call has been queued on this context before
     uint32_t history_windows = 0;         // its batch size
+    // What the caller knows about the batch it hands over: 0 = windows of short reads, 1 = the LONG windows of a -B run.  The history
+    // above describes the batch before this one; when the kind changes it says nothing about this one (a LONG batch sized from
+    // the plan of the SHORT batch before it got 256 of its 2 048 waves: 1.84 s instead of 0.35 s on the 250 Mbp set of round 4),
+    // and the call waits for its own plan as a first call does.
+    int next_kind = 0, last_kind = 0;
 };
 void poa_release(PoaAux* a);
 

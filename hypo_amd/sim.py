@@ -206,7 +206,7 @@ def solid_bitset(codes: np.ndarray, k: int, max_count: int = 1) -> np.ndarray:
     return words
 
 
-def c4_batch(n_short: int, n_long: int, seed: int = 1, long_err: float = 0.10) -> HostBatch:
+def c4_batch(n_short: int, n_long: int, seed: int = 1, long_err: float = 0.10, long_len=(120, 500), long_arms=(12, 45)) -> HostBatch:
     """The window mix of BASELINE config C4 (short reads + noisy long reads, `-B`): C1-shaped SHORT windows and LONG windows
     (120-500 bp, 12-45 long-read arms of about the window's length with `long_err` errors incl. indels, up to two empty arms),
     shuffled into one batch as Hypo::polish hands them over."""
@@ -214,7 +214,7 @@ def c4_batch(n_short: int, n_long: int, seed: int = 1, long_err: float = 0.10) -
     tab, cnt = load_shape("c1_shape")
     sh = tab[rng.choice(tab.shape[0], size=n_short, p=cnt / cnt.sum())]
     zeros = np.zeros(n_long, np.int64)
-    lg = np.stack([rng.integers(120, 500, size=n_long), rng.integers(12, 45, size=n_long), zeros, zeros, rng.integers(0, 3, size=n_long)], axis=1)
+    lg = np.stack([rng.integers(long_len[0], long_len[1], size=n_long), rng.integers(long_arms[0], long_arms[1], size=n_long), zeros, zeros, rng.integers(0, 3, size=n_long)], axis=1)
     shapes = np.concatenate([sh, lg])
     mask = np.concatenate([np.zeros(n_short, bool), np.ones(n_long, bool)])
     perm = rng.permutation(shapes.shape[0])

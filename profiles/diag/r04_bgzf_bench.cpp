@@ -11,10 +11,10 @@ int main(int argc, char** argv) {
     double tcut = 0;
     while (blocks < 100000) {
         bool more = sf.read_block(b, 1 << 19, (size_t)128 << 20);
-        n += b.n(); for (size_t i = 0; i < b.n(); i += 1000) bytes += b.len(i);
+        n += b.n(); for (size_t i = 0; i < b.n(); i += 16) bytes += 16 * (b.len(i) + 4);
         ++blocks;
         if (!more && b.n() == 0) break;
     }
     double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    printf("%zu records in %.2f s = %.1f M rec/s (%d blocks) ~%.2f GB/s inflated\n", n, dt, n / dt / 1e6, blocks, n * 284.0 / dt / 1e9);
+    printf("%zu records in %.2f s = %.1f M rec/s (%d blocks) ~%.2f GB/s inflated\n", n, dt, n / dt / 1e6, blocks, (double)bytes / dt / 1e9);
 }

@@ -22,7 +22,10 @@ def main():
     b = build_batch(wins)
     if len(sys.argv) > 2 and sys.argv[2] == "c4":
         from hypo_amd import sim
-        b = sim.c4_batch(0, rep, seed=404)
+        if len(sys.argv) > 7:                             # long_rate.py <n> c4 <len_lo> <len_hi> <arms_lo> <arms_hi> <err>: the shapes of an end-to-end run
+            b = sim.c4_batch(0, rep, seed=404, long_err=float(sys.argv[7]), long_len=(int(sys.argv[3]), int(sys.argv[4])), long_arms=(int(sys.argv[5]), int(sys.argv[6])))
+        else:
+            b = sim.c4_batch(0, rep, seed=404)
         wins = [None] * rep
     lib = os.environ.get("HYPO_GPU_LIB")
     gpu = capi.HypoGpu(0, path=lib) if lib else capi.HypoGpu(0)

@@ -138,7 +138,7 @@ def build_fast_generator():
     return FAST_GEN_BIN
 
 
-def run_fast_case(name, outdir, threads, extra_args=(), extra_env=None, timeout=1800, bam=False):
+def run_fast_case(name, outdir, threads, extra_args=(), extra_env=None, timeout=1800, bam=False, device="gpu"):
     """Generates the inputs of golden `name` with the C++ generator (checked against the manifest's checksums), runs the `hypo`
     binary on them.  Returns (manifest, CompletedProcess, seconds of the run, peak RSS of the child in MB).  bam: the same records
     as BAM (BGZF) instead of SAM text (the generator's --bam; the draft, the solid set and the number of records are checked against
@@ -148,17 +148,20 @@ def run_fast_case(name, outdir, threads, extra_args=(), extra_env=None, timeout=
     man = json.load(open(os.path.join(GOLD, name + ".manifest.json")))
     a = man["args"]
     gen = build_fast_generator()
+    flags = list(a["flags"]) if "flags" in a else []
+    golden_is_bam = "--bam" in flags
+    if bam and not golden_is_bam:
+        flags.append("--bam")
     rep = json.loads(subprocess.check_output([gen, str(outdir), str(a["seed"]), str(a["contigs"]), str(a["contig_len"]), str(a["k"]),
-                                              str(a["coverage"]), str(a["read_len"]), str(a["read_sub_ppm"])] +
-                                             (list(a["flags"]) if "flags" in a else (["--bam"] if bam else [])), text=True))
+                                              str(a["coverage"]), str(a["read_len"]), str(a["read_sub_ppm"])] + flags, text=True))
     want = man["generator_report"]
-    if "flags" in a:                                 # a golden made from the flagged output itself (BAM): everything must match
-        bam = "--bam" in a["flags"]
+    if golden_is_bam or ("flags" in a and not bam):  # a golden made from the flagged output itself: everything must match
+        bam = golden_is_bam
         assert rep == want, f"{name}: the generator's output changed: {rep}"
-    elif bam:
+    elif bam:                                        # the records of a SAM golden as BAM
         assert "fnv_bam_blocks" in rep
-        for key in ("contigs", "draft_bases", "reads", "solid_kmers", "fnv_draft", "fnv_bitvector"):
-            assert rep[key] == want[key], f"{name}: the generator's output changed: {key} = {rep[key]}"
+        for key in ("contigs", "draft_bases", "reads", "solid_kmers", "fnv_draft", "fnv_bitvector", "long_reads"):
+            assert rep.get(key) == want.get(key), f"{name}: the generator's output changed: {key} = {rep.get(key)}"
     else:
         assert rep == want, f"{name}: the generator's output changed: {rep}"
     argv = [BIN] + man["command"].split()[1:]
@@ -171,13 +174,15 @@ def run_fast_case(name, outdir, threads, extra_args=(), extra_env=None, timeout=
     argv[argv.index("-t") + 1] = str(threads)
     argv += list(extra_args)
     env = dict(os.environ)
+    if device == "shim":                             # the CPU oracle behind the C-ABI (tests/shim): the host pipeline without a GPU
+        env["LD_LIBRARY_PATH"] = SHIM_DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
     env.update(extra_env or {})
     before = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
     t0 = time.perf_counter()
     p = subprocess.run(argv, cwd=str(outdir), env=env, capture_output=True, text=True, timeout=timeout)
     dt = time.perf_counter() - t0
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    assert "oracle_device_shim" not in p.stderr, "wrong device library behind the C-ABI"
+    assert ("oracle_device_shim" in p.stderr) == (device == "shim"), "wrong device library behind the C-ABI"
     rss = max(resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss, before) / 1024.0
     return man, p, dt, rss
 

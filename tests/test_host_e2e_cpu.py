@@ -53,3 +53,16 @@ def test_e2e_ccs_windows_match_the_reference_with_kind_ccs_applied(built, tmp_pa
     3-kbp HiFi-like reads: 236 windows of ~ 500 bp, graphs of up to 546 nodes."""
     man, _ = eu.run_case("e2e_120k_ccs_s47", tmp_path, "shim")
     assert eu.check_outputs("e2e_120k_ccs_s47", tmp_path, man) > 200
+
+
+@pytest.mark.parametrize("bam", [False, True])
+def test_e2e_long_read_edit_distance_filter_counts_and_fasta(built, bam, tmp_path):
+    """`-n 7` on the C4-in-small set (one 5 Mbp contig, 40x long reads with 8 % errors): the NM-based filter of the long-read
+    constructor (src/Alignment.cpp:51-58: edit distance * 100 / reference span, integers, compared with the threshold) drops 22 401
+    of the 24 894 long reads.  The flat long-read parser (Hypo::parse_block) reads NM from a SAM line and from a BAM record's
+    optional fields alike: the loaded / invalid counts and the polished FASTA are the REAL reference's (manifest)."""
+    import re
+    man, p, _, _ = eu.run_fast_case("e2e_c4s_5m_s55_n7", tmp_path, threads=8, bam=bam, device="shim")
+    counts = re.findall(r"Number of alignments \(Batch 0\): loaded \((\d+)\) invalid \((\d+)\)", p.stdout)
+    assert [int(x) for x in counts[-1]] == man["expected_long_reads_loaded_invalid"], counts
+    assert eu.fasta_md5(tmp_path) == man["expected_fasta_md5"]
