@@ -38,6 +38,15 @@ public:
         while (--need) word &= word - 1;
         return lo * 64 + (uint64_t)__builtin_ctzll(word);
     }
+    // the positions of all set bits, in order (entry i = select(i + 1)): one pass over the words instead of a binary search per bit
+    template <class T> void list_set(std::vector<T>& out) const {
+        out.clear();
+        if (!_r.empty()) out.reserve(_r.back());
+        for (uint64_t wi = 0; wi < _w.size(); ++wi) {
+            uint64_t word = _w[wi];
+            while (word) { out.push_back((T)(wi * 64 + (uint64_t)__builtin_ctzll(word))); word &= word - 1; }
+        }
+    }
     void clear() { _n = 0; std::vector<uint64_t>().swap(_w); std::vector<uint64_t>().swap(_r); }
 
 private:

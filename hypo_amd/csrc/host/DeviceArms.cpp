@@ -260,8 +260,11 @@ bool DeviceArms::build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c
         const uint64_t base = cbase[(size_t)ci];
         uint64_t r = rbase[(size_t)ci];
         const uint32_t sr_before = (uint32_t)(abase[(size_t)ci] / 2);
+        std::vector<uint32_t> border;                              // (a 250 Mbp contig has 7 M regions: no select() per region)
+        ctg._reg_pos.list_set(border);
+        if (border.size() < nr) { bad = true; continue; }
         for (uint32_t i = 0; i < nr; ++i, ++r) {
-            start[r] = (uint32_t)(base + ctg._reg_pos.select((uint64_t)i + 1));
+            start[r] = (uint32_t)(base + border[i]);
             type[r] = (uint8_t)ctg._reg_type[i];
             info[r] = ctg._reg_info[i] + (ctg._reg_type[i] == RegionType::SR ? sr_before : 0u);
             _reg_window[r] = ctg._pwindows[i].get();
