@@ -147,6 +147,15 @@ void Hypo::polish() {
             // parallel phases run next to it)
             prefetch = std::thread([this, batch_id, &staged, helper_threads] { omp_set_num_threads(helper_threads); create_alignments_flat(batch_id + 1, staged); });
         }
+        // ... and THIS batch's long reads (-B) are read and parsed while its short-read phases run (the reference loads them behind the
+        // short arms, src/Hypo.cpp:225-229; what they are does not depend on anything those phases compute): 2.4 of the 8 s of the
+        // 250 Mbp set.  The record the long reader consumed for a later contig during the LAST batch is already in that contig's
+        // store entry (below), so the order of the two streams is the reference's.
+        std::thread long_prefetch;
+        if (prefetch_on && !_cFlags.lr_bam_filename.empty()) {
+            _reads_long.reset(_contigs.size());
+            long_prefetch = std::thread([this, batch_id, helper_threads] { omp_set_num_threads(helper_threads); create_alignments_flat(batch_id, _reads_long, false); });
+        }
         std::vector<char> materialized(final_cid - initial_cid, 0);        // per contig of the batch: its Alignment objects exist (host loops)
         _mat_base = initial_cid;
         // The first long read of a contig may have been consumed while the previous batch's long reads were loaded; the reference
@@ -338,8 +347,8 @@ void Hypo::polish() {
             // build on the 250 Mbp set).  The reader stops behind the first kept record of a later contig; the reference files that
             // record in ITS contig's store entry (src/Hypo.cpp:314-325), where that batch's short-read phases find it: it becomes
             // an object there (see the top of the batch loop).
-            _reads_long.reset(_contigs.size());
-            create_alignments_flat(batch_id, _reads_long, false);
+            if (long_prefetch.joinable()) long_prefetch.join();
+            else { _reads_long.reset(_contigs.size()); create_alignments_flat(batch_id, _reads_long, false); }
             if (_rs_long.carry_blk) {
                 ReadBatch one;
                 one.reset(_contigs.size());
@@ -349,8 +358,10 @@ void Hypo::polish() {
             }
             stop("[Hypo:Hypo]: Loaded alignments of Long reads. ");
             start();
+            const auto tl0 = std::chrono::steady_clock::now();
 #pragma omp parallel for schedule(static, 1)
             for (int64_t i = initial_cid; i < (int64_t)final_cid; ++i) _contigs[(size_t)i]->prepare_long_windows();
+            const auto tl1 = std::chrono::steady_clock::now();
             // the long reads are cut into arms, filtered (Filter::is_good) and kept as a second resident batch by the context that
             // holds the contig's short arms; --host-arms, an unsorted file or a device error take the reference's host loops
             std::vector<char> long_on_dev(final_cid - initial_cid, 0);
@@ -388,7 +399,12 @@ void Hypo::polish() {
                 _contigs[(size_t)i]->fill_long_windows(_alignment_store[(size_t)i]); _alignment_store[(size_t)i].clear();
             }
             for (uint32_t c = initial_cid; c < final_cid; ++c) long_dev[c - initial_cid] = long_on_dev[c - initial_cid];
+            const auto tl2 = std::chrono::steady_clock::now();
             _reads_long.clear(&_block_pool, &_pool_mu);
+            if (std::getenv("HYPO_HOST_TIMING")) {
+                auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+                std::fprintf(stderr, "[timing] long arms: prepare_long_windows %.3f s, arms %.3f s, long reads released %.3f s\n", sec(tl0, tl1), sec(tl1, tl2), sec(tl2, std::chrono::steady_clock::now()));
+            }
             stop("[Hypo:Hypo]: Long arms filling. ");
         } else {
             Contig::set_no_long_reads();

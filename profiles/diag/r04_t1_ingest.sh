@@ -17,6 +17,10 @@ for l in sys.stdin:
     if m: acc[m.group(1)]=acc.get(m.group(1),0)+float(m.group(2))
 print('  '.join(f'{k}: {v:.2f}' for k,v in acc.items()))"
   grep "create_alignments_flat" run.err | awk '{w+=$6; p+=$10; c+=$15} END {printf "  reader: waiting for records %.2f s, parse %.2f s, into the batch %.2f s\n", w, p, c}'
-  grep "upload_reads" run.err | awk '{f+=$8; u+=$11} END {printf "  upload_reads: flatten %.2f s, upload %.2f s\n", f, u}'
+  grep "upload_reads" run.err | awk '{f+=$8; u+=$17} END {printf "  upload_reads: flatten %.2f s, upload %.2f s\n", f, u}'
+  grep "support_kmers:" run.err | sed 's/.*whole call //' | awk '{w+=$1} END {printf "  support_kmers: whole calls %.2f s\n", w}'
+  grep "support_minimizers:" run.err | awk '{t+=$4; k+=$7} END {printf "  support_minimizers: tables %.2f s, device call %.2f s\n", t, k}'
+  grep "device arms: flatten" run.err | awk '{f+=$5; b+=$8; p+=$13} END {printf "  short arms: tables %.2f s, hypo_gpu_arms_build %.2f s, prune %.2f s\n", f, b, p}'
+  grep "hypo_gpu_arms_poa: device" run.err | sed 's/.*kernels //' | awk '{k+=$1} END {printf "  hypo_gpu_arms_poa: kernels %.2f s\n", k / 1000}'
 done
 rm -rf $D
