@@ -75,7 +75,7 @@ void Hypo::polish() {
     if (!_sf_short->ok()) { std::fprintf(stderr, "[Hypo::Hypo] Error: File open error: %s\n", _cFlags.sr_bam_filename.c_str()); std::exit(1); }
     _sf_short->set_inflate_threads(std::max(1, (int)_cFlags.threads));      // (BGZF: inflate is what bounds a BAM run — 280 bytes per 150-bp record)
     // the short reads of the first batch are parsed while the contigs are scanned (the parser needs the contigs' names and lengths only)
-    std::thread prefetch;
+    std::thread prefetch, long_release;
     ReadBatch staged;                                      // the next batch's short reads while the helper parses them
     const bool prefetch_on = !(std::getenv("HYPO_PREFETCH") && std::atoi(std::getenv("HYPO_PREFETCH")) == 0);
     const int helper_threads = (2 * (int)_cFlags.threads <= (int)std::thread::hardware_concurrency()) ? (int)_cFlags.threads : std::max(1, (int)_cFlags.threads / 2);
@@ -153,6 +153,7 @@ void Hypo::polish() {
         // store entry (below), so the order of the two streams is the reference's.
         std::thread long_prefetch;
         if (prefetch_on && !_cFlags.lr_bam_filename.empty()) {
+            if (long_release.joinable()) long_release.join();
             _reads_long.reset(_contigs.size());
             long_prefetch = std::thread([this, batch_id, helper_threads] { omp_set_num_threads(helper_threads); create_alignments_flat(batch_id, _reads_long, false); });
         }
@@ -400,7 +401,10 @@ void Hypo::polish() {
             }
             for (uint32_t c = initial_cid; c < final_cid; ++c) long_dev[c - initial_cid] = long_on_dev[c - initial_cid];
             const auto tl2 = std::chrono::steady_clock::now();
-            _reads_long.clear(&_block_pool, &_pool_mu);
+            // (7 GB of parsed long reads on the 250 Mbp set: handed back behind the POA, not in front of it)
+            if (long_release.joinable()) long_release.join();
+            long_release = std::thread([this, spent = std::make_shared<ReadBatch>(std::move(_reads_long))] { spent->clear(&_block_pool, &_pool_mu); });
+            _reads_long = ReadBatch();
             if (std::getenv("HYPO_HOST_TIMING")) {
                 auto sec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
                 std::fprintf(stderr, "[timing] long arms: prepare_long_windows %.3f s, arms %.3f s, long reads released %.3f s\n", sec(tl0, tl1), sec(tl1, tl2), sec(tl2, std::chrono::steady_clock::now()));
@@ -472,6 +476,7 @@ void Hypo::polish() {
         });
     }
     _alignment_store.clear();
+    if (long_release.joinable()) long_release.join();
 
     start();
     if (writer.joinable()) writer.join();
