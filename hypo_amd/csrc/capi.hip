@@ -1098,8 +1098,8 @@ int hypo_gpu_support_minimizers(const HypoMegaWindows* W, uint32_t* coverage, ui
     HIP_TRY(hipMemsetAsync(d + o_cov, 0, c.at - o_cov, st));
     hypo::MegaWindows M;
     M.contig_base = (const uint32_t*)(d + o_cb); M.reg_base = (const uint32_t*)(d + o_rbase); M.win_even = (const uint8_t*)(d + o_even); M.info_base = (const uint32_t*)(d + o_ib);
-    M.start = (const uint32_t*)(d + o_start); M.mw_off = (const uint32_t*)(d + o_off); M.rel_pos = (const uint32_t*)(d + o_rel); M.minimisers = (const uint32_t*)(d + o_min);
-    HIP_TRY(hypo::support_minimizers(support_reads_of(g_ctx), M, (uint32_t*)(d + o_cov), (uint32_t*)(d + o_sup), st));
+    M.start = (const uint32_t*)(d + o_start); M.mw_off = (const uint32_t*)(d + o_off); M.rel_pos = (uint32_t*)(d + o_rel); M.minimisers = (const uint32_t*)(d + o_min);
+    HIP_TRY(hypo::support_minimizers(support_reads_of(g_ctx), M, nc, W->n_info, (uint32_t*)(d + o_cov), (uint32_t*)(d + o_sup), st));
     HIP_TRY(hipMemcpyAsync(coverage, d + o_cov, n_ent * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(support, d + o_sup, n_ent * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

@@ -492,6 +492,24 @@ void Contig::fill_long_windows(std::vector<std::unique_ptr<Alignment>>& alignmen
     std::vector<uint32_t>().swap(_true_reg_id);
 }
 
+void Contig::dump_votes(std::FILE* f, int which) const {
+    const uint32_t head[2] = {(uint32_t)which, _id};
+    std::fwrite(head, 4, 2, f);
+    if (which == 0) {
+        const uint64_t n = _kcov.size();
+        std::fwrite(&n, 8, 1, f);
+        std::fwrite(_kcov.data(), 4, n, f); std::fwrite(_ksup.data(), 4, n, f);
+    } else {
+        const uint64_t n = _minimserinfo.size();
+        std::fwrite(&n, 8, 1, f);
+        for (const MWMinimiserInfo& mi : _minimserinfo) {
+            const uint64_t m = mi.coverage.size();
+            std::fwrite(&m, 8, 1, f);
+            std::fwrite(mi.coverage.data(), 4, m, f); std::fwrite(mi.support.data(), 4, m, f);
+        }
+    }
+}
+
 void Contig::release_after_output() {
     std::vector<std::unique_ptr<Window>>().swap(_pwindows);
     std::vector<RegionType>(1, RegionType::SR).swap(_reg_type);      // (get_num_regions() stays defined: 0)

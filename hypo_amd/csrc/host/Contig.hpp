@@ -5,6 +5,7 @@
 // batched by Hypo::polish through Window::generate_consensus_batch.  sdsl's bit vectors are BitVec; the per-k-mer
 // mutexes of the reference are atomic adds.
 #pragma once
+#include <cstdio>
 #include <cstdint>
 #include <iosfwd>
 #include <memory>
@@ -42,6 +43,9 @@ public:
 
     int find_solid_pos(const SolidKmers& sk, bool set_on_device = false);                        // device scan; HYPO_OK or C-ABI error
     void adopt_solid_scan(const uint64_t* words, const uint64_t* rank, const uint64_t* kids, uint64_t n_solid);
+    // test hook (HYPO_DUMP_VOTES): the vote counters as they stand — which = 0: KmerInfo coverage / support of the solid k-mers (before
+    // prepare_for_division spends them), 1: MWMinimiserInfo coverage / support (before divide_into_regions does)
+    void dump_votes(std::FILE* f, int which) const;
     void prepare_for_division(unsigned k);
     void divide_into_regions();
     void fill_short_windows(std::vector<std::unique_ptr<Alignment>>& alignments);

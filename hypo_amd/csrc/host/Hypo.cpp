@@ -250,6 +250,8 @@ void Hypo::polish() {
             }
         }
         hypo_gpu_use_device(0);
+        if (const char* vp = std::getenv("HYPO_DUMP_VOTES"))        // (tests: device votes against the host loops of the reference, counter by counter)
+            if (std::FILE* vf = std::fopen(vp, batch_id == 0 ? "wb" : "ab")) { for (uint32_t c = initial_cid; c < final_cid; ++c) _contigs[c]->dump_votes(vf, 0); std::fclose(vf); }
         stop("[Hypo:Hypo]: Solid kmers support update. ");
 
         start();
@@ -285,6 +287,8 @@ void Hypo::polish() {
             }
         }
         hypo_gpu_use_device(0);
+        if (const char* vp = std::getenv("HYPO_DUMP_VOTES"))
+            if (std::FILE* vf = std::fopen(vp, "ab")) { for (uint32_t c = initial_cid; c < final_cid; ++c) _contigs[c]->dump_votes(vf, 1); std::fclose(vf); }
         stop("[Hypo:Hypo]: Minimisers support update. ");
 
         start();

@@ -9,7 +9,7 @@ run() {   # name, generator args..., then hypo args after --
   local D=/dev/shm/e2ek_$$_$name; rm -rf $D; mkdir -p $D
   local gen=(); while [ "$1" != "--" ]; do gen+=("$1"); shift; done; shift
   $R/tests/_build/gen_e2e_fast $D "${gen[@]}" > /dev/null
-  (cd $D && GPU_MAX_HW_QUEUES=8 rocprofv3 --kernel-trace --stats -d $D/prof -o t -- $R/hypo_amd/_build/hypo "$@" -o out.fa > run.log 2> run.err) || { tail -5 $D/run.err; return 1; }
+  (cd $D && GPU_MAX_HW_QUEUES=8 rocprofv3 --kernel-trace --stats --output-format csv -d $D/prof -o t -- $R/hypo_amd/_build/hypo "$@" -o out.fa > run.log 2> run.err) || { tail -5 $D/run.err; return 1; }
   echo "== $name: $(grep Overall $D/run.log | sed 's/.*TIME= //')"
   local f=$(find $D/prof -name "*kernel_stats.csv" | head -1)
   python3 - "$f" <<'PY'
