@@ -1,13 +1,14 @@
 #!/bin/bash
 # Where the 1 Gbp run (row T1, BAM) spends its time at -t 64 / -t 128: phase sums + the reader's own split (waiting / parse / collect).
+# env: K (15), SZ (1g), P (10), THREADS ("64 128"); e.g. K=17 SZ=3g P=50 THREADS=64 r04_t1_ingest.sh 500 = the shape of the 3 Gbp row in small
 set -e
-N=${1:-1000}
+N=${1:-1000}; K=${K:-15}; SZ=${SZ:-1g}; P=${P:-10}; THREADS=${THREADS:-"64 128"}
 D=/dev/shm/t1ing_$$; rm -rf $D; mkdir -p $D
-tests/_build/gen_e2e_fast $D 91 $N 1000000 15 30 150 2000 --bam --fast-hash > /dev/null
+tests/_build/gen_e2e_fast $D 91 $N 1000000 $K 30 150 2000 --bam --fast-hash > /dev/null
 cd $D
 export GPU_MAX_HW_QUEUES=8
-for T in 64 128; do
-  HYPO_HOST_TIMING=1 $GRAFT_REPO_ROOT/hypo_amd/_build/hypo -d draft.fa -r reads.fa -s 1g -c 30 -b sr.bam -t $T -i -p 10 -o out.fa > run.log 2> run.err
+for T in $THREADS; do
+  HYPO_HOST_TIMING=1 $GRAFT_REPO_ROOT/hypo_amd/_build/hypo -d draft.fa -r reads.fa -s $SZ -c 30 -b sr.bam -t $T -i -p $P -o out.fa > run.log 2> run.err
   echo "== -t $T: $(grep Overall run.log | sed 's/.*TIME= //')  md5 $(md5sum out.fa | cut -c1-32)"
   grep "RESOURCES" run.log | python3 -c "
 import sys,re,collections
