@@ -185,6 +185,41 @@ hipError_t h2d(void* dst, const void* src, size_t bytes, hipStream_t st) {
     return hipSuccess;
 }
 
+// Device memory -> host memory behind what is queued on `st`; the data is in `dst` on return.  The way back of h2d: the DMA engine
+// fills one bounce buffer while the copy threads empty the other into the caller's ordinary memory (160 MB of vote counters per
+// 50 Mbp batch of the 3 Gbp run come back this way).  Page-locked `dst`: copied into directly (queued; the caller synchronises).
+hipError_t d2h(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    constexpr size_t kStagedFrom = (size_t)8 << 20;
+    if (bytes < kStagedFrom) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, dst) == hipSuccess && at.type != hipMemoryTypeUnregistered) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+    (void)hipGetLastError();
+    Ctx& c = cur();
+    hipError_t e = c.bounce.ensure();
+    if (e != hipSuccess) { (void)hipGetLastError(); return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st); }
+    std::lock_guard<std::mutex> lk(g_copy_mu);
+    Bounce& b = c.bounce;
+    size_t prev_at = 0, prev_n = 0; int prev_i = -1;
+    for (size_t at0 = 0; at0 < bytes; at0 += Bounce::kChunk) {
+        const size_t n = bytes - at0 < Bounce::kChunk ? bytes - at0 : Bounce::kChunk;
+        const int i = b.turn; b.turn ^= 1;
+        if (b.used[i] && (e = hipEventSynchronize(b.ev[i])) != hipSuccess) return e;      // (an upload that last read this buffer)
+        if ((e = hipMemcpyAsync(b.buf[i], (const char*)src + at0, n, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+        if ((e = hipEventRecord(b.ev[i], st)) != hipSuccess) return e;
+        b.used[i] = true;
+        if (prev_i >= 0) {                                                                 // empty the other buffer while this one fills
+            if ((e = hipEventSynchronize(b.ev[prev_i])) != hipSuccess) return e;
+            g_copy_pool.copy((char*)dst + prev_at, (const char*)b.buf[prev_i], prev_n);
+        }
+        prev_i = i; prev_at = at0; prev_n = n;
+    }
+    if (prev_i >= 0) {
+        if ((e = hipEventSynchronize(b.ev[prev_i])) != hipSuccess) return e;
+        g_copy_pool.copy((char*)dst + prev_at, (const char*)b.buf[prev_i], prev_n);
+    }
+    return hipSuccess;
+}
+
 ProfCall* prof_next(int kind) {
     if (g_prof.used >= (int)g_prof.calls.size()) return nullptr;
     ProfCall* c = &g_prof.calls[g_prof.used++];
@@ -834,8 +869,8 @@ int hypo_gpu_solid_scan(const uint8_t* packed4, uint64_t n_bases, uint32_t k, co
     if (rc) return rc;
     uint64_t ns = 0;
     HIP_TRY(hipMemcpyAsync(&ns, dN.p, 8, hipMemcpyDeviceToHost, st));
-    if (nw) HIP_TRY(hipMemcpyAsync(solid_pos_words, dWords.p, nw * 8, hipMemcpyDeviceToHost, st));
-    if (word_rank) HIP_TRY(hipMemcpyAsync(word_rank, dRank.p, (nw + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (nw) HIP_TRY(d2h(solid_pos_words, dWords.p, nw * 8, st));
+    if (word_rank) HIP_TRY(d2h(word_rank, dRank.p, (nw + 1) * 8, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (kids && kids_cap) {
         const uint64_t cnt = ns < kids_cap ? ns : kids_cap;
@@ -875,8 +910,8 @@ int hypo_gpu_solid_scan_keep(uint32_t handle, const uint8_t* packed4, uint64_t n
                            narrow ? (uint32_t*)kid_arena : nullptr, spos_arena));
     uint64_t ns = 0;
     HIP_TRY(hipMemcpyAsync(&ns, dN.p, 8, hipMemcpyDeviceToHost, st));
-    if (nw) HIP_TRY(hipMemcpyAsync(solid_pos_words, dWords.p, nw * 8, hipMemcpyDeviceToHost, st));
-    if (word_rank) HIP_TRY(hipMemcpyAsync(word_rank, dRank.p, (nw + 1) * 8, hipMemcpyDeviceToHost, st));
+    if (nw) HIP_TRY(d2h(solid_pos_words, dWords.p, nw * 8, st));
+    if (word_rank) HIP_TRY(d2h(word_rank, dRank.p, (nw + 1) * 8, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (handle >= g_ctx.kept.size()) g_ctx.kept.resize((size_t)handle + 1);
     Ctx::KeptScan& ks = g_ctx.kept[handle];
@@ -996,8 +1031,8 @@ int hypo_gpu_support_kmers(uint32_t k, uint64_t n_solid, const uint32_t* spos, c
     HIP_TRY(h2d(d + o_kd, kids, n_solid * 8, st));
     HIP_TRY(hipMemsetAsync(d + o_cov, 0, c.at - o_cov, st));
     HIP_TRY(hypo::support_kmers(support_reads_of(g_ctx), k, (uint32_t)n_solid, (const uint32_t*)(d + o_sp), (const uint64_t*)(d + o_kd), (uint32_t*)(d + o_cov), (uint32_t*)(d + o_sup), st));
-    HIP_TRY(hipMemcpyAsync(coverage, d + o_cov, n_solid * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(support, d + o_sup, n_solid * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(d2h(coverage, d + o_cov, n_solid * 4, st));
+    HIP_TRY(d2h(support, d + o_sup, n_solid * 4, st));
     HIP_TRY(hipStreamSynchronize(st));
     return HYPO_OK;
 }
@@ -1042,8 +1077,8 @@ int hypo_gpu_support_kmers_kept(uint32_t k, uint32_t n_contigs, const uint32_t* 
     HIP_TRY(hipMemsetAsync(d + o_cov, 0, c.at - o_cov, st));
     if (narrow) HIP_TRY(hypo::support_kmers32(support_reads_of(g_ctx), k, (uint32_t)ns, (const uint32_t*)(d + o_sp), (const uint32_t*)(d + o_kd), (uint32_t*)(d + o_cov), (uint32_t*)(d + o_sup), st));
     else HIP_TRY(hypo::support_kmers(support_reads_of(g_ctx), k, (uint32_t)ns, (const uint32_t*)(d + o_sp), (const uint64_t*)(d + o_kd), (uint32_t*)(d + o_cov), (uint32_t*)(d + o_sup), st));
-    HIP_TRY(hipMemcpyAsync(coverage, d + o_cov, ns * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(support, d + o_sup, ns * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(d2h(coverage, d + o_cov, ns * 4, st));
+    HIP_TRY(d2h(support, d + o_sup, ns * 4, st));
     HIP_TRY(hipStreamSynchronize(st));
     return HYPO_OK;
 }
@@ -1100,8 +1135,8 @@ int hypo_gpu_support_minimizers(const HypoMegaWindows* W, uint32_t* coverage, ui
     M.contig_base = (const uint32_t*)(d + o_cb); M.reg_base = (const uint32_t*)(d + o_rbase); M.win_even = (const uint8_t*)(d + o_even); M.info_base = (const uint32_t*)(d + o_ib);
     M.start = (const uint32_t*)(d + o_start); M.mw_off = (const uint32_t*)(d + o_off); M.rel_pos = (uint32_t*)(d + o_rel); M.minimisers = (const uint32_t*)(d + o_min);
     HIP_TRY(hypo::support_minimizers(support_reads_of(g_ctx), M, nc, W->n_info, (uint32_t*)(d + o_cov), (uint32_t*)(d + o_sup), st));
-    HIP_TRY(hipMemcpyAsync(coverage, d + o_cov, n_ent * 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(support, d + o_sup, n_ent * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(d2h(coverage, d + o_cov, n_ent * 4, st));
+    HIP_TRY(d2h(support, d + o_sup, n_ent * 4, st));
     HIP_TRY(hipStreamSynchronize(st));
     return HYPO_OK;
 }
@@ -1269,7 +1304,7 @@ static int arms_download_impl(int which, HypoWindow* windows, uint32_t* win_regi
     if (win_region && S.n_windows) HIP_TRY(hipMemcpyAsync(win_region, O.win_region, (size_t)S.n_windows * 4, hipMemcpyDeviceToHost, st));
     if (arm_len && S.n_arms) HIP_TRY(hipMemcpyAsync(arm_len, O.arm_len, (size_t)S.n_arms * 4, hipMemcpyDeviceToHost, st));
     if (arm_off && S.n_arms) HIP_TRY(hipMemcpyAsync(arm_off, O.arm_off, (size_t)S.n_arms * 8, hipMemcpyDeviceToHost, st));
-    if (arms2 && S.arms2_bytes) HIP_TRY(hipMemcpyAsync(arms2, O.arms2, S.arms2_bytes, hipMemcpyDeviceToHost, st));
+    if (arms2 && S.arms2_bytes) HIP_TRY(d2h(arms2, O.arms2, S.arms2_bytes, st));
     if (draft4 && S.draft4_bytes) HIP_TRY(hipMemcpyAsync(draft4, O.draft4, S.draft4_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return HYPO_OK;
@@ -1320,7 +1355,7 @@ static int arms_poa_impl(int which, const HypoScoreParams* scores, char* bases, 
     HIP_TRY(pr);
     if (timing) HIP_TRY(hipStreamSynchronize(st));
     const auto t2 = std::chrono::steady_clock::now();
-    HIP_TRY(hipMemcpyAsync(bases, ob + o_bases, S.out_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(d2h(bases, ob + o_bases, S.out_bytes, st));
     HIP_TRY(hipMemcpyAsync(off, O.out_off, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(len, ob + o_len, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(status, ob + o_st, n, hipMemcpyDeviceToHost, st));

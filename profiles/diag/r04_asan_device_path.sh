@@ -19,6 +19,7 @@ run() {  # name, expected md5 or -, generator args -- hypo args
   local n=$(grep -c "ERROR: AddressSanitizer\|runtime error" $D/run.err || true)
   echo "$name: md5 $got (expected $want), sanitizer reports: $n, device paths: $(grep -c 'on the device' $D/run.log)"
   grep -m3 "ERROR: AddressSanitizer\|runtime error" $D/run.err || true
+  grep -o "[a-z -]* on the device\|[a-z -]* on the host" $D/run.log | sort | uniq -c | sed 's/^/      /'
   rm -rf $D
 }
 run c4s_sam_n7 ce099e4541083bb19aa895b68bb87bfe 55 5 1000000 11 30 150 2000 --join --long 40 8000 --gaps 100000 1500 -- -d draft.fa -r reads.fa -s 5m -c 30 -b sr.sam -B lr.sam -t 16 -i -n 7
