@@ -5,7 +5,7 @@ Reference types mirrored: ScoreParams (include/globalDefs.hpp:58-66), hypo::Wind
 """
 import ctypes as C
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 HYPO_OK = 0
 HYPO_E_INVALID = -1

@@ -30,7 +30,7 @@ EXPORTS = [
     "hypo_gpu_arms_build", "hypo_gpu_arms_download", "hypo_gpu_arms_poa",
     "hypo_gpu_arms_build_long", "hypo_gpu_arms_download_long", "hypo_gpu_arms_poa_long",
     "hypo_gpu_reads_upload", "hypo_gpu_support_kmers", "hypo_gpu_support_minimizers",
-    "hypo_gpu_solid_scan_keep", "hypo_gpu_solid_release", "hypo_gpu_support_kmers_kept", "hypo_gpu_host_alloc", "hypo_gpu_host_free",
+    "hypo_gpu_solid_scan_keep", "hypo_gpu_solid_release", "hypo_gpu_support_kmers_kept", "hypo_gpu_host_alloc", "hypo_gpu_host_free", "hypo_gpu_host_register", "hypo_gpu_host_unregister",
 ]
 
 

@@ -141,6 +141,9 @@ struct Ctx {
     // buffers per handle (the caller's contig number); hypo_gpu_support_kmers_kept votes against them
     struct KeptScan { void* kids = nullptr; uint32_t* spos = nullptr; uint64_t n = 0, n_bases = 0; uint32_t k = 0; bool used = false; };
     std::vector<KeptScan> kept;
+    // released scans are parked, not freed: hipFree waits for the device and costs 0.1-0.3 ms a call — a contig batch of the 3 Gbp
+    // run releases 50 scans (100 buffers) inside its vote call.  Freed together when 16 GB are parked, and at shutdown.
+    std::vector<void*> kept_parked; size_t kept_parked_bytes = 0;
     int poa_flags = 0;                                 // hypo_gpu_set_option
     Bounce bounce;                                     // page-locked staging of large copies out of pageable memory (h2d below)
     std::vector<HypoWindow> sh_win; std::vector<uint64_t> sh_aoff, sh_off;   // rebased descriptors of this device's share (hypo_gpu_poa_batch_sharded)
@@ -369,6 +372,8 @@ static void release_ctx(Ctx& c) {
         c.bounce.release();
         for (auto& ks : c.kept) { if (ks.kids) (void)hipFree(ks.kids); if (ks.spos) (void)hipFree(ks.spos); }
         c.kept.clear();
+        for (void* p : c.kept_parked) (void)hipFree(p);
+        c.kept_parked.clear(); c.kept_parked_bytes = 0;
         if (c.stream) (void)hipStreamDestroy(c.stream);
     }
     c.ready = false; c.device = -1; c.num_cus = 0; c.stream = nullptr;
@@ -933,11 +938,23 @@ int hypo_gpu_solid_release(uint32_t handle) {
     HYPO_LOCKED();
     HYPO_ON_DEVICE();
     if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
-    auto drop = [](Ctx::KeptScan& ks) { if (ks.kids) (void)hipFree(ks.kids); if (ks.spos) (void)hipFree(ks.spos); ks = Ctx::KeptScan(); };
-    if (handle == 0xffffffffu) { HIP_TRY(hipStreamSynchronize(g_ctx.stream)); for (auto& ks : g_ctx.kept) drop(ks); return HYPO_OK; }
-    if (handle >= g_ctx.kept.size() || !g_ctx.kept[handle].used) return fail(HYPO_E_INVALID, "handle %u holds no scan on this context", handle);
-    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-    drop(g_ctx.kept[handle]);
+    Ctx& cx = g_ctx;
+    auto drop = [&cx](Ctx::KeptScan& ks) {
+        const size_t kb = (size_t)ks.n * (ks.k <= 16 ? 4 : 8), sb = (size_t)ks.n * 4;
+        if (ks.kids) { cx.kept_parked.push_back(ks.kids); cx.kept_parked_bytes += kb; }
+        if (ks.spos) { cx.kept_parked.push_back(ks.spos); cx.kept_parked_bytes += sb; }
+        ks = Ctx::KeptScan();
+    };
+    if (handle == 0xffffffffu) for (auto& ks : cx.kept) drop(ks);
+    else {
+        if (handle >= cx.kept.size() || !cx.kept[handle].used) return fail(HYPO_E_INVALID, "handle %u holds no scan on this context", handle);
+        drop(cx.kept[handle]);
+    }
+    if (handle == 0xffffffffu || cx.kept_parked_bytes > ((size_t)16 << 30)) {
+        HIP_TRY(hipStreamSynchronize(cx.stream));
+        for (void* p : cx.kept_parked) (void)hipFree(p);
+        cx.kept_parked.clear(); cx.kept_parked_bytes = 0;
+    }
     return HYPO_OK;
 }
 
@@ -954,6 +971,18 @@ int hypo_gpu_host_free(void* p) {
     HIP_TRY(hipHostFree(p));
     return HYPO_OK;
 }
+int hypo_gpu_host_register(void* p, size_t bytes) {
+    if (!p || !bytes) return fail(HYPO_E_INVALID, "NULL / empty range");
+    HYPO_ON_DEVICE();
+    if (!g_ctx.ready) return fail(HYPO_E_NOTINIT, "hypo_gpu_init was not called");
+    HIP_TRY(hipHostRegister(p, bytes, hipHostRegisterDefault));
+    return HYPO_OK;
+}
+int hypo_gpu_host_unregister(void* p) {
+    if (!p) return HYPO_OK;
+    HIP_TRY(hipHostUnregister(p));
+    return HYPO_OK;
+}
 
 // ---- support votes on the device (kernels in support_kernel.hip) -----------------------------------------
 
@@ -968,19 +997,49 @@ int hypo_gpu_reads_upload(const HypoArmsReads* A, const uint32_t* read_contig, u
     if (na && (!A->rb || !A->re || !A->qae || !A->seq_off || !A->reads2 || !A->cigar_off || !A->cigar)) return fail(HYPO_E_INVALID, "NULL buffer in reads");
     uint32_t max_span = 0; uint64_t sum_span = 0;
     rr.ctg_min_rb.clear(); rr.ctg_max_re.clear();
-    for (uint32_t a = 0; a < na; ++a) {
-        if (A->re[a] <= A->rb[a] || A->re[a] > total_len) return fail(HYPO_E_INVALID, "alignment %u: span [%u, %u) outside the %llu bases", a, A->rb[a], A->re[a], (unsigned long long)total_len);
-        if (a && A->rb[a - 1] > A->rb[a]) return fail(HYPO_E_INVALID, "alignments are not sorted by reference start (alignment %u)", a);
-        if (A->seq_off[a] + ((uint64_t)A->qae[a] + 3) / 4 > A->reads2_bytes) return fail(HYPO_E_INVALID, "alignment %u: read outside reads2", a);
-        if (A->cigar_off[a] > A->cigar_off[a + 1]) return fail(HYPO_E_INVALID, "alignment %u: cigar_off decreases", a);
-        const uint32_t span = A->re[a] - A->rb[a];
-        max_span = span > max_span ? span : max_span;
-        sum_span += span;
-        const uint32_t rc = read_contig[a];
-        if (rc >= 0x01000000u) return fail(HYPO_E_INVALID, "alignment %u: contig index %u out of range", a, rc);
-        if (rc >= rr.ctg_min_rb.size()) { rr.ctg_min_rb.resize((size_t)rc + 1, 0xffffffffu); rr.ctg_max_re.resize((size_t)rc + 1, 0u); }
-        if (A->rb[a] < rr.ctg_min_rb[rc]) rr.ctg_min_rb[rc] = A->rb[a];
-        if (A->re[a] > rr.ctg_max_re[rc]) rr.ctg_max_re[rc] = A->re[a];
+    {   // every record is checked before anything is sent (10 M records per 50 Mbp batch: 40 ms on one thread, so eight share them)
+        struct Part { uint32_t bad = 0xffffffffu, max_span = 0; uint64_t sum_span = 0; std::vector<uint32_t> lo, hi; };
+        const int P = na >= (1u << 18) ? 8 : 1;
+        std::vector<Part> part((size_t)P);
+        auto bad_record = [&](uint32_t a) -> bool {
+            return A->re[a] <= A->rb[a] || A->re[a] > total_len || (a && A->rb[a - 1] > A->rb[a]) || A->seq_off[a] + ((uint64_t)A->qae[a] + 3) / 4 > A->reads2_bytes ||
+                   A->cigar_off[a] > A->cigar_off[a + 1] || read_contig[a] >= 0x01000000u;
+        };
+        auto run = [&](int t) {
+            Part& pt = part[(size_t)t];
+            const uint32_t a0 = (uint32_t)((uint64_t)na * (uint64_t)t / (uint64_t)P), a1 = (uint32_t)((uint64_t)na * ((uint64_t)t + 1) / (uint64_t)P);
+            for (uint32_t a = a0; a < a1; ++a) {
+                if (bad_record(a)) { pt.bad = a; return; }
+                const uint32_t span = A->re[a] - A->rb[a];
+                pt.max_span = span > pt.max_span ? span : pt.max_span;
+                pt.sum_span += span;
+                const uint32_t rc = read_contig[a];
+                if (rc >= pt.lo.size()) { pt.lo.resize((size_t)rc + 1, 0xffffffffu); pt.hi.resize((size_t)rc + 1, 0u); }
+                if (A->rb[a] < pt.lo[rc]) pt.lo[rc] = A->rb[a];
+                if (A->re[a] > pt.hi[rc]) pt.hi[rc] = A->re[a];
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < P; ++t) th.emplace_back(run, t);
+        run(0);
+        for (auto& x : th) x.join();
+        for (const Part& pt : part) {
+            if (pt.bad != 0xffffffffu) {                       // (parts are in record order: this is the first bad record)
+                const uint32_t a = pt.bad;
+                if (A->re[a] <= A->rb[a] || A->re[a] > total_len) return fail(HYPO_E_INVALID, "alignment %u: span [%u, %u) outside the %llu bases", a, A->rb[a], A->re[a], (unsigned long long)total_len);
+                if (a && A->rb[a - 1] > A->rb[a]) return fail(HYPO_E_INVALID, "alignments are not sorted by reference start (alignment %u)", a);
+                if (A->seq_off[a] + ((uint64_t)A->qae[a] + 3) / 4 > A->reads2_bytes) return fail(HYPO_E_INVALID, "alignment %u: read outside reads2", a);
+                if (A->cigar_off[a] > A->cigar_off[a + 1]) return fail(HYPO_E_INVALID, "alignment %u: cigar_off decreases", a);
+                return fail(HYPO_E_INVALID, "alignment %u: contig index %u out of range", a, read_contig[a]);
+            }
+            max_span = pt.max_span > max_span ? pt.max_span : max_span;
+            sum_span += pt.sum_span;
+            if (pt.lo.size() > rr.ctg_min_rb.size()) { rr.ctg_min_rb.resize(pt.lo.size(), 0xffffffffu); rr.ctg_max_re.resize(pt.lo.size(), 0u); }
+            for (size_t c = 0; c < pt.lo.size(); ++c) {
+                if (pt.lo[c] < rr.ctg_min_rb[c]) rr.ctg_min_rb[c] = pt.lo[c];
+                if (pt.hi[c] > rr.ctg_max_re[c]) rr.ctg_max_re[c] = pt.hi[c];
+            }
+        }
     }
     rr.total_len = total_len;
     const uint64_t n_cig = na ? A->cigar_off[na] : 0;

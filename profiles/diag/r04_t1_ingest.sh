@@ -1,14 +1,17 @@
 #!/bin/bash
 # Where the 1 Gbp run (row T1, BAM) spends its time at -t 64 / -t 128: phase sums + the reader's own split (waiting / parse / collect).
-# env: K (15), SZ (1g), P (10), THREADS ("64 128"); e.g. K=17 SZ=3g P=50 THREADS=64 r04_t1_ingest.sh 500 = the shape of the 3 Gbp row in small
+# env: K (15), SZ (1g), P (10), THREADS ("64 128"), VARIANTS="X=1|Y=2" VAR=value settings to run one after the other on the same files; e.g. K=17 SZ=3g P=50 THREADS=64 r04_t1_ingest.sh 500 = the shape of the 3 Gbp row in small
 set -e
 N=${1:-1000}; K=${K:-15}; SZ=${SZ:-1g}; P=${P:-10}; THREADS=${THREADS:-"64 128"}
 D=/dev/shm/t1ing_$$; rm -rf $D; mkdir -p $D
 tests/_build/gen_e2e_fast $D 91 $N 1000000 $K 30 150 2000 --bam --fast-hash > /dev/null
 cd $D
 export GPU_MAX_HW_QUEUES=8
+IFS="|" read -ra VARR <<< "${VARIANTS:-A=1}"
+for V in "${VARR[@]}"; do
 for T in $THREADS; do
-  HYPO_HOST_TIMING=1 $GRAFT_REPO_ROOT/hypo_amd/_build/hypo -d draft.fa -r reads.fa -s $SZ -c 30 -b sr.bam -t $T -i -p $P -o out.fa > run.log 2> run.err
+  echo "-- $V"
+  env $V HYPO_HOST_TIMING=1 $GRAFT_REPO_ROOT/hypo_amd/_build/hypo -d draft.fa -r reads.fa -s $SZ -c 30 -b sr.bam -t $T -i -p $P -o out.fa > run.log 2> run.err
   echo "== -t $T: $(grep Overall run.log | sed 's/.*TIME= //')  md5 $(md5sum out.fa | cut -c1-32)"
   grep "RESOURCES" run.log | python3 -c "
 import sys,re,collections
@@ -23,5 +26,6 @@ print('  '.join(f'{k}: {v:.2f}' for k,v in acc.items()))"
   grep "support_minimizers:" run.err | awk '{t+=$4; k+=$7} END {printf "  support_minimizers: tables %.2f s, device call %.2f s\n", t, k}'
   grep "device arms: flatten" run.err | awk '{f+=$5; b+=$8; p+=$13} END {printf "  short arms: tables %.2f s, hypo_gpu_arms_build %.2f s, prune %.2f s\n", f, b, p}'
   grep "hypo_gpu_arms_poa: device" run.err | sed 's/.*kernels //' | awk '{k+=$1} END {printf "  hypo_gpu_arms_poa: kernels %.2f s\n", k / 1000}'
+done
 done
 rm -rf $D

@@ -57,6 +57,8 @@ int hypo_gpu_solid_release(uint32_t h) { (void)h; return HYPO_OK; }
 int hypo_gpu_support_kmers_kept(uint32_t k, uint32_t n, const uint32_t* h, const uint32_t* b, uint32_t* cv, uint32_t* su, uint64_t* t) { (void)k; (void)n; (void)h; (void)b; (void)cv; (void)su; (void)t; return HYPO_E_UNSUPPORTED; }
 int hypo_gpu_host_alloc(size_t bytes, void** out) { *out = malloc(bytes ? bytes : 16); return *out ? HYPO_OK : HYPO_E_HIP; }
 int hypo_gpu_host_free(void* p) { free(p); return HYPO_OK; }
+int hypo_gpu_host_register(void* p, size_t bytes) { (void)p; (void)bytes; return HYPO_E_UNSUPPORTED; }
+int hypo_gpu_host_unregister(void* p) { (void)p; return HYPO_OK; }
 int hypo_gpu_poa_last_stats(HypoPoaStats* out) { (void)out; return HYPO_E_UNSUPPORTED; }
 int hypo_gpu_arms_build_long(const HypoArmsRegions* r, const HypoArmsReads* a, uint8_t* v, HypoArmsSummary* s) { (void)r; (void)a; (void)v; (void)s; return HYPO_E_UNSUPPORTED; }
 int hypo_gpu_arms_download_long(HypoWindow* w, uint32_t* r, uint32_t* l, uint64_t* o, uint8_t* a, uint8_t* d) { (void)w; (void)r; (void)l; (void)o; (void)a; (void)d; return HYPO_E_UNSUPPORTED; }
