@@ -73,12 +73,13 @@ void Hypo::polish() {
     if (_contig_batch_size && _contigs.size() % _contig_batch_size != 0) ++num_batches;
     _sf_short.reset(new SamReader(_cFlags.sr_bam_filename));
     if (!_sf_short->ok()) { std::fprintf(stderr, "[Hypo::Hypo] Error: File open error: %s\n", _cFlags.sr_bam_filename.c_str()); std::exit(1); }
-    _sf_short->set_inflate_threads(std::max(1, (int)_cFlags.threads));      // (BGZF: inflate is what bounds a BAM run — 280 bytes per 150-bp record)
+    _sf_short->set_inflate_threads(std::getenv("HYPO_INFLATE_THREADS") ? std::max(1, std::atoi(std::getenv("HYPO_INFLATE_THREADS"))) : std::max(1, (int)_cFlags.threads));      // (BGZF: inflate is what bounds a BAM run — 280 bytes per 150-bp record)
     // the short reads of the first batch are parsed while the contigs are scanned (the parser needs the contigs' names and lengths only)
     std::thread prefetch, long_release;
     ReadBatch staged;                                      // the next batch's short reads while the helper parses them
     const bool prefetch_on = !(std::getenv("HYPO_PREFETCH") && std::atoi(std::getenv("HYPO_PREFETCH")) == 0);
-    const int helper_threads = (2 * (int)_cFlags.threads <= (int)std::thread::hardware_concurrency()) ? (int)_cFlags.threads : std::max(1, (int)_cFlags.threads / 2);
+    int helper_threads = (2 * (int)_cFlags.threads <= (int)std::thread::hardware_concurrency()) ? (int)_cFlags.threads : std::max(1, (int)_cFlags.threads / 2);
+    if (const char* e = std::getenv("HYPO_HELPER_THREADS")) helper_threads = std::max(1, std::atoi(e));        // (experiments: the parser's team)
     if (prefetch_on && num_batches > 0) {
         staged.reset(_contigs.size());
         prefetch = std::thread([this, &staged, helper_threads] { omp_set_num_threads(helper_threads); create_alignments_flat(0, staged); });
