@@ -73,13 +73,19 @@ void Hypo::polish() {
     if (_contig_batch_size && _contigs.size() % _contig_batch_size != 0) ++num_batches;
     _sf_short.reset(new SamReader(_cFlags.sr_bam_filename));
     if (!_sf_short->ok()) { std::fprintf(stderr, "[Hypo::Hypo] Error: File open error: %s\n", _cFlags.sr_bam_filename.c_str()); std::exit(1); }
-    _sf_short->set_inflate_threads(std::getenv("HYPO_INFLATE_THREADS") ? std::max(1, std::atoi(std::getenv("HYPO_INFLATE_THREADS"))) : std::max(1, (int)_cFlags.threads));      // (BGZF: inflate is what bounds a BAM run — 280 bytes per 150-bp record)
+    // (a run of ONE batch has nothing beside the parser but the scans: it keeps whole teams)
+    const int side_team = num_batches > 1 ? std::max(1, (int)_cFlags.threads / 2) : std::max(1, (int)_cFlags.threads);
+    const int inflate_threads = std::getenv("HYPO_INFLATE_THREADS") ? std::max(1, std::atoi(std::getenv("HYPO_INFLATE_THREADS"))) : side_team;
+    _sf_short->set_inflate_threads(inflate_threads);      // (BGZF: inflate is what bounds a BAM run — 280 bytes per 150-bp record)
     // the short reads of the first batch are parsed while the contigs are scanned (the parser needs the contigs' names and lengths only)
     std::thread prefetch, long_release;
     ReadBatch staged;                                      // the next batch's short reads while the helper parses them
     const bool prefetch_on = !(std::getenv("HYPO_PREFETCH") && std::atoi(std::getenv("HYPO_PREFETCH")) == 0);
-    int helper_threads = (2 * (int)_cFlags.threads <= (int)std::thread::hardware_concurrency()) ? (int)_cFlags.threads : std::max(1, (int)_cFlags.threads / 2);
-    if (const char* e = std::getenv("HYPO_HELPER_THREADS")) helper_threads = std::max(1, std::atoi(e));        // (experiments: the parser's team)
+    // The parser's team and the team that inflates BGZF blocks for it are HALF of -t each: with all three teams (these two and the main
+    // thread's phases) at -t the stages only got in each other's way — 500 Mbp at k = 17, -t 64 on the 128-core box: 4.4-4.8 s with
+    // 64 / 64, 3.7-4.0 s with 32 / 32, 3.8 s with 16 / 16 or 24 / 24 (profiles/r04_thread_split.txt).
+    int helper_threads = side_team;
+    if (const char* e = std::getenv("HYPO_HELPER_THREADS")) helper_threads = std::max(1, std::atoi(e));        // (experiments)
     if (prefetch_on && num_batches > 0) {
         staged.reset(_contigs.size());
         prefetch = std::thread([this, &staged, helper_threads] { omp_set_num_threads(helper_threads); create_alignments_flat(0, staged); });
@@ -105,7 +111,7 @@ void Hypo::polish() {
     if (!_cFlags.lr_bam_filename.empty()) {
         _sf_long.reset(new SamReader(_cFlags.lr_bam_filename));
         if (!_sf_long->ok()) { std::fprintf(stderr, "[Hypo::Hypo] Error: File open error: %s\n", _cFlags.lr_bam_filename.c_str()); std::exit(1); }
-        _sf_long->set_inflate_threads(std::max(1, (int)_cFlags.threads));
+        _sf_long->set_inflate_threads(inflate_threads);
     }
     std::ofstream dump;
     if (!_region_dump.empty()) dump.open(_region_dump);
