@@ -77,7 +77,6 @@ void Hypo::polish() {
     const int side_team = num_batches > 1 ? std::max(1, (int)_cFlags.threads / 2) : std::max(1, (int)_cFlags.threads);
     const int inflate_threads = std::getenv("HYPO_INFLATE_THREADS") ? std::max(1, std::atoi(std::getenv("HYPO_INFLATE_THREADS"))) : side_team;
     _sf_short->set_inflate_threads(inflate_threads);
-    _sf_short->set_hop_threads(std::getenv("HYPO_HOP_THREADS") ? std::max(1, std::atoi(std::getenv("HYPO_HOP_THREADS"))) : std::min(4, std::max(1, inflate_threads)));      // (BGZF: inflate is what bounds a BAM run — 280 bytes per 150-bp record)
     // the short reads of the first batch are parsed while the contigs are scanned (the parser needs the contigs' names and lengths only)
     std::thread prefetch, long_release;
     ReadBatch staged;                                      // the next batch's short reads while the helper parses them

@@ -351,87 +351,6 @@ public:
         size_t len(size_t i) const { return lens.empty() ? (size_t)(off[i + 1] - off[i] - 1) : (size_t)lens[i]; }
         void clear() { buf.clear(); off.clear(); lens.clear(); base = nullptr; }
     };
-    // The hop over the records of an inflated run is one thread's chain of dependent loads — 57 M records/s at best, 10.5 of the 21 s
-    // of the 3 Gbp run.  It is cut into stretches: a stretch other than the first starts at the first offset behind its cut from
-    // which FOUR records in a row look like BAM records (sizes, reference ids, name terminator, lengths that add up); the stretches are
-    // hopped side by side, and a stretch counts only if the one before it ENDED exactly where it began — the chain from the true start
-    // vouches for every border it reaches, a guess it does not reach is dropped and the plain hop takes over from there.  Returns the
-    // offset behind the last record filed in b (0: nothing done).
-    bool looks_like_record(const char* p, size_t avail) const {
-        if (avail < 36) return false;
-        const int32_t bs = le32(p), ref = le32(p + 4), pos = le32(p + 8), l_seq = le32(p + 20), nref = le32(p + 24);
-        const unsigned l_name = (unsigned char)p[12], n_cig = le16(p + 16);
-        const int32_t nr = (int32_t)_names.size();
-        if (bs < 32 || bs > (1 << 26) || ref < -1 || ref >= nr || nref < -1 || nref >= nr || pos < -1 || l_seq < 0 || l_name < 1) return false;
-        const size_t need = 32 + (size_t)l_name + 4ull * n_cig + ((size_t)l_seq + 1) / 2 + (size_t)l_seq;
-        if (need > (size_t)bs) return false;
-        if (4 + 32 + (size_t)l_name <= avail && p[4 + 32 + l_name - 1] != '\0') return false;
-        return true;
-    }
-    size_t hop_side_by_side(RecordBlock& b, const char* p0, size_t avail, size_t max_records) {
-        static const size_t kMinStretch = std::getenv("HYPO_HOP_MIN_STRETCH") ? (size_t)std::max(64, std::atoi(std::getenv("HYPO_HOP_MIN_STRETCH"))) : ((size_t)8 << 20);   // (tests: small files)
-        static const bool misguess = std::getenv("HYPO_HOP_MISGUESS") != nullptr;          // (tests: every guess is one byte off — nothing but the first stretch may count)
-        const int K = (int)std::min<size_t>(_hop_threads, avail / kMinStretch);
-        if (K < 2 || b.n() != 0) return 0;
-        std::vector<size_t> start((size_t)K + 1, 0), end((size_t)K, 0);
-        for (int i = 1; i < K; ++i) {
-            size_t o = avail * (size_t)i / (size_t)K;
-            const size_t stop = std::min(avail, o + ((size_t)1 << 16));
-            bool ok = false;
-            for (; o + 36 <= stop; ++o) {
-                size_t q = o; int good = 0;
-                while (good < 4 && q + 36 <= avail && looks_like_record(p0 + q, avail - q)) { q += 4 + (size_t)le32(p0 + q); ++good; }
-                if (good == 4) { ok = true; break; }
-            }
-            if (!ok) return 0;
-            start[(size_t)i] = misguess ? o + 1 : o;
-        }
-        start[(size_t)K] = avail;
-        std::vector<std::vector<uint64_t>> offs((size_t)K);
-        std::vector<std::vector<uint32_t>> lens((size_t)K);
-        int bad = 0;
-#pragma omp parallel for schedule(static, 1) num_threads(K) reduction(| : bad)
-        for (int i = 0; i < K; ++i) {
-            size_t at = start[(size_t)i];
-            const size_t lim = start[(size_t)i + 1];
-            auto& of = offs[(size_t)i]; auto& ln = lens[(size_t)i];
-            of.reserve((lim - at) / 200 + 16); ln.reserve((lim - at) / 200 + 16);
-            while (at < lim && at + 4 <= avail) {
-                int32_t bs; std::memcpy(&bs, p0 + at, 4);
-                __builtin_prefetch(p0 + at + 16 * (4 + (size_t)(uint32_t)bs));
-                __builtin_prefetch(p0 + at + 16 * (4 + (size_t)(uint32_t)bs) + 64);
-                if (bs < 32) { bad |= (i == 0); break; }                 // (a malformed record on the true chain is fatal; elsewhere the stretch is dropped)
-                if (at + 4 + (size_t)bs > avail) break;
-                of.push_back(at + 4); ln.push_back((uint32_t)bs);
-                at += 4 + (size_t)bs;
-            }
-            end[(size_t)i] = at;
-        }
-        if (bad) { std::fprintf(stderr, "[Hypo::SamReader] Error: malformed BAM record\n"); std::exit(1); }
-        int used = 1;
-        while (used < K && end[(size_t)used - 1] == start[(size_t)used]) ++used;
-        size_t total = 0;
-        for (int i = 0; i < used; ++i) total += offs[(size_t)i].size();
-        if (total == 0) return 0;
-        size_t at = end[(size_t)used - 1];
-        if (total > max_records) {                               // (the caller's limit: the rest is found again by the next call)
-            total = max_records;
-        }
-        b.off.resize(total + 1); b.lens.resize(total);
-        size_t w = 0;
-        for (int i = 0; i < used && w < total; ++i) {
-            const size_t n = std::min(offs[(size_t)i].size(), total - w);
-            std::memcpy(b.off.data() + w, offs[(size_t)i].data(), n * 8);
-            std::memcpy(b.lens.data() + w, lens[(size_t)i].data(), n * 4);
-            w += n;
-        }
-        if (w < total) { total = w; b.off.resize(total + 1); b.lens.resize(total); }
-        at = (size_t)b.off[total - 1] + (size_t)b.lens[total - 1];
-        b.off[total] = at;                                       // (the placeholder the plain hop overwrites with its next record)
-        return at;
-    }
-    int _hop_threads = 1;
-    void set_hop_threads(int n) { _hop_threads = n < 1 ? 1 : n; }
     // fills b with up to max_records records (or ~max_bytes); false once the end of the file has been reached
     bool read_block(RecordBlock& b, size_t max_records, size_t max_bytes = 32u << 20) {
         b.clear();
@@ -464,7 +383,6 @@ public:
                 const size_t avail = _lr.buffered_bytes();
                 size_t at = 0;
                 b.base = p0;
-                at = hop_side_by_side(b, p0, avail, max_records);        // (0: too small to split or no sure footing — the plain hop below does it all)
                 while (b.n() < max_records && at + 4 <= avail) {
                     int32_t bs; std::memcpy(&bs, p0 + at, 4);
                     // (the hop is a chain of dependent loads over 100+ MB that has just been written by other cores: 60 ns per

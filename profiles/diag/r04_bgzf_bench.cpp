@@ -5,7 +5,6 @@ int main(int argc, char** argv) {
     hypo::SamReader sf(argv[1]);
     const int nt = atoi(argv[2]);
     sf.set_inflate_threads(nt);
-    if (argc > 3) sf.set_hop_threads(atoi(argv[3]));
     hypo::SamReader::RecordBlock b;
     size_t n = 0, bytes = 0; int blocks = 0; uint64_t sig = 1469598103934665603ull;
     auto t0 = std::chrono::steady_clock::now();

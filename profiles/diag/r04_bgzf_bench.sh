@@ -6,7 +6,6 @@ g++ -O2 -fopenmp -std=c++17 -o /tmp/bgzf_bench_$$ profiles/diag/r04_bgzf_bench.c
 tests/_build/gen_e2e_fast $D 77 250 1000000 15 30 150 2000 --bam --fast-hash > /dev/null
 ls -la $D/sr.bam
 for t in 1 8 32 64 128; do echo "threads $t:"; OMP_WAIT_POLICY=passive /tmp/bgzf_bench_$$ $D/sr.bam $t; done
-for h in 2 4 8; do echo "threads 32, records located on $h threads:"; OMP_WAIT_POLICY=passive /tmp/bgzf_bench_$$ $D/sr.bam 32 $h; done
 echo "active wait policy, 64:"; /tmp/bgzf_bench_$$ $D/sr.bam 64
 cp $D/sr.bam /tmp/sr_disk.bam; echo "from the overlay disk, 64:"; /tmp/bgzf_bench_$$ /tmp/sr_disk.bam 64
 rm -rf $D /tmp/sr_disk.bam

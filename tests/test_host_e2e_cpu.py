@@ -67,18 +67,3 @@ def test_e2e_long_read_edit_distance_filter_counts_and_fasta(built, bam, tmp_pat
     assert [int(x) for x in counts[-1]] == man["expected_long_reads_loaded_invalid"], counts
     assert eu.fasta_md5(tmp_path) == man["expected_fasta_md5"]
 
-
-@pytest.mark.parametrize("misguess", [False, True])
-def test_e2e_bam_records_located_side_by_side(built, misguess, tmp_path):
-    """The BAM reader cuts the hop over the records of an inflated run into stretches that start at GUESSED record borders (four
-    plausible records in a row) and keeps a stretch only if the chain from the true start ends exactly on its first byte
-    (SamReader::hop_side_by_side).  Small stretches force it on a small golden; HYPO_HOP_MISGUESS puts every guess one byte off:
-    the plain hop has to take over behind the first stretch.  Same records, same FASTA either way."""
-    env = {"HYPO_HOP_MIN_STRETCH": "4096", "HYPO_HOP_THREADS": "4"}
-    if misguess:
-        env["HYPO_HOP_MISGUESS"] = "1"
-    for name in ("e2e_20k_s1", "e2e_5ctg_long_s21"):
-        d = tmp_path / name
-        d.mkdir()
-        man, _ = eu.run_case(name, d, "shim", as_bam=True, extra_env=env)
-        eu.check_outputs(name, d, man)
