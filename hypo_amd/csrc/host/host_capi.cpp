@@ -4,6 +4,7 @@
 #include <memory>
 #include <string>
 #include <vector>
+#include "SeqIO.hpp"
 #include "Contig.hpp"
 #include "Window.hpp"
 
@@ -83,6 +84,21 @@ int hypo_host_contig_scan(const char* seq, unsigned k, const uint64_t* words, ui
     for (int i = 0; i < n_rank; ++i) rank_a[i] = c.rank(rank_q[i]);
     for (int i = 0; i < n_sel; ++i) sel_a[i] = c.select(sel_q[i]);
     return 0;
+}
+
+// read_fastx through the mapped reader (line_by_line = 0) or the line-by-line one: "name\tsequence\n" per record into out; the number of
+// bytes, -1 when the file is not FASTA / FASTQ, -2 when out is too small
+int hypo_host_read_fastx(const char* path, int line_by_line, char* out, int cap) {
+    std::vector<hypo::FastaRecord> recs;
+    if (!hypo::read_fastx(path, recs, line_by_line == 0)) return -1;
+    size_t at = 0;
+    for (const auto& r : recs) {
+        const size_t need = r.name.size() + 1 + r.seq.size() + 1;
+        if (at + need > (size_t)cap) return -2;
+        std::memcpy(out + at, r.name.data(), r.name.size()); at += r.name.size(); out[at++] = '\t';
+        std::memcpy(out + at, r.seq.data(), r.seq.size()); at += r.seq.size(); out[at++] = '\n';
+    }
+    return (int)at;
 }
 
 }  // extern "C"

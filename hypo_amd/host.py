@@ -27,6 +27,14 @@ class HostMirror:
         self.lib.hypo_host_filter(draft.encode(), C.c_int(len(arms)), self._arr(arms), good)
         return [int(x) for x in good][:len(arms)]
 
+    def read_fastx(self, path, line_by_line=False, cap=1 << 24):
+        """[(name, sequence)] of a FASTA / FASTQ file through SeqIO.hpp's reader (the mapped, parallel one unless line_by_line)"""
+        out = C.create_string_buffer(cap)
+        r = self.lib.hypo_host_read_fastx(str(path).encode(), C.c_int(1 if line_by_line else 0), out, C.c_int(cap))
+        if r < 0:
+            return None
+        return [tuple(l.split("\t")) for l in out.raw[:r].decode().split("\n")[:-1]]
+
     def pack_roundtrip(self, nb, text):
         out = C.create_string_buffer(len(text) + 8)
         r = self.lib.hypo_host_pack_roundtrip(C.c_int(nb), text.encode(), out, C.c_int(len(text) + 8))

@@ -90,3 +90,42 @@ def test_window_beyond_device_capacity_keeps_its_draft(mirror, device, capfd):
     assert cons[1] == truth                                   # deep, but polished
     assert cons[2] == draft
     assert "kept unpolished" in capfd.readouterr().err
+
+
+def test_draft_reader_mapped_and_line_by_line_agree(mirror, tmp_path):
+    """The draft is read on all threads out of the mapped file (read_fasta_mapped: record starts found chunk by chunk) or line by line
+    (gzip, FASTQ, pipes): the same records for wrapped sequences, CR LF line ends, empty lines, a header with a description, a record
+    without a sequence, no line feed at the end — and what klib's kseq gives the reference for such files (src/Hypo.cpp:82-95)."""
+    import random
+    rng = random.Random(5)
+    seq = lambda n: "".join(rng.choice("ACGTNacgt") for _ in range(n))
+    recs = [("c1", seq(1000)), ("c2", seq(61)), ("empty", ""), ("c4", seq(5_000_00)), ("c5", seq(7))]
+
+    def write(path, eol, wrap, blank, final_eol):
+        with open(path, "wb") as f:
+            f.write((eol * 2).encode())                                    # empty lines in front
+            for i, (name, s) in enumerate(recs):
+                f.write((">" + name + (" some description\tmore" if i % 2 else "") + eol).encode())
+                lines = [s[j:j + wrap] for j in range(0, len(s), wrap)] if wrap else ([s] if s else [])
+                for k, ln in enumerate(lines):
+                    last = i == len(recs) - 1 and k == len(lines) - 1
+                    f.write((ln + ("" if last and not final_eol else eol)).encode())
+                    if blank and k % 3 == 1:
+                        f.write(eol.encode())
+    n = 0
+    for eol in ("\n", "\r\n"):
+        for wrap in (0, 60, 1):
+            for blank in (False, True):
+                for final_eol in (True, False):
+                    if wrap == 1 and (blank or not final_eol):
+                        continue
+                    p = tmp_path / f"d{n}.fa"
+                    write(p, eol, wrap, blank, final_eol)
+                    a = mirror.read_fastx(p, line_by_line=False)
+                    b = mirror.read_fastx(p, line_by_line=True)
+                    assert a == b == [(nm, s) for nm, s in recs], (eol, wrap, blank, final_eol)
+                    n += 1
+    assert n >= 16
+    fq = tmp_path / "r.fq"
+    fq.write_text("@r1 x\nACGT\n+\nIIII\n@r2\nGG\n+\nII\n")
+    assert mirror.read_fastx(fq) == mirror.read_fastx(fq, line_by_line=True) == [("r1", "ACGT"), ("r2", "GG")]
