@@ -16,9 +16,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <condition_variable>
-#include <mutex>
-#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -99,12 +96,7 @@ public:
         }
         if (!_map && !_cmap) { _fp = gzopen(path.c_str(), "r"); if (_fp) { gzbuffer(_fp, 1 << 20); _buf.resize(kBuf); _src = _buf.data(); } }
     }
-    ~LineReader() {
-        if (_ahead.th.joinable()) { { std::lock_guard<std::mutex> lk(_ahead.mu); _ahead.quit = true; } _ahead.cv.notify_all(); _ahead.th.join(); }
-        if (_fp) gzclose(_fp);
-        if (_map) ::munmap((void*)_map, _map_len);
-        if (_cmap) ::munmap((void*)_cmap, _cmap_len);
-    }
+    ~LineReader() { if (_fp) gzclose(_fp); if (_map) ::munmap((void*)_map, _map_len); if (_cmap) ::munmap((void*)_cmap, _cmap_len); }
     // threads that inflate BGZF blocks side by side (a reader thread calls the read functions; its team is its own)
     void set_inflate_threads(int n) { _inflate_threads = n < 1 ? 1 : n; _bgzf_run = std::max<size_t>((size_t)32 << 20, (size_t)_inflate_threads << 21); }
     LineReader(const LineReader&) = delete;
@@ -211,9 +203,7 @@ private:
     // inflated size in the trailer.  A run of blocks (about 32 MB inflated) is located by hopping over the sizes, then inflated side
     // by side, every block straight to its place in _buf; the CRC-32 of every block is checked as htslib does.  gzread inflated
     // the file as ONE stream on one thread: 0.3 GB/s, the bound of every BAM run (a 100 Mbp / 30x set holds 5.6 GB of records).
-    // One run of blocks: located from _cpos on, inflated side by side into buffer `b` behind kPad spare bytes (the unread tail of the
-    // run before it goes in front, see fill_bgzf).  Returns the inflated size, 0 at the end of the file.  Runs on the ahead thread.
-    size_t inflate_run(int b) {
+    bool fill_bgzf() {
         struct Blk { size_t at, data, clen, out; uint32_t isize; };
         std::vector<Blk> blks;
         size_t total = 0;
@@ -235,10 +225,15 @@ private:
             total += isize;
             _cpos += bsize;
         }
-        if (blks.empty()) return 0;
-        std::vector<char>& nb = _bz[b];
-        if (nb.size() < kPad + total) nb.resize(kPad + total);
-        char* const dst = nb.data() + kPad;
+        if (blks.empty()) { _eof = true; return false; }          // (what is unread stays where it is)
+        // Two buffers take turns: the records a caller cut out of the previous one in place (SamReader::read_block, BAM) are
+        // still being parsed while this one fills; the unread tail of the previous buffer (a record that straddles the two
+        // runs of blocks) moves to the front of this one.
+        const size_t keep = _end - _pos;
+        std::vector<char>& nb = _bz[_bz_cur ^ 1];
+        if (nb.size() < keep + total) nb.resize(keep + total);
+        if (keep) std::memcpy(nb.data(), _src + _pos, keep);
+        char* const dst = nb.data() + keep;
         int bad = 0;
         const int nt = (int)std::min<size_t>((size_t)_inflate_threads, blks.size());
 #pragma omp parallel num_threads(nt) reduction(| : bad)
@@ -246,10 +241,10 @@ private:
             BlockInflater inf;                                 // (one decoder per thread and run of blocks)
 #pragma omp for schedule(dynamic, 4)
             for (int64_t i = 0; i < (int64_t)blks.size(); ++i) {
-                const Blk& bk = blks[(size_t)i];
-                const unsigned char* t = _cmap + bk.data + bk.clen;
+                const Blk& b = blks[(size_t)i];
+                const unsigned char* t = _cmap + b.data + b.clen;
                 const uint32_t want = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
-                bad |= inf.run(_cmap + bk.data, bk.clen, dst + bk.out, bk.isize, want);
+                bad |= inf.run(_cmap + b.data, b.clen, dst + b.out, b.isize, want);
             }
         }
         if (bad) bgzf_fail(bad & 2 ? "CRC mismatch in a BGZF block" : "a BGZF block does not inflate");
@@ -260,57 +255,8 @@ private:
             (void)::madvise((void*)(_cmap + _creleased), upto - _creleased, MADV_DONTNEED);
             _creleased = upto;
         }
-        return total;
-    }
-    // THREE buffers take turns, and a thread of its own inflates the run after the one in hand: the records a caller cut out of the
-    // previous buffer in place (SamReader::read_block, BAM) are still being parsed while the caller hops over this one and the next
-    // one fills — the reader's own thread used to inflate a run and THEN hop over it, taking turns with itself (30 M records/s inside
-    // the 3 Gbp run, which waited 11 of its 21 s for it).  The unread tail of the buffer in hand (a record that straddles two runs)
-    // moves into the spare bytes in front of the next run.
-    bool fill_bgzf() {
-        if (!_ahead.th.joinable()) {                            // first call: the thread, and the first run
-            _ahead.th = std::thread([this] {
-                std::unique_lock<std::mutex> lk(_ahead.mu);
-                for (;;) {
-                    _ahead.cv.wait(lk, [this] { return _ahead.want >= 0 || _ahead.quit; });
-                    if (_ahead.quit) return;
-                    const int b = _ahead.want;
-                    lk.unlock();
-                    const size_t total = inflate_run(b);
-                    lk.lock();
-                    _ahead.want = -1; _ahead.got = b; _ahead.total = total;
-                    _ahead.cv.notify_all();
-                }
-            });
-            std::lock_guard<std::mutex> lk(_ahead.mu);
-            _ahead.want = (_bz_cur + 1) % 3;
-            _ahead.cv.notify_all();
-        }
-        int b; size_t total;
-        {
-            std::unique_lock<std::mutex> lk(_ahead.mu);
-            if (_ahead.done) { _eof = true; return false; }
-            _ahead.cv.wait(lk, [this] { return _ahead.got >= 0; });
-            b = _ahead.got; total = _ahead.total; _ahead.got = -1;
-            if (total == 0) { _ahead.done = true; _eof = true; return false; }       // (what is unread stays where it is)
-        }
-        const size_t keep = _end - _pos;
-        std::vector<char>& nb = _bz[b];
-        if (keep > kPad) {                                       // (a record of more than 4 MB across two runs: make room in front of the run)
-            nb.insert(nb.begin(), keep - kPad, '\0');
-            std::memcpy(nb.data(), _src + _pos, keep);
-            _src = nb.data();
-        } else {
-            if (keep) std::memcpy(nb.data() + kPad - keep, _src + _pos, keep);
-            _src = nb.data() + kPad - keep;
-        }
-        _bz_cur = b;
-        _pos = 0; _end = keep + total;
-        {   // the run behind this one, into the buffer whose records the caller has let go of (two calls ago)
-            std::lock_guard<std::mutex> lk(_ahead.mu);
-            _ahead.want = (b + 1) % 3;
-            _ahead.cv.notify_all();
-        }
+        _bz_cur ^= 1;
+        _src = nb.data(); _pos = 0; _end = keep + total;
         return true;
     }
     [[noreturn]] static void bgzf_fail(const char* what) { std::fprintf(stderr, "[Hypo::SeqIO] Error: %s\n", what); std::exit(1); }
@@ -320,9 +266,7 @@ private:
     size_t _bgzf_run = (size_t)32 << 20;               // inflated bytes per fill_bgzf call: a few blocks per inflating thread
     gzFile _fp = nullptr;
     std::vector<char> _buf;
-    static constexpr size_t kPad = (size_t)4 << 20;
-    struct Ahead { std::thread th; std::mutex mu; std::condition_variable cv; int want = -1, got = -1; size_t total = 0; bool quit = false, done = false; } _ahead;
-    std::vector<char> _bz[3]; int _bz_cur = 0;          // BGZF: the inflated run of blocks in hand and the one before it
+    std::vector<char> _bz[2]; int _bz_cur = 0;          // BGZF: the inflated run of blocks in hand and the one before it
     const char* _map = nullptr; size_t _map_len = 0, _released = 0;
     const char* _src = nullptr;                        // the bytes being consumed: _buf or the mapping
     size_t _pos = 0, _end = 0;
