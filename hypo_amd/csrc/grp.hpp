@@ -112,6 +112,7 @@ struct Grp {
 };
 HD int popc64(uint64_t x) { return __builtin_popcountll(x); }
 HD int ctz64(uint64_t x) { return __builtin_ctzll(x); }
+HD int clz64(uint64_t x) { return __builtin_clzll(x); }
 
 #else
 // ---- device back end (gfx950, wave64) ------------------------------------------------------------
@@ -197,6 +198,7 @@ struct Grp {
 };
 HD int popc64(uint64_t x) { return __popcll(x); }
 HD int ctz64(uint64_t x) { return __ffsll((unsigned long long)x) - 1; }
+HD int clz64(uint64_t x) { return __clzll((long long)x); }
 #endif
 
 // ---- packed pairs of int16 (two neighbouring DP columns in one register) -------------------------------------

@@ -44,8 +44,11 @@
 #include "../../include/hypo_gpu.h"
 
 namespace hypo {
+#ifdef HYPO_EMU_DBG
+static unsigned long g_dbg_reason[16];
+#endif
 
-enum { MODE_NW = 1, MODE_LOV = 3, MODE_ROV = 4, MODE_SEEN = 0x100 /* flag beside the mode: sequence table bit 14 */ };
+enum { MODE_NW = 1, MODE_LOV = 3, MODE_ROV = 4 };
 enum { C_A = 0, C_C = 1, C_G = 2, C_T = 3, C_N = 4, C_J = 5, C_O = 6, C_NONE = 7 };
 // Optional per-phase cycle accounting (diagnostic build only: make -C hypo_amd/csrc prof).
 enum { PH_LOAD = 0, PH_DP = 1, PH_TRACE = 2, PH_ADD = 3, PH_TOPO = 4, PH_CONS = 5, PH_OUT = 6, PH_META = 7, PH_EXACT = 8, PH_N = 9 };
@@ -93,20 +96,13 @@ struct PoaParamRef {
 };
 #endif
 
-// exact threading of sequences that spell a path (Poa::rows_exact); HYPO_EXACT=0 sends every alignment through the score rows
+// exact threading of sequences that spell a path (Poa::thread_cols); HYPO_EXACT=0 sends every alignment through the score rows
 #ifndef HYPO_EXACT
 #define HYPO_EXACT 1
 #endif
-// ... run by run (Poa::rows_exact_runs) instead of row by row (Poa::rows_exact, kept as the plain form of the same recurrence)
-#ifndef HYPO_EXACT_RUNS
-#define HYPO_EXACT_RUNS 1
-#endif
-// ... also in the class of wide windows (class 3): off, see Poa::align
+// ... also in the class of wide windows (class 3)
 #ifndef HYPO_EXACT_WIDE
 #define HYPO_EXACT_WIDE 0
-#endif
-#ifndef HYPO_EXACT_ADAPT
-#define HYPO_EXACT_ADAPT 6
 #endif
 // int16 score rows as packed pairs of columns (Poa::rows_pk); HYPO_PACKED=0 builds the one-column-per-register loop everywhere
 #ifndef HYPO_PACKED
@@ -268,6 +264,7 @@ struct Poa {
     static constexpr int NEG = -(1 << 29);
     static constexpr bool PK = Cfg::PACKED;
     static_assert(!PK || Cfg::NIB, "packed rows store nibble codes");
+    static_assert(!PK || (int)sizeof(score_t) * Cfg::RINGCELLS >= Cfg::STK * (int)sizeof(id_t), "packed classes: the DFS stack fits the score ring");
     // direction codes
     static constexpr int DIR_FAST = NIB ? 15 : 0xFF;     // diagonal via pred 0 and pred 0 is the previous row
     static constexpr int DIR_HORIZ = NIB ? 14 : 0xFE;
@@ -280,8 +277,7 @@ struct Poa {
     static constexpr int pow2_of(int x) { return x & -x; }
     struct alignas(pow2_of((int)sizeof(score_t) * CPL)) Pack { score_t v[CPL]; };
     struct alignas(pow2_of(NIB ? CPL / 2 : CPL)) DPack { uint8_t v[NIB ? CPL / 2 : CPL]; };
-    // sequence table entry: bits 0-13 src (LDS offset of the staged bytes, or arm index), 14 "an earlier sequence of the window
-    // has the same bytes, length, markers and mode" (a hint, from a hash: such a sequence spells a path of the graph), 15 "byte-identical to
+    // sequence table entry: bits 0-13 src (LDS offset of the staged bytes, or arm index), 14 unused, 15 "byte-identical to
     // the previous entry", 16-25 length, 26 head marker J, 27 tail marker O,
     // 28-29 mode (0 NW, 1 LOV, 2 ROV), 30-31 where (0 staged in LDS, 1 arms2 in HBM, 2 draft4 in HBM: 4-bit packed)
     HD static uint32_t seq_ent(uint32_t src, uint32_t len, bool head, bool tail, int mode, bool /*four*/, int where) {
@@ -305,6 +301,8 @@ struct Poa {
     int n_nodes; int L; bool topo_dirty; bool meta_dirty;
     int tb_steps; int tb_fv;
     bool last_changed;         // did the most recent add_alignment change the graph topology?
+    bool weights_done;         // ... and the weights along its path are already incremented (Poa::thread_guided)
+    bool threaded;             // the alignment in hand was threaded (Poa::thread_cols): every position sits on a node of its own letter, along existing edges
     // Group-uniform scalars that change rarely live in a small block of the group's LDS slice (PoaLayout::oStat) instead of
     // registers; lane 0 writes, everybody may read after the next sync.
     //   ST_CELLS .. ST_CEXACT  per-window counters: reference-equivalent cells / alignments, reused alignments, threaded ones,
@@ -338,7 +336,7 @@ struct Poa {
     HD uint32_t stat_get(int k) const { return stat[k]; }
 #if defined(HYPO_PHASE_TIMERS) || defined(HYPO_EMU)
 #define HYPO_DIAG(x) do { x; } while (0)
-    uint32_t rows_done, topo_runs, cons_serial, rows_slow, exact_tries, rows_exact_n, rows_scored_n, topo_dfs, topo_fast;
+    uint32_t rows_done, topo_runs, cons_serial, rows_slow, exact_tries, guided_hits, rows_scored_n, topo_dfs, topo_fast;
 #else
 #define HYPO_DIAG(x) do { } while (0)
 #endif
@@ -354,7 +352,9 @@ struct Poa {
         posnode = (int16_t*)(HYB ? fast + Lay::fPosnode : mem + Lay::oPosnode);
         inp = (id_t*)(mem + Lay::oInp); al = (id_t*)(mem + Lay::oAl);
         r2n = (id_t*)(mem + Lay::oR2n); n2r = (id_t*)(mem + Lay::oN2r);
-        stack = (id_t*)(HYB ? fast + Lay::fPosnode : mem + Lay::oPosnode); code = (uint8_t*)(mem + Lay::oCode);
+        // DFS stack (toposort) / arm indices while staging: beside posnode in the hybrid classes; in the packed classes in the score ring
+        // (idle outside the row loop), so that posnode[] — the path of the sequence before — survives a sort and can guide the next arm
+        stack = (id_t*)(HYB ? fast + Lay::fPosnode : (PK ? mem + Lay::oRing : mem + Lay::oPosnode)); code = (uint8_t*)(mem + Lay::oCode);
         nin = (uint8_t*)(HYB ? fast + Lay::fNin : mem + Lay::oNin); nout = (uint8_t*)(mem + Lay::oNout);
         nal = (uint8_t*)(HYB ? fast + Lay::fNal : mem + Lay::oNal); mark = (uint8_t*)(HYB ? fast + Lay::fMark : mem + Lay::oMark);
         seq = (uint8_t*)(HYB ? fast + Lay::fSeq : mem + Lay::oSeq); armbuf = (uint8_t*)(mem + Lay::oArms);
@@ -364,14 +364,14 @@ struct Poa {
         msa = (uint16_t*)(mem + Lay::oMsa); dstcnt = (uint32_t*)(mem + Lay::oDst); consbuf = (uint8_t*)(mem + Lay::oCons);
         predrows = (id_t*)(mem + Lay::oPredRows);
         r2n_alt = (id_t*)(mem + Lay::oR2nAlt); n2r_alt = (id_t*)(mem + Lay::oN2rAlt); newid = (id_t*)(mem + Lay::oNewId); newslot = (int16_t*)(mem + Lay::oNewSlot);
-        lazy_on = false; n_new = 0;
+        lazy_on = false; n_new = 0; guide_len = -1; guide_mode = 0;
         stat = (uint32_t*)(HYB ? fast + Lay::fStat : mem + Lay::oStat);
         for (int t = g.lane; t < Lay::STAT_BYTES / 4; t += GW) stat[t] = 0;
         ring1 = (score_t*)(HYB ? fast + Lay::fRing1 : mem + Lay::oRing);
         n_paths = 0; path_used = 0; head_first = 0;
         n_nodes = 0; L = 0; topo_dirty = false; meta_dirty = true; tb_steps = 0; tb_fv = 0;
-        last_changed = true;
-        HYPO_DIAG(rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; rows_exact_n = 0; rows_scored_n = 0; topo_dfs = 0; topo_fast = 0);
+        last_changed = true; threaded = false;
+        HYPO_DIAG(rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; guided_hits = 0; rows_scored_n = 0; topo_dfs = 0; topo_fast = 0);
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
         tlast = 0;
         HYPO_TICK_RESET();
@@ -492,36 +492,6 @@ struct Poa {
             }
         }
         g.sync();
-        if constexpr (PK) {
-            // ... and arms that repeat ANY earlier arm of the window (not only their neighbour): a hash per arm, parked in
-            // the ring (idle until the first alignment), every lane looks its arm up among the earlier ones.  Such an arm spells
-            // the path the earlier copy was threaded along or created, so threading it cannot fail (Poa::align attempts it whatever
-            // the hit rate of the window's other arms is); a hash collision only costs a wasted attempt.
-            uint32_t* const hs = (uint32_t*)ring;
-            static_assert((int)sizeof(score_t) * Cfg::RINGCELLS >= 4 * Cfg::SEQMAX, "arm hashes fit the ring");
-            for (int t = g.lane; t < narm; t += GW) {
-                const uint32_t e = seqtab[base + t];
-                uint32_t h = 0;
-                if (((e >> 16) & 0x3ff) != 0) {
-                    const int nb = (int)(((e >> 16) & 0x3ff) + 3) >> 2;
-                    const uint8_t* pa = (e >> 30) == 0 ? armbuf + (e & 0x3fff) : P->arms2 + P->arm_off[a0 + (e & 0x3fff)];
-                    h = 2166136261u ^ (e & 0x3fff0000u);
-                    HYPO_NOUNROLL
-                    for (int k = 0; k < nb; ++k) h = (h ^ pa[k]) * 16777619u;
-                    h |= 1u;
-                }
-                hs[t] = h;
-            }
-            g.sync();
-            for (int t = g.lane; t < narm; t += GW) {
-                const uint32_t h = hs[t];
-                bool seen = false;
-                HYPO_NOUNROLL
-                for (int u = 0; u < t; ++u) seen |= hs[u] == h;
-                if (seen && h) seqtab[base + t] |= 0x4000u;
-            }
-            g.sync();
-        }
         *n_seq_out = narm + base;
         *added_out = any_len;
         return RES_OK;
@@ -554,8 +524,6 @@ struct Poa {
         const int ni = (int)W.n_internal, np = (int)W.n_prefix;
         bool over = false, any_len = false, bad = false;
         uint32_t armb = 0;
-        uint32_t* const hs = (uint32_t*)ring;                  // arm hashes, parked in the ring (idle until the first alignment)
-        static_assert((int)sizeof(score_t) * Cfg::RINGCELLS >= 4 * Cfg::SEQMAX, "arm hashes fit the ring");
         uint32_t prev_e = 0, prev_d[NDW];                      // the arm before this round's first (group-uniform)
         HYPO_UNROLL
         for (int i = 0; i < NDW; ++i) prev_d[i] = 0;
@@ -603,12 +571,10 @@ struct Poa {
             // copy of the arm before it: same length, markers and mode, same bytes
             const uint32_t pe = g.shfl_up1(e0, prev_e);
             bool same = on && t > 0 && nb > 0 && ((e0 ^ pe) & 0x3fff0000u) == 0;
-            uint32_t h = 2166136261u ^ (e0 & 0x3fff0000u);
             HYPO_UNROLL
             for (int i = 0; i < NDW; ++i) {
                 const uint32_t pd = g.shfl_up1(d[i], prev_d[i]);
                 same &= pd == d[i];
-                h = (h ^ d[i]) * 16777619u; h ^= h >> 15;
             }
             // place in armbuf: copies take none, the others a word-aligned slot while the arms so far fit
             const int slot = (nb + 3) & ~3;
@@ -617,7 +583,6 @@ struct Poa {
             const int off = incl - slot;
             if (on) {
                 seqtab[base + t] = staged ? ((e0 & 0x3fff0000u) | (uint32_t)off | (same ? 0x8000u : 0u)) : (e0 | (same ? 0x8000u : 0u));
-                hs[t] = nb ? (h | 1u) : 0u;
                 if (staged && !same && nb) {
                     uint32_t* const dst = (uint32_t*)(armbuf + off);
                     const int ndw = (nb + 3) >> 2;
@@ -637,15 +602,6 @@ struct Poa {
         any_len = g.any(any_len);
         if constexpr (Hook::enabled) { armb = (uint32_t)g.reduce_add((int)armb); stat_set(ST_ARMB, armb); }
         g.sync();
-        // arms that repeat ANY earlier arm of the window spell a path of the graph when their turn comes (see build_seqtab)
-        for (int t = g.lane; t < narm; t += GW) {
-            const uint32_t h = hs[t];
-            bool seen = false;
-            HYPO_NOUNROLL
-            for (int u = 0; u < t; ++u) seen |= hs[u] == h;
-            if (seen && h) seqtab[base + t] |= 0x4000u;
-        }
-        g.sync();
         *n_seq_out = narm + base;
         *added_out = any_len;
         return RES_OK;
@@ -656,7 +612,7 @@ struct Poa {
         const bool head = (e >> 26) & 1, tail = (e >> 27) & 1;
         const int mc = (int)((e >> 28) & 3), where = (int)(e >> 30);
         const bool four = where == 2;
-        *mode_out = (mc == 0 ? MODE_NW : (mc == 1 ? MODE_LOV : MODE_ROV)) | ((e & 0x4000u) ? (int)MODE_SEEN : 0);
+        *mode_out = mc == 0 ? MODE_NW : (mc == 1 ? MODE_LOV : MODE_ROV);
         const int len = (int)((e >> 16) & 0x3ff);
         if (len == 0) { L = 0; return RES_OK; }
         L = g.uniform(len + (head ? 1 : 0) + (tail ? 1 : 0));   // group-uniform by construction; tells the compiler (scalar control flow for 64-lane groups)
@@ -722,9 +678,9 @@ struct Poa {
             const bool slow = !(k == 1 && p0 == r) || sink;
             const uint32_t c = code[u];
 #ifdef HYPO_DBG_SAVEALL
-            rowmeta[r] = c | META_SLOW | META_SAVE | (sink ? META_SINK : 0u) | ((uint32_t)k << 8) | (PK ? (c << 16) : 0u) | ((uint32_t)p0 << P0_SHIFT);
+            rowmeta[r] = c | META_SLOW | META_SAVE | (sink ? META_SINK : 0u) | ((PK && nout[u] == 1) ? META_OUT1 : 0u) | ((uint32_t)k << 8) | (PK ? (c << 16) : 0u) | ((uint32_t)p0 << P0_SHIFT);
 #else
-            rowmeta[r] = c | (slow ? META_SLOW : 0u) | (sink ? META_SINK : 0u) | ((uint32_t)k << 8) | (PK ? (c << 16) : 0u) | ((uint32_t)p0 << P0_SHIFT);
+            rowmeta[r] = c | (slow ? META_SLOW : 0u) | (sink ? META_SINK : 0u) | ((PK && nout[u] == 1) ? META_OUT1 : 0u) | ((uint32_t)k << 8) | (PK ? (c << 16) : 0u) | ((uint32_t)p0 << P0_SHIFT);
 #endif
         }
         meta_dirty = false;
@@ -767,10 +723,6 @@ struct Poa {
                 else rowmeta[r] |= meta_backs(b0, b1);
             }
             stat_set(ST_MAXD, (uint32_t)g.reduce_max(mds));
-            // last rank without in-edges: behind it no new perfect path can start in kNW / kLOV (Poa::rows_exact_runs gives up early)
-            int ls = -1;
-            for (int r = g.lane; r < n_nodes; r += GW) if (meta_k(rowmeta[r]) == 0) ls = r;
-            stat_set(ST_LSRC, (uint32_t)g.reduce_max(ls));
             g.sync();
             return;
         }
@@ -1057,396 +1009,356 @@ struct Poa {
     // With m > 0, n < m and g < 0 no cell can exceed H[i][j] <= m * j, and H[i][j] == m * j exactly when some path that ends
     // in node i spells seq[0..j) with j matches and nothing else (kNW / kLOV: starting at a node without in-edges, because
     // the first column costs g per node, sisd..cpp:200-211; kROV: starting anywhere, the first column being 0, :237-239).
-    // Call such a cell PERFECT.  perfect(i, j) = letter(i) == seq[j-1] and perfect(p, j-1) for some pred p of i: a one-bit
-    // recurrence over the same rows, predecessors and ring as the score rows, without the horizontal scan.  If an end-cell
+    // Call such a cell PERFECT.  perfect(i, j) = letter(i) == seq[j-1] and perfect(p, j-1) for some pred p of i.  If an end-cell
     // candidate (kNW / kROV: a sink, kLOV: any node; column L) is perfect, its score m * L is the maximum, so the reference
     // starts its traceback at the FIRST such row in rank order (strictly-greater rule, sisd..cpp:279-288,332-339) and at
     // every perfect cell takes the diagonal through the first pred (in-edge order) whose cell (p, j-1) is perfect: diagonals
-    // are tried before anything else (:370-428) and H[p][j-1] + m == m * j holds for exactly those preds.  The direction
-    // codes of that walk are written in the usual format, so the traceback and the graph update below run unchanged.
-    // Returns the end row, or -1 when no candidate is perfect (the sequence spells no path: the caller runs the score rows).
-    HD int rows_exact(int mode, int S, int R) {
-        constexpr int NP = CPL / 2;
-        const int j0 = CPL * g.lane;
-        P2 SQ[NP], P0[NP], LAST[NP];
+    // are tried before anything else (:370-428) and H[p][j-1] + m == m * j holds for exactly those preds.
+    //
+    // Computed COLUMN BY COLUMN with lanes = graph ranks (rounds 2-4 walked the rows in rank order, through the ring, 200-850
+    // cycles a row): the perfect cells of column j are a set of ranks F_j, one bit per rank in XW 64-bit words, and
+    //   F_1     = { sources (kROV: any node) whose letter is seq[0] }        (perfect(p, 0) holds for the virtual row 0 only; kROV: for every row)
+    //   F_{j+1} = { v : letter(v) == seq[j] and a pred of v is in F_j }.
+    // For a CHAIN rank (one in-edge, from the rank before it: ~90 % of a window's graph) "a pred is in F_j" is the mask shifted
+    // by one, so a column costs a letter compare per owned rank, a few mask operations and no memory access at all; the other
+    // ranks test their in-edge sources bit by bit, and only in columns where F_j holds a rank that has an out-edge other than
+    // "the chain link to the next rank" (NCP).  The attempt ends in the column where F runs empty: a sequence that spells no path
+    // costs the columns up to its first error.  Lane c - 1 keeps F_c; the alignment is then read off without a traceback:
+    // the end row is the first rank of F_L (kNW / kROV: among the sinks), a column with ONE perfect cell must be that cell
+    // (every cell of the walk is perfect), and the few columns with several (the first ones of a kROV arm, repeats inside a
+    // bubble) take the first in-edge source, in order, of the cell chosen to their right that is in their F.
+    // Leaves posnode[] (node of every position), tb_steps = L, tb_fv = 0 and returns 1; returns 0 when no end-cell candidate
+    // is perfect (the caller runs the score rows).
+    static constexpr int XRPL = (NMAX + GW - 1) / GW;       // ranks per lane: rank = q * GW + lane
+    static constexpr int XSL = (Cfg::LMAX + GW - 1) / GW;   // columns per lane: column c = 1 + t * GW + lane
+    static constexpr int XW = (XRPL * GW + 63) / 64;        // 64-bit words of a rank set (bit r of the concatenation = rank r)
+    typedef typename std::conditional<(KIN <= 4), uint32_t, uint64_t>::type xpw_t;      // a rank's in-edge sources, a byte each
+    static constexpr uint32_t META_OUT1 = 0x80u;            // rowmeta bit 7 (packed classes): the node has exactly one out-edge
+    struct XSet { uint64_t w[XW]; };
+    HD static bool x_in(const XSet& F, int rank) {
+        uint64_t w = F.w[0];
         HYPO_UNROLL
-        for (int q = 0; q < NP; ++q) {
-            const int j = j0 + 2 * q;
-            const int s0 = (j >= 1 && j <= L) ? (int)seq[j - 1] : (int)C_NONE;
-            const int s1 = (j + 1 <= L) ? (int)seq[j] : (int)C_NONE;
-            SQ[q] = pk_make(s0, s1);
-            P0[q] = pk_make(j == 0 ? 1 : 0, 0);              // virtual source row: only H[0][0] = 0 is perfect
-            LAST[q] = P0[q];
+        for (int t = 1; t < XW; ++t) if ((rank >> 6) == t) w = F.w[t];
+        return ((w >> (rank & 63)) & 1ull) != 0;
+    }
+    HD static bool x_any(const XSet& F) { uint64_t o = F.w[0]; HYPO_UNROLL for (int t = 1; t < XW; ++t) o |= F.w[t]; return o != 0; }
+    HD static int x_first(const XSet& F) {                  // lowest rank of a non-empty set
+        int e = 0;
+        HYPO_UNROLL
+        for (int t = XW - 1; t >= 0; --t) if (F.w[t] != 0) e = t * 64 + ctz64(F.w[t]);
+        return e;
+    }
+    // the set of ranks whose owner says yes for them (pred[q] of lane l speaks for rank q * GW + l)
+    HD XSet x_ballot(const bool (&pred)[XRPL]) const {
+        XSet S;
+        HYPO_UNROLL
+        for (int t = 0; t < XW; ++t) S.w[t] = 0;
+        HYPO_UNROLL
+        for (int q = 0; q < XRPL; ++q) S.w[(q * GW) / 64] |= g.ballot(pred[q]) << ((q * GW) % 64);
+        return S;
+    }
+    HD XSet x_shfl(const XSet& v, int src) const {
+        XSet r;
+        HYPO_UNROLL
+        for (int t = 0; t < XW; ++t) {
+            const uint32_t lo = (uint32_t)g.shfl((int)(uint32_t)v.w[t], src), hi = (uint32_t)g.shfl((int)(uint32_t)(v.w[t] >> 32), src);
+            r.w[t] = ((uint64_t)hi << 32) | lo;
         }
-        int vONE = pk_bits(pk_splat(1));
-        HYPO_IN_VGPR(vONE);
-        const P2 ONE = pk_from_bits(vONE);
-        // kROV: H[i][0] = 0 = m * 0 in every row: column 0 (lane 0, low half) is perfect everywhere
-        const int col0 = (g.lane == 0 && mode == MODE_ROV) ? 1 : 0;
-        const bool lov = mode == MODE_LOV;
-        const int le = L / CPL, ce = L % CPL;               // owner of the last column
-        unsigned first = 0xffffffffu;                        // first row (rank order) whose end-cell candidate is perfect (lane `le`)
-        int wslotS = 0, scount = 0, rowS = 0;
-        const int RS = R * S;
-        int nbreg = 0;                                       // lane 0 keeps 0: there is no column -1
-        constexpr bool META_CHUNKED = (GW == 64);
-        uint32_t mchunk = 0u;
-        uint32_t meta_a = META_CHUNKED ? 0u : rowmeta[0];
-        uint32_t meta_b = (!META_CHUNKED && n_nodes > 1) ? rowmeta[1] : 0u;
-        auto load_pk = [&](int off, P2 (&out)[NP]) {
-            if (j0 < S) {
-                const PackP pk = *(const PackP*)(ring + off + j0);
-                HYPO_UNROLL
-                for (int q = 0; q < NP; ++q) out[q] = pk.v[q];
-            } else {
-                HYPO_UNROLL
-                for (int q = 0; q < NP; ++q) out[q] = pk_splat(0);
+        return r;
+    }
+    // ---- threading along a guide: the path of the sequence before ----------------------------------------------------------
+    // The arms of a window are reads of one locus: an arm differs from the arm before it in a base or two, and posnode[] still
+    // holds that arm's path (the node of every position; Poa::add_alignment leaves it complete).  So the path this arm would
+    // spell is known up to those bases — position q sits on the guide's node for it (kNW: position q, kROV: counted from the
+    // end), or, where the letters differ, on the member of that node's aligned clique that carries the arm's letter — and all
+    // that is left is to CHECK it, every position at once (lanes = positions, a handful of dependent LDS reads):
+    //   * every node carries its position's letter and every pair of neighbours is joined by an in-edge (the path exists);
+    //   * kNW: the first node has no in-edges (Poa::thread_cols' comment: only then is its cell perfect); the last node is a sink;
+    //   * the reference's traceback is FORCED along this path: the last node is the only sink with the last letter (so it
+    //     is the only end-cell candidate that can be perfect), and at every node the path's in-edge is the FIRST, in in-edge
+    //     order, whose source carries the letter of the position before (a perfect predecessor must carry it; the walk takes
+    //     the first perfect one; the path's own is perfect, so nothing behind it in the list matters).
+    //     kLOV ends anywhere: see the backward check below.
+    // Returns 1: threaded (posnode[] is the alignment, the edge weights along it are already incremented); 0: cannot tell
+    // (no guide of this shape; a forced-ness check failed) — the caller asks Poa::thread_cols; -1: along a guide of its own
+    // kind the arm spells no path — the caller goes to the score rows, which are exact whatever was tried before them.
+#ifdef HYPO_EMU_DBG
+#define DBGR(i) do { if (g.lane == 0) g_dbg_reason[i]++; } while (0)
+#else
+#define DBGR(i) do { } while (0)
+#endif
+    int guide_len, guide_mode;                              // posnode[0 .. guide_len) is the path of the last sequence added (its mode); -1: none
+    HD int thread_guided(int mode) {
+        const int Lu = g.uniform(L), Gl = g.uniform(guide_len);
+        if (Gl < Lu) { DBGR(Gl < 0 ? 1 : 2); return 0; }
+        const int d = mode == MODE_ROV ? Gl - Lu : 0;       // kROV arms end where the guide ends, the others start where it starts
+        if (mode == MODE_NW && Gl != Lu) { DBGR(3); return 0; }
+        const bool strong = guide_mode == mode;              // the guide is anchored like this arm: a letter it cannot place is an error of the arm
+        int v[XSL], pidx[XSL];
+        bool bad = false, amb = false;
+        HYPO_UNROLL
+        for (int t = 0; t < XSL; ++t) {
+            const int q = t * GW + g.lane;
+            v[t] = -1; pidx[t] = -1;
+            if (q < Lu) {
+                const int g0 = (int)posnode[q + d], c = (int)seq[q];
+                if ((int)code[g0] == c) v[t] = g0;
+                else {
+                    const int ka = (int)nal[g0];
+                    for (int a = 0; a < ka; ++a) { const int x = (int)al[g0 * AL + a]; if ((int)code[x] == c) v[t] = x; }
+                }
+                if (v[t] < 0) bad = true;
             }
-        };
-        auto ring_back = [&](int back) -> int {
-            int ps = wslotS - back * S;
-            return ps < 0 ? ps + RS : ps;
-        };
-        // end-cell bookkeeping without selects: column L's bit (0 / 1) minus one is 0 or all ones
-        const int ce_shift = 16 * (ce & 1);
-        auto note_end = [&](const P2 (&v)[NP], int i) {
-            int w = pk_bits(v[0]);
-            HYPO_UNROLL
-            for (int q = 1; q < NP; ++q) if (ce / 2 == q) w = pk_bits(v[q]);
-            const unsigned cand = (unsigned)i | ((((unsigned)w >> ce_shift) & 1u) - 1u);
-            first = cand < first ? cand : first;
-        };
-        for (int r = 0; r < n_nodes; ++r) {
-            const int i = r + 1;
-            uint32_t meta;
-            if (META_CHUNKED) {
-                if ((r & 63) == 0) { mchunk = r + g.lane < n_nodes ? rowmeta[r + g.lane] : 0u; HYPO_ARRIVED(mchunk); }
-                meta = (uint32_t)g.shfl((int)mchunk, r & 63);
-            } else {
-                meta = meta_a;
-                meta_a = meta_b;
-                if (r + 2 < n_nodes) meta_b = rowmeta[r + 2];
-            }
-            const P2 CD = pk_from_bits((int)(meta & 0x00070007u));
-            if (!(meta & META_SLOW)) {
-                // ---- FAST row: one predecessor, the previous row ----
-                const int nb = nbreg = g.shfl_up1(pk_bits(LAST[NP - 1]), nbreg);
-                int d[NP];
-                HYPO_UNROLL
-                for (int q = 0; q < NP; ++q) d[q] = pk_bits(pk_shift_in(q ? LAST[q - 1] : pk_from_bits(nb), LAST[q]));   // perfect(pred, j-1)
-                HYPO_UNROLL
-                for (int q = 0; q < NP; ++q) LAST[q] = pk_from_bits(d[q] & ~pk_bits(pk_minu(pk_xor(SQ[q], CD), ONE)));    // and the letters agree
-                LAST[0] = pk_from_bits(pk_bits(LAST[0]) | col0);
-                uint8_t* dst = dir + (rowS >> 1) + (j0 >> 1);
-                if (NP == 1) *dst = (uint8_t)0xffu;          // DIR_FAST in both nibbles
-                else if (NP == 2) *(uint16_t*)dst = (uint16_t)0xffffu;
-                else *(uint32_t*)dst = 0xffffffffu;
-                if (lov) { HYPO_NO_IFCVT(); note_end(LAST, i); }
-                rowS += S;
-                g.sync();
-                continue;
-            }
-            // ---- SLOW row ----
-            HYPO_NO_IFCVT();
-            const int k = meta_k(meta);
-            const int p0 = meta_p0(meta);                    // 0 when k == 0 (virtual source row)
-            const bool fastrow = p0 == i - 1;
-            const int fastcode = fastrow ? (int)DIR_FAST : dir_diag(0);
-            P2 D[NP], cD[NP];
-            {
-                P2 hp[NP];
-                if (fastrow) { HYPO_UNROLL for (int q = 0; q < NP; ++q) hp[q] = LAST[q]; }
-                else if (p0 == 0) { HYPO_UNROLL for (int q = 0; q < NP; ++q) hp[q] = P0[q]; }
-                else load_pk(ring_back(meta_back0(meta)), hp);
-                const int nb = nbreg = g.shfl_up1(pk_bits(hp[NP - 1]), nbreg);
-                HYPO_UNROLL
-                for (int q = 0; q < NP; ++q) D[q] = pk_shift_in(q ? hp[q - 1] : pk_from_bits(nb), hp[q]);
-            }
-            if (k > 1) {                                     // the first pred (in-edge order) with a perfect cell wins
-                P2 pD[NP];
-                HYPO_UNROLL
-                for (int q = 0; q < NP; ++q) pD[q] = pk_splat(0);
-                for (int p = 1; p < k; ++p) {
-                    P2 hp[NP];
-                    const int back = p == 1 ? meta_back1(meta) : scount - (int)sidx[g.uniform(pred_row(r, p)) - 1];
-                    load_pk(ring_back(back), hp);
-                    const int nb = nbreg = g.shfl_up1(pk_bits(hp[NP - 1]), nbreg);
-                    const P2 PP = pk_splat(p);
-                    HYPO_UNROLL
-                    for (int q = 0; q < NP; ++q) {
-                        const P2 d = pk_shift_in(q ? hp[q - 1] : pk_from_bits(nb), hp[q]);
-                        const P2 nd = pk_from_bits(pk_bits(D[q]) | pk_bits(d));
-                        pD[q] = pk_mad(pk_sub(nd, D[q]), pk_sub(PP, pD[q]), pD[q]);       // newly perfect through pred p
-                        D[q] = nd;
+        }
+        // (every lane has read its guide nodes before any lane writes posnode[] below: the collectives in between are rendezvous)
+        if (g.any(bad)) { DBGR(strong ? 4 : 5); return strong ? -1 : 0; }
+        int carry = -1;
+        HYPO_UNROLL
+        for (int t = 0; t < XSL; ++t) {
+            const int q = t * GW + g.lane;
+            const int prev = g.shfl_up1(v[t], carry);
+            if (t + 1 < XSL) carry = g.shfl(v[t], GW - 1);
+            if (q < Lu) {
+                const int u = v[t];
+                const int k = (int)nin[u];
+                if (q == 0) { if (mode != MODE_ROV && k != 0) bad = true; }
+                else {
+                    const int cp = (int)seq[q - 1];
+                    int first_same = -1;                      // first in-edge (the reference tries them in this order) whose source carries the letter before
+                    for (int p = 0; p < k; ++p) {
+                        const int src = (int)inp[u * KIN + p];
+                        if (src == prev) pidx[t] = p;
+                        if (k > 1 && first_same < 0 && (int)code[src] == cp) first_same = p;
                     }
+                    if (pidx[t] < 0) bad = true;
+                    if (k > 1 && first_same != pidx[t]) amb = true;
                 }
-                const P2 FC = pk_splat(fastcode);
-                HYPO_UNROLL
-                for (int q = 0; q < NP; ++q) cD[q] = pk_mad(pk_sub(ONE, pk_minu(pD[q], ONE)), FC, pD[q]);
-            } else {
-                HYPO_UNROLL
-                for (int q = 0; q < NP; ++q) cD[q] = pk_splat(fastcode);
+                if (q == Lu - 1 && mode != MODE_LOV && nout[u] != 0) bad = true;
             }
-            P2 v[NP];
-            HYPO_UNROLL
-            for (int q = 0; q < NP; ++q) v[q] = pk_from_bits(pk_bits(D[q]) & ~pk_bits(pk_minu(pk_xor(SQ[q], CD), ONE)));
-            v[0] = pk_from_bits(pk_bits(v[0]) | col0);
-            if (j0 < S) {
-                uint32_t codes = 0;
-                PackP pk;
-                HYPO_UNROLL
-                for (int q = 0; q < NP; ++q) {
-                    const uint32_t b = (uint32_t)pk_bits(cD[q]);
-                    codes |= ((b | (b >> 12)) & 0xffu) << (8 * q);
-                    pk.v[q] = v[q];
-                }
-                uint8_t* dst = dir + (rowS >> 1) + (j0 >> 1);
-                if (NP == 1) *dst = (uint8_t)codes;
-                else if (NP == 2) *(uint16_t*)dst = (uint16_t)codes;
-                else *(uint32_t*)dst = codes;
-                if (meta & META_SAVE) *(PackP*)(ring + wslotS + j0) = pk;
-            }
-            if (meta & META_SAVE) { scount += 1; wslotS = wslotS + S == RS ? 0 : wslotS + S; }
-            rowS += S;
-            HYPO_UNROLL
-            for (int q = 0; q < NP; ++q) LAST[q] = v[q];
-            if (lov || meta_sink(meta)) note_end(v, i);
-            g.sync();
         }
-        return g.shfl((int)first, le);                       // -1: no perfect candidate
+        int ns = 1;                                          // sinks that carry the last letter (kNW / kROV)
+        if (mode != MODE_LOV) {
+            ns = 0;
+            const int cl = (int)seq[Lu - 1];
+            for (int u = g.lane; u < n_nodes; u += GW) ns += (nout[u] == 0 && (int)code[u] == cl) ? 1 : 0;
+            ns = g.reduce_add(ns);
+        }
+        if (g.any(bad)) { DBGR(strong ? 6 : 7); return strong ? -1 : 0; }
+        if (g.any(amb) || ns != 1) { DBGR(g.any(amb) ? 8 : 9); return 0; }
+        if (mode == MODE_LOV) {
+            // kLOV's end row is the FIRST row in rank order whose cell in column L is perfect: no node that carries the last
+            // letter and ranks before the path's last node may be the end of a perfect path.  Followed backwards — the in-edge
+            // sources that carry the letter before, theirs, .. — such candidates die out within a few columns (one in four
+            // survives a step); one that reaches a source in column 1, or is still alive eight columns back, is left to
+            // Poa::thread_cols.  flag[]: a byte per node in the score ring (idle here).
+            int vl = v[0];
+            HYPO_UNROLL
+            for (int t = 1; t < XSL; ++t) if ((Lu - 1) / GW == t) vl = v[t];
+            vl = g.shfl(vl, (Lu - 1) & (GW - 1));
+            uint8_t* const flag = (uint8_t*)ring;
+            static_assert((int)sizeof(score_t) * Cfg::RINGCELLS >= NMAX, "a byte per node fits the ring");
+            const int rv = (int)n2r[vl], cl = (int)seq[Lu - 1];
+            bool in[XRPL];
+            HYPO_UNROLL
+            for (int q = 0; q < XRPL; ++q) { const int u = q * GW + g.lane; in[q] = u < n_nodes && (int)code[u] == cl && (int)n2r[u] < rv; }
+            for (int j = Lu; ; --j) {                        // in[]: nodes whose cell in column j may be perfect
+                bool some = false, src = false;
+                HYPO_UNROLL
+                for (int q = 0; q < XRPL; ++q) { some = some || in[q]; src = src || (in[q] && nin[q * GW + g.lane] == 0); }
+                if (!g.any(some)) break;
+                if (j == 1) { if (g.any(src)) { DBGR(10); return 0; } break; }      // (column 1 is perfect for a node without in-edges only)
+                if (Lu - j >= 8) { DBGR(11); return 0; }
+                const int cb = (int)seq[j - 2];
+                HYPO_UNROLL
+                for (int q = 0; q < XRPL; ++q) { const int u = q * GW + g.lane; if (u < n_nodes) flag[u] = 0; }
+                g.sync();
+                HYPO_UNROLL
+                for (int q = 0; q < XRPL; ++q) {
+                    const int u = q * GW + g.lane;
+                    if (in[q]) { const int k = (int)nin[u]; for (int p = 0; p < k; ++p) { const int sx = (int)inp[u * KIN + p]; if ((int)code[sx] == cb) flag[sx] = 1; } }
+                }
+                g.sync();
+                HYPO_UNROLL
+                for (int q = 0; q < XRPL; ++q) { const int u = q * GW + g.lane; in[q] = u < n_nodes && flag[u] != 0; }
+                g.sync();
+            }
+        }
+        g.sync();
+        HYPO_UNROLL
+        for (int t = 0; t < XSL; ++t) {
+            const int q = t * GW + g.lane;
+            if (q < Lu) {
+                posnode[q] = (int16_t)v[t];
+                if (q >= 1) inw[v[t] * KIN + pidx[t]] = (wt_t)(inw[v[t] * KIN + pidx[t]] + 2);      // (graph.cpp:104-109; a path visits a node once)
+            }
+        }
+        tb_steps = Lu; tb_fv = 0;
+        g.sync();
+        return 1;
     }
 
-    // ---- the same threading, run by run ------------------------------------------------------------------------------------
-    // Between two SLOW rows the graph is a chain (every row's only predecessor is the row before it), and along a chain a
-    // perfect cell can only continue down its diagonal: (rank a, column b) -> (a + 1, b + 1) -> ...  A run of T such rows
-    // therefore needs no row loop: every perfect column of the row before the run (there are one or two of them: perfect paths
-    // are nearly unique) is extended by comparing the run's node letters with the sequence, 64 characters per step, lanes =
-    // positions along the diagonal.  kROV adds the diagonals that are born in column 0 of every row of the run (a suffix
-    // may start anywhere): all births are screened together on their first characters (lanes = births), the few that pass
-    // are checked like any other candidate.  SLOW rows (several predecessors, ring traffic, end-cell candidates of kNW /
-    // kROV) are computed exactly as in rows_exact().  The direction codes of chain rows are all DIR_FAST: the code area is
-    // filled with it once, SLOW rows store theirs.
-    HD int rows_exact_runs(int mode, int S, int R) {
-        constexpr int NP = CPL / 2;
-        const int j0 = CPL * g.lane;
-        P2 SQ[NP], P0[NP], LAST[NP];
-        HYPO_UNROLL
-        for (int q = 0; q < NP; ++q) {
-            const int j = j0 + 2 * q;
-            const int s0 = (j >= 1 && j <= L) ? (int)seq[j - 1] : (int)C_NONE;
-            const int s1 = (j + 1 <= L) ? (int)seq[j] : (int)C_NONE;
-            SQ[q] = pk_make(s0, s1);
-            P0[q] = pk_make(j == 0 ? 1 : 0, 0);              // virtual source row: only H[0][0] = 0 is perfect
-            LAST[q] = P0[q];
-        }
-        int vONE = pk_bits(pk_splat(1));
-        HYPO_IN_VGPR(vONE);
-        const P2 ONE = pk_from_bits(vONE);
+    HD int thread_cols(int mode) {
         const bool rov = mode == MODE_ROV, lov = mode == MODE_LOV;
-        const int col0 = (g.lane == 0 && rov) ? 1 : 0;      // kROV: column 0 is perfect in every row
-        const int le = L / CPL, ce = L % CPL;
-        const int ce_shift = 16 * (ce & 1);
-        unsigned first = 0xffffffffu;                        // first row (rank order) whose end-cell candidate is perfect
-        int wslotS = 0, scount = 0;
-        const int RS = R * S;
-        int nbreg = 0;
-        uint32_t nzsaved = 0;                                // bit t: the row saved t saves ago holds a perfect cell (ring reads reach back <= 31 saves)
-        {   // every chain row's codes
-            const int bytes = (n_nodes * S) >> 1;
-            for (int o = g.lane * 16; o < bytes; o += GW * 16) *(uint4v*)(dir + o) = uint4v{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        const int Lu = g.uniform(L);                         // (a member the compiler cannot prove uniform: the column loop must not run under an exec mask)
+        uint32_t mt[XRPL]; xpw_t pw[XRPL];                  // a lane's ranks: row metadata; in-edge sources as matrix rows, a byte each, in in-edge order
+        HYPO_UNROLL
+        for (int q = 0; q < XRPL; ++q) { const int r = q * GW + g.lane; mt[q] = r < n_nodes ? rowmeta[r] : 0u; }
+        XSet CH, NCP, F;
+        int kmax = 0;
+        // the sequence: 64-lane groups keep it in a register (lane t: letters t, t + 64, ..) and read a column's letter with
+        // v_readlane; narrower groups read it from LDS one column ahead
+        uint32_t sreg = 0;
+        if constexpr (GW == 64) {
+            HYPO_UNROLL
+            for (int t = 0; t < XSL; ++t) { const int c = t * GW + g.lane; if (c < Lu) sreg |= (uint32_t)seq[c] << (8 * t); }
         }
-        auto load_pk = [&](int off, P2 (&out)[NP]) {
-            if (j0 < S) {
-                const PackP pk = *(const PackP*)(ring + off + j0);
-                HYPO_UNROLL
-                for (int q = 0; q < NP; ++q) out[q] = pk.v[q];
-            } else {
-                HYPO_UNROLL
-                for (int q = 0; q < NP; ++q) out[q] = pk_splat(0);
-            }
+        static_assert(GW != 64 || XSL <= 4, "a lane's letters fit a register");
+        auto letter = [&](int j) -> int {                    // seq[j] (64-lane groups)
+            return (int)(((uint32_t)g.shfl((int)sreg, j & 63) >> (8 * (j >> 6))) & 0xffu);
         };
-        auto ring_back = [&](int back) -> int {
-            int ps = wslotS - back * S;
-            return ps < 0 ? ps + RS : ps;
-        };
-        // letters of ranks rank0.. against seq[s0..], `len` of them: length of the common prefix (all arguments group-uniform)
-        auto lcp = [&](int rank0, int s0, int len) -> int {
-            int done = 0;
-            while (done < len) {
-                const int u = done + g.lane;
-                const bool mis = u < len && (int)(rowmeta[rank0 + u] & 7u) != (int)seq[s0 + u];
-                const uint64_t b = g.ballot(mis);
-                if (b) return done + ctz64(b);
-                done += GW;
+        {
+            bool chain[XRPL], src1[XRPL], out1[XRPL], valid[XRPL];
+            const int s0 = GW == 64 ? letter(0) : (int)seq[0];
+            HYPO_UNROLL
+            for (int q = 0; q < XRPL; ++q) {
+                const int r = q * GW + g.lane;
+                valid[q] = r < n_nodes;
+                const int k = meta_k(mt[q]), p0 = meta_p0(mt[q]);
+                chain[q] = valid[q] && k == 1 && p0 == r;
+                out1[q] = valid[q] && (mt[q] & META_OUT1) != 0;
+                // column 1: perfect(p, 0) holds for the virtual row 0 only (kROV: for every row)
+                src1[q] = valid[q] && meta_code(mt[q]) == s0 && (rov || k == 0);
+                pw[q] = (xpw_t)(uint32_t)p0;
+                if (!chain[q] && k > kmax) kmax = k;
             }
-            return len;
-        };
-        int r = 0;
-        while (r < n_nodes) {
-            // ---- next SLOW row ----
-            int rs = r;
-            for (;;) {
-                const int x = rs + g.lane;
-                const bool stop = x >= n_nodes || (rowmeta[x] & META_SLOW) != 0;
-                const uint64_t b = g.ballot(stop);
-                if (b) { rs += ctz64(b); break; }
-                rs += GW;
-            }
-            const int T = rs - r;                            // chain rows: ranks r .. rs - 1
-            if (T > 0) {
-                // perfect columns of rank r - 1 (LAST): low halves = even columns of the lanes' pairs, high halves = odd ones.  One
-                // column class at a time (runtime loop: the candidate code exists once).
-                P2 NEWV[NP];
-                HYPO_UNROLL
-                for (int q = 0; q < NP; ++q) NEWV[q] = pk_splat(0);
-                auto survivor = [&](int c) {                  // column c is perfect in rank rs - 1
-                    const int w = 1 << (16 * (c & 1));
-                    HYPO_UNROLL
-                    for (int q = 0; q < NP; ++q) if (g.lane == c / CPL && (c % CPL) / 2 == q) NEWV[q] = pk_from_bits(pk_bits(NEWV[q]) | w);
-                };
-                // a diagonal that starts below (rank a - 1, column b): ranks a.. against seq[b..]
-                auto extend = [&](int a, int b) {
-                    const int rows_left = rs - a, cols_left = L - b;
-                    const int len = rows_left < cols_left ? rows_left : cols_left;
-                    if (len <= 0) return;
-                    const int l = lcp(a, b, len);
-                    if (lov && cols_left <= rows_left && l >= cols_left) {       // reaches column L inside the run: an end-cell candidate
-                        const unsigned row = (unsigned)(a + cols_left);          // matrix row of rank a + cols_left - 1
-                        first = row < first ? row : first;
-                    }
-                    if (rows_left <= cols_left && l >= rows_left) survivor(b + rows_left);
-                };
-                for (int c = 0; c < CPL; ++c) {
-                    int w = pk_bits(LAST[0]);
-                    HYPO_UNROLL
-                    for (int q = 1; q < NP; ++q) if (c / 2 == q) w = pk_bits(LAST[q]);
-                    uint64_t m = g.ballot((((uint32_t)w >> (16 * (c & 1))) & 1u) != 0);
-                    while (m) {
-                        const int ln = ctz64(m);
-                        m &= m - 1;
-                        const int b = ln * CPL + c;
-                        if (b <= L && !(rov && b == 0)) { HYPO_NO_IFCVT(); extend(r, b); }          // kROV's column 0 is a birth, below
-                    }
-                }
-                if (rov) {
-                    // births: column 0 of ranks r - 1 .. rs - 2 is perfect, so a diagonal may start with rank a = r + t matched to
-                    // seq[0] for every t in [0, T).  Screen on up to 4 characters, lanes = births.
-                    for (int base = 0; base < T; base += GW) {
-                        const int t = base + g.lane;
-                        bool ok = t < T;
-                        for (int u = 0; u < 4 && u < L; ++u) {               // (not unrolled: register pressure)
-                            HYPO_NO_IFCVT();
-                            const bool in = ok && t + u < T;
-                            const int cdx = in ? (int)(rowmeta[r + t + u] & 7u) : 0;
-                            ok = ok && (!in || cdx == (int)seq[u]);
-                        }
-                        uint64_t m = g.ballot(ok);
-                        while (m) {
-                            const int ln = ctz64(m);
-                            m &= m - 1;
-                            extend(r + base + ln, 0);
-                        }
-                    }
-                }
-                bool any = false;
-                HYPO_UNROLL
-                for (int q = 0; q < NP; ++q) { LAST[q] = NEWV[q]; any = any || pk_bits(NEWV[q]) != 0; }
-                LAST[0] = pk_from_bits(pk_bits(LAST[0]) | col0);
-                r = rs;
-                g.sync();
-                // Nothing perfect is left (no cell in this row, none in a ring row a later row could still read) and no path can
-                // start further down (kNW / kLOV start at nodes without in-edges only): the sequence spells no path.
-                if (!rov && r > (int)stat[ST_LSRC] && nzsaved == 0 && !g.any(any)) return (int)first;      // (kLOV may have met its end cell already)
-                // kLOV: rows come in rank order and the first perfect end-cell candidate wins, so the rest of the matrix is not needed
-                if (lov && first != 0xffffffffu) return (int)first;
-            }
-            if (r >= n_nodes) break;
-            // ---- SLOW row (as in rows_exact) ----
-            {
-                const int i = r + 1;
-                const uint32_t meta = (uint32_t)g.uniform((int)rowmeta[r]);
-                const int rowS = r * S;
-                const P2 CD = pk_from_bits((int)(meta & 0x00070007u));
-                const int k = meta_k(meta);
-                const int p0 = meta_p0(meta);
-                const bool fastrow = p0 == i - 1;
-                const int fastcode = fastrow ? (int)DIR_FAST : dir_diag(0);
-                P2 D[NP], cD[NP];
-                {
-                    P2 hp[NP];
-                    if (fastrow) { HYPO_UNROLL for (int q = 0; q < NP; ++q) hp[q] = LAST[q]; }
-                    else if (p0 == 0) { HYPO_UNROLL for (int q = 0; q < NP; ++q) hp[q] = P0[q]; }
-                    else load_pk(ring_back(meta_back0(meta)), hp);
-                    const int nb = nbreg = g.shfl_up1(pk_bits(hp[NP - 1]), nbreg);
-                    HYPO_UNROLL
-                    for (int q = 0; q < NP; ++q) D[q] = pk_shift_in(q ? hp[q - 1] : pk_from_bits(nb), hp[q]);
-                }
-                if (k > 1) {
-                    P2 pD[NP];
-                    HYPO_UNROLL
-                    for (int q = 0; q < NP; ++q) pD[q] = pk_splat(0);
-                    for (int p = 1; p < k; ++p) {
-                        P2 hp[NP];
-                        const int back = p == 1 ? meta_back1(meta) : scount - (int)sidx[g.uniform(pred_row(r, p)) - 1];
-                        load_pk(ring_back(back), hp);
-                        const int nb = nbreg = g.shfl_up1(pk_bits(hp[NP - 1]), nbreg);
-                        const P2 PP = pk_splat(p);
-                        HYPO_UNROLL
-                        for (int q = 0; q < NP; ++q) {
-                            const P2 d = pk_shift_in(q ? hp[q - 1] : pk_from_bits(nb), hp[q]);
-                            const P2 nd = pk_from_bits(pk_bits(D[q]) | pk_bits(d));
-                            pD[q] = pk_mad(pk_sub(nd, D[q]), pk_sub(PP, pD[q]), pD[q]);
-                            D[q] = nd;
-                        }
-                    }
-                    const P2 FC = pk_splat(fastcode);
-                    HYPO_UNROLL
-                    for (int q = 0; q < NP; ++q) cD[q] = pk_mad(pk_sub(ONE, pk_minu(pD[q], ONE)), FC, pD[q]);
-                } else {
-                    HYPO_UNROLL
-                    for (int q = 0; q < NP; ++q) cD[q] = pk_splat(fastcode);
-                }
-                P2 v[NP];
-                HYPO_UNROLL
-                for (int q = 0; q < NP; ++q) v[q] = pk_from_bits(pk_bits(D[q]) & ~pk_bits(pk_minu(pk_xor(SQ[q], CD), ONE)));
-                v[0] = pk_from_bits(pk_bits(v[0]) | col0);
-                if (j0 < S) {
-                    uint32_t codes = 0;
-                    PackP pk;
-                    HYPO_UNROLL
-                    for (int q = 0; q < NP; ++q) {
-                        const uint32_t b = (uint32_t)pk_bits(cD[q]);
-                        codes |= ((b | (b >> 12)) & 0xffu) << (8 * q);
-                        pk.v[q] = v[q];
-                    }
-                    uint8_t* dst = dir + (rowS >> 1) + (j0 >> 1);
-                    if (NP == 1) *dst = (uint8_t)codes;
-                    else if (NP == 2) *(uint16_t*)dst = (uint16_t)codes;
-                    else *(uint32_t*)dst = codes;
-                    if (meta & META_SAVE) *(PackP*)(ring + wslotS + j0) = pk;
-                }
-                if (meta & META_SAVE) {
-                    scount += 1; wslotS = wslotS + S == RS ? 0 : wslotS + S;
-                    bool nz = false;
-                    HYPO_UNROLL
-                    for (int q = 0; q < NP; ++q) nz = nz || (j0 < S && pk_bits(v[q]) != 0);
-                    nzsaved = (nzsaved << 1) | (g.any(nz) ? 1u : 0u);
-                }
-                HYPO_UNROLL
-                for (int q = 0; q < NP; ++q) LAST[q] = v[q];
-                if (lov || meta_sink(meta)) {
-                    int w = pk_bits(v[0]);
-                    HYPO_UNROLL
-                    for (int q = 1; q < NP; ++q) if (ce / 2 == q) w = pk_bits(v[q]);
-                    const unsigned hit = (unsigned)g.shfl((int)(((unsigned)w >> ce_shift) & 1u), le);
-                    if (hit && (unsigned)i < first) first = (unsigned)i;
-                }
-                ++r;
-                g.sync();
-                if (lov && first != 0xffffffffu) return (int)first;
+            CH = x_ballot(chain);
+            F = x_ballot(src1);
+            // NCP: ranks with an out-edge other than "the chain link to the next rank" (only they can feed a rank that is no chain link)
+            const XSet O1 = x_ballot(out1), AV = x_ballot(valid);
+            HYPO_UNROLL
+            for (int t = 0; t < XW; ++t) {
+                const uint64_t nextch = (CH.w[t] >> 1) | (t + 1 < XW ? CH.w[t + 1 < XW ? t + 1 : t] << 63 : 0ull);
+                NCP.w[t] = AV.w[t] & ~(O1.w[t] & nextch);
             }
         }
-        return (int)first;                                   // group-uniform; -1: no perfect candidate
+        if (!x_any(F)) return 0;
+        kmax = g.reduce_max(kmax);
+        HYPO_NOUNROLL
+        for (int p = 1; p < kmax; ++p) {                     // further in-edges of the ranks that are no chain links (three dependent reads each)
+            HYPO_UNROLL
+            for (int q = 0; q < XRPL; ++q) {
+                const int r = q * GW + g.lane;
+                if (r < n_nodes && p < meta_k(mt[q])) pw[q] |= (xpw_t)((xpw_t)(uint32_t)pred_row(r, p) << (8 * p));
+            }
+        }
+        static_assert(KIN <= 8 && NMAX <= 255, "in-edge sources of a rank fit eight bytes");
+        XSet st[XSL];                                        // lane c - 1 (slot (c - 1) / GW) keeps F_c
+        HYPO_UNROLL
+        for (int t = 0; t < XSL; ++t) { HYPO_UNROLL for (int u = 0; u < XW; ++u) st[t].w[u] = 0; }
+        if (g.lane == 0) st[0] = F;
+        int s_next = (GW == 64 || Lu < 2) ? 0 : (int)seq[1];
+        for (int j = 2; j <= Lu; ++j) {
+            int s;
+            if constexpr (GW == 64) s = letter(j - 1);
+            else { s = s_next; if (j < Lu) s_next = (int)seq[j]; }
+            bool mq[XRPL];
+            HYPO_UNROLL
+            for (int q = 0; q < XRPL; ++q) mq[q] = q * GW + g.lane < n_nodes && meta_code(mt[q]) == s;
+            const XSet M = x_ballot(mq);
+            XSet C;
+            uint64_t trig = 0;
+            HYPO_UNROLL
+            for (int t = 0; t < XW; ++t) {
+                C.w[t] = ((F.w[t] << 1) | (t ? F.w[t ? t - 1 : 0] >> 63 : 0ull)) & CH.w[t];
+                trig |= F.w[t] & NCP.w[t];
+            }
+            if (trig != 0) {
+                HYPO_NO_IFCVT();
+                bool hit[XRPL];
+                HYPO_UNROLL
+                for (int q = 0; q < XRPL; ++q) hit[q] = false;
+                HYPO_NOUNROLL
+                for (int p = 0; p < kmax; ++p) {
+                    HYPO_UNROLL
+                    for (int q = 0; q < XRPL; ++q) {
+                        const bool ch = x_in(CH, q * GW + g.lane);
+                        if (!ch && p < meta_k(mt[q])) hit[q] = hit[q] || x_in(F, (int)((pw[q] >> (8 * p)) & 0xffu) - 1);
+                    }
+                }
+                const XSet H = x_ballot(hit);
+                HYPO_UNROLL
+                for (int t = 0; t < XW; ++t) C.w[t] |= H.w[t];
+            }
+            HYPO_UNROLL
+            for (int t = 0; t < XW; ++t) F.w[t] = C.w[t] & M.w[t];
+            if (!x_any(F)) return 0;                         // no path of the graph spells seq[0..j)
+            if (g.lane == ((j - 1) & (GW - 1))) {            // lane j - 1 keeps column j
+                HYPO_UNROLL
+                for (int t = 0; t < XSL; ++t) if ((j - 1) / GW == t) st[t] = F;
+            }
+        }
+        // end row: first perfect candidate in rank order (kNW / kROV: among the sinks)
+        if (!lov) {
+            bool sk[XRPL];
+            HYPO_UNROLL
+            for (int q = 0; q < XRPL; ++q) sk[q] = q * GW + g.lane < n_nodes && meta_sink(mt[q]);
+            const XSet SNK = x_ballot(sk);
+            HYPO_UNROLL
+            for (int t = 0; t < XW; ++t) F.w[t] &= SNK.w[t];
+            if (!x_any(F)) return 0;
+        }
+        const int e = x_first(F);
+        // the rank of every column: the end row, a column's only perfect cell, or (-1) to be settled from the right
+        int rk[XSL];
+        HYPO_UNROLL
+        for (int t = 0; t < XSL; ++t) {
+            const int c = 1 + t * GW + g.lane;
+            int cnt = 0;
+            HYPO_UNROLL
+            for (int u = 0; u < XW; ++u) cnt += popc64(st[t].w[u]);
+            rk[t] = c == Lu ? e : (cnt == 1 ? x_first(st[t]) : -1);
+        }
+        HYPO_UNROLL
+        for (int t = XSL - 1; t >= 0; --t) {
+            uint64_t amb = g.ballot(1 + t * GW + g.lane < Lu && rk[t] < 0);
+            while (amb) {
+                HYPO_NO_IFCVT();
+                const int ln = 63 - clz64(amb);
+                amb &= ~(1ull << ln);
+                const int c = 1 + t * GW + ln;               // the column to settle; column c + 1 is settled (lane c % GW, slot c / GW)
+                int rnv = rk[0];
+                HYPO_UNROLL
+                for (int u = 1; u < XSL; ++u) if (c / GW == u) rnv = rk[u];
+                const int rn = g.shfl(rnv, c & (GW - 1));
+                if (rn < 0) return 0;                         // (cannot happen)
+                // in-edges of that cell's rank, from the lane that owns it
+                uint32_t mv = mt[0]; xpw_t pv = pw[0];
+                HYPO_UNROLL
+                for (int u = 1; u < XRPL; ++u) if (rn / GW == u) { mv = mt[u]; pv = pw[u]; }
+                const int own = rn & (GW - 1);
+                const uint32_t mtn = (uint32_t)g.shfl((int)mv, own);
+                uint64_t pwn = (uint64_t)(uint32_t)g.shfl((int)(uint32_t)pv, own);
+                if constexpr (sizeof(xpw_t) == 8) pwn |= (uint64_t)(uint32_t)g.shfl((int)(uint32_t)((uint64_t)pv >> 32), own) << 32;
+                const XSet Fc = x_shfl(st[t], ln);
+                const int k = meta_k(mtn);
+                int found = -1;
+                HYPO_NOUNROLL
+                for (int p = 0; p < k; ++p) {
+                    const int x = (int)((pwn >> (8 * p)) & 0xffu) - 1;
+                    if (found < 0 && x >= 0 && x_in(Fc, x)) found = x;
+                }
+                if (found < 0) return 0;                      // (cannot happen: the cell to the right is perfect through one of them)
+                if (g.lane == ln) rk[t] = found;
+            }
+        }
+        HYPO_UNROLL
+        for (int t = 0; t < XSL; ++t) {
+            const int c = 1 + t * GW + g.lane;
+            if (c <= Lu) posnode[c - 1] = (int16_t)r2n[rk[t]];
+        }
+        tb_steps = Lu; tb_fv = 0;
+        g.sync();
+        return 1;
     }
 
     // ---- the hybrid class's traceback through a tile in LDS -----------------------------------------------------------------------
@@ -1804,12 +1716,10 @@ struct Poa {
 
     // [tb_fv, L) and tb_steps (number of traceback steps; 0 = "empty alignment").
     HD int align(int mode, int m, int n, int gp) {
-        tb_steps = 0; tb_fv = L;
+        tb_steps = 0; tb_fv = L; threaded = false; weights_done = false;
         if (n_nodes == 0 || L == 0) return RES_OK;
         n_nodes = g.uniform(n_nodes);
         mode = g.uniform(mode);                             // group-uniform by construction (one sequence per group at a time)
-        const bool seen_before = (mode & MODE_SEEN) != 0;
-        mode &= 0xff;
         const int W = g.uniform(L) + 1;
         // row stride (even when NIB); the hybrid class rounds to a multiple of 16 as well, so that the traceback's tile loads of
         // direction codes (traceback_tiled) are 16-byte aligned
@@ -1835,30 +1745,27 @@ struct Poa {
 
         int best_i = -1;
         if constexpr (PK) {
-            // a sequence that spells a path of the graph (most reads do) is threaded without scores; what spells none goes
-            // through the score rows
-            // (not in the class of wide windows, Cfg::LMAX > 127: with four columns per lane a threaded row costs 734 cycles
-            // against 818 for a scored one, so a failed attempt is pure loss and a read of 130+ bases rarely spells a path —
-            // 160-bp windows with 1 % read error: 20 % of the attempts hit)
+            // a sequence that spells a path of the graph (most reads do) is threaded without scores (Poa::thread_cols: no rows, no
+            // traceback; posnode[] is final); what spells none goes through the score rows.  An attempt costs the columns up to
+            // the sequence's first error, so every alignment starts with one.
+            // (not in the class of wide windows, Cfg::LMAX > 127, unless HYPO_EXACT_WIDE)
             constexpr bool EXACT_HERE = HYPO_EXACT && (Cfg::LMAX <= 127 || HYPO_EXACT_WIDE);
-            // ... and not in a window whose reads keep failing to thread: an attempt costs about half a scored alignment, so below
-            // one hit in two it is a loss (HYPO_EXACT_ADAPT: tries before the rate counts)
-            stat_set(ST_LASTX, 0u);
-            const int x_tries = (int)stat[ST_XT], x_hits = (int)stat[ST_XH];
-            // (a copy of an earlier arm threads for sure and does not count: the rate is that of the window's OTHER arms)
-            const bool worth = seen_before || HYPO_EXACT_ADAPT == 0 || x_tries < HYPO_EXACT_ADAPT || 2 * x_hits >= x_tries;
-            if (EXACT_HERE && worth && m > 0 && n < m && gp < 0) {
-                best_i = HYPO_EXACT_RUNS ? rows_exact_runs(mode, S, R) : rows_exact(mode, S, R);
+            if (EXACT_HERE && m > 0 && n < m && gp < 0) {
+                // first along the path of the sequence before (Poa::thread_guided), then, where that cannot tell, column by column
+                int hit = thread_guided(mode);
+                weights_done = hit > 0;
+                if (hit == 0) hit = thread_cols(mode);
+                if (hit < 0) hit = 0;
                 HYPO_TICK(PH_EXACT);
                 if (g.lane == 0) {
                     stat[ST_CEXACT] += (uint32_t)((n_nodes + 1) * W);
-                    stat[ST_LASTX] = best_i > 0 ? 1u : 0u;
-                    if (!seen_before) { stat[ST_XT] += 1; if (best_i > 0) stat[ST_XH] += 1; }
-                    if (best_i > 0) stat[ST_XHITS] += 1;
+                    stat[ST_LASTX] = hit ? 1u : 0u;
+                    if (hit) stat[ST_XHITS] += 1;
                 }
-                HYPO_DIAG(exact_tries += 1; rows_exact_n += (uint32_t)n_nodes);
-            }
-            if (best_i <= 0) { best_i = rows_pk(mode, m, n, gp, S, R); stat_add(ST_CSCORED, (uint32_t)((n_nodes + 1) * W)); HYPO_DIAG(rows_scored_n += (uint32_t)n_nodes); }
+                HYPO_DIAG(exact_tries += 1; guided_hits += weights_done ? 1u : 0u);
+                if (hit) { threaded = true; return RES_OK; }
+            } else stat_set(ST_LASTX, 0u);
+            { best_i = rows_pk(mode, m, n, gp, S, R); stat_add(ST_CSCORED, (uint32_t)((n_nodes + 1) * W)); HYPO_DIAG(rows_scored_n += (uint32_t)n_nodes); }
         } else {
         stat_add(ST_CSCORED, (uint32_t)((n_nodes + 1) * W));
         int ntie = 0;                                        // lazy rank order: rows tied for the end row (in newslot[], dead until add_alignment)
@@ -2207,6 +2114,7 @@ struct Poa {
                 if (t > 0) { nin[id] = 1; inp[id * KIN] = (id_t)(id - 1); inw[id * KIN] = 2; }
                 if (t < fv - 1) nout[id] = 1;
                 if constexpr (Cfg::LAZY) { if (lazy_on) { newid[t] = (id_t)id; newslot[t] = -1; } }    // the unaligned head goes in front of everything
+                if constexpr (PK) posnode[t] = (int16_t)id;                                                 // (the guide of the next arm: Poa::thread_guided)
             }
             n_new = fv;
             head = n_nodes + fv - 1;
@@ -2512,6 +2420,16 @@ struct Poa {
     HD int add_sequence_step(int mode, int m, int n, int gp) {
         int rc = align(mode, m, n, gp);
         if (rc != RES_OK) { if (rc == RES_OVERFLOW) stat_set(ST_CKIND, CARRY_BEFORE); return rc; }       // align() never changes the graph
+        if (threaded) {
+            // a threaded sequence adds no node and no edge (graph.cpp:154-271 would find every node and edge in place): only the
+            // weights along its path grow, the rank order and the row metadata stay valid
+            rc = weights_done ? (int)RES_OK : readd_alignment(1);
+            last_changed = false;
+            guide_len = L; guide_mode = mode;
+            HYPO_TICK(PH_ADD);
+            return rc;
+        }
+        guide_len = -1;
         rc = add_alignment();
         HYPO_TICK(PH_ADD);
         if (rc == RES_OVERFLOW_CLEAN) {
@@ -2523,6 +2441,7 @@ struct Poa {
             return RES_OVERFLOW;
         }
         if (rc != RES_OK) return rc;
+        if constexpr (PK) { guide_len = L; guide_mode = mode; }       // posnode[] = the node of every position (the sort below leaves it alone: its stack is in the ring)
         if (topo_dirty) {
             rc = toposort(); HYPO_DIAG(topo_runs += 1); HYPO_TICK(PH_TOPO);
             if (rc == RES_OVERFLOW) stat_set(ST_CKIND, CARRY_UNSORTED);                                 // (the DFS stack: the graph itself is complete)
@@ -3036,9 +2955,9 @@ struct Poa {
         g.sync();
         if (g.lane < ST_N) stat[g.lane] = 0;
         g.sync();
-        HYPO_DIAG(rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; rows_exact_n = 0; rows_scored_n = 0; topo_dfs = 0; topo_fast = 0);
+        HYPO_DIAG(rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; guided_hits = 0; rows_scored_n = 0; topo_dfs = 0; topo_fast = 0);
         n_paths = 0; path_used = 0; head_first = 0; L = 0; tb_steps = 0; tb_fv = 0;
-        lazy_on = false; n_new = 0;
+        lazy_on = false; n_new = 0; guide_len = -1;
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
         HYPO_TICK_RESET();
         const uint32_t ne = W.n_internal + W.n_prefix + W.n_suffix;

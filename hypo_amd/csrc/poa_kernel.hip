@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
         }
 #ifdef HYPO_PHASE_TIMERS
         for (int i = 0; i < PH_N; ++i) tph[i] += poa.tphase[i];
-        dbg[0] += poa.rows_done; dbg[1] += stt[PoaT::ST_ALIGNS] - stt[PoaT::ST_REUSED]; dbg[2] += stt[PoaT::ST_REUSED]; dbg[3] += poa.topo_runs; dbg[4] += poa.cons_serial; dbg[5] += poa.rows_slow; dbg[6] += poa.exact_tries; dbg[7] += stt[PoaT::ST_XHITS]; dbg[8] += poa.rows_exact_n; dbg[9] += poa.rows_scored_n; dbg[10] += poa.topo_dfs; dbg[11] += poa.topo_fast;
+        dbg[0] += poa.rows_done; dbg[1] += stt[PoaT::ST_ALIGNS] - stt[PoaT::ST_REUSED]; dbg[2] += stt[PoaT::ST_REUSED]; dbg[3] += poa.topo_runs; dbg[4] += poa.cons_serial; dbg[5] += poa.rows_slow; dbg[6] += poa.exact_tries; dbg[7] += stt[PoaT::ST_XHITS]; dbg[8] += poa.guided_hits; dbg[9] += poa.rows_scored_n; dbg[10] += poa.topo_dfs; dbg[11] += poa.topo_fast;
 #endif
         if (rc == RES_OK) {
             if (g.lane == 0) {                                  // algorithmic bytes, SURVEY.md 8(d)

@@ -40,7 +40,7 @@ def main():
         print(f"    per window: rows={ph[c, D] / nw:.1f} real alignments={ph[c, D + 1] / nw:.2f} reused={ph[c, D + 2] / nw:.2f} "
               f"toposorts={ph[c, D + 3] / nw:.2f} serial consensus={ph[c, D + 4] / nw:.3f}; exact threading {ph[c, D + 7] / nw:.2f} of {ph[c, D + 6] / nw:.2f} tries")
         print(f"    score rows: {ph[c, D + 9] / nw:.1f} per window at {ph[c, 1] / max(ph[c, D + 9], 1):.0f} cycles/row ({100 * ph[c, D + 5] / max(ph[c, D + 9], 1):.1f}% slow-path rows)   "
-              f"exact rows: {ph[c, D + 8] / nw:.1f} per window at {ph[c, NP - 1] / max(ph[c, D + 8], 1):.0f} cycles/row")
+              f"threading: {ph[c, D + 8] / nw:.2f} per window along the guide; {ph[c, NP - 1] / max(ph[c, D + 6], 1):.0f} cycles per attempt")
         for i in range(NP):
             print(f"    {NAMES[i]:14s} {100 * ph[c, i] / tot:6.2f}%   {ph[c, i] / max(st['n_class'][c], 1) / 1e3:9.2f} kcycles/window")
 

@@ -109,7 +109,7 @@ void run_group(Sched& s, int gw, void (*body)(int, void*), void* arg) {
     for (int l = 0; l < gw; ++l) if (!s.done[l]) { fprintf(stderr, "[emu] lane %d did not finish\n", l); abort(); }
 }
 
-uint64_t g_exact[3] = {0, 0, 0};      // exact-threading attempts / successes / reused alignments since the last emu_exact_stats
+uint64_t g_exact[4] = {0, 0, 0, 0};   // exact-threading attempts / successes / reused alignments / successes along the guide since the last emu_exact_stats
 
 // what a re-queued window takes along (Poa::spill), as the kernel's queue entry would
 struct Carry {
@@ -147,7 +147,7 @@ void lane_body(int lane, void* arg) {
     } else if (rc == hypo::RES_OVERFLOW && poa.stat_get(PoaT::ST_CPASS) && lane == 0) j->carry_len = ~0u;
     if (lane == 0) {
         j->need_nodes = (int)poa.stat_get(PoaT::ST_NEED); j->cells = poa.stat_get(PoaT::ST_CELLS); j->aligns = poa.stat_get(PoaT::ST_ALIGNS);
-        g_exact[0] += poa.exact_tries; g_exact[1] += poa.stat_get(PoaT::ST_XHITS); g_exact[2] += poa.stat_get(PoaT::ST_REUSED);
+        g_exact[0] += poa.exact_tries; g_exact[1] += poa.stat_get(PoaT::ST_XHITS); g_exact[2] += poa.stat_get(PoaT::ST_REUSED); g_exact[3] += poa.guided_hits;
     }
 }
 
@@ -270,7 +270,8 @@ extern "C" int emu_poa_chain(const HypoScoreParams* sp, const HypoWindowBatch* i
     return 0;
 }
 
-extern "C" void emu_exact_stats(uint64_t* out) { for (int i = 0; i < 3; ++i) { out[i] = g_exact[i]; g_exact[i] = 0; } }
+extern "C" void emu_exact_stats(uint64_t* out) { for (int i = 0; i < 3; ++i) out[i] = g_exact[i]; for (int i = 0; i < 4; ++i) g_exact[i] = 0; }
+extern "C" uint64_t emu_guided_hits() { return g_exact[3]; }      // (read before emu_exact_stats clears it)
 
 extern "C" int emu_class_bytes(int cfg_id) {
     switch (cfg_id) {
@@ -281,3 +282,6 @@ extern "C" int emu_class_bytes(int cfg_id) {
         default: return -1;
     }
 }
+#ifdef HYPO_EMU_DBG
+extern "C" void emu_dbg_reasons(unsigned long* out) { for (int i = 0; i < 16; ++i) { out[i] = hypo::g_dbg_reason[i]; hypo::g_dbg_reason[i] = 0; } }
+#endif
