@@ -100,9 +100,9 @@ struct PoaParamRef {
 #ifndef HYPO_EXACT
 #define HYPO_EXACT 1
 #endif
-// ... also in the class of wide windows (class 3)
+// ... also in the class of wide windows (class 3: along the guide only, see Poa::align)
 #ifndef HYPO_EXACT_WIDE
-#define HYPO_EXACT_WIDE 0
+#define HYPO_EXACT_WIDE 1
 #endif
 // int16 score rows as packed pairs of columns (Poa::rows_pk); HYPO_PACKED=0 builds the one-column-per-register loop everywhere
 #ifndef HYPO_PACKED
@@ -1094,12 +1094,12 @@ struct Poa {
         const int d = mode == MODE_ROV ? Gl - Lu : 0;       // kROV arms end where the guide ends, the others start where it starts
         if (mode == MODE_NW && Gl != Lu) { DBGR(3); return 0; }
         const bool strong = guide_mode == mode;              // the guide is anchored like this arm: a letter it cannot place is an error of the arm
-        int v[XSL], pidx[XSL];
+        int v[XSL];                                          // node of position t * GW + lane; from the edge check on: | in-edge index << 16
         bool bad = false, amb = false;
         HYPO_UNROLL
         for (int t = 0; t < XSL; ++t) {
             const int q = t * GW + g.lane;
-            v[t] = -1; pidx[t] = -1;
+            v[t] = -1;
             if (q < Lu) {
                 const int g0 = (int)posnode[q + d], c = (int)seq[q];
                 if ((int)code[g0] == c) v[t] = g0;
@@ -1116,7 +1116,7 @@ struct Poa {
         HYPO_UNROLL
         for (int t = 0; t < XSL; ++t) {
             const int q = t * GW + g.lane;
-            const int prev = g.shfl_up1(v[t], carry);
+            const int prev = g.shfl_up1(v[t], carry);        // (v[t] is still the plain node here)
             if (t + 1 < XSL) carry = g.shfl(v[t], GW - 1);
             if (q < Lu) {
                 const int u = v[t];
@@ -1124,14 +1124,15 @@ struct Poa {
                 if (q == 0) { if (mode != MODE_ROV && k != 0) bad = true; }
                 else {
                     const int cp = (int)seq[q - 1];
-                    int first_same = -1;                      // first in-edge (the reference tries them in this order) whose source carries the letter before
+                    int first_same = -1, pi = -1;                      // first in-edge (the reference tries them in this order) whose source carries the letter before
                     for (int p = 0; p < k; ++p) {
                         const int src = (int)inp[u * KIN + p];
-                        if (src == prev) pidx[t] = p;
+                        if (src == prev) pi = p;
                         if (k > 1 && first_same < 0 && (int)code[src] == cp) first_same = p;
                     }
-                    if (pidx[t] < 0) bad = true;
-                    if (k > 1 && first_same != pidx[t]) amb = true;
+                    if (pi < 0) bad = true;
+                    if (k > 1 && first_same != pi) amb = true;
+                    if (pi >= 0) v[t] |= pi << 16;
                 }
                 if (q == Lu - 1 && mode != MODE_LOV && nout[u] != 0) bad = true;
             }
@@ -1154,7 +1155,7 @@ struct Poa {
             int vl = v[0];
             HYPO_UNROLL
             for (int t = 1; t < XSL; ++t) if ((Lu - 1) / GW == t) vl = v[t];
-            vl = g.shfl(vl, (Lu - 1) & (GW - 1));
+            vl = g.shfl(vl, (Lu - 1) & (GW - 1)) & 0xffff;
             uint8_t* const flag = (uint8_t*)ring;
             static_assert((int)sizeof(score_t) * Cfg::RINGCELLS >= NMAX, "a byte per node fits the ring");
             const int rv = (int)n2r[vl], cl = (int)seq[Lu - 1];
@@ -1188,8 +1189,9 @@ struct Poa {
         for (int t = 0; t < XSL; ++t) {
             const int q = t * GW + g.lane;
             if (q < Lu) {
-                posnode[q] = (int16_t)v[t];
-                if (q >= 1) inw[v[t] * KIN + pidx[t]] = (wt_t)(inw[v[t] * KIN + pidx[t]] + 2);      // (graph.cpp:104-109; a path visits a node once)
+                const int u = v[t] & 0xffff, pi = v[t] >> 16;
+                posnode[q] = (int16_t)u;
+                if (q >= 1) inw[u * KIN + pi] = (wt_t)(inw[u * KIN + pi] + 2);      // (graph.cpp:104-109; a path visits a node once)
             }
         }
         tb_steps = Lu; tb_fv = 0;
@@ -1754,7 +1756,8 @@ struct Poa {
                 // first along the path of the sequence before (Poa::thread_guided), then, where that cannot tell, column by column
                 int hit = thread_guided(mode);
                 weights_done = hit > 0;
-                if (hit == 0) hit = thread_cols(mode);
+                // (column by column not in the wide class and not in four-groups-per-wave class 0, where every rank set is a vector register per lane: both would lose a wave per SIMD to it and thread along the guide only)
+                if constexpr (Cfg::LMAX <= 127 && GW >= 32) { if (hit == 0) hit = thread_cols(mode); }
                 if (hit < 0) hit = 0;
                 HYPO_TICK(PH_EXACT);
                 if (g.lane == 0) {
