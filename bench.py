@@ -250,6 +250,14 @@ def end_to_end_1g_leg():
                                "Row T1 at 1 Gbp end to end: 1000 x 1 Mbp draft, 30x 150-bp reads (198.8 M records as BAM), -s 1g -> k = 15, -p 10, hypo binary = host pipeline + device on ONE MI355X, one run")
 
 
+def end_to_end_k17_leg():
+    return end_to_end_fast_leg("e2e_k17_10m_s117", True,
+                               "k = 17 against the reference: 10 x 1 Mbp draft, 30x 150-bp reads (1.99 M records as BAM), -s 3g -> k = 17 (2 GiB solid set), one run")
+
+
+T1_3GBP_MD5_ROUND4 = "a4b0764b66b0a285dca0f630a0bbfde9"      # profiles/r04_t1_3gbp.json: 3000 x 1 Mbp, seed 97, -s 3g, identical for -p 50 / -p 100
+
+
 def end_to_end_t1_leg(n_contigs, contig_len=1_000_000, batchings=(10, 50)):
     """Row T1 (north_star: 3 Gbp / 30x short reads on one GPU): `n_contigs` x 1 Mbp from the C++ generator as BAM, `-s <size>` picks k as the
     reference does (1g -> 15, 3g -> 17), the run is made once per contig-batch size in `batchings` and the FASTA of all of them must be
@@ -302,7 +310,7 @@ def end_to_end_t1_leg(n_contigs, contig_len=1_000_000, batchings=(10, 50)):
                 "input_generation_seconds": round(tg, 1), "bam_bytes": os.path.getsize(os.path.join(d, "sr.bam")),
                 "workload": f"T1: {n_contigs} x {contig_len // 1000} kbp draft, 30x 150-bp short reads as BAM, -s {size_flag} -> k = {kk}, hypo binary = host pipeline + device on ONE MI355X, "
                             f"-p {' and -p '.join(str(x) for x in batchings)}; seconds = the binary's Overall timer of the faster run",
-                "fasta": "identical across contig-batch sizes; no reference md5 at this size (the same binary matches the real reference's md5 at 5 / 17 / 100 / 250 Mbp)"}
+                "fasta": "no reference md5 at this size (the same binary matches the real reference's md5 at 5 / 10 (k = 17) / 17 / 100 / 250 / 1000 Mbp)"}
     except (subprocess.SubprocessError, OSError, ValueError) as ex:
         return {"error": str(ex)[:300]}
     finally:
@@ -337,7 +345,8 @@ def main():
     ap.add_argument("--no-e2e-k15", action="store_true", help="skip the 250 Mbp / k = 15 end-to-end run (BAM input, about half a minute)")
     ap.add_argument("--no-e2e-c4", action="store_true", help="skip the C4-at-size end-to-end run (one 250 Mbp contig, short + long reads, about a minute)")
     ap.add_argument("--no-e2e-1g", action="store_true", help="skip the 1 Gbp end-to-end run (BAM input, about a minute of input generation + half a minute)")
-    ap.add_argument("--t1-contigs", type=int, default=int(os.environ.get("HYPO_BENCH_T1_CONTIGS", "0")),
+    ap.add_argument("--no-e2e-k17", action="store_true", help="skip the 10 Mbp run at -s 3g (k = 17, the real reference's md5)")
+    ap.add_argument("--t1-contigs", type=int, default=int(os.environ.get("HYPO_BENCH_T1_CONTIGS", "3000")),
                     help="also run row T1 end to end on this many 1 Mbp contigs (3000 = the north star's 3 Gbp; needs ~20 GB of /dev/shm and a few minutes)")
     ap.add_argument("--no-extras", action="store_true", help="skip value_at_0p5pct / value_at_1pct / value_dense / value_c4mix and host_api")
     args = ap.parse_args()
@@ -700,6 +709,8 @@ def main():
     e2e_k15 = None
     e2e_c4 = None
     e2e_t1 = None
+    e2e_1g = None
+    e2e_k17 = None
     if rank == 0 and world == 1 and not args.no_e2e and not strong:
         e2e = end_to_end_leg()
         if not args.no_e2e_c3:
@@ -708,10 +719,20 @@ def main():
             e2e_k15 = end_to_end_k15_leg()
         if not args.no_e2e_c4:
             e2e_c4 = end_to_end_c4_leg()
+        if not args.no_e2e_k17:
+            e2e_k17 = end_to_end_k17_leg()                 # k = 17 (-s 3g) pinned to the real reference on 10 Mbp
+        if not args.no_e2e_1g:
+            e2e_1g = end_to_end_1g_leg()                   # 1 Gbp with the real reference's md5
         if args.t1_contigs > 0:
-            e2e_t1 = end_to_end_t1_leg(args.t1_contigs)
-        elif not args.no_e2e_1g:
-            e2e_t1 = end_to_end_1g_leg()                   # (the default: 1 Gbp with the real reference's md5; --t1-contigs 3000 = the 3 Gbp run)
+            # row T1 at size: 3 Gbp / 30x short reads, -s 3g -> k = 17, one -p 50 run (about two minutes of input generation + the run)
+            e2e_t1 = end_to_end_t1_leg(args.t1_contigs, batchings=(50,))
+            if e2e_t1 and "fasta_md5" in e2e_t1 and args.t1_contigs == 3000:
+                # no reference md5 exists at this size; what is checked is that the FASTA is the one this repo's round-4 runs produced
+                # for the same generator arguments at -p 50 and -p 100 (profiles/r04_t1_3gbp.json) — k = 17 itself is pinned to the
+                # reference by e2e_k17_10m above
+                e2e_t1["fasta_same_as_round4_runs"] = e2e_t1["fasta_md5"] == T1_3GBP_MD5_ROUND4
+                if not e2e_t1["fasta_same_as_round4_runs"]:
+                    raise SystemExit("bench: the 3 Gbp FASTA differs from the one of profiles/r04_t1_3gbp.json — refusing to report a number")
 
     if strong and world > 1:                               # per-rank imbalance of the measured step
         tt = torch.tensor([my_dt], dtype=torch.float64, device=dev)
@@ -745,7 +766,7 @@ def main():
                        "contig_bases": total_bases, "k": k,
                        "parallelism": f"window sharding x{world}" + (" + RCCL all-gather of consensus" if world > 1 else "")},
             "mbp_per_s": round(total_bases * args.steps / dt / 1e6, 2),
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "e2e": e2e, "e2e_c3": e2e_c3, "e2e_k15_250m": e2e_k15, "e2e_c4_250m": e2e_c4, "e2e_t1": e2e_t1,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "e2e": e2e, "e2e_c3": e2e_c3, "e2e_k15_250m": e2e_k15, "e2e_c4_250m": e2e_c4, "e2e_k17_10m": e2e_k17, "e2e_1g": e2e_1g, "e2e_t1": e2e_t1,
         }
         if imbalance:
             out["imbalance"] = imbalance

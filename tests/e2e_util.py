@@ -227,7 +227,7 @@ def long_reads_pass_nm_filter(sam_path, ned_th=20):
     return True
 
 
-def run_vs_reference_stage(outdir, seed, device, messy, threads=4, long_reads=False):
+def run_vs_reference_stage(outdir, seed, device, messy, threads=4, long_reads=False, k=None):
     """One single-contig short-read set made NOW (no committed golden behind it): this repo's `hypo` (region dump) against the
     real Alignment / Contig / Window code of the reference run on the same records (oracle.RefArms): region borders and types
     (A14, through the support votes N1), arm counts and crc32 of the arms of every window (A13 / N2).  Returns the number of
@@ -241,15 +241,17 @@ def run_vs_reference_stage(outdir, seed, device, messy, threads=4, long_reads=Fa
         if nc != 1 or with_long != long_reads:
             return None
     else:
-        k = [7, 9, 11][seed % 3]
+        # k: the caller's (13 / 15 / 17: the 32- and 64-bit-id vote kernels, nearly every position of a small genome marked: the
+        # regime of the 250 Mbp - 3 Gbp sets) or 7 / 9 / 11 by seed; -s is the size flag that derives it (src/main.cpp:490-528)
+        k = k if k is not None else [7, 9, 11][seed % 3]
         gen.generate(str(outdir), seed, [8000, 20000, 40000][seed % 3], long_reads, k)
         with_long = long_reads
-        args = ["-d", "draft.fa", "-r", "reads.fa", "-s", {7: "10k", 9: "100k", 11: "1m"}[k], "-c", "30", "-b", "sr.sam"] + (["-B", "lr.sam"] if long_reads else []) + ["-t", "1", "-i"]
+        args = ["-d", "draft.fa", "-r", "reads.fa", "-s", SIZE_FLAG_OF_K[k], "-c", "30", "-b", "sr.sam"] + (["-B", "lr.sam"] if long_reads else []) + ["-t", "1", "-i"]
     if with_long:
         ned = int(args[args.index("-n") + 1]) if "-n" in args else 20
         if not long_reads_pass_nm_filter(os.path.join(str(outdir), "lr.sam"), ned):
             return None
-    k = {"10k": 7, "100k": 9, "1m": 11}[args[args.index("-s") + 1]]
+    k = {v: kk for kk, v in SIZE_FLAG_OF_K.items()}[args[args.index("-s") + 1]]
     mq = int(args[args.index("-q") + 1]) if "-q" in args else 2
     argv = [BIN] + args
     argv[argv.index("-t") + 1] = str(threads)
@@ -289,4 +291,5 @@ def run_vs_reference_stage(outdir, seed, device, messy, threads=4, long_reads=Fa
     return n
 
 
+SIZE_FLAG_OF_K = {7: "10k", 9: "100k", 11: "1m", 13: "100m", 15: "250m", 17: "3g"}     # -s values and the k they derive
 LAST_LONG_WINDOWS = 0          # LONG windows among those the last run_vs_reference_stage call compared

@@ -108,17 +108,30 @@ def generate(outdir, seed, G, with_long, K=11, read_len=RL, read_sub=0.002):
         km = truth[i:i + K]
         cnt[min(km, rc(km))] += 1
     nb = 1 << (2 * K)
-    words = [0] * (nb // 64)
     ns = 0
-    for km, c in cnt.items():
-        if c == 1 and km[0] != km[1] and km[-1] != km[-2]:
-            for x in (km, rc(km)):
-                v = enc(x)
-                words[v >> 6] |= (1 << (v & 63))
-            ns += 1
-    with open(os.path.join(outdir, "aux", "solid_kmers.bvsd"), "wb") as f:
-        f.write(struct.pack("<Q", nb))
-        f.write(struct.pack(f"<{len(words)}Q", *words))
+    if K >= 12:                                  # 4^k bits no longer fit a Python list (k = 17: 2 GiB): same bits through numpy
+        import numpy as np
+        words = np.zeros(nb // 64, dtype=np.uint64)
+        for km, c in cnt.items():
+            if c == 1 and km[0] != km[1] and km[-1] != km[-2]:
+                for x in (km, rc(km)):
+                    v = enc(x)
+                    words[v >> 6] |= np.uint64(1 << (v & 63))
+                ns += 1
+        with open(os.path.join(outdir, "aux", "solid_kmers.bvsd"), "wb") as f:
+            f.write(struct.pack("<Q", nb))
+            words.tofile(f)
+    else:
+        words = [0] * (nb // 64)
+        for km, c in cnt.items():
+            if c == 1 and km[0] != km[1] and km[-1] != km[-2]:
+                for x in (km, rc(km)):
+                    v = enc(x)
+                    words[v >> 6] |= (1 << (v & 63))
+                ns += 1
+        with open(os.path.join(outdir, "aux", "solid_kmers.bvsd"), "wb") as f:
+            f.write(struct.pack("<Q", nb))
+            f.write(struct.pack(f"<{len(words)}Q", *words))
     w("aux/stage.txt", "Stage:SolidKmers [2026-09-28 12:00:00]\t1\n")
     if with_long:
         LCOV, LL = 40, 8000

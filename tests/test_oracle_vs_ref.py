@@ -107,6 +107,19 @@ def test_host_stage_vs_real_alignment_and_contig_code(tmp_path):
     assert done >= 4 and total > 500, (done, total)
 
 
+def test_host_stage_vs_real_code_at_k13(tmp_path):
+    """The same stage check at k = 13 (`-s 100m`, BASELINE config C3's k): nearly every k-mer of a 20 kbp genome is solid, so 40 %
+    of the positions are marked — the regime of the large sets.  (k = 15 / 17 run on the GPU box: tests/test_gpu_e2e.py.)"""
+    import pytest
+    import oracle
+    import e2e_util
+    if not oracle.RefArms.available():
+        pytest.skip("oracle/_ref/libhyporef_arms.so not built (the real reference only exists in the build container)")
+    e2e_util.build_binary()
+    e2e_util.build_shim()
+    assert e2e_util.run_vs_reference_stage(tmp_path / "k13", 305, "shim", messy=False, k=13) > 20
+
+
 def test_host_long_read_stage_vs_real_filter_and_alignment_code(tmp_path):
     """`-B` sets generated now: long-read arm selection (Alignment::find_long_arms, src/Alignment.cpp:262-299) and the minimizer
     filter of LONG windows (include/Filter.hpp through the real Window::add_*) of this repo's host mirror (over the CPU shim)
