@@ -282,6 +282,20 @@ class RefArms:
         return (np.array(pos, dtype=np.uint32), np.array(coff, dtype=np.uint32), np.array(cig or [0], dtype=np.uint32),
                 np.array(soff, dtype=np.uint64), "".join(seq).encode())
 
+    def fasta(self, contig_seq: bytes, name: str, k: int, bvsd_path: str, records, out_path: str, scores=(5, -4, -8, 3, -5, -4)) -> int:
+        """The polished FASTA record of one contig written by the reference's own `operator<<(Contig)` after its own short-read
+        stage and its own Window::generate_consensus (hyporef_fasta, row A15 in place).  Returns the number of regions."""
+        pos, coff, cig, soff, seq = records
+        if not hasattr(self.lib, "hyporef_fasta"):
+            raise RuntimeError("oracle/_ref/libhyporef_arms.so predates hyporef_fasta: make -C oracle ref")
+        self.lib.hyporef_fasta.restype = C.c_long
+        rc = self.lib.hyporef_fasta(contig_seq, C.c_uint64(len(contig_seq)), name.encode(), C.c_uint32(k), bvsd_path.encode(),
+                                    C.c_uint32(len(pos)), _ptr(pos), _ptr(coff), _ptr(cig), _ptr(soff), seq, out_path.encode(),
+                                    (C.c_int8 * 6)(*scores))
+        if rc < 0:
+            raise RuntimeError(f"hyporef_fasta rc={rc}")
+        return int(rc)
+
     def regions_dump(self, contig_seq: bytes, k: int, bvsd_path: str, records, work_dir: str, long_records=None) -> str:
         """Runs the stage and returns the path of the reference's dump (aux/inspect_c.txt under work_dir).  long_records: the
         long reads of a `-B` run (same layout): the LONG-read stage follows (prepare_long_windows, find_long_arms, fill_long_windows

@@ -28,8 +28,10 @@
 #include <vector>
 #include <unistd.h>
 #include <sys/stat.h>
+#include <omp.h>
 #include "Contig.hpp"
 #include "Alignment.hpp"
+#include "Window.hpp"
 
 namespace {
 uint8_t nt16(char c) {
@@ -200,4 +202,43 @@ long hyporef_arms(const char* contig, uint64_t n, uint32_t k, const char* bvsd_p
     }
     if (chdir(cwd) != 0) return -2;
     return rc;
+}
+
+extern "C" __attribute__((visibility("default")))
+// Row A15 in place: the whole short-read polish of ONE contig by the reference's own code — the stage above, then
+// Window::prepare_for_poa + Contig::generate_consensus on every valid window (src/Hypo.cpp:237-247: the real Window class and
+// spoa), then the REAL `operator<<(std::ostream&, const Contig&)` (src/Contig.cpp:345-366) into out_path: `>name`, the
+// concatenation of strong regions, window consensus and untouched draft, one line.  What this repo's `hypo` writes for the same
+// records must be these bytes (tests/test_oracle_vs_ref.py, tests/test_gpu_e2e.py).  scores: -m -x -g -M -X -G as the CLI
+// stores them (src/main.cpp:100-113).  Returns the number of regions, -1 / -2 as hyporef_arms.
+long hyporef_fasta(const char* contig, uint64_t n, const char* name, uint32_t k, const char* bvsd_path, uint32_t n_reads, const uint32_t* pos,
+                   const uint32_t* cigar_off, const uint32_t* cigar, const uint64_t* seq_off, const char* seq, const char* out_path, const int8_t* scores) {
+    auto sk = std::make_unique<suk::SolidKmers>(k);
+    if (!sk->load(std::string(bvsd_path))) return -1;
+    hypo::Contig c(0, std::string(name), std::string(contig, (size_t)n));
+    c.find_solid_pos(sk);
+    uint64_t invalid = 0;
+    std::vector<std::unique_ptr<hypo::Alignment>> als;
+    make_alignments(c, n_reads, pos, cigar_off, cigar, seq_off, seq, als, invalid);
+    #pragma omp parallel for
+    for (uint64_t t = 0; t < als.size(); ++t) als[t]->update_solidkmers_support(k, c);
+    c.prepare_for_division(k);
+    #pragma omp parallel for
+    for (uint64_t t = 0; t < als.size(); ++t) als[t]->update_minimisers_support(c);
+    c.divide_into_regions();
+    #pragma omp parallel for
+    for (uint64_t t = 0; t < als.size(); ++t) als[t]->find_short_arms(k, c);
+    c.fill_short_windows(als);
+    hypo::Contig::set_no_long_reads();                                     // src/Hypo.cpp:230-232 (a run without -B)
+    hypo::ScoreParams sp{scores[0], scores[1], scores[2], scores[3], scores[4], scores[5]};      // -m -x -g -M -X -G
+    const int threads = omp_get_max_threads();
+    hypo::Window::prepare_for_poa(sp, (hypo::UINT32)threads);              // src/Hypo.cpp:237
+    const uint64_t num_reg = c.get_num_regions();
+    #pragma omp parallel for schedule(static, 1)
+    for (uint64_t w = 0; w < num_reg; ++w)
+        if (c.is_valid_window(w)) c.generate_consensus(w, omp_get_thread_num());   // :238-247
+    std::ofstream ofile(out_path);
+    if (!ofile.is_open()) return -2;
+    ofile << c;                                                            // :261-263
+    return (long)num_reg;
 }

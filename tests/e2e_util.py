@@ -273,6 +273,17 @@ def run_vs_reference_stage(outdir, seed, device, messy, threads=4, long_reads=Fa
     work = os.path.join(str(outdir), "refstage")
     os.makedirs(work, exist_ok=True)
     lrecs = ref.sam_records(os.path.join(str(outdir), "lr.sam"), name, mq) if with_long else None
+    if not with_long:
+        # row A15 in place: the FASTA record the reference's own operator<<(Contig) writes after its own stage and its own POA
+        # (hyporef_fasta) against the file this repo's binary wrote — no CMake-built binary in between
+        ref_fa = os.path.join(work, "ref.fa")
+        sc = [5, -4, -8, 3, -5, -4]
+        for i, fl in enumerate(("-m", "-x", "-g", "-M", "-X", "-G")):
+            if fl in args:
+                sc[i] = int(args[args.index(fl) + 1])
+        ref.fasta(draft.encode(), name, k, os.path.join(str(outdir), "aux", "solid_kmers.bvsd"), recs, ref_fa, scores=sc)
+        ours = open(os.path.join(str(outdir), "hypo_draft.fasta"), "rb").read()
+        assert ours == open(ref_fa, "rb").read(), f"seed {seed}: polished FASTA differs from the reference's own operator<<(Contig)"
     dump = ref.regions_dump(draft.encode(), k, os.path.join(str(outdir), "aux", "solid_kmers.bvsd"), recs, work, long_records=lrecs)
     regions = _reference_dump_regions(dump)
     rows = [l.rstrip("\n").split("\t") for l in open(os.path.join(str(outdir), "regions.tsv"))]
