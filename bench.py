@@ -132,7 +132,8 @@ def _run_hypo(argv, cwd, timeout=3000):
     peak = [0]
     start_busy, stop_busy = _gpu_busy_sampler()
     tw = time.perf_counter()
-    proc = subprocess.Popen(argv, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    # (HYPO_REQUIRE_DEVICE: a stage that falls back to the host loops ends the run with an error instead of a number)
+    proc = subprocess.Popen(argv, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, HYPO_REQUIRE_DEVICE="1"))
     start_busy()
     def watch():
         # (VmHWM belongs to the new address space; getrusage's ru_maxrss, which the binary prints, starts from this python process's own high-water mark)

@@ -313,7 +313,7 @@ bool DeviceArms::build(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c
 }
 
 bool DeviceArms::build_long(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1, const ReadBatch& reads) {
-    _active_long = false;
+    _active_long = false; _long_failed = false;
     if (hypo_gpu_use_device(_slot) != HYPO_OK) return false;
     const bool timing = std::getenv("HYPO_HOST_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -337,7 +337,9 @@ bool DeviceArms::build_long(std::vector<std::unique_ptr<Contig>>& contigs, uint3
     // mode: the reads that overlap this context's span of the contig)
     bool sorted = true;
     if (!reads.flatten(c0, c1, base, _stage_long, sorted, _piece ? _span : nullptr)) return false;
-    if (!sorted) { std::fprintf(stdout, "[Hypo::Hypo] Info: long-read alignments are not sorted by position: long arms are computed on the host\n"); return false; }
+    // (an unsorted -B file — the reference takes any order, src/Hypo.cpp:278-329 — is sorted by position on ingest and carries its file
+    // ranks like an unsorted -b file: the arms of a LONG window are laid out in file order, arms_window_kernel)
+    if (!sorted) std::fprintf(stdout, "[Hypo::Hypo] Info: long-read alignments are not sorted by position: sorted on ingest, the arms of a window keep their file order\n");
     std::vector<uint32_t> start(n_reg + 1);
     std::vector<uint8_t> type(n_reg + 1, (uint8_t)RegionType::SR);
     std::vector<uint8_t> contig4((total + 1) / 2, 0);
@@ -365,7 +367,7 @@ bool DeviceArms::build_long(std::vector<std::unique_ptr<Contig>>& contigs, uint3
     R.n_regions = (uint32_t)n_reg; R.start = start.data(); R.type = type.data(); R.info = nullptr;
     R.n_anchor_kmers = 0; R.anchor_kmers = nullptr; R.k = 10; R.contig4 = contig4.data();
     HypoArmsReads A;
-    A.file_rank = nullptr;
+    A.file_rank = _stage_long.ranked ? _stage_long.file_rank : nullptr;
     A.n_alignments = (uint32_t)_stage_long.n_reads; A.rb = _stage_long.rb; A.re = _stage_long.re; A.qae = _stage_long.qae; A.seq_off = _stage_long.seq_off;
     A.reads2 = _stage_long.reads2; A.reads2_bytes = _stage_long.n_bytes; A.cigar_off = _stage_long.cigar_off; A.cigar = _stage_long.cigar;
     std::vector<uint8_t> valid(n_reg, 0);
@@ -373,7 +375,7 @@ bool DeviceArms::build_long(std::vector<std::unique_ptr<Contig>>& contigs, uint3
     const int rc = hypo_gpu_arms_build_long(&R, &A, valid.data(), &_sum_long);
     if (timing) std::fprintf(stderr, "[timing] device long arms: flatten %.3f s (%.0f MB of bases, %.0f MB of CIGAR), hypo_gpu_arms_build_long %.3f s\n", secs(t0, t1), _stage_long.n_bytes / 1e6, _stage_long.n_cigar * 4 / 1e6, secs(t1, now()));
     if (rc != HYPO_OK) {
-        if (rc != HYPO_E_UNSUPPORTED) std::fprintf(stdout, "[Hypo::Hypo] Info: long arms are computed on the host (%s)\n", hypo_gpu_last_error());
+        if (rc != HYPO_E_UNSUPPORTED) { _long_failed = true; std::fprintf(stdout, "[Hypo::Hypo] Info: long arms are computed on the host (%s)\n", hypo_gpu_last_error()); }
         return false;
     }
     // what Contig::fill_long_windows leaves behind (include/Contig.hpp:91-113): the pseudo tables are gone

@@ -58,6 +58,7 @@ public:
     // released (what Contig::fill_long_windows does at its end); false: nothing changed, the host loops must run.
     bool build_long(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1, const ReadBatch& long_reads);
     bool active_long() const { return _active_long; }
+    bool long_failed() const { return _long_failed; }            // the last build_long() reached the device and failed there (--require-device)
     // what build() / build_long() leave behind in the contigs once ALL contexts that work on them are done (piece mode defers it)
     static void finish_short(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1);
     static void finish_long(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1);
@@ -83,6 +84,7 @@ private:
     void adopt_arms(const std::vector<uint32_t>& which, const std::vector<HypoWindow>& hw, const std::vector<uint32_t>& win_region, bool lng);
     int polish_impl(bool lng, const ScoreParams& sp, bool keep_arms, std::vector<Window*>* retry);
     bool _active_long = false;
+    bool _long_failed = false;
     HypoArmsSummary _sum_long{};
     std::vector<Window*> _preg_window;       // pseudo region of the coordinate space -> its LONG window (nullptr: pseudo SR, filler)
 };

@@ -141,12 +141,15 @@ void Hypo::polish() {
         start();
         // (records of contigs behind the previous batch that it had consumed — _reads holds them — come first, then what the helper
         // or this thread parses now)
+        const size_t slices_before = _reads.n_slices();
         if (prefetch.joinable()) {
             prefetch.join();
             _reads.append(staged);
         } else {
             create_alignments_flat(batch_id, _reads);
         }
+        // (read before the helper starts on the next batch: did this batch's load open with the record carried over, and of which contig)
+        const int32_t opened_with_cid = _rs_short.opened_with_cid;
         stop("[Hypo:Hypo]: Loaded alignments. ");
         if (prefetch_on && batch_id + 1 < num_batches) {
             staged.reset(_contigs.size());
@@ -169,8 +172,11 @@ void Hypo::polish() {
         // The first long read of a contig may have been consumed while the previous batch's long reads were loaded; the reference
         // files it in this contig's store entry, where the short-read phases of THIS batch find it in front of the short reads and
         // treat it as one of them (src/Hypo.cpp:314-325, :126-199).  Same here: it moves to the front of the flat batch.
+        // ... in front of them but for ONE: when the short-read loader of the batch before had already consumed this contig's first short
+        // read, that record was filed first (store entry = [short carry, long carry, this batch's short reads ..]): the long read goes
+        // behind the batch's opening record then.  Arm order inside a window is record order, and POA depends on it.
         for (uint32_t c = initial_cid; c < final_cid; ++c)
-            if (!_alignment_store[c].empty()) { _reads.prepend(c, _alignment_store[c]); _alignment_store[c].clear(); }
+            if (!_alignment_store[c].empty()) { _reads.prepend(c, _alignment_store[c], opened_with_cid == (int32_t)c ? slices_before + 1 : 0); _alignment_store[c].clear(); }
 
         // With several devices the contigs of the batch are dealt out to the contexts in contiguous ranges of about equal
         // numbers of alignments: every context keeps the reads of its contigs, counts their support votes, cuts their arms and
@@ -236,6 +242,17 @@ void Hypo::polish() {
         // N1: the reads go to the device once, now; the support votes are counted there (support_kernel.hip) and the arm kernels
         // use the same copy later.  --host-arms, an unsorted file or a device error: the reference's host loops, per contig range.
         start();
+        // --require-device / HYPO_REQUIRE_DEVICE=1: a stage that was meant for the device and is about to run in the host loops ends
+        // the run instead (the Info lines of DeviceArms say why it did not run there).  Not with --host-arms / HYPO_HOST_SUPPORT,
+        // which ask for the host loops.
+        const bool require_device = (_cFlags.require_device || (std::getenv("HYPO_REQUIRE_DEVICE") && std::atoi(std::getenv("HYPO_REQUIRE_DEVICE")) != 0)) &&
+                                    !_cFlags.host_arms && !std::getenv("HYPO_HOST_SUPPORT");
+        auto host_fallback = [&](const char* what) {
+            if (!require_device) return;
+            std::fflush(stdout);
+            std::fprintf(stderr, "[Hypo::Hypo] Error: --require-device: %s would be computed on the host (last device message: %s)\n", what, hypo_gpu_last_error());
+            std::exit(1);
+        };
         std::vector<char> votes_dev((size_t)n_ctx, 0);         // per context: its reads are resident
         if (!_cFlags.host_arms && !std::getenv("HYPO_HOST_SUPPORT"))
             for (int d = 0; d < n_ctx; ++d) {
@@ -248,6 +265,7 @@ void Hypo::polish() {
             if (c0 >= c1) continue;
             if (votes_dev[(size_t)d] && device_arms[(size_t)d]->support_kmers(_contigs, c0, c1, _cFlags.k)) continue;
             if (work[(size_t)d].piece) piece_failed(d, "the k-mer support votes");
+            { uint64_t nr = 0; for (uint32_t c = c0; c < c1; ++c) nr += _reads.count(c); if (nr) host_fallback("the k-mer support votes"); }
             materialize_alignments(c0, c1, materialized);
             for (uint32_t cid = c0; cid < c1; ++cid) {
                 _contigs[cid]->ensure_kids();
@@ -286,6 +304,7 @@ void Hypo::polish() {
             if (c0 >= c1) continue;
             if (votes_dev[(size_t)d] && device_arms[(size_t)d]->support_minimizers(_contigs, c0, c1)) continue;
             if (work[(size_t)d].piece) piece_failed(d, "the minimizer support votes");
+            { uint64_t nr = 0; for (uint32_t c = c0; c < c1; ++c) nr += _reads.count(c); if (nr) host_fallback("the minimizer support votes"); }
             materialize_alignments(c0, c1, materialized);
             for (uint32_t cid = c0; cid < c1; ++cid) {
                 auto& alns = _alignment_store[cid];
@@ -330,6 +349,7 @@ void Hypo::polish() {
         }
         for (uint32_t cid = initial_cid; cid < final_cid; ++cid) {
             if (on_dev[cid - initial_cid]) { _alignment_store[cid].clear(); continue; }       // (objects a host vote loop had asked for)
+            if (!_cFlags.host_arms && _reads.count(cid) > 0) host_fallback("short-arm selection");
             materialize_alignments(cid, cid + 1, materialized);
             auto& alns = _alignment_store[cid];
 #pragma omp parallel for
@@ -383,7 +403,10 @@ void Hypo::polish() {
                     if (c0 >= c1) continue;
                     if (device_arms[(size_t)d]->build_long(_contigs, c0, c1, _reads_long))
                         for (uint32_t c = c0; c < c1; ++c) long_on_dev[c - initial_cid] |= 1;
-                    else if (work[(size_t)d].piece) long_on_dev[c0 - initial_cid] |= 2;      // (a shared contig: all of its contexts or none)
+                    else {
+                        if (device_arms[(size_t)d]->long_failed()) host_fallback("long-arm selection");
+                        if (work[(size_t)d].piece) long_on_dev[c0 - initial_cid] |= 2;      // (a shared contig: all of its contexts or none)
+                    }
                 }
                 for (int d = 0; d < n_ctx; ++d) {
                     if (!work[(size_t)d].piece) continue;
@@ -590,7 +613,8 @@ void Hypo::create_alignments_flat(uint32_t batch_id, ReadBatch& into, bool is_sr
     constexpr size_t kBlock = 1 << 19, kBlockBytes = (size_t)128 << 20;     // (a block of records = about one run of inflated BGZF blocks, SeqIO.hpp)
     // (the record a call consumed for a contig behind its batch: a short read opens that contig's batch; a LONG read has been filed
     // as an object in that contig's store entry by Hypo::polish, where the reference's short-read phases find it)
-    if (rs.carry_blk && is_sr) into.add(rs.carry_blk, rs.carry_r0, rs.carry_r1);
+    rs.opened_with_cid = -1;
+    if (rs.carry_blk && is_sr) { into.add(rs.carry_blk, rs.carry_r0, rs.carry_r1); rs.opened_with_cid = rs.carry_cid; }
     rs.carry_blk.reset();
     bool stop = false, more_ahead = true;
     double t_wait = 0, t_par = 0, t_col = 0; auto now = []{ return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };

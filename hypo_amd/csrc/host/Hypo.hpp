@@ -76,6 +76,7 @@ private:
         // a contig of a later batch (the reference files it in that contig's store entry, src/Hypo.cpp:314-325)
         std::shared_ptr<ParsedBlock> parsed; size_t ppos = 0;
         std::shared_ptr<ParsedBlock> carry_blk; size_t carry_r0 = 0, carry_r1 = 0; int32_t carry_cid = -1;
+        int32_t opened_with_cid = -1;      // the batch loaded last began with the record carried over from the call before, of this contig (-1: it did not)
     };
     RecordStream _rs_short, _rs_long;
     PhaseTimes _times;

@@ -60,7 +60,7 @@ void ReadBatch::append(ReadBatch& other) {
     other._slices.clear(); std::fill(other._per_contig.begin(), other._per_contig.end(), 0); other._n = 0;
 }
 
-void ReadBatch::prepend(uint32_t cid, const std::vector<std::unique_ptr<Alignment>>& objs) {
+void ReadBatch::prepend(uint32_t cid, const std::vector<std::unique_ptr<Alignment>>& objs, size_t at_slice) {
     if (objs.empty()) return;
     auto blk = std::make_shared<ParsedBlock>();
     blk->chunks.resize(1);
@@ -78,7 +78,10 @@ void ReadBatch::prepend(uint32_t cid, const std::vector<std::unique_ptr<Alignmen
     ReadBatch front;
     front.reset(_per_contig.size());
     front.add(blk, 0, blk->n);
+    const size_t n_new = front._slices.size();
     front.append(*this);
+    if (at_slice > 0 && front._slices.size() >= n_new + at_slice)   // [.. carried record | objs | the rest]: the slices that were in front of `at_slice` move back to the front
+        std::rotate(front._slices.begin(), front._slices.begin() + n_new, front._slices.begin() + n_new + at_slice);
     _slices.swap(front._slices); _per_contig.swap(front._per_contig); _n = front._n;
 }
 

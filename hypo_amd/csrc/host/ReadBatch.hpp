@@ -105,7 +105,9 @@ public:
     void add(const std::shared_ptr<ParsedBlock>& blk, size_t r0, size_t r1);
     void append(ReadBatch& other);                                  // other's slices behind this one's (other is left empty)
     // Alignment objects of contig cid (in their order) in FRONT of everything the batch holds
-    void prepend(uint32_t cid, const std::vector<std::unique_ptr<Alignment>>& objs);
+    // (at_slice > 0: in front of slice `at_slice` instead — behind the one record the loader carried over from the call before)
+    void prepend(uint32_t cid, const std::vector<std::unique_ptr<Alignment>>& objs, size_t at_slice = 0);
+    size_t n_slices() const { return _slices.size(); }
     uint64_t size() const { return _n; }
     uint64_t count(uint32_t cid) const { return cid < _per_contig.size() ? _per_contig[cid] : 0; }
     bool empty() const { return _slices.empty(); }

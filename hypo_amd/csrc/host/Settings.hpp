@@ -21,6 +21,7 @@ struct InputFlags {                        // include/globalDefs.hpp:68-87
     int gpus = 1;                          // new, opt-in: --gpus N (devices 0..N-1)
     std::vector<int> devices;              // new, opt-in: --devices a,b,c
     bool native_klov = false;              // new, opt-in: --native-klov (match a -march=native build of the reference)
+    bool require_device = false;           // new, opt-in: --require-device (a stage the device should run must not quietly fall back to the host loops: error instead)
     bool host_arms = false;                // new, opt-in: --host-arms (cut the short reads into arms on the host, not on the device)
     bool ccs_windows = false;              // new, opt-in: --ccs-windows (the window sizes -k ccs was meant to select)
 };

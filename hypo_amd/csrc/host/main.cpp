@@ -28,7 +28,7 @@ const struct option long_options[] = {
     {"intermed", no_argument, nullptr, 'i'}, {"help", no_argument, nullptr, 'h'},
     {"device", required_argument, nullptr, 1000}, {"gpus", required_argument, nullptr, 1001},
     {"devices", required_argument, nullptr, 1002}, {"native-klov", no_argument, nullptr, 1003},
-    {"ccs-windows", no_argument, nullptr, 1004}, {"host-arms", no_argument, nullptr, 1005}, {nullptr, 0, nullptr, 0}};
+    {"ccs-windows", no_argument, nullptr, 1004}, {"host-arms", no_argument, nullptr, 1005}, {"require-device", no_argument, nullptr, 1006}, {nullptr, 0, nullptr, 0}};
 
 // Same layout as the reference's usage() (src/main.cpp:363-430): "Usage: hypo <args>", the mandatory block, the optional
 // block, every flag as "-x, --long <type>" followed by what it does and its default.  The wording is this build's own.
@@ -61,6 +61,7 @@ void usage() {
         {"    --native-klov", "[MI355X build] Choose the end row of prefix arms like the AVX2 / SSE4.1 alignment engine of a -march=native build of the reference does (the default follows the scalar engine of the reference's default build; the two differ on noisy prefix arms).", "off"},
         {"    --ccs-windows", "[MI355X build] Cut windows with the sizes -k ccs was meant to select (ideal length 500, search threshold 400; the reference parses -k but never applies it).", "off"},
         {"    --host-arms", "[MI355X build] Cut the short reads into arms on the host (the reference's loops) instead of on the device.", "off"},
+        {"    --require-device", "[MI355X build] Exit with an error, instead of an Info line and the host loops, when a stage the device should run (support votes, arm selection) cannot run there (also: HYPO_REQUIRE_DEVICE=1).", "off"},
         {"-h, --help", "Print the usage.", nullptr}};
     std::printf("\n Usage: hypo <args>\n\n ** Mandatory args:\n");
     for (const auto& e : mandatory) std::printf("\t%s\n\t%s\n\n", e.flag, e.what);
@@ -166,6 +167,7 @@ int main(int argc, char** argv) {
             case 1003: flags.native_klov = true; break;
             case 1004: flags.ccs_windows = true; break;
             case 1005: flags.host_arms = true; break;
+            case 1006: flags.require_device = true; break;
             case 1002: {
                 flags.devices.clear();
                 for (const char* c = optarg; *c;) { flags.devices.push_back(std::atoi(c)); while (*c && *c != ',') ++c; if (*c == ',') ++c; }

@@ -46,6 +46,10 @@
 namespace hypo {
 #ifdef HYPO_EMU_DBG
 static unsigned long g_dbg_reason[16];
+static unsigned long g_dbg_hist[64];
+#define DBGH(d) do { if (g.lane == 0) g_dbg_hist[(d) < 63 ? (d) : 63]++; } while (0)
+#else
+#define DBGH(d) do { } while (0)
 #endif
 
 enum { MODE_NW = 1, MODE_LOV = 3, MODE_ROV = 4 };
@@ -1557,8 +1561,18 @@ struct Poa {
             }
         };
         auto load_row = [&](int i, int pr, P2 (&out)[NP]) {          // matrix row pr as row i sees it
+            DBGH(i - pr);
             if (R1 > 0 && i - pr <= R1) { int ps = slot1S - (i - pr) * S; ps = ps < 0 ? ps + R1S : ps; load_pk(ring1, ps, out); }
-            else { int ps = slotS - (i - pr) * S; ps = ps < 0 ? ps + RS : ps; load_pk(ring, ps, out); }
+            else {
+                // a row from the HBM ring (rare: a predecessor further back than the LDS ring reaches).  Its wait stays INSIDE this
+                // branch: left to the point where the two paths join, the compiler waits there for "whatever memory operation may
+                // be pending" — s_waitcnt vmcnt(0) on every row, i.e. for the direction-code stores of the row before to be
+                // acknowledged by HBM (2 000 cycles a row of the LONG class in rounds 2-4, profiles/r05_long_waitcnt.txt)
+                HYPO_NO_IFCVT();
+                int ps = slotS - (i - pr) * S; ps = ps < 0 ? ps + RS : ps; load_pk(ring, ps, out);
+                HYPO_UNROLL
+                for (int q = 0; q < NP; ++q) { int b = pk_bits(out[q]); HYPO_ARRIVED(b); (void)b; }
+            }
         };
         auto hscan = [&](P2 (&v)[NP]) {
             P2 x[NP];

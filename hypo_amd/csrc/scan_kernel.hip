@@ -8,9 +8,9 @@
 //     L2-resident for k <= 13 = 8 MiB, Infinity-Cache-resident for k = 15 = 128 MiB, HBM sectors for k = 17 = 2 GiB), with the
 //     reference's two homopolymer-edge tests; four lanes put their 16 mark bits together into one output word;
 //   * the rank directory behind the reference's sdsl rank/select support (Contig.cpp:72-73) is an exclusive prefix sum of the
-//     words' popcounts: inside the tile by one wave; across tiles through a status word per tile (agent-scope atomics) — a contig
-//     of up to 16.8 Mbp (4 096 tiles, all resident at once) has every tile add up the aggregates of the tiles before it in one
-//     round trip, a longer one chains inclusive prefixes by a decoupled look-back, where tiles outnumber the resident ones;
+//     words' popcounts: inside the tile by one wave; across tiles through a status word per tile and one per group of 256 tiles
+//     (agent-scope atomics): a tile adds up the counts of its group's earlier tiles and the totals of the earlier groups — two
+//     levels of waiting, no chain, whatever the contig's length;
 //   * every marked position then re-reads its k bases from the tile's LDS copy and writes the k-mer id at its rank
 //     (Contig::_kmerinfo order, Contig.cpp:67-68).
 // Round 2 had five launches here (mark, three for the prefix sum, k-mer ids): 94 us for the 5 Mbp contig of the C2 batch, most of
@@ -28,9 +28,9 @@ constexpr int SCAN_POS_PER_BLOCK = SCAN_THREADS * SCAN_POS_PER_LANE;   // 4096 p
 constexpr int SCAN_BYTES_PER_BLOCK = SCAN_POS_PER_BLOCK / 2;            // 2048 bytes
 constexpr int SCAN_WORDS_PER_BLOCK = SCAN_POS_PER_BLOCK / 64;           // 64 output words
 constexpr int SCAN_LDS_BYTES = SCAN_BYTES_PER_BLOCK + 32;               // + 1 byte before, k+1 bases after
-constexpr uint64_t SCAN_DIRECT_TILES = 4096;                               // up to 16.8 Mbp: every tile sums its predecessors' aggregates itself
+constexpr uint64_t SCAN_GROUP = SCAN_THREADS;                              // tiles per group of the two-level prefix (one tile per lane)
 constexpr uint32_t kScanSpinLimit = 1u << 20;                               // polls of a status word (about a microsecond each) before a tile gives up
-constexpr uint64_t ST_AGGREGATE = 1ull << 62, ST_INCLUSIVE = 2ull << 62, ST_VALUE = (1ull << 62) - 1ull;   // status word of a tile
+constexpr uint64_t ST_AGGREGATE = 1ull << 62, ST_VALUE = (1ull << 62) - 1ull;   // status word of a tile
 
 // Stages the workgroup's 2 KiB of packed bases (+ one byte before, 16 after) into LDS: sb[16 + x] = packed4[blk_byte0 + x] for
 // x in [-1, 2048 + 16); out of range -> 0x44 ("NN").
@@ -112,8 +112,8 @@ scan_fused_kernel(const uint8_t* __restrict__ packed4, uint64_t n_bases, uint32_
     __shared__ uint32_t wc[SCAN_WORDS_PER_BLOCK];
     __shared__ uint64_t s_prefix;
     __shared__ uint32_t s_total;
-    __shared__ uint64_t s_part[SCAN_THREADS / 64];
-    const bool direct = n_tiles <= SCAN_DIRECT_TILES;
+    __shared__ uint64_t s_part[2 * SCAN_THREADS / 64];
+    uint64_t* const gstatus = status + n_tiles;              // totals of the groups of SCAN_GROUP tiles, behind the tiles' own status words
     const int tid = threadIdx.x, lane = tid & 63;
     // Tiles are workgroups in launch order.  A tile waits for tiles with smaller indices only, and workgroups are dispatched in
     // index order, so what it waits for is resident or done.  (A ticket from one atomic counter would make that order explicit, as
@@ -141,62 +141,44 @@ scan_fused_kernel(const uint8_t* __restrict__ packed4, uint64_t n_bases, uint32_
         wc[wl] = (uint32_t)__popcll(word);
     }
     __syncthreads();
-    // ---- ranks: inside the tile (wave 0), then the tile's exclusive prefix by look-back over the tiles before it
+    // ---- ranks: inside the tile (wave 0), then the tile's exclusive prefix over the tiles before it — without a chain.  Tiles
+    // form groups of 256.  A tile publishes its own count (depends on nothing but its marks); the LAST tile of a group adds up the
+    // group's counts and publishes the group's total; every tile then sums the counts of the tiles of its group before it (one
+    // load per lane) and the totals of the groups before its own (n_tiles / 65 536 loads per lane): two levels of waiting whatever
+    // the contig's length.  (Rounds 2-4 chained inclusive prefixes by a decoupled look-back once a contig had more than 4 096
+    // tiles: the front of published prefixes advanced 64 tiles per round trip through L2, 0.4 of the 0.68 ms of a 100 Mbp scan and
+    // 2 of the 6.4 ms of a 512 Mbp one.)  What a tile waits for was published by tiles with smaller indices, which were dispatched
+    // before it: resident or done.
     if (tid < 64) {
         const uint32_t c = wc[tid];
         uint32_t inc = c;
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
         wex[tid] = inc - c;
         const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
-        uint64_t prefix = 0;
-        if (direct) {
-            if (lane == 0) st_store(status + tile, ST_AGGREGATE | (uint64_t)total);       // (summed by the tiles behind it, below)
-        } else if (tile == 0) {
-            if (lane == 0) st_store(status, ST_INCLUSIVE | (uint64_t)total);
-        } else {
-            if (lane == 0) st_store(status + tile, ST_AGGREGATE | (uint64_t)total);
-            int64_t j = (int64_t)tile - 1;                        // lane l looks at tile j - l
-            uint32_t spins = 0;
-            for (;;) {
-                const int64_t idx = j - lane;
-                const uint64_t s = idx >= 0 ? st_load(status + idx) : ST_INCLUSIVE;       // (before tile 0: an inclusive prefix of 0)
-                const uint64_t inc_mask = __ballot((s >> 62) == 2), pend_mask = __ballot((s >> 62) == 0);
-                const int f = inc_mask ? __ffsll((unsigned long long)inc_mask) - 1 : 63;   // nearest tile with an inclusive prefix
-                const uint64_t need = f == 63 ? ~0ull : ((2ull << f) - 1ull);
-                if (pend_mask & need) {                                                  // a tile in between has not published yet
-                    if (++spins > kScanSpinLimit) { if (lane == 0) hdr[2] = 1; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
-                }
-                uint64_t v = lane <= f ? (s & ST_VALUE) : 0ull;
-                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-                prefix += v;
-                if (inc_mask) break;
-                j -= 64;
-            }
-            if (lane == 0) st_store(status + tile, ST_INCLUSIVE | (prefix + (uint64_t)total));
-        }
-        if (lane == 0) { s_prefix = prefix; s_total = total; }
+        if (lane == 0) { st_store(status + tile, ST_AGGREGATE | (uint64_t)total); s_total = total; }
     }
-    __syncthreads();
-    if (direct) {
-        // few tiles (all of them resident at once, so a chain of inclusive prefixes would be pure latency: 20 - 35 us at 5 Mbp): every
-        // tile adds up the aggregates of ALL tiles before it, each of its lanes a few independent loads — one round trip.  A tile's
-        // aggregate depends on nothing but its own marks, and tiles start in ticket order, so the wait below always ends.
-        uint64_t v = 0;
-        for (uint64_t idx = (uint64_t)tid; idx < tile; idx += SCAN_THREADS) {
+    {
+        const uint64_t grp = tile / SCAN_GROUP, g0 = grp * SCAN_GROUP;
+        auto wait_for = [&](const uint64_t* p) -> uint64_t {
             uint64_t st;
             uint32_t spins = 0;
-            while (((st = st_load(status + idx)) >> 62) == 0) {
+            while (((st = st_load(p)) >> 62) == 0) {
                 if (++spins > kScanSpinLimit) { hdr[2] = 1; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
-            v += st & ST_VALUE;
-        }
-        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-        if (lane == 0) s_part[tid >> 6] = v;
+            return st & ST_VALUE;
+        };
+        uint64_t vin = 0, vgr = 0;                            // counts of this group's tiles before this one; totals of the groups before
+        if (g0 + (uint64_t)tid < tile) vin = wait_for(status + g0 + tid);
+        for (uint64_t g = (uint64_t)tid; g < grp; g += SCAN_THREADS) vgr += wait_for(gstatus + g);
+        for (int d = 32; d >= 1; d >>= 1) { vin += __shfl_xor(vin, d, 64); vgr += __shfl_xor(vgr, d, 64); }
+        if (lane == 0) { s_part[tid >> 6] = vin; s_part[4 + (tid >> 6)] = vgr; }
         __syncthreads();
-        if (tid == 0) s_prefix = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        if (tid == 0) {
+            const uint64_t in = s_part[0] + s_part[1] + s_part[2] + s_part[3], gr = s_part[4] + s_part[5] + s_part[6] + s_part[7];
+            if (tile == g0 + SCAN_GROUP - 1) st_store(gstatus + grp, ST_AGGREGATE | (in + (uint64_t)s_total));      // the group's total
+            s_prefix = in + gr;
+        }
         __syncthreads();
     }
     const uint64_t prefix = s_prefix;
@@ -256,7 +238,7 @@ hipError_t scan_run(const uint8_t* packed4, uint64_t n_bases, uint32_t k, const 
     char* ws = (char*)workspace;
     uint64_t* hdr = (uint64_t*)ws;
     uint64_t* status = (uint64_t*)(ws + 256);
-    const size_t status_bytes = (n_tiles * 8 + 255) / 256 * 256;           // <= n_words * 4 rounded up: inside round 2's wcount area
+    const size_t status_bytes = ((n_tiles + (n_tiles + SCAN_GROUP - 1) / SCAN_GROUP) * 8 + 255) / 256 * 256;   // tiles + groups; <= n_words * 4 rounded up (a tile has 64 words): inside round 2's wcount area
     uint64_t* own_rank = (uint64_t*)(ws + 256 + (n_words * 4 + 255) / 256 * 256 + ((n_words + 1023) / 1024 * 8 + 255) / 256 * 256);
     if (!word_rank) word_rank = own_rank;
     hipError_t e;

@@ -34,4 +34,10 @@ python profiles/c4_rate.py 2>&1 | grep -v amdgpu.ids > $OUT/c4_rate.txt
 PMC_CMD="python $R/profiles/long_rate.py 200" bash profiles/run_pmc.sh ${TAG}_long > /dev/null 2>&1
 python profiles/summarize_pmc.py gpurun_out/pmc_${TAG}_long | grep "^kernel\|131072" > $OUT/pmc_long.csv
 bash profiles/kernel_registers.sh > $OUT/kernel_registers.csv 2>/dev/null
+# the scan's counters at the sizes the rate table quotes (round 5: FETCH_SIZE / TCC hit + miss / SQ_WAIT_ANY of the 100 / 250 / 512 Mbp launches)
+for spec in "100000000 13" "250000000 15" "512000000 17"; do
+  set -- $spec
+  PMC_CMD="python $R/profiles/scan_rate.py $1 $2" bash profiles/run_pmc.sh ${TAG}_scan$2 > /dev/null 2>&1
+  python profiles/summarize_pmc.py gpurun_out/pmc_${TAG}_scan$2 | grep "^kernel\|scan_fused" > $OUT/pmc_scan_k$2.csv
+done
 ls -la $OUT

@@ -72,6 +72,8 @@ def run_case(name, outdir, device, threads=4, extra_env=None, as_bam=False, extr
     env["HYPO_REGION_DUMP"] = os.path.join(str(outdir), "regions.tsv")
     if device == "shim":
         env["LD_LIBRARY_PATH"] = SHIM_DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    else:
+        env.setdefault("HYPO_REQUIRE_DEVICE", "1")      # a stage that quietly ran in the host loops fails the run (hypo --require-device)
     env.update(extra_env or {})
     p = subprocess.run(argv, cwd=str(outdir), env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
@@ -119,6 +121,8 @@ def run_messy_seed(seed, rec, outdir, device, threads=4):
     env = dict(os.environ)
     if device == "shim":
         env["LD_LIBRARY_PATH"] = SHIM_DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    else:
+        env.setdefault("HYPO_REQUIRE_DEVICE", "1")      # a stage that quietly ran in the host loops fails the run (hypo --require-device)
     p = subprocess.run(argv, cwd=str(outdir), env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
     assert ("oracle_device_shim" in p.stderr) == (device == "shim")
@@ -176,6 +180,8 @@ def run_fast_case(name, outdir, threads, extra_args=(), extra_env=None, timeout=
     env = dict(os.environ)
     if device == "shim":                             # the CPU oracle behind the C-ABI (tests/shim): the host pipeline without a GPU
         env["LD_LIBRARY_PATH"] = SHIM_DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    else:
+        env.setdefault("HYPO_REQUIRE_DEVICE", "1")      # a stage that quietly ran in the host loops fails the run (hypo --require-device)
     env.update(extra_env or {})
     before = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
     t0 = time.perf_counter()
@@ -259,13 +265,15 @@ def run_vs_reference_stage(outdir, seed, device, messy, threads=4, long_reads=Fa
     env["HYPO_REGION_DUMP"] = os.path.join(str(outdir), "regions.tsv")
     if device == "shim":
         env["LD_LIBRARY_PATH"] = SHIM_DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    else:
+        env.setdefault("HYPO_REQUIRE_DEVICE", "1")      # a stage that quietly ran in the host loops fails the run (hypo --require-device)
     p = subprocess.run(argv, cwd=str(outdir), env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert ("oracle_device_shim" in p.stderr) == (device == "shim"), "wrong device library behind the C-ABI"
     if device != "shim":
         assert "short arms cut on the device" in p.stdout          # (unsorted records too: sorted on ingest, arms in file order)
         if with_long:
-            assert "long arms cut on the device" in p.stdout or "long-read alignments are not sorted" in p.stdout
+            assert "long arms cut on the device" in p.stdout          # (unsorted -B files too since round 5: sorted on ingest, arms in file order)
     fa = open(os.path.join(str(outdir), "draft.fa")).read().split("\n")
     name, draft = fa[0][1:].split()[0], "".join(fa[1:])
     ref = oracle.RefArms()

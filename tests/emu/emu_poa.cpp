@@ -283,5 +283,6 @@ extern "C" int emu_class_bytes(int cfg_id) {
     }
 }
 #ifdef HYPO_EMU_DBG
+extern "C" void emu_dbg_hist(unsigned long* out) { for (int i = 0; i < 64; ++i) { out[i] = hypo::g_dbg_hist[i]; hypo::g_dbg_hist[i] = 0; } }
 extern "C" void emu_dbg_reasons(unsigned long* out) { for (int i = 0; i < 16; ++i) { out[i] = hypo::g_dbg_reason[i]; hypo::g_dbg_reason[i] = 0; } }
 #endif
