@@ -151,15 +151,31 @@ struct Grp {
         return (m >> gbase()) & ((1ull << (GW & 63)) - 1ull);
     }
     HD bool any(bool p) const { return ballot(p) != 0; }
+    // Reductions over the group: an inclusive DPP scan (register to register, six dependent VALU operations) whose last lane holds
+    // the result, handed to the group by v_readlane (64-lane groups) or one ds_bpermute.  (Rounds 1-4 folded with __shfl_xor:
+    // five or six ds_bpermute round trips through the LDS crossbar per reduction, ~600 cycles each time a phase asked.)
     HD int reduce_max(int v) const {
-        HYPO_UNROLL
-        for (int d = GW / 2; d >= 1; d >>= 1) { int o = __shfl_xor(v, d, GW); v = o > v ? o : v; }
-        return uniform(v);          // tells the compiler the result is wave-uniform -> scalar control flow
+        constexpr int ID = (int)0x80000000;
+        int x = v, t;
+        t = dpp_mov<0x111>(ID, x); x = t > x ? t : x;                 // row_shr:1
+        t = dpp_mov<0x112>(ID, x); x = t > x ? t : x;                 // row_shr:2
+        t = dpp_mov<0x114>(ID, x); x = t > x ? t : x;                 // row_shr:4
+        t = dpp_mov<0x118>(ID, x); x = t > x ? t : x;                 // row_shr:8
+        if (GW >= 32) { t = dpp_mov<0x142, 0xa>(ID, x); x = t > x ? t : x; }   // row_bcast:15 -> rows 1,3
+        if (GW == 64) { t = dpp_mov<0x143, 0xc>(ID, x); x = t > x ? t : x; }   // row_bcast:31 -> rows 2,3
+        if (GW == 64) return __builtin_amdgcn_readlane(x, 63);          // wave-uniform -> scalar control flow
+        return __shfl(x, GW - 1, GW);
     }
     HD int reduce_add(int v) const {
-        HYPO_UNROLL
-        for (int d = GW / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, GW);
-        return uniform(v);
+        int x = v;
+        x += dpp_mov<0x111>(0, x);
+        x += dpp_mov<0x112>(0, x);
+        x += dpp_mov<0x114>(0, x);
+        x += dpp_mov<0x118>(0, x);
+        if (GW >= 32) x += dpp_mov<0x142, 0xa>(0, x);
+        if (GW == 64) x += dpp_mov<0x143, 0xc>(0, x);
+        if (GW == 64) return __builtin_amdgcn_readlane(x, 63);
+        return __shfl(x, GW - 1, GW);
     }
     // exclusive prefix max over the group's lanes; lane 0 gets INT_MIN.  INT_MIN is max's identity, which lets
     // the compiler fold every row_shr / row_bcast move into the v_max_i32 that consumes it (one VALU op per step).

@@ -1145,8 +1145,7 @@ struct Poa {
         if (mode != MODE_LOV) {
             ns = 0;
             const int cl = (int)seq[Lu - 1];
-            for (int u = g.lane; u < n_nodes; u += GW) ns += (nout[u] == 0 && (int)code[u] == cl) ? 1 : 0;
-            ns = g.reduce_add(ns);
+            for (int u0 = 0; u0 < n_nodes; u0 += GW) { const int u = u0 + g.lane; ns += popc64(g.ballot(u < n_nodes && nout[u] == 0 && (int)code[u] == cl)); }
         }
         if (g.any(bad)) { DBGR(strong ? 6 : 7); return strong ? -1 : 0; }
         if (g.any(amb) || ns != 1) { DBGR(g.any(amb) ? 8 : 9); return 0; }
