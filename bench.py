@@ -256,6 +256,11 @@ def end_to_end_k17_leg():
                                "k = 17 against the reference: 10 x 1 Mbp draft, 30x 150-bp reads (1.99 M records as BAM), -s 3g -> k = 17 (2 GiB solid set), one run")
 
 
+def end_to_end_c5_leg():
+    return end_to_end_fast_leg("e2e_c5_250m_s207", True,
+                               "C5 slice end to end: 250 x 1 Mbp draft, 50x HiFi-like 15 kbp reads passed as the short reads (822 163 records, 3.0 GB of BAM), -s 3g -> k = 17, -c 50, -p 50, one run")
+
+
 T1_3GBP_MD5_ROUND4 = "a4b0764b66b0a285dca0f630a0bbfde9"      # profiles/r04_t1_3gbp.json: 3000 x 1 Mbp, seed 97, -s 3g, identical for -p 50 / -p 100
 
 
@@ -346,6 +351,7 @@ def main():
     ap.add_argument("--no-e2e-k15", action="store_true", help="skip the 250 Mbp / k = 15 end-to-end run (BAM input, about half a minute)")
     ap.add_argument("--no-e2e-c4", action="store_true", help="skip the C4-at-size end-to-end run (one 250 Mbp contig, short + long reads, about a minute)")
     ap.add_argument("--no-e2e-1g", action="store_true", help="skip the 1 Gbp end-to-end run (BAM input, about a minute of input generation + half a minute)")
+    ap.add_argument("--no-e2e-c5", action="store_true", help="skip the 250 Mbp C5 slice (15 kbp reads as -b, k = 17; about 40 s of input generation)")
     ap.add_argument("--no-e2e-k17", action="store_true", help="skip the 10 Mbp run at -s 3g (k = 17, the real reference's md5)")
     ap.add_argument("--t1-contigs", type=int, default=int(os.environ.get("HYPO_BENCH_T1_CONTIGS", "3000")),
                     help="also run row T1 end to end on this many 1 Mbp contigs (3000 = the north star's 3 Gbp; needs ~20 GB of /dev/shm and a few minutes)")
@@ -712,6 +718,7 @@ def main():
     e2e_t1 = None
     e2e_1g = None
     e2e_k17 = None
+    e2e_c5 = None
     if rank == 0 and world == 1 and not args.no_e2e and not strong:
         e2e = end_to_end_leg()
         if not args.no_e2e_c3:
@@ -722,6 +729,8 @@ def main():
             e2e_c4 = end_to_end_c4_leg()
         if not args.no_e2e_k17:
             e2e_k17 = end_to_end_k17_leg()                 # k = 17 (-s 3g) pinned to the real reference on 10 Mbp
+        if not args.no_e2e_c5:
+            e2e_c5 = end_to_end_c5_leg()                   # BASELINE config C5 as a workload: 15 kbp reads as -b at k = 17, 250 Mbp, the real reference's md5
         if not args.no_e2e_1g:
             e2e_1g = end_to_end_1g_leg()                   # 1 Gbp with the real reference's md5
         if args.t1_contigs > 0:
@@ -767,7 +776,7 @@ def main():
                        "contig_bases": total_bases, "k": k,
                        "parallelism": f"window sharding x{world}" + (" + RCCL all-gather of consensus" if world > 1 else "")},
             "mbp_per_s": round(total_bases * args.steps / dt / 1e6, 2),
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "e2e": e2e, "e2e_c3": e2e_c3, "e2e_k15_250m": e2e_k15, "e2e_c4_250m": e2e_c4, "e2e_k17_10m": e2e_k17, "e2e_1g": e2e_1g, "e2e_t1": e2e_t1,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "e2e": e2e, "e2e_c3": e2e_c3, "e2e_k15_250m": e2e_k15, "e2e_c4_250m": e2e_c4, "e2e_k17_10m": e2e_k17, "e2e_c5_slice": e2e_c5, "e2e_1g": e2e_1g, "e2e_t1": e2e_t1,
         }
         if imbalance:
             out["imbalance"] = imbalance

@@ -1067,6 +1067,7 @@ int hypo_gpu_reads_upload(const HypoArmsReads* A, const uint32_t* read_contig, u
 static hypo::SupportReads support_reads_of(const Ctx& c) {
     hypo::SupportReads R;
     R.n_alignments = c.rr.n; R.rb = c.rr.rb; R.re = c.rr.re; R.qae = c.rr.qae; R.seq_off = c.rr.seq_off; R.reads2 = c.rr.reads2; R.read_contig = c.rr.read_contig;
+    R.mean_span = c.rr.n ? (uint32_t)(c.rr.sum_span / c.rr.n) : 0u;
     return R;
 }
 

@@ -44,32 +44,53 @@ __device__ __forceinline__ uint32_t count_less_equal(const uint32_t* a, uint32_t
 // bases come in 16 at a time.  A block whose stretch does not fit (sparse reads) takes the same walk over global memory.  Which
 // (k-mer, read) pairs vote, and in which order within a read, is unchanged.
 namespace {
-constexpr uint32_t KCAP = 2048;                           // solid k-mers of a block's stretch held in LDS
+constexpr uint32_t KCAP = 2048;                           // solid k-mers of a block's tile held in LDS
+constexpr uint32_t kLongReadSpan = 1000;                  // mean reference span above which a block takes 64 reads instead of 256
 __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) {
     typedef uint32_t __attribute__((aligned(1))) u32u;
     return *(const u32u*)p;
 }
-// one read's walk (src/Alignment.cpp:78-132).  sp / kd: the solid k-mers [first, last) of the read's span (LDS or global);
-// vote(c): k-mer first + c is supported by the read
-// TAGS: `tags` holds the low byte of every k-mer id of the block's stretch, four to a word, entry `toff` being the read's first
-// k-mer: the ~14 candidates of a read k-mer are screened four at a time on that byte (no false negatives; a hit is verified on the
-// whole id), from the last one down, as the plain loop visits them
-template <typename KidT, bool TAGS, typename Vote>
-__device__ __forceinline__ void walk_read(const uint32_t* sp, const KidT* kd, const uint32_t* tags, uint32_t toff, uint32_t n, uint32_t rb, uint32_t re, const uint8_t* rd, uint32_t nq, uint32_t k, Vote vote) {
-    const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
-    const uint32_t num_cbases = re - rb;
+// A read's walk (src/Alignment.cpp:78-132) as a RESUMABLE state: the block keeps a tile of KCAP solid k-mers in LDS, every lane
+// walks its read as far as the tile reaches and pauses; the next tile starts at the first entry an unfinished lane still needs.
+// Reads of 150 bases see their whole stretch in one tile (round 4's kernel); reads of 15 kbp (BASELINE config C5: HiFi reads passed
+// as the short reads) walk through a few dozen tiles instead of chasing ~30 dependent loads per position through L2 — 1 111 ms of
+// the 1 570 ms of device time of the 250 Mbp C5 slice before (profiles/r05_c5_slice_before.txt).  Which (k-mer, read) pairs vote,
+// and in which order within a read, is unchanged: the state a lane carries from tile to tile is the serial loop's own.
+struct WalkState {
     uint64_t kmer = 0; uint32_t kmer_len = 0;
     int64_t pvs_supp_kpos = -1; uint32_t pvs_supp_r_bind = 0;
-    uint32_t lo = 0, hi = 0;                                  // solid k-mers [lo, hi): offset within k of the read k-mer's
+    uint32_t lo = 0, hi = 0;                                  // solid k-mers [lo, hi) of the read's [0, n): offset within k of the read k-mer's
+    uint32_t r_ind = 0;                                       // next base of the read
     uint32_t word = 0;                                        // 16 bases of the read: byte j of the word holds bases 4j .. 4j + 3, first base in the top bits
-    for (uint32_t r_ind = 0; r_ind < nq; ++r_ind) {
-        if ((r_ind & 15u) == 0) word = load_u32_unaligned(rd + (r_ind >> 2));
+};
+// sp / kd: entry c of the read's stretch is sp[c] / kd[c] for c in [lo, tile_end) (pointers offset by the caller; entries before
+// the tile are never touched: lo only grows and the tile starts at or before it); tile_end: entries [.., tile_end) are in the
+// tile, n: entries of the read.  tags: low byte of every k-mer id of the tile, four to a word, entry c of the read = tags entry
+// toff + c: the ~14 candidates of a read k-mer are screened four at a time on that byte (no false negatives; a hit is verified
+// on the whole id), from the last one down, as the plain loop visits them.  Returns true when the read is finished.
+template <typename KidT, typename Vote>
+__device__ __forceinline__ bool walk_read(WalkState& S, const uint32_t* sp, const KidT* kd, const uint32_t* tags, int32_t toff, uint32_t n, uint32_t tile_end,
+                                          uint32_t rb, uint32_t re, const uint8_t* rd, uint32_t nq, uint32_t k, Vote vote) {
+    const uint64_t kmask = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    const uint32_t num_cbases = re - rb;
+    uint64_t kmer = S.kmer; uint32_t kmer_len = S.kmer_len;
+    int64_t pvs_supp_kpos = S.pvs_supp_kpos; uint32_t pvs_supp_r_bind = S.pvs_supp_r_bind;
+    uint32_t lo = S.lo, hi = S.hi, word = S.word, r_ind = S.r_ind;
+    bool done = true;
+    for (; r_ind < nq; ++r_ind) {
+        if (r_ind + 1 >= k) {
+            // the window of this position first: when it reaches the end of the tile with entries of the read left, the position
+            // waits for the next tile (nothing of it has happened yet)
+            const uint32_t r_bind = r_ind + 1 - k;
+            while (hi < tile_end && (int64_t)sp[hi] - (int64_t)rb <= (int64_t)r_bind + (int64_t)k) ++hi;
+            if (hi == tile_end && hi < n) { done = false; break; }
+        }
+        if ((r_ind & 15u) == 0 || r_ind == S.r_ind) word = load_u32_unaligned(rd + ((r_ind >> 4) << 2));
         const uint32_t b = (word >> (8 * ((r_ind >> 2) & 3u) + 6 - 2 * (r_ind & 3u))) & 3u;
         kmer = ((kmer << 2) | b) & kmask;
         if (kmer_len < k) ++kmer_len;
         if (kmer_len != k) continue;
         const uint32_t r_bind = r_ind + 1 - k;
-        while (hi < n && (int64_t)sp[hi] - (int64_t)rb <= (int64_t)r_bind + (int64_t)k) ++hi;
         while (lo < hi && (int64_t)sp[lo] - (int64_t)rb + (int64_t)k < (int64_t)r_bind) ++lo;
         auto candidate = [&](uint32_t c) {
             if ((uint64_t)kd[c] != kmer) return;
@@ -87,10 +108,8 @@ __device__ __forceinline__ void walk_read(const uint32_t* sp, const KidT* kd, co
                 vote(c);
             }
         };
-        if (!TAGS) {
-            for (uint32_t c = hi; c-- > lo;) candidate(c);
-        } else if (hi > lo) {
-            const uint32_t A = toff + lo, B = toff + hi;      // entries [A, B) of the block's stretch
+        if (hi > lo) {
+            const uint32_t A = (uint32_t)(toff + (int32_t)lo), B = (uint32_t)(toff + (int32_t)hi);      // entries [A, B) of the tile
             const uint32_t want = ((uint32_t)kmer & 0xffu) * 0x01010101u;
             for (uint32_t wi = (B - 1) >> 2;; --wi) {
                 const uint32_t x = tags[wi] ^ want;
@@ -99,27 +118,35 @@ __device__ __forceinline__ void walk_read(const uint32_t* sp, const KidT* kd, co
                     const uint32_t j = (31u - (uint32_t)__clz(m)) >> 3;       // highest flagged byte first
                     m &= ~(0x80u << (8 * j));
                     const uint32_t e = 4 * wi + j;
-                    if (e >= A && e < B) candidate(e - toff);
+                    if (e >= A && e < B) candidate((uint32_t)((int32_t)e - toff));
                 }
                 if (wi == (A >> 2)) break;
             }
         }
     }
+    S.kmer = kmer; S.kmer_len = kmer_len; S.pvs_supp_kpos = pvs_supp_kpos; S.pvs_supp_r_bind = pvs_supp_r_bind;
+    S.lo = lo; S.hi = hi; S.word = word; S.r_ind = r_ind;
+    return done;
 }
 }  // namespace
 
-template <typename KidT>
-__global__ void __launch_bounds__(T) support_kmers_kernel(SupportReads R, uint32_t k, uint32_t n_solid, const uint32_t* __restrict__ spos,
-                                                          const KidT* __restrict__ kids, uint32_t* __restrict__ cov, uint32_t* __restrict__ sup) {
+// TT lanes = TT reads per block: 256 for reads of a few hundred bases (their stretches overlap almost entirely), 64 for long reads
+// (the lanes of a block are then in the same tile most of the time)
+template <typename KidT, int TT>
+__global__ void __launch_bounds__(TT) support_kmers_kernel(SupportReads R, uint32_t k, uint32_t n_solid, const uint32_t* __restrict__ spos,
+                                                           const KidT* __restrict__ kids, uint32_t* __restrict__ cov, uint32_t* __restrict__ sup) {
+    // (64 long reads per block walk serially for milliseconds: what hides their LDS latency is other blocks on the CU, so their tile
+    // is a quarter of the short reads' — 10.5 KB instead of 42 KB of LDS per block, 15 blocks per CU instead of 3)
+    constexpr uint32_t KCAP = TT >= 256 ? hypo::KCAP : hypo::KCAP / 4;
     __shared__ uint32_t s_sp[KCAP];
     __shared__ KidT s_kd[KCAP];
     __shared__ int s_cov[KCAP + 1];                           // difference array of the coverage
     __shared__ uint32_t s_sup[KCAP];
     __shared__ uint32_t s_tag[KCAP / 4];                      // low byte of every id, entry i in byte i % 4 of word i / 4
-    __shared__ int s_part[T];
-    __shared__ uint32_t s_lo, s_hi;
+    __shared__ int s_part[TT];
+    __shared__ uint32_t s_lo, s_hi, s_next;
     const uint32_t tid = threadIdx.x;
-    const uint32_t a = blockIdx.x * T + tid;
+    const uint32_t a = blockIdx.x * TT + tid;
     bool active = a < R.n_alignments;
     uint32_t rb = 0, re = 0, first = 0, last = 0;
     if (active) {
@@ -136,48 +163,61 @@ __global__ void __launch_bounds__(T) support_kmers_kernel(SupportReads R, uint32
     __syncthreads();
     const uint32_t blo = s_lo, bhi = s_hi;
     if (blo >= bhi) return;                                   // (block-uniform: no read of the block sees a solid k-mer)
-    const uint32_t span = bhi - blo;
-    const bool in_lds = span <= KCAP;
-    if (in_lds) {
-        for (uint32_t i = tid; i < span; i += T) { s_sp[i] = spos[blo + i]; s_kd[i] = kids[blo + i]; s_cov[i] = 0; s_sup[i] = 0u; }
-        if (tid == 0) s_cov[span] = 0;
+    const uint32_t n = active ? last - first : 0u;
+    const uint8_t* rd = active ? R.reads2 + R.seq_off[a] : nullptr;
+    const uint32_t nq = active ? R.qae[a] : 0u;
+    WalkState S;
+    bool walking = active;                                    // the read has positions left
+    uint32_t g0 = blo;                                        // the tile: entries [g0, g0 + tn) of the tables
+    for (;;) {
+        const uint32_t tn = bhi - g0 < KCAP ? bhi - g0 : KCAP;
+        for (uint32_t i = tid; i < tn; i += TT) { s_sp[i] = spos[g0 + i]; s_kd[i] = kids[g0 + i]; s_sup[i] = 0u; }
+        if (tid == 0) s_next = 0xffffffffu;
         __syncthreads();
-        for (uint32_t w = tid; w < (span + 3) / 4; w += T) {
+        for (uint32_t w = tid; w < (tn + 3) / 4; w += TT) {
             uint32_t v = 0;
-            for (uint32_t j = 0; j < 4 && 4 * w + j < span; ++j) v |= ((uint32_t)s_kd[4 * w + j] & 0xffu) << (8 * j);
+            for (uint32_t j = 0; j < 4 && 4 * w + j < tn; ++j) v |= ((uint32_t)s_kd[4 * w + j] & 0xffu) << (8 * j);
             s_tag[w] = v;
         }
         __syncthreads();
-    }
-    if (active) {
-        const uint32_t n = last - first;
-        const uint8_t* rd = R.reads2 + R.seq_off[a];
-        const uint32_t nq = R.qae[a];
-        if (in_lds) {
-            const uint32_t off = first - blo;
-            atomicAdd(&s_cov[off], 1); atomicAdd(&s_cov[off + n], -1);
-            walk_read<KidT, true>(s_sp + off, s_kd + off, s_tag, off, n, rb, re, rd, nq, k, [&](uint32_t c) { atomicAdd(&s_sup[off + c], 1u); });
-        } else {
-            for (uint32_t t = 0; t < n; ++t) atomicAdd(&cov[first + t], 1u);
-            walk_read<KidT, false>(spos + first, kids + first, nullptr, 0u, n, rb, re, rd, nq, k, [&](uint32_t c) { atomicAdd(&sup[first + c], 1u); });
+        if (walking && first + S.lo < g0 + tn) {              // (a read whose first entry lies behind the tile waits)
+            const int32_t off = (int32_t)(first - g0);       // entry c of the read = entry off + c of the tile (negative once the read began in an earlier tile)
+            const uint32_t tile_end = g0 + tn - first < n ? g0 + tn - first : n;
+            const bool done = walk_read<KidT>(S, s_sp + off, s_kd + off, s_tag, off, n, tile_end, rb, re, rd, nq, k, [&](uint32_t c) { atomicAdd(&s_sup[off + (int32_t)c], 1u); });
+            if (done) walking = false;
         }
-    }
-    if (!in_lds) return;
-    __syncthreads();
-    // coverage = prefix sums of the difference array: every thread owns a run of consecutive entries
-    const uint32_t per = (span + T - 1) / T;
-    const uint32_t i0 = tid * per, i1 = i0 + per < span ? i0 + per : span;
-    int sum = 0;
-    for (uint32_t i = i0; i < i1; ++i) sum += s_cov[i];
-    s_part[tid] = sum;
-    __syncthreads();
-    int run = 0;
-    for (uint32_t t = 0; t < tid; ++t) run += s_part[t];
-    for (uint32_t i = i0; i < i1; ++i) {
-        run += s_cov[i];
-        if (run) atomicAdd(&cov[blo + i], (uint32_t)run);
-        const uint32_t v = s_sup[i];
-        if (v) atomicAdd(&sup[blo + i], v);
+        if (walking) atomicMin(&s_next, first + S.lo);
+        __syncthreads();
+        // what the tile collected goes out; the coverage of the entries no later tile comes back to: [g0, next tile's start)
+        for (uint32_t i = tid; i < tn; i += TT) { const uint32_t v = s_sup[i]; if (v) atomicAdd(&sup[g0 + i], v); }
+        const uint32_t g1 = s_next == 0xffffffffu ? bhi : s_next;     // (>= g0: cursors only grow; > g0 unless a lane paused without moving, which a tile of KCAP entries excludes)
+        for (uint32_t c0 = g0; c0 < g1; c0 += KCAP) {
+            const uint32_t c1 = g1 - c0 < KCAP ? g1 : c0 + KCAP, cn = c1 - c0;
+            __syncthreads();
+            for (uint32_t i = tid; i <= cn; i += TT) s_cov[i] = 0;
+            __syncthreads();
+            if (active) {
+                const uint32_t x0 = first < c0 ? c0 : first, x1 = last > c1 ? c1 : last;
+                if (x0 < x1) { atomicAdd(&s_cov[x0 - c0], 1); atomicAdd(&s_cov[x1 - c0], -1); }
+            }
+            __syncthreads();
+            // coverage = prefix sums of the difference array: every thread owns a run of consecutive entries
+            const uint32_t per = (cn + TT - 1) / TT;
+            const uint32_t i0 = tid * per < cn ? tid * per : cn, i1 = i0 + per < cn ? i0 + per : cn;
+            int sum = 0;
+            for (uint32_t i = i0; i < i1; ++i) sum += s_cov[i];
+            s_part[tid] = sum;
+            __syncthreads();
+            int run = 0;
+            for (uint32_t t = 0; t < tid; ++t) run += s_part[t];
+            for (uint32_t i = i0; i < i1; ++i) {
+                run += s_cov[i];
+                if (run) atomicAdd(&cov[c0 + i], (uint32_t)run);
+            }
+        }
+        if (g1 >= bhi) break;
+        g0 = g1;
+        __syncthreads();
     }
 }
 
@@ -193,32 +233,35 @@ __global__ void __launch_bounds__(T) support_kmers_kernel(SupportReads R, uint32
 // of a block are neighbours, so their runs are one short stretch of the table: like the k-mer kernel above, the block keeps that
 // stretch (positions, k-mers) and its counters in LDS.  C3 batch of 2 M reads: 10.1 -> see profiles (the largest kernel of that run).
 namespace {
-constexpr uint32_t MCAP = 1024;                           // minimizers of a block's stretch held in LDS
-// one read's votes (src/Alignment.cpp:134-220) over entries [E0, E1): P[e - pbase] = position, Q[e - pbase] = k-mer of entry e
-template <typename Cover, typename Vote>
-__device__ __forceinline__ void walk_minimizers(const uint32_t* P, const uint32_t* Q, uint32_t pbase, uint32_t E0, uint32_t E1, uint32_t rb, uint32_t re,
-                                                const uint8_t* rd, uint32_t nq, Cover cover, Vote vote) {
+constexpr uint32_t MCAP = 1024;                           // minimizers of a block's tile held in LDS
+// One read's votes (src/Alignment.cpp:134-220) as a resumable walk over a tile of the table, like WalkState above: P[e], Q[e] =
+// position and k-mer of entry e for e in [tile start, tile_end) (pointers offset by the caller).  The read's own window minimizers
+// are produced in order and matched against the contig minimizers whose range [c_dist - 2K, c_dist + 3K] holds them; a position
+// is only begun when the tile reaches beyond everything it can look at.
+struct MinState {
+    uint32_t key[10];
+    uint32_t kmer = 0, processed = 0, last_found = 0, lo = 0, i = 0, word = 0;
+};
+template <typename Vote>
+__device__ __forceinline__ bool walk_minimizers(MinState& S, const uint32_t* P, const uint32_t* Q, uint32_t tile_end, uint32_t E1, uint32_t rb, uint32_t re,
+                                                const uint8_t* rd, uint32_t nq, Vote vote) {
     constexpr uint32_t K = 10, W = 10;                       // Minimizer_settings (include/globalDefs.hpp:128-139)
-    // the read's minimizers cover the mega-window minimizers lying inside its span (:189-203): coverage first.  (`break` of the
-    // reference's inner loop: a minimizer at or behind the read's end ends its window; the windows behind it start behind the read's
-    // end too.)  Entries in front of the read were skipped by the caller.
-    uint32_t Ec = E0;
-    while (Ec < E1 && P[Ec - pbase] < re) ++Ec;
-    if (Ec == E0) return;
-    cover(E0, Ec);
-    // the read's own window minimizers, in order, against the contig minimizers whose range [c_dist - 2K, c_dist + 3K] holds them
     const uint32_t mask = (1u << (2 * K)) - 1u;
     const uint16_t num_cbases = (uint16_t)(re - rb);          // 16-bit in the reference (:188)
+    // positions the tile suffices for: an entry is looked at while its c_dist <= start + 2K <= i + 2K, so position i may begin
+    // when the tile's last entry lies behind that (or the tile ends the read's entries)
+    const uint32_t i_limit = tile_end >= E1 ? nq : (P[tile_end - 1] - rb > 2 * K ? P[tile_end - 1] - rb - 2 * K : 0u);
+    uint32_t kmer = S.kmer, processed = S.processed, last_found = S.last_found, lo = S.lo, word = S.word, i = S.i;
     uint32_t key[W];
 #pragma unroll
-    for (uint32_t j = 0; j < W; ++j) key[j] = 0xffffffffu;
-    uint32_t kmer = 0, processed = 0, last_found = nq + 1;
-    uint32_t lo = E0;                                         // first contig minimizer that can still match
-    uint32_t word = 0;                                        // 16 bases of the read at a time
-    for (uint32_t i = 0; i < nq; ++i) {                       // (a 2-bit read has no N: every position from K - 1 on pushes a k-mer)
+    for (uint32_t j = 0; j < W; ++j) key[j] = S.key[j];
+    const uint32_t i0 = i;
+    bool done = true;
+    for (; i < nq; ++i) {                                     // (a 2-bit read has no N: every position from K - 1 on pushes a k-mer)
+        if (i >= i_limit) { done = false; break; }
 #pragma unroll
         for (int j = W - 1; j >= 1; --j) key[j] = key[j - 1];
-        if ((i & 15u) == 0) word = load_u32_unaligned(rd + (i >> 2));
+        if ((i & 15u) == 0 || i == i0) word = load_u32_unaligned(rd + ((i >> 4) << 2));
         kmer = ((kmer << 2) | ((word >> (8 * ((i >> 2) & 3u) + 6 - 2 * (i & 3u))) & 3u)) & mask;
         key[0] = i + 1 >= K ? kmer : 0xffffffffu;
         if (i + 1 < K) continue;
@@ -230,31 +273,37 @@ __device__ __forceinline__ void walk_minimizers(const uint32_t* P, const uint32_
         if (start == last_found) continue;
         last_found = start;
         // contig minimizers with c_dist + 3K < start can never match again (start only grows)
-        while (lo < E1 && (uint64_t)(P[lo - pbase] - rb) + 3 * K < start) ++lo;
-        if (lo >= E1) break;
-        for (uint32_t e = lo; e < E1; ++e) {
-            const uint32_t p = P[e - pbase];
+        while (lo < tile_end && (uint64_t)(P[lo] - rb) + 3 * K < start) ++lo;
+        if (lo >= E1) { i = nq; break; }
+        for (uint32_t e = lo; e < tile_end; ++e) {
+            const uint32_t p = P[e];
             if (p >= re) break;
             const uint32_t c_dist = p - rb;
             if (c_dist > start + 2 * K) break;                // its range starts behind `start`: so do all later ones
             const uint32_t range_left = c_dist > 2 * K ? c_dist - 2 * K : 0u;
             const uint16_t rr16 = (uint16_t)(c_dist + 3 * K);
             const uint32_t range_right = num_cbases < rr16 ? num_cbases : rr16;
-            if (Q[e - pbase] == best && start >= range_left && start <= range_right) vote(e);
+            if (Q[e] == best && start >= range_left && start <= range_right) vote(e);
         }
     }
+    S.kmer = kmer; S.processed = processed; S.last_found = last_found; S.lo = lo; S.word = word; S.i = i;
+#pragma unroll
+    for (uint32_t j = 0; j < W; ++j) S.key[j] = key[j];
+    return done;
 }
 }  // namespace
 
-__global__ void __launch_bounds__(T) support_minimizers_kernel(SupportReads R, MegaWindows M, uint32_t* __restrict__ cov, uint32_t* __restrict__ sup) {
+template <int TT>
+__global__ void __launch_bounds__(TT) support_minimizers_kernel(SupportReads R, MegaWindows M, uint32_t* __restrict__ cov, uint32_t* __restrict__ sup) {
+    constexpr uint32_t MCAP = TT >= 256 ? hypo::MCAP : hypo::MCAP / 4;      // (long reads: small tiles, many blocks per CU; see support_kmers_kernel)
     __shared__ uint32_t s_pos[MCAP], s_min[MCAP], s_sup[MCAP];
     __shared__ int s_cov[MCAP + 1];                           // difference array of the coverage
-    __shared__ int s_part[T];
-    __shared__ uint32_t s_lo, s_hi;
+    __shared__ int s_part[TT];
+    __shared__ uint32_t s_lo, s_hi, s_next;
     const uint32_t tid = threadIdx.x;
-    const uint32_t a = blockIdx.x * T + tid;
+    const uint32_t a = blockIdx.x * TT + tid;
     bool active = a < R.n_alignments;
-    uint32_t rb = 0, re = 0, E0 = 0, E1 = 0;
+    uint32_t rb = 0, re = 0, E0 = 0, E1 = 0, Ec = 0;
     if (active) {
         const uint32_t c = R.read_contig[a];
         const uint32_t base = M.contig_base[c];
@@ -277,6 +326,13 @@ __global__ void __launch_bounds__(T) support_minimizers_kernel(SupportReads R, M
             while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (M.rel_pos[m] < rb) lo = m + 1; else hi = m; }
             E0 = lo; E1 = M.mw_off[x1 + 1];
             active = E0 < E1;
+            // the read covers the mega-window minimizers lying inside its span (:189-203): entries [E0, Ec), positions ascending.
+            // (`break` of the reference's inner loop: a minimizer at or behind the read's end ends its window; the windows behind it
+            // start behind the read's end too.)
+            uint32_t l2 = E0, h2 = E1;
+            while (l2 < h2) { const uint32_t m = (l2 + h2) >> 1; if (M.rel_pos[m] < re) l2 = m + 1; else h2 = m; }
+            Ec = l2;
+            if (Ec == E0) active = false;                     // (nothing covered: the reference returns before it looks at the read)
         }
     }
     if (tid == 0) { s_lo = 0xffffffffu; s_hi = 0u; }
@@ -285,51 +341,69 @@ __global__ void __launch_bounds__(T) support_minimizers_kernel(SupportReads R, M
     __syncthreads();
     const uint32_t blo = s_lo, bhi = s_hi;
     if (blo >= bhi) return;                                   // (block-uniform)
-    const uint32_t span = bhi - blo;
-    const bool in_lds = span <= MCAP;
-    if (in_lds) {
-        for (uint32_t i = tid; i < span; i += T) { s_pos[i] = M.rel_pos[blo + i]; s_min[i] = M.minimisers[blo + i]; s_cov[i] = 0; s_sup[i] = 0u; }
-        if (tid == 0) s_cov[span] = 0;
+    const uint8_t* rd = active ? R.reads2 + R.seq_off[a] : nullptr;
+    const uint32_t nq = active ? R.qae[a] : 0u;
+    MinState S;
+#pragma unroll
+    for (uint32_t j = 0; j < 10; ++j) S.key[j] = 0xffffffffu;
+    S.last_found = nq + 1; S.lo = E0;
+    bool walking = active;
+    uint32_t g0 = blo;
+    for (;;) {
+        const uint32_t tn = bhi - g0 < MCAP ? bhi - g0 : MCAP;
+        for (uint32_t i = tid; i < tn; i += TT) { s_pos[i] = M.rel_pos[g0 + i]; s_min[i] = M.minimisers[g0 + i]; s_sup[i] = 0u; }
+        if (tid == 0) s_next = 0xffffffffu;
         __syncthreads();
-    }
-    if (active) {
-        const uint8_t* rd = R.reads2 + R.seq_off[a];
-        const uint32_t nq = R.qae[a];
-        if (in_lds)
-            walk_minimizers(s_pos, s_min, blo, E0, E1, rb, re, rd, nq,
-                            [&](uint32_t e0, uint32_t e1) { atomicAdd(&s_cov[e0 - blo], 1); atomicAdd(&s_cov[e1 - blo], -1); },
-                            [&](uint32_t e) { atomicAdd(&s_sup[e - blo], 1u); });
-        else
-            walk_minimizers(M.rel_pos, M.minimisers, 0u, E0, E1, rb, re, rd, nq,
-                            [&](uint32_t e0, uint32_t e1) { for (uint32_t e = e0; e < e1; ++e) atomicAdd(&cov[e], 1u); },
-                            [&](uint32_t e) { atomicAdd(&sup[e], 1u); });
-    }
-    if (!in_lds) return;
-    __syncthreads();
-    const uint32_t per = (span + T - 1) / T;
-    const uint32_t i0 = tid * per < span ? tid * per : span, i1 = i0 + per < span ? i0 + per : span;
-    int sum = 0;
-    for (uint32_t i = i0; i < i1; ++i) sum += s_cov[i];
-    s_part[tid] = sum;
-    __syncthreads();
-    int run = 0;
-    for (uint32_t t = 0; t < tid; ++t) run += s_part[t];
-    for (uint32_t i = i0; i < i1; ++i) {
-        run += s_cov[i];
-        if (run) atomicAdd(&cov[blo + i], (uint32_t)run);
-        const uint32_t v = s_sup[i];
-        if (v) atomicAdd(&sup[blo + i], v);
+        if (walking && S.lo < g0 + tn) {
+            const uint32_t tile_end = g0 + tn < E1 ? g0 + tn : E1;
+            // (pointers shifted so that absolute entry numbers index the tile; entries before g0 are never touched: S.lo >= g0)
+            const bool done = walk_minimizers(S, s_pos - g0, s_min - g0, tile_end, E1, rb, re, rd, nq, [&](uint32_t e) { atomicAdd(&s_sup[e - g0], 1u); });
+            if (done) walking = false;
+        }
+        if (walking) atomicMin(&s_next, S.lo);
+        __syncthreads();
+        for (uint32_t i = tid; i < tn; i += TT) { const uint32_t v = s_sup[i]; if (v) atomicAdd(&sup[g0 + i], v); }
+        uint32_t g1 = s_next == 0xffffffffu ? bhi : s_next;
+        if (g1 <= g0) g1 = g0 + 1 < bhi ? g0 + 1 : bhi;       // (cannot happen: a tile of >= 256 entries spans more than the 5K bases a position looks at)
+        for (uint32_t c0 = g0; c0 < g1; c0 += MCAP) {
+            const uint32_t c1 = g1 - c0 < MCAP ? g1 : c0 + MCAP, cn = c1 - c0;
+            __syncthreads();
+            for (uint32_t i = tid; i <= cn; i += TT) s_cov[i] = 0;
+            __syncthreads();
+            if (active) {
+                const uint32_t x0 = E0 < c0 ? c0 : E0, x1 = Ec > c1 ? c1 : Ec;
+                if (x0 < x1) { atomicAdd(&s_cov[x0 - c0], 1); atomicAdd(&s_cov[x1 - c0], -1); }
+            }
+            __syncthreads();
+            const uint32_t per = (cn + TT - 1) / TT;
+            const uint32_t i0 = tid * per < cn ? tid * per : cn, i1 = i0 + per < cn ? i0 + per : cn;
+            int sum = 0;
+            for (uint32_t i = i0; i < i1; ++i) sum += s_cov[i];
+            s_part[tid] = sum;
+            __syncthreads();
+            int run = 0;
+            for (uint32_t t = 0; t < tid; ++t) run += s_part[t];
+            for (uint32_t i = i0; i < i1; ++i) {
+                run += s_cov[i];
+                if (run) atomicAdd(&cov[c0 + i], (uint32_t)run);
+            }
+        }
+        if (g1 >= bhi) break;
+        g0 = g1;
+        __syncthreads();
     }
 }
 
 hipError_t support_kmers(const SupportReads& R, uint32_t k, uint32_t n_solid, const uint32_t* spos, const uint64_t* kids, uint32_t* cov, uint32_t* sup, hipStream_t st) {
     if (!R.n_alignments || !n_solid) return hipSuccess;
-    hipLaunchKernelGGL(support_kmers_kernel<uint64_t>, dim3((R.n_alignments + T - 1) / T), dim3(T), 0, st, R, k, n_solid, spos, kids, cov, sup);
+    if (R.mean_span > kLongReadSpan) hipLaunchKernelGGL((support_kmers_kernel<uint64_t, 64>), dim3((R.n_alignments + 63) / 64), dim3(64), 0, st, R, k, n_solid, spos, kids, cov, sup);
+    else hipLaunchKernelGGL((support_kmers_kernel<uint64_t, T>), dim3((R.n_alignments + T - 1) / T), dim3(T), 0, st, R, k, n_solid, spos, kids, cov, sup);
     return hipGetLastError();
 }
 hipError_t support_kmers32(const SupportReads& R, uint32_t k, uint32_t n_solid, const uint32_t* spos, const uint32_t* kids32, uint32_t* cov, uint32_t* sup, hipStream_t st) {
     if (!R.n_alignments || !n_solid) return hipSuccess;
-    hipLaunchKernelGGL(support_kmers_kernel<uint32_t>, dim3((R.n_alignments + T - 1) / T), dim3(T), 0, st, R, k, n_solid, spos, kids32, cov, sup);
+    if (R.mean_span > kLongReadSpan) hipLaunchKernelGGL((support_kmers_kernel<uint32_t, 64>), dim3((R.n_alignments + 63) / 64), dim3(64), 0, st, R, k, n_solid, spos, kids32, cov, sup);
+    else hipLaunchKernelGGL((support_kmers_kernel<uint32_t, T>), dim3((R.n_alignments + T - 1) / T), dim3(T), 0, st, R, k, n_solid, spos, kids32, cov, sup);
     return hipGetLastError();
 }
 // out[i] = in[i] + base: the contig-local positions a resident scan kept, moved into the batch's coordinate space
@@ -358,7 +432,8 @@ __global__ void __launch_bounds__(T) minimizer_positions_kernel(MegaWindows M, u
 hipError_t support_minimizers(const SupportReads& R, const MegaWindows& M, uint32_t n_contigs, uint32_t n_info, uint32_t* cov, uint32_t* sup, hipStream_t st) {
     if (!R.n_alignments || !n_info || !n_contigs) return hipSuccess;
     hipLaunchKernelGGL(minimizer_positions_kernel, dim3((n_info + T - 1) / T), dim3(T), 0, st, M, n_contigs, n_info);
-    hipLaunchKernelGGL(support_minimizers_kernel, dim3((R.n_alignments + T - 1) / T), dim3(T), 0, st, R, M, cov, sup);
+    if (R.mean_span > kLongReadSpan) hipLaunchKernelGGL(support_minimizers_kernel<64>, dim3((R.n_alignments + 63) / 64), dim3(64), 0, st, R, M, cov, sup);
+    else hipLaunchKernelGGL(support_minimizers_kernel<T>, dim3((R.n_alignments + T - 1) / T), dim3(T), 0, st, R, M, cov, sup);
     return hipGetLastError();
 }
 

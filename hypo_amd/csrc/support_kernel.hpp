@@ -13,6 +13,7 @@ struct SupportReads {                // the resident short reads of a contig bat
     const uint64_t* seq_off;         // byte offset of the aligned query (PackedSeq<2>) in reads2
     const uint8_t* reads2;
     const uint32_t* read_contig;     // contig of the batch the read maps to
+    uint32_t mean_span;              // mean reference span of the reads (block shapes of the vote kernels)
 };
 
 struct MegaWindows {                 // Contig::_reg_pos / _is_win_even / _minimserinfo after prepare_for_division, all contigs of the batch
