@@ -25,31 +25,20 @@ typedef PoaCfg<16, 4, 47, 48, 4, 2208, 384, 384, 64, int16_t, uint8_t> PoaClass0
 // the windows per wave but half the partners a group waits for when the windows of a wave differ.  poa_run picks one of the
 // two per call: four groups when the batch is tiny windows almost only (dense short reads: 56 vs 46 M windows/s), two groups
 // otherwise (C2: 3.89 vs 4.08 ms).
-#ifndef HYPO_C0W_GW
 #define HYPO_C0W_GW 32
-#endif
 // Class 1 runs ONE window per wave (64 lanes x 2 columns) since round 3: with two 32-lane groups per wave (x 4 columns, the
 // geometry of rounds 1-2: -DHYPO_C1_GW=32 -DHYPO_C1_CPL=4) a window cost 345 k wave-cycles against 472 k for a class-2 window with
 // four times the rows — the two windows of a wave wait for each other at every step and their group-uniform values are vector
 // registers.  A window of its own per wave: class 1 alone 1.73 -> 1.33 ms on the C2 batch in 3/4 of the LDS, C2 call 2.90 -> 2.56
 // ms, 1 % read error 11.3 -> 10.2 ms, dense short reads 59.6 -> 76 M windows/s (profiles/diag/r03_wave_wide_*.sh).
-#ifndef HYPO_C1_GW
 #define HYPO_C1_GW 64
 #define HYPO_C1_CPL 2
-#endif
 typedef PoaCfg<HYPO_C0W_GW, 2, 47, 48, 4, 2208, 384, 384, 64, int16_t, uint8_t> PoaClass0W;
 typedef PoaCfg<HYPO_C1_GW, HYPO_C1_CPL, 79, 84, 4, 6720, 640, 640, 64, int16_t, uint8_t> PoaClass1;     // (640 staged arm bytes: two groups + their stat blocks fill 32 LDS granules of 512 B exactly; copies of a neighbour take none)
-#ifndef HYPO_C2_GW
 #define HYPO_C2_GW 64
 #define HYPO_C2_CPL 2
-#endif
-#ifndef HYPO_C2_ARMBYTES
 #define HYPO_C2_ARMBYTES 1024
-#endif
-#ifndef HYPO_C2_DIRG
-#define HYPO_C2_DIRG 0
-#endif
-typedef PoaCfg<HYPO_C2_GW, HYPO_C2_CPL, 127, 126, 6, 13440, 1024, HYPO_C2_ARMBYTES, 127, int16_t, uint8_t, 0, false, (HYPO_C2_DIRG != 0)> PoaClass2;
+typedef PoaCfg<HYPO_C2_GW, HYPO_C2_CPL, 127, 126, 6, 13440, 1024, HYPO_C2_ARMBYTES, 127, int16_t, uint8_t> PoaClass2;      // (direction codes in LDS: in HBM scratch like class 3's it was measured slower, round 3)
 // class 3 keeps its direction codes (up to 254 x 256 cells) in HBM scratch (Cfg::DIRG): 16 KB of LDS per window instead of 40
 typedef PoaCfg<64, 4, 255, 254, 7, 65536, 2048, 1024, 192, int16_t, uint8_t, 0, false, true> PoaClass3;
 typedef PoaCfg<64, 10, 639, 2400, 12, 1536000, 491520, 16384, 256, int16_t, uint16_t, 1 << 18, true> PoaClass4;          // + 256 K path ids: runs LONG windows

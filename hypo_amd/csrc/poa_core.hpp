@@ -105,20 +105,9 @@ struct PoaParamRef {
 #define HYPO_EXACT 1
 #endif
 // ... also in the class of wide windows (class 3: along the guide only, see Poa::align)
-#ifndef HYPO_EXACT_WIDE
 #define HYPO_EXACT_WIDE 1
-#endif
 // int16 score rows as packed pairs of columns (Poa::rows_pk); HYPO_PACKED=0 builds the one-column-per-register loop everywhere
-#ifndef HYPO_PACKED
 #define HYPO_PACKED 1
-#endif
-// experiments (register pressure): parts of the carry-over that can be compiled out
-#ifndef HYPO_CARRY_RESTORE
-#define HYPO_CARRY_RESTORE 1
-#endif
-#ifndef HYPO_CARRY_SPILL
-#define HYPO_CARRY_SPILL 1
-#endif
 template <int GW_, int CPL_, int LCAP_, int NMAX_, int KIN_, int DIRCELLS_, int RINGCELLS_, int ARMBYTES_,
           int SEQMAX_, class ScoreT, class IdT, int PATHCAP_ = 0, bool HYBRID_ = false, bool DIRG_ = false>
 struct PoaCfg {
@@ -131,9 +120,7 @@ struct PoaCfg {
     static constexpr bool HYBRID = HYBRID_;     // state in HBM scratch except the arrays the graph walks hammer (PoaLayout::FAST_BYTES of LDS)
     // ... and the hybrid class runs its int16 rows on packed pairs as well (Poa::rows_pk_hyb: the dense ring, byte codes, any
     // in-degree); HYPO_PACKED_HYB=0 keeps the one-column-per-register loop there
-#ifndef HYPO_PACKED_HYB
 #define HYPO_PACKED_HYB 1
-#endif
     static constexpr bool PACKED_HYB = HYPO_PACKED_HYB && HYBRID_ && sizeof(ScoreT) == 2 && CPL_ % 2 == 0 && PATHCAP_ > 0;
     static constexpr int PATHCAP = PATHCAP_;    // node ids of the sequences' paths (LONG windows only; 0 = class cannot run them)
     static constexpr int GW = GW_;              // lanes per window
@@ -146,18 +133,12 @@ struct PoaCfg {
     static constexpr int ARMBYTES = ARMBYTES_;  // packed arm bytes staged per window
     static constexpr int SEQMAX = SEQMAX_;      // sequences (arms + backbone) per window
     static constexpr int AL = 6;                // aligned clique partners (alphabet ACGTNJO -> at most 6)
-#ifndef HYPO_HYB_STK
 #define HYPO_HYB_STK 1536
-#endif
     static constexpr int STK = HYBRID_ ? HYPO_HYB_STK : 2 * NMAX_;   // DFS stack entries (hybrid: the LDS copy is smaller; deeper DFS -> next class)
-    #ifndef HYPO_RING1
 #define HYPO_RING1 6
-#endif
 // LONG windows in the hybrid class: the rank order is kept valid incrementally and the literal DFS order of the reference is
 // computed only where it can be observed (Poa::lazy_update); 0: literal sort after every alignment that changed the graph
-#ifndef HYPO_LAZY_TOPO
 #define HYPO_LAZY_TOPO 1
-#endif
     static constexpr int RING1 = HYBRID_ ? HYPO_RING1 : 0;
     static constexpr bool LAZY = HYBRID_ && (HYPO_LAZY_TOPO != 0) && PATHCAP_ > 0;  // hybrid: this many most recent score rows are also kept in LDS
     // direction codes: 4 bits when the pred index fits (diag p = p, vert p = 7+p, horiz = 14, fast = 15)
@@ -510,9 +491,7 @@ struct Poa {
     // are), the stores.  What differs from the passes above is invisible to the alignment: once an arm does not fit `armbuf` no
     // later arm is staged either (the serial pass skipped it and went on), and the hash is a different function.
     static constexpr int STAGE_NB = (Cfg::LMAX + 3) / 4, STAGE_NDW = (STAGE_NB + 3) / 4;
-#ifndef HYPO_STAGE_FUSED
 #define HYPO_STAGE_FUSED 1
-#endif
     static constexpr bool STAGE_FUSED = HYPO_STAGE_FUSED && PK && STAGE_NDW <= 8;
     HD static uint32_t load_u32(const uint8_t* p) {
 #ifdef HYPO_EMU
@@ -681,11 +660,7 @@ struct Poa {
             const bool sink = nout[u] == 0;
             const bool slow = !(k == 1 && p0 == r) || sink;
             const uint32_t c = code[u];
-#ifdef HYPO_DBG_SAVEALL
-            rowmeta[r] = c | META_SLOW | META_SAVE | (sink ? META_SINK : 0u) | ((PK && nout[u] == 1) ? META_OUT1 : 0u) | ((uint32_t)k << 8) | (PK ? (c << 16) : 0u) | ((uint32_t)p0 << P0_SHIFT);
-#else
             rowmeta[r] = c | (slow ? META_SLOW : 0u) | (sink ? META_SINK : 0u) | ((PK && nout[u] == 1) ? META_OUT1 : 0u) | ((uint32_t)k << 8) | (PK ? (c << 16) : 0u) | ((uint32_t)p0 << P0_SHIFT);
-#endif
         }
         meta_dirty = false;
         if (PK) {
@@ -1372,9 +1347,7 @@ struct Poa {
     // a step at a time, so a block of direction codes around the cell in hand, with the node and the metadata of its rows, is
     // fetched in one go (two rows per lane, 16-byte loads) into the LDS the recent score rows occupy
     // during the row loop (idle here), and the steps read LDS until the walk leaves the block.  Same moves, same result.
-#ifndef HYPO_TB_TILE
 #define HYPO_TB_TILE 1
-#endif
     HD int traceback_tiled(int mode, int best_i, int S) {
         // 128 rows x 48 columns: a LONG window's graph has ~2.6 rows per column (1 300 nodes for 500 bases), so the walk leaves a
         // block of that shape through its top and its left edge at about the same time (~5 blocks per alignment)
@@ -1713,9 +1686,7 @@ struct Poa {
     // columns (Poa::hyb_pairs; the row stride is a multiple of the lane's columns, Poa::align).  Scores, codes and their places
     // in memory do not depend on the split.
     static constexpr int HYB_NP_MAX = Cfg::CPL / 2;
-#ifndef HYPO_HYB_ADAPT
 #define HYPO_HYB_ADAPT 1
-#endif
     HD static constexpr int hyb_pairs(int W) {             // register pairs per lane for rows of W columns
         return !HYPO_HYB_ADAPT ? HYB_NP_MAX : (W <= 2 * GW * 2 && HYB_NP_MAX >= 2 ? 2 : (W <= 3 * GW * 2 && HYB_NP_MAX >= 3 ? 3 : (W <= 4 * GW * 2 && HYB_NP_MAX >= 4 ? 4 : HYB_NP_MAX)));
     }
@@ -1832,9 +1803,7 @@ struct Poa {
         // ... and, in the classes that tabulate pred rows in HBM scratch, the matrix row of pred 1 of the same 64 rows: nearly every
         // row with several predecessors has two, and looking the second one up inside the loop was an HBM load whose wait also
         // drained the rows' outstanding stores
-#ifndef HYPO_P1_CHUNK
 #define HYPO_P1_CHUNK 1
-#endif
         constexpr bool P1_CHUNKED = (HYPO_P1_CHUNK != 0) && META_CHUNKED && PRED_TABLE && KIN >= 2;
         int p1chunk = 0;
         uint32_t meta_a = (META_IN_REGS || META_CHUNKED) ? 0u : rowmeta[0];
@@ -2897,7 +2866,7 @@ struct Poa {
         bool prev_aligned = false;                           // the previous non-reused sequence went through align()
         int s = 0;
         int chain0_in = 0;
-        if (HYPO_CARRY_RESTORE && carry_in) {                                      // the graph another class built from sequences [0, s): continue from there
+        if (carry_in) {                                      // the graph another class built from sequences [0, s): continue from there
             if ((rc = restore(carry_in, &s, &chain0_in)) != RES_OK) return rc;
             if (s > n_seq) return RES_INVALID;
             if (topo_dirty) { if ((rc = toposort()) != RES_OK) return rc; HYPO_DIAG(topo_runs += 1); HYPO_TICK(PH_TOPO); }

@@ -44,9 +44,7 @@ __device__ __forceinline__ uint32_t plan_key_from(const HypoWindow& W, uint32_t 
     // arms of equal length, about two per new node).  The kernel re-queues a window that outgrows its class all the same.
     uint32_t maxlen = (W.n_internal == 0 || W.type != HYPO_WIN_SHORT) ? W.draft_len + 2 : 0;
     if (narm) maxlen = maxarm + 2 > maxlen ? maxarm + 2 : maxlen;
-#ifndef HYPO_PLAN_GROW_Q
 #define HYPO_PLAN_GROW_Q 2            // expected new nodes per differing byte, in quarters
-#endif
     const uint32_t slack = maxlen / 16 + 3, grow = changes * HYPO_PLAN_GROW_Q / 4 + 3;
     const uint32_t est_nodes = maxlen + (grow > slack ? grow : slack);
     const ClassLimits lim[kNumPoaClasses] = {
@@ -204,13 +202,9 @@ struct PoaPrefetch {
     __device__ __forceinline__ uint32_t item(uint32_t idx) const { const PoaKArgPtr k = ka(); return k->Q.items[(size_t)k->cls * k->Q.stride + idx]; }
     __device__ __forceinline__ uint32_t carry(uint32_t w) const { return ka()->Q.carry[w]; }
 };
-#ifndef HYPO_PREFETCH_NEXT
 #define HYPO_PREFETCH_NEXT 1
-#endif
 
-#ifndef HYPO_C4_WAVES
 #define HYPO_C4_WAVES 2
-#endif
 template <class Cfg> struct PoaMinWaves { static constexpr int value = Cfg::HYBRID ? HYPO_C4_WAVES : 1; };
 // POLL: the kernel runs NEXT to the classes that feed it and takes re-queued windows as they arrive: it leaves when every lane
 // group of every launch of the lower classes has exited (Q.done) and the queue is drained.  Every launch it waits for is
@@ -300,7 +294,7 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
             // what the window takes along: the graph of the sequences it has been through (Poa::spill) when the step that failed
             // left one, else the spill it came with
             uint32_t cv = 0;
-            if (HYPO_CARRY_SPILL && rc == RES_OVERFLOW && stt[PoaT::ST_CKIND] != PoaT::CARRY_NONE) {
+            if (rc == RES_OVERFLOW && stt[PoaT::ST_CKIND] != PoaT::CARRY_NONE) {
                 const uint32_t sz16 = poa.spill_size() >> 4;
                 // (the cursor saturates: a request that does not fit leaves it where it is, so that it cannot wrap around after 2^32
                 // units of failed requests and hand out memory that still holds another window's spill)
@@ -574,7 +568,6 @@ static size_t poa_workspace_prefix(uint32_t n_windows) {       // header, class 
     b += ((size_t)n_windows * 4 + 255) / 256 * 256;
     b += poa_spill_bytes(n_windows);
     b += (size_t)groups3_for(n_windows) * PoaLayout<PoaClass3>::DIRG_BYTES;
-    b += (size_t)groups3_for(n_windows) * PoaLayout<PoaClass2>::DIRG_BYTES;      // (0 unless HYPO_C2_DIRG)
     return b;
 }
 
@@ -690,8 +683,6 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     Q.work = (uint64_t*)(ws + 7936);
     const ClassScratch scr3{ws + off, groups3_for(n_windows)};
     off += (size_t)scr3.groups * PoaLayout<PoaClass3>::DIRG_BYTES;
-    const ClassScratch scr2{PoaClass2::DIRG ? ws + off : nullptr, PoaClass2::DIRG ? groups3_for(n_windows) : 0};
-    off += (size_t)scr2.groups * PoaLayout<PoaClass2>::DIRG_BYTES;
     char* scratch = ws + off;
     const ClassScratch scr4{scratch, groups4}, scr5{scratch, groups5}, scr_lds{nullptr, 0};
     hipError_t e = hipMemsetAsync(ws, 0, kPoaHeaderBytes, stream);
@@ -795,7 +786,7 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
 #define HYPO_LAUNCH(ID, CFG)                                                                              \
         rec(2 + 2 * ID, stream);                                                                          \
         if ((e = launch_class<CFG, (ID < kFirstGlobalClass)>(P, Q, ID, ID >= 3 ? rare_grid_hint(ID) : n_windows,                   \
-                                                             (ID == 3 ? scr3 : (ID == 4 ? scr4 : (ID == 5 ? scr5 : (ID == 2 ? scr2 : scr_lds)))), num_cus, stream)) != hipSuccess) return e; \
+                                                             (ID == 3 ? scr3 : (ID == 4 ? scr4 : (ID == 5 ? scr5 : scr_lds))), num_cus, stream)) != hipSuccess) return e; \
         rec(3 + 2 * ID, stream);
         HYPO_FOR_EACH_CLASS(HYPO_LAUNCH)
 #undef HYPO_LAUNCH
@@ -841,7 +832,7 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
         uint32_t producers = 0;                              // lane groups of every launch of classes 0 - 2 (what class 3's polling pass waits for)
         auto first2 = [&]() -> hipError_t {
             rec(2 + 2 * 2, stream);
-            hipError_t r = launch_class<PoaClass2, true>(P, Q, 2, n_windows, scr2, num_cus, stream, caps[2], false, &producers);
+            hipError_t r = launch_class<PoaClass2, true>(P, Q, 2, n_windows, scr_lds, num_cus, stream, caps[2], false, &producers);
             rec(3 + 2 * 2, stream);
             return r;
         };

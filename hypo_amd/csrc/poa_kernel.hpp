@@ -10,9 +10,7 @@ constexpr int kFirstLongClass = 4;       // LONG windows (<= 500 bp, ~1.3 k node
 constexpr int kRequeueClass = 3;         // where a SHORT window goes that outgrows classes 0 - 2 (the class that polls its queue)
 // resident groups of the HBM-scratch classes (one wavefront each; the scratch is provisioned for this many).  The LONG class
 // is register-bound at 2 waves per SIMD: 8 per CU x 256 CUs; the last class is a rare safety net.
-#ifndef HYPO_C4_GROUPS
 #define HYPO_C4_GROUPS 2048
-#endif
 constexpr int kMaxGlobalGroups4 = HYPO_C4_GROUPS;
 constexpr int kMaxGlobalGroups5 = 32;
 inline int max_global_groups(int cls, uint32_t n_windows) {
