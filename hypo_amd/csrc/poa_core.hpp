@@ -139,8 +139,14 @@ struct PoaCfg {
 // LONG windows in the hybrid class: the rank order is kept valid incrementally and the literal DFS order of the reference is
 // computed only where it can be observed (Poa::lazy_update); 0: literal sort after every alignment that changed the graph
 #define HYPO_LAZY_TOPO 1
+// ... and SHORT windows of the packed classes as well (round 5): HYPO_LAZY_PACKED
+#define HYPO_LAZY_PACKED 1
     static constexpr int RING1 = HYBRID_ ? HYPO_RING1 : 0;
-    static constexpr bool LAZY = HYBRID_ && (HYPO_LAZY_TOPO != 0) && PATHCAP_ > 0;  // hybrid: this many most recent score rows are also kept in LDS
+    // class 3 (wide windows, and every window re-queued from classes 0-2: the ones whose graphs keep changing): the lazy order's scratch
+    // lives in the score ring (idle between row loops).  Classes 0-2 sort literally: their windows see one to three sorts, and carrying the
+    // tie bookkeeping through their row loops cost 5-9 % at 0.2 % read error (measured, profiles/diag/r05_sched_experiments.txt)
+    static constexpr bool LAZY_RING = HYPO_LAZY_PACKED && PACKED && DIRG_;
+    static constexpr bool LAZY = (HYBRID_ && (HYPO_LAZY_TOPO != 0) && PATHCAP_ > 0) || LAZY_RING;  // hybrid: this many most recent score rows are also kept in LDS
     // direction codes: 4 bits when the pred index fits (diag p = p, vert p = 7+p, horiz = 14, fast = 15)
     static constexpr bool NIB = (KIN_ <= 7) && (CPL_ % 2 == 0);
     static constexpr int DIRBYTES = NIB ? DIRCELLS_ / 2 : DIRCELLS_;
@@ -205,8 +211,8 @@ struct PoaLayout {   // byte offsets inside a group's memory slice
     // lazy rank order (Cfg::LAZY): a second rank -> node array (the update writes the new order beside the old one; the literal
     // order of an end-row tie goes there as well), a second node -> rank array for the latter, and the new nodes of the
     // alignment in hand with the rank they are inserted behind
-    static constexpr int LAZYN = Cfg::LAZY ? Cfg::NMAX : 0;
-    static constexpr int LAZYL = Cfg::LAZY ? Cfg::LMAX + 1 : 0;
+    static constexpr int LAZYN = (Cfg::LAZY && !Cfg::LAZY_RING) ? Cfg::NMAX : 0;
+    static constexpr int LAZYL = (Cfg::LAZY && !Cfg::LAZY_RING) ? Cfg::LMAX + 1 : 0;
     static constexpr int oR2nAlt = oPredRows + align_up<16>(LONGN * Cfg::KIN * (int)sizeof(id_t));
     static constexpr int oN2rAlt = oR2nAlt + align_up<16>(LAZYN * (int)sizeof(id_t));
     static constexpr int oNewId = oN2rAlt + align_up<16>(LAZYN * (int)sizeof(id_t));
@@ -307,7 +313,7 @@ struct Poa {
     //                          the window in hand and the part of its algorithmic bytes the descriptor gives
     enum { ST_CELLS = 0, ST_ALIGNS, ST_REUSED, ST_XHITS, ST_CSCORED, ST_CEXACT, ST_XT, ST_XH, ST_NEED, ST_CKIND, ST_CS, ST_CCHAIN0, ST_CPASS, ST_ARMB, ST_OLEN, ST_N,
            ST_LASTX = ST_CPASS,   // while a window runs: did its latest alignment thread?  (ST_CPASS is written after the window's last step only)
-           ST_MAXD = ST_N, ST_LSRC,   // of the rank order in hand (Poa::build_rowmeta): ring rows the furthest predecessor needs; last rank without in-edges
+           ST_MAXD = ST_N, ST_NSORT,  // ST_MAXD: of the rank order in hand (Poa::build_rowmeta), ring rows the furthest predecessor needs; ST_NSORT: literal sorts of the window in hand
            ACC_CELLS, ACC_ALIGNS, ACC_ABYTES, ACC_REUSED, ACC_THR, ACC_CSCORED, ACC_CTHR, ACC_NOK, ACC_NESC, ACC_NFAIL, ACC_NCARRIED, ACC_END,
            NX_W0 = ACC_END, NX_OFF = NX_W0 + 10, NX_WIDX = NX_OFF + 4, NX_CARRY, CUR_STATIC, CUR_OFF, NX_END = CUR_OFF + 4 };
     static constexpr uint32_t NX_NONE = 0xffffffffu;         // NX_WIDX: the queue is drained
@@ -349,6 +355,13 @@ struct Poa {
         msa = (uint16_t*)(mem + Lay::oMsa); dstcnt = (uint32_t*)(mem + Lay::oDst); consbuf = (uint8_t*)(mem + Lay::oCons);
         predrows = (id_t*)(mem + Lay::oPredRows);
         r2n_alt = (id_t*)(mem + Lay::oR2nAlt); n2r_alt = (id_t*)(mem + Lay::oN2rAlt); newid = (id_t*)(mem + Lay::oNewId); newslot = (int16_t*)(mem + Lay::oNewSlot);
+        if constexpr (Cfg::LAZY_RING) {
+            // score ring, between row loops: [shift table of lazy_update / DFS stack of a literal sort | r2n_alt | n2r_alt | newid | newslot]
+            constexpr int oA = align_up<2>((NMAX + 1) * 2 > Cfg::STK * (int)sizeof(id_t) ? (NMAX + 1) * 2 : Cfg::STK * (int)sizeof(id_t));
+            constexpr int oB = oA + NMAX * (int)sizeof(id_t), oC = oB + NMAX * (int)sizeof(id_t), oD = align_up<2>(oC + (Cfg::LMAX + 1) * (int)sizeof(id_t));
+            static_assert(oD + (Cfg::LMAX + 1) * 2 <= (int)sizeof(score_t) * Cfg::RINGCELLS, "the lazy order's scratch fits the score ring");
+            r2n_alt = (id_t*)(mem + Lay::oRing + oA); n2r_alt = (id_t*)(mem + Lay::oRing + oB); newid = (id_t*)(mem + Lay::oRing + oC); newslot = (int16_t*)(mem + Lay::oRing + oD);
+        }
         lazy_on = false; n_new = 0; guide_len = -1; guide_mode = 0;
         stat = (uint32_t*)(HYB ? fast + Lay::fStat : mem + Lay::oStat);
         for (int t = g.lane; t < Lay::STAT_BYTES / 4; t += GW) stat[t] = 0;
@@ -753,7 +766,8 @@ struct Poa {
     // Two bodies per row.  FAST (kNW, one predecessor = the previous row, not a sink, not read from the ring later: ~95 % of
     // the rows): everything the row needs is in registers or a constant, the only memory operation is the store of its
     // direction codes.  SLOW: any predecessors (ring reads located through sidx[]), end-cell bookkeeping, ring save.
-    HD int rows_pk(int mode, int m, int n, int gp, int S, int R) {
+    static constexpr int PK_TIECAP = 47;                    // rows remembered as tied for the end row (lazy rank order); count and list live in posnode[] during the row loop: tie[0] = count, tie[1 ..] = rows
+    HD int rows_pk(int mode, int m, int n, int gp, int S, int R, int* ntie_out) {
         constexpr int NP = CPL / 2;
         const int j0 = CPL * g.lane;
         int amax = m < 0 ? -m : m; { const int b = n < 0 ? -n : n, c2 = gp < 0 ? -gp : gp; amax = amax > b ? amax : b; amax = amax > c2 ? amax : c2; }
@@ -784,6 +798,11 @@ struct Poa {
         const int le = L / CPL, ce = L % CPL;               // owner of the last column
         const int ce_shift = 16 * (ce & 1);
         int best = NEG, best_i = -1;
+        int16_t* const tie = posnode;                        // (the guide has been tried by now; the traceback writes posnode[] after the ties are settled)
+        const bool ties = Cfg::LAZY && lazy_on;
+        static_assert((PK_TIECAP + 1) * 2 <= Lay::POS_BYTES, "the tie list fits posnode");
+        if (ties && g.lane == 0) tie[0] = 0;
+        g.sync();
         // native kLOV flavour: a row's end value is its maximum over columns 1..L (every lane then holds the same value)
         const bool native_lov = mode == MODE_LOV && (P->flags & POA_NATIVE_KLOV) != 0;
         auto end_value = [&](const P2 (&v)[NP]) -> int {
@@ -881,6 +900,10 @@ struct Poa {
                 if (lov) {                                   // end cell: first strictly greater in rank order; only lane `le` counts
                     HYPO_NO_IFCVT();
                     const int val = end_value(v);
+                    if (ties && g.lane == le) {              // lazy rank order: rows that tie for the end row are remembered
+                        if (val > best) { tie[0] = 1; tie[1] = (int16_t)i; }
+                        else if (val == best) { const int nt = tie[0]; if (nt < PK_TIECAP) tie[1 + nt] = (int16_t)i; tie[0] = (int16_t)(nt + 1); }
+                    }
                     best_i = val > best ? i : best_i;
                     best = val > best ? val : best;
                 }
@@ -976,11 +999,17 @@ struct Poa {
             // end cell: first strictly greater in rank order (sisd..cpp:279-288,332-339)
             if (mode == MODE_LOV || meta_sink(meta)) {
                 const int val = end_value(v);                // (all lanes keep score; lane `le` is the one that is read)
+                if (ties && g.lane == le) {
+                    if (val > best) { tie[0] = 1; tie[1] = (int16_t)i; }
+                    else if (val == best) { const int nt = tie[0]; if (nt < PK_TIECAP) tie[1 + nt] = (int16_t)i; tie[0] = (int16_t)(nt + 1); }
+                }
                 best_i = val > best ? i : best_i;
                 best = val > best ? val : best;
             }
             g.sync();
         }
+        g.sync();
+        *ntie_out = ties ? (int)tie[0] : 0;
         return g.shfl(best_i, le);
     }
 
@@ -1136,10 +1165,11 @@ struct Poa {
             vl = g.shfl(vl, (Lu - 1) & (GW - 1)) & 0xffff;
             uint8_t* const flag = (uint8_t*)ring;
             static_assert((int)sizeof(score_t) * Cfg::RINGCELLS >= NMAX, "a byte per node fits the ring");
-            const int rv = (int)n2r[vl], cl = (int)seq[Lu - 1];
+            const int rv = Cfg::LAZY ? 0 : (int)n2r[vl], cl = (int)seq[Lu - 1];
             bool in[XRPL];
             HYPO_UNROLL
-            for (int q = 0; q < XRPL; ++q) { const int u = q * GW + g.lane; in[q] = u < n_nodes && (int)code[u] == cl && (int)n2r[u] < rv; }
+            // (every OTHER node that carries the letter, whatever its rank: under the lazy rank order n2r[] is not the reference's)
+            for (int q = 0; q < XRPL; ++q) { const int u = q * GW + g.lane; in[q] = u < n_nodes && (int)code[u] == cl && (Cfg::LAZY ? u != vl : (int)n2r[u] < rv); }
             for (int j = Lu; ; --j) {                        // in[]: nodes whose cell in column j may be perfect
                 bool some = false, src = false;
                 HYPO_UNROLL
@@ -1287,7 +1317,24 @@ struct Poa {
             for (int t = 0; t < XW; ++t) F.w[t] &= SNK.w[t];
             if (!x_any(F)) return 0;
         }
-        const int e = x_first(F);
+        int e = x_first(F);
+        if constexpr (Cfg::LAZY) {
+            // several perfect end rows under the lazy rank order: the first in the REFERENCE's order (a literal sort into the ring)
+            int cnt = 0;
+            HYPO_UNROLL
+            for (int t = 0; t < XW; ++t) cnt += popc64(F.w[t]);
+            if (lazy_on && cnt > 1) {
+                HYPO_NO_IFCVT();
+                if (literal_order() != RES_OK) return 0;
+                int key = 0x7fffffff;
+                HYPO_UNROLL
+                for (int q = 0; q < XRPL; ++q) {
+                    const int r = q * GW + g.lane;
+                    if (r < n_nodes && x_in(F, r)) { const int k2 = ((int)n2r_alt[r2n[r]] << 8) | r; key = k2 < key ? k2 : key; }
+                }
+                e = (-g.reduce_max(-key)) & 255;
+            }
+        }
         // the rank of every column: the end row, a column's only perfect cell, or (-1) to be settled from the right
         int rk[XSL];
         HYPO_UNROLL
@@ -1752,7 +1799,17 @@ struct Poa {
                 HYPO_DIAG(exact_tries += 1; guided_hits += weights_done ? 1u : 0u);
                 if (hit) { threaded = true; return RES_OK; }
             } else stat_set(ST_LASTX, 0u);
-            { best_i = rows_pk(mode, m, n, gp, S, R); stat_add(ST_CSCORED, (uint32_t)((n_nodes + 1) * W)); HYPO_DIAG(rows_scored_n += (uint32_t)n_nodes); }
+            int ntie_pk = 0;
+            { best_i = rows_pk(mode, m, n, gp, S, R, &ntie_pk); stat_add(ST_CSCORED, (uint32_t)((n_nodes + 1) * W)); HYPO_DIAG(rows_scored_n += (uint32_t)n_nodes); }
+            if constexpr (Cfg::LAZY) {
+                if (lazy_on && ntie_pk > 1) {
+                    // several rows share the best end value: the reference takes the first of them in ITS rank order
+                    if (ntie_pk > PK_TIECAP) return RES_OVERFLOW;         // (the class that takes the window over sorts first)
+                    g.sync();
+                    const int rc = first_of_rows(posnode + 1, ntie_pk, &best_i);
+                    if (rc != RES_OK) return rc;
+                }
+            }
         } else {
         stat_add(ST_CSCORED, (uint32_t)((n_nodes + 1) * W));
         int ntie = 0;                                        // lazy rank order: rows tied for the end row (in newslot[], dead until add_alignment)
@@ -2231,7 +2288,7 @@ struct Poa {
     // (newslot[i] = rank they go behind, -1 = in front), so new rank of new node i = slot + 1 + i and an old rank r moves up
     // by the number of new nodes with slot < r: a running maximum over `cum` (kept where the recent score rows live, dead here).
     HD void lazy_update(int n_old) {
-        static_assert(!Cfg::LAZY || (Cfg::RING1 * Lay::SMAX * (int)sizeof(score_t)) / 2 >= NMAX + 1, "the shift table fits the LDS row ring");
+        static_assert(!Cfg::LAZY || Cfg::LAZY_RING || (Cfg::RING1 * Lay::SMAX * (int)sizeof(score_t)) / 2 >= NMAX + 1, "the shift table fits the LDS row ring");
         int16_t* cum = (int16_t*)ring1;
         const int k = n_new;
         for (int r = g.lane; r <= n_old; r += GW) cum[r] = 0;
@@ -2259,8 +2316,36 @@ struct Poa {
             const int nr = (int)newslot[i] + 1 + i;
             r2n_alt[nr] = (id_t)u; n2r[u] = (id_t)nr;
         }
-        id_t* t = r2n; r2n = r2n_alt; r2n_alt = t;
+        if constexpr (Cfg::LAZY_RING) {                      // (the new order was written into the score ring: back into the window's own array)
+            g.sync();
+            for (int r = g.lane; r < n_old + k; r += GW) r2n[r] = r2n_alt[r];
+        } else { id_t* t = r2n; r2n = r2n_alt; r2n_alt = t; }
         g.sync();
+    }
+    // The reference's own rank order where it can be observed in the middle of a window (a tied end row, several perfect end
+    // rows): a literal sort into the spare arrays (packed classes: in the score ring, idle outside the row loop); n2r_alt[node] is
+    // the node's rank in the reference's order afterwards.  The sort marks nodes in mark[], which the packed row loop reads as
+    // sidx[]: the row metadata are rebuilt before the next row loop.
+    HD int literal_order() {
+        id_t* const sr = r2n; id_t* const sn = n2r;
+        const bool td = topo_dirty;
+        r2n = r2n_alt; n2r = n2r_alt;
+        const int rc = toposort();
+        r2n = sr; n2r = sn; topo_dirty = td;
+        if (PK) meta_dirty = true;
+        HYPO_DIAG(topo_runs += 1);
+        return rc;
+    }
+    // of the matrix rows tie[0 .. ntie): the one the reference's order ranks first
+    HD int first_of_rows(const int16_t* tie, int ntie, int* row_out) {
+        const int rc = literal_order();
+        if (rc != RES_OK) return rc;
+        int key = 0x7fffffff;
+        for (int t = g.lane; t < ntie; t += GW) { const int k2 = ((int)n2r_alt[r2n[(int)tie[t] - 1]] << 8) | t; key = k2 < key ? k2 : key; }
+        const int kmin = -g.reduce_max(-key);
+        *row_out = (int)tie[kmin & 255];
+        g.sync();
+        return RES_OK;
     }
 
     // ---- exact reuse of the previous alignment -------------------------------------------------------
@@ -2429,6 +2514,15 @@ struct Poa {
         if constexpr (PK) { guide_len = L; guide_mode = mode; }       // posnode[] = the node of every position (the sort below leaves it alone: its stack is in the ring)
         if (topo_dirty) {
             rc = toposort(); HYPO_DIAG(topo_runs += 1); HYPO_TICK(PH_TOPO);
+            if constexpr (Cfg::LAZY_RING) {
+                // A window whose graph keeps changing goes over to the lazy rank order (Poa::lazy_update) after its second literal sort:
+                // the literal order it has by now is a valid one with the cliques as blocks, which is all the lazy order asks for.  One
+                // or two sorts are cheaper than the updates plus the literal sort the consensus then needs (C2 at 0.2 % read error:
+                // lazy from the first sequence on cost 1.90 -> 2.20 ms per call; from 3 % on it gains 25 %).
+                if (g.lane == 0) stat[ST_NSORT] += 1;
+                g.sync();
+                if (stat[ST_NSORT] >= 2u && !(P->flags & POA_NATIVE_KLOV)) lazy_on = true;
+            }
             if (rc == RES_OVERFLOW) stat_set(ST_CKIND, CARRY_UNSORTED);                                 // (the DFS stack: the graph itself is complete)
         }
         return rc;
@@ -2452,7 +2546,8 @@ struct Poa {
         uint16_t* h = (uint16_t*)out;
         if (g.lane == 0) {
             h[0] = (uint16_t)CARRY_MAGIC; h[1] = (uint16_t)n; h[2] = (uint16_t)stat[ST_CS]; h[3] = (uint16_t)stat[ST_CCHAIN0];
-            h[4] = (uint16_t)(stat[ST_CKIND] | (KIN << 8)); h[5] = (uint16_t)stat[ST_XT]; h[6] = (uint16_t)stat[ST_XH]; h[7] = 0;
+            // (bit 7 of the kind: r2n / n2r are A valid order kept lazily, not the reference's — a class that needs the latter sorts first)
+            h[4] = (uint16_t)(stat[ST_CKIND] | ((Cfg::LAZY && lazy_on) ? 0x80u : 0u) | (KIN << 8)); h[5] = (uint16_t)stat[ST_XT]; h[6] = (uint16_t)stat[ST_XH]; h[7] = 0;
             // the reference-equivalent work of the sequences behind the cursor is accounted by whoever finishes the window
             uint32_t* c = (uint32_t*)(out + 16);
             c[0] = stat[ST_CELLS]; c[1] = stat[ST_ALIGNS]; c[2] = stat[ST_REUSED]; c[3] = stat[ST_XHITS];
@@ -2476,7 +2571,8 @@ struct Poa {
     HD int restore(const uint8_t* in, int* s_out, int* chain0_out) {
         const uint16_t* h = (const uint16_t*)in;
         if (h[0] != (uint16_t)CARRY_MAGIC) return RES_INVALID;
-        const int n = h[1], kin = h[4] >> 8, kind = h[4] & 0xff;
+        const int n = h[1], kin = h[4] >> 8, kind = h[4] & 0x7f;
+        const bool lazy_order = (h[4] & 0x80) != 0;
         if (n > NMAX || n < 1) return RES_OVERFLOW;
         const uint8_t* b = in + 32;
         bool over = false;
@@ -2510,7 +2606,8 @@ struct Poa {
             const uint32_t* c = (const uint32_t*)(in + 16);
             stat[ST_CELLS] = c[0]; stat[ST_ALIGNS] = c[1]; stat[ST_REUSED] = c[2]; stat[ST_XHITS] = c[3];
         }
-        topo_dirty = kind == CARRY_UNSORTED; meta_dirty = true; last_changed = true;
+        if (lazy_order && Cfg::LAZY_RING && !(P->flags & POA_NATIVE_KLOV)) lazy_on = true;      // (a window that went lazy stays lazy in the class that takes it over)
+        topo_dirty = kind == CARRY_UNSORTED || (lazy_order && !(Cfg::LAZY && lazy_on)); meta_dirty = true; last_changed = true;
         g.sync();
         return RES_OK;
     }
@@ -2859,7 +2956,8 @@ struct Poa {
         // SHORT windows that ended up in the hybrid class (wide windows of --ccs-windows, large graphs) keep their rank order
         // lazily as well: kLOV's end row (first row in rank order among equal maxima of the last column) goes through the same
         // list of tied rows as the sinks of kNW / kROV.  Not with the native kLOV flavour, whose end row is ranked differently.
-        lazy_on = Cfg::LAZY && !(P->flags & POA_NATIVE_KLOV);
+        lazy_on = Cfg::LAZY && !Cfg::LAZY_RING && !(P->flags & POA_NATIVE_KLOV);      // (packed classes: after the window's second literal sort, Poa::add_sequence_step)
+        stat_set(ST_NSORT, 0u);
         int n_seq = 0; bool added = false;
         int rc = build_seqtab(W, false, &n_seq, &added);
         if (rc != RES_OK) return rc;
@@ -2870,6 +2968,8 @@ struct Poa {
             if ((rc = restore(carry_in, &s, &chain0_in)) != RES_OK) return rc;
             if (s > n_seq) return RES_INVALID;
             if (topo_dirty) { if ((rc = toposort()) != RES_OK) return rc; HYPO_DIAG(topo_runs += 1); HYPO_TICK(PH_TOPO); }
+            // (a window that outgrew another class keeps changing: it goes lazy at once)
+            if constexpr (Cfg::LAZY_RING) { if (!(P->flags & POA_NATIVE_KLOV)) lazy_on = true; }
         }
         // A window that outgrows this class's node table says how many nodes it will probably need, so that it is re-queued
         // straight into a class that holds it instead of climbing one class at a time: the sequences added so far grew the
