@@ -220,7 +220,7 @@ def end_to_end_fast_leg(name, bam, what):
         return {"mbp_per_s": round(G / 1e6 / overall, 2), "seconds": round(overall, 3), "process_wall_seconds": round(wall, 3),
                 "peak_rss_mb": rss, "gpu_busy_percent_mean": busy, "host_threads": threads,
                 "windows": nwin, "poa_seconds_total": round(sum(poa), 3), "contig_batches": len(poa),
-                "input_generation_seconds": round(tg, 1), "alignment_file": "BAM (BGZF, inflated in parallel)" if bam else "SAM text",
+                "input_generation_seconds": round(tg, 1), "alignment_file": ("BAM (BGZF, inflated in parallel by " + (re.search(r"BGZF blocks are inflated by (\w+)", out).group(1) if re.search(r"BGZF blocks are inflated by (\w+)", out) else "?") + ")") if bam else "SAM text",
                 "reference": {"seconds": man["reference_run"]["overall_seconds"], "threads": man["reference_run"]["threads"],
                               "peak_rss_mb": man["reference_run"]["peak_rss_mb"], "where": man["reference_run"]["host"] + " (not this box)"},
                 "workload": what,

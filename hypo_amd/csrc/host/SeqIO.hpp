@@ -402,6 +402,7 @@ public:
     }
     bool ok() const { return _lr.ok(); }
     void set_inflate_threads(int n) { _lr.set_inflate_threads(n); }
+    bool bgzf() const { return _lr.bgzf(); }                   // a BGZF (BAM) file: its blocks are inflated by BlockInflater::name()
     const std::string& tid2name(int32_t tid) const { return _names[(size_t)tid]; }
     // A block of raw records in one buffer: record i = bytes [off[i], off[i + 1] - 1), followed by a NUL.  SAM: the text of
     // one alignment line; BAM: one alignment block without its 4-byte size.  I/O and inflate are serial (one reader thread),

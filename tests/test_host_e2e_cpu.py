@@ -67,3 +67,22 @@ def test_e2e_long_read_edit_distance_filter_counts_and_fasta(built, bam, tmp_pat
     assert [int(x) for x in counts[-1]] == man["expected_long_reads_loaded_invalid"], counts
     assert eu.fasta_md5(tmp_path) == man["expected_fasta_md5"]
 
+
+
+def test_require_device_turns_a_host_fallback_into_an_error(built, tmp_path):
+    """`hypo --require-device`: over the CPU shim (which answers the device stages of the support votes and arm selection with
+    "unsupported", so the host loops would take over) the run ends with exit code 1 and says which stage it was; without the flag
+    the same run goes through the host loops and matches the reference (the tests above)."""
+    import os
+    import shlex
+    import subprocess
+    man = eu.make_inputs("e2e_20k_s1", tmp_path)
+    argv = shlex.split(man["command"])
+    argv[0] = eu.BIN
+    env = dict(os.environ, LD_LIBRARY_PATH=eu.SHIM_DIR + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    env.pop("HYPO_REQUIRE_DEVICE", None)
+    p = subprocess.run(argv + ["--require-device"], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 1, p.stdout[-500:] + p.stderr[-500:]
+    assert "--require-device" in p.stderr and "would be computed on the host" in p.stderr
+    p = subprocess.run(argv, cwd=str(tmp_path), env=dict(env, HYPO_REQUIRE_DEVICE="1"), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 1 and "would be computed on the host" in p.stderr
