@@ -106,6 +106,10 @@ struct PoaParamRef {
 #endif
 // ... also in the class of wide windows (class 3: along the guide only, see Poa::align)
 #define HYPO_EXACT_WIDE 1
+// ... and kNW arms one substitution off the path of the arm before them (Poa::guided_one_sub); 0: they go through the score rows
+#ifndef HYPO_ONE_SUB
+#define HYPO_ONE_SUB 1
+#endif
 // int16 score rows as packed pairs of columns (Poa::rows_pk); HYPO_PACKED=0 builds the one-column-per-register loop everywhere
 #define HYPO_PACKED 1
 template <int GW_, int CPL_, int LCAP_, int NMAX_, int KIN_, int DIRCELLS_, int RINGCELLS_, int ARMBYTES_,
@@ -1091,12 +1095,105 @@ struct Poa {
     // (no guide of this shape; a forced-ness check failed) — the caller asks Poa::thread_cols; -1: along a guide of its own
     // kind the arm spells no path — the caller goes to the score rows, which are exact whatever was tried before them.
 #ifdef HYPO_EMU_DBG
-#define DBGR(i) do { if (g.lane == 0) g_dbg_reason[i]++; } while (0)
+#define DBGR(i) do { const int dbgr_i = (i); if (g.lane == 0) g_dbg_reason[dbgr_i]++; } while (0)
 #else
 #define DBGR(i) do { } while (0)
 #endif
+    // ---- one substitution off the guide --------------------------------------------------------------------------------------
+    // A kNW arm as long as its guide whose letters the guide's nodes (or their aligned cliques) carry at every position but
+    // ONE, q0: the alignment A* that walks the guide's path with a mismatch on the guide's own node x at q0 scores
+    // m (L - 1) + n, i.e. it is m - n short of perfect.  With gp < n and m - n < -2 gp (Poa::align checks; the defaults 5 / -4 / -8
+    // do) anything at least as good has no horizontal step and at most ONE edit, a mismatch or a vertical step, and is perfect
+    // everywhere else.  A* is the reference's alignment if no other such alignment exists, and that is checked on the graph,
+    // lanes = positions, without a score:
+    //   (end)    the graph has one sink, the path's last node, and no other node carries the last letter: every candidate ends
+    //            in a match on that node;
+    //   (forced) of the in-edge sources of the path's node at q exactly one carries the letter of q - 1 (the path's own) — at
+    //            q0 + 1 none does.  Walking back from the end, a candidate therefore stays on the path for as long as its steps
+    //            are perfect, and cannot pass q0 perfectly: its edit is at q0 or behind it, and everything before the edit is a
+    //            perfect prefix that starts at a node without in-edges;
+    //   (entrances) an edit at t >= q0 leaves the path through an in-edge source z of the path's node at t + 1: as a mismatch
+    //            on z (z is not the path's own; the prefix ends at a source of z that carries the letter of t - 1), or as a
+    //            vertical step over z (any z; the prefix ends at a source of z that carries the letter of t).  Either prefix is
+    //            followed backwards letter by letter (Poa::back_alive) and has to DIE: a handful of nodes, one in four
+    //            survives a step.  A candidate that meets the path's own node of its position behind q0 is dead too (forced:
+    //            it would have to pass q0 perfectly); one that meets it at or before q0, reaches a node without in-edges in
+    //            column 1, or is still alive eight steps back fails the check;
+    //   (prefix) up to q0 the path is forced the same way and starts at a node without in-edges.
+    // Returns 2: posnode[] is the alignment (every position aligned; Poa::add_alignment adds the new node at q0); -1: cannot
+    // tell, the score rows decide (posnode[] no longer holds the guide).
+    HD bool back_alive(int z, int pos, int q0) const {
+        uint64_t cur = 0; int n = 0;                         // up to four candidates, 16 bits each
+        bool alive = false;
+        auto expand = [&](int u, int ps, uint64_t& dst, int& dn) {
+            const int c = (int)seq[ps], k = (int)nin[u], own = (int)posnode[ps];
+            for (int p = 0; p < k; ++p) {
+                const int sx = (int)inp[u * KIN + p];
+                if ((int)code[sx] != c) continue;
+                if (sx == own) { if (ps <= q0) alive = true; continue; }
+                if (ps == 0) { if (nin[sx] == 0) alive = true; continue; }
+                bool dup = false;
+                for (int i = 0; i < dn; ++i) dup = dup || (int)((dst >> (16 * i)) & 0xffffu) == sx;
+                if (dup) continue;
+                if (dn == 4) { alive = true; continue; }
+                dst |= (uint64_t)(uint32_t)sx << (16 * dn); ++dn;
+            }
+        };
+        expand(z, pos, cur, n);
+        for (int step = 0; step < 8 && n != 0 && !alive; ++step) {
+            uint64_t nx = 0; int nn = 0;
+            --pos;
+            for (int i = 0; i < n; ++i) expand((int)((cur >> (16 * i)) & 0xffffu), pos, nx, nn);
+            cur = nx; n = nn;
+        }
+        return alive || n != 0;
+    }
+    HD int guided_one_sub(int q0) {                        // (posnode[] holds the path; loops kept rolled: the code is cold next to the score rows it replaces, and must not set the kernel's register count)
+        const int Lu = g.uniform(L);
+        q0 = g.uniform(q0);
+        if (q0 < 1 || q0 >= Lu - 1) return -1;
+        bool bad = false;
+        HYPO_NOUNROLL
+        for (int q = g.lane; q < Lu; q += GW) {
+            const int u = (int)posnode[q];
+            const int k = (int)nin[u];
+            if (q == 0) { if (k != 0) bad = true; }
+            else {
+                const int prev = (int)posnode[q - 1], cp = (int)seq[q - 1];
+                int same = 0; bool own = false;
+                for (int p = 0; p < k; ++p) {
+                    const int src = (int)inp[u * KIN + p];
+                    own = own || src == prev;
+                    same += (int)code[src] == cp ? 1 : 0;
+                }
+                if (!own || same != (q == q0 + 1 ? 0 : 1)) bad = true;
+                if (!bad && q > q0) {
+                    for (int p = 0; p < k; ++p) {
+                        const int z = (int)inp[u * KIN + p];
+                        if (back_alive(z, q - 1, q0)) bad = true;                      // a vertical step over z
+                        if (z != prev && back_alive(z, q - 2, q0)) bad = true;         // a mismatch on z
+                    }
+                }
+            }
+            if (q == Lu - 1 && nout[u] != 0) bad = true;
+        }
+        int ns = 0, nl = 0;                                  // sinks; nodes that carry the last letter
+        {
+            const int cl = (int)seq[Lu - 1];
+            for (int u0 = 0; u0 < n_nodes; u0 += GW) {
+                const int u = u0 + g.lane;
+                ns += popc64(g.ballot(u < n_nodes && nout[u] == 0));
+                nl += popc64(g.ballot(u < n_nodes && (int)code[u] == cl));
+            }
+        }
+        if (g.any(bad) || ns != 1 || nl != 1) { DBGR(12); return -1; }
+        tb_steps = Lu; tb_fv = 0;
+        g.sync();
+        DBGR(13);
+        return 2;
+    }
     int guide_len, guide_mode;                              // posnode[0 .. guide_len) is the path of the last sequence added (its mode); -1: none
-    HD int thread_guided(int mode) {
+    HD int thread_guided(int mode, bool sub_ok) {
         const int Lu = g.uniform(L), Gl = g.uniform(guide_len);
         if (Gl < Lu) { DBGR(Gl < 0 ? 1 : 2); return 0; }
         const int d = mode == MODE_ROV ? Gl - Lu : 0;       // kROV arms end where the guide ends, the others start where it starts
@@ -1119,7 +1216,24 @@ struct Poa {
             }
         }
         // (every lane has read its guide nodes before any lane writes posnode[] below: the collectives in between are rendezvous)
-        if (g.any(bad)) { DBGR(strong ? 4 : 5); return strong ? -1 : 0; }
+        if (g.any(bad)) {
+            if (HYPO_ONE_SUB && strong && sub_ok && mode == MODE_NW) {       // a single letter the guide cannot place: Poa::guided_one_sub
+                int nbad = 0, q0 = 0;
+                HYPO_UNROLL
+                for (int t = 0; t < XSL; ++t) {
+                    const uint64_t b = g.ballot(t * GW + g.lane < Lu && v[t] < 0);
+                    if (b != 0) q0 = t * GW + ctz64(b);
+                    nbad += popc64(b);
+                }
+                if (nbad == 1) {                             // the path, with the guide's own node at q0 (every lane has read its guide nodes: the ballots were rendezvous)
+                    HYPO_UNROLL
+                    for (int t = 0; t < XSL; ++t) { const int q = t * GW + g.lane; if (q < Lu && q != q0) posnode[q] = (int16_t)v[t]; }
+                    g.sync();
+                    return guided_one_sub(q0);
+                }
+            }
+            DBGR(strong ? 4 : 5); return strong ? -1 : 0;
+        }
         int carry = -1;
         HYPO_UNROLL
         for (int t = 0; t < XSL; ++t) {
@@ -1785,8 +1899,8 @@ struct Poa {
             constexpr bool EXACT_HERE = HYPO_EXACT && (Cfg::LMAX <= 127 || HYPO_EXACT_WIDE);
             if (EXACT_HERE && m > 0 && n < m && gp < 0) {
                 // first along the path of the sequence before (Poa::thread_guided), then, where that cannot tell, column by column
-                int hit = thread_guided(mode);
-                weights_done = hit > 0;
+                int hit = thread_guided(mode, gp < n && m - n < -2 * gp);
+                weights_done = hit == 1;
                 // (column by column not in the wide class and not in four-groups-per-wave class 0, where every rank set is a vector register per lane: both would lose a wave per SIMD to it and thread along the guide only)
                 if constexpr (Cfg::LMAX <= 127 && GW >= 32) { if (hit == 0) hit = thread_cols(mode); }
                 if (hit < 0) hit = 0;
@@ -1797,6 +1911,7 @@ struct Poa {
                     if (hit) stat[ST_XHITS] += 1;
                 }
                 HYPO_DIAG(exact_tries += 1; guided_hits += weights_done ? 1u : 0u);
+                if (hit == 2) return RES_OK;                   // aligned, one substitution off the guide: posnode[] goes to add_alignment
                 if (hit) { threaded = true; return RES_OK; }
             } else stat_set(ST_LASTX, 0u);
             int ntie_pk = 0;

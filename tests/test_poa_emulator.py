@@ -200,3 +200,54 @@ def test_requeue_chain_under_asan():
     code = "import sys; sys.path[:0] = [%r, %r]; import test_poa_emulator as t; print('carried', t._requeue_check(True))" % (os.path.dirname(here), here)
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "carried" in p.stdout, (p.stdout[-400:], p.stderr[-1200:])
+
+
+def _one_sub_windows(rng, n):
+    """Windows built to sit on the checks of Poa::guided_one_sub: arms that differ from the arm before them in one base, over
+    drafts of two or three letters (homopolymer runs, repeats: several in-edge sources carry the letter before), with arms
+    that lack a base or carry one more (triangles: the side entrances of the path), and the same substitution seen twice."""
+    from hypo_amd.batch import TextWindow
+    wins = []
+    for _ in range(n):
+        L = int(rng.choice([8, 14, 22, 33, 45, 60, 90, 120]))
+        letters = "ACGT"[:int(rng.choice([2, 3, 4]))]
+        truth = "".join(letters[i] for i in rng.integers(0, len(letters), size=L))
+        arms = []
+        for _ in range(int(rng.integers(4, 26))):
+            a = list(truth)
+            r = rng.random()
+            if r < 0.55:                                  # one substitution
+                a[int(rng.integers(L))] = letters[int(rng.integers(len(letters)))]
+            elif r < 0.70:                                # two
+                for _ in range(2):
+                    a[int(rng.integers(L))] = letters[int(rng.integers(len(letters)))]
+            elif r < 0.80 and L > 4:                      # a base less
+                del a[int(rng.integers(L))]
+            elif r < 0.90:                                # a base more
+                a.insert(int(rng.integers(L)), letters[int(rng.integers(len(letters)))])
+            arms.append("".join(a))
+            if rng.random() < 0.25:
+                arms.append(arms[int(rng.integers(len(arms)))])
+        wins.append(TextWindow(truth, arms, [], []))
+    return wins
+
+
+@pytest.mark.parametrize("seed,scores", [(1, (5, -4, -8, 3, -5, -4)), (2, (5, -4, -8, 3, -5, -4)), (3, (2, -1, -2, 3, -5, -4)),
+                                         (4, (3, -6, -5, 3, -5, -4))])
+def test_one_substitution_off_the_guide_vs_oracle(seed, scores):
+    """Poa::guided_one_sub (an arm one base off the path of the arm before it is aligned without score rows) against the
+    oracle, every window through the re-queue chain from class 0 on; (2, -1, -2) is a score set the shortcut accepts with
+    other margins, (3, -6, -5) one it must refuse (a horizontal step costs less than a mismatch there)."""
+    import numpy as np
+    import oracle
+    rng = np.random.default_rng(4200 + seed)
+    b = build_batch(_one_sub_windows(rng, 500))
+    emu = emu_util.Emu()
+    cons, res = emu.poa_chain(b, 0, scores=scores)[:2]
+    want = oracle.Oracle().poa_batch(b, scores=scores)[0]
+    n_ran = 0
+    for i in range(b.n_windows):
+        if res[i] == emu_util.RES_OK:
+            assert cons[i] == want[i], i
+            n_ran += 1
+    assert n_ran > 450
