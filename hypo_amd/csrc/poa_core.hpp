@@ -110,6 +110,10 @@ struct PoaParamRef {
 #ifndef HYPO_ONE_SUB
 #define HYPO_ONE_SUB 1
 #endif
+// a new node in an old clique goes into the literal order without a sort (Poa::topo_insert); 0: every change of the graph is sorted
+#ifndef HYPO_TOPO_INSERT
+#define HYPO_TOPO_INSERT 1
+#endif
 // int16 score rows as packed pairs of columns (Poa::rows_pk); HYPO_PACKED=0 builds the one-column-per-register loop everywhere
 #define HYPO_PACKED 1
 template <int GW_, int CPL_, int LCAP_, int NMAX_, int KIN_, int DIRCELLS_, int RINGCELLS_, int ARMBYTES_,
@@ -674,10 +678,10 @@ struct Poa {
                 const int d = r + 1 - pr;
                 md = d > md ? d : md;
             }
-            const bool sink = nout[u] == 0;
+            const bool sink = n_out(u) == 0;
             const bool slow = !(k == 1 && p0 == r) || sink;
             const uint32_t c = code[u];
-            rowmeta[r] = c | (slow ? META_SLOW : 0u) | (sink ? META_SINK : 0u) | ((PK && nout[u] == 1) ? META_OUT1 : 0u) | ((uint32_t)k << 8) | (PK ? (c << 16) : 0u) | ((uint32_t)p0 << P0_SHIFT);
+            rowmeta[r] = c | (slow ? META_SLOW : 0u) | (sink ? META_SINK : 0u) | ((PK && n_out(u) == 1) ? META_OUT1 : 0u) | ((uint32_t)k << 8) | (PK ? (c << 16) : 0u) | ((uint32_t)p0 << P0_SHIFT);
         }
         meta_dirty = false;
         if (PK) {
@@ -1175,14 +1179,14 @@ struct Poa {
                     }
                 }
             }
-            if (q == Lu - 1 && nout[u] != 0) bad = true;
+            if (q == Lu - 1 && n_out(u) != 0) bad = true;
         }
         int ns = 0, nl = 0;                                  // sinks; nodes that carry the last letter
         {
             const int cl = (int)seq[Lu - 1];
             for (int u0 = 0; u0 < n_nodes; u0 += GW) {
                 const int u = u0 + g.lane;
-                ns += popc64(g.ballot(u < n_nodes && nout[u] == 0));
+                ns += popc64(g.ballot(u < n_nodes && n_out(u) == 0));
                 nl += popc64(g.ballot(u < n_nodes && (int)code[u] == cl));
             }
         }
@@ -1256,14 +1260,14 @@ struct Poa {
                     if (k > 1 && first_same != pi) amb = true;
                     if (pi >= 0) v[t] |= pi << 16;
                 }
-                if (q == Lu - 1 && mode != MODE_LOV && nout[u] != 0) bad = true;
+                if (q == Lu - 1 && mode != MODE_LOV && n_out(u) != 0) bad = true;
             }
         }
         int ns = 1;                                          // sinks that carry the last letter (kNW / kROV)
         if (mode != MODE_LOV) {
             ns = 0;
             const int cl = (int)seq[Lu - 1];
-            for (int u0 = 0; u0 < n_nodes; u0 += GW) { const int u = u0 + g.lane; ns += popc64(g.ballot(u < n_nodes && nout[u] == 0 && (int)code[u] == cl)); }
+            for (int u0 = 0; u0 < n_nodes; u0 += GW) { const int u = u0 + g.lane; ns += popc64(g.ballot(u < n_nodes && n_out(u) == 0 && (int)code[u] == cl)); }
         }
         if (g.any(bad)) { DBGR(strong ? 6 : 7); return strong ? -1 : 0; }
         if (g.any(amb) || ns != 1) { DBGR(g.any(amb) ? 8 : 9); return 0; }
@@ -2141,8 +2145,8 @@ struct Poa {
                     {
                         const int u0 = (int)r2n[(int)newslot[0] - 1];
                         const int ka0 = (int)nal[u0];
-                        int cmin = u0; bool all_sinks = nout[u0] == 0;
-                        for (int a = 0; a < ka0; ++a) { const int x = (int)al[u0 * AL + a]; cmin = x < cmin ? x : cmin; all_sinks = all_sinks && nout[x] == 0; }
+                        int cmin = u0; bool all_sinks = n_out(u0) == 0;
+                        for (int a = 0; a < ka0; ++a) { const int x = (int)al[u0 * AL + a]; cmin = x < cmin ? x : cmin; all_sinks = all_sinks && n_out(x) == 0; }
                         int pos = 0x7fff; bool member = true;
                         if (g.lane < ntie) {
                             const int u = (int)r2n[(int)newslot[g.lane] - 1];
@@ -2244,6 +2248,10 @@ struct Poa {
     HD void new_node(int id, int c) {
         code[id] = (uint8_t)c; nin[id] = 0; nout[id] = 0; nal[id] = 0;
     }
+    // nout[]: out-degree in bits 0-6 (only 0, 1 and "more" are ever asked); bit 7: the literal sort emitted this node from its
+    // main loop — as a root whose in-edge sources, and its clique's, were all marked — and not inside a DFS (Poa::topo_insert)
+    static constexpr int NOUT_RE = 0x80;
+    HD int n_out(int u) const { return (int)nout[u] & 0x7f; }
     // adds edge prev->to (graph.cpp:99-115).  Returns 0 = existing edge, 1 = new edge, 2 = no room.
     HD int add_edge(int prev, int to) {
         const int k = nin[to];
@@ -2251,7 +2259,7 @@ struct Poa {
             if ((int)inp[to * KIN + p] == prev) { inw[to * KIN + p] = (wt_t)(inw[to * KIN + p] + 2); return 0; }
         if (k == KIN) return 2;
         inp[to * KIN + k] = (id_t)prev; inw[to * KIN + k] = 2; nin[to] = (uint8_t)(k + 1);
-        if (nout[prev] != 255) nout[prev] = (uint8_t)(nout[prev] + 1);
+        if (n_out(prev) != 127) nout[prev] = (uint8_t)(nout[prev] + 1);         // (seven bits, saturating; bit 7 is NOUT_RE)
         return 1;
     }
     HD int add_alignment() {
@@ -2261,6 +2269,9 @@ struct Poa {
         bool changed = false;
         const int n_old = n_nodes;                         // (lazy rank order: nodes from here on are new)
         n_new = 0;
+        // Poa::topo_insert: up to TI_MAX new nodes, each aligned to an old clique: their positions (0xff: more, or another kind)
+        const bool order_was_valid = !topo_dirty;
+        uint32_t ti_q = 0; int ti_n = 0; bool ti_ok = true;
         // unaligned head [0, fv): new chain (graph.cpp:194-196,273-291)
         int head = -1;
         if (fv > 0) {
@@ -2324,6 +2335,12 @@ struct Poa {
             const uint64_t nb = g.ballot(act && kind != 0);
             const int tot = popc64(nb);
             if (n_nodes + tot > NMAX) { node_over = true; break; }
+            if constexpr (TOPO_INSERT) {
+                if (tot) {
+                    if (g.ballot(act && kind == 1) != 0 || ti_n + tot > TI_MAX) ti_ok = false;
+                    else { uint64_t b2 = nb; while (b2) { ti_q |= (uint32_t)(base + ctz64(b2)) << (8 * ti_n); ++ti_n; b2 &= b2 - 1; } }
+                }
+            }
             if (act && kind != 0) {
                 const int below = popc64(nb & ((1ull << g.lane) - 1ull));
                 const int id = n_nodes + below;
@@ -2367,12 +2384,12 @@ struct Poa {
         }
         g.sync();
         // edges between consecutive positions (graph.cpp:250-258)
-        int st = 0;
+        int st = 0, ne = 0;
         for (int base = fv; base < L; base += GW) {
             const int q = base + g.lane;
             if (q < L) {
                 const int prev = q == fv ? head : (int)posnode[q - 1];
-                if (prev >= 0) { const int e = add_edge(prev, (int)posnode[q]); st = e > st ? e : st; }
+                if (prev >= 0) { const int e = add_edge(prev, (int)posnode[q]); st = e > st ? e : st; ne += e == 1 ? 1 : 0; }
             }
         }
         const int sm = g.reduce_max(st);
@@ -2380,6 +2397,13 @@ struct Poa {
         if (sm == 1) changed = true;
         g.sync();
         if (changed) { topo_dirty = true; meta_dirty = true; }
+        if constexpr (TOPO_INSERT) {
+            // the usual change — a new base or two, each a new node in an old clique with its two edges — keeps the literal order up
+            // to where the new nodes go (Poa::topo_insert); anything else is sorted again
+            if (changed && order_was_valid && ti_ok && ti_n > 0 && fv == 0 && !lazy_on_()) {
+                if (topo_insert(ti_q, ti_n, n_old, g.reduce_add(ne))) topo_dirty = false;
+            }
+        }
         last_changed = changed;
         if constexpr (Cfg::LAZY) {
             if (lazy_on) {                                 // the order stays valid: new edges follow it, new nodes are slotted in
@@ -2489,6 +2513,62 @@ struct Poa {
         return g.any(bad) ? RES_UNDEFINED : RES_OK;
     }
 
+    // ---- the literal order after a substitution, without sorting ------------------------------------------------------------
+    // What most alignments that change the graph add is a base the column has not seen: ONE new node y (the largest id), aligned
+    // to the clique of the node x its position was aligned to, with an in-edge from the node before it on the path and an
+    // out-edge, appended to the in-edge list of the node after it.  If the last literal sort emitted x's clique from its main
+    // loop (NOUT_RE: it reached the clique's first member as a root, found the in-edge sources of every member marked and emitted
+    // member + aligned list at once, graph.cpp:311-349) and y's source is an in-edge source of x, a sort of the new graph runs
+    // exactly as the old one did: nothing it visits before that root mentions y (only the clique's aligned lists and the node
+    // after y do, and had the DFS reached one of those first the clique would have been emitted inside a DFS); at the root every
+    // member's sources are marked, y's among them, and the clique is emitted with y LAST (add_alignment appends y to every
+    // member's aligned list); from then on y is marked and never pushed.  So the new order is the old one with y behind its
+    // clique, and y is NOUT_RE in turn.  Several such nodes of one alignment (not on neighbouring positions: then an edge joins
+    // two of them) are the same graph as one alignment each, in position order.  Everything else — an unaligned base, a new edge
+    // between old nodes, a clique emitted inside a DFS (the nodes behind an insertion) — is sorted literally.
+    static constexpr bool TOPO_INSERT = HYPO_TOPO_INSERT && PK && !Cfg::LAZY;
+    static constexpr int TI_MAX = 3;
+    HD bool lazy_on_() const { if constexpr (Cfg::LAZY) return lazy_on; else return false; }
+    HD bool topo_insert(uint32_t ti_q, int ti_n, int n_old, int new_edges) {
+        // (group-uniform throughout: every lane reads the same few table entries)
+        int want = 0, last_q = -2;
+        for (int t = 0; t < ti_n; ++t) {
+            const int q = (int)((ti_q >> (8 * t)) & 0xffu);
+            if (q == last_q + 1) { DBGR(15); return false; }
+            last_q = q;
+            want += (q > 0 ? 1 : 0) + (q + 1 < L ? 1 : 0);
+            const int y = (int)posnode[q];
+            const int ka = (int)nal[y];
+            const int x = (int)al[y * AL + ka - 1];           // (add_alignment: the node the position was aligned to closes y's list)
+            if (y < n_old || !(nout[x] & NOUT_RE)) { DBGR(15); return false; }
+            if (q > 0) {
+                const int prev = (int)posnode[q - 1], k = (int)nin[x];
+                bool found = false;
+                for (int p = 0; p < k; ++p) found = found || (int)inp[x * KIN + p] == prev;
+                if (!found || prev >= n_old) { DBGR(15); return false; }
+            }
+        }
+        if (new_edges != want) { DBGR(15); return false; }
+        for (int t = 0; t < ti_n; ++t) {
+            const int q = (int)((ti_q >> (8 * t)) & 0xffu);
+            const int y = (int)posnode[q];
+            const int ka = (int)nal[y];
+            int pos = 0;                                       // rank y takes: behind the last member of its clique
+            for (int a = 0; a < ka; ++a) { const int r = (int)n2r[al[y * AL + a]]; pos = r + 1 > pos ? r + 1 : pos; }
+            const int n_in = n_old + t;                        // nodes in the order so far
+            id_t keep[XRPL];
+            HYPO_UNROLL
+            for (int i = 0; i < XRPL; ++i) { const int r = i * GW + g.lane; keep[i] = (r >= pos && r < n_in) ? r2n[r] : (id_t)0; }
+            g.sync();
+            HYPO_UNROLL
+            for (int i = 0; i < XRPL; ++i) { const int r = i * GW + g.lane; if (r >= pos && r < n_in) { r2n[r + 1] = keep[i]; n2r[keep[i]] = (id_t)(r + 1); } }
+            if (g.lane == 0) { r2n[pos] = (id_t)y; n2r[y] = (id_t)pos; nout[y] = (uint8_t)(nout[y] | NOUT_RE); }
+            g.sync();
+        }
+        DBGR(14);
+        return true;
+    }
+
     // ---- Graph::topological_sort (graph.cpp:293-353) ---------------------------------------------
     // mark bit0 = permanently marked, bit1 = "aligned nodes already pushed by another clique member".
     HD int toposort() {
@@ -2541,14 +2621,14 @@ struct Poa {
                 HYPO_DIAG(topo_fast += 1);
                 const bool em = g.lane < run && !isdone;       // lanes < run have r < n_nodes (pre is false beyond)
                 const uint64_t eb = g.ballot(em);
-                if (em) { r2n[cnt + popc64(eb & ((1ull << g.lane) - 1ull))] = (id_t)r; mark[r] = 1; }
+                if (em) { r2n[cnt + popc64(eb & ((1ull << g.lane) - 1ull))] = (id_t)r; mark[r] = 1; nout[r] = (uint8_t)(nout[r] | NOUT_RE); }
                 cnt += popc64(eb);
                 root += run;
                 if (has_clq) {
                     const int kc = g.shfl(ka, run);
                     if (g.lane == run) {
-                        r2n[cnt] = (id_t)r; mark[r] = 1;
-                        for (int j = 0; j < ka; ++j) { const int a = al[r * AL + j]; r2n[cnt + 1 + j] = (id_t)a; mark[a] = 1; }
+                        r2n[cnt] = (id_t)r; mark[r] = 1; nout[r] = (uint8_t)(nout[r] | NOUT_RE);
+                        for (int j = 0; j < ka; ++j) { const int a = al[r * AL + j]; r2n[cnt + 1 + j] = (id_t)a; mark[a] = 1; nout[a] = (uint8_t)(nout[a] | NOUT_RE); }
                     }
                     cnt += 1 + kc;
                     root += 1;
@@ -2576,6 +2656,7 @@ struct Poa {
                 if (b == 0) {
                     if (g.lane == 0) {
                         mark[v] = (uint8_t)(mv | 1);
+                        nout[v] = (uint8_t)n_out(v);             // (emitted inside a DFS: not NOUT_RE)
                         if (!(mv & 2)) r2n[cnt] = (id_t)v;
                     }
                     if (!(mv & 2)) {
@@ -2669,7 +2750,7 @@ struct Poa {
         }
         uint8_t* b = out + 32;
         HYPO_NOUNROLL
-        for (int u = g.lane; u < n; u += GW) { b[u] = code[u]; b[n + u] = nin[u]; b[2 * n + u] = nout[u]; b[3 * n + u] = nal[u]; }
+        for (int u = g.lane; u < n; u += GW) { b[u] = code[u]; b[n + u] = nin[u]; b[2 * n + u] = (uint8_t)n_out(u); b[3 * n + u] = nal[u]; }
         uint16_t* o_r2n = (uint16_t*)(b + align_up<16>(4 * n));
         uint16_t* o_n2r = o_r2n + align_up<16>(2 * n) / 2;
         uint16_t* o_inp = o_n2r + align_up<16>(2 * n) / 2;
@@ -2795,7 +2876,7 @@ struct Poa {
         key = g.reduce_max(key);
         const int best_r = (key >> 8) == 0 ? (int)n2r[0] : 255 - (key & 255);
         const int max_id = r2n[best_r];
-        if (nout[max_id] != 0) return CONS_SERIAL;
+        if (n_out(max_id) != 0) return CONS_SERIAL;
         const int len = g.uniform(acc[best_r] & 255);
         for (int t = g.lane; t < len; t += GW) {
             int x = best_r;
@@ -2859,7 +2940,7 @@ struct Poa {
         g.sync();
         // branch completion (graph.cpp:660-705) while the best node is not a sink
         int rounds = 0;
-        while (nout[max_id] != 0) {
+        while (n_out(max_id) != 0) {
             if (++rounds > n_nodes) return -1;             // hang guard (cannot happen on a DAG)
             // invalidate the other sources feeding max_id's successors
             for (int t = g.lane; t < n_nodes; t += GW) {
