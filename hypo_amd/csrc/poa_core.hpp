@@ -114,6 +114,10 @@ struct PoaParamRef {
 #ifndef HYPO_TOPO_INSERT
 #define HYPO_TOPO_INSERT 1
 #endif
+// the packed classes build the row metadata when the score rows or Poa::thread_cols are reached, not at the start of every alignment
+#ifndef HYPO_DEFER_META
+#define HYPO_DEFER_META 1
+#endif
 // int16 score rows as packed pairs of columns (Poa::rows_pk); HYPO_PACKED=0 builds the one-column-per-register loop everywhere
 #define HYPO_PACKED 1
 template <int GW_, int CPL_, int LCAP_, int NMAX_, int KIN_, int DIRCELLS_, int RINGCELLS_, int ARMBYTES_,
@@ -1889,10 +1893,20 @@ struct Poa {
             if (a * (n_nodes + L + 1) >= 32767) return RES_OVERFLOW;
             if ((PK || Cfg::PACKED_HYB) && a * (n_nodes + 2 * L + CPL + 8) >= 32767) return RES_OVERFLOW;   // rows_pk: H - j*g and NEG16 + score in 16 bits
         }
-        if (meta_dirty) { build_rowmeta(); HYPO_TICK(PH_META); }
+        // The row metadata (by rank: rebuilt after every change of the graph, four passes of dependent LDS reads) are what the score
+        // rows and Poa::thread_cols read; threading along the guide does not, so the packed classes build them only when one of
+        // those two is reached — between two arms that thread along the guide, or sit one substitution off it, nobody asks.
         const int R = g.uniform(Cfg::RINGCELLS / S);        // ring rows; row i can still see rows i-R .. i-1
-        if (R < (int)stat[ST_MAXD] + 1 || R < 1) return RES_OVERFLOW;
+        auto need_meta = [&]() -> bool {                    // false: the ring is too shallow for this rank order (RES_OVERFLOW)
+            if (meta_dirty) { build_rowmeta(); HYPO_TICK(PH_META); }
+            return !(R < (int)stat[ST_MAXD] + 1 || R < 1);
+        };
+        if constexpr (!PK || !HYPO_DEFER_META) { if (!need_meta()) return RES_OVERFLOW; }
         if (g.lane == 0) { stat[ST_CELLS] += (uint32_t)((n_nodes + 1) * W); stat[ST_ALIGNS] += 1; } HYPO_DIAG(rows_done += (uint32_t)n_nodes);
+        auto overflow_late = [&]() -> int {                 // (the class that takes the window over makes this alignment again and counts it there)
+            if (g.lane == 0) { stat[ST_CELLS] -= (uint32_t)((n_nodes + 1) * W); stat[ST_ALIGNS] -= 1; }
+            return RES_OVERFLOW;
+        };
 
         int best_i = -1;
         if constexpr (PK) {
@@ -1906,7 +1920,13 @@ struct Poa {
                 int hit = thread_guided(mode, gp < n && m - n < -2 * gp);
                 weights_done = hit == 1;
                 // (column by column not in the wide class and not in four-groups-per-wave class 0, where every rank set is a vector register per lane: both would lose a wave per SIMD to it and thread along the guide only)
-                if constexpr (Cfg::LMAX <= 127 && GW >= 32) { if (hit == 0) hit = thread_cols(mode); }
+                if constexpr (Cfg::LMAX <= 127 && GW >= 32) {
+                    if (hit == 0) {
+                        HYPO_TICK(PH_EXACT);
+                        if (!need_meta()) return overflow_late();
+                        hit = thread_cols(mode);
+                    }
+                }
                 if (hit < 0) hit = 0;
                 HYPO_TICK(PH_EXACT);
                 if (g.lane == 0) {
@@ -1919,6 +1939,7 @@ struct Poa {
                 if (hit) { threaded = true; return RES_OK; }
             } else stat_set(ST_LASTX, 0u);
             int ntie_pk = 0;
+            if (!need_meta()) return overflow_late();
             { best_i = rows_pk(mode, m, n, gp, S, R, &ntie_pk); stat_add(ST_CSCORED, (uint32_t)((n_nodes + 1) * W)); HYPO_DIAG(rows_scored_n += (uint32_t)n_nodes); }
             if constexpr (Cfg::LAZY) {
                 if (lazy_on && ntie_pk > 1) {
