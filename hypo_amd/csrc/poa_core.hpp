@@ -1886,7 +1886,9 @@ struct Poa {
             sq = np == 3 ? 48 : (np == CPL / 2 ? SQ : 16);
         }
         const int S = (W + sq - 1) / sq * sq;
-        if (n_nodes * S > Cfg::DIRCELLS) return RES_OVERFLOW;
+        // (the packed classes ask only when direction codes are about to be written: need_meta below)
+        const bool dir_fits = n_nodes * S <= Cfg::DIRCELLS;
+        if (!(PK && HYPO_DEFER_META) && !dir_fits) return RES_OVERFLOW;
         if (sizeof(score_t) < 4) {                          // int16 rows are exact only below this bound
             int a = m < 0 ? -m : m, b = n < 0 ? -n : n, c2 = gp < 0 ? -gp : gp;
             a = a > b ? a : b; a = a > c2 ? a : c2;
@@ -1897,11 +1899,12 @@ struct Poa {
         // rows and Poa::thread_cols read; threading along the guide does not, so the packed classes build them only when one of
         // those two is reached — between two arms that thread along the guide, or sit one substitution off it, nobody asks.
         const int R = g.uniform(Cfg::RINGCELLS / S);        // ring rows; row i can still see rows i-R .. i-1
-        auto need_meta = [&]() -> bool {                    // false: the ring is too shallow for this rank order (RES_OVERFLOW)
+        auto need_meta = [&](bool rows) -> bool {           // false (score rows only): no room for the direction codes, or the ring is too shallow for this rank order (RES_OVERFLOW)
+            if (rows && !dir_fits) return false;
             if (meta_dirty) { build_rowmeta(); HYPO_TICK(PH_META); }
-            return !(R < (int)stat[ST_MAXD] + 1 || R < 1);
+            return !rows || !(R < (int)stat[ST_MAXD] + 1 || R < 1);
         };
-        if constexpr (!PK || !HYPO_DEFER_META) { if (!need_meta()) return RES_OVERFLOW; }
+        if constexpr (!PK || !HYPO_DEFER_META) { if (!need_meta(true)) return RES_OVERFLOW; }
         if (g.lane == 0) { stat[ST_CELLS] += (uint32_t)((n_nodes + 1) * W); stat[ST_ALIGNS] += 1; } HYPO_DIAG(rows_done += (uint32_t)n_nodes);
         auto overflow_late = [&]() -> int {                 // (the class that takes the window over makes this alignment again and counts it there)
             if (g.lane == 0) { stat[ST_CELLS] -= (uint32_t)((n_nodes + 1) * W); stat[ST_ALIGNS] -= 1; }
@@ -1923,7 +1926,7 @@ struct Poa {
                 if constexpr (Cfg::LMAX <= 127 && GW >= 32) {
                     if (hit == 0) {
                         HYPO_TICK(PH_EXACT);
-                        if (!need_meta()) return overflow_late();
+                        need_meta(false);
                         hit = thread_cols(mode);
                     }
                 }
@@ -1939,7 +1942,7 @@ struct Poa {
                 if (hit) { threaded = true; return RES_OK; }
             } else stat_set(ST_LASTX, 0u);
             int ntie_pk = 0;
-            if (!need_meta()) return overflow_late();
+            if (!need_meta(true)) return overflow_late();
             { best_i = rows_pk(mode, m, n, gp, S, R, &ntie_pk); stat_add(ST_CSCORED, (uint32_t)((n_nodes + 1) * W)); HYPO_DIAG(rows_scored_n += (uint32_t)n_nodes); }
             if constexpr (Cfg::LAZY) {
                 if (lazy_on && ntie_pk > 1) {
