@@ -567,7 +567,7 @@ void Hypo::parse_block(const SamReader& sf, const SamReader::RecordBlock& raw, P
                     rec.tid = bc.tid; rec.pos = bc.pos; rec.flag = bc.flag; rec.mapq = bc.mapq;
                     rec.cigar.resize(bc.n_cigar);
                     if (bc.n_cigar) std::memcpy(rec.cigar.data(), bc.cigar, 4ull * bc.n_cigar);
-                    rec.qname.assign(bc.qname);
+                    rec.qname.assign(bc.qname, bc.l_qname);
                     if (long_reads) rec.has_nm = sf.bam_nm(raw.rec(i), raw.len(i), bc, rec.nm);
                 } else {
                     sf.parse(raw.rec(i), raw.len(i), rec);

@@ -214,7 +214,7 @@ private:
             size_t bsize = 0;
             for (size_t x = 12; x + 4 <= 12 + xlen && _cpos + x + 4 <= _cmap_len;) {      // extra subfields: SI1 SI2 SLEN data
                 const size_t slen = h[x + 2] | ((size_t)h[x + 3] << 8);
-                if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2) bsize = (h[x + 4] | ((size_t)h[x + 5] << 8)) + 1;
+                if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2 && x + 6 <= 12 + xlen && _cpos + x + 6 <= _cmap_len) bsize = (h[x + 4] | ((size_t)h[x + 5] << 8)) + 1;
                 x += 4 + slen;
             }
             if (bsize < 12 + xlen + 8 || _cpos + bsize > _cmap_len) bgzf_fail("truncated or malformed BGZF block");
@@ -535,7 +535,7 @@ public:
     // into 2 bits: no SamRecord, no ASCII detour).  false: a long-CIGAR placeholder (the real operations are in the CG tag) — the
     // caller takes parse() for that record.
     bool is_bam() const { return _bam; }
-    struct BamCore { int32_t tid; uint32_t pos, mapq, flag, n_cigar, l_seq; const char* qname; const char* cigar; const uint8_t* seq4; };
+    struct BamCore { int32_t tid; uint32_t pos, mapq, flag, n_cigar, l_seq; const char* qname; uint32_t l_qname; const char* cigar; const uint8_t* seq4; };      // l_qname: bytes of the name without its terminator
     bool bam_core(const char* p, size_t n, BamCore& c) const {
         const int32_t ref = le32(p), l_seq = le32(p + 16);
         const unsigned l_name = (unsigned char)p[8];
@@ -545,7 +545,7 @@ public:
         }
         c.tid = (ref >= 0 && (size_t)ref < _names.size()) ? ref : -1;
         c.pos = (uint32_t)le32(p + 4); c.l_seq = (uint32_t)l_seq;
-        c.qname = p + 32; c.cigar = p + 32 + l_name; c.seq4 = (const uint8_t*)(c.cigar + 4ull * c.n_cigar);
+        c.qname = p + 32; c.l_qname = (uint32_t)::strnlen(p + 32, l_name); c.cigar = p + 32 + l_name; c.seq4 = (const uint8_t*)(c.cigar + 4ull * c.n_cigar);
         if (c.n_cigar == 2) {
             const uint32_t c0 = (uint32_t)le32(c.cigar), c1 = (uint32_t)le32(c.cigar + 4);
             if ((c0 & 0xf) == 4 && (c0 >> 4) == c.l_seq && (c1 & 0xf) == 3) return false;
@@ -587,7 +587,7 @@ public:
     }
     // read name of a raw record (for messages)
     std::string record_name(const char* line, size_t n) const {
-        if (_bam) return n > 32 ? std::string(line + 32) : std::string("?");
+        if (_bam) return n > 32 ? std::string(line + 32, ::strnlen(line + 32, std::min<size_t>(n - 32, (unsigned char)line[8]))) : std::string("?");
         const char* t = (const char*)std::memchr(line, '\t', n);
         return std::string(line, t ? (size_t)(t - line) : n);
     }
@@ -605,7 +605,7 @@ private:
             if (!_bam_ok) break;
             std::string name((size_t)l_name, '\0');
             _bam_ok = _lr.read_bytes(&name[0], (size_t)l_name) && _lr.read_bytes(&l_ref, 4);
-            name.resize(std::strlen(name.c_str()));
+            name.resize(::strnlen(name.data(), name.size()));
             _names.push_back(name);
             _tid[name] = (int32_t)_names.size() - 1;
         }
@@ -649,7 +649,7 @@ private:
                 case 'I': iv = (uint32_t)le32(p + o); adv = 4; break;
                 case 'A': is_int = false; adv = 1; break;
                 case 'f': is_int = false; adv = 4; break;
-                case 'Z': case 'H': is_int = false; adv = std::strlen(p + o) + 1; break;
+                case 'Z': case 'H': is_int = false; adv = ::strnlen(p + o, n - o) + 1; break;      // (records are cut in place from the inflated block: no terminator behind them)
                 case 'B': {
                     is_int = false;
                     const char st = p[o]; const uint32_t cnt = (uint32_t)le32(p + o + 1);

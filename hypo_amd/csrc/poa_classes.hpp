@@ -25,7 +25,9 @@ typedef PoaCfg<16, 4, 47, 48, 4, 2208, 384, 384, 64, int16_t, uint8_t> PoaClass0
 // the windows per wave but half the partners a group waits for when the windows of a wave differ.  poa_run picks one of the
 // two per call: four groups when the batch is tiny windows almost only (dense short reads: 56 vs 46 M windows/s), two groups
 // otherwise (C2: 3.89 vs 4.08 ms).
+#ifndef HYPO_C0W_GW
 #define HYPO_C0W_GW 32
+#endif
 // Class 1 runs ONE window per wave (64 lanes x 2 columns) since round 3: with two 32-lane groups per wave (x 4 columns, the
 // geometry of rounds 1-2: -DHYPO_C1_GW=32 -DHYPO_C1_CPL=4) a window cost 345 k wave-cycles against 472 k for a class-2 window with
 // four times the rows — the two windows of a wave wait for each other at every step and their group-uniform values are vector

@@ -36,6 +36,8 @@ template <class Cfg> __host__ __device__ constexpr ClassLimits limits_of() {
 
 constexpr int PLAN_THREADS = 256;
 constexpr int PLAN_STAGE = 8192;          // arm lengths staged per workgroup (32 KiB of LDS)
+constexpr int PLAN_LANES = 4;             // lanes per window in poa_plan_count_kernel
+constexpr int PLAN_WPB = PLAN_THREADS / PLAN_LANES;
 
 __device__ __forceinline__ uint32_t plan_key_from(const HypoWindow& W, uint32_t maxarm, uint32_t changes, bool* trivial) {
     const uint32_t narm = W.n_internal + W.n_prefix + W.n_suffix;
@@ -68,15 +70,17 @@ __device__ __forceinline__ uint32_t plan_key_from(const HypoWindow& W, uint32_t 
     return (uint32_t)cls * kPlanBuckets + (kPlanBuckets - 1 - b);
 }
 
-// One lane per window.  The arm lengths of a workgroup's windows are normally one contiguous range of
-// arm_len: it is staged through LDS with coalesced loads, then every lane scans its own sub-range there.
+// PLAN_LANES lanes per window (a window's arms are compared with their predecessors one after the other, two dependent HBM
+// round trips each: with one lane per window that chain was the kernel's 78 us on the C2 batch; the lanes of a window take
+// every PLAN_LANES-th arm and fold their counts with two shuffles).  The arm lengths of a workgroup's windows are normally one
+// contiguous range of arm_len: it is staged through LDS with coalesced loads, then every lane scans its share there.
 // The (class, bucket) histogram is accumulated in LDS and flushed with one global atomic per non-empty key.
 __global__ void __launch_bounds__(PLAN_THREADS)
 poa_plan_count_kernel(PoaParams P, PoaQueues Q, uint32_t n_windows) {
     __shared__ uint32_t lens[PLAN_STAGE];
     __shared__ uint32_t hist[kNumPoaClasses * kPlanBuckets];
     __shared__ uint32_t amin, amax, ntriv;
-    const uint32_t w = blockIdx.x * PLAN_THREADS + threadIdx.x;
+    const uint32_t w = blockIdx.x * PLAN_WPB + threadIdx.x / PLAN_LANES, sub = threadIdx.x % PLAN_LANES;
     for (int i = threadIdx.x; i < kNumPoaClasses * kPlanBuckets; i += PLAN_THREADS) hist[i] = 0;
     if (threadIdx.x == 0) { amin = 0xffffffffu; amax = 0; ntriv = 0; }
     __syncthreads();
@@ -88,29 +92,35 @@ poa_plan_count_kernel(PoaParams P, PoaQueues Q, uint32_t n_windows) {
         // a descriptor whose arms run past the arm table is answered HYPO_ST_INVALID by whichever class gets it (Poa::run_window);
         // the plan must not walk its "arms" either (a wrapped count made one lane read 4 G arm lengths: 20 s for one window)
         if ((uint64_t)W.n_internal + W.n_prefix + W.n_suffix + (uint64_t)W.first_arm > P.n_arms) { narm = 0; W.n_internal = W.n_prefix = W.n_suffix = 0; }
-        if (narm) { atomicMin(&amin, W.first_arm); atomicMax(&amax, W.first_arm + narm); }
+        if (narm && sub == 0) { atomicMin(&amin, W.first_arm); atomicMax(&amax, W.first_arm + narm); }
     }
     __syncthreads();
     const uint32_t a0 = amin, a1 = amax;
     const bool staged = a1 > a0 && a1 - a0 <= (uint32_t)PLAN_STAGE;
     if (staged) for (uint32_t i = threadIdx.x; i < a1 - a0; i += PLAN_THREADS) lens[i] = P.arm_len[a0 + i];
     __syncthreads();
-    if (w < n_windows) {
+    {
         uint32_t maxarm = 0;
-        if (staged) { for (uint32_t a = 0; a < narm; ++a) { const uint32_t l = lens[W.first_arm - a0 + a]; maxarm = l > maxarm ? l : maxarm; } }
-        else { for (uint32_t a = 0; a < narm; ++a) { const uint32_t l = P.arm_len[W.first_arm + a]; maxarm = l > maxarm ? l : maxarm; } }
+        if (staged) { for (uint32_t a = sub; a < narm; a += PLAN_LANES) { const uint32_t l = lens[W.first_arm - a0 + a]; maxarm = l > maxarm ? l : maxarm; } }
+        else { for (uint32_t a = sub; a < narm; a += PLAN_LANES) { const uint32_t l = P.arm_len[W.first_arm + a]; maxarm = l > maxarm ? l : maxarm; } }
         // arm diversity: packed bytes (4 bases each) in which an internal arm differs from the arm before it, equal lengths only.
         // A read error changes one byte against the predecessor and one against the successor, at any error rate: about two
         // differing bytes per node the window's graph will grow beyond its first chain.  (13.6 MB of arms on the C2 batch, read
         // once here and once more by the size-class kernels.)
         uint32_t changes = 0;
         if (W.type == HYPO_WIN_SHORT && (uint64_t)W.first_arm + narm <= P.n_arms) {
-            const uint8_t* q = nullptr; uint32_t pl = 0xffffffffu;
-            for (uint32_t a = 0; a < W.n_internal; ++a) {
+            auto arm_at = [&](uint32_t a, uint32_t* l_out) -> const uint8_t* {
                 const uint32_t l = staged ? lens[W.first_arm - a0 + a] : P.arm_len[W.first_arm + a];
                 const uint64_t o = P.arm_off[W.first_arm + a];
                 const uint32_t nb = (l + 3) / 4;
-                const uint8_t* p = (o <= P.arms2_bytes && nb <= P.arms2_bytes - o) ? P.arms2 + o : nullptr;
+                *l_out = l;
+                return (o <= P.arms2_bytes && nb <= P.arms2_bytes - o) ? P.arms2 + o : nullptr;
+            };
+            for (uint32_t a = 1 + sub; a < W.n_internal; a += PLAN_LANES) {          // arm a against arm a - 1
+                uint32_t l, pl;
+                const uint8_t* p = arm_at(a, &l);
+                const uint8_t* q = arm_at(a - 1, &pl);
+                const uint32_t nb = (l + 3) / 4;
                 if (p && q && l == pl) {                       // eight bytes per (unaligned) load, the rest one by one
                     typedef uint64_t __attribute__((aligned(1))) u64u;
                     uint32_t b = 0;
@@ -121,15 +131,21 @@ poa_plan_count_kernel(PoaParams P, PoaQueues Q, uint32_t n_windows) {
                     }
                     for (; b < nb; ++b) changes += p[b] != q[b];
                 }
-                q = p; pl = l;
             }
         }
-        bool trivial;
-        const uint32_t key = plan_key_from(W, maxarm, changes, &trivial);
-        Q.keys[w] = (uint16_t)key;
-        Q.carry[w] = 0;                                       // no spill yet (poa_class_kernel sets it when it re-queues the window)
-        atomicAdd(&hist[key], 1u);
-        if (trivial) atomicAdd(&ntriv, 1u);
+        for (int d = 1; d < PLAN_LANES; d <<= 1) {            // (every lane of the workgroup is here: lanes without a window carry zeros)
+            changes += (uint32_t)__shfl_xor((int)changes, d, PLAN_LANES);
+            const uint32_t om = (uint32_t)__shfl_xor((int)maxarm, d, PLAN_LANES);
+            maxarm = om > maxarm ? om : maxarm;
+        }
+        if (w < n_windows && sub == 0) {
+            bool trivial;
+            const uint32_t key = plan_key_from(W, maxarm, changes, &trivial);
+            Q.keys[w] = (uint16_t)key;
+            Q.carry[w] = 0;                                   // no spill yet (poa_class_kernel sets it when it re-queues the window)
+            atomicAdd(&hist[key], 1u);
+            if (trivial) atomicAdd(&ntriv, 1u);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < kNumPoaClasses * kPlanBuckets; i += PLAN_THREADS)
@@ -696,7 +712,7 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     if ((e = hipMemsetAsync(Q.items + (size_t)3 * n_windows, 0xff, (size_t)n_windows * sizeof(uint32_t), stream)) != hipSuccess) return e;
     int pe = 0;
     if (prof) (void)hipEventRecord(prof->ev[0], stream);
-    hipLaunchKernelGGL(poa_plan_count_kernel, dim3((n_windows + PLAN_THREADS - 1) / PLAN_THREADS), dim3(PLAN_THREADS), 0, stream, P, Q, n_windows);
+    hipLaunchKernelGGL(poa_plan_count_kernel, dim3((n_windows + PLAN_WPB - 1) / PLAN_WPB), dim3(PLAN_THREADS), 0, stream, P, Q, n_windows);
     hipLaunchKernelGGL(poa_plan_scan_kernel, dim3(1), dim3(64), 0, stream, Q);
     hipLaunchKernelGGL(poa_plan_scatter_kernel, dim3((n_windows + PLAN_THREADS - 1) / PLAN_THREADS), dim3(PLAN_THREADS), 0, stream, Q, n_windows);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -771,7 +787,11 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     // {3,4,5} 3.64 / 3.55, {4,3,5} 3.60 / 3.71, {4,4,4} 3.64 / 3.94, {5,5,5} 3.61 / 3.78, {5,4,4} 3.58 / 4.13.  Class 0 is set below.
     // After Poa::fetch_next and with class 1 at one window per wave (8 KB per wave): {5,5,6} (profiles/diag/r03_wave_wide_sweep2.sh:
     // C2 2.56 ms, 0.5 % read error 4.76, 1 % 10.2; {4,5,6} 2.56 / 4.72 / 11.1, {4,6,6} 2.65 / 4.96 / 11.3, {4,4,5} 2.94 / - / 9.8-11).
-    int caps[kNumPoaClasses] = {5, 5, 6, 0, 0, 0};
+    // Round 5, after the one-substitution shortcut and Poa::topo_insert took a third off class 2's work: {5,5,5} (154.6 KB: every wave
+    // resident, the three kernels' times stop swapping places between runs) — profiles/diag/r05_caps_fit.txt, ms per call at
+    // 0.2 / 0.5 / 2 / 3 % read error: {5,5,6} 1.61-1.64 / 2.43-2.44 / 15.2-15.7 / 24.7-24.9, {5,5,5} 1.55 x 3 / 2.33 / 13.7-14.1 /
+    // 22.5-22.6, {6,4,5} 1.56-1.59, {5,4,6} 1.55-1.69, {4,5,6} 1.61-1.66; 1 % alone prefers {5,5,6} (5.4-5.8 against 5.8-6.6).
+    int caps[kNumPoaClasses] = {5, 5, 5, 0, 0, 0};
     if (const char* cs = getenv("HYPO_POA_CAPS")) sscanf(cs, "%d,%d,%d,%d,%d", &caps[0], &caps[1], &caps[2], &caps[3], &caps[4]);
     // wave-time per class of the last finished call (PoaQueues::work; read like the counts above: whatever call finished last)
     uint64_t last_work[3];
