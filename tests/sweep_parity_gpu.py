@@ -17,6 +17,7 @@ from hypo_amd import capi, sim  # noqa: E402
 from hypo_amd.batch import build_batch  # noqa: E402
 import oracle  # noqa: E402
 from test_gpu_fuzz import _window  # noqa: E402
+from test_poa_emulator import _one_sub_windows  # noqa: E402
 
 
 def compare(gpu, orc, b, scores, tag):
@@ -57,6 +58,9 @@ def one_round(gpu, orc, rnd):
     for scores in (default, (3, -6, -5, 3, -5, -4), (1, -1, -1, 1, -1, -1)):
         wins = [_window(rng, False) for _ in range(6000)] + [_window(rng, True) for _ in range(150)]
         total += compare(gpu, orc, build_batch(wins), scores, f"fuzz scores={scores} round={rnd}")
+    # arms one base off the arm before them over low-complexity drafts (Poa::guided_one_sub, Poa::topo_insert)
+    for scores in (default, (2, -1, -2, 3, -5, -4), (4, -3, -5, 3, -5, -4)):
+        total += compare(gpu, orc, build_batch(_one_sub_windows(rng, 8000)), scores, f"one-sub scores={scores} round={rnd}")
     return total
 
 

@@ -111,3 +111,21 @@ def test_both_class0_geometries(gpu, oracle_lib, lanes, monkeypatch):
     assert [i for i in range(len(wins)) if cons[i] != ocons[i] or st[i] != ost[i]] == []
     s = gpu.last_stats()
     assert s["n_failed"] == 0 and s["n_class"][0] > 2000
+
+
+@pytest.mark.parametrize("seed,scores", [(11, (5, -4, -8, 3, -5, -4)), (12, (2, -1, -2, 3, -5, -4)), (13, (4, -3, -5, 3, -5, -4)),
+                                         (14, (3, -6, -5, 3, -5, -4))])
+def test_one_substitution_shapes_vs_oracle(gpu, oracle_lib, seed, scores):
+    """The windows of tests/test_poa_emulator.py::_one_sub_windows (arms one base off the arm before them over two- and
+    three-letter drafts, arms a base short or long, repeated substitutions) on the device: Poa::guided_one_sub and
+    Poa::topo_insert under three score sets that allow the shortcut (other margins between mismatch, gap and two gaps) and one
+    that must refuse it."""
+    from test_poa_emulator import _one_sub_windows
+    rng = np.random.default_rng(8800 + seed)
+    wins = _one_sub_windows(rng, 6000)
+    b = build_batch(wins)
+    cons, st = gpu.poa_consensus(b, scores)
+    ocons, ost = oracle_lib.poa_batch(b, scores=scores)[:2]
+    bad = [i for i in range(len(wins)) if cons[i] != ocons[i] or st[i] != ost[i]]
+    assert not bad, f"{len(bad)} of {len(wins)} windows differ; first: window {bad[0]}"
+    assert gpu.last_stats()["n_failed"] == 0
