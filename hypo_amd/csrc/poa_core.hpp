@@ -110,6 +110,9 @@ struct PoaParamRef {
 #ifndef HYPO_ONE_SUB
 #define HYPO_ONE_SUB 1
 #endif
+#ifndef HYPO_ONE_SUB_ROV
+#define HYPO_ONE_SUB_ROV 1          // ... kROV and kLOV arms too (suffix arms end where the guide ends and may start anywhere; prefix arms start where it starts and may end anywhere)
+#endif
 // a new node in an old clique goes into the literal order without a sort (Poa::topo_insert); 0: every change of the graph is sorted
 #ifndef HYPO_TOPO_INSERT
 #define HYPO_TOPO_INSERT 1
@@ -1130,7 +1133,7 @@ struct Poa {
     //   (prefix) up to q0 the path is forced the same way and starts at a node without in-edges.
     // Returns 2: posnode[] is the alignment (every position aligned; Poa::add_alignment adds the new node at q0); -1: cannot
     // tell, the score rows decide (posnode[] no longer holds the guide).
-    HD bool back_alive(int z, int pos, int q0) const {
+    HD bool back_alive(int z, int pos, int q0, bool rov) const {
         uint64_t cur = 0; int n = 0;                         // up to four candidates, 16 bits each
         bool alive = false;
         auto expand = [&](int u, int ps, uint64_t& dst, int& dn) {
@@ -1139,7 +1142,7 @@ struct Poa {
                 const int sx = (int)inp[u * KIN + p];
                 if ((int)code[sx] != c) continue;
                 if (sx == own) { if (ps <= q0) alive = true; continue; }
-                if (ps == 0) { if (nin[sx] == 0) alive = true; continue; }
+                if (ps == 0) { if (rov || nin[sx] == 0) alive = true; continue; }       // (column 1 is perfect for a node without in-edges; kROV: for any node)
                 bool dup = false;
                 for (int i = 0; i < dn; ++i) dup = dup || (int)((dst >> (16 * i)) & 0xffffu) == sx;
                 if (dup) continue;
@@ -1156,16 +1159,55 @@ struct Poa {
         }
         return alive || n != 0;
     }
-    HD int guided_one_sub(int q0) {                        // (posnode[] holds the path; loops kept rolled: the code is cold next to the score rows it replaces, and must not set the kernel's register count)
+    // A set of nodes, each the last node of a would-be perfect path whose last letter sits in column j, followed backwards column
+    // by column (a byte per node in the score ring, idle here).  True if some chain may be real: it reaches column 1 at a node without
+    // in-edges, is still alive eight columns back, is alive in column jstop, or — skip_path — meets the path: the set then starts
+    // without the path's own last node (the caller accounts for that chain), and a candidate that reaches the path's node of its
+    // column is a second way to spell the letters behind it.
+    HD bool set_alive(bool (&in)[XRPL], int j, int jstop, bool skip_path) {
+        uint8_t* const flag = (uint8_t*)ring;
+        const int jtop = j;
+        for (;; --j) {
+            if (skip_path) {
+                const int pn = (int)posnode[j - 1];
+                bool on_path = false;
+                HYPO_UNROLL
+                for (int q = 0; q < XRPL; ++q) if (q * GW + g.lane == pn) { on_path = in[q]; in[q] = false; }
+                if (j != jtop && g.any(on_path)) return true;
+            }
+            bool some = false, src = false;
+            HYPO_UNROLL
+            for (int q = 0; q < XRPL; ++q) { some = some || in[q]; src = src || (in[q] && nin[q * GW + g.lane] == 0); }
+            if (!g.any(some)) return false;
+            if (j == 1) return g.any(src);
+            if (j == jstop || jtop - j >= 8) return true;
+            const int cb = (int)seq[j - 2];
+            HYPO_UNROLL
+            for (int q = 0; q < XRPL; ++q) { const int u = q * GW + g.lane; if (u < n_nodes) flag[u] = 0; }
+            g.sync();
+            HYPO_UNROLL
+            for (int q = 0; q < XRPL; ++q) {
+                const int u = q * GW + g.lane;
+                if (in[q]) { const int k = (int)nin[u]; for (int p = 0; p < k; ++p) { const int sx = (int)inp[u * KIN + p]; if ((int)code[sx] == cb) flag[sx] = 1; } }
+            }
+            g.sync();
+            HYPO_UNROLL
+            for (int q = 0; q < XRPL; ++q) { const int u = q * GW + g.lane; in[q] = u < n_nodes && flag[u] != 0; }
+            g.sync();
+        }
+    }
+    HD int guided_one_sub(int q0, int mode) {                        // (posnode[] holds the path; loops kept rolled: the code is cold next to the score rows it replaces, and must not set the kernel's register count)
         const int Lu = g.uniform(L);
         q0 = g.uniform(q0);
         if (q0 < 1 || q0 >= Lu - 1) return -1;
+        const bool rov = mode == MODE_ROV;                  // kROV: the first column is free (sisd..cpp:237-239) — a prefix may start at any node, the path's first node too
+        const bool lov = mode == MODE_LOV;                  // kLOV: the end is free — see below
         bool bad = false;
         HYPO_NOUNROLL
         for (int q = g.lane; q < Lu; q += GW) {
             const int u = (int)posnode[q];
             const int k = (int)nin[u];
-            if (q == 0) { if (k != 0) bad = true; }
+            if (q == 0) { if (!rov && k != 0) bad = true; }
             else {
                 const int prev = (int)posnode[q - 1], cp = (int)seq[q - 1];
                 int same = 0; bool own = false;
@@ -1175,15 +1217,37 @@ struct Poa {
                     same += (int)code[src] == cp ? 1 : 0;
                 }
                 if (!own || same != (q == q0 + 1 ? 0 : 1)) bad = true;
-                if (!bad && q > q0) {
+                if (!bad && (lov ? q == q0 + 1 : q > q0)) {
                     for (int p = 0; p < k; ++p) {
                         const int z = (int)inp[u * KIN + p];
-                        if (back_alive(z, q - 1, q0)) bad = true;                      // a vertical step over z
-                        if (z != prev && back_alive(z, q - 2, q0)) bad = true;         // a mismatch on z
+                        if (back_alive(z, q - 1, q0, rov)) bad = true;                 // a vertical step over z
+                        if (z != prev && back_alive(z, q - 2, q0, rov)) bad = true;    // a mismatch on z
                     }
                 }
             }
-            if (q == Lu - 1 && n_out(u) != 0) bad = true;
+            if (!lov && q == Lu - 1 && n_out(u) != 0) bad = true;
+        }
+        if constexpr (GW >= 32) if (lov) {        // (not in class 0's four-groups-per-wave geometry: the node sets would cost it a wave per SIMD)
+            // kLOV ends on any node, so nothing is forced from the end.  Instead: (i) no path from a node without in-edges spells
+            // seq[0 .. q0] — every node that carries the letter of q0, followed backwards, dies — so every rival has its edit at q0 or
+            // before it and is perfect behind it; (ii) the only path that spells what is behind q0 is the guide's: every OTHER node that
+            // carries the last letter, followed backwards, dies before column q0 + 2 without meeting the path (a chain that joins it is a
+            // second end for the same letters: 9-10-11 beside 9-11-12 in a run of C), and the path's own chain ends
+            // at q0 + 1, none of whose in-edge sources carries the letter of q0 — so the edit is AT q0, on or over an in-edge source of
+            // the path's node at q0 + 1 (the entrance searches above).
+            if (g.any(bad)) { DBGR(12); return -1; }
+            bool in[XRPL];
+            const int c0 = (int)seq[q0], cl = (int)seq[Lu - 1];
+            HYPO_UNROLL
+            for (int q = 0; q < XRPL; ++q) { const int u = q * GW + g.lane; in[q] = u < n_nodes && (int)code[u] == c0; }
+            if (set_alive(in, q0 + 1, 0, false)) { DBGR(12); return -1; }
+            HYPO_UNROLL
+            for (int q = 0; q < XRPL; ++q) { const int u = q * GW + g.lane; in[q] = u < n_nodes && (int)code[u] == cl; }
+            if (set_alive(in, Lu, q0 + 2, true)) { DBGR(12); return -1; }
+            tb_steps = Lu; tb_fv = 0;
+            g.sync();
+            DBGR(13);
+            return 2;
         }
         int ns = 0, nl = 0;                                  // sinks; nodes that carry the last letter
         {
@@ -1225,7 +1289,7 @@ struct Poa {
         }
         // (every lane has read its guide nodes before any lane writes posnode[] below: the collectives in between are rendezvous)
         if (g.any(bad)) {
-            if (HYPO_ONE_SUB && strong && sub_ok && mode == MODE_NW) {       // a single letter the guide cannot place: Poa::guided_one_sub
+            if (HYPO_ONE_SUB && strong && sub_ok && (mode == MODE_NW || (HYPO_ONE_SUB_ROV && (mode == MODE_ROV || (GW >= 32 && mode == MODE_LOV))))) {       // a single letter the guide cannot place: Poa::guided_one_sub
                 int nbad = 0, q0 = 0;
                 HYPO_UNROLL
                 for (int t = 0; t < XSL; ++t) {
@@ -1234,10 +1298,12 @@ struct Poa {
                     nbad += popc64(b);
                 }
                 if (nbad == 1) {                             // the path, with the guide's own node at q0 (every lane has read its guide nodes: the ballots were rendezvous)
-                    HYPO_UNROLL
-                    for (int t = 0; t < XSL; ++t) { const int q = t * GW + g.lane; if (q < Lu && q != q0) posnode[q] = (int16_t)v[t]; }
+                    const int x0 = (int)posnode[q0 + d];
                     g.sync();
-                    return guided_one_sub(q0);
+                    HYPO_UNROLL
+                    for (int t = 0; t < XSL; ++t) { const int q = t * GW + g.lane; if (q < Lu) posnode[q] = (int16_t)(q == q0 ? x0 : v[t]); }
+                    g.sync();
+                    return guided_one_sub(q0, mode);
                 }
             }
             DBGR(strong ? 4 : 5); return strong ? -1 : 0;

@@ -222,7 +222,8 @@ struct PoaPrefetch {
 
 #define HYPO_C4_WAVES 2
 // (class 3 — the wide windows, and everything re-queued — is held to four waves per SIMD: it sat at 129 registers with the lazy rank order)
-template <class Cfg> struct PoaMinWaves { static constexpr int value = Cfg::HYBRID ? HYPO_C4_WAVES : (Cfg::DIRG ? 4 : 1); };
+// (class 0's sub-wave geometries sit at the edge of three waves per SIMD, 168 VGPRs: the bound keeps them there)
+template <class Cfg> struct PoaMinWaves { static constexpr int value = Cfg::HYBRID ? HYPO_C4_WAVES : (Cfg::DIRG ? 4 : (Cfg::GW < 64 ? 3 : 1)); };
 // POLL: the kernel runs NEXT to the classes that feed it and takes re-queued windows as they arrive: it leaves when every lane
 // group of every launch of the lower classes has exited (Q.done) and the queue is drained.  Every launch it waits for is
 // submitted BEFORE it, so whatever the streams' mapping to hardware queues is, nothing it depends on can be stuck behind it; a

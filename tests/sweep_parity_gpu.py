@@ -61,6 +61,8 @@ def one_round(gpu, orc, rnd):
     # arms one base off the arm before them over low-complexity drafts (Poa::guided_one_sub, Poa::topo_insert)
     for scores in (default, (2, -1, -2, 3, -5, -4), (4, -3, -5, 3, -5, -4)):
         total += compare(gpu, orc, build_batch(_one_sub_windows(rng, 8000)), scores, f"one-sub scores={scores} round={rnd}")
+    # ... and the same with prefix and suffix arms in every window (kLOV / kROV: free ends inside runs of one letter)
+    total += compare(gpu, orc, build_batch(_one_sub_windows(rng, 30000, mixed_frac=1.0)), default, f"one-sub prefix/suffix arms round={rnd}")
     return total
 
 

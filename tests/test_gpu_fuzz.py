@@ -129,3 +129,13 @@ def test_one_substitution_shapes_vs_oracle(gpu, oracle_lib, seed, scores):
     bad = [i for i in range(len(wins)) if cons[i] != ocons[i] or st[i] != ost[i]]
     assert not bad, f"{len(bad)} of {len(wins)} windows differ; first: window {bad[0]}"
     assert gpu.last_stats()["n_failed"] == 0
+
+
+def test_klov_one_substitution_with_a_second_end(gpu, oracle_lib):
+    """The window of tests/test_poa_emulator.py::test_klov_one_substitution_with_a_second_end on the device, alone and among
+    copies (every class-0 / class-1 lane group of a wave busy with it)."""
+    from test_poa_emulator import _second_end_window
+    b = build_batch([_second_end_window() for _ in range(300)])
+    cons, st = gpu.poa_consensus(b, (5, -4, -8, 3, -5, -4))
+    ocons, ost = oracle_lib.poa_batch(b)[:2]
+    assert [i for i in range(300) if cons[i] != ocons[i] or st[i] != ost[i]] == []

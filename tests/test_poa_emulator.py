@@ -202,33 +202,47 @@ def test_requeue_chain_under_asan():
     assert p.returncode == 0 and "carried" in p.stdout, (p.stdout[-400:], p.stderr[-1200:])
 
 
-def _one_sub_windows(rng, n):
+def _one_sub_windows(rng, n, mixed_frac=0.34):
     """Windows built to sit on the checks of Poa::guided_one_sub: arms that differ from the arm before them in one base, over
     drafts of two or three letters (homopolymer runs, repeats: several in-edge sources carry the letter before), with arms
-    that lack a base or carry one more (triangles: the side entrances of the path), and the same substitution seen twice."""
+    that lack a base or carry one more (triangles: the side entrances of the path), and the same substitution seen twice.
+    A third of the windows mix in suffix arms (kROV: they end where the window ends and may start anywhere) and prefix arms
+    (kLOV), cut at random and edited the same way."""
     from hypo_amd.batch import TextWindow
     wins = []
     for _ in range(n):
         L = int(rng.choice([8, 14, 22, 33, 45, 60, 90, 120]))
         letters = "ACGT"[:int(rng.choice([2, 3, 4]))]
         truth = "".join(letters[i] for i in rng.integers(0, len(letters), size=L))
-        arms = []
-        for _ in range(int(rng.integers(4, 26))):
-            a = list(truth)
+        mixed = rng.random() < mixed_frac
+        internal, prefix, suffix = [], [], []
+
+        def edited(src):
+            a = list(src)
             r = rng.random()
             if r < 0.55:                                  # one substitution
-                a[int(rng.integers(L))] = letters[int(rng.integers(len(letters)))]
+                a[int(rng.integers(len(a)))] = letters[int(rng.integers(len(letters)))]
             elif r < 0.70:                                # two
                 for _ in range(2):
-                    a[int(rng.integers(L))] = letters[int(rng.integers(len(letters)))]
-            elif r < 0.80 and L > 4:                      # a base less
-                del a[int(rng.integers(L))]
+                    a[int(rng.integers(len(a)))] = letters[int(rng.integers(len(letters)))]
+            elif r < 0.80 and len(a) > 4:                 # a base less
+                del a[int(rng.integers(len(a)))]
             elif r < 0.90:                                # a base more
-                a.insert(int(rng.integers(L)), letters[int(rng.integers(len(letters)))])
-            arms.append("".join(a))
+                a.insert(int(rng.integers(len(a))), letters[int(rng.integers(len(letters)))])
+            return "".join(a)
+
+        for _ in range(int(rng.integers(4, 26))):
+            kind = "internal" if not mixed else str(rng.choice(["internal", "suffix", "suffix", "prefix"]))
+            if kind == "internal":
+                dst, src = internal, truth
+            elif kind == "suffix":
+                dst, src = suffix, truth[int(rng.integers(0, max(1, L - 3))):]
+            else:
+                dst, src = prefix, truth[:int(rng.integers(3, L + 1))]
+            dst.append(edited(src))
             if rng.random() < 0.25:
-                arms.append(arms[int(rng.integers(len(arms)))])
-        wins.append(TextWindow(truth, arms, [], []))
+                dst.append(dst[int(rng.integers(len(dst)))])
+        wins.append(TextWindow(truth, internal, prefix, suffix))
     return wins
 
 
@@ -251,3 +265,27 @@ def test_one_substitution_off_the_guide_vs_oracle(seed, scores):
             assert cons[i] == want[i], i
             n_ran += 1
     assert n_ran > 450
+
+
+def _second_end_window():
+    from hypo_amd.batch import TextWindow
+    return TextWindow("ATATAAGCACCCACCGTGTACACGAAAACCCGAATTNTCTGGGCACGCGGGATGTCTGCGGCCCGCTGACG",
+                      ["ATATAAGCACCCCACCGTGTCACGAAAACCGATTATCTGGGACGCGGGATGTCTGCGGCCGCTGACG",
+                       "ATATAAGCACCCACCGTGTACACGAAAACCGAATTATCTGGGCACGCGGGAGGTCTGCGGCCCGCTGACG"],
+                      ["ATATAAGC", "ATATAACACCC", "ATTAAGCACCCACCGTGTACACGAAAA", "ATCTAAGCACC",
+                       "ATATAAGCACCCACCGTGTACACGCAAAACCGAATTATCTGGACACGCGGGATGGT"],
+                      ["TCTGCGGCCCGCTGACG", "GGGATGTCTGCGGCCCGCTGGACG"])
+
+
+def test_klov_one_substitution_with_a_second_end():
+    """Found by tests/sweep_parity_gpu.py (round 4009, window 3941; one in ~5 M windows): the prefix arm ATCTAAGCACC is one base
+    off its guide, whose path ends ..A-C-C on nodes 9-11-12 of a run of three C; 9-10-11 spells the same letters, scores the
+    same and ranks first.  The kLOV variant of Poa::guided_one_sub must see that second end (Poa::set_alive: a chain that
+    joins the path is alive) and leave the arm to the score rows."""
+    import oracle
+    b = build_batch([_second_end_window()])
+    want = oracle.Oracle().poa_batch(b)[0]
+    emu = emu_util.Emu()
+    for cfg in (1, 2, 3):
+        cons, res = emu.poa_chain(b, cfg)[:2]
+        assert res[0] == emu_util.RES_OK and cons[0] == want[0], cfg
