@@ -1131,6 +1131,10 @@ struct Poa {
     //            it would have to pass q0 perfectly); one that meets it at or before q0, reaches a node without in-edges in
     //            column 1, or is still alive eight steps back fails the check;
     //   (prefix) up to q0 the path is forced the same way and starts at a node without in-edges.
+    // kROV arms (suffix arms: they end at the sink like kNW, their first column is free, sisd..cpp:237-239): the same walk back from
+    // the end; a rival's prefix may start at ANY node, so a candidate that reaches column 1 is alive whatever its in-degree, and the
+    // path's first node needs no test.  kLOV arms (prefix arms: they start like kNW and end on any node): nothing is forced from the
+    // end; two searches over node sets take its place (Poa::set_alive, comment in the code below).
     // Returns 2: posnode[] is the alignment (every position aligned; Poa::add_alignment adds the new node at q0); -1: cannot
     // tell, the score rows decide (posnode[] no longer holds the guide).
     HD bool back_alive(int z, int pos, int q0, bool rov) const {
