@@ -286,7 +286,57 @@ def end_to_end_c5_leg():
 T1_3GBP_MD5_ROUND4 = "a4b0764b66b0a285dca0f630a0bbfde9"      # profiles/r04_t1_3gbp.json: 3000 x 1 Mbp, seed 97, -s 3g, identical for -p 50 / -p 100
 
 
-def end_to_end_t1_leg(n_contigs, contig_len=1_000_000, batchings=(10, 50)):
+def t1_reference_pin(d, out_name, n_contigs, k, run, n_pick):
+    """Row T1 pinned at size: a fixed-seed sample of the run's contigs goes, with the records of the SAME BAM file, through the reference's
+    own code compiled in place (oracle/_ref/libhyporef_arms.so, hyporef_fasta_bam: an independent minimal BGZF / BAM decoder hands every
+    record to the reference's Alignment constructor as bam1_t; its own stage, Window::generate_consensus and operator<<(Contig) follow,
+    OpenMP on all host cores in the reference's own loop shape, src/Hypo.cpp:126-268) and every FASTA record must be the bytes the `hypo`
+    binary wrote.  The reference's seconds (without any file decoding: the decoder here is not its work) give the same-box baseline of
+    this shape.  A difference ends the bench: no number is reported for a run that is not the reference's output."""
+    try:
+        import oracle
+        if not oracle.RefArms.available():
+            return {"error": "oracle/_ref/libhyporef_arms.so missing"}
+        pick = sorted(int(x) for x in np.random.default_rng(97).choice(n_contigs, size=min(n_pick, n_contigs), replace=False))
+        ref = oracle.RefArms()
+        tw = time.perf_counter()
+        rr = ref.fasta_file(os.path.join(d, "draft.fa"), os.path.join(d, "sr.bam"), k, os.path.join(d, "aux", "solid_kmers.bvsd"), os.path.join(d, "ref_pick.fa"), pick=pick)
+        tw = time.perf_counter() - tw
+        want = {}
+        with open(os.path.join(d, "ref_pick.fa")) as f:
+            for line in f:
+                if line.startswith(">"):
+                    name = line[1:].split()[0]
+                else:
+                    want[name] = want.get(name, "") + line.rstrip("\n")
+        same, seen, name = 0, 0, None
+        with open(os.path.join(d, out_name)) as f:
+            for line in f:
+                if line.startswith(">"):
+                    name = line[1:].split()[0]
+                elif name in want:
+                    seen += 1
+                    same += line.rstrip("\n") == want[name]
+    except (OSError, RuntimeError) as ex:
+        return {"error": str(ex)[:300]}
+    if len(want) != len(pick) or seen != len(pick) or same != len(pick):
+        raise SystemExit(f"bench: T1: {len(pick) - same} of {len(pick)} sampled contigs differ from the reference's own polish of the same BAM — refusing to report a number")
+    ref_s = rr["alignment_object_seconds"] + rr["stage_seconds"] + rr["poa_seconds"] + rr["write_seconds"]
+    ref_mbp, ref_wps = rr["draft_bases"] / 1e6 / ref_s, rr["windows"] / rr["poa_seconds"]
+    our_wps = run["windows"] / run["poa_seconds_total"] if run["poa_seconds_total"] else None
+    return {"contigs_checked": len(pick), "identical": same, "sample": f"numpy default_rng(97).choice({n_contigs}, {len(pick)}) of the run's contigs, records from the same sr.bam",
+            "ref_seconds": round(ref_s, 2), "ref_threads": rr["threads"], "ref_phases": {"alignment_objects": round(rr["alignment_object_seconds"], 2), "stage": round(rr["stage_seconds"], 2),
+                                                                                       "poa": round(rr["poa_seconds"], 2), "write": round(rr["write_seconds"], 2)},
+            "ref_excludes": f"all file decoding (this harness's BGZF / BAM decoder took {rr['decode_seconds']:.1f} s for the whole file) and loading the solid set; wall of the call {tw:.1f} s",
+            "ref_draft_bases": rr["draft_bases"], "ref_alignments": rr["alignments"], "ref_windows": rr["windows"],
+            "ref_mbp_per_s": round(ref_mbp, 3), "ref_poa_windows_per_s": round(ref_wps, 1),
+            "ours_mbp_per_s": run["mbp_per_s"], "ours_poa_windows_per_s": round(our_wps, 1) if our_wps else None,
+            "same_box_ratio_mbp_per_s": round(run["mbp_per_s"] / ref_mbp, 1), "same_box_ratio_poa_windows_per_s": round(our_wps / ref_wps, 1) if our_wps else None,
+            "what": "ours = the whole `hypo` run of all contigs (file parsing, solid set loading and output included) on this box's GPU + host; "
+                    "ref = the reference's polish of the sampled contigs on this box's host cores, scaled per base / per window"}
+
+
+def end_to_end_t1_leg(n_contigs, contig_len=1_000_000, batchings=(10, 50), pin_contigs=0):
     """Row T1 (north_star: 3 Gbp / 30x short reads on one GPU): `n_contigs` x 1 Mbp from the C++ generator as BAM, `-s <size>` picks k as the
     reference does (1g -> 15, 3g -> 17), the run is made once per contig-batch size in `batchings` and the FASTA of all of them must be
     identical (`-p` invariance); no reference md5 at this size (the real reference needs hours and > 100 GB for it), the same binary
@@ -323,7 +373,8 @@ def end_to_end_t1_leg(n_contigs, contig_len=1_000_000, batchings=(10, 50)):
             m = re.search(r"Overall\. \): TIME= ([0-9.eE+-]+) sec", out)
             overall = float(m.group(1)) if m else wall
             md5s.append(_fasta_md5(os.path.join(d, outp)))
-            os.remove(os.path.join(d, outp))
+            if pb != batchings[-1]:
+                os.remove(os.path.join(d, outp))
             poa = [float(x) for x in re.findall(r"POA of windows\. \): TIME= ([0-9.eE+-]+) sec", out)]
             nwin = sum(int(x) for x in re.findall(r"polished windows \(Batch \d+\): (\d+)", out))
             phases = {}
@@ -332,13 +383,15 @@ def end_to_end_t1_leg(n_contigs, contig_len=1_000_000, batchings=(10, 50)):
             runs.append({"p": pb, "seconds": round(overall, 2), "mbp_per_s": round(rep["draft_bases"] / 1e6 / overall, 2), "process_wall_seconds": round(wall, 2),
                          "peak_rss_mb": rss, "gpu_busy_percent_mean": busy, "windows": nwin, "poa_seconds_total": round(sum(poa), 2), "contig_batches": len(poa), "phases": phases})
         best = min(runs, key=lambda r: r["seconds"])
-        return {"mbp_per_s": best["mbp_per_s"], "seconds": best["seconds"], "draft_bases": rep["draft_bases"], "reads": rep["reads"], "k": kk, "size_flag": size_flag,
+        pin = t1_reference_pin(d, f"out_p{batchings[-1]}.fa", n_contigs, kk, runs[-1], pin_contigs) if pin_contigs else None
+        return {"reference_pin": pin, "mbp_per_s": best["mbp_per_s"], "seconds": best["seconds"], "draft_bases": rep["draft_bases"], "reads": rep["reads"], "k": kk, "size_flag": size_flag,
                 "solid_kmers": rep["solid_kmers"], "peak_rss_mb": best["peak_rss_mb"], "gpu_busy_percent_mean": best["gpu_busy_percent_mean"], "windows": best["windows"],
                 "runs": runs, "fasta_identical_across_batchings": len(set(md5s)) == 1, "fasta_md5": md5s[0], "host_threads": threads,
                 "input_generation_seconds": round(tg, 1), "bam_bytes": os.path.getsize(os.path.join(d, "sr.bam")),
                 "workload": f"T1: {n_contigs} x {contig_len // 1000} kbp draft, 30x 150-bp short reads as BAM, -s {size_flag} -> k = {kk}, hypo binary = host pipeline + device on ONE MI355X, "
                             f"-p {' and -p '.join(str(x) for x in batchings)}; seconds = the binary's Overall timer of the faster run",
-                "fasta": "no reference md5 at this size (the same binary matches the real reference's md5 at 5 / 10 (k = 17) / 17 / 100 / 250 / 1000 Mbp)"}
+                "fasta": "reference_pin: a fixed-seed sample of the contigs byte-identical to the reference's own polish of the same BAM on this box (no md5 of a whole "
+                         "reference run exists at this size; the same binary matches the real reference's md5 at 5 / 10 (k = 17) / 17 / 100 / 250 / 1000 Mbp)"}
     except (subprocess.SubprocessError, OSError, ValueError) as ex:
         return {"error": str(ex)[:300]}
     finally:
@@ -377,6 +430,8 @@ def main():
     ap.add_argument("--no-e2e-k17", action="store_true", help="skip the 10 Mbp run at -s 3g (k = 17, the real reference's md5)")
     ap.add_argument("--t1-contigs", type=int, default=int(os.environ.get("HYPO_BENCH_T1_CONTIGS", "3000")),
                     help="also run row T1 end to end on this many 1 Mbp contigs (3000 = the north star's 3 Gbp; needs ~20 GB of /dev/shm and a few minutes)")
+    ap.add_argument("--t1-pin", type=int, default=int(os.environ.get("HYPO_BENCH_T1_PIN", "150")),
+                    help="contigs of the T1 run (fixed-seed sample) that also go through the reference compiled in place and are compared record by record (0 = none)")
     ap.add_argument("--no-extras", action="store_true", help="skip value_at_0p5pct / value_at_1pct / value_dense / value_c4mix and host_api")
     args = ap.parse_args()
 
@@ -757,14 +812,13 @@ def main():
             e2e_1g = end_to_end_1g_leg()                   # 1 Gbp with the real reference's md5
         if args.t1_contigs > 0:
             # row T1 at size: 3 Gbp / 30x short reads, -s 3g -> k = 17, one -p 50 run (about two minutes of input generation + the run)
-            e2e_t1 = end_to_end_t1_leg(args.t1_contigs, batchings=(50,))
+            # (one -p 50 run; the pin: --t1-pin contigs of it against the reference compiled in place, on this box)
+            e2e_t1 = end_to_end_t1_leg(args.t1_contigs, batchings=(50,), pin_contigs=args.t1_pin)
             if e2e_t1 and "fasta_md5" in e2e_t1 and args.t1_contigs == 3000:
-                # no reference md5 exists at this size; what is checked is that the FASTA is the one this repo's round-4 runs produced
-                # for the same generator arguments at -p 50 and -p 100 (profiles/r04_t1_3gbp.json) — k = 17 itself is pinned to the
-                # reference by e2e_k17_10m above
+                # recorded, not enforced: the md5 of this repo's own round-4 runs of the same generator arguments
+                # (profiles/history/r04_t1_3gbp.json, -p 50 and -p 100) — the check that counts is reference_pin above
                 e2e_t1["fasta_same_as_round4_runs"] = e2e_t1["fasta_md5"] == T1_3GBP_MD5_ROUND4
-                if not e2e_t1["fasta_same_as_round4_runs"]:
-                    raise SystemExit("bench: the 3 Gbp FASTA differs from the one of profiles/r04_t1_3gbp.json — refusing to report a number")
+                e2e_t1["batchings_run"] = [50]
 
     if strong and world > 1:                               # per-rank imbalance of the measured step
         tt = torch.tensor([my_dt], dtype=torch.float64, device=dev)

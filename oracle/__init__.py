@@ -282,14 +282,55 @@ class RefArms:
         return (np.array(pos, dtype=np.uint32), np.array(coff, dtype=np.uint32), np.array(cig or [0], dtype=np.uint32),
                 np.array(soff, dtype=np.uint64), "".join(seq).encode())
 
+    _score_libs = {}
+
+    def _lib_for_scores(self, scores):
+        """The reference keeps its POA engines in statics that Window::prepare_for_poa only ever appends to (src/Window.cpp:28-42) and
+        generate_consensus indexes from the front: a process that polishes with a SECOND score set would still use the first one's
+        engines.  Every score set therefore runs in a private copy of the library (its own statics), like the long-read stage below."""
+        key = tuple(int(x) for x in scores)
+        lib = RefArms._score_libs.get(key)
+        if lib is None:
+            import shutil
+            import tempfile
+            d = tempfile.mkdtemp(prefix="hyporef_scores_")
+            dst = os.path.join(d, "libhyporef_arms_%d.so" % len(RefArms._score_libs))
+            shutil.copy(REF_ARMS_SO, dst)
+            lib = C.CDLL(dst)
+            RefArms._score_libs[key] = lib
+        return lib
+
+    def fasta_file(self, draft_path: str, aln_path: str, k: int, bvsd_path: str, out_path: str, pick=None, min_mapq: int = 2,
+                   scores=(5, -4, -8, 3, -5, -4)) -> dict:
+        """Whole files through the reference (rows T1 and N3 in place; oracle/ref_arms_harness.cpp, hyporef_fasta_bam / _sam): the
+        short-read polish of the contigs `pick` (indices into the draft FASTA; None = all) with the records of a BAM or SAM file, decoded
+        by the harness's own minimal reader and handed to the reference's Alignment constructor as bam1_t.  Returns the timers and counts
+        of the reference's work (seconds: alignment objects, stage, POA loop, output; the decoder's own time apart)."""
+        lib = self._lib_for_scores(scores)
+        fn = getattr(lib, "hyporef_fasta_bam" if aln_path.endswith(".bam") else "hyporef_fasta_sam", None)
+        if fn is None:
+            raise RuntimeError("oracle/_ref/libhyporef_arms.so predates hyporef_fasta_bam: make -C oracle ref")
+        fn.restype = C.c_long
+        pk = np.ascontiguousarray(sorted(set(int(x) for x in pick)) if pick is not None else [], dtype=np.uint32)
+        sec = (C.c_double * 5)()
+        cnt = (C.c_uint64 * 6)()
+        rc = fn(draft_path.encode(), aln_path.encode(), C.c_uint32(k), bvsd_path.encode(), C.c_uint32(pk.size), _ptr(pk) if pk.size else None,
+                C.c_uint32(min_mapq), out_path.encode(), (C.c_int8 * 6)(*scores), sec, cnt)
+        if rc < 0:
+            raise RuntimeError(f"hyporef_fasta_{'bam' if aln_path.endswith('.bam') else 'sam'} rc={rc}")
+        return {"contigs": int(cnt[0]), "draft_bases": int(cnt[1]), "alignments": int(cnt[2]), "invalid": int(cnt[3]), "regions": int(cnt[4]),
+                "windows": int(cnt[5]), "decode_seconds": float(sec[0]), "alignment_object_seconds": float(sec[1]), "stage_seconds": float(sec[2]),
+                "poa_seconds": float(sec[3]), "write_seconds": float(sec[4]), "threads": int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))}
+
     def fasta(self, contig_seq: bytes, name: str, k: int, bvsd_path: str, records, out_path: str, scores=(5, -4, -8, 3, -5, -4)) -> int:
         """The polished FASTA record of one contig written by the reference's own `operator<<(Contig)` after its own short-read
         stage and its own Window::generate_consensus (hyporef_fasta, row A15 in place).  Returns the number of regions."""
         pos, coff, cig, soff, seq = records
         if not hasattr(self.lib, "hyporef_fasta"):
             raise RuntimeError("oracle/_ref/libhyporef_arms.so predates hyporef_fasta: make -C oracle ref")
-        self.lib.hyporef_fasta.restype = C.c_long
-        rc = self.lib.hyporef_fasta(contig_seq, C.c_uint64(len(contig_seq)), name.encode(), C.c_uint32(k), bvsd_path.encode(),
+        lib = self._lib_for_scores(scores)
+        lib.hyporef_fasta.restype = C.c_long
+        rc = lib.hyporef_fasta(contig_seq, C.c_uint64(len(contig_seq)), name.encode(), C.c_uint32(k), bvsd_path.encode(),
                                     C.c_uint32(len(pos)), _ptr(pos), _ptr(coff), _ptr(cig), _ptr(soff), seq, out_path.encode(),
                                     (C.c_int8 * 6)(*scores))
         if rc < 0:

@@ -242,3 +242,363 @@ long hyporef_fasta(const char* contig, uint64_t n, const char* name, uint32_t k,
     ofile << c;                                                            // :261-263
     return (long)num_reg;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 6: whole FILES through the reference's own code — rows T1 (the 3 Gbp north-star run pinned contig by contig) and N3 (record
+// field extraction pinned in place).  An independent minimal decoder (BGZF blocks inflated with plain zlib, BAM records cut out as the
+// SAM specification section 4.2 lays them down; SAM text split on tabs) hands every record to the reference as the bam1_t that htslib's
+// bam_read1 / sam_parse1 would have built: the core fields copied one by one, the variable part (name, CIGAR, 4-bit bases, qualities,
+// tags) VERBATIM from the file behind the NUL-padded name (htslib/sam.h:206-215).  From there on everything is the reference's:
+// the flag / mapping-quality filter of src/Hypo.cpp:299-301 (restated in three lines below because create_alignments itself needs
+// htslib's reader), Alignment::Alignment(Contig&, bam1_t*) with its own bam_get_* field extraction (src/Alignment.cpp:28-38,513-571),
+// the short-read stage, Window::generate_consensus, operator<<(Contig).  Nothing of this repo's readers (hypo_amd/csrc/host/SeqIO.hpp) is
+// used, so "this repo's FASTA record == these bytes" pins its BAM / SAM parsing together with everything behind it.
+// Short reads only (the long-read constructor calls bam_aux_get, which is htslib code; see the header of this file).
+#include <chrono>
+#include <map>
+#include <sstream>
+#include <zlib.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+
+namespace {
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct RawRec {                        // the fixed part of a BAM record (SAM spec 4.2) + where its variable part lies in ContigRecs::bytes
+    int32_t tid, pos; uint8_t l_read_name, mapq; uint16_t bin, flag; uint32_t n_cigar; int32_t l_seq, mtid, mpos, tlen;
+    size_t off, len;                   // read_name .. end of record
+};
+struct ContigRecs { std::vector<RawRec> recs; std::vector<uint8_t> bytes; void clear() { recs.clear(); bytes.clear(); } };
+
+struct FileTotals { double align = 0, stage = 0, poa = 0, write = 0; uint64_t kept = 0, invalid = 0, regions = 0, windows = 0, contigs = 0, bases = 0; };
+
+// One contig through the reference (src/Hypo.cpp:126-268 for a batch of one contig and no -B file)
+void polish_contig(const std::unique_ptr<suk::SolidKmers>& sk, uint32_t k, uint32_t cid, const std::string& name, const std::string& seq,
+                   const ContigRecs& R, std::ostream& out, FileTotals& T) {
+    double t0 = now_s();
+    hypo::Contig c(cid, name, seq);
+    c.find_solid_pos(sk);                                                  // src/Hypo.cpp:100-103
+    double t1 = now_s();
+    T.stage += t1 - t0;
+    std::vector<std::unique_ptr<hypo::Alignment>> als;
+    als.reserve(R.recs.size());
+    std::vector<uint8_t> data;
+    for (const RawRec& r : R.recs) {
+        bam1_t b;
+        std::memset(&b, 0, sizeof b);
+        const uint32_t extranul = (4 - (r.l_read_name & 3)) & 3;           // htslib pads the name so that the CIGAR is 32-bit aligned
+        b.core.tid = r.tid; b.core.pos = r.pos; b.core.bin = r.bin; b.core.qual = r.mapq; b.core.l_extranul = (uint8_t)extranul;
+        b.core.flag = r.flag; b.core.l_qname = (uint16_t)(r.l_read_name + extranul); b.core.n_cigar = r.n_cigar; b.core.l_qseq = r.l_seq;
+        b.core.mtid = r.mtid; b.core.mpos = r.mpos; b.core.isize = r.tlen;
+        // (+ 16 bytes per CIGAR operation of slack: Alignment::copy_data copies n_cigar * 4 UINT32s from the CIGAR's address, src/Alignment.cpp:565-567)
+        data.assign(r.len + extranul + 16ull * r.n_cigar + 16, 0);
+        std::memcpy(data.data(), R.bytes.data() + r.off, r.l_read_name);
+        std::memcpy(data.data() + r.l_read_name + extranul, R.bytes.data() + r.off + r.l_read_name, r.len - r.l_read_name);
+        b.data = data.data();
+        b.l_data = (int)(r.len + extranul);
+        b.m_data = (uint32_t)data.size();
+        als.emplace_back(std::make_unique<hypo::Alignment>(c, &b));       // src/Hypo.cpp:309
+        if (!als.back()->is_valid) { als.pop_back(); ++T.invalid; }        // :314-318
+    }
+    T.kept += als.size();
+    double t2 = now_s();
+    T.align += t2 - t1;
+    #pragma omp parallel for
+    for (uint64_t t = 0; t < als.size(); ++t) als[t]->update_solidkmers_support(k, c);      // :135-142
+    c.prepare_for_division(k);
+    #pragma omp parallel for
+    for (uint64_t t = 0; t < als.size(); ++t) als[t]->update_minimisers_support(c);
+    c.divide_into_regions();
+    #pragma omp parallel for
+    for (uint64_t t = 0; t < als.size(); ++t) als[t]->find_short_arms(k, c);
+    c.fill_short_windows(als);
+    als.clear();                                                           // :196-199 (the alignments of the batch are released before the POA)
+    double t3 = now_s();
+    T.stage += t3 - t2;
+    const uint64_t num_reg = c.get_num_regions();
+    uint64_t nwin = 0;
+    #pragma omp parallel for schedule(static, 1) reduction(+ : nwin)
+    for (uint64_t w = 0; w < num_reg; ++w)
+        if (c.is_valid_window(w)) { c.generate_consensus(w, omp_get_thread_num()); ++nwin; }   // :238-247
+    double t4 = now_s();
+    T.poa += t4 - t3;
+    out << c;                                                              // :261-263
+    T.write += now_s() - t4;
+    T.regions += num_reg; T.windows += nwin; T.contigs += 1; T.bases += seq.size();
+}
+
+// minimal FASTA reader: the name is the header line up to the first blank (kseq's rule), the sequence every following line joined
+bool read_fasta(const char* path, std::vector<std::string>& names, std::vector<std::string>& seqs, const std::vector<char>* want) {
+    std::ifstream f(path);
+    if (!f.is_open()) return false;
+    std::string line;
+    long idx = -1; bool keep = false;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (!line.empty() && line[0] == '>') {
+            ++idx;
+            size_t e = 1; while (e < line.size() && line[e] != ' ' && line[e] != '\t') ++e;
+            names.emplace_back(line.substr(1, e - 1)); seqs.emplace_back();
+            keep = !want || ((size_t)idx < want->size() && (*want)[(size_t)idx]);
+        } else if (idx >= 0 && keep) seqs.back() += line;
+    }
+    return true;
+}
+
+// BGZF: gzip members with a 'BC' extra subfield that holds the member's size (SAM spec 4.1).  The stream is inflated in runs of blocks,
+// side by side (plain zlib, raw deflate, CRC-32 and ISIZE checked); take() hands out the next n bytes of the inflated stream.
+struct BgzfStream {
+    const uint8_t* map = nullptr; size_t size = 0, at = 0;
+    std::vector<uint8_t> buf; size_t head = 0, len = 0;      // buf[head, len) = inflated bytes not handed out yet (buf only grows: no zero-fill per run)
+    bool bad = false;
+    bool open(const char* path) {
+        int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st; if (fstat(fd, &st) != 0) { ::close(fd); return false; }
+        size = (size_t)st.st_size;
+        void* p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        if (p == MAP_FAILED) return false;
+        map = (const uint8_t*)p;
+        return true;
+    }
+    ~BgzfStream() { if (map) munmap((void*)map, size); }
+    bool fill() {                                   // appends the next run of blocks behind the unread tail; false at the end of the file
+        if (at >= size || bad) return false;
+        struct Blk { size_t c0, clen, out, isize; };
+        std::vector<Blk> blks;
+        size_t total = 0;
+        while (at < size && blks.size() < 4096) {
+            if (at + 18 > size || map[at] != 0x1f || map[at + 1] != 0x8b || map[at + 2] != 8 || !(map[at + 3] & 4)) { bad = true; return false; }
+            const size_t xlen = map[at + 10] | (size_t)map[at + 11] << 8;
+            size_t bsize = 0, x = at + 12;
+            while (x + 4 <= at + 12 + xlen) {
+                const size_t slen = map[x + 2] | (size_t)map[x + 3] << 8;
+                if (map[x] == 'B' && map[x + 1] == 'C' && slen == 2) bsize = (map[x + 4] | (size_t)map[x + 5] << 8) + 1;
+                x += 4 + slen;
+            }
+            if (!bsize || at + bsize > size || bsize < 12 + xlen + 8) { bad = true; return false; }
+            const size_t isize = map[at + bsize - 4] | (size_t)map[at + bsize - 3] << 8 | (size_t)map[at + bsize - 2] << 16 | (size_t)map[at + bsize - 1] << 24;
+            blks.push_back({at + 12 + xlen, bsize - 12 - xlen - 8, total, isize});
+            total += isize; at += bsize;
+        }
+        if (head) { std::memmove(buf.data(), buf.data() + head, len - head); len -= head; head = 0; }
+        const size_t base = len;
+        if (buf.size() < base + total) buf.resize(base + total);
+        len = base + total;
+        int failed = 0;
+        #pragma omp parallel for schedule(dynamic, 16) reduction(+ : failed)
+        for (size_t i = 0; i < blks.size(); ++i) {
+            const Blk& b = blks[i];
+            if (!b.isize) continue;
+            z_stream zs; std::memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) { ++failed; continue; }
+            zs.next_in = (Bytef*)(map + b.c0); zs.avail_in = (uInt)b.clen;
+            zs.next_out = buf.data() + base + b.out; zs.avail_out = (uInt)b.isize;
+            const int rc = inflate(&zs, Z_FINISH);
+            const bool ok = rc == Z_STREAM_END && zs.total_out == b.isize;
+            inflateEnd(&zs);
+            const uint8_t* t = map + b.c0 + b.clen;
+            const uint32_t crc = t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+            if (!ok || (uint32_t)crc32(crc32(0, nullptr, 0), buf.data() + base + b.out, (uInt)b.isize) != crc) ++failed;
+        }
+        if (failed) { bad = true; return false; }
+        return true;
+    }
+    const uint8_t* take(size_t n) {
+        while (len - head < n) if (!fill()) return nullptr;
+        const uint8_t* p = buf.data() + head;
+        head += n;
+        return p;
+    }
+};
+int32_t le32(const uint8_t* p) { int32_t v; std::memcpy(&v, p, 4); return v; }
+uint16_t le16(const uint8_t* p) { uint16_t v; std::memcpy(&v, p, 2); return v; }
+
+struct FileJob {
+    std::unique_ptr<suk::SolidKmers> sk;
+    uint32_t k = 0, min_mapq = 2;
+    std::vector<std::string> names, seqs;
+    std::vector<char> want;                         // by contig index of the draft file; empty = all
+    std::map<std::string, uint32_t> cname_to_id;   // src/Hypo.cpp:88 (_cname_to_id)
+    std::ofstream out;
+    FileTotals T;
+    ContigRecs cur; long cur_cid = -1;
+    std::vector<char> done;
+    bool picked(uint32_t cid) const { return want.empty() || (cid < want.size() && want[cid]); }
+    void flush() {
+        if (cur_cid >= 0) { polish_contig(sk, k, (uint32_t)cur_cid, names[(size_t)cur_cid], seqs[(size_t)cur_cid], cur, out, T); done[(size_t)cur_cid] = 1; }
+        cur.clear(); cur_cid = -1;
+    }
+    // A record of contig `cid` in file order.  The records of a contig are taken to be contiguous in the file (coordinate-sorted or
+    // grouped by reference, as every set of this repo is); a contig that comes back after another one was begun is an error (-4).
+    int record(uint32_t cid, const RawRec& r, const uint8_t* var) {
+        if (r.flag & (0x4 | 0x100 | 0x200 | 0x400)) return 0;             // BAM_FUNMAP | BAM_FSECONDARY | BAM_FQCFAIL | BAM_FDUP, src/Hypo.cpp:299
+        if (r.mapq < min_mapq) return 0;                                   // :301
+        if (!picked(cid)) return 0;
+        if ((long)cid != cur_cid) { if (done[cid]) return -4; flush(); cur_cid = (long)cid; }
+        RawRec q = r; q.off = cur.bytes.size();
+        cur.bytes.insert(cur.bytes.end(), var, var + r.len);
+        cur.recs.push_back(q);
+        return 0;
+    }
+    // picked contigs without a single kept record are polished too (the reference writes every contig of the draft), in draft order at the end
+    void finish() {
+        flush();
+        for (size_t c = 0; c < names.size(); ++c) if (picked((uint32_t)c) && !done[c]) { cur_cid = (long)c; flush(); }
+    }
+};
+
+bool job_begin(FileJob& J, const char* draft_path, uint32_t k, const char* bvsd_path, uint32_t n_pick, const uint32_t* pick, uint32_t min_mapq,
+               const char* out_path, const int8_t* scores) {
+    J.k = k; J.min_mapq = min_mapq;
+    J.sk = std::make_unique<suk::SolidKmers>(k);
+    if (!J.sk->load(std::string(bvsd_path))) return false;
+    if (n_pick) { uint32_t mx = 0; for (uint32_t i = 0; i < n_pick; ++i) mx = pick[i] > mx ? pick[i] : mx; J.want.assign((size_t)mx + 1, 0); for (uint32_t i = 0; i < n_pick; ++i) J.want[pick[i]] = 1; }
+    if (!read_fasta(draft_path, J.names, J.seqs, n_pick ? &J.want : nullptr)) return false;
+    for (size_t c = 0; c < J.names.size(); ++c) J.cname_to_id[J.names[c]] = (uint32_t)c;
+    J.done.assign(J.names.size(), 0);
+    J.out.open(out_path);
+    if (!J.out.is_open()) return false;
+    hypo::Contig::set_no_long_reads();                                     // src/Hypo.cpp:230-232 (a run without -B)
+    static bool engines = false;                                           // Window::prepare_for_poa appends engines at every call (src/Window.cpp:31-42): once per process
+    if (!engines) {
+        hypo::ScoreParams sp{scores[0], scores[1], scores[2], scores[3], scores[4], scores[5]};
+        hypo::Window::prepare_for_poa(sp, (hypo::UINT32)omp_get_max_threads());   // :237
+        engines = true;
+    }
+    return true;
+}
+void job_report(const FileJob& J, double decode_s, double* seconds, uint64_t* counts) {
+    if (seconds) { seconds[0] = decode_s; seconds[1] = J.T.align; seconds[2] = J.T.stage; seconds[3] = J.T.poa; seconds[4] = J.T.write; }
+    if (counts) { counts[0] = J.T.contigs; counts[1] = J.T.bases; counts[2] = J.T.kept; counts[3] = J.T.invalid; counts[4] = J.T.regions; counts[5] = J.T.windows; }
+}
+}  // namespace
+
+extern "C" __attribute__((visibility("default")))
+// The reference's short-read polish of the contigs `pick[0..n_pick)` (indices into the draft FASTA; n_pick = 0: every contig) with the
+// records of a BAM file, written to out_path in draft order of first appearance in the BAM (contigs without records last).  One process
+// may call this with ONE score set only (the reference keeps its engines in statics).  seconds[5]: this decoder (not the reference's
+// work), Alignment objects, stage (find_solid_pos, votes, division, arms, windows), POA loop, operator<<; counts[6]: contigs, draft bases,
+// alignments kept, invalid, regions, valid windows.  Returns the number of contigs written; -1 solid set / draft / output cannot be
+// opened, -3 malformed BAM, -4 a contig's records are not contiguous, -5 a reference name that the draft does not have (src/Hypo.cpp:303-306).
+long hyporef_fasta_bam(const char* draft_path, const char* bam_path, uint32_t k, const char* bvsd_path, uint32_t n_pick, const uint32_t* pick,
+                       uint32_t min_mapq, const char* out_path, const int8_t* scores, double* seconds, uint64_t* counts) {
+    FileJob J;
+    if (!job_begin(J, draft_path, k, bvsd_path, n_pick, pick, min_mapq, out_path, scores)) return -1;
+    BgzfStream S;
+    if (!S.open(bam_path)) return -1;
+    double decode = 0, t0 = now_s();
+    const uint8_t* p = S.take(8);
+    if (!p || std::memcmp(p, "BAM\1", 4) != 0) return -3;
+    const int32_t l_text = le32(p + 4);
+    if (l_text < 0 || !S.take((size_t)l_text)) return -3;
+    p = S.take(4); if (!p) return -3;
+    const int32_t n_ref = le32(p);
+    std::vector<long> tid_to_cid((size_t)(n_ref > 0 ? n_ref : 0), -1);
+    for (int32_t i = 0; i < n_ref; ++i) {
+        p = S.take(4); if (!p) return -3;
+        const int32_t l_name = le32(p);
+        p = S.take((size_t)l_name + 4); if (!p || l_name < 1) return -3;
+        auto it = J.cname_to_id.find(std::string((const char*)p, (size_t)l_name - 1));
+        if (it != J.cname_to_id.end()) tid_to_cid[(size_t)i] = it->second;
+    }
+    for (;;) {
+        p = S.take(4);
+        if (!p) break;
+        const int32_t bs = le32(p);
+        if (bs < 32) return -3;
+        p = S.take((size_t)bs);
+        if (!p) return -3;
+        RawRec r;
+        r.tid = le32(p); r.pos = le32(p + 4); r.l_read_name = p[8]; r.mapq = p[9]; r.bin = le16(p + 10); r.n_cigar = le16(p + 12); r.flag = le16(p + 14);
+        r.l_seq = le32(p + 16); r.mtid = le32(p + 20); r.mpos = le32(p + 24); r.tlen = le32(p + 28);
+        r.off = 0; r.len = (size_t)bs - 32;
+        if ((size_t)r.l_read_name + 4ull * r.n_cigar + ((size_t)r.l_seq + 1) / 2 + (size_t)r.l_seq > r.len) return -3;
+        if (r.flag & (0x4 | 0x100 | 0x200 | 0x400)) continue;              // (before the name lookup, as src/Hypo.cpp:299-306 orders them)
+        if (r.mapq < min_mapq) continue;
+        if (r.tid < 0 || r.tid >= n_ref || tid_to_cid[(size_t)r.tid] < 0) return -5;
+        const uint32_t cid = (uint32_t)tid_to_cid[(size_t)r.tid];
+        if (!J.picked(cid)) continue;
+        decode += now_s() - t0;
+        const int rc = J.record(cid, r, p + 32);
+        if (rc) return rc;
+        t0 = now_s();
+    }
+    if (S.bad) return -3;
+    decode += now_s() - t0;
+    J.finish();
+    job_report(J, decode, seconds, counts);
+    return (long)J.T.contigs;
+}
+
+extern "C" __attribute__((visibility("default")))
+// The same from SAM text: every alignment line split on tabs, CIGAR and bases encoded as sam_parse1 stores them (operation codes
+// "MIDNSHP=XB", 4-bit bases "=ACMGRSVTWYHKDBN", qualities minus 33 or 0xff for "*"), no tags (the short-read path reads none).
+long hyporef_fasta_sam(const char* draft_path, const char* sam_path, uint32_t k, const char* bvsd_path, uint32_t n_pick, const uint32_t* pick,
+                       uint32_t min_mapq, const char* out_path, const int8_t* scores, double* seconds, uint64_t* counts) {
+    FileJob J;
+    if (!job_begin(J, draft_path, k, bvsd_path, n_pick, pick, min_mapq, out_path, scores)) return -1;
+    std::ifstream f(sam_path);
+    if (!f.is_open()) return -1;
+    double decode = 0, t0 = now_s();
+    std::string line;
+    std::vector<uint8_t> var;
+    static const char kOps[] = "MIDNSHP=XB", kNt[] = "=ACMGRSVTWYHKDBN";
+    while (std::getline(f, line)) {
+        if (line.empty() || line[0] == '@') continue;
+        if (line.back() == '\r') line.pop_back();
+        std::vector<std::string> fld;
+        { size_t a = 0; while (fld.size() < 11) { size_t b = line.find('\t', a); if (b == std::string::npos) { fld.emplace_back(line.substr(a)); break; } fld.emplace_back(line.substr(a, b - a)); a = b + 1; } }
+        if (fld.size() < 11) return -3;
+        RawRec r; std::memset(&r, 0, sizeof r);
+        r.flag = (uint16_t)std::strtoul(fld[1].c_str(), nullptr, 10);
+        r.mapq = (uint8_t)std::strtoul(fld[4].c_str(), nullptr, 10);
+        if (r.flag & (0x4 | 0x100 | 0x200 | 0x400)) continue;
+        if (r.mapq < min_mapq) continue;
+        auto it = J.cname_to_id.find(fld[2]);
+        if (it == J.cname_to_id.end()) return -5;
+        const uint32_t cid = it->second;
+        if (!J.picked(cid)) continue;
+        r.tid = (int32_t)cid; r.pos = (int32_t)std::strtol(fld[3].c_str(), nullptr, 10) - 1; r.mtid = -1; r.mpos = -1;
+        var.clear();
+        var.insert(var.end(), fld[0].begin(), fld[0].end()); var.push_back(0);
+        if (var.size() > 255) return -3;
+        r.l_read_name = (uint8_t)var.size();
+        uint32_t ncig = 0;
+        if (fld[5] != "*") {
+            const char* s = fld[5].c_str();
+            while (*s) {
+                char* e; const unsigned long n = std::strtoul(s, &e, 10);
+                const char* o = std::strchr(kOps, *e);
+                if (e == s || !*e || !o) return -3;
+                const uint32_t v = (uint32_t)(n << 4) | (uint32_t)(o - kOps);
+                var.insert(var.end(), (const uint8_t*)&v, (const uint8_t*)&v + 4);
+                ++ncig; s = e + 1;
+            }
+        }
+        r.n_cigar = ncig;
+        const std::string& sq = fld[9];
+        const size_t lq = sq == "*" ? 0 : sq.size();
+        r.l_seq = (int32_t)lq;
+        const size_t s0 = var.size();
+        var.resize(s0 + (lq + 1) / 2 + lq, 0);
+        for (size_t i = 0; i < lq; ++i) {
+            const char ch = (char)std::toupper((unsigned char)sq[i]);
+            const char* o = std::strchr(kNt, ch);
+            const uint8_t code = (o && ch) ? (uint8_t)(o - kNt) : 15;
+            var[s0 + (i >> 1)] |= (uint8_t)(code << ((~i & 1) << 2));
+        }
+        if (fld[10] == "*" || fld[10].size() != lq) std::memset(var.data() + s0 + (lq + 1) / 2, 0xff, lq);
+        else for (size_t i = 0; i < lq; ++i) var[s0 + (lq + 1) / 2 + i] = (uint8_t)(fld[10][i] - 33);
+        r.len = var.size();
+        decode += now_s() - t0;
+        const int rc = J.record(cid, r, var.data());
+        if (rc) return rc;
+        t0 = now_s();
+    }
+    decode += now_s() - t0;
+    J.finish();
+    job_report(J, decode, seconds, counts);
+    return (long)J.T.contigs;
+}

@@ -312,3 +312,94 @@ def run_vs_reference_stage(outdir, seed, device, messy, threads=4, long_reads=Fa
 
 SIZE_FLAG_OF_K = {7: "10k", 9: "100k", 11: "1m", 13: "100m", 15: "250m", 17: "3g"}     # -s values and the k they derive
 LAST_LONG_WINDOWS = 0          # LONG windows among those the last run_vs_reference_stage call compared
+
+
+# ---- whole FILES through the reference compiled in place (rows T1 and N3; oracle/ref_arms_harness.cpp: hyporef_fasta_bam / _sam) -------
+def fasta_records(path):
+    """{name: sequence} of a FASTA file (the name up to the first blank)."""
+    d, name, parts = {}, None, []
+    with open(path) as f:
+        for line in f:
+            if line.startswith(">"):
+                if name is not None:
+                    d[name] = "".join(parts)
+                name, parts = line[1:].split()[0], []
+            else:
+                parts.append(line.rstrip("\n"))
+    if name is not None:
+        d[name] = "".join(parts)
+    return d
+
+
+def run_messy_files_vs_reference(outdir, seed, device, as_bam, threads=4):
+    """One messy set WITHOUT long reads (1-3 contigs; clips, `=`/`X`, unmapped / secondary / duplicate / QC-fail flags, low mapping
+    qualities, N and lower case, non-default -q / scores): this repo's `hypo` reads the SAM or BAM file with its own readers
+    (host/SeqIO.hpp); the reference's code gets the same file through the harness's independent minimal decoder as bam1_t records and
+    applies its own field extraction (Alignment::initialise_pos / copy_data).  The two FASTA files must hold the same records byte for
+    byte: row N3 pinned in place, no CMake-built binary in between.  Returns the number of alignments the reference kept, or None when
+    the seed's set has long reads."""
+    import oracle
+    os.makedirs(str(outdir), exist_ok=True)
+    gen = _gen()
+    args, nc, with_long = gen.generate_messy(str(outdir), seed)
+    if with_long:
+        return None
+    aln = "sr.sam"
+    if as_bam:
+        import bam_util
+        bam_util.sam_to_bam(os.path.join(str(outdir), "sr.sam"), os.path.join(str(outdir), "sr.bam"), nm_type="i", extra_tags=True)
+        aln = "sr.bam"
+        args = list(args)
+        args[args.index("-b") + 1] = aln
+    k = {v: kk for kk, v in SIZE_FLAG_OF_K.items()}[args[args.index("-s") + 1]]
+    mq = int(args[args.index("-q") + 1]) if "-q" in args else 2
+    sc = [5, -4, -8, 3, -5, -4]
+    for i, fl in enumerate(("-m", "-x", "-g", "-M", "-X", "-G")):
+        if fl in args:
+            sc[i] = int(args[args.index(fl) + 1])
+    argv = [BIN] + list(args)
+    argv[argv.index("-t") + 1] = str(threads)
+    env = dict(os.environ)
+    if device == "shim":
+        env["LD_LIBRARY_PATH"] = SHIM_DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    else:
+        env.setdefault("HYPO_REQUIRE_DEVICE", "1")
+    p = subprocess.run(argv, cwd=str(outdir), env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert ("oracle_device_shim" in p.stderr) == (device == "shim"), "wrong device library behind the C-ABI"
+    ref = oracle.RefArms()
+    rep = ref.fasta_file(os.path.join(str(outdir), "draft.fa"), os.path.join(str(outdir), aln), k, os.path.join(str(outdir), "aux", "solid_kmers.bvsd"),
+                         os.path.join(str(outdir), "ref_files.fa"), min_mapq=mq, scores=sc)
+    ours, theirs = fasta_records(os.path.join(str(outdir), "hypo_draft.fasta")), fasta_records(os.path.join(str(outdir), "ref_files.fa"))
+    assert list(ours) and set(ours) == set(theirs) and rep["contigs"] == nc, (seed, list(ours), list(theirs))
+    for name in ours:
+        assert ours[name] == theirs[name], f"messy seed {seed} ({aln}): record {name} differs from the reference's own polish of the same file"
+    return rep["alignments"]
+
+
+def run_t1_slice_vs_reference(outdir, n_contigs, contig_len, k, size_flag, pick, threads, device="gpu", seed=97, p=50):
+    """Row T1's shape (x 1 Mbp contigs from the C++ generator as BAM, `-s <size_flag>` -> k) through this repo's `hypo`, and the contigs
+    `pick` through the reference compiled in place with the records of the same BAM file (hyporef_fasta_bam).  Returns (our seconds,
+    the reference's report, number of picked records that are byte-identical)."""
+    import time
+    import oracle
+    gen = build_fast_generator()
+    rep = json.loads(subprocess.check_output([gen, str(outdir), str(seed), str(n_contigs), str(contig_len), str(k), "30", "150", "2000", "--bam", "--fast-hash"], text=True))
+    argv = [BIN, "-d", "draft.fa", "-r", "reads.fa", "-s", size_flag, "-c", "30", "-b", "sr.bam", "-t", str(threads), "-i", "-p", str(p), "-o", "out.fa"]
+    env = dict(os.environ)
+    if device == "shim":
+        env["LD_LIBRARY_PATH"] = SHIM_DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    else:
+        env.setdefault("HYPO_REQUIRE_DEVICE", "1")
+    t0 = time.perf_counter()
+    pr = subprocess.run(argv, cwd=str(outdir), env=env, capture_output=True, text=True, timeout=3000)
+    dt = time.perf_counter() - t0
+    assert pr.returncode == 0, pr.stdout[-2000:] + pr.stderr[-2000:]
+    assert f"({size_flag}): {k}" in pr.stdout, pr.stdout[:400]
+    ref = oracle.RefArms()
+    rr = ref.fasta_file(os.path.join(str(outdir), "draft.fa"), os.path.join(str(outdir), "sr.bam"), k, os.path.join(str(outdir), "aux", "solid_kmers.bvsd"),
+                        os.path.join(str(outdir), "ref_pick.fa"), pick=pick)
+    ours, theirs = fasta_records(os.path.join(str(outdir), "out.fa")), fasta_records(os.path.join(str(outdir), "ref_pick.fa"))
+    assert len(ours) == rep["contigs"] and len(theirs) == len(set(pick))
+    same = sum(1 for name in theirs if ours.get(name) == theirs[name])
+    return dt, rr, same

@@ -147,3 +147,27 @@ def test_host_long_read_stage_vs_real_filter_and_alignment_code(tmp_path):
             n_long += e2e_util.LAST_LONG_WINDOWS
             done += 1
     assert done >= 4 and total > 300 and n_long >= 10, (done, total, n_long)
+
+
+def test_files_through_the_reference_in_place(tmp_path):
+    """Rows N3 and T1 on the CPU: whole alignment FILES, not parsed records, go to the reference's code (hyporef_fasta_sam / _bam: the
+    harness's independent minimal SAM / BGZF + BAM decoder lays every record out as bam1_t, the reference's own constructor extracts
+    the fields) and the FASTA records must be the bytes this repo's `hypo` (own readers, host/SeqIO.hpp, over the CPU shim) wrote: the
+    messy seeds without long reads as SAM text and as BAM with tags, and a 6 x 100 kbp set of T1's generator with three picked contigs."""
+    import pytest
+    import oracle
+    import e2e_util
+    if not oracle.RefArms.available():
+        pytest.skip("oracle/_ref/libhyporef_arms.so not built (the real reference only exists in the build container)")
+    e2e_util.build_binary()
+    e2e_util.build_shim()
+    done, kept, multi = 0, 0, 0
+    for seed in range(400, 424):
+        for as_bam in (False, True):
+            n = e2e_util.run_messy_files_vs_reference(tmp_path / f"m{seed}_{int(as_bam)}", seed, "shim", as_bam)
+            if n is not None:
+                done += 1
+                kept += n
+    assert done >= 12 and kept > 5000, (done, kept)
+    dt, rr, same = e2e_util.run_t1_slice_vs_reference(tmp_path / "t1", 6, 100000, 11, "1m", [1, 3, 4], 4, device="shim", p=2)
+    assert same == 3 and rr["contigs"] == 3 and rr["windows"] > 3000, (same, rr)
