@@ -417,6 +417,11 @@ int hypo_gpu_set_option(const char* name, int value) {
         for (int i = 0; i < kMaxDevices; ++i) g_ctxs[i].poa_flags = (g_ctxs[i].poa_flags & ~hypo::POA_NATIVE_KLOV) | (value ? hypo::POA_NATIVE_KLOV : 0);
         return HYPO_OK;
     }
+    if (!strcmp(name, "poa_min_class")) {                // 0 .. 3: SHORT windows start in at least this size class (parity sweeps: every class's code on small windows)
+        if (value < 0 || value > 3) return fail(HYPO_E_INVALID, "poa_min_class %d out of range 0..3", value);
+        for (int i = 0; i < kMaxDevices; ++i) g_ctxs[i].poa_flags = (g_ctxs[i].poa_flags & ~(3 << hypo::POA_MIN_CLASS_SHIFT)) | (value << hypo::POA_MIN_CLASS_SHIFT);
+        return HYPO_OK;
+    }
     return fail(HYPO_E_INVALID, "unknown option %s", name);
 }
 

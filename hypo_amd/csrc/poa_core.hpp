@@ -82,7 +82,7 @@ struct PoaParams {
 };
 // opt-in: rank kLOV end rows by the maximum over the whole row, like the AVX2 / SSE4.1 engine of a -march=native build of the
 // reference does (simd_alignment_engine.cpp:803,834-840; traceback still starts in column L, :859-861)
-enum { POA_NATIVE_KLOV = 1 };
+enum { POA_NATIVE_KLOV = 1, POA_MIN_CLASS_SHIFT = 8 };      // bits 8-9: smallest size class a SHORT window starts in (0 = the plan's choice)
 
 // How the per-window code reaches PoaParams.  On the device it is a pointer into the kernel-argument segment
 // (constant address space) that is made opaque at every use, so each use is a fresh scalar load instead of nine
@@ -343,6 +343,7 @@ struct Poa {
 #if defined(HYPO_PHASE_TIMERS) || defined(HYPO_EMU)
 #define HYPO_DIAG(x) do { x; } while (0)
     uint32_t rows_done, topo_runs, cons_serial, rows_slow, exact_tries, guided_hits, rows_scored_n, topo_dfs, topo_fast;
+    uint32_t one_sub_hits, cols_hits, topo_inserts, lazy_updates, tie_sorts;      // hits of guided_one_sub / thread_cols / topo_insert, lazy_update calls, first_of_rows calls
 #else
 #define HYPO_DIAG(x) do { } while (0)
 #endif
@@ -384,7 +385,7 @@ struct Poa {
         n_paths = 0; path_used = 0; head_first = 0;
         n_nodes = 0; L = 0; topo_dirty = false; meta_dirty = true; tb_steps = 0; tb_fv = 0;
         last_changed = true; threaded = false;
-        HYPO_DIAG(rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; guided_hits = 0; rows_scored_n = 0; topo_dfs = 0; topo_fast = 0);
+        HYPO_DIAG(rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; guided_hits = 0; rows_scored_n = 0; topo_dfs = 0; topo_fast = 0; one_sub_hits = 0; cols_hits = 0; topo_inserts = 0; lazy_updates = 0; tie_sorts = 0);
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;
         tlast = 0;
         HYPO_TICK_RESET();
@@ -2007,7 +2008,7 @@ struct Poa {
                     stat[ST_LASTX] = hit ? 1u : 0u;
                     if (hit) stat[ST_XHITS] += 1;
                 }
-                HYPO_DIAG(exact_tries += 1; guided_hits += weights_done ? 1u : 0u);
+                HYPO_DIAG(exact_tries += 1; guided_hits += weights_done ? 1u : 0u; one_sub_hits += hit == 2 ? 1u : 0u; cols_hits += (hit == 1 && !weights_done) ? 1u : 0u);
                 if (hit == 2) return RES_OK;                   // aligned, one substitution off the guide: posnode[] goes to add_alignment
                 if (hit) { threaded = true; return RES_OK; }
             } else stat_set(ST_LASTX, 0u);
@@ -2017,9 +2018,12 @@ struct Poa {
             if constexpr (Cfg::LAZY) {
                 if (lazy_on && ntie_pk > 1) {
                     // several rows share the best end value: the reference takes the first of them in ITS rank order
-                    if (ntie_pk > PK_TIECAP) return RES_OVERFLOW;         // (the class that takes the window over sorts first)
+                    // (the class that takes the window over sorts first, makes this alignment again and counts it there)
+                    if (ntie_pk > PK_TIECAP) { stat_add(ST_CSCORED, 0u - (uint32_t)((n_nodes + 1) * W)); return overflow_late(); }
                     g.sync();
+                    HYPO_DIAG(tie_sorts += 1);
                     const int rc = first_of_rows(posnode + 1, ntie_pk, &best_i);
+                    if (rc == RES_OVERFLOW) { stat_add(ST_CSCORED, 0u - (uint32_t)((n_nodes + 1) * W)); return overflow_late(); }
                     if (rc != RES_OK) return rc;
                 }
             }
@@ -2495,13 +2499,13 @@ struct Poa {
             // the usual change — a new base or two, each a new node in an old clique with its two edges — keeps the literal order up
             // to where the new nodes go (Poa::topo_insert); anything else is sorted again
             if (changed && order_was_valid && ti_ok && ti_n > 0 && fv == 0 && !lazy_on_()) {
-                if (topo_insert(ti_q, ti_n, n_old, g.reduce_add(ne))) topo_dirty = false;
+                if (topo_insert(ti_q, ti_n, n_old, g.reduce_add(ne))) { topo_dirty = false; HYPO_DIAG(topo_inserts += 1); }
             }
         }
         last_changed = changed;
         if constexpr (Cfg::LAZY) {
             if (lazy_on) {                                 // the order stays valid: new edges follow it, new nodes are slotted in
-                if (n_new > 0) lazy_update(n_old);
+                if (n_new > 0) { lazy_update(n_old); HYPO_DIAG(lazy_updates += 1); }
                 topo_dirty = false;
             }
         }
@@ -3330,7 +3334,7 @@ struct Poa {
         g.sync();
         if (g.lane < ST_N) stat[g.lane] = 0;
         g.sync();
-        HYPO_DIAG(rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; guided_hits = 0; rows_scored_n = 0; topo_dfs = 0; topo_fast = 0);
+        HYPO_DIAG(rows_done = 0; topo_runs = 0; cons_serial = 0; rows_slow = 0; exact_tries = 0; guided_hits = 0; rows_scored_n = 0; topo_dfs = 0; topo_fast = 0; one_sub_hits = 0; cols_hits = 0; topo_inserts = 0; lazy_updates = 0; tie_sorts = 0);
         n_paths = 0; path_used = 0; head_first = 0; L = 0; tb_steps = 0; tb_fv = 0;
         lazy_on = false; n_new = 0; guide_len = -1;
         for (int i = 0; i < PH_N; ++i) tphase[i] = 0;

@@ -39,7 +39,7 @@ constexpr int PLAN_STAGE = 8192;          // arm lengths staged per workgroup (3
 constexpr int PLAN_LANES = 4;             // lanes per window in poa_plan_count_kernel
 constexpr int PLAN_WPB = PLAN_THREADS / PLAN_LANES;
 
-__device__ __forceinline__ uint32_t plan_key_from(const HypoWindow& W, uint32_t maxarm, uint32_t changes, bool* trivial) {
+__device__ __forceinline__ uint32_t plan_key_from(const HypoWindow& W, uint32_t maxarm, uint32_t changes, bool* trivial, int min_short_class = 0) {
     const uint32_t narm = W.n_internal + W.n_prefix + W.n_suffix;
     // longest sequence the window will align (markers included) and a node estimate: the first sequence's chain plus what the
     // arms that differ from their predecessor are expected to add (`changes`: differing packed bytes between consecutive internal
@@ -61,6 +61,7 @@ __device__ __forceinline__ uint32_t plan_key_from(const HypoWindow& W, uint32_t 
             (uint64_t)est_nodes * S <= (uint64_t)lim[c].dircells && lim[c].ringcells / (int)S >= 6) { cls = c; break; }
     }
     if (W.type != HYPO_WIN_SHORT && cls < kFirstLongClass) cls = kFirstLongClass;
+    if (W.type == HYPO_WIN_SHORT && cls < min_short_class) cls = min_short_class;      // hypo_gpu_set_option("poa_min_class"): parity sweeps run small windows through the code of the larger classes
     *trivial = W.n_empty > narm || narm < 2;
     // cost ~ rows x sequences; bucket 0 = most expensive of the class
     const uint32_t cost = *trivial ? 0u : maxlen * (narm + 1);
@@ -140,7 +141,7 @@ poa_plan_count_kernel(PoaParams P, PoaQueues Q, uint32_t n_windows) {
         }
         if (w < n_windows && sub == 0) {
             bool trivial;
-            const uint32_t key = plan_key_from(W, maxarm, changes, &trivial);
+            const uint32_t key = plan_key_from(W, maxarm, changes, &trivial, (P.flags >> POA_MIN_CLASS_SHIFT) & 3);
             Q.keys[w] = (uint16_t)key;
             Q.carry[w] = 0;                                   // no spill yet (poa_class_kernel sets it when it re-queues the window)
             atomicAdd(&hist[key], 1u);
@@ -263,7 +264,7 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
     uint32_t carry_in = 0;                                      // Q.carry value of the window in hand
 #ifdef HYPO_PHASE_TIMERS
     uint64_t tph[PH_N] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t dbg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t dbg[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const uint64_t tstart = (uint64_t)clock64();
 #endif
     // what happens to a window once Poa::run / step has returned something other than RES_CONTINUE
@@ -283,7 +284,7 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
         }
 #ifdef HYPO_PHASE_TIMERS
         for (int i = 0; i < PH_N; ++i) tph[i] += poa.tphase[i];
-        dbg[0] += poa.rows_done; dbg[1] += stt[PoaT::ST_ALIGNS] - stt[PoaT::ST_REUSED]; dbg[2] += stt[PoaT::ST_REUSED]; dbg[3] += poa.topo_runs; dbg[4] += poa.cons_serial; dbg[5] += poa.rows_slow; dbg[6] += poa.exact_tries; dbg[7] += stt[PoaT::ST_XHITS]; dbg[8] += poa.guided_hits; dbg[9] += poa.rows_scored_n; dbg[10] += poa.topo_dfs; dbg[11] += poa.topo_fast;
+        dbg[0] += poa.rows_done; dbg[1] += stt[PoaT::ST_ALIGNS] - stt[PoaT::ST_REUSED]; dbg[2] += stt[PoaT::ST_REUSED]; dbg[3] += poa.topo_runs; dbg[4] += poa.cons_serial; dbg[5] += poa.rows_slow; dbg[6] += poa.exact_tries; dbg[7] += stt[PoaT::ST_XHITS]; dbg[8] += poa.guided_hits; dbg[9] += poa.rows_scored_n; dbg[10] += poa.topo_dfs; dbg[11] += poa.topo_fast; dbg[12] += poa.one_sub_hits; dbg[13] += poa.cols_hits; dbg[14] += poa.topo_inserts; dbg[15] += poa.lazy_updates; dbg[16] += poa.tie_sorts;
 #endif
         if (rc == RES_OK) {
             if (g.lane == 0) {                                  // algorithmic bytes, SURVEY.md 8(d)
@@ -449,11 +450,12 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
         atomicAdd((unsigned long long*)&st->cells_scored, (unsigned long long)c_scored);
         atomicAdd((unsigned long long*)&st->cells_threaded, (unsigned long long)c_thr);
 #ifdef HYPO_PHASE_TIMERS
-        unsigned long long* ph = (unsigned long long*)((char*)fresh(ka)->Q.count + 512) + (size_t)cls * 24;   // header + 512: [class][24]
+        static_assert(kNumPoaClasses * 32 * 8 <= 2048 - 512 && PH_N + 2 + 17 <= 32, "phase block of the header");
+        unsigned long long* ph = (unsigned long long*)((char*)fresh(ka)->Q.count + 512) + (size_t)cls * 32;   // header + 512: [class][32]
         for (int i = 0; i < PH_N; ++i) atomicAdd(&ph[i], (unsigned long long)tph[i]);
         atomicAdd(&ph[PH_N], (unsigned long long)((uint64_t)clock64() - tstart));                // wave lifetime
         atomicAdd(&ph[PH_N + 1], 1ull);                                                           // waves
-        for (int i = 0; i < 12; ++i) atomicAdd(&ph[PH_N + 2 + i], (unsigned long long)dbg[i]);      // rows, real alignments, reused, toposorts, serial consensus passes, slow rows, exact tries / hits
+        for (int i = 0; i < 17; ++i) atomicAdd(&ph[PH_N + 2 + i], (unsigned long long)dbg[i]);      // rows, real alignments, reused, toposorts, serial consensus passes, slow rows, exact tries / hits
 #endif
         // this group will push nothing more: what it re-queued is in the queues (a polling kernel of a later class counts these)
         __threadfence();

@@ -128,7 +128,10 @@ int hypo_gpu_use_device(int slot);
 /* Opt-in behaviour switches (all contexts; set before the POA calls they should affect):
  *   "native_klov"  1 = rank the end rows of prefix arms (kLOV) by the maximum over the whole row, as the AVX2 / SSE4.1 alignment
  *                  engine of a -march=native build of the reference does (external/spoa/src/simd_alignment_engine.cpp:803,
- *                  834-840,859-861); 0 (default) = the scalar engine's rule, which the reference's default build uses. */
+ *                  834-840,859-861); 0 (default) = the scalar engine's rule, which the reference's default build uses.
+ *   "poa_min_class" 0..3 (default 0): SHORT windows start in at least this size class of the POA kernel.  Results do not depend on it
+ *                  (every class computes the reference's consensus); parity sweeps use it to run small windows through the code
+ *                  of the larger classes (tests/exhaustive_parity.py). */
 int hypo_gpu_set_option(const char* name, int value);
 /* First 16 hex digits of the SHA-256 over the library's sources (the .hip and .hpp files of hypo_amd/csrc and this header, in sorted
  * order), embedded at build time: says which sources a prebuilt libhypo_gpu.so came from (tests/test_abi.py checks it). */

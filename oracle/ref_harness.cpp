@@ -132,11 +132,18 @@ int hyporef_batch(const int8_t sc[6], const HypoWindowBatch* in, HypoConsensusBa
     const int base = g_engines;
     Window::prepare_for_poa(sp, (UINT32)n_threads);
     g_engines += n_threads;
+    std::vector<uint8_t> undefined(n, 0);
     const auto t0 = std::chrono::steady_clock::now();
 #pragma omp parallel for schedule(static, 1) num_threads(n_threads)
-    for (int64_t w = 0; w < (int64_t)n; ++w) ws[w]->generate_consensus((UINT32)(base + omp_get_thread_num()));
+    for (int64_t w = 0; w < (int64_t)n; ++w) {
+        // (a window the reference itself cannot answer — its consensus is shorter than the two markers that Window.hpp:144 cuts off, the
+        // iterator range is negative and libstdc++ throws — is reported as HYPO_ST_UNDEFINED; nothing else is caught)
+        try { ws[w]->generate_consensus((UINT32)(base + omp_get_thread_num())); }
+        catch (const std::length_error&) { undefined[w] = 1; }
+    }
     if (seconds_out) *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (uint32_t w = 0; w < n; ++w) {
+        if (undefined[w]) { out->len[w] = 0; out->status[w] = HYPO_ST_UNDEFINED; continue; }
         const std::string c = ws[w]->get_consensus();
         const uint64_t cap = out->off[w + 1] - out->off[w];
         out->len[w] = (uint32_t)c.size();

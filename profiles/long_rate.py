@@ -43,7 +43,7 @@ def main():
         import numpy as np
         names = ["load_seq", "dp_rows", "traceback", "add_alignment", "toposort", "consensus", "output", "rowmeta", "exact_rows"]
         NP = len(names)                                   # then lifetime, waves, 10 counters (poa_kernel.hip)
-        ph = db.workspace[512:512 + 8 * 24 * 8].cpu().numpy().view(np.uint64).reshape(8, 24)
+        ph = db.workspace[512:512 + 6 * 32 * 8].cpu().numpy().view(np.uint64).reshape(6, 32)
         c = 4
         tot = float(ph[c, :NP].sum())
         nw = max(st['n_class'][c], 1)

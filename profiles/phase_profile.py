@@ -12,7 +12,7 @@ import torch  # noqa: E402
 from hypo_amd import capi, sim  # noqa: E402
 
 NAMES = ["load_seq", "score_rows", "traceback", "add_alignment", "toposort", "consensus", "output", "rowmeta", "exact_rows", "wave_lifetime", "waves"]
-NP = 9      # phases; then lifetime, waves, 10 counters (poa_kernel.hip)
+NP = 9      # phases; then lifetime, waves, 17 counters (poa_kernel.hip)
 
 
 def main():
@@ -26,9 +26,9 @@ def main():
         db.run()
     torch.cuda.synchronize()
     st = db.stats()
-    ph = db.workspace[512:512 + 8 * 24 * 8].cpu().numpy().view(np.uint64).reshape(8, 24)
+    ph = db.workspace[512:512 + 6 * 32 * 8].cpu().numpy().view(np.uint64).reshape(6, 32)      # poa_kernel.hip: [class][32]
     print("windows per class", st["n_class"], "escalated", st["n_escalated"])
-    for c in range(8):
+    for c in range(6):
         if ph[c, NP + 1] == 0 or st['n_class'][c] == 0:
             continue
         tot = float(ph[c, :NP].sum())

@@ -20,9 +20,28 @@ from test_gpu_fuzz import _window  # noqa: E402
 from test_poa_emulator import _one_sub_windows  # noqa: E402
 
 
+REF = oracle.Ref() if oracle.Ref.available() else None      # the real reference classes compiled in place (oracle/_ref/libhyporef.so)
+REF_SLICE = 25000                                            # windows of every comparison that also go through it
+REF_CHECKED = [0]
+
+
 def compare(gpu, orc, b, scores, tag):
     bases, off, ln, st = gpu.poa_batch(b, scores)
     ob, ooff, oln, ost = orc.poa_batch_raw(b, scores=scores)[:4]
+    if REF is not None:
+        # a slice of every batch against hypo::Window::generate_consensus itself, not only against the restatement
+        from hypo_amd import dist as hd
+        import exhaustive_parity as ex
+        n = min(b.n_windows, REF_SLICE)
+        sb = hd.take_windows(b, 0, n, compact=True)
+        soff = sb.slot_layout()
+        rb, _, rln, rst, _ = REF.poa_batch_raw(sb, scores=scores, off=soff)
+        gb2, _, gln2, gst2 = gpu.poa_batch(sb, scores, off=soff)
+        w = ex.first_difference((gb2, gln2, gst2), (rb, rln, rst), soff)
+        if w >= 0:
+            print(f"MISMATCH vs the REAL reference {tag}: window {w}: {ex.describe(sb, w)}", flush=True)
+            sys.exit(1)
+        REF_CHECKED[0] += n
     bad = np.nonzero((ln != oln) | (st != ost))[0]
     if len(bad) == 0:
         for i in np.nonzero(st == 0)[0]:
@@ -75,8 +94,8 @@ def main():
     while time.time() < t_end:
         rnd += 1
         total += one_round(gpu, orc, rnd)
-        print(f"round {rnd}: {total} windows identical so far", flush=True)
-    print(f"OK: {total} windows, 0 mismatches")
+        print(f"round {rnd}: {total} windows identical to the oracle so far, {REF_CHECKED[0]} of them also to oracle/_ref/libhyporef.so", flush=True)
+    print(f"OK: {total} windows, 0 mismatches ({REF_CHECKED[0]} windows also compared with the real reference classes)")
 
 
 if __name__ == "__main__":
