@@ -243,8 +243,9 @@ def end_to_end_fast_leg(name, bam, what):
                 "peak_rss_mb": rss, "gpu_busy_percent_mean": busy, "host_threads": threads,
                 "windows": nwin, "poa_seconds_total": round(sum(poa), 3), "contig_batches": len(poa),
                 "input_generation_seconds": round(tg, 1), "alignment_file": ("BAM (BGZF, inflated in parallel by " + (re.search(r"BGZF blocks are inflated by (\w+)", out).group(1) if re.search(r"BGZF blocks are inflated by (\w+)", out) else "?") + ")") if bam else "SAM text",
-                "reference": {"seconds": man["reference_run"]["overall_seconds"], "threads": man["reference_run"]["threads"],
-                              "peak_rss_mb": man["reference_run"]["peak_rss_mb"], "where": man["reference_run"]["host"] + " (not this box)"},
+                "reference": ({"seconds": man["reference_run"]["overall_seconds"], "threads": man["reference_run"]["threads"],
+                               "peak_rss_mb": man["reference_run"]["peak_rss_mb"], "where": man["reference_run"]["host"] + " (not this box)"} if "reference_run" in man else
+                              {"pinned_by": man.get("pinned_by")}),
                 "workload": what,
                 "fasta": "md5 identical to the real reference's output for these inputs"}
     except (subprocess.SubprocessError, OSError, ValueError) as ex:
@@ -276,6 +277,60 @@ def end_to_end_1g_leg():
 def end_to_end_k17_leg():
     return end_to_end_fast_leg("e2e_k17_10m_s117", True,
                                "k = 17 against the reference: 10 x 1 Mbp draft, 30x 150-bp reads (1.99 M records as BAM), -s 3g -> k = 17 (2 GiB solid set), one run")
+
+
+def end_to_end_real_leg():
+    return end_to_end_fast_leg("e2e_real_5m_s131", True,
+                               "non-i.i.d. inputs end to end: 5 x 1 Mbp with 15 % of the genome in tandem repeats / homopolymer runs / dispersed copies, a second haplotype (0.1 % SNPs, "
+                               "0.04 % 1-base indels), 150-bp reads at 30x with 0.2 % substitutions + 0.05 % indels each way (x 5 in homopolymers), 0.2 % mis-placed reads, k = 11, -p 2; "
+                               "the md5 is that of the reference compiled in place (oracle/_ref/libhyporef_arms.so) on the same files")
+
+
+def value_repeat_leg(gpu, torch, dev):
+    """windows/s of the POA call on the REAL windows of the non-i.i.d. 5 Mbp set, as the reference itself cut them (tests/e2e_util.py:
+    realistic_window_batch), next to the headline's simulator batch; every consensus is compared with the string the reference's own
+    Window::generate_consensus left in its dump."""
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import e2e_util as eu
+        import oracle
+        if not oracle.RefArms.available():
+            return {"error": "oracle/_ref/libhyporef_arms.so missing (the windows are cut by the reference compiled in place)"}
+        d = tempfile.mkdtemp(prefix="hypo_bench_real_")
+        try:
+            b, cons, man, rr = eu.realistic_window_batch(d)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+        off = b.slot_layout()
+        dbs = [gpu.device_batch(b, off=off) for _ in range(2)]
+        for _ in range(2):
+            for x in dbs:
+                x.run()
+        cnt = [0]
+        def call():
+            dbs[cnt[0] % 2].run()
+            cnt[0] += 1
+        t = timed(call, 6, lambda: torch.cuda.synchronize(dev))
+        bases, _, ln, st = dbs[1].results()
+        same = bool((st == 0).all()) and all(bases[int(off[i]):int(off[i]) + int(ln[i])].tobytes() == cons[i].encode() for i in range(b.n_windows))
+        if not same:
+            raise SystemExit("bench: value_repeat: device consensus differs from the reference's own — refusing to report a number")
+        s = dbs[1].stats()
+        na = max(s["n_alignments"], 1)
+        w = b.windows
+        return {"value": round(b.n_windows / t, 1), "unit": "windows/s", "ms_per_call": round(t * 1e3, 3), "windows": b.n_windows, "arms": b.n_arms,
+                "mean_draft_len": round(float(w["draft_len"].mean()), 1), "windows_per_class": s["n_class"][:6], "requeued_windows": s["n_escalated"], "failed": s["n_failed"],
+                "alignments": {"total": s["n_alignments"], "reused": round(s["n_reused"] / na, 4), "threaded": round(s["n_threaded"] / na, 4),
+                               "scored": round(1.0 - (s["n_reused"] + s["n_threaded"]) / na, 4), "cells_scored": s["cells_scored"]},
+                "gcups": round(s["dp_cells"] / t / 1e9, 1),
+                "reference_same_box": {"poa_seconds": round(rr["poa_seconds"], 3), "windows_per_s": round(rr["windows"] / rr["poa_seconds"], 1), "threads": rr["threads"], "kind": "reference"},
+                "parity": f"all {b.n_windows} consensus strings identical to the reference's own dump",
+                "workload": "POA call only on the real windows of the non-i.i.d. 5 Mbp set (e2e_real_5m_s131: repeats, second haplotype, read indels, mis-placed reads), "
+                            "cut by the reference compiled in place; two resident copies alternate"}
+    except (OSError, RuntimeError, ImportError, AssertionError) as ex:
+        return {"error": str(ex)[:300]}
 
 
 def end_to_end_c5_leg():
@@ -673,6 +728,8 @@ def main():
         extra["value_c4mix"] = {"value": round(408000 / t5, 1), "unit": "windows/s", "ms_per_call": round(t5 * 1e3, 3), "failed": cdb.stats()["n_failed"],
                                 "workload": "C4 window mix: 400 000 C1-shaped SHORT + 8 000 LONG windows (120-500 bp, 12-45 noisy long-read arms) in one batch, POA call only"}
         del cdb
+        if os.environ.get("HYPO_BENCH_VALUE_REPEAT", "1") == "1":
+            extra["value_repeat"] = value_repeat_leg(gpu, torch, dev)
         # the N > 1 workload on ONE GPU: the like-for-like base of the scaling curve (BASELINE configs[2]: the same 1.94 M windows,
         # the same 100 scans of 1 Mbp at k = 13, the same resident-input protocol; only the all-gather has nobody to talk to)
         if os.environ.get("HYPO_BENCH_VALUE_C3", "1") == "1":
@@ -796,6 +853,7 @@ def main():
     e2e_1g = None
     e2e_k17 = None
     e2e_c5 = None
+    e2e_real = None
     if rank == 0 and world == 1 and not args.no_e2e and not strong:
         e2e = end_to_end_leg()
         if not args.no_e2e_c3:
@@ -804,6 +862,7 @@ def main():
             e2e_k15 = end_to_end_k15_leg()
         if not args.no_e2e_c4:
             e2e_c4 = end_to_end_c4_leg()
+        e2e_real = end_to_end_real_leg()                   # non-i.i.d. genome, second haplotype, read indels (round 6), md5 of the reference compiled in place
         if not args.no_e2e_k17:
             e2e_k17 = end_to_end_k17_leg()                 # k = 17 (-s 3g) pinned to the real reference on 10 Mbp
         if not args.no_e2e_c5:
@@ -852,7 +911,7 @@ def main():
                        "contig_bases": total_bases, "k": k,
                        "parallelism": f"window sharding x{world}" + (" + RCCL all-gather of consensus" if world > 1 else "")},
             "mbp_per_s": round(total_bases * args.steps / dt / 1e6, 2),
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "e2e": e2e, "e2e_c3": e2e_c3, "e2e_k15_250m": e2e_k15, "e2e_c4_250m": e2e_c4, "e2e_k17_10m": e2e_k17, "e2e_c5_slice": e2e_c5, "e2e_1g": e2e_1g, "e2e_t1": e2e_t1,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "e2e": e2e, "e2e_c3": e2e_c3, "e2e_k15_250m": e2e_k15, "e2e_c4_250m": e2e_c4, "e2e_k17_10m": e2e_k17, "e2e_real_5m": e2e_real, "e2e_c5_slice": e2e_c5, "e2e_1g": e2e_1g, "e2e_t1": e2e_t1,
         }
         if imbalance:
             out["imbalance"] = imbalance

@@ -3,6 +3,7 @@
 // SURVEY.md Appendix A.4/A.5 and the cited lines; data lives in flat vectors and BitVec instead of sdsl objects and
 // per-k-mer heap nodes.
 #include "Contig.hpp"
+#include <atomic>
 #include <omp.h>
 #include <fcntl.h>
 #include <unistd.h>
@@ -126,6 +127,12 @@ void Contig::ensure_kids() {
     for (int64_t i = 0; i < (int64_t)_n_solid; ++i) _kids[(size_t)i] = kmer_at(_solid_pos.select((uint64_t)i + 1), _scan_k);
 }
 
+// Which branches of the segmentation a run reached (printed by Hypo::polish under HYPO_STAGE_COUNTERS=1; the manifests of the round-6
+// goldens quote them): [0] solid k-mers accepted with 40-80 % support (src/Contig.cpp:104-109), [1] such k-mers refused because the
+// one before was one too, [2] Contig::force_divide calls (src/Contig.cpp:630-711), [3] minimizers dropped because they recur in their
+// mega-window, [4] poly-base minimizers dropped (src/Contig.cpp:509-511)
+std::atomic<uint64_t> g_stage_counters[5];
+
 // ---- Contig::prepare_for_division (src/Contig.cpp:75-185) -----------------------------------------------------------
 void Contig::prepare_for_division(unsigned k) {
     std::vector<uint32_t> sr_pos, sr_len;
@@ -162,7 +169,7 @@ void Contig::prepare_for_division(unsigned k) {
             if (cov >= Sr_settings.cov_th) {
                 const uint32_t supp_th = (uint32_t)(Sr_settings.supp_frac * cov);
                 if (sup >= 2 * supp_th) { is_valid = true; pvs_80 = true; }
-                else if (sup >= supp_th) { if (pvs_80) is_valid = true; pvs_80 = false; }
+                else if (sup >= supp_th) { if (pvs_80) is_valid = true; pvs_80 = false; g_stage_counters[is_valid ? 0 : 1].fetch_add(1, std::memory_order_relaxed); }
             }
             if (is_valid) {
                 if (!in_sr) { first_kind = i; first_sr_pos = pos; in_sr = true; }
@@ -242,9 +249,9 @@ void Contig::initialise_minimserinfo(const std::string& draft_seq, uint32_t minf
     MWMinimiserInfo& mi = _minimserinfo[minfoind];
     last_found_position = 0;
     for (size_t i = 0; i < found.size(); ++i) {
-        if (counter[found[i]] != 1) continue;
+        if (counter[found[i]] != 1) { g_stage_counters[3].fetch_add(1, std::memory_order_relaxed); continue; }
         const uint32_t m = found[i];
-        if (m == Minimizer_settings.polyA || m == Minimizer_settings.polyC || m == Minimizer_settings.polyG || m == Minimizer_settings.polyT) continue;
+        if (m == Minimizer_settings.polyA || m == Minimizer_settings.polyC || m == Minimizer_settings.polyG || m == Minimizer_settings.polyT) { g_stage_counters[4].fetch_add(1, std::memory_order_relaxed); continue; }
         mi.minimisers.push_back(m);
         mi.rel_pos.push_back(found_pos[i] - last_found_position);
         last_found_position = found_pos[i];
@@ -351,6 +358,7 @@ void Contig::divide(uint32_t reg_index, uint32_t beg, uint32_t end, char pvs, ch
 
 // ---- Contig::force_divide (src/Contig.cpp:630-711) --------------------------------------------------------------------
 void Contig::force_divide(uint32_t beg, uint32_t end, char pvs, char nxt) {
+    g_stage_counters[2].fetch_add(1, std::memory_order_relaxed);
     uint32_t start = beg, remaining = end - start;
     std::vector<uint32_t> cut_pos;
     while (remaining > Window_settings.ideal_swind_size) {

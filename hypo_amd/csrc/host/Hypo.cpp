@@ -10,7 +10,9 @@
 #include <fstream>
 #include <iostream>
 
+#include <atomic>
 namespace hypo {
+extern std::atomic<uint64_t> g_stage_counters[5];      // host/Contig.cpp
 
 Hypo::Hypo(const InputFlags& flags) : _cFlags(flags) {
     omp_set_num_threads((int)_cFlags.threads);
@@ -523,6 +525,10 @@ void Hypo::polish() {
     stop("[Hypo:Hypo]: Writing results. ");
     _times.overall = std::chrono::duration<double>(std::chrono::steady_clock::now() - _tstart).count();
     std::fprintf(stdout, "RESOURCES ([Hypo:Hypo]: Overall. ): TIME= %g sec.\n", _times.overall);
+    if (std::getenv("HYPO_STAGE_COUNTERS"))
+        std::fprintf(stdout, "[Hypo::Hypo] Info: stage counters: solid k-mers accepted with 40-80 %% support %llu, refused after another such k-mer %llu; force_divide calls %llu; "
+                             "minimizers dropped as recurring %llu, as poly-base %llu\n", (unsigned long long)g_stage_counters[0].load(), (unsigned long long)g_stage_counters[1].load(),
+                     (unsigned long long)g_stage_counters[2].load(), (unsigned long long)g_stage_counters[3].load(), (unsigned long long)g_stage_counters[4].load());
     // (1.5 M windows with their arms and consensus strings: freed contig by contig on all threads, 0.37 s of the C3 run's wall otherwise)
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t i = 0; i < (int64_t)_contigs.size(); ++i) _contigs[(size_t)i].reset();

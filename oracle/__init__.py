@@ -284,11 +284,12 @@ class RefArms:
 
     _score_libs = {}
 
-    def _lib_for_scores(self, scores):
+    def _lib_for_scores(self, scores, long_run=False):
         """The reference keeps its POA engines in statics that Window::prepare_for_poa only ever appends to (src/Window.cpp:28-42) and
         generate_consensus indexes from the front: a process that polishes with a SECOND score set would still use the first one's
         engines.  Every score set therefore runs in a private copy of the library (its own statics), like the long-read stage below."""
-        key = tuple(int(x) for x in scores)
+        # (... and Contig::set_no_long_reads() of a run without -B is sticky as well: runs with long reads get copies of their own)
+        key = tuple(int(x) for x in scores) + (bool(long_run),)
         lib = RefArms._score_libs.get(key)
         if lib is None:
             import shutil
@@ -301,21 +302,32 @@ class RefArms:
         return lib
 
     def fasta_file(self, draft_path: str, aln_path: str, k: int, bvsd_path: str, out_path: str, pick=None, min_mapq: int = 2,
-                   scores=(5, -4, -8, 3, -5, -4)) -> dict:
+                   scores=(5, -4, -8, 3, -5, -4), long_path=None, ned_th: int = 20, dump_dir=None) -> dict:
         """Whole files through the reference (rows T1 and N3 in place; oracle/ref_arms_harness.cpp, hyporef_fasta_bam / _sam): the
         short-read polish of the contigs `pick` (indices into the draft FASTA; None = all) with the records of a BAM or SAM file, decoded
         by the harness's own minimal reader and handed to the reference's Alignment constructor as bam1_t.  Returns the timers and counts
         of the reference's work (seconds: alignment objects, stage, POA loop, output; the decoder's own time apart)."""
-        lib = self._lib_for_scores(scores)
-        fn = getattr(lib, "hyporef_fasta_bam" if aln_path.endswith(".bam") else "hyporef_fasta_sam", None)
+        lib = self._lib_for_scores(scores, long_run=long_path is not None)
+        bam = aln_path.endswith(".bam")
+        if long_path is not None and not (bam and long_path.endswith(".bam")):
+            raise RuntimeError("long reads (-B) go through the BAM entry point only")
+        fn = getattr(lib, "hyporef_fasta_bam2" if bam else "hyporef_fasta_sam", None)
         if fn is None:
-            raise RuntimeError("oracle/_ref/libhyporef_arms.so predates hyporef_fasta_bam: make -C oracle ref")
+            raise RuntimeError("oracle/_ref/libhyporef_arms.so predates hyporef_fasta_bam2: make -C oracle ref")
         fn.restype = C.c_long
         pk = np.ascontiguousarray(sorted(set(int(x) for x in pick)) if pick is not None else [], dtype=np.uint32)
         sec = (C.c_double * 5)()
         cnt = (C.c_uint64 * 6)()
-        rc = fn(draft_path.encode(), aln_path.encode(), C.c_uint32(k), bvsd_path.encode(), C.c_uint32(pk.size), _ptr(pk) if pk.size else None,
-                C.c_uint32(min_mapq), out_path.encode(), (C.c_int8 * 6)(*scores), sec, cnt)
+        # dump_dir: the reference's own per-region dump (type, arms, draft, consensus) of every polished contig goes to <dump_dir>/aux/inspect_<contig>.txt
+        lib.hyporef_set_dump_dir.restype = None
+        lib.hyporef_set_dump_dir(dump_dir.encode() if dump_dir else None)
+        if bam:
+            # (long_path: the long reads of a `-B` file through the SHORT-read constructor; rc -6 = a record the reference's NM filter would drop)
+            rc = fn(draft_path.encode(), aln_path.encode(), long_path.encode() if long_path else None, C.c_uint32(k), bvsd_path.encode(), C.c_uint32(pk.size),
+                    _ptr(pk) if pk.size else None, C.c_uint32(min_mapq), C.c_uint32(ned_th), out_path.encode(), (C.c_int8 * 6)(*scores), sec, cnt)
+        else:
+            rc = fn(draft_path.encode(), aln_path.encode(), C.c_uint32(k), bvsd_path.encode(), C.c_uint32(pk.size), _ptr(pk) if pk.size else None,
+                    C.c_uint32(min_mapq), out_path.encode(), (C.c_int8 * 6)(*scores), sec, cnt)
         if rc < 0:
             raise RuntimeError(f"hyporef_fasta_{'bam' if aln_path.endswith('.bam') else 'sam'} rc={rc}")
         return {"contigs": int(cnt[0]), "draft_bases": int(cnt[1]), "alignments": int(cnt[2]), "invalid": int(cnt[3]), "regions": int(cnt[4]),

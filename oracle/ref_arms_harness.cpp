@@ -270,11 +270,33 @@ struct RawRec {                        // the fixed part of a BAM record (SAM sp
 };
 struct ContigRecs { std::vector<RawRec> recs; std::vector<uint8_t> bytes; void clear() { recs.clear(); bytes.clear(); } };
 
+std::string g_dump_dir;                // hyporef_set_dump_dir: where polish_contig leaves the reference's own per-region dump (empty: nowhere)
+
 struct FileTotals { double align = 0, stage = 0, poa = 0, write = 0; uint64_t kept = 0, invalid = 0, regions = 0, windows = 0, contigs = 0, bases = 0; };
 
 // One contig through the reference (src/Hypo.cpp:126-268 for a batch of one contig and no -B file)
+std::unique_ptr<hypo::Alignment> make_alignment(hypo::Contig& c, const ContigRecs& R, const RawRec& r, std::vector<uint8_t>& data) {
+    bam1_t b;
+    std::memset(&b, 0, sizeof b);
+    const uint32_t extranul = (4 - (r.l_read_name & 3)) & 3;           // htslib pads the name so that the CIGAR is 32-bit aligned
+    b.core.tid = r.tid; b.core.pos = r.pos; b.core.bin = r.bin; b.core.qual = r.mapq; b.core.l_extranul = (uint8_t)extranul;
+    b.core.flag = r.flag; b.core.l_qname = (uint16_t)(r.l_read_name + extranul); b.core.n_cigar = r.n_cigar; b.core.l_qseq = r.l_seq;
+    b.core.mtid = r.mtid; b.core.mpos = r.mpos; b.core.isize = r.tlen;
+    // (+ 16 bytes per CIGAR operation of slack: Alignment::copy_data copies n_cigar * 4 UINT32s from the CIGAR's address, src/Alignment.cpp:565-567)
+    data.assign(r.len + extranul + 16ull * r.n_cigar + 16, 0);
+    std::memcpy(data.data(), R.bytes.data() + r.off, r.l_read_name);
+    std::memcpy(data.data() + r.l_read_name + extranul, R.bytes.data() + r.off + r.l_read_name, r.len - r.l_read_name);
+    b.data = data.data();
+    b.l_data = (int)(r.len + extranul);
+    b.m_data = (uint32_t)data.size();
+    return std::make_unique<hypo::Alignment>(c, &b);
+}
+
+// L: the long reads of a `-B` file (nullptr: a run without one).  They go through the SHORT-read constructor — the long-read one
+// (src/Alignment.cpp:40-63) differs by its NM filter only and calls htslib's bam_aux_get, which this build does not have; the file
+// reader below refuses a file with a record that filter would drop (-6), so the two constructors build the same objects.
 void polish_contig(const std::unique_ptr<suk::SolidKmers>& sk, uint32_t k, uint32_t cid, const std::string& name, const std::string& seq,
-                   const ContigRecs& R, std::ostream& out, FileTotals& T) {
+                   const ContigRecs& R, std::ostream& out, FileTotals& T, const ContigRecs* L = nullptr, bool long_run = false) {
     double t0 = now_s();
     hypo::Contig c(cid, name, seq);
     c.find_solid_pos(sk);                                                  // src/Hypo.cpp:100-103
@@ -284,20 +306,7 @@ void polish_contig(const std::unique_ptr<suk::SolidKmers>& sk, uint32_t k, uint3
     als.reserve(R.recs.size());
     std::vector<uint8_t> data;
     for (const RawRec& r : R.recs) {
-        bam1_t b;
-        std::memset(&b, 0, sizeof b);
-        const uint32_t extranul = (4 - (r.l_read_name & 3)) & 3;           // htslib pads the name so that the CIGAR is 32-bit aligned
-        b.core.tid = r.tid; b.core.pos = r.pos; b.core.bin = r.bin; b.core.qual = r.mapq; b.core.l_extranul = (uint8_t)extranul;
-        b.core.flag = r.flag; b.core.l_qname = (uint16_t)(r.l_read_name + extranul); b.core.n_cigar = r.n_cigar; b.core.l_qseq = r.l_seq;
-        b.core.mtid = r.mtid; b.core.mpos = r.mpos; b.core.isize = r.tlen;
-        // (+ 16 bytes per CIGAR operation of slack: Alignment::copy_data copies n_cigar * 4 UINT32s from the CIGAR's address, src/Alignment.cpp:565-567)
-        data.assign(r.len + extranul + 16ull * r.n_cigar + 16, 0);
-        std::memcpy(data.data(), R.bytes.data() + r.off, r.l_read_name);
-        std::memcpy(data.data() + r.l_read_name + extranul, R.bytes.data() + r.off + r.l_read_name, r.len - r.l_read_name);
-        b.data = data.data();
-        b.l_data = (int)(r.len + extranul);
-        b.m_data = (uint32_t)data.size();
-        als.emplace_back(std::make_unique<hypo::Alignment>(c, &b));       // src/Hypo.cpp:309
+        als.emplace_back(make_alignment(c, R, r, data));                   // src/Hypo.cpp:309
         if (!als.back()->is_valid) { als.pop_back(); ++T.invalid; }        // :314-318
     }
     T.kept += als.size();
@@ -313,6 +322,18 @@ void polish_contig(const std::unique_ptr<suk::SolidKmers>& sk, uint32_t k, uint3
     for (uint64_t t = 0; t < als.size(); ++t) als[t]->find_short_arms(k, c);
     c.fill_short_windows(als);
     als.clear();                                                           // :196-199 (the alignments of the batch are released before the POA)
+    if (long_run) {                                                        // :203-229
+        std::vector<std::unique_ptr<hypo::Alignment>> lals;
+        if (L) for (const RawRec& r : L->recs) {
+            lals.emplace_back(make_alignment(c, *L, r, data));
+            if (!lals.back()->is_valid) { lals.pop_back(); ++T.invalid; }
+        }
+        T.kept += lals.size();
+        c.prepare_long_windows();                                          // :212
+        #pragma omp parallel for
+        for (uint64_t t = 0; t < lals.size(); ++t) lals[t]->find_long_arms(c);   // :217
+        c.fill_long_windows(lals);                                         // :222
+    }
     double t3 = now_s();
     T.stage += t3 - t2;
     const uint64_t num_reg = c.get_num_regions();
@@ -324,6 +345,16 @@ void polish_contig(const std::unique_ptr<suk::SolidKmers>& sk, uint32_t k, uint3
     T.poa += t4 - t3;
     out << c;                                                              // :261-263
     T.write += now_s() - t4;
+    if (!g_dump_dir.empty()) {
+        // the reference's own debug dump of every region — type, arm counts, draft, CONSENSUS, arms (Contig::generate_inspect_file,
+        // src/Contig.cpp:368-453, which the reference calls from src/Hypo.cpp:265 when that line is un-commented): <dir>/aux/inspect_<name>.txt
+        char cwd[4096];
+        if (getcwd(cwd, sizeof cwd) && chdir(g_dump_dir.c_str()) == 0) {
+            mkdir("aux", 0777);
+            { std::ofstream bed(BEDFILE, std::ios::app); if (bed.is_open()) c.generate_inspect_file(bed); }
+            if (chdir(cwd) != 0) std::abort();
+        }
+    }
     T.regions += num_reg; T.windows += nwin; T.contigs += 1; T.bases += seq.size();
 }
 
@@ -425,9 +456,16 @@ struct FileJob {
     FileTotals T;
     ContigRecs cur; long cur_cid = -1;
     std::vector<char> done;
+    bool long_run = false;                          // a `-B` file was given
+    std::map<uint32_t, ContigRecs> longs;           // its records by contig (read whole before the short reads stream through)
+    uint32_t ned_th = 20;                           // -n
     bool picked(uint32_t cid) const { return want.empty() || (cid < want.size() && want[cid]); }
     void flush() {
-        if (cur_cid >= 0) { polish_contig(sk, k, (uint32_t)cur_cid, names[(size_t)cur_cid], seqs[(size_t)cur_cid], cur, out, T); done[(size_t)cur_cid] = 1; }
+        if (cur_cid >= 0) {
+            auto it = longs.find((uint32_t)cur_cid);
+            polish_contig(sk, k, (uint32_t)cur_cid, names[(size_t)cur_cid], seqs[(size_t)cur_cid], cur, out, T, it == longs.end() ? nullptr : &it->second, long_run);
+            done[(size_t)cur_cid] = 1;
+        }
         cur.clear(); cur_cid = -1;
     }
     // A record of contig `cid` in file order.  The records of a contig are taken to be contiguous in the file (coordinate-sorted or
@@ -460,7 +498,7 @@ bool job_begin(FileJob& J, const char* draft_path, uint32_t k, const char* bvsd_
     J.done.assign(J.names.size(), 0);
     J.out.open(out_path);
     if (!J.out.is_open()) return false;
-    hypo::Contig::set_no_long_reads();                                     // src/Hypo.cpp:230-232 (a run without -B)
+    if (!J.long_run) hypo::Contig::set_no_long_reads();                    // src/Hypo.cpp:230-232 (a run without -B; sticky for the process: a `-B` job needs a private copy of the library)
     static bool engines = false;                                           // Window::prepare_for_poa appends engines at every call (src/Window.cpp:31-42): once per process
     if (!engines) {
         hypo::ScoreParams sp{scores[0], scores[1], scores[2], scores[3], scores[4], scores[5]};
@@ -483,12 +521,45 @@ extern "C" __attribute__((visibility("default")))
 // alignments kept, invalid, regions, valid windows.  Returns the number of contigs written; -1 solid set / draft / output cannot be
 // opened, -3 malformed BAM, -4 a contig's records are not contiguous, -5 a reference name that the draft does not have (src/Hypo.cpp:303-306).
 long hyporef_fasta_bam(const char* draft_path, const char* bam_path, uint32_t k, const char* bvsd_path, uint32_t n_pick, const uint32_t* pick,
-                       uint32_t min_mapq, const char* out_path, const int8_t* scores, double* seconds, uint64_t* counts) {
-    FileJob J;
-    if (!job_begin(J, draft_path, k, bvsd_path, n_pick, pick, min_mapq, out_path, scores)) return -1;
+                       uint32_t min_mapq, const char* out_path, const int8_t* scores, double* seconds, uint64_t* counts);
+namespace {
+// reference span and NM tag of a BAM record's variable part; the long-read filter of src/Alignment.cpp:51-58 would drop the record when
+// ceil(NM * 100 / span) > -n (integer division first, as written there)
+bool nm_filter_drops(const RawRec& r, const uint8_t* var, uint32_t ned_th) {
+    const uint8_t* cg = var + r.l_read_name;
+    uint64_t span = 0;
+    for (uint32_t i = 0; i < r.n_cigar; ++i) { uint32_t v; std::memcpy(&v, cg + 4ull * i, 4); const uint32_t op = v & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) span += v >> 4; }
+    const uint8_t* a = cg + 4ull * r.n_cigar + ((size_t)r.l_seq + 1) / 2 + (size_t)r.l_seq;
+    const uint8_t* const e = var + r.len;
+    while (a + 3 <= e) {
+        const char t0 = (char)a[0], t1 = (char)a[1], ty = (char)a[2];
+        a += 3;
+        int64_t val = 0; size_t sz = 0; bool is_int = true;
+        switch (ty) {
+            case 'c': val = (int8_t)a[0]; sz = 1; break;
+            case 'C': val = a[0]; sz = 1; break;
+            case 's': { int16_t v; std::memcpy(&v, a, 2); val = v; sz = 2; break; }
+            case 'S': { uint16_t v; std::memcpy(&v, a, 2); val = v; sz = 2; break; }
+            case 'i': { int32_t v; std::memcpy(&v, a, 4); val = v; sz = 4; break; }
+            case 'I': { uint32_t v; std::memcpy(&v, a, 4); val = v; sz = 4; break; }
+            case 'A': sz = 1; is_int = false; break;
+            case 'f': sz = 4; is_int = false; break;
+            case 'Z': case 'H': { const uint8_t* z = a; while (z < e && *z) ++z; sz = (size_t)(z - a) + 1; is_int = false; break; }
+            case 'B': { const char st = (char)a[0]; uint32_t cnt; std::memcpy(&cnt, a + 1, 4); const size_t es = (st == 'c' || st == 'C') ? 1 : ((st == 's' || st == 'S') ? 2 : 4); sz = 5 + es * cnt; is_int = false; break; }
+            default: return false;
+        }
+        if (t0 == 'N' && t1 == 'M' && is_int) return span && (uint64_t)(val * 100 / (int64_t)span) > ned_th;
+        a += sz;
+    }
+    return false;
+}
+
+// every record of a BAM file that passes the flag / mapping-quality filter and belongs to a picked contig -> fn(cid, record, variable part)
+template <class Fn> long read_bam(FileJob& J, const char* bam_path, double& decode, Fn fn) {
     BgzfStream S;
     if (!S.open(bam_path)) return -1;
-    double decode = 0, t0 = now_s();
+    double t0 = now_s();
+    const uint32_t min_mapq = J.min_mapq;
     const uint8_t* p = S.take(8);
     if (!p || std::memcmp(p, "BAM\1", 4) != 0) return -3;
     const int32_t l_text = le32(p + 4);
@@ -521,15 +592,54 @@ long hyporef_fasta_bam(const char* draft_path, const char* bam_path, uint32_t k,
         const uint32_t cid = (uint32_t)tid_to_cid[(size_t)r.tid];
         if (!J.picked(cid)) continue;
         decode += now_s() - t0;
-        const int rc = J.record(cid, r, p + 32);
+        const int rc = fn(cid, r, p + 32);
         if (rc) return rc;
         t0 = now_s();
     }
     if (S.bad) return -3;
     decode += now_s() - t0;
+    return 0;
+}
+}  // namespace
+
+extern "C" __attribute__((visibility("default")))
+// dir: an existing directory (NULL or "": off).  Every contig a later hyporef_fasta_* call polishes also leaves the reference's per-region
+// dump there (not re-entrant: chdir).
+void hyporef_set_dump_dir(const char* dir) { g_dump_dir = dir ? dir : ""; }
+
+extern "C" __attribute__((visibility("default")))
+// ... and with the long reads of a `-B` BAM file (long_bam_path; NULL = none): read whole first, then the short reads stream through and
+// every contig runs the short-read stage, the long-read stage (prepare_long_windows, find_long_arms, fill_long_windows) and the POA of its
+// SHORT and LONG windows.  ned_th = -n.  -6: a long read that the reference's NM filter would drop (this build cannot apply it).
+// A process that ever ran a job WITHOUT long reads cannot run one with (Contig::set_no_long_reads is sticky): use a private copy of the library.
+long hyporef_fasta_bam2(const char* draft_path, const char* bam_path, const char* long_bam_path, uint32_t k, const char* bvsd_path, uint32_t n_pick, const uint32_t* pick,
+                        uint32_t min_mapq, uint32_t ned_th, const char* out_path, const int8_t* scores, double* seconds, uint64_t* counts) {
+    FileJob J;
+    J.long_run = long_bam_path != nullptr; J.ned_th = ned_th;
+    if (!job_begin(J, draft_path, k, bvsd_path, n_pick, pick, min_mapq, out_path, scores)) return -1;
+    double decode = 0;
+    if (long_bam_path) {
+        const long rc = read_bam(J, long_bam_path, decode, [&](uint32_t cid, const RawRec& r, const uint8_t* var) -> int {
+            if (nm_filter_drops(r, var, J.ned_th)) return -6;
+            ContigRecs& L = J.longs[cid];
+            RawRec q = r; q.off = L.bytes.size();
+            L.bytes.insert(L.bytes.end(), var, var + r.len);
+            L.recs.push_back(q);
+            return 0;
+        });
+        if (rc) return rc;
+    }
+    const long rc = read_bam(J, bam_path, decode, [&](uint32_t cid, const RawRec& r, const uint8_t* var) -> int { return J.record(cid, r, var); });
+    if (rc) return rc;
     J.finish();
     job_report(J, decode, seconds, counts);
     return (long)J.T.contigs;
+}
+
+extern "C" __attribute__((visibility("default")))
+long hyporef_fasta_bam(const char* draft_path, const char* bam_path, uint32_t k, const char* bvsd_path, uint32_t n_pick, const uint32_t* pick,
+                       uint32_t min_mapq, const char* out_path, const int8_t* scores, double* seconds, uint64_t* counts) {
+    return hyporef_fasta_bam2(draft_path, bam_path, nullptr, k, bvsd_path, n_pick, pick, min_mapq, 20, out_path, scores, seconds, counts);
 }
 
 extern "C" __attribute__((visibility("default")))

@@ -403,3 +403,34 @@ def run_t1_slice_vs_reference(outdir, n_contigs, contig_len, k, size_flag, pick,
     assert len(ours) == rep["contigs"] and len(theirs) == len(set(pick))
     same = sum(1 for name in theirs if ours.get(name) == theirs[name])
     return dt, rr, same
+
+
+def realistic_window_batch(outdir, name="e2e_real_5m_s131"):
+    """The REAL windows of a non-i.i.d. set, as the reference itself cut them: the inputs of golden `name` are generated, the reference
+    compiled in place polishes them (oracle.RefArms.fasta_file) and leaves its own per-region dump (Contig::generate_inspect_file: arms,
+    draft and CONSENSUS of every window); returns (HostBatch of all windows, the reference's consensus per window, manifest, the reference's
+    report).  These windows have what the simulator's lack: read indels inside SHORT windows, repeats, a second haplotype, mis-placed reads."""
+    import importlib.util
+    import oracle
+    from hypo_amd.batch import build_batch
+    man = json.load(open(os.path.join(GOLD, name + ".manifest.json")))
+    a = man["args"]
+    gen = build_fast_generator()
+    rep = json.loads(subprocess.check_output([gen, str(outdir), str(a["seed"]), str(a["contigs"]), str(a["contig_len"]), str(a["k"]), str(a["coverage"]),
+                                              str(a["read_len"]), str(a["read_sub_ppm"])] + list(a["flags"]), text=True))
+    assert rep == man["generator_report"], f"{name}: the generator's output changed"
+    with_long = "--long" in a["flags"]
+    dump = os.path.join(str(outdir), "refdump")
+    os.makedirs(dump, exist_ok=True)
+    rr = oracle.RefArms().fasta_file(os.path.join(str(outdir), "draft.fa"), os.path.join(str(outdir), "sr.bam"), a["k"], os.path.join(str(outdir), "aux", "solid_kmers.bvsd"),
+                                     os.path.join(str(outdir), "ref.fa"), long_path=os.path.join(str(outdir), "lr.bam") if with_long else None, dump_dir=dump)
+    assert hashlib.md5(open(os.path.join(str(outdir), "ref.fa"), "rb").read()).hexdigest() == man["expected_fasta_md5"]
+    spec = importlib.util.spec_from_file_location("inspect_dump", os.path.join(GOLD, "inspect_dump.py"))
+    idump = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(idump)
+    wins, cons = [], []
+    for c in range(a["contigs"]):
+        for hdr, typ, w, cs in idump.parse(os.path.join(dump, "aux", f"inspect_ctg{c + 1}.txt")):
+            wins.append(w)
+            cons.append(cs)
+    return build_batch(wins), cons, man, rr

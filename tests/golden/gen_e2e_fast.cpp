@@ -23,8 +23,20 @@
 // composing the two edit scripts, NM tag) and `--gaps <every> <len>` leaves the short reads out of <len> bases every <every> bases,
 // which is where the reference builds LONG windows from the long reads (src/Contig.cpp:292-343).
 //
+// Round 6 (non-i.i.d. genomes; every option off = the files of rounds 3-5 byte for byte, the new draws come from a generator of their own):
+//   --repeats <ppm>     this share of the truth's bases lies in low-complexity blocks: tandem repeats (unit 2-12, 30-600 bases), homopolymer
+//                       runs (6-40), dispersed copies of an earlier stretch of the contig (200-1500 bases), all with ~1 % divergence — k-mers
+//                       there are not unique, so no solid positions: long weak regions, Contig::force_divide (src/Contig.cpp:630-711), minimizers
+//                       that recur or are poly-base (src/Contig.cpp:455-524)
+//   --diploid <ppm>     a second haplotype: SNPs at this rate, 1-base deletions and insertions at a fifth of it each; every read comes from
+//                       one of the two with equal probability (solid k-mers and the draft come from the first): k-mers over a heterozygous
+//                       site get about half the support — the 40-80 % branch of SR detection (src/Contig.cpp:96-127)
+//   --read-indel <ppm>  deletion and insertion errors in the short reads at this rate each, five times that inside homopolymer runs
+//   --mismap <ppm>      this share of the short reads carries the sequence of ANOTHER place of the contig under the CIGAR of this one
+//
 // usage: gen_e2e_fast <outdir> <seed> <n_contigs> <contig_len> <k> [coverage=30] [read_len=150] [read_sub_ppm=2000]
 //                     [--bam] [--fast-hash] [--threads N] [--join] [--long <cov> <len>] [--gaps <every> <len>]
+//                     [--repeats <ppm>] [--diploid <ppm>] [--read-indel <ppm>] [--mismap <ppm>]
 // build: g++ -O2 -fopenmp -o gen_e2e_fast gen_e2e_fast.cpp -lz      (test infrastructure: tests/ and bench.py's e2e legs only)
 #include <zlib.h>
 #include <omp.h>
@@ -69,6 +81,8 @@ struct Extra {                                   // config C4 options
     bool join = false; uint64_t pos_off = 0;     // join: all pieces are one contig; this piece starts at pos_off of it
     uint32_t long_cov = 0, long_len = 0;         // long reads (0 = none)
     uint32_t gap_every = 0, gap_len = 0;         // short reads leave [x * gap_every + gap_every / 2, ... + gap_len) of the truth alone
+    uint32_t rep_ppm = 0, het_ppm = 0, rindel_ppm = 0, mismap_ppm = 0;      // round 6: low-complexity truth, second haplotype, read indels, mis-placed reads
+    bool realistic() const { return rep_ppm || het_ppm || rindel_ppm || mismap_ppm; }
 };
 
 Rng contig_rng(uint64_t seed, int idx) {
@@ -126,12 +140,65 @@ int reg2bin(int64_t beg, int64_t end) {            // SAM spec 5.3
     return 0;
 }
 
+// the generator of the round-6 options of a contig: its own stream, so that the main one draws what it always drew
+Rng extra_rng(uint64_t seed, int idx, uint64_t salt) {
+    Rng base = contig_rng(seed ^ 0x6a09e667f3bcc909ull, idx);
+    uint64_t s0 = base.next() ^ salt;
+    s0 = (s0 ^ (s0 >> 31)) * 0x94d049bb133111ebull; s0 ^= s0 >> 29;
+    return Rng(s0);
+}
+
+// low-complexity blocks written over a random truth (--repeats): the same for both passes over a contig
+template <class Str> void apply_repeats(Str& truth, uint64_t seed, int idx, uint32_t G, uint32_t rep_ppm) {
+    if (!rep_ppm) return;
+    Rng x = extra_rng(seed, idx, 0x7265706561747321ull);
+    const uint32_t mean_block = 160;                              // blocks start with probability rep_ppm / mean_block per base
+    uint32_t i = 0;
+    while (i < G) {
+        if (x.below(1000000u) >= rep_ppm / mean_block + 1) { ++i; continue; }
+        const uint32_t kind = x.below(10);
+        uint32_t len;
+        if (kind < 4) {                                           // tandem repeat
+            const uint32_t u = 2 + x.below(11);
+            len = 30 + x.below(571);
+            char unit[12];
+            for (uint32_t j = 0; j < u; ++j) unit[j] = kA[x.below(4)];
+            for (uint32_t j = 0; j < len && i + j < G; ++j) truth[i + j] = x.below(100) == 0 ? kA[x.below(4)] : unit[j % u];
+        } else if (kind < 7) {                                    // homopolymer run
+            len = 6 + x.below(35);
+            const char b = kA[x.below(4)];
+            for (uint32_t j = 0; j < len && i + j < G; ++j) truth[i + j] = b;
+        } else {                                                  // dispersed copy of an earlier stretch
+            len = 200 + x.below(1301);
+            if (i > len + 1000) {
+                const uint32_t from = x.below(i - len);
+                for (uint32_t j = 0; j < len && i + j < G; ++j) truth[i + j] = x.below(100) == 0 ? kA[x.below(4)] : truth[from + j];
+            }
+        }
+        i += len;
+    }
+}
+
 // ops: 0 = M (truth base == draft base), 1 = X (substituted), 2 = D (draft lacks the truth base), 3 = I (draft has an extra base)
 // cnt: saturating (at 2) counters of the canonical k-mers of all truths, shared by the generating threads
 void make_contig(Contig& c, uint64_t seed, int idx, uint32_t G, uint32_t cov, uint32_t rl, uint32_t sub_ppm, bool bam, int K, uint8_t* cnt, const Extra& ex = Extra()) {
     Rng r = contig_rng(seed, idx);
     c.truth.resize(G);
     for (uint32_t i = 0; i < G; ++i) c.truth[i] = kA[r.below(4)];
+    apply_repeats(c.truth, seed, idx, G, ex.rep_ppm);
+    // second haplotype (--diploid): per truth position 0 = as the first, 1 = another base, 2 = the base is missing, 3 = an extra base behind it
+    std::vector<uint8_t> hv; std::vector<char> hb;
+    if (ex.het_ppm) {
+        Rng hx = extra_rng(seed, idx, 0x6469706c6f696421ull);
+        hv.assign(G, 0); hb.assign(G, 0);
+        for (uint32_t i = 0; i < G; ++i) {
+            const uint32_t q = hx.below(1000000u);
+            if (q < ex.het_ppm) { char d; do d = kA[hx.below(4)]; while (d == c.truth[i]); hv[i] = 1; hb[i] = d; }
+            else if (q < ex.het_ppm + ex.het_ppm / 5) hv[i] = 2;
+            else if (q < ex.het_ppm + 2 * (ex.het_ppm / 5)) { hv[i] = 3; hb[i] = kA[hx.below(4)]; }
+        }
+    }
+    Rng rx = extra_rng(seed, idx, 0x7265616465727221ull);          // per-read draws of the round-6 options
     std::vector<uint8_t> op; std::vector<char> tb, db;       // per op: kind, truth base (0 = none), draft base (0 = none)
     op.reserve(G + G / 100); tb.reserve(G + G / 100); db.reserve(G + G / 100);
     for (uint32_t i = 0; i < G; ++i) {
@@ -177,10 +244,39 @@ void make_contig(Contig& c, uint64_t seed, int idx, uint32_t G, uint32_t cov, ui
             char last = 0; uint32_t run = 0, rspan = 0;
             auto emit = [&]() { if (!last) return; if (bam) cigops.push_back((run << 4) | (last == 'M' ? 0u : (last == 'I' ? 1u : 2u))); else { append_uint(cig, run); cig.push_back(last); } };
             auto push = [&](char ch) { if (ch == last) ++run; else { emit(); last = ch; run = 1; } };
+            if (!ex.realistic()) {
             for (size_t i = i0; i < i1; ++i) {
                 if (op[i] <= 1) { char b = tb[i]; if (r.ppm(sub_ppm)) b = kA[r.below(4)]; seq.push_back(b); push('M'); ++rspan; }
                 else if (op[i] == 2) { seq.push_back(tb[i]); push('I'); }
                 else { push('D'); ++rspan; }
+            }
+            } else {
+                // round 6: the read follows one of two haplotypes and has indel errors of its own; its CIGAR against the draft composes
+                // truth -> draft, haplotype and read errors.  First and last base stay matches (a record starts and ends on M).
+                const bool hap_b = ex.het_ppm && rx.below(2) == 1;
+                uint32_t ti = s;                              // truth position of the next op that has a truth base
+                char prev = 0;
+                for (size_t i = i0; i < i1; ++i) {
+                    if (op[i] == 3) { push('D'); ++rspan; continue; }       // a base only the draft has
+                    const bool edge = i == i0 || i + 1 == i1;
+                    char b = tb[i];
+                    const uint32_t t = ti++;
+                    bool skip = false, extra = false; char xb = 0;
+                    if (hap_b && !edge) { if (hv[t] == 1) b = hb[t]; else if (hv[t] == 2) skip = true; else if (hv[t] == 3) { extra = true; xb = hb[t]; } }
+                    if (ex.rindel_ppm && !edge) {
+                        const uint32_t rate = ex.rindel_ppm * (b == prev ? 5u : 1u);
+                        if (rx.below(1000000u) < rate) skip = true;
+                        if (rx.below(1000000u) < rate) { extra = true; xb = (b == prev) ? b : kA[rx.below(4)]; }
+                    }
+                    if (op[i] <= 1 && r.ppm(sub_ppm)) b = kA[r.below(4)];
+                    if (skip) { if (op[i] <= 1) { push('D'); ++rspan; } }
+                    else { seq.push_back(b); if (op[i] <= 1) { push('M'); ++rspan; } else push('I'); prev = b; }
+                    if (extra) { seq.push_back(xb); push('I'); }
+                }
+                if (ex.mismap_ppm && rx.below(1000000u) < ex.mismap_ppm && G > 4 * rl) {
+                    const uint32_t s2 = rx.below(G - (uint32_t)seq.size() - 1);
+                    for (size_t j = 0; j < seq.size(); ++j) seq[j] = c.truth[s2 + j];
+                }
             }
             emit();
             if (dropped) continue;                           // (every random draw of the read was made: the stream behind it is unchanged)
@@ -308,10 +404,11 @@ void make_contig(Contig& c, uint64_t seed, int idx, uint32_t G, uint32_t cov, ui
 
 // first pass: the draft's length only — the same draws as make_contig's truth and edit script (a substituted base is drawn until
 // it differs from the truth base, so the truth bases are kept for the length of this call: 1 byte per base)
-uint32_t draft_length_exact(uint64_t seed, int idx, uint32_t G) {
+uint32_t draft_length_exact(uint64_t seed, int idx, uint32_t G, uint32_t rep_ppm) {
     Rng r = contig_rng(seed, idx);
     std::vector<char> truth(G);
     for (uint32_t i = 0; i < G; ++i) truth[i] = kA[r.below(4)];
+    apply_repeats(truth, seed, idx, G, rep_ppm);
     uint32_t d = 0;
     for (uint32_t i = 0; i < G; ++i) {
         const char t = truth[i];
@@ -338,6 +435,10 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--join")) ex0.join = true;
         else if (!strcmp(argv[i], "--long") && i + 2 < argc) { ex0.long_cov = (uint32_t)atoi(argv[++i]); ex0.long_len = (uint32_t)atoi(argv[++i]); }
         else if (!strcmp(argv[i], "--gaps") && i + 2 < argc) { ex0.gap_every = (uint32_t)atoi(argv[++i]); ex0.gap_len = (uint32_t)atoi(argv[++i]); }
+        else if (!strcmp(argv[i], "--repeats") && i + 1 < argc) ex0.rep_ppm = (uint32_t)atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--diploid") && i + 1 < argc) ex0.het_ppm = (uint32_t)atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--read-indel") && i + 1 < argc) ex0.rindel_ppm = (uint32_t)atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--mismap") && i + 1 < argc) ex0.mismap_ppm = (uint32_t)atoi(argv[++i]);
         else pos.push_back(argv[i]);
     }
     if (pos.size() < 5) { fprintf(stderr, "usage: gen_e2e_fast <outdir> <seed> <n_contigs> <contig_len> <k> [coverage=30] [read_len=150] [read_sub_ppm=2000] [--bam] [--fast-hash] [--threads N]\n"); return 2; }
@@ -357,7 +458,7 @@ int main(int argc, char** argv) {
     // ---- first pass: draft lengths (the header names them) ----
     std::vector<uint32_t> dlen((size_t)nc);
 #pragma omp parallel for schedule(dynamic, 1)
-    for (int c = 0; c < nc; ++c) dlen[(size_t)c] = draft_length_exact(seed, c, G);
+    for (int c = 0; c < nc; ++c) dlen[(size_t)c] = draft_length_exact(seed, c, G, ex0.rep_ppm);
     std::vector<uint64_t> pos_off((size_t)nc + 1, 0);
     for (int c = 0; c < nc; ++c) pos_off[(size_t)c + 1] = pos_off[(size_t)c] + dlen[(size_t)c];
     if (ex0.join && pos_off[(size_t)nc] >= 0x7fffffffull) { fprintf(stderr, "gen_e2e_fast: a joined contig of %llu bases exceeds BAM's 2^31\n", (unsigned long long)pos_off[(size_t)nc]); return 2; }
@@ -460,8 +561,11 @@ int main(int argc, char** argv) {
         f = fopen((out + "/reads.fa").c_str(), "wb");          // named on the command line, not read when -i finds the aux files
         fputs(">unused\nACGT\n", f); fclose(f);
     }
-    char extra[256] = "";
-    if (ex0.long_cov || ex0.join || ex0.gap_every)
+ char extra[384] = "";
+    if (ex0.realistic())
+        snprintf(extra, sizeof extra, ", \"joined\": %s, \"long_reads\": %llu, \"fnv_long_records\": \"%016llx\", \"gaps\": [%u, %u], \"repeats_ppm\": %u, \"diploid_ppm\": %u, \"read_indel_ppm\": %u, \"mismap_ppm\": %u",
+                 ex0.join ? "true" : "false", (unsigned long long)n_long, (unsigned long long)h_long, ex0.gap_every, ex0.gap_len, ex0.rep_ppm, ex0.het_ppm, ex0.rindel_ppm, ex0.mismap_ppm);
+    else if (ex0.long_cov || ex0.join || ex0.gap_every)
         snprintf(extra, sizeof extra, ", \"joined\": %s, \"long_reads\": %llu, \"fnv_long_records\": \"%016llx\", \"gaps\": [%u, %u]", ex0.join ? "true" : "false",
                  (unsigned long long)n_long, (unsigned long long)h_long, ex0.gap_every, ex0.gap_len);
     printf("{\"contigs\": %d, \"draft_bases\": %llu, \"reads\": %llu, \"solid_kmers\": %llu, \"fnv_draft\": \"%016llx\", \"%s\": \"%016llx\", \"fnv_bitvector\": \"%016llx\"%s%s}\n",

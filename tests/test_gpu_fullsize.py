@@ -293,3 +293,43 @@ def test_last_resort_class_vs_oracle_and_reference(gpu, oracle_lib):
             rb, _, rln, rst, _ = ref.poa_batch_raw(b, off=off)
             assert (rst == 0).all() and (rln == ln).all()
             assert _cons_list(bases, off, ln) == _cons_list(rb, off, rln)
+
+
+@pytest.mark.parametrize("name", ["e2e_real_5m_s131", "e2e_real_long_s137"])
+def test_real_windows_of_non_iid_sets_vs_the_reference_own_consensus(gpu, name, tmp_path):
+    """Round 6: the REAL windows of the non-i.i.d. goldens — cut by the reference compiled in place from reads with indel errors, a second
+    haplotype and mis-placed reads over a genome with tandem repeats, homopolymer runs and dispersed copies (tests/e2e_util.py:
+    realistic_window_batch) — through the device in every short size class; the consensus of every window must be the string the reference's
+    own Window::generate_consensus left in its per-region dump (no oracle in between).  ~96 k SHORT windows (5 Mbp set), SHORT + LONG windows
+    with real long-read arms (the `-B` set)."""
+    import ctypes as C
+    import os
+    import e2e_util as eu
+    import oracle
+    if not oracle.RefArms.available():
+        pytest.skip("oracle/_ref/libhyporef_arms.so not built (the real reference only exists in the build container)")
+    b, cons, man, rr = eu.realistic_window_batch(tmp_path, name)
+    assert b.n_windows == man["reference_counts"]["windows"] > 50000
+    want = [c.encode() for c in cons]
+    off = b.slot_layout()
+    db = gpu.device_batch(b, off=off)
+    try:
+        for variant, (mc, lanes) in {"0": (0, "16"), "0w": (0, "32"), "1": (1, None), "2": (2, None), "3": (3, None)}.items():
+            if lanes:
+                os.environ["HYPO_POA_CLASS0"] = lanes
+            else:
+                os.environ.pop("HYPO_POA_CLASS0", None)
+            assert gpu.lib.hypo_gpu_set_option(b"poa_min_class", C.c_int(mc)) == 0
+            db.run()
+            bases, _, ln, st = db.results()
+            assert (st == 0).all(), (variant, np.nonzero(st)[0][:5])
+            got = _cons_list(bases, off, ln)
+            bad = [i for i in range(b.n_windows) if got[i] != want[i]]
+            assert not bad, f"{name} class variant {variant}: {len(bad)} windows differ from the reference's consensus, first {bad[0]}"
+            s = db.stats()
+            na = max(s["n_alignments"], 1)
+            print(f"{name} variant {variant}: windows per class {s['n_class'][:6]} alignments reused {s['n_reused'] / na:.3f} threaded {s['n_threaded'] / na:.3f} "
+                  f"scored {1 - (s['n_reused'] + s['n_threaded']) / na:.3f} re-queued {s['n_escalated']}")
+    finally:
+        os.environ.pop("HYPO_POA_CLASS0", None)
+        gpu.lib.hypo_gpu_set_option(b"poa_min_class", C.c_int(0))

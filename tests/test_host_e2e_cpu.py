@@ -86,3 +86,17 @@ def test_require_device_turns_a_host_fallback_into_an_error(built, tmp_path):
     assert "--require-device" in p.stderr and "would be computed on the host" in p.stderr
     p = subprocess.run(argv, cwd=str(tmp_path), env=dict(env, HYPO_REQUIRE_DEVICE="1"), capture_output=True, text=True, timeout=300)
     assert p.returncode == 1 and "would be computed on the host" in p.stderr
+
+
+def test_realistic_golden_with_long_reads_over_the_shim(built, tmp_path):
+    """A non-i.i.d. set (repeats, second haplotype, read indels, mis-placed reads, `-B` long reads: tests/golden/make_realistic_golden.py)
+    through the host pipeline over the CPU shim: FASTA = what the reference compiled in place wrote (the manifest's md5), and, where
+    oracle/_ref/libhyporef_arms.so exists, the reference polishes the same files again here."""
+    import oracle
+    man, p, dt, rss = eu.run_fast_case("e2e_real_long_s137", tmp_path, threads=4, device="shim")
+    assert eu.fasta_md5(tmp_path) == man["expected_fasta_md5"]
+    if oracle.RefArms.available():
+        rr = oracle.RefArms().fasta_file(str(tmp_path / "draft.fa"), str(tmp_path / "sr.bam"), 11, str(tmp_path / "aux" / "solid_kmers.bvsd"), str(tmp_path / "ref.fa"),
+                                         long_path=str(tmp_path / "lr.bam"))
+        assert open(tmp_path / "ref.fa", "rb").read() == open(tmp_path / "hypo_draft.fasta", "rb").read()
+        assert rr["windows"] == man["reference_counts"]["windows"]
