@@ -480,7 +480,9 @@ def main():
     ap.add_argument("--no-e2e-c3", action="store_true", help="skip the 100 Mbp end-to-end run (about a minute and 4 GB of scratch files)")
     ap.add_argument("--no-e2e-k15", action="store_true", help="skip the 250 Mbp / k = 15 end-to-end run (BAM input, about half a minute)")
     ap.add_argument("--no-e2e-c4", action="store_true", help="skip the C4-at-size end-to-end run (one 250 Mbp contig, short + long reads, about a minute)")
-    ap.add_argument("--no-e2e-1g", action="store_true", help="skip the 1 Gbp end-to-end run (BAM input, about a minute of input generation + half a minute)")
+    ap.add_argument("--no-e2e-1g", action="store_true", help="(kept for old command lines: the 1 Gbp run is opt-in now)")
+    ap.add_argument("--e2e-1g", action="store_true", help="also run the 1 Gbp end-to-end set (BAM input, about a minute of input generation + half a minute; md5 of the CMake-built "
+                                                           "reference binary; since round 6 the 3 Gbp run is pinned against the reference compiled in place, which made this leg redundant)")
     ap.add_argument("--no-e2e-c5", action="store_true", help="skip the 250 Mbp C5 slice (15 kbp reads as -b, k = 17; about 40 s of input generation)")
     ap.add_argument("--no-e2e-k17", action="store_true", help="skip the 10 Mbp run at -s 3g (k = 17, the real reference's md5)")
     ap.add_argument("--t1-contigs", type=int, default=int(os.environ.get("HYPO_BENCH_T1_CONTIGS", "3000")),
@@ -673,6 +675,25 @@ def main():
                                             "issue_frac": round(j["valu_insts"] / slots, 4), "source": j.get("source", "profiles/")}
             except Exception:
                 pass
+        # every size-class kernel of the step (classes 0-2 run SIDE BY SIDE on three streams: which of them is the longest changes from run
+        # to run, so "the dominant kernel" above is whichever took longest this time) and the step as a whole
+        kern = []
+        for c in range(cls_ms.size):
+            if busy[c] == 0.0:
+                continue
+            a_c, ms_c = float(stats["alg_bytes"][c]), float(cls_ms[c])
+            e = {"name": f"poa_class_kernel<class {c}>", "ms": round(ms_c, 4), "windows": int(stats["n_class"][c]), "algorithmic_bytes": int(a_c),
+                 "achieved_gbs": round(a_c / (ms_c * 1e-3) / 1e9, 3) if ms_c > 0 else None, "traffic": None}
+            try:
+                j = json.load(open(tr)).get(e["name"], {}) if os.path.exists(tr) else {}
+                if j.get("windows") == e["windows"]:
+                    e["traffic"] = j.get("hbm_bytes_per_launch")
+                    e["valu_insts"], e["salu_insts"] = j.get("valu_insts"), j.get("salu_insts")
+            except Exception:
+                pass
+            kern.append(e)
+        roofline["kernels"] = kern
+        roofline["concurrent"] = "classes 0-2 run concurrently on three streams (fixed wave shares per CU); `kernel` = the longest of them in THIS run"
         poa_ms_total = float(ms[:, -1].mean())                    # whole POA call (the class kernels overlap)
         extra["poa_kernels_ms"] = [round(float(x), 4) for x in ms.mean(axis=0)]
         extra["gcups"] = round(stats["dp_cells"] / (poa_ms_total * 1e-3) / 1e9, 3)     # reference-equivalent cells
@@ -690,6 +711,15 @@ def main():
         a_scan = (contig_bases + 1) // 2 + (contig_bases + 7) // 8 + 8 * n_solid + min((1 << (2 * k)) // 8, 32 * (contig_bases - k + 1))
         extra["scan_kernels_ms"] = [round(float(x), 4) for x in sm]
         extra["scan_gbs"] = round(a_scan / (float(sm.sum()) * 1e-3) / 1e9, 2)
+        if roofline is not None:                                   # the step: every kernel's algorithmic bytes over the step's wall time
+            step_alg = float(sum(stats["alg_bytes"])) + float(a_scan) * len(scans)
+            step_s = dt / args.steps
+            step_traffic = None
+            if all(kk.get("traffic") for kk in roofline.get("kernels", [])) and roofline.get("kernels"):
+                step_traffic = int(sum(kk["traffic"] for kk in roofline["kernels"]))
+            roofline["step"] = {"algorithmic_bytes": int(step_alg), "ms": round(step_s * 1e3, 4), "achieved_gbs": round(step_alg / step_s / 1e9, 3),
+                                "frac": round(step_alg / step_s / 1e9 / HBM_PEAK_GBS, 8), "poa_traffic": step_traffic,
+                                "what": "POA kernels (all size classes) + solid-kmer scan(s) of one step: sum of algorithmic bytes / ms_per_step"}
 
     # ---- the same POA call on noisier reads and through the host-pointer entry point (N = 1 only, a few calls each) ----
     if rank == 0 and world == 1 and not args.no_extras:
@@ -728,6 +758,28 @@ def main():
         extra["value_c4mix"] = {"value": round(408000 / t5, 1), "unit": "windows/s", "ms_per_call": round(t5 * 1e3, 3), "failed": cdb.stats()["n_failed"],
                                 "workload": "C4 window mix: 400 000 C1-shaped SHORT + 8 000 LONG windows (120-500 bp, 12-45 noisy long-read arms) in one batch, POA call only"}
         del cdb
+        # the window-level grid — length x arms x arm error, 60 / 20 / 20 internal / prefix / suffix arms — POA call only:
+        # windows/s, the TRUE cell rate of the score-row loop (cells that went through rows_pk / the int32 rows per second of the call), and
+        # the share of alignments that needed no rows.  The 8 % column is where every alignment is scored.
+        if os.environ.get("HYPO_BENCH_GRID", "1") == "1":
+            grid = []
+            for err in (0.005, 0.08):
+                for length in (8, 16, 32, 64, 100, 200):
+                    for arms in (6, 12, 30, 50):
+                        nwin = max(4000, min(60000, 24_000_000 // (length * arms)))
+                        gdb = gpu.device_batch(sim.grid_batch(length, arms, nwin, err, seed=11))
+                        for _ in range(2):
+                            gdb.run()
+                            torch.cuda.synchronize(dev)
+                        tg = timed(gdb.run, 3, lambda: torch.cuda.synchronize(dev))
+                        gs = gdb.stats()
+                        gna = max(gs["n_alignments"], 1)
+                        grid.append({"len": length, "arms": arms, "err": err, "windows": nwin, "windows_per_s": round(nwin / tg, 1), "ms": round(tg * 1e3, 3),
+                                     "gcups_reference_cells": round(gs["dp_cells"] / tg / 1e9, 1), "gcups_scored_rows": round(gs["cells_scored"] / tg / 1e9, 2),
+                                     "scored_share": round(1.0 - (gs["n_reused"] + gs["n_threaded"]) / gna, 4), "classes": gs["n_class"][:4], "requeued": gs["n_escalated"], "failed": gs["n_failed"]})
+                        del gdb
+            extra["grid"] = {"cells": grid, "what": "SURVEY 8(d) grid, POA call only, one resident batch per cell (3 timed calls); gcups_scored_rows = cells that went through the score rows / call time "
+                                                    "(the call also threads, sorts and builds consensus: a lower bound of the row loop's own rate)"}
         if os.environ.get("HYPO_BENCH_VALUE_REPEAT", "1") == "1":
             extra["value_repeat"] = value_repeat_leg(gpu, torch, dev)
         # the N > 1 workload on ONE GPU: the like-for-like base of the scaling curve (BASELINE configs[2]: the same 1.94 M windows,
@@ -867,7 +919,7 @@ def main():
             e2e_k17 = end_to_end_k17_leg()                 # k = 17 (-s 3g) pinned to the real reference on 10 Mbp
         if not args.no_e2e_c5:
             e2e_c5 = end_to_end_c5_leg()                   # BASELINE config C5 as a workload: 15 kbp reads as -b at k = 17, 250 Mbp, the real reference's md5
-        if not args.no_e2e_1g:
+        if args.e2e_1g and not args.no_e2e_1g:
             e2e_1g = end_to_end_1g_leg()                   # 1 Gbp with the real reference's md5
         if args.t1_contigs > 0:
             # row T1 at size: 3 Gbp / 30x short reads, -s 3g -> k = 17, one -p 50 run (about two minutes of input generation + the run)
@@ -878,6 +930,25 @@ def main():
                 # (profiles/history/r04_t1_3gbp.json, -p 50 and -p 100) — the check that counts is reference_pin above
                 e2e_t1["fasta_same_as_round4_runs"] = e2e_t1["fasta_md5"] == T1_3GBP_MD5_ROUND4
                 e2e_t1["batchings_run"] = [50]
+
+    # ---- N > 1: what the all-gather delivered, re-assembled in global window order, against the oracle on the WHOLE batch (opt-in:
+    # HYPO_BENCH_CHECK_GATHER=1; tests/test_gpu_distributed.py runs it with every rank on device 0) -----------------------------------
+    parity_gathered = None
+    if strong and world > 1 and os.environ.get("HYPO_BENCH_CHECK_GATHER") == "1":
+        gb, gl = exchange.gather(db.bases, db.len[:n_w])
+        torch.cuda.synchronize(dev)
+        if rank == 0:
+            import oracle
+            n_total = int(os.environ.get("HYPO_BENCH_C3_WINDOWS", C3_REPLICAS * N_WINDOWS))
+            whole = sim.window_batch(n_total, seed=3000)
+            rngs = hd.shard_contiguous(hd.window_costs(whole.windows, whole.arm_len), world)
+            offs = [hd.take_windows(whole, b0, e0, compact=True).slot_layout() for b0, e0 in rngs]
+            got = hd.reassemble(gb.cpu().numpy(), gl.cpu().numpy(), offs, rngs)
+            want, wst, _, _ = oracle.Oracle().poa_batch(whole)
+            if len(got) != n_total or got != list(want):
+                raise SystemExit("bench: the gathered consensus of the sharded batch differs from the oracle's — refusing to report a number")
+            parity_gathered = f"all-gathered consensus of {n_total} windows from {world} ranks, re-assembled in window order, bit-exact vs oracle"
+        dist.barrier()
 
     if strong and world > 1:                               # per-rank imbalance of the measured step
         tt = torch.tensor([my_dt], dtype=torch.float64, device=dev)
@@ -915,6 +986,8 @@ def main():
         }
         if imbalance:
             out["imbalance"] = imbalance
+        if parity_gathered:
+            out["parity_gathered"] = parity_gathered
         out.update(extra)
         print(json.dumps(out))
     if world > 1:

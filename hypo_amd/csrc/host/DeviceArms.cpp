@@ -14,6 +14,27 @@ namespace hypo {
 // as the flat slices the parser threads wrote (ReadBatch); flatten() lays them out in this context's page-locked staging arrays,
 // which hypo_gpu_reads_upload copies at the link's rate — no per-record objects to walk, no fresh pages per batch, nothing to
 // release afterwards.
+uint32_t DeviceArms::longest_owned_window(const Contig& ctg, bool long_windows) const {
+    uint32_t longest = 0;
+    if (!long_windows) {
+        std::vector<uint32_t> pos;
+        ctg._reg_pos.list_set(pos);                              // region starts, then the contig's length
+        const size_t nr = (size_t)ctg.get_num_regions();
+        for (size_t r = 0; r < nr && r + 1 < pos.size(); ++r) {
+            const RegionType t = ctg._reg_type[r];
+            if (t == RegionType::SR || t == RegionType::MSR || !owns(pos[r])) continue;
+            longest = std::max(longest, pos[r + 1] - pos[r]);
+        }
+    } else if (!ctg._pseudo_reg_type.empty()) {
+        std::vector<uint32_t> pos;
+        ctg._pseudo_reg_pos.list_set(pos);
+        const size_t np = ctg._pseudo_reg_type.size() - 1;
+        for (size_t i = 0; i < np && i + 1 < pos.size(); ++i)
+            if (ctg._pseudo_reg_type[i] == RegionType::LONG && owns(pos[i])) longest = std::max(longest, pos[i + 1] - pos[i]);
+    }
+    return longest;
+}
+
 bool DeviceArms::upload_reads(std::vector<std::unique_ptr<Contig>>& contigs, uint32_t c0, uint32_t c1, const ReadBatch& reads) {
     _reads_resident = false;
     const bool timing = std::getenv("HYPO_HOST_TIMING") != nullptr;

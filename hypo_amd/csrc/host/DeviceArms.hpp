@@ -26,9 +26,23 @@ public:
     // give an arm to an owned window lies inside the halo (halo >= longest read span + longest window), and a read's walk over the
     // k-mers / minimizers of its own span sees all of them, so the owned results are what a single context computes.
     void set_piece(uint32_t own0, uint32_t own1, uint32_t halo, uint32_t contig_len) {
-        _piece = true; _own0 = own0; _own1 = own1;
+        _piece = true; _own0 = own0; _own1 = own1; _halo = halo; _piece_len = contig_len;
         _span[0] = own0 > halo ? own0 - halo : 0; _span[1] = (uint64_t)own1 + halo < contig_len ? own1 + halo : contig_len;
     }
+    // The halo is chosen before the contig is divided (the votes that decide the division need the reads first); a read gives an arm to
+    // an owned window [ws, we) iff rb < we, so every such read lies inside the span iff the halo is at least the longest owned window.
+    // longest_owned_window: that length, over the SHORT windows (long_windows = false: the regions of divide_into_regions that are not
+    // strong) or the LONG pseudo-windows of prepare_long_windows — a weak region inside a homopolymer run that force_divide cannot cut
+    // (src/Contig.cpp:641-666) has no bound.  widen_halo: true when the halo had to grow (the span is recomputed and the resident short
+    // reads are dropped, so that build() uploads the reads of the wider span; build_long() flattens the long reads by the span anyway).
+    uint32_t longest_owned_window(const Contig& ctg, bool long_windows) const;
+    bool widen_halo(uint32_t need) {
+        if (!_piece || need <= _halo) return false;
+        set_piece(_own0, _own1, need, _piece_len);
+        _reads_resident = false;
+        return true;
+    }
+    uint32_t halo() const { return _halo; }
     void clear_piece() { _piece = false; }
     bool piece() const { return _piece; }
     bool owns(uint64_t pos) const { return !_piece || (pos >= _own0 && pos < _own1); }
@@ -70,7 +84,7 @@ public:
 
 private:
     int _slot = 0;
-    bool _piece = false; uint32_t _own0 = 0, _own1 = 0, _span[2] = {0, 0};
+    bool _piece = false; uint32_t _own0 = 0, _own1 = 0, _span[2] = {0, 0}, _halo = 0, _piece_len = 0;
     uint64_t _n_pol[2] = {0, 0};
     bool _reads_resident = false; uint32_t _reads_c0 = 0, _reads_c1 = 0;
     bool _active = false;

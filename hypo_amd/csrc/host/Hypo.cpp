@@ -13,6 +13,10 @@
 #include <atomic>
 namespace hypo {
 extern std::atomic<uint64_t> g_stage_counters[5];      // host/Contig.cpp
+namespace {
+std::string pending_tmp;                               // <output>.tmp while a run is writing it (Hypo::polish); removed by a run that fails
+void remove_pending_output() { if (!pending_tmp.empty()) std::remove(pending_tmp.c_str()); }
+}
 
 Hypo::Hypo(const InputFlags& flags) : _cFlags(flags) {
     omp_set_num_threads((int)_cFlags.threads);
@@ -130,9 +134,15 @@ void Hypo::polish() {
     // The polished contigs of a batch are filed by a writer thread while the next batch is processed (the reference writes
     // everything at the end, src/Hypo.cpp:256-268: the same bytes in the same order); what a written contig no longer needs is
     // released there.
-    std::ofstream ofile(_cFlags.output_filename);
+    // The records go to <output>.tmp, which takes the output's name only when every contig is in it and the file closed without an error:
+    // a run that fails half way (a device error, a bad record three batches in) leaves no truncated file under the name the caller asked
+    // for, and an earlier result under that name stays what it was.  A failing run removes its .tmp on the way out.
+    pending_tmp = _cFlags.output_filename + ".tmp";
+    static bool cleanup_registered = false;
+    if (!cleanup_registered) { cleanup_registered = true; std::atexit(remove_pending_output); }
+    std::ofstream ofile(pending_tmp);
     if (!ofile.is_open()) {
-        std::fprintf(stderr, "[Hypo::Hypo] Error: File open error: Output File (%s) could not be opened!\n", _cFlags.output_filename.c_str());
+        std::fprintf(stderr, "[Hypo::Hypo] Error: File open error: Output File (%s) could not be opened!\n", pending_tmp.c_str());
         std::exit(1);
     }
     std::thread writer;
@@ -181,8 +191,14 @@ void Hypo::polish() {
         // ... in front of them but for ONE: when the short-read loader of the batch before had already consumed this contig's first short
         // read, that record was filed first (store entry = [short carry, long carry, this batch's short reads ..]): the long read goes
         // behind the batch's opening record then.  Arm order inside a window is record order, and POA depends on it.
+        // (the contig the batch opened with goes FIRST: `slices_before + 1` is an index into the slice list as it stands now, and every
+        // other contig's records are put in front of everything afterwards, which shifts indices but not the order inside a contig)
+        if (opened_with_cid >= (int32_t)initial_cid && opened_with_cid < (int32_t)final_cid && !_alignment_store[(size_t)opened_with_cid].empty()) {
+            _reads.prepend((uint32_t)opened_with_cid, _alignment_store[(size_t)opened_with_cid], slices_before + 1);
+            _alignment_store[(size_t)opened_with_cid].clear();
+        }
         for (uint32_t c = initial_cid; c < final_cid; ++c)
-            if (!_alignment_store[c].empty()) { _reads.prepend(c, _alignment_store[c], opened_with_cid == (int32_t)c ? slices_before + 1 : 0); _alignment_store[c].clear(); }
+            if (!_alignment_store[c].empty()) { _reads.prepend(c, _alignment_store[c], 0); _alignment_store[c].clear(); }
 
         // With several devices the contigs of the batch are dealt out to the contexts in contiguous ranges of about equal
         // numbers of alignments: every context keeps the reads of its contigs, counts their support votes, cuts their arms and
@@ -346,6 +362,13 @@ void Hypo::polish() {
             for (int d = 0; d < n_ctx; ++d) {
                 const uint32_t c0 = work[(size_t)d].c0, c1 = work[(size_t)d].c1;
                 if (c0 >= c1) continue;
+                if (work[(size_t)d].piece) {
+                    // the halo was chosen before the division: a window longer than it (a weak region force_divide could not cut) would lose
+                    // the arms of the reads beyond it — the span grows to the longest window this context owns and its reads go over again
+                    const uint32_t longest = device_arms[(size_t)d]->longest_owned_window(*_contigs[c0], false);
+                    if (device_arms[(size_t)d]->widen_halo(longest + 64))
+                        std::fprintf(stdout, "[Hypo::Hypo] Info: context %d owns a window of %u bases: halo widened to %u, its reads are uploaded again\n", d, longest, device_arms[(size_t)d]->halo());
+                }
                 if (device_arms[(size_t)d]->build(_contigs, c0, c1, _reads, _cFlags.k))
                     for (uint32_t c = c0; c < c1; ++c) on_dev[c - initial_cid] = 1;
                 else if (work[(size_t)d].piece) piece_failed(d, "short-arm selection");
@@ -407,6 +430,11 @@ void Hypo::polish() {
                 for (int d = 0; d < n_ctx; ++d) {
                     const uint32_t c0 = work[(size_t)d].c0, c1 = work[(size_t)d].c1;
                     if (c0 >= c1) continue;
+                    if (work[(size_t)d].piece) {                     // (as for the short arms: the LONG pseudo-windows exist only now)
+                        const uint32_t longest = device_arms[(size_t)d]->longest_owned_window(*_contigs[c0], true);
+                        if (device_arms[(size_t)d]->widen_halo(longest + 64))
+                            std::fprintf(stdout, "[Hypo::Hypo] Info: context %d owns a LONG window of %u bases: halo widened to %u\n", d, longest, device_arms[(size_t)d]->halo());
+                    }
                     if (device_arms[(size_t)d]->build_long(_contigs, c0, c1, _reads_long))
                         for (uint32_t c = c0; c < c1; ++c) long_on_dev[c - initial_cid] |= 1;
                     else {
@@ -521,7 +549,12 @@ void Hypo::polish() {
     start();
     if (writer.joinable()) writer.join();
     ofile.close();
-    if (!ofile) { std::fprintf(stderr, "[Hypo::Hypo] Error: writing the output file (%s) failed!\n", _cFlags.output_filename.c_str()); std::exit(1); }
+    if (!ofile) { std::fprintf(stderr, "[Hypo::Hypo] Error: writing the output file (%s) failed!\n", pending_tmp.c_str()); std::exit(1); }
+    if (std::rename(pending_tmp.c_str(), _cFlags.output_filename.c_str()) != 0) {
+        std::fprintf(stderr, "[Hypo::Hypo] Error: could not move %s to %s!\n", pending_tmp.c_str(), _cFlags.output_filename.c_str());
+        std::exit(1);
+    }
+    pending_tmp.clear();
     stop("[Hypo:Hypo]: Writing results. ");
     _times.overall = std::chrono::duration<double>(std::chrono::steady_clock::now() - _tstart).count();
     std::fprintf(stdout, "RESOURCES ([Hypo:Hypo]: Overall. ): TIME= %g sec.\n", _times.overall);
@@ -664,6 +697,7 @@ void Hypo::create_alignments_flat(uint32_t batch_id, ReadBatch& into, bool is_sr
                 // (this may be the helper thread, with the main thread inside a device call: leave without running the static
                 // destructors under it)
                 std::fflush(nullptr);
+                remove_pending_output();
                 std::_Exit(1);
             }
             if (st == ParsedBlock::ST_KEPT) ++num_alns; else ++num_invalid;

@@ -170,15 +170,17 @@ scan_fused_kernel(const uint8_t* __restrict__ packed4, uint64_t n_bases, uint32_
         };
         uint64_t vin = 0, vgr = 0;                            // counts of this group's tiles before this one; totals of the groups before
         if (g0 + (uint64_t)tid < tile) vin = wait_for(status + g0 + tid);
-        for (uint64_t g = (uint64_t)tid; g < grp; g += SCAN_THREADS) vgr += wait_for(gstatus + g);
-        for (int d = 32; d >= 1; d >>= 1) { vin += __shfl_xor(vin, d, 64); vgr += __shfl_xor(vgr, d, 64); }
-        if (lane == 0) { s_part[tid >> 6] = vin; s_part[4 + (tid >> 6)] = vgr; }
-        __syncthreads();
-        if (tid == 0) {
-            const uint64_t in = s_part[0] + s_part[1] + s_part[2] + s_part[3], gr = s_part[4] + s_part[5] + s_part[6] + s_part[7];
-            if (tile == g0 + SCAN_GROUP - 1) st_store(gstatus + grp, ST_AGGREGATE | (in + (uint64_t)s_total));      // the group's total
-            s_prefix = in + gr;
+        for (int d = 32; d >= 1; d >>= 1) vin += __shfl_xor(vin, d, 64);
+        if (lane == 0) s_part[tid >> 6] = vin;
+        if (tile == g0 + SCAN_GROUP - 1) {                    // (block-uniform) the group's total goes out BEFORE this tile waits for the totals
+            __syncthreads();                                  // of the groups before it: a group's total depends on its own tiles only, no chain
+            if (tid == 0) st_store(gstatus + grp, ST_AGGREGATE | (s_part[0] + s_part[1] + s_part[2] + s_part[3] + (uint64_t)s_total));
         }
+        for (uint64_t g = (uint64_t)tid; g < grp; g += SCAN_THREADS) vgr += wait_for(gstatus + g);
+        for (int d = 32; d >= 1; d >>= 1) vgr += __shfl_xor(vgr, d, 64);
+        if (lane == 0) s_part[4 + (tid >> 6)] = vgr;
+        __syncthreads();
+        if (tid == 0) s_prefix = s_part[0] + s_part[1] + s_part[2] + s_part[3] + s_part[4] + s_part[5] + s_part[6] + s_part[7];
         __syncthreads();
     }
     const uint64_t prefix = s_prefix;

@@ -190,7 +190,10 @@ __global__ void __launch_bounds__(TT) support_kmers_kernel(SupportReads R, uint3
         __syncthreads();
         // what the tile collected goes out; the coverage of the entries no later tile comes back to: [g0, next tile's start)
         for (uint32_t i = tid; i < tn; i += TT) { const uint32_t v = s_sup[i]; if (v) atomicAdd(&sup[g0 + i], v); }
-        const uint32_t g1 = s_next == 0xffffffffu ? bhi : s_next;     // (>= g0: cursors only grow; > g0 unless a lane paused without moving, which a tile of KCAP entries excludes)
+        uint32_t g1 = s_next == 0xffffffffu ? bhi : s_next;           // (>= g0: cursors only grow; > g0 unless a lane paused without moving, which a tile of KCAP entries excludes)
+        // forward-progress guard, as in support_minimizers_kernel: should the invariant above ever be violated (duplicate positions in a
+        // batch's coordinate space, a k beyond what KCAP / 4 entries cover) the tile still advances and the launch ends instead of spinning
+        if (g1 <= g0) g1 = g0 + 1 < bhi ? g0 + 1 : bhi;
         for (uint32_t c0 = g0; c0 < g1; c0 += KCAP) {
             const uint32_t c1 = g1 - c0 < KCAP ? g1 : c0 + KCAP, cn = c1 - c0;
             __syncthreads();

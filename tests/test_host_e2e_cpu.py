@@ -100,3 +100,29 @@ def test_realistic_golden_with_long_reads_over_the_shim(built, tmp_path):
                                          long_path=str(tmp_path / "lr.bam"))
         assert open(tmp_path / "ref.fa", "rb").read() == open(tmp_path / "hypo_draft.fasta", "rb").read()
         assert rr["windows"] == man["reference_counts"]["windows"]
+
+
+def test_output_appears_only_when_the_run_succeeded(built, tmp_path):
+    """The polished FASTA is written to <output>.tmp and renamed when complete: a run that dies after its first batch — here a
+    record that names a contig the draft does not have, the reference's own fatal error (src/Hypo.cpp:303-306) — leaves an earlier file under
+    the output's name untouched and no .tmp behind; a good run replaces it."""
+    import subprocess
+    import shlex
+    man = eu.make_inputs("e2e_5ctg_long_s21", tmp_path)
+    argv = shlex.split(man["command"])
+    argv[0] = eu.BIN
+    argv += ["-p", "1"] if "-p" not in argv else []
+    env = dict(__import__("os").environ, LD_LIBRARY_PATH=eu.SHIM_DIR)
+    out = tmp_path / "hypo_draft.fasta"
+    out.write_text("OLD RESULT\n")
+    sam = tmp_path / "sr.sam"
+    good = sam.read_text()
+    sam.write_text(good + "zz\t0\tno_such_contig\t5\t60\t10M\t*\t0\t0\tACGTACGTAC\t*\n")
+    p = subprocess.run(argv, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "does not exist in the draft" in p.stderr
+    assert "polished windows (Batch 0)" in p.stdout                       # it had got past the first batch
+    assert out.read_text() == "OLD RESULT\n" and not (tmp_path / "hypo_draft.fasta.tmp").exists()
+    sam.write_text(good)
+    p = subprocess.run(argv, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-500:]
+    assert eu._md5(str(out)) == man["expected_fasta_md5"] and not (tmp_path / "hypo_draft.fasta.tmp").exists()
