@@ -422,6 +422,11 @@ int hypo_gpu_set_option(const char* name, int value) {
         for (int i = 0; i < kMaxDevices; ++i) g_ctxs[i].poa_flags = (g_ctxs[i].poa_flags & ~(3 << hypo::POA_MIN_CLASS_SHIFT)) | (value << hypo::POA_MIN_CLASS_SHIFT);
         return HYPO_OK;
     }
+    if (!strcmp(name, "giant_arena_mb")) {               // HBM of size class 6 per POA context created from now on (poa_giant.hpp); 0 = none
+        if (value < 0 || value > (1 << 20)) return fail(HYPO_E_INVALID, "giant_arena_mb %d out of range", value);
+        hypo::poa_set_giant_arena_mb(value);
+        return HYPO_OK;
+    }
     return fail(HYPO_E_INVALID, "unknown option %s", name);
 }
 

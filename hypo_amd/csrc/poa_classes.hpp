@@ -50,6 +50,7 @@ typedef PoaCfg<64, 10, 639, 2400, 12, 1536000, 491520, 16384, 256, int16_t, uint
 // node (61 MB of HBM scratch per resident group, few groups: it is slow and rare).
 typedef PoaCfg<64, 16, 1023, 32767, 58, 1 << 25, 1 << 21, 16384, 16383, int32_t, uint16_t, 1 << 22> PoaClass5;
 constexpr int kNumPoaClasses = 6;
+constexpr int kGiantClass = 6;          // poa_giant.hpp: its queue counter / head / statistics use slot 6 of the per-class arrays, its queue the region of class 0's
 }  // namespace hypo
 
 #define HYPO_FOR_EACH_CLASS(X) X(0, PoaClass0) X(1, PoaClass1) X(2, PoaClass2) X(3, PoaClass3) X(4, PoaClass4) X(5, PoaClass5)

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include "poa_classes.hpp"
 #include "poa_kernel.hpp"
+#include "poa_giant.hpp"
 #include <cstring>
 
 namespace hypo {
@@ -341,6 +342,13 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
                 __hip_atomic_store(&fresh(ka)->Q.items[(size_t)to * fresh(ka)->Q.stride + slot], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if constexpr (USE_LDS) { if (g.lane == 0) stt[PoaT::ACC_NESC] += 1; } else ++n_esc;
+        } else if (rc == RES_OVERFLOW || rc == RES_UNSUPPORTED) {
+            // beyond the last table-driven class: the window goes to size class 6 (poa_giant.hpp), which runs behind this launch and takes
+            // its windows from the queue region class 0 no longer needs (classes 0-2 were joined before this class started)
+            if (g.lane == 0) {
+                const uint32_t slot = atomicAdd(&fresh(ka)->Q.count[kGiantClass], 1u);
+                __hip_atomic_store(&fresh(ka)->Q.items[slot], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         } else {
             if (g.lane == 0) {
                 P->out_len[w] = 0;
@@ -463,6 +471,57 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
     }
     if (!POLL && USE_LDS && wl == 0) atomicAdd((unsigned long long*)(fresh(ka)->Q.work + cls), (unsigned long long)wall_clock64());
 }
+
+// ------------------------------------------------------------------------------------------------
+// size class 6: one wave per window, the window's state in a slice of PoaAux::giant_arena (poa_giant.hpp)
+// ------------------------------------------------------------------------------------------------
+struct GiantKArgs { PoaParams P; PoaQueues Q; char* arena; uint64_t slice_bytes; };
+__global__ void __launch_bounds__(64) poa_giant_kernel(GiantKArgs /*read through the kernarg segment*/) {
+    typedef const GiantKArgs __attribute__((address_space(4)))* KPtr;
+    const KPtr ka = (KPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    const uint32_t pending = ka->Q.count[kGiantClass];
+    if (pending == 0) return;                                  // (nearly every call)
+    const Grp<64> g{(int)(threadIdx.x & 63)};
+    const PoaParamRef P{&ka->P};
+    uint64_t cells = 0, aligns = 0, abytes = 0;
+    uint32_t n_ok = 0, n_fail = 0;
+    char* const slice = ka->arena ? ka->arena + (size_t)blockIdx.x * ka->slice_bytes : nullptr;
+    for (;;) {
+        uint32_t idx = 0;
+        if (g.lane == 0) idx = atomicAdd(ka->Q.head + kGiantClass, 1u);
+        idx = (uint32_t)g.shfl((int)idx, 0);
+        if (idx >= pending) break;
+        const uint32_t w = ka->Q.items[idx];
+        Giant<Grp<64>> gi(g, P);
+        const int rc = slice ? gi.run(w, slice, ka->slice_bytes) : (int)RES_OVERFLOW;
+        if (rc == RES_OK) {
+            cells += gi.cells; aligns += gi.aligns; ++n_ok;
+            const HypoWindow W = P->windows[w];
+            const uint32_t narm = W.n_internal + W.n_prefix + W.n_suffix;
+            uint64_t a = (uint64_t)(W.draft_len + 1) / 2 + 16 + 8ull * (1 + narm) + P->out_len[w];
+            uint32_t part = 0;
+            for (uint32_t t = (uint32_t)g.lane; t < narm; t += 64) part += (P->arm_len[W.first_arm + t] + 3) / 4;
+            abytes += a + (uint64_t)(uint32_t)g.reduce_add((int)part);
+        } else {
+            if (g.lane == 0) {
+                P->out_len[w] = 0;
+                P->out_status[w] = (uint8_t)(rc == RES_UNDEFINED ? HYPO_ST_UNDEFINED : (rc == RES_INVALID ? HYPO_ST_INVALID : HYPO_ST_CAPACITY));
+            }
+            ++n_fail;
+        }
+    }
+    if (g.lane == 0) {
+        HypoPoaStats* st = ka->Q.stats;
+        atomicAdd((unsigned long long*)&st->n_class[kGiantClass], (unsigned long long)n_ok);
+        atomicAdd((unsigned long long*)&st->n_failed, (unsigned long long)n_fail);
+        atomicAdd((unsigned long long*)&st->dp_cells, (unsigned long long)cells);
+        atomicAdd((unsigned long long*)&st->n_alignments, (unsigned long long)aligns);
+        atomicAdd((unsigned long long*)&st->cells_scored, (unsigned long long)cells);
+        atomicAdd((unsigned long long*)&st->alg_bytes[kGiantClass], (unsigned long long)abytes);
+    }
+}
+static int g_giant_arena_mb = 1024;
+void poa_set_giant_arena_mb(int mb) { g_giant_arena_mb = mb < 0 ? 0 : mb; }
 
 // ------------------------------------------------------------------------------------------------
 // launch
@@ -949,6 +1008,16 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
         if ((e = launch_class<PoaClass5, false>(P, Q, 5, rare_grid_hint(5), scr5, num_cus, stream)) != hipSuccess) return e;
         rec(3 + 2 * 5, stream);
     }
+    // size class 6 behind everything else: what class 5 could not hold (its launch is empty-handed in nearly every call and leaves at once)
+    {
+        if (!A->giant_arena && g_giant_arena_mb > 0) {
+            const size_t want = (size_t)g_giant_arena_mb << 20;
+            if (hipMalloc((void**)&A->giant_arena, want) == hipSuccess) A->giant_bytes = want; else { A->giant_arena = nullptr; A->giant_bytes = 0; (void)hipGetLastError(); }
+        }
+        GiantKArgs ga{P, Q, A->giant_arena, (uint64_t)(A->giant_bytes / kGiantWaves) / 256 * 256};
+        hipLaunchKernelGGL(poa_giant_kernel, dim3(kGiantWaves), dim3(64), 0, stream, ga);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     // this call's final and planned counts for the next call's grid sizes (no wait: whoever reads them gets the last finished call)
     (void)hipMemcpyAsync(pinned + 8, Q.count, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
     (void)hipMemcpyAsync(pinned + 24, Q.work, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream);
@@ -971,6 +1040,7 @@ void poa_release(PoaAux* a) {
     if (a->fork_ev) (void)hipEventDestroy(a->fork_ev);
     if (a->planned_ev) (void)hipEventDestroy(a->planned_ev);
     if (a->planned_host) (void)hipHostFree(a->planned_host);
+    if (a->giant_arena) (void)hipFree(a->giant_arena);
     *a = PoaAux();
 }
 

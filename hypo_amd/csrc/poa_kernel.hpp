@@ -70,7 +70,13 @@ struct PoaAux {
     // the plan of the SHORT batch before it got 256 of its 2 048 waves: 1.84 s instead of 0.35 s on the 250 Mbp set of round 4),
     // and the call waits for its own plan as a first call does.
     int next_kind = 0, last_kind = 0;
+    // size class 6 (poa_giant.hpp): HBM for the windows nothing else holds, kGiantWaves slices; allocated by the first call
+    char* giant_arena = nullptr;
+    size_t giant_bytes = 0;
 };
+constexpr int kGiantWaves = 2;                 // resident windows of class 6 (one wave and one slice of the arena each)
+// megabytes of PoaAux::giant_arena of contexts created from now on (default 1024; 0: no class 6, such windows answer HYPO_ST_CAPACITY)
+void poa_set_giant_arena_mb(int mb);
 void poa_release(PoaAux* a);
 
 // Bytes for a batch of n_windows windows.  long_groups = resident groups of the LONG class the scratch is provisioned for

@@ -131,7 +131,11 @@ int hypo_gpu_use_device(int slot);
  *                  834-840,859-861); 0 (default) = the scalar engine's rule, which the reference's default build uses.
  *   "poa_min_class" 0..3 (default 0): SHORT windows start in at least this size class of the POA kernel.  Results do not depend on it
  *                  (every class computes the reference's consensus); parity sweeps use it to run small windows through the code
- *                  of the larger classes (tests/exhaustive_parity.py). */
+ *                  of the larger classes (tests/exhaustive_parity.py).
+ *   "giant_arena_mb" megabytes of HBM that size class 6 of the POA kernel gets per POA context created after the call (default 1024): the
+ *                  windows beyond the table-driven classes — an arm or draft of more than 1 021 bases, more than 16 382 sequences, more
+ *                  than 32 767 nodes — run there with their whole state in a slice of it (two windows at a time), by the reference's own
+ *                  procedure with its full score matrix.  A window that needs more than a slice answers HYPO_ST_CAPACITY; 0 = no class 6. */
 int hypo_gpu_set_option(const char* name, int value);
 /* First 16 hex digits of the SHA-256 over the library's sources (the .hip and .hpp files of hypo_amd/csrc and this header, in sorted
  * order), embedded at build time: says which sources a prebuilt libhypo_gpu.so came from (tests/test_abi.py checks it). */

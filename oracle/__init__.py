@@ -133,6 +133,9 @@ def _replay(fn, seqs, modes, scores):
         cons[:cl.value].tobytes().decode()
 
 
+REF_ST_FILTERED = 0xF0      # hyporef_batch: a LONG window whose own arm filter dropped one of the arms it was handed (not comparable with the batch)
+
+
 class Ref:
     """The real reference (hypo::Window + adapted spoa), SISD flavour."""
 

@@ -117,6 +117,7 @@ int hyporef_batch(const int8_t sc[6], const HypoWindowBatch* in, HypoConsensusBa
     if (n_threads < 1) n_threads = omp_get_max_threads();
     const uint32_t n = in->n_windows;
     std::vector<std::unique_ptr<Window>> ws(n);
+    std::vector<uint8_t> filtered(n, 0);
 #pragma omp parallel for schedule(static) num_threads(n_threads)
     for (int64_t w = 0; w < (int64_t)n; ++w) {
         const HypoWindow& W = in->windows[w];
@@ -127,6 +128,10 @@ int hyporef_batch(const int8_t sc[6], const HypoWindowBatch* in, HypoConsensusBa
         for (uint32_t i = 0; i < W.n_prefix; ++i, ++a) ws[w]->add_prefix(PackedSeq<2>(text2(in->arms2 + in->arm_off[a], in->arm_len[a])));
         for (uint32_t i = 0; i < W.n_suffix; ++i, ++a) ws[w]->add_suffix(PackedSeq<2>(text2(in->arms2 + in->arm_off[a], in->arm_len[a])));
         for (uint32_t i = 0; i < W.n_empty; ++i) ws[w]->add_empty();
+        // A LONG window filters its arms as they are added (Filter::is_good in Window::add_*, include/Window.hpp:66-101).  The C-ABI batch
+        // holds the arms that PASSED (the arm kernels / the host apply the filter when they cut the arms); a window handed over here
+        // with an arm its own filter drops is not the window the batch describes: reported as HYPOREF_ST_FILTERED, not compared.
+        if (ws[w]->get_num_total() != W.n_internal + W.n_prefix + W.n_suffix + W.n_empty) filtered[w] = 1;
     }
     ScoreParams sp{sc[0], sc[1], sc[2], sc[3], sc[4], sc[5]};
     const int base = g_engines;
@@ -144,6 +149,7 @@ int hyporef_batch(const int8_t sc[6], const HypoWindowBatch* in, HypoConsensusBa
     if (seconds_out) *seconds_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (uint32_t w = 0; w < n; ++w) {
         if (undefined[w]) { out->len[w] = 0; out->status[w] = HYPO_ST_UNDEFINED; continue; }
+        if (filtered[w]) { out->len[w] = 0; out->status[w] = 0xF0; continue; }      // HYPOREF_ST_FILTERED
         const std::string c = ws[w]->get_consensus();
         const uint64_t cap = out->off[w + 1] - out->off[w];
         out->len[w] = (uint32_t)c.size();

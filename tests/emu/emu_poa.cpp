@@ -13,6 +13,7 @@
 #include <cstring>
 #include <vector>
 #include "../../hypo_amd/csrc/poa_core.hpp"
+#include "../../hypo_amd/csrc/poa_giant.hpp"
 
 #if defined(__has_feature)
 #if __has_feature(address_sanitizer)
@@ -68,7 +69,10 @@ thread_local Sched* tl_sched = nullptr;
 void yield_cb(void* s_) {
     Sched* s = (Sched*)s_;
     int cur = s->cur, nxt = (cur + 1) % s->gw;
-    if (s->done[nxt]) { fprintf(stderr, "[emu] non-uniform control flow: lane %d waits for finished lane %d\n", cur, nxt); abort(); }
+    static thread_local uint64_t n_yield[64];
+    n_yield[cur]++;
+    if (s->done[nxt]) { fprintf(stderr, "[emu] non-uniform control flow: lane %d waits for finished lane %d (yields so far: lane 0 %llu, lane 1 %llu, lane 62 %llu, lane 63 %llu)\n", cur, nxt,
+                                (unsigned long long)n_yield[0], (unsigned long long)n_yield[1], (unsigned long long)n_yield[62], (unsigned long long)n_yield[63]); abort(); }
     s->cur = nxt;
     emu_switch(&s->sp[cur], s->sp[nxt]);
 }
@@ -286,3 +290,54 @@ extern "C" int emu_class_bytes(int cfg_id) {
 extern "C" void emu_dbg_hist(unsigned long* out) { for (int i = 0; i < 64; ++i) { out[i] = hypo::g_dbg_hist[i]; hypo::g_dbg_hist[i] = 0; } }
 extern "C" void emu_dbg_reasons(unsigned long* out) { for (int i = 0; i < 16; ++i) { out[i] = hypo::g_dbg_reason[i]; hypo::g_dbg_reason[i] = 0; } }
 #endif
+
+
+// ---- size class 6 (hypo_amd/csrc/poa_giant.hpp): every window of the batch through Giant::run with a slice of `slice_bytes` ------------
+namespace {
+struct GiantJob {
+    hypo::EmuGroup eg;
+    const hypo::PoaParams* P;
+    char* slice; uint64_t slice_bytes;
+    uint32_t w;
+    int rc[64];
+    uint64_t cells, aligns;
+};
+void giant_lane_body(int lane, void* arg) {
+    GiantJob* j = (GiantJob*)arg;
+    hypo::Grp<64> g{lane, &j->eg};
+    const hypo::PoaParamRef pr{j->P};
+    hypo::Giant<hypo::Grp<64>> gi(g, pr);
+    j->rc[lane] = gi.run(j->w, j->slice, j->slice_bytes);
+    if (getenv("HYPO_EMU_DEBUG") && (lane < 2 || lane == 63)) fprintf(stderr, "[emu] giant lane %d rc %d\n", lane, j->rc[lane]);
+    if (lane == 0) { j->cells = gi.cells; j->aligns = gi.aligns; }
+}
+}  // namespace
+
+extern "C" int emu_poa_giant(const HypoScoreParams* sp, const HypoWindowBatch* in, HypoConsensusBatch* out, uint64_t slice_bytes,
+                             uint8_t* res, uint64_t* cells, uint64_t* aligns) {
+    hypo::PoaParams P;
+    P.windows = in->windows; P.draft4 = in->draft4; P.arm_off = in->arm_off; P.arm_len = in->arm_len; P.arms2 = in->arms2;
+    P.out_bases = out->bases; P.out_off = out->off; P.out_len = out->len; P.out_status = out->status;
+    P.sr_m = sp->sr_match; P.sr_n = sp->sr_mismatch; P.sr_g = sp->sr_gap;
+    P.lr_m = sp->lr_match; P.lr_n = sp->lr_mismatch; P.lr_g = sp->lr_gap;
+    P.n_arms = in->n_arms; P.draft4_bytes = in->draft4_bytes; P.arms2_bytes = in->arms2_bytes;
+    P.flags = getenv("HYPO_EMU_NATIVE_KLOV") ? hypo::POA_NATIVE_KLOV : 0;
+    *cells = 0; *aligns = 0;
+    Sched s;
+    const int fill = getenv("HYPO_EMU_FILL") ? (int)strtol(getenv("HYPO_EMU_FILL"), nullptr, 0) : 0xA5;
+    for (uint32_t w = 0; w < in->n_windows; ++w) {
+        GiantJob job;
+        job.P = &P; job.eg.gw = 64; job.eg.yield = yield_cb; job.eg.sched = &s;
+        job.slice = (char*)malloc(slice_bytes);                  // exact size: ASan sees overruns
+        memset(job.slice, fill, slice_bytes);
+        job.slice_bytes = slice_bytes; job.w = w; job.cells = job.aligns = 0;
+        out->status[w] = 0xFF; out->len[w] = 0;
+        run_group(s, 64, giant_lane_body, &job);
+        for (int l = 1; l < 64; ++l) if (job.rc[l] != job.rc[0]) { fprintf(stderr, "[emu] giant: lanes disagree on the result of window %u\n", w); abort(); }
+        res[w] = (uint8_t)job.rc[0];
+        if (job.rc[0] == hypo::RES_OK) { *cells += job.cells; *aligns += job.aligns; }
+        free(job.slice);
+    }
+    free(s.stacks);
+    return 0;
+}

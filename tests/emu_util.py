@@ -73,3 +73,24 @@ class Emu:
         cons = [bases[int(off[i]):int(off[i]) + int(ln[i])].tobytes().decode()
                 if (res[i] == RES_OK and st[i] == 0) else None for i in range(n)]
         return cons, res, hops, carried
+
+    def poa_giant(self, b, scores=abi.DEFAULT_SCORES, off=None, slice_bytes=1 << 24):
+        """Every window through size class 6 (hypo_amd/csrc/poa_giant.hpp: Giant::run with a slice of `slice_bytes`).  Returns
+        (consensus strings or None, status, result codes, cells, alignments)."""
+        sp = abi.ScoreParams(*scores)
+        if off is None:
+            off = b.slot_layout()
+        n = b.n_windows
+        bases = np.zeros(int(off[-1]) + 1, dtype=np.uint8)
+        ln = np.zeros(n, dtype=np.uint32)
+        st = np.zeros(n, dtype=np.uint8)
+        res = np.zeros(n, dtype=np.uint8)
+        ins = _oracle.batch_struct(b)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        out = abi.ConsensusBatch(p(bases), p(off), p(ln), p(st))
+        cells, aligns = C.c_uint64(0), C.c_uint64(0)
+        self.lib.emu_poa_giant.restype = C.c_int
+        rc = self.lib.emu_poa_giant(C.byref(sp), C.byref(ins), C.byref(out), C.c_uint64(slice_bytes), p(res), C.byref(cells), C.byref(aligns))
+        assert rc == 0
+        cons = [bases[int(off[i]):int(off[i]) + int(ln[i])].tobytes().decode() if (res[i] == RES_OK and st[i] == 0) else None for i in range(n)]
+        return cons, st, res, int(cells.value), int(aligns.value)

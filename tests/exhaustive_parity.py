@@ -168,6 +168,11 @@ def describe(b, w):
 def first_difference(a, b, off):
     """a, b = (bases, len, status) laid out on the same slots `off`; index of the first window that differs, or -1."""
     (ab, al, ast), (bb, bl, bst) = a, b
+    skip = (ast == 0xF0) | (bst == 0xF0)      # oracle.REF_ST_FILTERED: a LONG window whose arms the reference's own Window filter would not all keep
+    if skip.any():
+        al, bl, ast, bst = al.copy(), bl.copy(), ast.copy(), bst.copy()
+        al[skip] = bl[skip] = 0
+        ast[skip] = bst[skip] = 0
     bad = np.nonzero((al != bl) | (ast != bst))[0]
     if bad.size:
         return int(bad[0])

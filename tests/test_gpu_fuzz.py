@@ -139,3 +139,38 @@ def test_klov_one_substitution_with_a_second_end(gpu, oracle_lib):
     cons, st = gpu.poa_consensus(b, (5, -4, -8, 3, -5, -4))
     ocons, ost = oracle_lib.poa_batch(b)[:2]
     assert [i for i in range(300) if cons[i] != ocons[i] or st[i] != ost[i]] == []
+
+
+def test_windows_beyond_the_table_driven_classes_run_in_class_6(gpu, oracle_lib):
+    """What used to keep its draft with HYPO_ST_CAPACITY: a LONG window in which two long-read arms carry a 1 500-base insertion (sequences
+    beyond class 5's 1 021 bases), a SHORT window with a 1 300-base draft, and the 20 000 short arms of a collapsed repeat (class 5 holds
+    16 382 sequences) run in size class 6 (hypo_amd/csrc/poa_giant.hpp) and answer what hypo::Window::generate_consensus answers
+    (oracle/_ref/libhyporef.so; the reference has no size limit: external/spoa/src/sisd_alignment_engine.cpp:60-93, graph.cpp:99-128)."""
+    import oracle
+    from test_giant import giant_windows
+    rng = np.random.default_rng(606)
+    wins = giant_windows(rng, deep_arms=20000) + [_window(rng, False) for _ in range(200)]
+    b = build_batch(wins)
+    off = b.slot_layout()
+    bases, _, ln, st = gpu.poa_batch(b, off=off)
+    s = gpu.last_stats()
+    assert (st == 0).all() and s["n_failed"] == 0, (st[:3], s)
+    assert s["n_class"][6] == 3, s["n_class"]                    # they really ran there
+    ob, _, oln, ost, cells, aligns = oracle_lib.poa_batch_raw(b, off=off)
+    assert (ost == 0).all() and (ln == oln).all()
+    got = [bases[int(off[i]):int(off[i]) + int(ln[i])].tobytes() for i in range(b.n_windows)]
+    assert got == [ob[int(off[i]):int(off[i]) + int(oln[i])].tobytes() for i in range(b.n_windows)]
+    assert s["dp_cells"] == cells and s["n_alignments"] == aligns
+    if oracle.Ref.available():
+        rb, _, rln, rst, _ = oracle.Ref().poa_batch_raw(b, off=off)
+        assert (rst == 0).all() and got == [rb[int(off[i]):int(off[i]) + int(rln[i])].tobytes() for i in range(b.n_windows)]
+    # a context without the arena answers HYPO_ST_CAPACITY for them (and only for them)
+    import ctypes as C
+    assert gpu.lib.hypo_gpu_set_option(b"giant_arena_mb", C.c_int(1)) == 0          # 1 MB: two slices of 512 KB hold none of the three
+    try:
+        g2 = type(gpu)(0)                                        # (re-initialises the library's context: its POA state is created anew)
+        bases2, _, ln2, st2 = g2.poa_batch(b, off=off)
+        assert list(st2[:3]) == [2, 2, 2] and (st2[3:] == 0).all()
+    finally:
+        assert gpu.lib.hypo_gpu_set_option(b"giant_arena_mb", C.c_int(1024)) == 0
+        type(gpu)(0)
