@@ -166,11 +166,15 @@ def test_windows_beyond_the_table_driven_classes_run_in_class_6(gpu, oracle_lib)
         assert (rst == 0).all() and got == [rb[int(off[i]):int(off[i]) + int(rln[i])].tobytes() for i in range(b.n_windows)]
     # a context without the arena answers HYPO_ST_CAPACITY for them (and only for them)
     import ctypes as C
-    assert gpu.lib.hypo_gpu_set_option(b"giant_arena_mb", C.c_int(1)) == 0          # 1 MB: two slices of 512 KB hold none of the three
+    assert gpu.lib.hypo_gpu_set_option(b"giant_arena_mb", C.c_int(1)) == 0          # 1 MB: a slice of 512 KB holds the deep window's small graph, not the score matrices of the other two
     try:
         g2 = type(gpu)(0)                                        # (re-initialises the library's context: its POA state is created anew)
         bases2, _, ln2, st2 = g2.poa_batch(b, off=off)
-        assert list(st2[:3]) == [2, 2, 2] and (st2[3:] == 0).all()
+        assert list(st2[:3]) == [2, 2, 0] and (st2[3:] == 0).all() and g2.last_stats()["n_failed"] == 2
+        assert gpu.lib.hypo_gpu_set_option(b"giant_arena_mb", C.c_int(0)) == 0      # no class 6 at all
+        g3 = type(gpu)(0)
+        bases3, _, ln3, st3 = g3.poa_batch(b, off=off)
+        assert list(st3[:3]) == [2, 2, 2] and (st3[3:] == 0).all()
     finally:
         assert gpu.lib.hypo_gpu_set_option(b"giant_arena_mb", C.c_int(1024)) == 0
         type(gpu)(0)
