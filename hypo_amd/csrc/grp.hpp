@@ -39,6 +39,23 @@
 #define HYPO_ARRIVED(x) asm volatile("" :: "v"(x))
 #endif
 
+// Device-coherent accesses (agent scope, relaxed): what one wave hands to a wave that may run on another XCD WHILE BOTH RUN — a re-queued
+// window's spill and carry word.  On gfx942 / gfx950 such a store is written through its XCD's L2 and such a load is served from beyond
+// it (the sc1 bit), so neither side needs an agent-scope fence: a release fence at that scope writes back the whole L2 of the XCD
+// (buffer_wbl2) and an acquire invalidates it (buffer_inv) — measured at tens of microseconds each, serialised per XCD, once per
+// re-queued window: a batch in which a fifth of the windows outgrew their class spent 160 of its 162 ms there (round 6,
+// profiles/r06_grid_diag.txt).  Ordering against the queue entry that publishes the window is a plain wait for the stores (workgroup-scope
+// release).  The emulator reads and writes memory.
+#ifdef HYPO_EMU
+#define HYPO_ST_DEV(p, v) (*(p) = (v))
+#define HYPO_LD_DEV(p) (*(p))
+#define HYPO_RELEASE_STORES() do { } while (0)
+#else
+#define HYPO_ST_DEV(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define HYPO_LD_DEV(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define HYPO_RELEASE_STORES() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup")
+#endif
+
 namespace hypo {
 
 struct alignas(16) uint4v { uint32_t x, y, z, w; };       // 16-byte store unit

@@ -2836,45 +2836,48 @@ struct Poa {
     }
     HD uint32_t spill_size() const { return spill_bytes(n_nodes, KIN); }
     HD void spill(uint8_t* out) const {
+        // (every store device-coherent: the class that takes the window over may already be running on another XCD, HYPO_ST_DEV in grp.hpp)
         const int n = n_nodes;
         uint16_t* h = (uint16_t*)out;
         if (g.lane == 0) {
-            h[0] = (uint16_t)CARRY_MAGIC; h[1] = (uint16_t)n; h[2] = (uint16_t)stat[ST_CS]; h[3] = (uint16_t)stat[ST_CCHAIN0];
+            HYPO_ST_DEV(h + 0, (uint16_t)CARRY_MAGIC); HYPO_ST_DEV(h + 1, (uint16_t)n); HYPO_ST_DEV(h + 2, (uint16_t)stat[ST_CS]); HYPO_ST_DEV(h + 3, (uint16_t)stat[ST_CCHAIN0]);
             // (bit 7 of the kind: r2n / n2r are A valid order kept lazily, not the reference's — a class that needs the latter sorts first)
-            h[4] = (uint16_t)(stat[ST_CKIND] | ((Cfg::LAZY && lazy_on) ? 0x80u : 0u) | (KIN << 8)); h[5] = (uint16_t)stat[ST_XT]; h[6] = (uint16_t)stat[ST_XH]; h[7] = 0;
+            HYPO_ST_DEV(h + 4, (uint16_t)(stat[ST_CKIND] | ((Cfg::LAZY && lazy_on) ? 0x80u : 0u) | (KIN << 8))); HYPO_ST_DEV(h + 5, (uint16_t)stat[ST_XT]); HYPO_ST_DEV(h + 6, (uint16_t)stat[ST_XH]); HYPO_ST_DEV(h + 7, (uint16_t)0);
             // the reference-equivalent work of the sequences behind the cursor is accounted by whoever finishes the window
             uint32_t* c = (uint32_t*)(out + 16);
-            c[0] = stat[ST_CELLS]; c[1] = stat[ST_ALIGNS]; c[2] = stat[ST_REUSED]; c[3] = stat[ST_XHITS];
+            HYPO_ST_DEV(c + 0, (uint32_t)stat[ST_CELLS]); HYPO_ST_DEV(c + 1, (uint32_t)stat[ST_ALIGNS]); HYPO_ST_DEV(c + 2, (uint32_t)stat[ST_REUSED]); HYPO_ST_DEV(c + 3, (uint32_t)stat[ST_XHITS]);
         }
         uint8_t* b = out + 32;
         HYPO_NOUNROLL
-        for (int u = g.lane; u < n; u += GW) { b[u] = code[u]; b[n + u] = nin[u]; b[2 * n + u] = (uint8_t)n_out(u); b[3 * n + u] = nal[u]; }
+        for (int u = g.lane; u < n; u += GW) { HYPO_ST_DEV(b + u, (uint8_t)code[u]); HYPO_ST_DEV(b + n + u, (uint8_t)nin[u]); HYPO_ST_DEV(b + 2 * n + u, (uint8_t)n_out(u)); HYPO_ST_DEV(b + 3 * n + u, (uint8_t)nal[u]); }
         uint16_t* o_r2n = (uint16_t*)(b + align_up<16>(4 * n));
         uint16_t* o_n2r = o_r2n + align_up<16>(2 * n) / 2;
         uint16_t* o_inp = o_n2r + align_up<16>(2 * n) / 2;
         uint16_t* o_inw = o_inp + align_up<16>(2 * n * KIN) / 2;
         uint16_t* o_al = o_inw + align_up<16>(2 * n * KIN) / 2;
         HYPO_NOUNROLL
-        for (int u = g.lane; u < n; u += GW) { o_r2n[u] = (uint16_t)r2n[u]; o_n2r[u] = (uint16_t)n2r[u]; }
+        for (int u = g.lane; u < n; u += GW) { HYPO_ST_DEV(o_r2n + u, (uint16_t)r2n[u]); HYPO_ST_DEV(o_n2r + u, (uint16_t)n2r[u]); }
         HYPO_NOUNROLL
-        for (int t = g.lane; t < n * KIN; t += GW) { o_inp[t] = (uint16_t)inp[t]; o_inw[t] = (uint16_t)inw[t]; }   // (slots beyond nin[u] hold garbage: never read)
+        for (int t = g.lane; t < n * KIN; t += GW) { HYPO_ST_DEV(o_inp + t, (uint16_t)inp[t]); HYPO_ST_DEV(o_inw + t, (uint16_t)inw[t]); }   // (slots beyond nin[u] hold garbage: never read)
         HYPO_NOUNROLL
-        for (int t = g.lane; t < n * AL; t += GW) o_al[t] = (uint16_t)al[t];
+        for (int t = g.lane; t < n * AL; t += GW) HYPO_ST_DEV(o_al + t, (uint16_t)al[t]);
     }
     // RES_OK, or RES_OVERFLOW when the graph does not fit this class either (the caller passes the window on with the same spill)
     HD int restore(const uint8_t* in, int* s_out, int* chain0_out) {
         const uint16_t* h = (const uint16_t*)in;
-        if (h[0] != (uint16_t)CARRY_MAGIC) return RES_INVALID;
-        const int n = h[1], kin = h[4] >> 8, kind = h[4] & 0x7f;
-        const bool lazy_order = (h[4] & 0x80) != 0;
+        // (device-coherent loads: the spill may have been written a moment ago by a wave on another XCD, HYPO_LD_DEV in grp.hpp)
+        if (HYPO_LD_DEV(h + 0) != (uint16_t)CARRY_MAGIC) return RES_INVALID;
+        const int h4 = HYPO_LD_DEV(h + 4);
+        const int n = HYPO_LD_DEV(h + 1), kin = h4 >> 8, kind = h4 & 0x7f;
+        const bool lazy_order = (h4 & 0x80) != 0;
         if (n > NMAX || n < 1) return RES_OVERFLOW;
         const uint8_t* b = in + 32;
         bool over = false;
         HYPO_NOUNROLL
         for (int u = g.lane; u < n; u += GW) {
-            const int k = b[n + u];
+            const int k = HYPO_LD_DEV(b + n + u);
             if (k > KIN) over = true;
-            code[u] = b[u]; nin[u] = (uint8_t)k; nout[u] = b[2 * n + u]; nal[u] = b[3 * n + u];
+            code[u] = HYPO_LD_DEV(b + u); nin[u] = (uint8_t)k; nout[u] = HYPO_LD_DEV(b + 2 * n + u); nal[u] = HYPO_LD_DEV(b + 3 * n + u);
         }
         if (g.any(over)) return RES_OVERFLOW;
         const uint16_t* i_r2n = (const uint16_t*)(b + align_up<16>(4 * n));
@@ -2885,20 +2888,20 @@ struct Poa {
         g.sync();
         HYPO_NOUNROLL
         for (int u = g.lane; u < n; u += GW) {
-            r2n[u] = (id_t)i_r2n[u]; n2r[u] = (id_t)i_n2r[u];
+            r2n[u] = (id_t)HYPO_LD_DEV(i_r2n + u); n2r[u] = (id_t)HYPO_LD_DEV(i_n2r + u);
             const int k = nin[u];
             HYPO_NOUNROLL
-            for (int p = 0; p < k; ++p) { inp[u * KIN + p] = (id_t)i_inp[u * kin + p]; inw[u * KIN + p] = (wt_t)i_inw[u * kin + p]; }
+            for (int p = 0; p < k; ++p) { inp[u * KIN + p] = (id_t)HYPO_LD_DEV(i_inp + u * kin + p); inw[u * KIN + p] = (wt_t)HYPO_LD_DEV(i_inw + u * kin + p); }
             const int ka = nal[u];
             HYPO_NOUNROLL
-            for (int a = 0; a < ka; ++a) al[u * AL + a] = (id_t)i_al[u * AL + a];
+            for (int a = 0; a < ka; ++a) al[u * AL + a] = (id_t)HYPO_LD_DEV(i_al + u * AL + a);
         }
         n_nodes = g.uniform(n);
-        *s_out = h[2]; *chain0_out = h[3];
+        *s_out = HYPO_LD_DEV(h + 2); *chain0_out = HYPO_LD_DEV(h + 3);
         if (g.lane == 0) {
-            stat[ST_XT] = h[5]; stat[ST_XH] = h[6];
+            stat[ST_XT] = HYPO_LD_DEV(h + 5); stat[ST_XH] = HYPO_LD_DEV(h + 6);
             const uint32_t* c = (const uint32_t*)(in + 16);
-            stat[ST_CELLS] = c[0]; stat[ST_ALIGNS] = c[1]; stat[ST_REUSED] = c[2]; stat[ST_XHITS] = c[3];
+            stat[ST_CELLS] = HYPO_LD_DEV(c + 0); stat[ST_ALIGNS] = HYPO_LD_DEV(c + 1); stat[ST_REUSED] = HYPO_LD_DEV(c + 2); stat[ST_XHITS] = HYPO_LD_DEV(c + 3);
         }
         if (lazy_order && Cfg::LAZY_RING && !(P->flags & POA_NATIVE_KLOV)) lazy_on = true;      // (a window that went lazy stays lazy in the class that takes it over)
         topo_dirty = kind == CARRY_UNSORTED || (lazy_order && !(Cfg::LAZY && lazy_on)); meta_dirty = true; last_changed = true;

@@ -218,7 +218,7 @@ struct PoaPrefetch {
     __device__ __forceinline__ static PoaKArgPtr ka() { return fresh((PoaKArgPtr)__builtin_amdgcn_kernarg_segment_ptr()); }
     __device__ __forceinline__ uint32_t claim() const { return atomicAdd(ka()->head, 1u); }
     __device__ __forceinline__ uint32_t item(uint32_t idx) const { const PoaKArgPtr k = ka(); return k->Q.items[(size_t)k->cls * k->Q.stride + idx]; }
-    __device__ __forceinline__ uint32_t carry(uint32_t w) const { return ka()->Q.carry[w]; }
+    __device__ __forceinline__ uint32_t carry(uint32_t w) const { return HYPO_LD_DEV(&ka()->Q.carry[w]); }
 };
 #define HYPO_PREFETCH_NEXT 1
 
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
     uint32_t carry_in = 0;                                      // Q.carry value of the window in hand
 #ifdef HYPO_PHASE_TIMERS
     uint64_t tph[PH_N] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t dbg[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t dbg[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // [17]: cycles in account(), [18], [19]: of those, in the spill-pool allocation / in Poa::spill
     const uint64_t tstart = (uint64_t)clock64();
 #endif
     // what happens to a window once Poa::run / step has returned something other than RES_CONTINUE
@@ -316,28 +316,37 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
             uint32_t cv = 0;
             if (rc == RES_OVERFLOW && stt[PoaT::ST_CKIND] != PoaT::CARRY_NONE) {
                 const uint32_t sz16 = poa.spill_size() >> 4;
-                // (the cursor saturates: a request that does not fit leaves it where it is, so that it cannot wrap around after 2^32
-                // units of failed requests and hand out memory that still holds another window's spill)
+                // One fetch-add on a 64-bit cursor (it cannot wrap; a request that does not fit is refused and every later one with it: the
+                // pool is full then).  Rounds 3-5 claimed with a compare-and-swap loop so that a refused request left the cursor alone:
+                // when a fifth of a batch's windows outgrow their class at about the same time, every success invalidated the value
+                // thousands of other waves were about to swap in — a quadratic storm of retries on one address, 160 of the 162 ms of such a
+                // batch (round 6, profiles/r06_grid_diag.txt: the 8 % cells of the SURVEY 8(d) grid).
                 const uint32_t cap16 = fresh(ka)->Q.spill_cap16;
                 uint32_t off = 0xffffffffu;
+#ifdef HYPO_PHASE_TIMERS
+                const uint64_t tc0 = (uint64_t)clock64();
+#endif
                 if (g.lane == 0) {
-                    uint32_t cur = __hip_atomic_load(fresh(ka)->Q.spill_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    while ((uint64_t)cur + sz16 <= (uint64_t)cap16) {
-                        const uint32_t seen = atomicCAS(fresh(ka)->Q.spill_used, cur, cur + sz16);
-                        if (seen == cur) { off = cur; break; }
-                        cur = seen;
-                    }
+                    const unsigned long long got = atomicAdd(fresh(ka)->Q.spill_used, (unsigned long long)sz16);
+                    if (got + sz16 <= (unsigned long long)cap16) off = (uint32_t)got;
                 }
                 off = (uint32_t)g.shfl((int)off, 0);
+#ifdef HYPO_PHASE_TIMERS
+                const uint64_t tc1 = (uint64_t)clock64();
+                dbg[18] += tc1 - tc0;
+#endif
                 if (off != 0xffffffffu) {
                     poa.spill((uint8_t*)fresh(ka)->Q.spill + (size_t)off * 16);
+#ifdef HYPO_PHASE_TIMERS
+                    dbg[19] += (uint64_t)clock64() - tc1;
+#endif
                     cv = off + 1;
                     if constexpr (USE_LDS) { if (g.lane == 0) stt[PoaT::ACC_NCARRIED] += 1; } else ++n_carried;
                 }
             } else if (rc == RES_OVERFLOW && stt[PoaT::ST_CPASS]) cv = carry_in;
             if (g.lane == 0) {
-                fresh(ka)->Q.carry[w] = cv;
-                __threadfence();                                // the spill and carry[w] are visible before the queue entry is
+                HYPO_ST_DEV(&fresh(ka)->Q.carry[w], cv);
+                HYPO_RELEASE_STORES();                          // the spill and carry[w] (device-coherent stores, grp.hpp) have landed before the queue entry is published
                 const uint32_t slot = atomicAdd(&fresh(ka)->Q.count[to], 1u);
                 __hip_atomic_store(&fresh(ka)->Q.items[(size_t)to * fresh(ka)->Q.stride + slot], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -392,7 +401,7 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
                         if (v != kQueueUnpublished) { *w = v; break; }
                         __builtin_amdgcn_s_sleep(8);
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // carry[w] and the spill were written before the entry
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // (carry[w] and the spill were written before the entry and are read with device-coherent loads)
                     break;
                 }
                 if (wall_clock64() - t0 > kPollLimitTicks) return false;
@@ -407,7 +416,7 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
             if (idx >= count) return false;
             *w = fresh(ka)->Q.items[(size_t)cls * fresh(ka)->Q.stride + idx];
         }
-        carry_in = idx >= planned ? fresh(ka)->Q.carry[*w] : 0u;
+        carry_in = idx >= planned ? HYPO_LD_DEV(&fresh(ka)->Q.carry[*w]) : 0u;
         return true;
     };
     PoaT poa(g, P, mem, fast, dirg);
@@ -431,8 +440,17 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
             if (g.lane < 4) stt[PoaT::CUR_OFF + g.lane] = oc;
             if (g.lane == 4) stt[PoaT::CUR_STATIC] = (uint32_t)((W.draft_len + 1) / 2 + 16 + 8 * (1 + W.n_internal + W.n_prefix + W.n_suffix));
             const int rc = poa.run_window(w, W, carry_in ? (const uint8_t*)fresh(ka)->Q.spill + (size_t)(carry_in - 1) * 16 : nullptr);
+#ifdef HYPO_PHASE_TIMERS
+            const uint64_t ta = (uint64_t)clock64();
+#endif
             account(poa, w, rc);
+#ifdef HYPO_PHASE_TIMERS
+            const uint64_t tb = (uint64_t)clock64();
+#endif
             poa.fetch_next();
+#ifdef HYPO_PHASE_TIMERS
+            dbg[17] += tb - ta;
+#endif
         }
     } else {
         uint32_t w;
@@ -458,15 +476,16 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
         atomicAdd((unsigned long long*)&st->cells_scored, (unsigned long long)c_scored);
         atomicAdd((unsigned long long*)&st->cells_threaded, (unsigned long long)c_thr);
 #ifdef HYPO_PHASE_TIMERS
-        static_assert(kNumPoaClasses * 32 * 8 <= 2048 - 512 && PH_N + 2 + 17 <= 32, "phase block of the header");
+        static_assert(kNumPoaClasses * 32 * 8 <= 2048 - 512 && PH_N + 2 + 20 <= 32, "phase block of the header");
         unsigned long long* ph = (unsigned long long*)((char*)fresh(ka)->Q.count + 512) + (size_t)cls * 32;   // header + 512: [class][32]
         for (int i = 0; i < PH_N; ++i) atomicAdd(&ph[i], (unsigned long long)tph[i]);
         atomicAdd(&ph[PH_N], (unsigned long long)((uint64_t)clock64() - tstart));                // wave lifetime
         atomicAdd(&ph[PH_N + 1], 1ull);                                                           // waves
-        for (int i = 0; i < 17; ++i) atomicAdd(&ph[PH_N + 2 + i], (unsigned long long)dbg[i]);      // rows, real alignments, reused, toposorts, serial consensus passes, slow rows, exact tries / hits
+        for (int i = 0; i < 20; ++i) atomicAdd(&ph[PH_N + 2 + i], (unsigned long long)dbg[i]);      // rows, real alignments, reused, toposorts, serial consensus passes, slow rows, exact tries / hits
 #endif
-        // this group will push nothing more: what it re-queued is in the queues (a polling kernel of a later class counts these)
-        __threadfence();
+        // this group will push nothing more: what it re-queued is in the queues (a polling kernel of a later class counts these).
+        // (every re-queue waited for its own device-coherent stores: no agent-scope fence — an L2 write-back per exiting wave — here either)
+        HYPO_RELEASE_STORES();
         atomicAdd(fresh(ka)->Q.done + cls, 1u);
     }
     if (!POLL && USE_LDS && wl == 0) atomicAdd((unsigned long long*)(fresh(ka)->Q.work + cls), (unsigned long long)wall_clock64());
@@ -633,7 +652,7 @@ static size_t arm_off_region_bytes(uint64_t n_arms) {        // offsets + block 
 // spill pool of the re-queued windows' graphs (Poa::spill: 1.5 KB for a class-0 window, 12 KB for a full class-3 one): a bump
 // allocator, a window that finds it full starts again from its first sequence as before
 static size_t poa_spill_bytes(uint32_t n_windows) {
-    size_t b = (size_t)n_windows * 256;
+    size_t b = (size_t)n_windows * 512;          // (256 until round 6: a batch in which a fifth of the windows outgrow their class ran out, and what found no room started over)
     const size_t lo = (size_t)1 << 20, hi = (size_t)1 << 30;
     b = b < lo ? lo : (b > hi ? hi : b);
     return b;
@@ -757,7 +776,7 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     Q.spill = ws + off;
     Q.spill_cap16 = (uint32_t)(poa_spill_bytes(n_windows) / 16);
     off += poa_spill_bytes(n_windows);
-    Q.spill_used = (uint32_t*)(ws + 7872);
+    Q.spill_used = (unsigned long long*)(ws + 7872);
     Q.done = (uint32_t*)(ws + 7808);
     Q.work = (uint64_t*)(ws + 7936);
     const ClassScratch scr3{ws + off, groups3_for(n_windows)};

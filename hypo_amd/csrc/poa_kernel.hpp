@@ -46,7 +46,7 @@ struct PoaQueues {
     uint32_t* carry;        // [n_windows]
     char* spill;
     uint32_t spill_cap16;   // pool size in 16-byte units
-    uint32_t* spill_used;
+    unsigned long long* spill_used;   // 64-bit: claimed with one fetch-add (poa_class_kernel), never wraps
     uint32_t* done;         // [classes] lane groups of class c's kernels that have exited (what a polling kernel waits for)
     uint64_t* work;         // [classes] summed lifetimes of the waves of class c's (non-polling) launches, 100 MHz ticks
 };
