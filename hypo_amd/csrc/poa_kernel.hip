@@ -652,7 +652,7 @@ static size_t arm_off_region_bytes(uint64_t n_arms) {        // offsets + block 
 // spill pool of the re-queued windows' graphs (Poa::spill: 1.5 KB for a class-0 window, 12 KB for a full class-3 one): a bump
 // allocator, a window that finds it full starts again from its first sequence as before
 static size_t poa_spill_bytes(uint32_t n_windows) {
-    size_t b = (size_t)n_windows * 512;          // (256 until round 6: a batch in which a fifth of the windows outgrow their class ran out, and what found no room started over)
+    size_t b = (size_t)n_windows * 1024;         // (256 until round 6: a batch in which a fifth of the windows outgrow their class ran out, and what found no room started over)
     const size_t lo = (size_t)1 << 20, hi = (size_t)1 << 30;
     b = b < lo ? lo : (b > hi ? hi : b);
     return b;
