@@ -338,7 +338,7 @@ def end_to_end_c5_leg():
                                "C5 slice end to end: 250 x 1 Mbp draft, 50x HiFi-like 15 kbp reads passed as the short reads (822 163 records, 3.0 GB of BAM), -s 3g -> k = 17, -c 50, -p 50, one run")
 
 
-T1_3GBP_MD5_ROUND4 = "a4b0764b66b0a285dca0f630a0bbfde9"      # profiles/r04_t1_3gbp.json: 3000 x 1 Mbp, seed 97, -s 3g, identical for -p 50 / -p 100
+T1_3GBP_MD5_ROUND4 = "a4b0764b66b0a285dca0f630a0bbfde9"      # profiles/history/r04_t1_3gbp.json: 3000 x 1 Mbp, seed 97, -s 3g, identical for -p 50 / -p 100
 
 
 def t1_reference_pin(d, out_name, n_contigs, k, run, n_pick):

@@ -30,7 +30,7 @@ int fail(int code, const char* fmt, ...) {
 
 // ---- host -> device copies of the host-pointer entry points ---------------------------------------------------------------
 // A caller of the C-ABI hands over ordinary (pageable) memory: the reference's objects know nothing of page-locked buffers, and
-// locking a few GB for one upload costs more than the upload (MI355X box, profiles/r04_pin_bench.txt: hipHostMalloc 0.18 s per GB
+// locking a few GB for one upload costs more than the upload (MI355X box, profiles/history/r04_pin_bench.txt: hipHostMalloc 0.18 s per GB
 // + 0.12 s per GB to free it; a copy out of page-locked memory 57 GB/s, out of pageable memory 15-25 GB/s).  Large copies out of
 // pageable memory are therefore staged here: a few threads copy the next 32 MB into one of two page-locked bounce buffers of the
 // context while the DMA engine drains the other.  Memory the caller did page-lock (hypo_gpu_host_alloc) is copied from directly.

@@ -89,7 +89,7 @@ void Hypo::polish() {
     const bool prefetch_on = !(std::getenv("HYPO_PREFETCH") && std::atoi(std::getenv("HYPO_PREFETCH")) == 0);
     // The parser's team and the team that inflates BGZF blocks for it are HALF of -t each: with all three teams (these two and the main
     // thread's phases) at -t the stages only got in each other's way — 500 Mbp at k = 17, -t 64 on the 128-core box: 4.4-4.8 s with
-    // 64 / 64, 3.7-4.0 s with 32 / 32, 3.8 s with 16 / 16 or 24 / 24 (profiles/r04_thread_split.txt).
+    // 64 / 64, 3.7-4.0 s with 32 / 32, 3.8 s with 16 / 16 or 24 / 24 (profiles/history/r04_thread_split.txt).
     int helper_threads = side_team;
     if (const char* e = std::getenv("HYPO_HELPER_THREADS")) helper_threads = std::max(1, std::atoi(e));        // (experiments)
     if (prefetch_on && num_batches > 0) {

@@ -47,7 +47,7 @@ struct ParsedBlock {
 // A grow-only buffer, page-locked (hypo_gpu_host_alloc) between 4 and 64 MB: copies from / into it run at the link's rate.
 // Small ones are plain memory — pinning has a per-call cost (a millisecond or more) that a 5 Mbp run, with two dozen staging arrays,
 // would pay for nothing.  LARGE ones are plain memory as well: page-locking costs 0.18 s per GB and 0.12 s per GB to undo (MI355X
-// box, profiles/r04_pin_bench.txt) — the 3.9 GB of read staging of the 250 Mbp set took 0.84 s to lock for an upload of 0.17 s —
+// box, profiles/history/r04_pin_bench.txt) — the 3.9 GB of read staging of the 250 Mbp set took 0.84 s to lock for an upload of 0.17 s —
 // while the library stages a large copy out of ordinary memory through its own bounce buffers at the same rate (capi.hip, h2d).
 // Plain memory it is, too, when the library has no pinned memory to give (the CPU test shim).
 struct PinnedBuf {
