@@ -35,9 +35,11 @@ PMC_CMD="python $R/profiles/long_rate.py 200" bash profiles/run_pmc.sh ${TAG}_lo
 python profiles/summarize_pmc.py gpurun_out/pmc_${TAG}_long | grep "^kernel\|131072" > $OUT/pmc_long.csv
 bash profiles/kernel_registers.sh > $OUT/kernel_registers.csv 2>/dev/null
 # the scan's counters at the sizes the rate table quotes (round 5: FETCH_SIZE / TCC hit + miss / SQ_WAIT_ANY of the 100 / 250 / 512 Mbp launches)
-for spec in "100000000 13" "250000000 15" "512000000 17"; do
+for spec in "5000000 11" "100000000 13" "250000000 15" "512000000 17"; do
   set -- $spec
   PMC_CMD="python $R/profiles/scan_rate.py $1 $2" bash profiles/run_pmc.sh ${TAG}_scan$2 > /dev/null 2>&1
   python profiles/summarize_pmc.py gpurun_out/pmc_${TAG}_scan$2 | grep "^kernel\|scan_fused" > $OUT/pmc_scan_k$2.csv
 done
+# round 6: the 8 % cells of the SURVEY 8(d) grid under several schedules (profiles/diag/r06_grid_cell.py)
+(for c in "32 6" "64 6" "100 6" "16 50" "32 12"; do echo "== cell $c 0.08"; python profiles/diag/r06_grid_cell.py $c 0.08 2>&1 | grep -v amdgpu.ids; done) > $OUT/grid_cells.txt
 ls -la $OUT
