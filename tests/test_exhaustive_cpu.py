@@ -47,7 +47,7 @@ def test_emulator_vs_reference_on_exhaustive_slices(name, stride):
     if not oracle.Ref.available():
         pytest.skip("oracle/_ref/libhyporef.so not built (the real reference only exists in the build container)")
     emu, ref = emu_util.Emu(), oracle.Ref()
-    b = next(ex.chunks(name, 6000, stride=stride, offset=1))
+    b = next(ex.chunks(name, 4000, stride=stride, offset=1))
     off = b.slot_layout()
     rb, _, rln, rst, _ = ref.poa_batch_raw(b, off=off)
     want = [rb[int(off[i]):int(off[i]) + int(rln[i])].tobytes().decode() for i in range(b.n_windows)]
