@@ -329,42 +329,69 @@ struct Giant {
             const int u = rank[r], i = r + 1;
             const int c = code[u];
             int* const row = H + (size_t)i * W;
+            // the rows of the predecessors (in-edge order; a node without one: the virtual row 0, :296-298): the first PC of them by offset, a
+            // node with more (rare) walks the rest of its list per strip
+            constexpr int PC = 8;
+            size_t poff[PC];
+            int np = 0;
+            for (int ed = in_head[u]; ed >= 0; ed = e_nin[ed]) { if (np < PC) poff[np] = (size_t)(n2r[e_src[ed]] + 1) * W; ++np; }
+            HYPO_UNROLL
+            for (int k = 0; k < PC; ++k) if (k >= np) poff[k] = 0;
+            const int npc = np == 0 ? 1 : (np < PC ? np : PC);
             // column 0 (:163-243): kNW / kLOV: the best predecessor's + g (a source: 0 + g); kROV: 0
             int h0;
             if (mode == MODE_ROV) h0 = 0;
             else {
-                int pen = in_head[u] < 0 ? 0 : GNEG;
+                int pen = np == 0 ? 0 : GNEG;
                 for (int ed = in_head[u]; ed >= 0; ed = e_nin[ed]) { const int pv = H[(size_t)(n2r[e_src[ed]] + 1) * W]; pen = pv > pen ? pv : pen; }
                 h0 = pen + gp;
             }
             if (g.lane == 0) row[0] = h0;
             int carry = h0;                                      // max over the columns so far of H[i][j] - j * g
             int row_max = ID;
-            for (int b = 1; b < W; b += 64) {
-                const int j = b + g.lane;
-                const bool valid = j < W;
-                int x = ID;
-                if (valid) {
-                    const int sc = (int)sq[j - 1] == c ? m : n_;
-                    int v;
-                    if (in_head[u] < 0) { const int a = H[j - 1] + sc, d = H[j] + gp; v = a > d ? a : d; }       // no predecessor: the virtual row 0 (:296-298)
-                    else {
-                        v = ID;
-                        for (int ed = in_head[u]; ed >= 0; ed = e_nin[ed]) {
-                            const int* const prow = H + (size_t)(n2r[e_src[ed]] + 1) * W;
+            // CH strips of 64 columns at a time: first the vertical / diagonal maxima of all of them (independent loads: in flight together),
+            // then the horizontal term strip by strip — H[i][j] = max(H[i][j], H[i][j-1] + g) <=> prefix maximum of H[i][j] - j * g (:321-329)
+            constexpr int CH = 8;
+            for (int b0 = 1; b0 < W; b0 += 64 * CH) {
+                int x[CH];
+                HYPO_UNROLL
+                for (int q = 0; q < CH; ++q) {
+                    const int j = b0 + 64 * q + g.lane;
+                    x[q] = ID;
+                    if (j < W) {
+                        const int sc = (int)sq[j - 1] == c ? m : n_;
+                        int v = ID;
+                        HYPO_UNROLL
+                        for (int k = 0; k < PC; ++k) if (k < npc) {
+                            const int* const prow = H + poff[k];
                             const int a = prow[j - 1] + sc, d = prow[j] + gp;
                             const int t = a > d ? a : d;
                             v = t > v ? t : v;
                         }
+                        if (np > PC) {
+                            int k = 0;
+                            for (int ed = in_head[u]; ed >= 0; ed = e_nin[ed], ++k) {
+                                if (k < PC) continue;
+                                const int* const prow = H + (size_t)(n2r[e_src[ed]] + 1) * W;
+                                const int a = prow[j - 1] + sc, d = prow[j] + gp;
+                                const int t = a > d ? a : d;
+                                v = t > v ? t : v;
+                            }
+                        }
+                        x[q] = v - j * gp;
                     }
-                    x = v - j * gp;
                 }
-                // H[i][j] = max(H[i][j], H[i][j-1] + g)  <=>  prefix maximum of H[i][j] - j * g (:321-329)
-                const int ex = g.scan_max_excl(x, ID);
-                int inc = x > ex ? x : ex;
-                inc = inc > carry ? inc : carry;
-                if (valid) { const int h = inc + j * gp; row[j] = h; if (native_lov) row_max = h > row_max ? h : row_max; }
-                carry = g.shfl(inc, 63);
+                HYPO_UNROLL
+                for (int q = 0; q < CH; ++q) {
+                    if (b0 + 64 * q < W) {                       // (group-uniform)
+                        const int j = b0 + 64 * q + g.lane;
+                        const int ex = g.scan_max_excl(x[q], ID);
+                        int inc = x[q] > ex ? x[q] : ex;
+                        inc = inc > carry ? inc : carry;
+                        if (j < W) { const int h = inc + j * gp; row[j] = h; if (native_lov) row_max = h > row_max ? h : row_max; }
+                        carry = g.shfl(inc, 63);
+                    }
+                }
             }
             g.sync();
             bool is_end = mode == MODE_LOV;                      // :338-339

@@ -434,3 +434,30 @@ def realistic_window_batch(outdir, name="e2e_real_5m_s131"):
             wins.append(w)
             cons.append(cs)
     return build_batch(wins), cons, man, rr
+
+
+def run_homopolymer_set(outdir, device, devices=None, threads=8):
+    """One 90 kbp contig whose truth holds a 4 000-base poly-A run, 30x short reads and 25x noisy 6 kbp long reads (`-B`): no window border can
+    be put into the run (Contig::force_divide, src/Contig.cpp:641-666), short reads cannot cover a window that long (it is pruned,
+    src/Contig.cpp:264-275), so it becomes ONE LONG window of ~4 000 bases with ~40 long-read arms — beyond every table-driven size class
+    (size class 6) and longer than piece mode's first halo.  Runs `hypo` (optionally with --devices) and the reference compiled in place on
+    the same files; returns (CompletedProcess, True when the two FASTA files are byte-identical, length of the longest LONG window)."""
+    import oracle
+    gen = build_fast_generator()
+    subprocess.check_output([gen, str(outdir), "141", "1", "90000", "9", "30", "150", "2000", "--bam", "--fast-hash", "--homopolymer", "29950", "4000", "--long", "25", "6000"])
+    argv = [BIN, "-d", "draft.fa", "-r", "reads.fa", "-s", "100k", "-c", "30", "-b", "sr.bam", "-B", "lr.bam", "-t", str(threads), "-i", "-o", "out.fa"]
+    env = dict(os.environ, HYPO_REGION_DUMP=os.path.join(str(outdir), "regions.tsv"))
+    if devices:
+        argv += ["--devices", devices]
+        env["HYPO_ALLOW_DUP_DEVICES"] = "1"
+    if device == "shim":
+        env["LD_LIBRARY_PATH"] = SHIM_DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    else:
+        env.setdefault("HYPO_REQUIRE_DEVICE", "1")
+    p = subprocess.run(argv, cwd=str(outdir), env=env, capture_output=True, text=True, timeout=1800)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    oracle.RefArms().fasta_file(os.path.join(str(outdir), "draft.fa"), os.path.join(str(outdir), "sr.bam"), 9, os.path.join(str(outdir), "aux", "solid_kmers.bvsd"),
+                                os.path.join(str(outdir), "ref.fa"), long_path=os.path.join(str(outdir), "lr.bam"))
+    same = open(os.path.join(str(outdir), "ref.fa"), "rb").read() == open(os.path.join(str(outdir), "out.fa"), "rb").read()
+    longest = max((int(r[2]) - int(r[1]) for r in (l.split("\t") for l in open(os.path.join(str(outdir), "regions.tsv"))) if r[3].strip() == "LNG"), default=0)
+    return p, same, longest

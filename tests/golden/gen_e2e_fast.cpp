@@ -36,7 +36,7 @@
 //
 // usage: gen_e2e_fast <outdir> <seed> <n_contigs> <contig_len> <k> [coverage=30] [read_len=150] [read_sub_ppm=2000]
 //                     [--bam] [--fast-hash] [--threads N] [--join] [--long <cov> <len>] [--gaps <every> <len>]
-//                     [--repeats <ppm>] [--diploid <ppm>] [--read-indel <ppm>] [--mismap <ppm>]
+//                     [--repeats <ppm>] [--diploid <ppm>] [--read-indel <ppm>] [--mismap <ppm>] [--homopolymer <pos> <len>]
 // build: g++ -O2 -fopenmp -o gen_e2e_fast gen_e2e_fast.cpp -lz      (test infrastructure: tests/ and bench.py's e2e legs only)
 #include <zlib.h>
 #include <omp.h>
@@ -82,6 +82,7 @@ struct Extra {                                   // config C4 options
     uint32_t long_cov = 0, long_len = 0;         // long reads (0 = none)
     uint32_t gap_every = 0, gap_len = 0;         // short reads leave [x * gap_every + gap_every / 2, ... + gap_len) of the truth alone
     uint32_t rep_ppm = 0, het_ppm = 0, rindel_ppm = 0, mismap_ppm = 0;      // round 6: low-complexity truth, second haplotype, read indels, mis-placed reads
+    uint32_t hp_pos = 0, hp_len = 0;             // one poly-A run of hp_len bases at truth position hp_pos of every contig (0 = none)
     bool realistic() const { return rep_ppm || het_ppm || rindel_ppm || mismap_ppm; }
 };
 
@@ -149,7 +150,10 @@ Rng extra_rng(uint64_t seed, int idx, uint64_t salt) {
 }
 
 // low-complexity blocks written over a random truth (--repeats): the same for both passes over a contig
-template <class Str> void apply_repeats(Str& truth, uint64_t seed, int idx, uint32_t G, uint32_t rep_ppm) {
+template <class Str> void apply_repeats(Str& truth, uint64_t seed, int idx, uint32_t G, uint32_t rep_ppm, uint32_t hp_pos = 0, uint32_t hp_len = 0) {
+    // --homopolymer: a run no window border can be put into (Contig::force_divide never cuts inside one, src/Contig.cpp:641-666): one weak
+    // region, and one window, at least as long as the run
+    for (uint32_t j = 0; j < hp_len && hp_pos + j < G; ++j) truth[hp_pos + j] = 'A';
     if (!rep_ppm) return;
     Rng x = extra_rng(seed, idx, 0x7265706561747321ull);
     const uint32_t mean_block = 160;                              // blocks start with probability rep_ppm / mean_block per base
@@ -185,7 +189,7 @@ void make_contig(Contig& c, uint64_t seed, int idx, uint32_t G, uint32_t cov, ui
     Rng r = contig_rng(seed, idx);
     c.truth.resize(G);
     for (uint32_t i = 0; i < G; ++i) c.truth[i] = kA[r.below(4)];
-    apply_repeats(c.truth, seed, idx, G, ex.rep_ppm);
+    apply_repeats(c.truth, seed, idx, G, ex.rep_ppm, ex.hp_pos, ex.hp_len);
     // second haplotype (--diploid): per truth position 0 = as the first, 1 = another base, 2 = the base is missing, 3 = an extra base behind it
     std::vector<uint8_t> hv; std::vector<char> hb;
     if (ex.het_ppm) {
@@ -404,11 +408,11 @@ void make_contig(Contig& c, uint64_t seed, int idx, uint32_t G, uint32_t cov, ui
 
 // first pass: the draft's length only — the same draws as make_contig's truth and edit script (a substituted base is drawn until
 // it differs from the truth base, so the truth bases are kept for the length of this call: 1 byte per base)
-uint32_t draft_length_exact(uint64_t seed, int idx, uint32_t G, uint32_t rep_ppm) {
+uint32_t draft_length_exact(uint64_t seed, int idx, uint32_t G, uint32_t rep_ppm, uint32_t hp_pos, uint32_t hp_len) {
     Rng r = contig_rng(seed, idx);
     std::vector<char> truth(G);
     for (uint32_t i = 0; i < G; ++i) truth[i] = kA[r.below(4)];
-    apply_repeats(truth, seed, idx, G, rep_ppm);
+    apply_repeats(truth, seed, idx, G, rep_ppm, hp_pos, hp_len);
     uint32_t d = 0;
     for (uint32_t i = 0; i < G; ++i) {
         const char t = truth[i];
@@ -439,6 +443,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--diploid") && i + 1 < argc) ex0.het_ppm = (uint32_t)atoi(argv[++i]);
         else if (!strcmp(argv[i], "--read-indel") && i + 1 < argc) ex0.rindel_ppm = (uint32_t)atoi(argv[++i]);
         else if (!strcmp(argv[i], "--mismap") && i + 1 < argc) ex0.mismap_ppm = (uint32_t)atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--homopolymer") && i + 2 < argc) { ex0.hp_pos = (uint32_t)atoi(argv[++i]); ex0.hp_len = (uint32_t)atoi(argv[++i]); }
         else pos.push_back(argv[i]);
     }
     if (pos.size() < 5) { fprintf(stderr, "usage: gen_e2e_fast <outdir> <seed> <n_contigs> <contig_len> <k> [coverage=30] [read_len=150] [read_sub_ppm=2000] [--bam] [--fast-hash] [--threads N]\n"); return 2; }
@@ -458,7 +463,7 @@ int main(int argc, char** argv) {
     // ---- first pass: draft lengths (the header names them) ----
     std::vector<uint32_t> dlen((size_t)nc);
 #pragma omp parallel for schedule(dynamic, 1)
-    for (int c = 0; c < nc; ++c) dlen[(size_t)c] = draft_length_exact(seed, c, G, ex0.rep_ppm);
+    for (int c = 0; c < nc; ++c) dlen[(size_t)c] = draft_length_exact(seed, c, G, ex0.rep_ppm, ex0.hp_pos, ex0.hp_len);
     std::vector<uint64_t> pos_off((size_t)nc + 1, 0);
     for (int c = 0; c < nc; ++c) pos_off[(size_t)c + 1] = pos_off[(size_t)c] + dlen[(size_t)c];
     if (ex0.join && pos_off[(size_t)nc] >= 0x7fffffffull) { fprintf(stderr, "gen_e2e_fast: a joined contig of %llu bases exceeds BAM's 2^31\n", (unsigned long long)pos_off[(size_t)nc]); return 2; }

@@ -126,3 +126,13 @@ def test_output_appears_only_when_the_run_succeeded(built, tmp_path):
     p = subprocess.run(argv, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-500:]
     assert eu._md5(str(out)) == man["expected_fasta_md5"] and not (tmp_path / "hypo_draft.fasta.tmp").exists()
+
+
+def test_window_longer_than_every_table_driven_class_over_the_shim(built, tmp_path):
+    """The 4 000-base LONG window of tests/e2e_util.py: run_homopolymer_set through the host pipeline (CPU shim): FASTA = the reference compiled
+    in place.  (On the device the window runs in size class 6 and piece mode widens its halo: tests/test_gpu_e2e.py.)"""
+    import oracle
+    if not oracle.RefArms.available():
+        pytest.skip("oracle/_ref/libhyporef_arms.so not built (the real reference only exists in the build container)")
+    p, same, longest = eu.run_homopolymer_set(tmp_path, "shim", threads=4)
+    assert longest > 3900 and same
