@@ -74,22 +74,24 @@ def test_contig_scan_rank_select(mirror, device, oracle_lib):
 
 
 @pytest.mark.gpu
-def test_window_beyond_device_capacity_keeps_its_draft(mirror, device, capfd):
-    """A window beyond the largest size class must not stop the run: it keeps its draft with a warning (the documented degraded
-    path), its neighbours are polished as usual.  Since round 3 depth alone no longer gets there (1 100 arms are polished: the last
-    class holds 16 382 sequences); an arm longer than 1 021 bases still does."""
+def test_window_beyond_the_table_driven_classes_is_polished(mirror, device, oracle_lib, capfd):
+    """Rounds 2-5: a window with an arm longer than 1 021 bases kept its draft with a warning (HYPO_ST_CAPACITY).  Since round 6 it runs in
+    size class 6 (hypo_amd/csrc/poa_giant.hpp) and the host mirror gets the reference's consensus for it, its neighbours as before; nothing
+    is "kept unpolished"."""
     import random
+    from hypo_amd.batch import build_batch
     rng = random.Random(5)
     truth = "".join(rng.choice("ACGT") for _ in range(40))
     draft = truth[:10] + "A" + truth[11:]
     deep = TextWindow(draft, [truth] * 1100)
     long_arm = TextWindow(draft, [truth] * 4 + ["".join(rng.choice("ACGT") for _ in range(1100))])
     normal = TextWindow(draft, [truth] * 8)
-    cons, _ = mirror.windows([normal, deep, long_arm, normal], batched=True)
+    wins = [normal, deep, long_arm, normal]
+    cons, _ = mirror.windows(wins, batched=True)
     assert cons[0] == truth and cons[3] == truth
-    assert cons[1] == truth                                   # deep, but polished
-    assert cons[2] == draft
-    assert "kept unpolished" in capfd.readouterr().err
+    assert cons[1] == truth                                   # deep, polished in the last table-driven class
+    assert cons[2] == oracle_lib.poa_batch(build_batch([long_arm]))[0][0]
+    assert "kept unpolished" not in capfd.readouterr().err
 
 
 def test_draft_reader_mapped_and_line_by_line_agree(mirror, tmp_path):
