@@ -349,11 +349,11 @@ struct Giant {
             if (g.lane == 0) row[0] = h0;
             int carry = h0;                                      // max over the columns so far of H[i][j] - j * g
             int row_max = ID;
-            // CH strips of 64 columns at a time: first the vertical / diagonal maxima of all of them (independent loads: in flight together),
-            // then the horizontal term strip by strip — H[i][j] = max(H[i][j], H[i][j-1] + g) <=> prefix maximum of H[i][j] - j * g (:321-329)
-            constexpr int CH = 8;
-            for (int b0 = 1; b0 < W; b0 += 64 * CH) {
-                int x[CH];
+            // CH strips of 64 columns at a time: the vertical / diagonal maxima of a chunk are loads that depend on nothing in this row, so the
+            // NEXT chunk's are issued before this chunk's horizontal pass (strip by strip: H[i][j] = max(H[i][j], H[i][j-1] + g) <=> prefix
+            // maximum of H[i][j] - j * g, :321-329) — the matrix is far larger than any cache and a load from it takes as long as a dozen scans
+            constexpr int CH = 16;
+            auto load_chunk = [&](int b0, int* x) {
                 HYPO_UNROLL
                 for (int q = 0; q < CH; ++q) {
                     const int j = b0 + 64 * q + g.lane;
@@ -381,17 +381,24 @@ struct Giant {
                         x[q] = v - j * gp;
                     }
                 }
+            };
+            int xa[CH], xb[CH];
+            load_chunk(1, xa);
+            for (int b0 = 1; b0 < W; b0 += 64 * CH) {
+                const bool more = b0 + 64 * CH < W;              // (group-uniform)
+                if (more) load_chunk(b0 + 64 * CH, xb);
                 HYPO_UNROLL
                 for (int q = 0; q < CH; ++q) {
                     if (b0 + 64 * q < W) {                       // (group-uniform)
                         const int j = b0 + 64 * q + g.lane;
-                        const int ex = g.scan_max_excl(x[q], ID);
-                        int inc = x[q] > ex ? x[q] : ex;
+                        const int ex = g.scan_max_excl(xa[q], ID);
+                        int inc = xa[q] > ex ? xa[q] : ex;
                         inc = inc > carry ? inc : carry;
                         if (j < W) { const int h = inc + j * gp; row[j] = h; if (native_lov) row_max = h > row_max ? h : row_max; }
                         carry = g.shfl(inc, 63);
                     }
                 }
+                if (more) { HYPO_UNROLL for (int q = 0; q < CH; ++q) xa[q] = xb[q]; }
             }
             g.sync();
             bool is_end = mode == MODE_LOV;                      // :338-339
