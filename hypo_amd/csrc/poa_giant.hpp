@@ -53,6 +53,14 @@ struct Giant {
     uint32_t Ncap, Ecap, Pcap, Scap;
     uint64_t Hcap;
     uint64_t cells, aligns;
+#if defined(HYPO_PHASE_TIMERS) && !defined(HYPO_EMU)
+    uint64_t t_rows = 0, t_trace = 0, t_add = 0, t_cons = 0, t_stage = 0;      // diagnostic build: cycles per part of a window (printed by Giant::run)
+#define HYPO_GT(var, t0) do { var += (uint64_t)clock64() - (t0); } while (0)
+#define HYPO_GT0() ((uint64_t)clock64())
+#else
+#define HYPO_GT(var, t0) do { } while (0)
+#define HYPO_GT0() 0ull
+#endif
 
     HD Giant(const G& g_, const PoaParamRef& P_) : g(g_), P(P_), cells(0), aligns(0) {}
 
@@ -325,6 +333,7 @@ struct Giant {
         g.sync();
         const bool native_lov = mode == MODE_LOV && (P->flags & POA_NATIVE_KLOV) != 0;
         int max_score = GNEG, max_i = -1;
+        const uint64_t tr0 = HYPO_GT0(); (void)tr0;
         for (int r = 0; r < nn; ++r) {
             const int u = rank[r], i = r + 1;
             const int c = code[u];
@@ -409,6 +418,8 @@ struct Giant {
                 if (max_score < endval) { max_score = endval; max_i = i; }
             } else if (native_lov) (void)g.reduce_max(row_max);
         }
+        HYPO_GT(t_rows, tr0);
+        const uint64_t tt0 = HYPO_GT0(); (void)tt0;
         // traceback (:344-438), lane 0
         if (g.lane == 0) {
             int i = max_i > 0 ? max_i : 0, j = max_i > 0 ? W - 1 : 0;
@@ -446,6 +457,7 @@ struct Giant {
             sh->aln_n = an;
         }
         g.sync();
+        HYPO_GT(t_trace, tt0);
         return RES_OK;
     }
 
@@ -472,8 +484,10 @@ struct Giant {
         int rc = align(L, mode, m, n_, gp);
         if (rc != RES_OK) return rc;
         g.sync();                                               // every lane has read what it needs of the graph before lane 0 changes it
+        const uint64_t ta0 = HYPO_GT0(); (void)ta0;
         if (g.lane == 0) sh->rc = g_add_alignment(L);
         g.sync();
+        HYPO_GT(t_add, ta0);
         return sh->rc;
     }
 
@@ -560,6 +574,7 @@ struct Giant {
                 if ((rc = add(L, MODE_NW, m, n_, gp)) != RES_OK) return rc;
             }
             if (!added) { answer_draft(); return RES_OK; }
+            const uint64_t tc0 = HYPO_GT0(); (void)tc0;
             if (g.lane == 0) {
                 const int len = g_consensus_custom();
                 const uint32_t thr = (uint32_t)floorf((float)ni * 0.4f);     // src/Window.cpp:28,245
@@ -568,8 +583,12 @@ struct Giant {
                 sh->conslen = o;
             }
             g.sync();
+            HYPO_GT(t_cons, tc0);
             conslen = sh->conslen;
         }
+#if defined(HYPO_PHASE_TIMERS) && !defined(HYPO_EMU)
+        if (g.lane == 0) printf("[giant] window %u: nodes %d, rows %llu Mcycles, traceback %llu, add_alignment + sort %llu, consensus %llu\n", w, sh->n_nodes, (unsigned long long)(t_rows >> 20), (unsigned long long)(t_trace >> 20), (unsigned long long)(t_add >> 20), (unsigned long long)(t_cons >> 20));
+#endif
         if ((uint64_t)conslen > cap) { if (g.lane == 0) { P->out_len[w] = (uint32_t)conslen; P->out_status[w] = HYPO_ST_CONS_OVERFLOW; } return RES_OK; }
         for (int i = g.lane; i < conslen; i += 64) out[i] = letter(ctext2[i]);
         if (g.lane == 0) { P->out_len[w] = (uint32_t)conslen; P->out_status[w] = HYPO_ST_OK; }
