@@ -203,6 +203,11 @@ int main(int argc, char** argv) {
         if (flags.gpus > 1) for (int d = 0; d < flags.gpus; ++d) flags.devices.push_back(d);
         else flags.devices.push_back(flags.device);
     }
+    // HYPO_GIANT_ARENA_MB: HBM per device context for the windows beyond the table-driven size classes (size class 6; default 1024, 0 = none:
+    // such windows then keep their draft with a warning, as before round 6)
+    if (const char* ga = std::getenv("HYPO_GIANT_ARENA_MB")) {
+        if (hypo_gpu_set_option("giant_arena_mb", std::atoi(ga)) != HYPO_OK) { std::fprintf(stderr, "[Hypo::] Error: %s\n", hypo_gpu_last_error()); return 1; }
+    }
     if (hypo_gpu_init(flags.devices.data(), (int)flags.devices.size()) != HYPO_OK) { std::fprintf(stderr, "[Hypo::] Error: %s\n", hypo_gpu_last_error()); return 1; }
     if (flags.native_klov && hypo_gpu_set_option("native_klov", 1) != HYPO_OK) { std::fprintf(stderr, "[Hypo::] Error: %s\n", hypo_gpu_last_error()); return 1; }
     if (flags.ccs_windows) { hypo::Window_settings.ideal_swind_size = 500; hypo::Window_settings.wind_size_search_th = 400; }   // src/main.cpp:577-580
