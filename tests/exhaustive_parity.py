@@ -12,6 +12,9 @@ bases the space holds  (sum_{l<=Ld} s^l) * (sum_{l<=La} s^l)^n * C(n+2, 2)  wind
     a2n4    {A,C}     4     1..4    1..3     17.3 M
     a3n2    {A,C,G}   2     1..4    1..4     10.4 M
     a3n3    {A,C,G}   3     1..3    1..3     23.1 M
+    a4n2    {A,C,G,T} 2     1..3    1..3      3.6 M
+    a4n3    {A,C,G,T} 3     1..2    1..2      1.6 M
+    a2n5    {A,C}     5     1..3    1..2      2.3 M
 
 Low-complexity two- and three-letter sequences are where the score-free shortcuts of hypo_amd/csrc/poa_core.hpp (Poa::thread_guided,
 thread_cols, guided_one_sub, topo_insert, the lazy rank order) meet ties, runs of one letter, second ends and side entrances — the
@@ -44,6 +47,9 @@ SPACES = {            # name: (alphabet size, arms, max draft, max arm)
     "a2n4": (2, 4, 4, 3),
     "a3n2": (3, 2, 4, 4),
     "a3n3": (3, 3, 3, 3),
+    "a4n2": (4, 2, 3, 3),      # four letters: cliques of four aligned nodes (3.6 M windows)
+    "a4n3": (4, 3, 2, 2),      # (1.6 M)
+    "a2n5": (2, 5, 3, 2),      # five arms (2.3 M)
 }
 SCORE_SETS = [(5, -4, -8, 3, -5, -4), (2, -1, -2, 3, -5, -4), (4, -3, -5, 3, -5, -4)]
 LETTERS = "ACGT"
