@@ -992,8 +992,20 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
         const char* poll_env = getenv("HYPO_POA_POLL");
         const bool poll3 = !(poll_env && atoi(poll_env) == 0);
         const uint32_t seen3 = last_count[3];                     // windows class 3 ended up with in the last finished call, scaled
-        uint32_t poll_waves = (seen3 > planned_host[3] ? seen3 : planned_host[3]);
-        poll_waves += poll_waves / 4;                             // (none: no polling launch; the regular one below still takes what turns up)
+        // Waves of the polling launch: what the plan put into class 3 (known work: one wave per window and a quarter more) + what the last
+        // call saw ARRIVE later.  A polling wave holds 16 KB of LDS while it waits, next to first-pass kernels whose shares fill the CU:
+        // a wave per expected arrival (rounds 3-5) cost the 1 % read-error point 3 of its 7 ms — 640 waves, two per CU, idling through a
+        // call whose 514 late windows are 0.18 s of wave time — so up to 1 024 arrivals get an eighth of that (they are served as they come,
+        // a few per wave, and the regular launch behind the join takes what is left), up to 2 048 a quarter (1.25 % / 1.5 %: 7.2 / 7.7 -> 5.7 / 6.7 ms);
+        // beyond that the class has real work and keeps a wave per window (2 % read error: 8.2 ms against 10.1-10.5 with 64-256 waves).  profiles/r06_poll_waves.txt; HYPO_POA_POLL_RULE=0: the old sizing.
+        const uint32_t planned3 = planned_host[3], arrivals = seen3 > planned3 ? seen3 - planned3 : 0u;
+        uint32_t poll_waves;
+        const char* rule_env = getenv("HYPO_POA_POLL_RULE");
+        if (rule_env && atoi(rule_env) == 0) { poll_waves = (seen3 > planned3 ? seen3 : planned3); poll_waves += poll_waves / 4; }
+        else {
+            poll_waves = planned3 + planned3 / 4;
+            if (arrivals) poll_waves += arrivals <= 1024u ? (arrivals / 8 > 8u ? arrivals / 8 : 8u) : (arrivals <= 2048u ? arrivals / 4 : arrivals + arrivals / 4);
+        }                                                         // (none: no polling launch; the regular one below still takes what turns up)
         const int poll_cap = poll_waves > 512u ? 2 : 1;
         if (const char* pw = getenv("HYPO_POA_POLL_WAVES")) poll_waves = (uint32_t)atoi(pw);
         // its stream: the third side stream, unless the LONG first pass is on it (then a fourth one, created on first use)
