@@ -1004,7 +1004,12 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
         if (rule_env && atoi(rule_env) == 0) { poll_waves = (seen3 > planned3 ? seen3 : planned3); poll_waves += poll_waves / 4; }
         else {
             poll_waves = planned3 + planned3 / 4;
-            if (arrivals) poll_waves += arrivals <= 1024u ? (arrivals / 8 > 8u ? arrivals / 8 : 8u) : (arrivals <= 2048u ? arrivals / 4 : arrivals + arrivals / 4);
+            // ... and none at all once more than about 3 % of the batch arrives late: the first-pass kernels then keep the chip busy for as long
+            // as the late windows take anyway, and class 3 runs behind the join with every CU to itself (2.5 / 3 / 4 % read error: 11.9 / 15.4 /
+            // 20.9 -> 10.8 / 12.9 / 17.0 ms; at 2 % read error, 3.0 % late, polling still wins: 8.4 against 9.0)
+            const bool many_late = (uint64_t)arrivals * 32u > (uint64_t)n_windows;
+            if (many_late) poll_waves = 0;                       // (what the plan put into class 3 waits for the join with the rest)
+            if (arrivals && !many_late) poll_waves += arrivals <= 1024u ? (arrivals / 8 > 8u ? arrivals / 8 : 8u) : (arrivals <= 2048u ? arrivals / 4 : arrivals + arrivals / 4);
         }                                                         // (none: no polling launch; the regular one below still takes what turns up)
         const int poll_cap = poll_waves > 512u ? 2 : 1;
         if (const char* pw = getenv("HYPO_POA_POLL_WAVES")) poll_waves = (uint32_t)atoi(pw);
