@@ -380,10 +380,17 @@ __global__ void __launch_bounds__(64, PoaMinWaves<Cfg>::value) poa_class_kernel(
             };
             uint64_t t0 = wall_clock64();
             for (;;) {
-                // once the classes that feed this one are done, what is left is the regular launch's (full width, no polling)
-                if (producers_done()) return false;
+                // Once the classes that feed this one are done the queue is final, and this launch leaves when it is empty.  What is left
+                // then (the last waves of class 2 publish theirs just before they count themselves done) is taken at once, next to the
+                // regular launch (poa_run starts it at that moment): until round 6 a polling wave left as soon as the producers were
+                // done, the regular launch started only behind the last wave of this one, and a large window handed to it then ran
+                // 5 ms behind an otherwise finished call (the non-i.i.d. batch: 14.2 ms in half of the calls, 11 in the others).
+                const bool final_queue = producers_done();
+                if (final_queue) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (the count read below is the one the producers left)
                 const uint32_t h = aload(fresh(ka)->head);
-                if (h < aload(cnt)) {
+                const uint32_t c = aload(cnt);
+                if (final_queue && h >= c) return false;
+                if (h < c) {
                     // Claimed with a compare-and-swap on the value just seen to be below the count: a claimed slot is always one a
                     // producer has already counted (its entry is at most a few instructions away).  An unconditional atomicAdd let
                     // several idle pollers that saw the same new entry claim slots BEHIND the count; one that then timed out left a
@@ -551,11 +558,12 @@ struct ClassScratch { char* base; int groups; };
 template <class Cfg, bool USE_LDS, bool POLL = false>
 static hipError_t launch_class(const PoaParams& P, const PoaQueues& Q, int cls, uint32_t n_windows,
                                ClassScratch scr, int num_cus, hipStream_t stream,
-                               int waves_per_cu_cap = 0, bool mop_up = false, uint32_t* groups_launched = nullptr, uint32_t expected = 0) {
+                               int waves_per_cu_cap = 0, bool mop_up = false, uint32_t* groups_launched = nullptr, uint32_t expected = 0,
+                               int first_slice = 0 /* scratch slices [first_slice, scr.groups) are this launch's: two launches of a class side by side */) {
     auto kern = poa_class_kernel<Cfg, USE_LDS, POLL>;
-    char* const scratch = scr.base;
-    const int group_cap = scr.groups;
     constexpr int GPW = 64 / Cfg::GW;
+    char* const scratch = scr.base + (size_t)first_slice * (Cfg::DIRG ? PoaLayout<Cfg>::DIRG_BYTES : PoaLayout<Cfg>::BYTES);
+    const int group_cap = scr.groups - first_slice;
     const size_t lds = USE_LDS ? (size_t)GPW * PoaLayout<Cfg>::BYTES : (Cfg::HYBRID ? (size_t)GPW * PoaLayout<Cfg>::FAST_BYTES : 0);
     hipError_t e;
     if (lds > 48 * 1024) {
@@ -1024,14 +1032,22 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
             poll_stream = aux[3];
         }
         rec(2 + 2 * 3, poll_stream);
+        uint32_t poll_groups = 0;
         if (poll3 && poll_waves > 0) {
-            if ((e = launch_class<PoaClass3, true, true>(P, Q, 3, poll_waves, scr3, num_cus, poll_stream, poll_cap, false, nullptr, producers)) != hipSuccess) return e;
+            if ((e = launch_class<PoaClass3, true, true>(P, Q, 3, poll_waves, scr3, num_cus, poll_stream, poll_cap, false, &poll_groups, producers)) != hipSuccess) return e;
         }
         rec(3 + 2 * 3, poll_stream);
         hipEvent_t& poll_join = long_first_pass ? join_ev[3] : join_ev[2];
         (void)hipEventRecord(poll_join, poll_stream);
-        (void)hipStreamWaitEvent(stream, poll_join, 0);
-        if ((e = launch_class<PoaClass3, true>(P, Q, 3, rare_grid_hint(3), scr3, num_cus, stream)) != hipSuccess) return e;
+        // The regular launch starts when classes 0 - 2 are done (the queue is final then) and does NOT wait for the polling launch's last
+        // window: the two drain the queue side by side (one cursor; the polling waves claim with a compare-and-swap below the count, the
+        // regular ones with a fetch-add that may run past it), each with direction-code slices of its own.  Behind the polling launch it
+        // started up to a millisecond late at 1 % read error (3.5-4.0 ms in most calls, 4.8-5.3 in a third of them).  When the scratch has
+        // no room for a second set of slices (tiny batches) it waits as before.
+        const bool side_by_side = poll_groups > 0 && scr3.groups - (int)poll_groups >= 64 && !getenv("HYPO_POA_POLL_JOIN_FIRST");
+        if (!side_by_side) (void)hipStreamWaitEvent(stream, poll_join, 0);
+        if ((e = launch_class<PoaClass3, true>(P, Q, 3, rare_grid_hint(3), scr3, num_cus, stream, 0, false, nullptr, 0, side_by_side ? (int)poll_groups : 0)) != hipSuccess) return e;
+        if (side_by_side) (void)hipStreamWaitEvent(stream, poll_join, 0);
         if (long_first_pass) {
             (void)hipStreamWaitEvent(stream, join_ev[2], 0);
             if ((e = launch_class<PoaClass4, false>(P, Q, 4, late_arrivals(4), scr4, num_cus, stream, 8, true)) != hipSuccess) return e;
