@@ -940,6 +940,11 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
         (void)hipStreamWaitEvent(aux[1], fork_ev, 0);
         (void)hipStreamWaitEvent(aux[2], fork_ev, 0);
         uint32_t producers = 0;                              // lane groups of every launch of classes 0 - 2 (what class 3's polling pass waits for)
+        // (experiment knob, off: a second class-2 launch behind class 0 / class 1 on their streams, to take over the LDS share those leave
+        // when they end early.  profiles/r06_backfill.txt: non-i.i.d. batch 10.4 -> 10.1-10.2 ms, C2 1.33 -> 1.38-1.46 ms, 1-2 % read error
+        // within noise — the waves that are resident already are what issue is shared between; more of them add little.)
+        int backfill[2] = {0, 0};
+        if (const char* bf = getenv("HYPO_POA_BACKFILL")) sscanf(bf, "%d,%d", &backfill[0], &backfill[1]);
         auto first2 = [&]() -> hipError_t {
             rec(2 + 2 * 2, stream);
             hipError_t r = launch_class<PoaClass2, true>(P, Q, 2, n_windows, scr_lds, num_cus, stream, caps[2], false, &producers);
@@ -950,12 +955,14 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
             rec(2 + 2 * 0, aux[0]);
             hipError_t r = four_groups ? launch_class<PoaClass0, true>(P, Q, 0, n_windows, scr_lds, num_cus, aux[0], caps[0], false, &producers)
                                        : launch_class<PoaClass0W, true>(P, Q, 0, n_windows, scr_lds, num_cus, aux[0], caps[0], false, &producers);
+            if (r == hipSuccess && backfill[0] > 0) r = launch_class<PoaClass2, true>(P, Q, 2, n_windows, scr_lds, num_cus, aux[0], backfill[0], false, &producers);
             rec(3 + 2 * 0, aux[0]);
             return r;
         };
         auto first1 = [&]() -> hipError_t {
             rec(2 + 2 * 1, aux[1]);
             hipError_t r = launch_class<PoaClass1, true>(P, Q, 1, n_windows, scr_lds, num_cus, aux[1], caps[1], false, &producers);
+            if (r == hipSuccess && backfill[1] > 0) r = launch_class<PoaClass2, true>(P, Q, 2, n_windows, scr_lds, num_cus, aux[1], backfill[1], false, &producers);
             rec(3 + 2 * 1, aux[1]);
             return r;
         };
@@ -1019,7 +1026,8 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
             if (many_late) poll_waves = 0;                       // (what the plan put into class 3 waits for the join with the rest)
             if (arrivals && !many_late) poll_waves += arrivals <= 1024u ? (arrivals / 8 > 8u ? arrivals / 8 : 8u) : (arrivals <= 2048u ? arrivals / 4 : arrivals + arrivals / 4);
         }                                                         // (none: no polling launch; the regular one below still takes what turns up)
-        const int poll_cap = poll_waves > 512u ? 2 : 1;
+        int poll_cap = poll_waves > 512u ? 2 : 1;
+        if (getenv("HYPO_POA_CAPS") && caps[3] > 0) poll_cap = caps[3];
         if (const char* pw = getenv("HYPO_POA_POLL_WAVES")) poll_waves = (uint32_t)atoi(pw);
         // its stream: the third side stream, unless the LONG first pass is on it (then a fourth one, created on first use)
         hipStream_t poll_stream = aux[2];
