@@ -1749,9 +1749,13 @@ struct Poa {
                 }
                 return g.reduce_max(mx);
             }
+            // (every candidate passes through a register of its own first: a chain of selects over v[q] was turned into ONE load from v[ce / 2] —
+            // the row's scores stored to private memory in every row, read back here behind an s_waitcnt vmcnt(0) that also waited for the
+            // row's direction codes to reach HBM; rounds 2-6, found in round 6's disassembly)
             int w = pk_bits(v[0]);
+            HYPO_IN_VGPR(w);
             HYPO_UNROLL
-            for (int q = 1; q < NP; ++q) if (ce / 2 == q) w = pk_bits(v[q]);
+            for (int q = 1; q < NP; ++q) { int b = pk_bits(v[q]); HYPO_IN_VGPR(b); if (ce / 2 == q) w = b; }
             return (int)(int16_t)(uint16_t)((uint32_t)w >> ce_shift);     // column L: meaningful in lane `le` only
         };
         int slot = 0, slotS = 0, rowS = 0;
@@ -1809,6 +1813,7 @@ struct Poa {
             const int p0 = meta_p0(meta);                    // 0 when k == 0 (virtual source row)
             const bool fastrow = p0 == i - 1;
             const int fastcode = fastrow ? (int)DIR_FAST : dir_diag(0);
+            HYPO_DIAG(rows_slow += k > 1; guided_hits += (!fastrow && p0 != 0); one_sub_hits += k > 2; cols_hits += (R1 > 0 && p0 != 0 && i - p0 > R1); exact_tries += (mode == MODE_LOV || sink));
             P2 MV[NP];
             {
                 const P2 CD = pk_splat(cd);
@@ -1834,6 +1839,8 @@ struct Poa {
                 for (int q = 0; q < NP; ++q) { pD[q] = pk_splat(0); pU[q] = pk_splat(0); }
                 for (int p = 1; p < k; ++p) {
                     P2 hp[NP];
+                    // (the third and later predecessors' rows come from HBM here, behind an s_waitcnt vmcnt(0); keeping them per 64-row chunk in
+                    // registers like the second's was measured in round 6 and gained nothing: 14-17 % of a LONG window's rows have three or more)
                     const int pr = (KIN >= 2 && p == 1) ? g.shfl(p1chunk, r & 63) : g.uniform(pred_row(r, p));
                     load_row(i, pr, hp);
                     const int nb = nbreg = g.shfl_up1(pk_bits(hp[NP - 1]), nbreg);
@@ -2035,6 +2042,7 @@ struct Poa {
         const int le = L / CPL;                              // owner of the last column
         if constexpr (Cfg::PACKED_HYB) {
             best_i = rows_pk_hyb(mode, m, n, gp, S, R, &ntie);
+            HYPO_DIAG(rows_scored_n += (uint32_t)n_nodes);
         } else {
         HYPO_IN_VGPR(m); HYPO_IN_VGPR(n); HYPO_IN_VGPR(gp);
         const int j0 = CPL * g.lane;

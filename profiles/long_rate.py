@@ -53,6 +53,9 @@ def main():
         print(f"    per window: rows={ph[c, D] / nw:.0f} alignments={ph[c, D + 1] / nw:.1f} reused={ph[c, D + 2] / nw:.1f} toposorts={ph[c, D + 3] / nw:.1f}"
               f" serial consensus={ph[c, D + 4] / nw:.2f}; score rows {ph[c, D + 9] / nw:.0f} at {ph[c, 1] / max(ph[c, D + 9], 1):.0f} cycles/row;"
               f" toposort {ph[c, 4] / max(ph[c, D + 3], 1) / 1e3:.1f} kcycles each, {ph[c, D + 10] / max(ph[c, D + 3], 1):.0f} DFS steps + {ph[c, D + 11] / max(ph[c, D + 3], 1):.0f} run steps")
+        rows = max(float(ph[c, D + 9]), 1.0)
+        print(f"    rows by kind (of the scored rows): several predecessors {100 * ph[c, D + 5] / rows:.1f} % (three or more {100 * ph[c, D + 12] / rows:.1f} %), one predecessor that is not the row before "
+              f"{100 * ph[c, D + 8] / rows:.1f} %, first predecessor beyond the LDS ring {100 * ph[c, D + 13] / rows:.1f} %, rows with the end-cell check {100 * ph[c, D + 6] / rows:.1f} %")
     import oracle
     orc = oracle.Oracle()
     if wins[0] is None:
