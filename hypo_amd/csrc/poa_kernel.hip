@@ -850,7 +850,10 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
         const uint32_t seen = last_count[cls] > last_planned[cls] ? last_count[cls] - last_planned[cls] : 0u;
         // the mop-up passes of classes 1 and 2 are launched on the side streams, where the dispatch of idle waves (they leave
         // after one look at the queue) costs nothing: they get a generous floor.  Class 3 and later start on the caller's stream.
-        const uint32_t floor = cls < 3 ? (n_windows / 8 > 256 ? n_windows / 8 : 256) : 256;
+        // (a rare class the last finished call saw nothing of gets 32 waves instead of 256: a launch whose waves all leave at once costs 5 us
+        // with 32 of them and 15-17 with 256, twice per call on the caller's stream = 1.3 % of the C2 step; waves are persistent, a surprise
+        // is still drained, and the next call sizes for it)
+        const uint32_t floor = cls < 3 ? (n_windows / 8 > 256 ? n_windows / 8 : 256) : ((have_history && last_count[cls] == 0) ? 32u : 256u);
         const uint32_t want = seen + seen / 2 + floor;
         return want < n_windows ? want : n_windows;
     };
