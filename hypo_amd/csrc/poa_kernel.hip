@@ -145,6 +145,13 @@ poa_plan_count_kernel(PoaParams P, PoaQueues Q, uint32_t n_windows) {
             const uint32_t key = plan_key_from(W, maxarm, changes, &trivial, (P.flags >> POA_MIN_CLASS_SHIFT) & 3);
             Q.keys[w] = (uint16_t)key;
             Q.carry[w] = 0;                                   // no spill yet (poa_class_kernel sets it when it re-queues the window)
+            // Every window's status starts as "not written" (HYPO_ST_UNWRITTEN) and its length as 0: a window no kernel answered cannot come
+            // back looking like HYPO_ST_OK with whatever the result buffers held before (the host mirror treats the sentinel as fatal).
+            // Class 3 is polled (poa_class_kernel<.., POLL>): its queue slots read "unpublished" until the scatter kernel or a re-queue
+            // fills them.  (Three hipMemsetAsync calls until round 6: a fill kernel of ~6 us each in front of every call.)
+            P.out_status[w] = 0xff;
+            P.out_len[w] = 0;
+            Q.items[(size_t)3 * Q.stride + w] = kQueueUnpublished;
             atomicAdd(&hist[key], 1u);
             if (trivial) atomicAdd(&ntriv, 1u);
         }
@@ -793,12 +800,7 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     const ClassScratch scr4{scratch, groups4}, scr5{scratch, groups5}, scr_lds{nullptr, 0};
     hipError_t e = hipMemsetAsync(ws, 0, kPoaHeaderBytes, stream);
     if (e != hipSuccess) return e;
-    // every window's status starts as "not written" (HYPO_ST_UNWRITTEN) and its length as 0: a window no kernel answered cannot come
-    // back looking like HYPO_ST_OK with whatever the result buffers held before (the host mirror treats the sentinel as fatal)
-    if ((e = hipMemsetAsync(P.out_status, 0xff, n_windows, stream)) != hipSuccess) return e;
-    if ((e = hipMemsetAsync(P.out_len, 0, (size_t)n_windows * sizeof(uint32_t), stream)) != hipSuccess) return e;
-    // class 3 is polled (poa_class_kernel<.., POLL>): its queue slots read "unpublished" until the plan or a re-queue fills them
-    if ((e = hipMemsetAsync(Q.items + (size_t)3 * n_windows, 0xff, (size_t)n_windows * sizeof(uint32_t), stream)) != hipSuccess) return e;
+    // (statuses, lengths and class 3's queue slots are reset by poa_plan_count_kernel)
     int pe = 0;
     if (prof) (void)hipEventRecord(prof->ev[0], stream);
     hipLaunchKernelGGL(poa_plan_count_kernel, dim3((n_windows + PLAN_WPB - 1) / PLAN_WPB), dim3(PLAN_THREADS), 0, stream, P, Q, n_windows);
