@@ -175,6 +175,13 @@ __global__ void poa_plan_scan_kernel(PoaQueues Q) {       // one wave: lane c sc
         Q.planned[c] = acc;          // windows the plan put into the class (before any re-queue)
         Q.head2[c] = acc;
     }
+    // the plan's counts for the host (poa_run sizes the NEXT call's grids from them; the first call of a context waits for them), written
+    // straight into page-locked host memory: a 32-byte hipMemcpyAsync was a copy command of its own on the stream
+    if (c < 8) {
+        uint32_t v = 0;
+        if (c < kNumPoaClasses) v = Q.count[c];
+        __hip_atomic_store(Q.host + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // Scatter with one global atomic per (workgroup, key): local ranks come from an LDS histogram.
@@ -512,6 +519,13 @@ struct GiantKArgs { PoaParams P; PoaQueues Q; char* arena; uint64_t slice_bytes;
 __global__ void __launch_bounds__(64) poa_giant_kernel(GiantKArgs /*read through the kernarg segment*/) {
     typedef const GiantKArgs __attribute__((address_space(4)))* KPtr;
     const KPtr ka = (KPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    // This launch is the last of a call and every other has finished when it starts: it leaves the call's final counts and wave-times where
+    // the host picks them up for the next call's grids and wave shares (page-locked host memory; two copy commands on the stream until round 6)
+    if (blockIdx.x == 0 && threadIdx.x < 8) {
+        uint32_t* const host = ka->Q.host;
+        __hip_atomic_store(host + 8 + threadIdx.x, ka->Q.count[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store((unsigned long long*)(host + 24) + threadIdx.x, (unsigned long long)ka->Q.work[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const uint32_t pending = ka->Q.count[kGiantClass];
     if (pending == 0) return;                                  // (nearly every call)
     const Grp<64> g{(int)(threadIdx.x & 63)};
@@ -798,8 +812,14 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     off += (size_t)scr3.groups * PoaLayout<PoaClass3>::DIRG_BYTES;
     char* scratch = ws + off;
     const ClassScratch scr4{scratch, groups4}, scr5{scratch, groups5}, scr_lds{nullptr, 0};
-    hipError_t e = hipMemsetAsync(ws, 0, kPoaHeaderBytes, stream);
-    if (e != hipSuccess) return e;
+    hipError_t e;
+    if (!A->planned_host) {
+        if ((e = hipHostMalloc((void**)&A->planned_host, 40 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return e;
+        memset(A->planned_host, 0, 40 * sizeof(uint32_t));
+        if ((e = hipEventCreateWithFlags(&A->planned_ev, hipEventDisableTiming)) != hipSuccess) return e;
+    }
+    Q.host = A->planned_host;
+    if ((e = hipMemsetAsync(ws, 0, kPoaHeaderBytes, stream)) != hipSuccess) return e;
     // (statuses, lengths and class 3's queue slots are reset by poa_plan_count_kernel)
     int pe = 0;
     if (prof) (void)hipEventRecord(prof->ev[0], stream);
@@ -812,11 +832,6 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
     // of the rare classes (3: oversized, 4: LONG, 5: catch-all): a grid of 2 048 single-wave workgroups costs ~0.1 ms of
     // dispatch even if every wave leaves at once, and these classes are empty in most batches (a few escalated windows still
     // find a small grid waiting).
-    if (!A->planned_host) {
-        if ((e = hipHostMalloc((void**)&A->planned_host, 40 * sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return e;
-        memset(A->planned_host, 0, 40 * sizeof(uint32_t));
-        if ((e = hipEventCreateWithFlags(&A->planned_ev, hipEventDisableTiming)) != hipSuccess) return e;
-    }
     // The FIRST call of a context waits for its own plan (nothing to go by yet).  Every later call is queued without a host wait:
     // it sizes its grids and picks class 0's geometry from the plan of the previous call, scaled to this batch's size (the
     // batches of one run look alike; a grid that turns out small only lowers the parallelism of that class, the persistent
@@ -835,7 +850,6 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
             hist[16 + c] = hist[c];
         }
     }
-    if ((e = hipMemcpyAsync(pinned, Q.planned, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
     (void)hipEventRecord(planned_ev, stream);
     if (wait_for_plan) {
         if ((e = hipEventSynchronize(planned_ev)) != hipSuccess) return e;
@@ -1084,8 +1098,7 @@ hipError_t poa_run(const PoaParams& P_in, uint32_t n_windows, void* workspace, s
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     // this call's final and planned counts for the next call's grid sizes (no wait: whoever reads them gets the last finished call)
-    (void)hipMemcpyAsync(pinned + 8, Q.count, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-    (void)hipMemcpyAsync(pinned + 24, Q.work, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream);
+    // (poa_giant_kernel has written this call's final counts and wave-times to A->planned_host)
     for (int c = 0; c < 8; ++c) A->last_planned[c] = hist[c];
     A->history_valid = true;
     A->history_windows = n_windows;

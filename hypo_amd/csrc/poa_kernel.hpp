@@ -49,6 +49,7 @@ struct PoaQueues {
     unsigned long long* spill_used;   // 64-bit: claimed with one fetch-add (poa_class_kernel), never wraps
     uint32_t* done;         // [classes] lane groups of class c's kernels that have exited (what a polling kernel waits for)
     uint64_t* work;         // [classes] summed lifetimes of the waves of class c's (non-polling) launches, 100 MHz ticks
+    uint32_t* host;         // PoaAux::planned_host (page-locked host memory the kernels write their counts to: no copy commands on the stream)
 };
 
 // optional event recorder: ev[0]/ev[1] around the plan kernels, ev[2+2c]/ev[3+2c] around size-class kernel c
