@@ -289,3 +289,15 @@ def test_klov_one_substitution_with_a_second_end():
     for cfg in (1, 2, 3):
         cons, res = emu.poa_chain(b, cfg)[:2]
         assert res[0] == emu_util.RES_OK and cons[0] == want[0], cfg
+
+
+def test_emulator_fuzz_script_runs():
+    """tests/emu_fuzz_cpu.py (opt-in, hours on many cores) stays runnable: a few rounds of it here."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "emu_fuzz_cpu.py"), "5", "0.3"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    last = out.stdout.strip().splitlines()[-1]
+    assert last.endswith("bad 0") and int(last.split("compared")[1].split()[0]) > 0, last
